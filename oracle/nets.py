@@ -1,0 +1,172 @@
+"""Functional CPU restatement of the reference hot path (test infrastructure).
+
+All functions take a flat ``state_dict``-style mapping of tensors (same keys as
+the reference modules) so that autograd works on leaf tensors directly.  Every
+function cites the reference lines it restates.  Parity status: pinned by
+``tests/golden`` (see ``oracle/__init__.py``).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .weights import ENC_LAYERS, DEC_LAYERS
+
+BN_EPS = 1e-5        # torch.nn.BatchNorm3d default, used at Unet3D.py:18,21 / Cae3D.py:40...
+BN_MOMENTUM = 0.1
+LEAKY = 0.01         # Unet3D.py:20,23,51
+
+
+def _bn(sd, prefix, x, training):
+    """``nn.BatchNorm3d`` call sites; training mode normalises with biased batch
+    variance and updates running stats with the unbiased one."""
+    rm, rv = sd[prefix + ".running_mean"], sd[prefix + ".running_var"]
+    if training:
+        sd[prefix + ".num_batches_tracked"] += 1
+    return F.batch_norm(x, rm, rv, sd[prefix + ".weight"], sd[prefix + ".bias"],
+                        training, BN_MOMENTUM, BN_EPS)
+
+
+def center_crop(t, like, dims=(2, 3, 4)):
+    """``crop`` Unet3D.py:6-11 -- offset (in-out)//2 per cropped dim."""
+    for d in dims:
+        t = t.narrow(d, (t.size(d) - like.size(d)) // 2, like.size(d))
+    return t
+
+
+def unet_block(sd, p, x, training):
+    """``Block3x3x3`` Unet3D.py:14-27: BN-conv(3,p0)-lrelu twice."""
+    for bn_i, cv_i in ((0, 1), (3, 4)):
+        x = _bn(sd, "%s.bn_conv_relu_2x.%d" % (p, bn_i), x, training)
+        x = F.conv3d(x, sd["%s.bn_conv_relu_2x.%d.weight" % (p, cv_i)],
+                     sd["%s.bn_conv_relu_2x.%d.bias" % (p, cv_i)])
+        x = F.leaky_relu(x, LEAKY)
+    return x
+
+
+def upsample2(x, align_corners=False):
+    """``nn.Upsample(scale_factor=2, mode='trilinear')`` Unet3D.py:44,46.
+    torch>=0.4 semantics (align_corners=False), as the importable reference."""
+    return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=align_corners)
+
+
+def unet_forward(sd, x, training=True, return_all=False):
+    """``Unet3D.forward`` Unet3D.py:56-79.  Returns sigmoid probs (B,2,...)."""
+    b1 = unet_block(sd, "block1", x, training)
+    b2 = unet_block(sd, "block2", F.max_pool3d(b1, 2, 2), training)
+    b3 = unet_block(sd, "block3", F.max_pool3d(b2, 2, 2), training)
+    u3 = upsample2(b3)
+    b4 = unet_block(sd, "block4", torch.cat((u3, center_crop(b2, u3)), dim=1), training)
+    u4 = upsample2(b4)
+    b5 = unet_block(sd, "block5", torch.cat((u4, center_crop(b1, u4)), dim=1), training)
+    h = F.leaky_relu(F.conv3d(b5, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY)
+    seg = torch.sigmoid(F.conv3d(h, sd["classify.2.weight"], sd["classify.2.bias"]))
+    if return_all:
+        return seg, dict(b1=b1, b2=b2, b3=b3, b4=b4, b5=b5)
+    return seg
+
+
+def batch_dice_loss(outputs, targets, label_weights=(1.0,), eps=1e-7, dim=1):
+    """``BatchDiceLoss.forward`` metrics.py:16-28 (sums over the whole batch)."""
+    assert targets.shape[dim] == len(label_weights)
+    acc = 0.0
+    for lab, w in enumerate(label_weights):
+        o = outputs.narrow(dim, lab, 1).reshape(-1)
+        t = targets.narrow(dim, lab, 1).reshape(-1)
+        acc = acc + w * (2.0 * (o * t).sum() + eps) / ((o * o).sum() + (t * t).sum() + eps)
+    return 1.0 - acc
+
+
+def unet_loss(seg, labels):
+    """``UnetSegmentationLearner.loss_step`` :21-28 -- mean of two Dice terms."""
+    return (batch_dice_loss(seg[:, 0:1], labels[:, 0:1]) + batch_dice_loss(seg[:, 1:2], labels[:, 1:2])) / 2
+
+
+# ----------------------------------------------------------------------------- CAE
+
+def _cae_stack(sd, prefix, layers, x, alpha, training, last_sigmoid):
+    n = len(layers)
+    for i, (kind, _ci, _co, _k, s, p) in enumerate(layers):
+        x = _bn(sd, "%s.%d" % (prefix, 3 * i), x, training)
+        w, b = sd["%s.%d.weight" % (prefix, 3 * i + 1)], sd["%s.%d.bias" % (prefix, 3 * i + 1)]
+        if kind == "conv":
+            x = F.conv3d(x, w, b, stride=s, padding=p)
+        else:
+            x = F.conv_transpose3d(x, w, b, stride=s, padding=p)
+        if last_sigmoid and i == n - 1:
+            x = torch.sigmoid(x)
+        else:
+            x = F.elu(x, alpha)
+    return x
+
+
+def enc_forward(sd, x, alpha=1.0, training=True, prefix="encoder"):
+    """``Enc3D.encoder`` Cae3D.py:39-76."""
+    return _cae_stack(sd, prefix, ENC_LAYERS, x, alpha, training, False)
+
+
+def dec_forward(sd, z, alpha=1.0, training=True, prefix="decoder"):
+    """``Dec3D.decoder`` Cae3D.py:176-220."""
+    return _cae_stack(sd, prefix, DEC_LAYERS, z, alpha, training, True)
+
+
+def time_to_treatment(clinical, normalization_hours_penumbra=10):
+    """``CaeInference.get_time_to_treatment`` CaeInference.py:18-31 (step=None):
+    tA->tR / (10 - tO->tA), shape (B,1,1,1,1) float32."""
+    c = clinical.float()
+    return (c[:, 1] / (normalization_hours_penumbra - c[:, 0])).reshape(-1, 1, 1, 1, 1)
+
+
+def cae_forward(sd, core, penu, lesion, step, alpha=1.0, training=True):
+    """``Cae3D.forward`` Cae3D.py:248-251 = ``Enc3D.forward`` :100-118 (three
+    encoder passes in the order core, penu, lesion; lerp :78-89) then
+    ``Dec3D.forward`` :227-239 (four decoder passes core, penu, lesion, interp)."""
+    lat = {}
+    for k, v in (("core", core), ("penu", penu), ("lesion", lesion)):
+        lat[k] = enc_forward(sd, v, alpha, training, "enc.encoder")
+    lat["interpolation"] = lat["core"] + step * (lat["penu"] - lat["core"])
+    rec = {}
+    for k in ("core", "penu", "lesion", "interpolation"):
+        rec[k] = dec_forward(sd, lat[k], alpha, training, "dec.decoder")
+    return lat, rec
+
+
+def cae_loss(lat, rec, core, penu, lesion, epoch):
+    """``CaeReconstructionLearner.loss_step`` CaeReconstructionLearner.py:52-70."""
+    factor = min(0.04 * max(0, epoch - 25), 1)
+    d_pf = rec["penu"] - rec["interpolation"]
+    d_pc = rec["penu"] - rec["core"]
+    loss = torch.mean(torch.abs(d_pf) - d_pf) + torch.mean(torch.abs(d_pc) - d_pc)
+    loss = loss + batch_dice_loss(rec["core"], core) + batch_dice_loss(rec["penu"], penu) \
+        + batch_dice_loss(rec["lesion"], lesion)
+    loss = loss + factor * torch.mean(torch.abs(lat["interpolation"] - lat["lesion"]))
+    return loss / (5 + factor)
+
+
+def cae_beta1(epoch, base=0.9, n_adapt=4):
+    """``CaeReconstructionLearner.adapt_betas`` :28-40."""
+    return base - 0.1 * (n_adapt - epoch) if epoch < n_adapt else base
+
+
+# ----------------------------------------------------------------------------- optimiser
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, step, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """One ``torch.optim.Adam`` step (L2-coupled weight decay, no amsgrad) as used
+    at train_unet_segmentation.py:32 / train_shape_reconstruction.py:40.
+    ``step`` is the 1-based step count.  In-place on params / moments."""
+    b1, b2 = betas
+    bc1 = 1 - b1 ** step
+    bc2 = 1 - b2 ** step
+    for p, g, m, v in zip(params, grads, exp_avg, exp_avg_sq):
+        if weight_decay != 0:
+            g = g + weight_decay * p
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+        p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def trainable(sd):
+    """Names that carry gradients (everything but BN buffers)."""
+    return [k for k in sd if not (k.endswith("running_mean") or k.endswith("running_var")
+                                  or k.endswith("num_batches_tracked"))]

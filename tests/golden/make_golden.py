@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by running the REAL reference modules on CPU.
+
+Run only in the build container (needs ``/root/reference``; nothing under
+``tests/`` reads that path at test time):
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tests/golden/make_golden.py
+
+The reference's model/loss/learner classes are imported unmodified.  Modules
+that the hot path imports but never uses and that are absent here (nibabel,
+torchvision, medpy, jsonpickle) are replaced by empty stand-in modules in
+``sys.modules`` before import.  Weights and inputs come from
+``oracle/weights.py`` (own generator), so fixtures hold data only: inputs are
+regenerated from seeds, outputs are stored.
+
+Versions recorded in each fixture: torch version (trilinear upsample runs with
+align_corners=False under torch>=0.4).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("STROKE_REFERENCE", "/root/reference")
+
+
+def _stub(name):
+    m = types.ModuleType(name)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    for n in ("nibabel", "torchvision", "medpy", "medpy.metric", "medpy.metric.binary", "jsonpickle"):
+        if n not in sys.modules:
+            _stub(n)
+    sys.modules["torchvision"].transforms = _stub("torchvision.transforms")
+    sys.modules["medpy"].metric = sys.modules["medpy.metric"]
+    sys.modules["medpy.metric"].binary = sys.modules["medpy.metric.binary"]
+    sys.path.insert(0, REF)
+
+
+def digest(t):
+    t = t.detach().double().reshape(-1)
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()], dtype=np.float64)
+
+
+def grads_summary(named):
+    out = {}
+    for n, p in named:
+        g = p.grad.detach().reshape(-1)
+        out["gnorm/" + n] = np.float64(g.double().norm().item())
+        out["ghead/" + n] = g[:8].numpy().copy()
+    return out
+
+
+def gen_unet(size, seed, fname):
+    from oracle import weights as W
+    from common.model.Unet3D import Unet3D
+    import common.dto.UnetDto as UnetDtoUtil
+    from common.metrics import BatchDiceLoss
+
+    ch = [2, 16, 32, 64, 32, 16, 32, 2]
+    model = Unet3D(ch)
+    model.load_state_dict(W.make_state_dict(W.unet_spec(ch), seed))
+    x, y = W.unet_inputs(2, size, seed)
+    crit = BatchDiceLoss([1.0])
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3,
+                           weight_decay=1e-5, betas=(0.99, 0.999))   # train_unet_segmentation.py:13-14,32
+    fx = {"channels": np.array(ch), "size": np.array(size), "seed": np.array(seed), "batch": np.array(2),
+          "torch_version": np.array(torch.__version__)}
+    model.train()
+    for step in range(3):
+        dto = UnetDtoUtil.init_dto(x, y[:, 0:1], y[:, 1:2])      # UnetInference.py:16-25
+        dto = model(dto)
+        # UnetSegmentationLearner.loss_step :21-28 (the learner ctor itself is broken)
+        loss = (crit(dto.outputs.core, dto.given_variables.core) + crit(dto.outputs.penu, dto.given_variables.penu)) / 2
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            fx["seg"] = torch.cat((dto.outputs.core, dto.outputs.penu), 1).detach().numpy().copy()
+            fx.update(grads_summary(model.named_parameters()))
+        fx["loss/%d" % step] = np.float64(loss.item())
+        opt.step()
+        if step in (0, 2):
+            for n, b in model.named_buffers():
+                if not n.endswith("num_batches_tracked"):
+                    fx["buf%d/%s" % (step + 1, n)] = b.detach().numpy().copy()
+    for n, p in model.named_parameters():
+        fx["pnorm3/" + n] = np.float64(p.detach().double().norm().item())
+        fx["phead3/" + n] = p.detach().reshape(-1)[:8].numpy().copy()
+    model.eval()
+    with torch.no_grad():
+        dto = model(UnetDtoUtil.init_dto(x))
+    fx["seg_eval3"] = torch.cat((dto.outputs.core, dto.outputs.penu), 1).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **fx)
+    print("wrote", fname, "loss", [fx["loss/%d" % i] for i in range(3)])
+
+
+def gen_unet_eval128(seed, fname):
+    from oracle import weights as W
+    from common.model.Unet3D import Unet3D
+    import common.dto.UnetDto as UnetDtoUtil
+    ch = [2, 16, 32, 64, 32, 16, 32, 2]
+    model = Unet3D(ch)
+    model.load_state_dict(W.make_state_dict(W.unet_spec(ch), seed))
+    model.freeze(True)
+    model.eval()
+    x, _ = W.unet_inputs(1, 128, seed)
+    with torch.no_grad():
+        dto = model(UnetDtoUtil.init_dto(x))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    fx = {"seed": np.array(seed), "shape": np.array(seg.shape), "torch_version": np.array(torch.__version__),
+          "mean": seg.double().mean(dim=(0, 2, 3, 4)).numpy(), "std": seg.double().std(dim=(0, 2, 3, 4)).numpy(),
+          "crop": seg[:, :, 42:46, 42:46, 42:46].numpy().copy(), "digest": digest(seg)}
+    np.savez_compressed(os.path.join(HERE, fname), **fx)
+    print("wrote", fname, fx["mean"], fx["std"])
+
+
+class _FakeLoader:
+    """Just enough of DataLoader for ``Learner.__init__`` (Learner.py:40-42)."""
+    batch_size = 2
+
+    def __len__(self):
+        return 1
+
+
+def gen_cae(ch, seed, fname, d=28, hw=128):
+    from oracle import weights as W
+    from common.model.Cae3D import Cae3D, Enc3D, Dec3D
+    from common.metrics import BatchDiceLoss
+    from learner.CaeReconstructionLearner import CaeReconstructionLearner
+
+    alpha = 1.0                                                    # train_shape_reconstruction.py:18
+    enc = Enc3D(size_input_xy=hw, size_input_z=d, channels=ch, n_ch_global=5, alpha=alpha)
+    dec = Dec3D(size_input_xy=hw, size_input_z=d, channels=ch, n_ch_global=5, alpha=alpha)
+    cae = Cae3D(enc, dec)
+    cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+    params = [p for p in cae.parameters() if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999))
+    learner = CaeReconstructionLearner(_FakeLoader(), None, cae, opt, None, n_epochs=1, path_previous_base=None,
+                                       path_outputs_base="/tmp/_golden_cae", criterion=BatchDiceLoss([1.0]))
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    batch = {"case_id": [0, 1], "images": None, "labels": labels, "clinical": clinical}
+    fx = {"channels": np.array(ch), "seed": np.array(seed), "d": np.array(d), "hw": np.array(hw),
+          "torch_version": np.array(torch.__version__)}
+    cae.train()
+    learner.adapt_betas(0)
+    fx["betas_epoch0"] = np.array(opt.param_groups[0]["betas"])
+    dto = learner.inference_step(batch)
+    fx["ttt"] = dto.given_variables.time_to_treatment.detach().numpy().copy()
+    for k in ("core", "penu", "lesion", "interpolation"):
+        lat = getattr(dto.latents.gtruth, k)
+        rec = getattr(dto.reconstructions.gtruth, k)
+        fx["lat_digest/" + k] = digest(lat)
+        fx["lat_head/" + k] = lat.detach().reshape(lat.shape[0], -1)[:, :64].numpy().copy()
+        fx["rec_digest/" + k] = digest(rec)
+        fx["rec_crop/" + k] = rec.detach()[:, 0, d // 2, 60:68, 60:68].numpy().copy()
+    for ep in (0, 30, 60):
+        fx["loss_epoch/%d" % ep] = np.float64(learner.loss_step(dto, ep).item())
+    loss = learner.loss_step(dto, 30)
+    opt.zero_grad()
+    loss.backward()
+    fx.update(grads_summary(cae.named_parameters()))
+    opt.step()
+    for n, b in cae.named_buffers():
+        if n.endswith("num_batches_tracked"):
+            fx["nbt/" + n] = b.numpy().copy()
+        elif n.startswith("enc.encoder.0.") or n.startswith("dec.decoder.0.") or n.startswith("dec.decoder.33."):
+            fx["buf1/" + n] = b.detach().numpy().copy()
+    for n, p in list(cae.named_parameters())[:8]:
+        fx["phead1/" + n] = p.detach().reshape(-1)[:8].numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **fx)
+    print("\nwrote", fname, {k: float(v) for k, v in fx.items() if k.startswith("loss_epoch")})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    import_reference()
+    which = sys.argv[1:] or ["unet", "unet128", "cae"]
+    if "unet" in which:
+        gen_unet(44, 11, "unet_44.npz")
+        gen_unet(48, 12, "unet_48.npz")
+        gen_unet((44, 48, 52), 13, "unet_44x48x52.npz")
+    if "unet128" in which:
+        gen_unet_eval128(14, "unet_eval128.npz")
+    if "cae" in which:
+        gen_cae([1, 16, 24, 32, 100, 200, 1], 21, "cae_200.npz")
+        gen_cae([1, 16, 24, 32, 100, 800, 1], 22, "cae_800.npz")

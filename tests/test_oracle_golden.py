@@ -1,0 +1,124 @@
+"""Pin the CPU oracle (oracle/) against fixtures produced by the REAL reference
+modules (tests/golden/make_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, weights as W
+
+UNET_CH = [2, 16, 32, 64, 32, 16, 32, 2]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _leafify(sd):
+    for k in nets.trainable(sd):
+        sd[k] = sd[k].clone().requires_grad_(True)
+    return sd
+
+
+@pytest.mark.parametrize("fname", ["unet_44.npz", "unet_48.npz", "unet_44x48x52.npz"])
+def test_unet_train_steps_match_reference(golden_dir, fname):
+    fx = _load(golden_dir, fname)
+    seed, size = int(fx["seed"]), tuple(int(s) for s in np.atleast_1d(fx["size"]))
+    size = size * 3 if len(size) == 1 else size
+    sd = _leafify(W.make_state_dict(W.unet_spec(UNET_CH), seed))
+    x, y = W.unet_inputs(2, size, seed)
+    names = nets.trainable(sd)
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    for step in range(3):
+        seg = nets.unet_forward(sd, x, training=True)
+        loss = nets.unet_loss(seg, y)
+        grads = torch.autograd.grad(loss, [sd[k] for k in names])
+        assert abs(loss.item() - float(fx["loss/%d" % step])) < 2e-6
+        if step == 0:
+            np.testing.assert_allclose(seg.detach().numpy(), fx["seg"], rtol=1e-5, atol=1e-6)
+            for k, g in zip(names, grads):
+                gn = float(fx["gnorm/" + k])
+                assert abs(g.double().norm().item() - gn) <= 2e-4 * gn + 1e-9, k
+                np.testing.assert_allclose(g.reshape(-1)[:8].numpy(), fx["ghead/" + k], rtol=2e-3, atol=1e-7 + 1e-4 * gn)
+        with torch.no_grad():
+            nets.adam_step([sd[k] for k in names], grads, m, v, step + 1, lr=1e-3, betas=(0.99, 0.999),
+                           weight_decay=1e-5)
+        if step in (0, 2):
+            for k in sd:
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    np.testing.assert_allclose(sd[k].numpy(), fx["buf%d/%s" % (step + 1, k)], rtol=1e-5, atol=1e-6)
+    for k in names:
+        np.testing.assert_allclose(sd[k].detach().reshape(-1)[:8].numpy(), fx["phead3/" + k], rtol=1e-4, atol=2e-5)
+    with torch.no_grad():
+        seg = nets.unet_forward(sd, x, training=False)
+    np.testing.assert_allclose(seg.numpy(), fx["seg_eval3"], rtol=1e-3, atol=1e-4)
+
+
+def test_unet_eval128_matches_reference(golden_dir):
+    fx = _load(golden_dir, "unet_eval128.npz")
+    sd = W.make_state_dict(W.unet_spec(UNET_CH), int(fx["seed"]))
+    x, _ = W.unet_inputs(1, 128, int(fx["seed"]))
+    with torch.no_grad():
+        seg = nets.unet_forward(sd, x, training=False)
+    assert tuple(seg.shape) == tuple(fx["shape"])
+    np.testing.assert_allclose(seg[:, :, 42:46, 42:46, 42:46].numpy(), fx["crop"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(seg.double().mean(dim=(0, 2, 3, 4)).numpy(), fx["mean"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("fname", ["cae_200.npz", "cae_800.npz"])
+def test_cae_step_matches_reference(golden_dir, fname):
+    fx = _load(golden_dir, fname)
+    ch, seed = [int(c) for c in fx["channels"]], int(fx["seed"])
+    sd = _leafify(W.make_state_dict(W.cae_spec(ch), seed))
+    labels, clinical = W.cae_inputs(2, int(fx["d"]), int(fx["hw"]), seed)
+    step = nets.time_to_treatment(clinical)
+    np.testing.assert_allclose(step.numpy(), fx["ttt"], rtol=1e-6)
+    core, penu, lesion = labels[:, 0:1], labels[:, 1:2], labels[:, 2:3]
+    lat, rec = nets.cae_forward(sd, core, penu, lesion, step, alpha=1.0, training=True)
+    for k in ("core", "penu", "lesion", "interpolation"):
+        np.testing.assert_allclose(lat[k].detach().reshape(2, -1)[:, :64].numpy(), fx["lat_head/" + k], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rec[k].detach()[:, 0, int(fx["d"]) // 2, 60:68, 60:68].numpy(), fx["rec_crop/" + k],
+                                   rtol=1e-4, atol=1e-5)
+        d = fx["rec_digest/" + k]
+        assert abs(rec[k].double().sum().item() - d[0]) <= 1e-5 * d[1]
+    for ep in (0, 30, 60):
+        assert abs(nets.cae_loss(lat, rec, core, penu, lesion, ep).item() - float(fx["loss_epoch/%d" % ep])) < 2e-6
+    names = nets.trainable(sd)
+    grads = torch.autograd.grad(nets.cae_loss(lat, rec, core, penu, lesion, 30), [sd[k] for k in names])
+    for k, g in zip(names, grads):
+        gn = float(fx["gnorm/" + k])
+        assert abs(g.double().norm().item() - gn) <= 1e-3 * gn + 1e-9, k
+    # BN bookkeeping: encoder BNs see 3 calls, decoder BNs 4 per step (Cae3D.py:105-107,230-233)
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(fx["nbt/" + k]) == (3 if k.startswith("enc.") else 4)
+    assert abs(nets.cae_beta1(0) - float(fx["betas_epoch0"][0])) < 1e-12
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    with torch.no_grad():
+        nets.adam_step([sd[k] for k in names], grads, m, v, 1, lr=1e-3, betas=(nets.cae_beta1(0), 0.999), weight_decay=1e-5)
+    for k in names[:8]:
+        np.testing.assert_allclose(sd[k].detach().reshape(-1)[:8].numpy(), fx["phead1/" + k], rtol=1e-4, atol=2e-5)
+    for k in sd:
+        if ("buf1/" + k) in fx.files:
+            np.testing.assert_allclose(sd[k].numpy(), fx["buf1/" + k], rtol=1e-5, atol=1e-6)
+
+
+def test_adam_restatement_matches_torch_optim():
+    torch.manual_seed(0)
+    p0 = [torch.randn(7, 5), torch.randn(11)]
+    ref = [p.clone().requires_grad_(True) for p in p0]
+    opt = torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    mine = [p.clone() for p in p0]
+    m = [torch.zeros_like(p) for p in p0]
+    v = [torch.zeros_like(p) for p in p0]
+    for step in range(1, 6):
+        grads = [torch.randn_like(p) for p in p0]
+        for p, g in zip(ref, grads):
+            p.grad = g.clone()
+        opt.step()
+        nets.adam_step(mine, grads, m, v, step, lr=1e-3, betas=(0.99, 0.999), weight_decay=1e-5)
+    for a, b in zip(ref, mine):
+        np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=1e-6, atol=1e-7)
