@@ -1,0 +1,200 @@
+/* stroke_amd.h -- C ABI of libstroke_amd.so (MI355X / gfx950 kernels).
+ *
+ * Drop-in boundary for the 3-D U-Net / CAE hot path of
+ * multimodallearning/stroke-prediction.  The reference has no native code: each
+ * entry point replaces the ATen/cuDNN kernels that the cited torch.nn call sites
+ * reach implicitly.
+ *
+ * Conventions
+ *  - plain C: raw device pointers, ints, floats; no C++ or torch types;
+ *  - every call ENQUEUES on the given hipStream_t and returns; nothing here
+ *    synchronises, allocates or frees device memory (caller owns all buffers);
+ *  - return 0 on success, SP_EINVAL (bad shapes/pointers/alignment) or SP_EHIP
+ *    (launch failure); text via sp_last_error() (thread-local);
+ *  - activations are "channels-last-3d": [B][D][H][W][CP] with CP (channel
+ *    pitch) a multiple of 8; dtype SP_BF16 (fast) or SP_F32 (parity mode, the
+ *    convolutions then run split-bf16 x3 MFMA, ~fp32 accurate);
+ *  - statistics / parameter buffers are fp32 unless stated; reduction
+ *    accumulators are fp64 ("sums" arguments) and must be zeroed by the caller.
+ */
+#ifndef STROKE_AMD_H
+#define STROKE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sp_stream_t; /* hipStream_t */
+
+enum { SP_OK = 0, SP_EINVAL = -1, SP_EHIP = -2 };
+enum { SP_BF16 = 0, SP_F32 = 1 };
+enum { SP_ACT_NONE = 0, SP_ACT_LEAKY = 1, SP_ACT_ELU = 2, SP_ACT_SIGMOID = 3 };
+
+int sp_version(void);
+/* copies the calling thread's last error text (NUL-terminated) into buf */
+void sp_last_error(char* buf, size_t n);
+
+/* ------------------------------------------------------------------ implicit-GEMM convolution
+ * One kernel serves nn.Conv3d forward (Unet3D.py:19,22; Cae3D.py:41-74,186-218), its data
+ * gradient, and nn.ConvTranspose3d (Cae3D.py:178-204) -- the host plans taps, padding and the
+ * K order (tables below) and the kernel is a table-driven LDS-tiled MFMA implicit GEMM:
+ *   y[b,o,co] = act( bias[co] + sum_{tap,ci} w[co,ci,tap] * xin[b, o*s + o0 + tapoff, ci] )
+ * with xin = x*in_scale[ci]+in_shift[ci] inside the input volume (BatchNorm applied on load,
+ * Unet3D.py:18,21) and 0 outside it (zero padding AFTER the norm, Cae3D.py:41).
+ */
+typedef struct sp_conv_args {
+  /* tensors */
+  const void* x;         /* [B][Di][Hi][Wi][CPi] */
+  void* y;               /* [B][YD][YH][YW][CPo] */
+  const void* wfrag_hi;  /* weight fragments from sp_conv_prep_weights */
+  const void* wfrag_lo;  /* low halves (SP_F32 mode) or NULL */
+  const float* in_scale; /* [CPi] or NULL (= no affine on load) */
+  const float* in_shift; /* [CPi] */
+  const float* bias;     /* [NTtot*16] padded with zeros, or NULL */
+  double* stats;         /* [CPo][2] sum / sum-of-squares of the outputs, or NULL */
+  const int32_t* ktab;   /* [steps_per_group*4] LDS byte offset of K-octet (step, lane group) */
+  int32_t dtype_in, dtype_out;
+  /* geometry */
+  int32_t B, Di, Hi, Wi, CPi;
+  int32_t Do, Ho, Wo;          /* logical output grid of this launch */
+  int32_t YD, YH, YW, CPo;     /* full output tensor */
+  int32_t osD, osH, osW;       /* output coordinate = o*os + oo (transposed-conv parity classes) */
+  int32_t ooD, ooH, ooW;
+  int32_t Cout;                /* real output channels; channels >= Cout are written as 0 */
+  int32_t sD, sH, sW;          /* input step per output step */
+  int32_t o0D, o0H, o0W;       /* input coordinate of (output 0, tap offset 0), may be negative */
+  /* tiling (host plan) */
+  int32_t TD, TH;              /* output tile = TD x TH rows of 16 voxels; TD*TH == 4*MT */
+  int32_t ITD, ITH, ITW;       /* staged input tile extent (voxels) */
+  int32_t MT, NT;              /* register blocking: M tiles per wave, N (cout/16) tiles per block */
+  int32_t NTtot;               /* total cout tiles (grid.y = NTtot/NT) */
+  int32_t ngroups;             /* channel groups staged one after the other */
+  int32_t octs_per_group;      /* 8-channel octets per group */
+  int32_t opp;                 /* octets per LDS plane */
+  int32_t vsb;                 /* bytes per voxel inside a plane */
+  int32_t plane_bytes;
+  int32_t lo_offset;           /* byte offset of the low-half planes (SP_F32), else 0 */
+  int32_t steps_per_group;     /* K steps (of 32) per group */
+  int32_t lds_bytes;
+  int32_t act;
+  float act_param;
+} sp_conv_args;
+
+int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
+
+/* Re-pack fp32 weights into MFMA A-fragments in the plan's K order.
+ * kmap[step*4+g] = (src_tap_index << 16) | cin_octet, or -1 for a padding octet.
+ * element (co, ci, tap) is read from w[co*sCo + ci*sCi + tap]. */
+int sp_conv_prep_weights(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin,
+                         const int32_t* kmap, int32_t nsteps, int32_t NTtot,
+                         void* wfrag_hi, void* wfrag_lo /* or NULL */, sp_stream_t stream);
+
+/* ------------------------------------------------------------------ weight gradient
+ * dw[co,ci,tap] += sum_{b,o} dz[b,o,co] * xin[b, o*s + o0 + tapoff(tap), ci]   (fp32 atomics)
+ * dw_acc layout: [ntap][CoutP16][CinP16] fp32 (zeroed by caller); sp_wgrad_finish scatters it
+ * (accumulating) into the (Cout,Cin,k,k,k)-layout gradient buffer. */
+typedef struct sp_wgrad_args {
+  const void* x;         /* [B][Di][Hi][Wi][CPi] conv input (pre-norm) */
+  const void* dz;        /* [B][Do][Ho][Wo][CPo] gradient at the conv output (pre-activation) */
+  const float* in_scale; /* BatchNorm-on-load of x, or NULL */
+  const float* in_shift;
+  const float* dz_scale; /* affine on load of dz (transposed-conv roles: dz operand = normalised input), or NULL */
+  const float* dz_shift;
+  float* dw_acc;
+  const int32_t* taps;   /* [ntap][3] input offsets (dz,dy,dx) added to o*s + o0 */
+  int32_t dtype;
+  int32_t B, Di, Hi, Wi, CPi, Do, Ho, Wo, CPo;
+  int32_t sD, sH, sW, o0D, o0H, o0W;
+  int32_t ntap;
+  int32_t kD, kH, kW;    /* tap offsets satisfy 0 <= offset < k (sizes the staged halo) */
+  int32_t CoT, CiT;      /* cout / cin tiles of 16 */
+  int32_t nblocks;       /* persistent grid size */
+} sp_wgrad_args;
+int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
+/* dw[co*sCo + ci*sCi + tapsrc[t]] += dw_acc[t][co][ci] */
+int sp_wgrad_finish(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                    int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw, sp_stream_t stream);
+
+/* ------------------------------------------------------------------ layout
+ * NCDHW fp32 (reference layout, README.md:13 / data.py:305) <-> channels-last-3d */
+int sp_ncdhw_to_cl(const float* src, void* dst, int32_t dtype, int32_t B, int32_t C, int64_t DHW, int32_t CP,
+                   sp_stream_t stream);
+int sp_cl_to_ncdhw(const void* src, float* dst, int32_t dtype, int32_t B, int32_t C, int64_t DHW, int32_t CP,
+                   sp_stream_t stream);
+
+/* ------------------------------------------------------------------ BatchNorm3d pieces (Unet3D.py:18,21; Cae3D.py:40..217)
+ * sums[c] = (sum x, sum x^2) over all nvox voxels of a channels-last tensor */
+int sp_bn_stats(const void* x, int32_t dtype, int64_t nvox, int32_t CP, double* sums /* [CP][2] */,
+                sp_stream_t stream);
+/* sums -> scale/shift for BN-on-load; updates running stats (momentum, unbiased var) like
+ * nn.BatchNorm3d; writes mean/invstd for the backward.  training=0: use running stats. */
+int sp_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int32_t training, int32_t C, int32_t CP,
+                   float* scale, float* shift, float* mean, float* invstd, sp_stream_t stream);
+/* backward reductions: sums[c] = (sum g, sum g*x) over the tensor */
+int sp_bn_bwd_reduce(const void* g, const void* x, int32_t dtype, int64_t nvox, int32_t CP, double* sums,
+                     sp_stream_t stream);
+/* from (sum g, sum g*x): dgamma, dbeta (ACCUMULATED into the gradient buffers, may be NULL) and
+ * coef[3][CP] with dx = coef0*g + coef1*x + coef2 */
+int sp_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* mean,
+                       const float* invstd, int32_t C, int32_t CP, float* dgamma, float* dbeta, float* coef,
+                       sp_stream_t stream);
+/* dz = (coef0*g + coef1*y + coef2) * act'(y)  (coef NULL: dz = g*act'(y));
+ * dbias_sums[c] += sum_voxels dz (fp64, may be NULL) */
+int sp_bn_act_bwd(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
+                  int32_t act, float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
+
+/* ------------------------------------------------------------------ pooling / upsampling / skip (Unet3D.py:59-72)
+ * MaxPool3d(2,2) floor mode; optional output statistics [CP][2] */
+int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
+                    double* stats, sp_stream_t stream);
+/* trilinear x2 (align_corners=0) into channels [0,CP) of a wider tensor with pitch CPd */
+int sp_upsample2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
+                     int32_t CPd, double* stats, sp_stream_t stream);
+/* centre-crop copy of src (pitch CPs) into channels [c0, c0+CPs) of dst (pitch CPd); stats [CPs][2] */
+int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B, int32_t Ds, int32_t Hs, int32_t Ws,
+                 int32_t CPs, int32_t Dd, int32_t Hd, int32_t Wd, int32_t CPd, int32_t c0, double* stats,
+                 sp_stream_t stream);
+/* gradient of a block output y that feeds (a) MaxPool3d(2,2) -> BN -> ... and (b) the cropped skip:
+ * dz = [ poolbwd(coefp0*gp + coefp1*pool(y) + coefp2) + crop-region(coefs0*gs + coefs1*cat + coefs2) ] * act'(y)
+ * either source may be NULL */
+int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
+                         const float* coefs, int32_t cs0, int32_t CPcat, int32_t dtype, int32_t B, int32_t D,
+                         int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
+                         float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
+/* gradient through trilinear x2: dz[lowres] = upsample^T(coef0*g + coef1*cat + coef2)[channels 0..CP) * act'(y) */
+int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
+                         int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
+                         float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
+
+/* ------------------------------------------------------------------ network output side + Dice (Unet3D.py:53,75-77;
+ * metrics.py:16-28).  dz[b,v,c] = dout[b,c,v]*act'(out[b,c,v]) : NCDHW fp32 -> channels-last */
+int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C, int64_t DHW, int32_t CP,
+                      int32_t dtype, int32_t act, float act_param, void* dz, double* dbias_sums,
+                      sp_stream_t stream);
+/* sums[c] = (sum o*t, sum o*o, sum t*t) per channel c of NCDHW fp32 tensors */
+int sp_dice_sums(const float* o, const float* t, int32_t B, int32_t C, int64_t DHW, double* sums, sp_stream_t stream);
+/* dout[b,c,v] = ca[c]*t + cb[c]*o */
+int sp_dice_bwd(const float* o, const float* t, const float* ca, const float* cb, int32_t B, int32_t C,
+                int64_t DHW, float* dout, sp_stream_t stream);
+
+/* ------------------------------------------------------------------ small utilities */
+int sp_add_f64_to_f32(const double* src, float* dst, int64_t n, float scale, sp_stream_t stream); /* dst += scale*src */
+int sp_axpby(const void* x, const void* y, void* out, int32_t dtype, int64_t n, float a, float b, sp_stream_t stream);
+/* latent lerp Cae3D.py:78-89: out[b,...] = c + step[b]*(p - c) */
+int sp_lerp_batch(const void* c, const void* p, const float* step, void* out, int32_t dtype, int32_t B,
+                  int64_t per_b, sp_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser (train_unet_segmentation.py:32,
+ * train_shape_reconstruction.py:40): torch.optim.Adam semantics (L2-coupled weight decay, bias
+ * correction, no amsgrad) on flat fp32 buffers; g is multiplied by grad_scale first */
+int sp_adam_step_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int32_t step, float grad_scale, sp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STROKE_AMD_H */

@@ -1,0 +1,143 @@
+// Shared device helpers for the gfx950 kernels of the U-Net / CAE hot path.
+// CDNA4 only: wave = 64 lanes, MFMA 16x16x32 bf16, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/stroke_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef unsigned short bf16_t;
+
+#define SP_WAVE 64
+
+// ---- error plumbing (thread-local message, see sp_last_error) ------------------------------
+void sp_set_error(const char* fmt, ...);
+#define SP_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      sp_set_error(__VA_ARGS__);           \
+      return SP_EINVAL;                    \
+    }                                      \
+  } while (0)
+#define SP_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      sp_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+      return SP_EHIP;                                                           \
+    }                                                                           \
+  } while (0)
+
+// ---- bf16 conversion ------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+// storage-type traits: T = bf16_t (fast path) or float (parity path)
+template <typename T> struct Store;
+template <> struct Store<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+  // 8 consecutive elements (16-byte aligned)
+  static __device__ __forceinline__ void ld8(const bf16_t* p, float* v) {
+    uint4 r = *reinterpret_cast<const uint4*>(p);
+    uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(w[i] << 16);
+      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void st8(bf16_t* p, const float* v) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  static __device__ __forceinline__ void st4(bf16_t* p, const float* v) {
+    uint32_t w0 = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+    uint32_t w1 = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = make_uint2(w0, w1);
+  }
+  static __device__ __forceinline__ void ld4(const bf16_t* p, float* v) {
+    uint2 r = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+  }
+};
+template <> struct Store<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void ld8(const float* p, float* v) {
+    float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void st8(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+  static __device__ __forceinline__ void st4(float* p, const float* v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  static __device__ __forceinline__ void ld4(const float* p, float* v) {
+    float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+};
+
+// ---- activations (fwd value; derivative as a function of the OUTPUT y) ------------------------
+__device__ __forceinline__ float act_fwd(int act, float p, float z) {
+  switch (act) {
+    case SP_ACT_LEAKY: return z > 0.f ? z : p * z;
+    case SP_ACT_ELU: return z > 0.f ? z : p * (__expf(z) - 1.f);
+    case SP_ACT_SIGMOID: return 1.f / (1.f + __expf(-z));
+    default: return z;
+  }
+}
+// dy/dz from y.  leaky: sign(y)=sign(z) for slope>0.  elu: y<=0 -> y+alpha.  sigmoid: y(1-y)
+__device__ __forceinline__ float act_bwd_from_y(int act, float p, float y) {
+  switch (act) {
+    case SP_ACT_LEAKY: return y > 0.f ? 1.f : p;
+    case SP_ACT_ELU: return y > 0.f ? 1.f : y + p;
+    case SP_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+// ---- exact unsigned division by a runtime constant (host computes mul/shift) --------------------
+struct FastDiv { uint32_t mul, shift; };
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }
+static inline FastDiv make_fastdiv(uint32_t d) {
+  FastDiv r; uint32_t s = 0;
+  while ((1ull << s) < d) ++s;
+  r.shift = s;
+  r.mul = (uint32_t)((((1ull << s) - d) << 32) / d + 1);
+  return r;
+}
+
+// ---- wave / block reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: workgroups that share halo data get
+// consecutive ids on ONE XCD (b and b+8 share an XCD under round-robin dispatch; speed only).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
+  uint32_t q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

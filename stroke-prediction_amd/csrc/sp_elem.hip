@@ -1,0 +1,794 @@
+// HBM-bound kernels of the U-Net / CAE hot path on gfx950: layout changes, BatchNorm statistics and
+// backward pieces, MaxPool3d / trilinear-x2 / crop-skip forward and fused backward, Dice sums, Adam.
+// Every kernel moves 16 bytes per lane per access on channels-last tensors (one 8-channel octet of
+// one voxel), keeps a thread's octet fixed over its grid-stride loop so per-channel partial sums live
+// in registers, and reduces wave -> LDS -> one fp64 atomic per channel per workgroup.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "sp_common.h"
+
+// ------------------------------------------------------------------------------------------------ core
+static thread_local char g_err[512] = "";
+void sp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" void sp_last_error(char* buf, size_t n) {
+  if (!buf || n == 0) return;
+  strncpy(buf, g_err, n - 1);
+  buf[n - 1] = 0;
+}
+extern "C" int sp_version(void) { return 100; }
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define MAX_BLOCKS 2048
+
+// thread -> (voxel slot, octet) for CP/8 octets; threads beyond vpb*OC idle
+struct OctMap {
+  int OC, vpb;
+  FastDiv d_oc;
+};
+static inline OctMap make_octmap(int CP) {
+  OctMap m;
+  m.OC = CP / 8;
+  m.vpb = 256 / m.OC;
+  m.d_oc = make_fastdiv(m.OC);
+  return m;
+}
+static inline unsigned grid_for(int64_t nvox, int vpb) {
+  int64_t nb = (nvox + vpb - 1) / vpb;
+  return (unsigned)(nb < 1 ? 1 : (nb > MAX_BLOCKS ? MAX_BLOCKS : nb));
+}
+
+// block-level per-channel reduction of NS partial sums per channel (8 channels per thread)
+template <int NS>
+__device__ __forceinline__ void block_channel_reduce(const float part[NS][8], int oc, bool active, int CP,
+                                                     double* __restrict__ out, float* red) {
+  for (int i = threadIdx.x; i < CP * NS; i += 256) red[i] = 0.f;
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&red[(oc * 8 + j) * NS + s], part[s][j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < CP * NS; i += 256) atomicAdd(&out[i], (double)red[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ layout
+template <typename T>
+__global__ void ncdhw_to_cl_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int64_t DHW, int CP,
+                                   int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / DHW, v = i - b * DHW;
+    for (int c0 = 0; c0 < CP; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (c0 + j < C) ? src[(b * C + c0 + j) * DHW + v] : 0.f;
+      Store<T>::st8(dst + i * CP + c0, f);
+    }
+  }
+}
+extern "C" int sp_ncdhw_to_cl(const float* src, void* dst, int32_t dtype, int32_t B, int32_t C, int64_t DHW,
+                              int32_t CP, sp_stream_t stream) {
+  SP_CHECK_ARG(src && dst && C <= CP && CP % 8 == 0, "sp_ncdhw_to_cl: bad arguments");
+  const int64_t total = (int64_t)B * DHW;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(ncdhw_to_cl_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), src, (bf16_t*)dst, C, DHW, CP, total);
+  else hipLaunchKernelGGL(ncdhw_to_cl_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), src, (float*)dst, C, DHW, CP, total);
+  SP_CHECK_LAUNCH("sp_ncdhw_to_cl");
+  return SP_OK;
+}
+
+template <typename T>
+__global__ void cl_to_ncdhw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int64_t DHW, int CP,
+                                   int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / DHW, v = i - b * DHW;
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float f[8];
+      Store<T>::ld8(src + i * CP + c0, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c0 + j < C) dst[(b * C + c0 + j) * DHW + v] = f[j];
+    }
+  }
+}
+extern "C" int sp_cl_to_ncdhw(const void* src, float* dst, int32_t dtype, int32_t B, int32_t C, int64_t DHW,
+                              int32_t CP, sp_stream_t stream) {
+  SP_CHECK_ARG(src && dst && C <= CP && CP % 8 == 0, "sp_cl_to_ncdhw: bad arguments");
+  const int64_t total = (int64_t)B * DHW;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(cl_to_ncdhw_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), (const bf16_t*)src, dst, C, DHW, CP, total);
+  else hipLaunchKernelGGL(cl_to_ncdhw_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)src, dst, C, DHW, CP, total);
+  SP_CHECK_LAUNCH("sp_cl_to_ncdhw");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ BatchNorm
+// NS=2: (sum x, sum x^2) of one tensor; two-tensor form: (sum g, sum g*x)
+template <typename T, bool TWO>
+__global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, const T* __restrict__ g, int64_t nvox,
+                                                       int CP, OctMap om, double* __restrict__ sums) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nvox; v += (int64_t)gridDim.x * om.vpb) {
+      float a[8];
+      Store<T>::ld8(x + v * CP + oc * 8, a);
+      if (TWO) {
+        float b[8];
+        Store<T>::ld8(g + v * CP + oc * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { part[0][j] += b[j]; part[1][j] += b[j] * a[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { part[0][j] += a[j]; part[1][j] += a[j] * a[j]; }
+      }
+    }
+  }
+  block_channel_reduce<2>(part, oc, active, CP, sums, red);
+}
+
+extern "C" int sp_bn_stats(const void* x, int32_t dtype, int64_t nvox, int32_t CP, double* sums, sp_stream_t stream) {
+  SP_CHECK_ARG(x && sums && CP % 8 == 0 && CP >= 8 && CP <= 2048, "sp_bn_stats: bad arguments (CP=%d)", CP);
+  OctMap om = make_octmap(CP);
+  const unsigned grid = grid_for(nvox, om.vpb * 8);
+  const size_t sh = (size_t)CP * 2 * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL((bn_sums_kernel<bf16_t, false>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (const bf16_t*)nullptr, nvox, CP, om, sums);
+  else hipLaunchKernelGGL((bn_sums_kernel<float, false>), dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (const float*)nullptr, nvox, CP, om, sums);
+  SP_CHECK_LAUNCH("sp_bn_stats");
+  return SP_OK;
+}
+extern "C" int sp_bn_bwd_reduce(const void* g, const void* x, int32_t dtype, int64_t nvox, int32_t CP, double* sums,
+                                sp_stream_t stream) {
+  SP_CHECK_ARG(g && x && sums && CP % 8 == 0 && CP >= 8 && CP <= 2048, "sp_bn_bwd_reduce: bad arguments");
+  OctMap om = make_octmap(CP);
+  const unsigned grid = grid_for(nvox, om.vpb * 8);
+  const size_t sh = (size_t)CP * 2 * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL((bn_sums_kernel<bf16_t, true>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (const bf16_t*)g, nvox, CP, om, sums);
+  else hipLaunchKernelGGL((bn_sums_kernel<float, true>), dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (const float*)g, nvox, CP, om, sums);
+  SP_CHECK_LAUNCH("sp_bn_bwd_reduce");
+  return SP_OK;
+}
+
+// nn.BatchNorm3d (training): normalise with biased batch variance, update running stats with the
+// unbiased one (momentum); eval: running stats.  Pad channels (c >= C) get scale = shift = 0.
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, int training, int C, int CP, float* scale, float* shift,
+                                   float* mean_out, float* invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP) return;
+  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; if (mean_out) { mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
+  float mean, invstd;
+  if (training) {
+    const double m = sums[2 * c] / count;
+    double var = sums[2 * c + 1] / count - m * m;
+    if (var < 0) var = 0;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c];
+    invstd = 1.f / sqrtf(running_var[c] + eps);
+  }
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  if (mean_out) { mean_out[c] = mean; invstd_out[c] = invstd; }
+}
+extern "C" int sp_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                              int32_t C, int32_t CP, float* scale, float* shift, float* mean, float* invstd,
+                              sp_stream_t stream) {
+  SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP, "sp_bn_finalize: bad arguments");
+  SP_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "sp_bn_finalize: missing statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((CP + 63) / 64), dim3(64), 0, ST(stream), sums, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, C, CP, scale, shift, mean, invstd);
+  SP_CHECK_LAUNCH("sp_bn_finalize");
+  return SP_OK;
+}
+
+// dgamma = (S2 - mean*S1)*invstd ; dbeta = S1 ; dx = coef0*g + coef1*x + coef2 with
+// coef0 = gamma*invstd, coef1 = -gamma*invstd^2*dgamma/N, coef2 = -coef0*dbeta/N - coef1*mean
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                       const float* __restrict__ mean, const float* __restrict__ invstd, int C, int CP,
+                                       float* dgamma, float* dbeta, float* coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CP) return;
+  if (c >= C) { coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f; return; }
+  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+  const double mu = mean[c], is = invstd[c], ga = gamma[c];
+  const double dg = (s2 - mu * s1) * is, db = s1;
+  if (dgamma) { dgamma[c] += (float)dg; dbeta[c] += (float)db; }
+  const double c0 = ga * is, c1 = -ga * is * is * dg / count;
+  coef[c] = (float)c0;
+  coef[CP + c] = (float)c1;
+  coef[2 * CP + c] = (float)(-c0 * db / count - c1 * mu);
+}
+extern "C" int sp_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* mean,
+                                  const float* invstd, int32_t C, int32_t CP, float* dgamma, float* dbeta, float* coef,
+                                  sp_stream_t stream) {
+  SP_CHECK_ARG(sums && gamma && mean && invstd && coef && count > 0, "sp_bn_bwd_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((CP + 63) / 64), dim3(64), 0, ST(stream), sums, count, gamma, mean, invstd, C, CP, dgamma, dbeta, coef);
+  SP_CHECK_LAUNCH("sp_bn_bwd_finalize");
+  return SP_OK;
+}
+
+// dz = (coef0*g + coef1*y + coef2) * act'(y)  [coef == NULL: dz = g*act'(y)] ; dbias_sums[c] += sum dz
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                          const float* __restrict__ coef, int64_t nvox, int CP,
+                                                          OctMap om, int act, float ap, T* __restrict__ dz,
+                                                          double* __restrict__ dbias) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  float part[1][8];
+  float c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    part[0][j] = 0.f;
+    c0[j] = (coef && active) ? coef[oc * 8 + j] : 1.f;
+    c1[j] = (coef && active) ? coef[CP + oc * 8 + j] : 0.f;
+    c2[j] = (coef && active) ? coef[2 * CP + oc * 8 + j] : 0.f;
+  }
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nvox; v += (int64_t)gridDim.x * om.vpb) {
+      float a[8], b[8], o[8];
+      Store<T>::ld8(g + v * CP + oc * 8, a);
+      Store<T>::ld8(y + v * CP + oc * 8, b);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = (c0[j] * a[j] + c1[j] * b[j] + c2[j]) * act_bwd_from_y(act, ap, b[j]);
+        part[0][j] += o[j];
+      }
+      Store<T>::st8(dz + v * CP + oc * 8, o);
+    }
+  }
+  if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
+}
+extern "C" int sp_bn_act_bwd(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
+                             int32_t act, float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+  SP_CHECK_ARG(g && y && dz && CP % 8 == 0 && CP <= 2048, "sp_bn_act_bwd: bad arguments");
+  OctMap om = make_octmap(CP);
+  const unsigned grid = grid_for(nvox, om.vpb * 4);
+  const size_t sh = (size_t)CP * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)g, (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);
+  else hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)g, (const float*)y, coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums);
+  SP_CHECK_LAUNCH("sp_bn_act_bwd");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pool / upsample / crop fwd
+struct Dims { int B, D, H, W; };
+__device__ __forceinline__ void unflatten(int64_t v, int D, int H, int W, int& b, int& z, int& y, int& x) {
+  x = (int)(v % W); v /= W;
+  y = (int)(v % H); v /= H;
+  z = (int)(v % D); b = (int)(v / D);
+}
+
+// MaxPool3d(2,2), floor mode (Unet3D.py:39,41)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims di, int CP,
+                                                            OctMap om, double* __restrict__ stats) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  const int Do = di.D / 2, Ho = di.H / 2, Wo = di.W / 2;
+  const int64_t nout = (int64_t)di.B * Do * Ho * Wo;
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nout; v += (int64_t)gridDim.x * om.vpb) {
+      int b, z, yy, xx;
+      unflatten(v, Do, Ho, Wo, b, z, yy, xx);
+      float m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = 2 * z + (k >> 2), iy = 2 * yy + ((k >> 1) & 1), ix = 2 * xx + (k & 1);
+        float a[8];
+        Store<T>::ld8(x + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], a[j]);
+      }
+      Store<T>::st8(y + v * CP + oc * 8, m);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { part[0][j] += m[j]; part[1][j] += m[j] * m[j]; }
+    }
+  }
+  if (stats) block_channel_reduce<2>(part, oc, active, CP, stats, red);
+}
+extern "C" int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
+                               int32_t CP, double* stats, sp_stream_t stream) {
+  SP_CHECK_ARG(x && y && CP % 8 == 0 && D >= 2 && H >= 2 && W >= 2, "sp_maxpool2_fwd: bad arguments");
+  OctMap om = make_octmap(CP);
+  Dims di{B, D, H, W};
+  const int64_t nout = (int64_t)B * (D / 2) * (H / 2) * (W / 2);
+  const unsigned grid = grid_for(nout, om.vpb * 2);
+  const size_t sh = (size_t)CP * 2 * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats);
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats);
+  SP_CHECK_LAUNCH("sp_maxpool2_fwd");
+  return SP_OK;
+}
+
+// nn.Upsample(scale_factor=2, mode='trilinear'), align_corners=False (Unet3D.py:44,46):
+// src = max(0, o/2 - 0.25); i0 = floor(src); i1 = min(i0+1, N-1); lambda = src - i0
+__device__ __forceinline__ void up_src(int o, int N, int& i0, int& i1, float& l1) {
+  float s = 0.5f * (float)o - 0.25f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + 1 < N ? i0 + 1 : N - 1;
+  l1 = s - (float)i0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims di, int CP,
+                                                             int CPd, OctMap om, double* __restrict__ stats) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  const int Do = di.D * 2, Ho = di.H * 2, Wo = di.W * 2;
+  const int64_t nout = (int64_t)di.B * Do * Ho * Wo;
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nout; v += (int64_t)gridDim.x * om.vpb) {
+      int b, z, yy, xx;
+      unflatten(v, Do, Ho, Wo, b, z, yy, xx);
+      int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+      up_src(z, di.D, z0, z1, lz); up_src(yy, di.H, y0, y1, ly); up_src(xx, di.W, x0, x1, lx);
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = (k & 4) ? z1 : z0, iy = (k & 2) ? y1 : y0, ix = (k & 1) ? x1 : x0;
+        const float w = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+        float a[8];
+        Store<T>::ld8(x + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(w, a[j], o[j]);
+      }
+      Store<T>::st8(y + v * CPd + oc * 8, o);
+      if (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = bf2f(f2bf(o[j]));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { part[0][j] += o[j]; part[1][j] += o[j] * o[j]; }
+    }
+  }
+  if (stats) block_channel_reduce<2>(part, oc, active, CP, stats, red);
+}
+extern "C" int sp_upsample2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
+                                int32_t CP, int32_t CPd, double* stats, sp_stream_t stream) {
+  SP_CHECK_ARG(x && y && CP % 8 == 0 && CPd >= CP && CPd % 8 == 0, "sp_upsample2_fwd: bad arguments");
+  OctMap om = make_octmap(CP);
+  Dims di{B, D, H, W};
+  const int64_t nout = (int64_t)B * D * H * W * 8;
+  const unsigned grid = grid_for(nout, om.vpb * 2);
+  const size_t sh = (size_t)CP * 2 * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(upsample2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, CPd, om, stats);
+  else hipLaunchKernelGGL(upsample2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, CPd, om, stats);
+  SP_CHECK_LAUNCH("sp_upsample2_fwd");
+  return SP_OK;
+}
+
+// centre crop (offset (in-out)//2, Unet3D.py:10) of src into channels [c0, c0+CPs) of dst
+template <typename T>
+__global__ __launch_bounds__(256) void crop_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, Dims ds, int CPs,
+                                                         Dims dd, int CPd, int c0, OctMap om, double* __restrict__ stats) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  const int oz = (ds.D - dd.D) / 2, oy = (ds.H - dd.H) / 2, ox = (ds.W - dd.W) / 2;
+  const int64_t nout = (int64_t)dd.B * dd.D * dd.H * dd.W;
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nout; v += (int64_t)gridDim.x * om.vpb) {
+      int b, z, yy, xx;
+      unflatten(v, dd.D, dd.H, dd.W, b, z, yy, xx);
+      float a[8];
+      Store<T>::ld8(src + ((((int64_t)b * ds.D + z + oz) * ds.H + yy + oy) * ds.W + xx + ox) * CPs + oc * 8, a);
+      Store<T>::st8(dst + v * CPd + c0 + oc * 8, a);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { part[0][j] += a[j]; part[1][j] += a[j] * a[j]; }
+    }
+  }
+  if (stats) block_channel_reduce<2>(part, oc, active, CPs, stats, red);
+}
+extern "C" int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B, int32_t Ds, int32_t Hs, int32_t Ws,
+                            int32_t CPs, int32_t Dd, int32_t Hd, int32_t Wd, int32_t CPd, int32_t c0, double* stats,
+                            sp_stream_t stream) {
+  SP_CHECK_ARG(src && dst && CPs % 8 == 0 && CPd % 8 == 0 && c0 % 8 == 0 && c0 + CPs <= CPd, "sp_crop_copy: bad channels");
+  SP_CHECK_ARG(Dd <= Ds && Hd <= Hs && Wd <= Ws, "sp_crop_copy: crop larger than source");
+  OctMap om = make_octmap(CPs);
+  Dims ds{B, Ds, Hs, Ws}, dd{B, Dd, Hd, Wd};
+  const unsigned grid = grid_for((int64_t)B * Dd * Hd * Wd, om.vpb * 4);
+  const size_t sh = (size_t)CPs * 2 * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(crop_copy_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)src, (bf16_t*)dst, ds, CPs, dd, CPd, c0, om, stats);
+  else hipLaunchKernelGGL(crop_copy_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)src, (float*)dst, ds, CPs, dd, CPd, c0, om, stats);
+  SP_CHECK_LAUNCH("sp_crop_copy");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fused backward pieces
+// Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
+// One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
+// (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
+    const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
+    const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, Dims di, int CP, Dims dc,
+    OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  const int Dw = (di.D + 1) / 2, Hw = (di.H + 1) / 2, Ww = (di.W + 1) / 2;      // windows incl. ragged edge
+  const int Dp = di.D / 2, Hp = di.H / 2, Wp = di.W / 2;                        // pooled dims (floor)
+  const int cz = (di.D - dc.D) / 2, cy = (di.H - dc.H) / 2, cx = (di.W - dc.W) / 2;
+  const int64_t nwin = (int64_t)di.B * Dw * Hw * Ww;
+  float part[1][8];
+  float p0[8], p1[8], p2[8], s0[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    part[0][j] = 0.f;
+    const int c = oc * 8 + j;
+    p0[j] = (gp && active) ? coefp[c] : 0.f; p1[j] = (gp && active) ? coefp[CP + c] : 0.f; p2[j] = (gp && active) ? coefp[2 * CP + c] : 0.f;
+    s0[j] = (gs && active) ? coefs[cs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[CPcat + cs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * CPcat + cs0 + c] : 0.f;
+  }
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nwin; v += (int64_t)gridDim.x * om.vpb) {
+      int b, wz, wy, wx;
+      unflatten(v, Dw, Hw, Ww, b, wz, wy, wx);
+      const bool pooled = gp && wz < Dp && wy < Hp && wx < Wp;
+      float yv[8][8];
+      float m[8]; int am[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = 0; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = 2 * wz + (k >> 2), iy = 2 * wy + ((k >> 1) & 1), ix = 2 * wx + (k & 1);
+        if (iz < di.D && iy < di.H && ix < di.W) {
+          Store<T>::ld8(y + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, yv[k]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) if (yv[k][j] > m[j]) { m[j] = yv[k][j]; am[j] = k; }
+        }
+      }
+      float dp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dp[j] = 0.f;
+      if (pooled) {
+        float g8[8];
+        Store<T>::ld8(gp + ((((int64_t)b * Dp + wz) * Hp + wy) * Wp + wx) * CP + oc * 8, g8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dp[j] = p0[j] * g8[j] + p1[j] * m[j] + p2[j];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = 2 * wz + (k >> 2), iy = 2 * wy + ((k >> 1) & 1), ix = 2 * wx + (k & 1);
+        if (iz < di.D && iy < di.H && ix < di.W) {
+          float d[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j] = (pooled && am[j] == k) ? dp[j] : 0.f;
+          const int qz = iz - cz, qy = iy - cy, qx = ix - cx;
+          if (gs && (unsigned)qz < (unsigned)dc.D && (unsigned)qy < (unsigned)dc.H && (unsigned)qx < (unsigned)dc.W) {
+            const int64_t o = ((((int64_t)b * dc.D + qz) * dc.H + qy) * dc.W + qx) * CPcat + cs0 + oc * 8;
+            float g8[8], c8[8];
+            Store<T>::ld8(gs + o, g8);
+            Store<T>::ld8(cat + o, c8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * c8[j] + s2[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_from_y(act, ap, yv[k][j]); part[0][j] += d[j]; }
+          Store<T>::st8(dz + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, d);
+        }
+      }
+    }
+  }
+  if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
+}
+extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
+                                    const float* coefs, int32_t cs0, int32_t CPcat, int32_t dtype, int32_t B, int32_t D,
+                                    int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
+                                    float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+  SP_CHECK_ARG(y && dz && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
+  SP_CHECK_ARG(!gp || coefp, "sp_pool_skip_act_bwd: pool gradient without coefficients");
+  SP_CHECK_ARG(!gs || (cat && coefs && cs0 % 8 == 0 && cs0 + CP <= CPcat && Dc <= D && Hc <= H && Wc <= W), "sp_pool_skip_act_bwd: bad skip arguments");
+  OctMap om = make_octmap(CP);
+  Dims di{B, D, H, W}, dc{B, Dc, Hc, Wc};
+  const int64_t nwin = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  const unsigned grid = grid_for(nwin, om.vpb);
+  const size_t sh = (size_t)CP * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(pool_skip_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);
+  else hipLaunchKernelGGL(pool_skip_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, di, CP, dc, om, act, act_param, (float*)dz, dbias_sums);
+  SP_CHECK_LAUNCH("sp_pool_skip_act_bwd");
+  return SP_OK;
+}
+
+// transposed trilinear x2: per axis, input i receives from outputs 2i-1 (w .25), 2i (.75, or 1 at i=0),
+// 2i+1 (.75, or 1 at i=N-1), 2i+2 (.25)
+__device__ __forceinline__ void upT_axis(int i, int N, int o[4], float w[4]) {
+  o[0] = 2 * i - 1; w[0] = i >= 1 ? 0.25f : 0.f;
+  o[1] = 2 * i;     w[1] = i >= 1 ? 0.75f : 1.f;
+  o[2] = 2 * i + 1; w[2] = i < N - 1 ? 0.75f : 1.f;
+  o[3] = 2 * i + 2; w[3] = i < N - 1 ? 0.25f : 0.f;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ cat,
+                                                                 const T* __restrict__ g, const float* __restrict__ coef,
+                                                                 int CPcat, Dims di, int CP, OctMap om, int act, float ap,
+                                                                 T* __restrict__ dz, double* __restrict__ dbias) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  const int Do = 2 * di.D, Ho = 2 * di.H, Wo = 2 * di.W;
+  const int64_t nin = (int64_t)di.B * di.D * di.H * di.W;
+  float part[1][8], c0[8], c1[8], c2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    part[0][j] = 0.f;
+    const int c = oc * 8 + j;
+    c0[j] = active ? coef[c] : 0.f; c1[j] = active ? coef[CPcat + c] : 0.f; c2[j] = active ? coef[2 * CPcat + c] : 0.f;
+  }
+  if (active) {
+    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nin; v += (int64_t)gridDim.x * om.vpb) {
+      int b, z, yy, xx;
+      unflatten(v, di.D, di.H, di.W, b, z, yy, xx);
+      int oz[4], oy[4], ox[4]; float wz[4], wy[4], wx[4];
+      upT_axis(z, di.D, oz, wz); upT_axis(yy, di.H, oy, wy); upT_axis(xx, di.W, ox, wx);
+      float d[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d[j] = 0.f;
+      for (int a = 0; a < 4; ++a) {
+        if (wz[a] == 0.f) continue;
+        for (int bb = 0; bb < 4; ++bb) {
+          if (wy[bb] == 0.f) continue;
+          const float wzy = wz[a] * wy[bb];
+          const int64_t rowbase = (((int64_t)b * Do + oz[a]) * Ho + oy[bb]) * Wo;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float w = wzy * wx[c];
+            if (w != 0.f) {
+              const int64_t o = (rowbase + ox[c]) * CPcat + oc * 8;
+              float g8[8], c8[8];
+              Store<T>::ld8(g + o, g8);
+              Store<T>::ld8(cat + o, c8);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) d[j] = fmaf(w, c0[j] * g8[j] + c1[j] * c8[j] + c2[j], d[j]);
+            }
+          }
+        }
+      }
+      float y8[8];
+      Store<T>::ld8(y + v * CP + oc * 8, y8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_from_y(act, ap, y8[j]); part[0][j] += d[j]; }
+      Store<T>::st8(dz + v * CP + oc * 8, d);
+    }
+  }
+  if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
+}
+extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
+                                    int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
+                                    float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+  SP_CHECK_ARG(y && cat && g && coef && dz && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
+  OctMap om = make_octmap(CP);
+  Dims di{B, D, H, W};
+  const unsigned grid = grid_for((int64_t)B * D * H * W, om.vpb);
+  const size_t sh = (size_t)CP * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(upsample2_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)cat, (const bf16_t*)g, coef, CPcat, di, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);
+  else hipLaunchKernelGGL(upsample2_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)cat, (const float*)g, coef, CPcat, di, CP, om, act, act_param, (float*)dz, dbias_sums);
+  SP_CHECK_LAUNCH("sp_upsample2_act_bwd");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ network output side
+// dz[b,v,c] = dout[b,c,v] * act'(out[b,c,v]) ; NCDHW fp32 -> channels-last ; dbias_sums[c] += sum dz
+template <typename T>
+__global__ __launch_bounds__(256) void out_grad_to_cl_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                              int C, int64_t DHW, int CP, int64_t total, int act, float ap,
+                                                              T* __restrict__ dz, double* __restrict__ dbias) {
+  __shared__ float red[8];
+  if (threadIdx.x < 8) red[threadIdx.x] = 0.f;
+  __syncthreads();
+  float part[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[j] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / DHW, v = i - b * DHW;
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      f[j] = 0.f;
+      if (j < C) {
+        const int64_t o = (b * C + j) * DHW + v;
+        f[j] = dout[o] * act_bwd_from_y(act, ap, out[o]);
+        part[j] += f[j];
+      }
+    }
+    Store<T>::st8(dz + i * CP, f);
+    for (int c0 = 8; c0 < CP; c0 += 8) {
+      float zz[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      Store<T>::st8(dz + i * CP + c0, zz);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float s = wave_sum(part[j]);
+    if ((threadIdx.x & 63) == 0 && j < C) atomicAdd(&red[j], s);
+  }
+  __syncthreads();
+  if (dbias && threadIdx.x < C) atomicAdd(&dbias[threadIdx.x], (double)red[threadIdx.x]);
+}
+extern "C" int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C, int64_t DHW, int32_t CP,
+                                 int32_t dtype, int32_t act, float act_param, void* dz, double* dbias_sums,
+                                 sp_stream_t stream) {
+  SP_CHECK_ARG(dout && out && dz && C >= 1 && C <= 8 && CP % 8 == 0, "sp_out_grad_to_cl: needs 1..8 output channels");
+  const int64_t total = (int64_t)B * DHW;
+  const unsigned grid = (unsigned)((total + 255) / 256 > MAX_BLOCKS ? MAX_BLOCKS : (total + 255) / 256);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(out_grad_to_cl_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), dout, out, C, DHW, CP, total, act, act_param, (bf16_t*)dz, dbias_sums);
+  else hipLaunchKernelGGL(out_grad_to_cl_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), dout, out, C, DHW, CP, total, act, act_param, (float*)dz, dbias_sums);
+  SP_CHECK_LAUNCH("sp_out_grad_to_cl");
+  return SP_OK;
+}
+
+// BatchDiceLoss pieces (metrics.py:16-28): sums[c] = (sum o*t, sum o*o, sum t*t) over batch and volume
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ o, const float* __restrict__ t, int C,
+                                                         int64_t DHW, int64_t chunks_per_c, double* __restrict__ sums) {
+  // grid.y = b*C + c ; grid.x strides over the volume
+  const int bc = blockIdx.y, c = bc % C;
+  const float* op = o + (int64_t)bc * DHW;
+  const float* tp = t + (int64_t)bc * DHW;
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < DHW; i += (int64_t)gridDim.x * 256) {
+    const float a = op[i], b = tp[i];
+    s[0] += a * b; s[1] += a * a; s[2] += b * b;
+  }
+  __shared__ float red[3];
+  if (threadIdx.x < 3) red[threadIdx.x] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float w = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], w);
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicAdd(&sums[c * 3 + threadIdx.x], (double)red[threadIdx.x]);
+}
+extern "C" int sp_dice_sums(const float* o, const float* t, int32_t B, int32_t C, int64_t DHW, double* sums,
+                            sp_stream_t stream) {
+  SP_CHECK_ARG(o && t && sums && B >= 1 && C >= 1, "sp_dice_sums: bad arguments");
+  int64_t gx = (DHW + 256 * 8 - 1) / (256 * 8);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, ST(stream), o, t, C, DHW, gx, sums);
+  SP_CHECK_LAUNCH("sp_dice_sums");
+  return SP_OK;
+}
+// do[b,c,v] = ca[c]*t + cb[c]*o   (ca = -w*2/den*up, cb = +w*2*num/den^2*up formed by the caller)
+__global__ void dice_bwd_kernel(const float* __restrict__ o, const float* __restrict__ t, const float* __restrict__ ca,
+                                const float* __restrict__ cb, int C, int64_t DHW, int64_t total, float* __restrict__ d) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / DHW) % C);
+    d[i] = ca[c] * t[i] + cb[c] * o[i];
+  }
+}
+extern "C" int sp_dice_bwd(const float* o, const float* t, const float* ca, const float* cb, int32_t B, int32_t C,
+                           int64_t DHW, float* dout, sp_stream_t stream) {
+  SP_CHECK_ARG(o && t && ca && cb && dout, "sp_dice_bwd: null pointer");
+  const int64_t total = (int64_t)B * C * DHW;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(dice_bwd_kernel, dim3(grid), dim3(256), 0, ST(stream), o, t, ca, cb, C, DHW, total, dout);
+  SP_CHECK_LAUNCH("sp_dice_bwd");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ utilities
+__global__ void add_f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] += scale * (float)src[i];
+}
+extern "C" int sp_add_f64_to_f32(const double* src, float* dst, int64_t n, float scale, sp_stream_t stream) {
+  SP_CHECK_ARG(src && dst && n > 0, "sp_add_f64_to_f32: bad arguments");
+  hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), src, dst, n, scale);
+  SP_CHECK_LAUNCH("sp_add_f64_to_f32");
+  return SP_OK;
+}
+
+// out[b,i] = c[b,i] + step[b]*(p[b,i]-c[b,i])   (Enc3D._interpolate, Cae3D.py:78-89)
+template <typename T>
+__global__ void lerp_batch_kernel(const T* __restrict__ c, const T* __restrict__ p, const float* __restrict__ step,
+                                  T* __restrict__ out, int64_t per_b, int64_t total8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total8; i += (int64_t)gridDim.x * 256) {
+    const int64_t e = i * 8;
+    const float s = step[e / per_b];
+    float a[8], b[8];
+    Store<T>::ld8(c + e, a);
+    Store<T>::ld8(p + e, b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = a[j] + s * (b[j] - a[j]);
+    Store<T>::st8(out + e, a);
+  }
+}
+extern "C" int sp_lerp_batch(const void* c, const void* p, const float* step, void* out, int32_t dtype, int32_t B,
+                             int64_t per_b, sp_stream_t stream) {
+  SP_CHECK_ARG(c && p && step && out && per_b % 8 == 0, "sp_lerp_batch: bad arguments");
+  const int64_t total8 = (int64_t)B * per_b / 8;
+  const unsigned grid = (unsigned)((total8 + 255) / 256 > 2048 ? 2048 : (total8 + 255) / 256);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(lerp_batch_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), (const bf16_t*)c, (const bf16_t*)p, step, (bf16_t*)out, per_b, total8);
+  else hipLaunchKernelGGL(lerp_batch_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)c, (const float*)p, step, (float*)out, per_b, total8);
+  SP_CHECK_LAUNCH("sp_lerp_batch");
+  return SP_OK;
+}
+
+// out = a*x + b*y elementwise on channels-last buffers (n multiple of 8)
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ x, const T* __restrict__ y, T* __restrict__ out, int64_t n8, float a, float b) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float u[8], v[8];
+    Store<T>::ld8(x + i * 8, u);
+    Store<T>::ld8(y + i * 8, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) u[j] = a * u[j] + b * v[j];
+    Store<T>::st8(out + i * 8, u);
+  }
+}
+extern "C" int sp_axpby(const void* x, const void* y, void* out, int32_t dtype, int64_t n, float a, float b, sp_stream_t stream) {
+  SP_CHECK_ARG(x && y && out && n % 8 == 0, "sp_axpby: bad arguments");
+  const int64_t n8 = n / 8;
+  const unsigned grid = (unsigned)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(axpby_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), (const bf16_t*)x, (const bf16_t*)y, (bf16_t*)out, n8, a, b);
+  else hipLaunchKernelGGL(axpby_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)x, (const float*)y, (float*)out, n8, a, b);
+  SP_CHECK_LAUNCH("sp_axpby");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+// torch.optim.Adam (no amsgrad): g += wd*p ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            int64_t n, float lr_over_bc1, float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2,
+                            float grad_scale) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float pi = p[i];
+    const float gi = g[i] * grad_scale + wd * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}
+extern "C" int sp_adam_step_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
+                                 sp_stream_t stream) {
+  SP_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "sp_adam_step_flat: bad arguments");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const unsigned grid = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, ST(stream), p, g, m, v, n, (float)(lr / bc1), beta1, beta2, eps,
+                     weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale);
+  SP_CHECK_LAUNCH("sp_adam_step_flat");
+  return SP_OK;
+}

@@ -1,0 +1,123 @@
+"""ctypes binding of ``libstroke_amd.so`` (the C ABI in ``include/stroke_amd.h``).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``hipcc
+--offload-arch=gfx950``).  There is no fallback: if it is missing or a call
+fails, a ``RuntimeError`` carrying ``sp_last_error`` is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_DIR = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libstroke_amd.so")
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+SOURCES = ["sp_conv.hip", "sp_wgrad.hip", "sp_elem.hip"]
+
+SP_BF16, SP_F32 = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
+
+i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ("x", "y", "wfrag_hi", "wfrag_lo", "in_scale", "in_shift", "bias", "stats", "ktab")] + \
+               [(n, i32) for n in (
+                   "dtype_in", "dtype_out", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "YD", "YH", "YW", "CPo",
+                   "osD", "osH", "osW", "ooD", "ooH", "ooW", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
+                   "TD", "TH", "ITD", "ITH", "ITW", "MT", "NT", "NTtot", "ngroups", "octs_per_group", "opp", "vsb",
+                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [(n, vp) for n in ("x", "dz", "in_scale", "in_shift", "dz_scale", "dz_shift", "dw_acc", "taps")] + \
+               [(n, i32) for n in ("dtype", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "sD", "sH", "sW",
+                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks")]
+
+
+_SIGS = {
+    "sp_version": ([], i32),
+    "sp_conv3d_igemm": ([C.POINTER(ConvArgs), vp], i32),
+    "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp], i32),
+    "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
+    "sp_wgrad_finish": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp], i32),
+    "sp_ncdhw_to_cl": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
+    "sp_cl_to_ncdhw": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
+    "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),
+    "sp_bn_finalize": ([vp, f64, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
+    "sp_bn_bwd_reduce": ([vp, vp, i32, i64, i32, vp, vp], i32),
+    "sp_bn_bwd_finalize": ([vp, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp], i32),
+    "sp_bn_act_bwd": ([vp, vp, vp, i32, i64, i32, i32, f32, vp, vp, vp], i32),
+    "sp_maxpool2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp, vp], i32),
+    "sp_upsample2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
+    "sp_crop_copy": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),
+    "sp_pool_skip_act_bwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
+                              f32, vp, vp, vp], i32),
+    "sp_upsample2_act_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp], i32),
+    "sp_out_grad_to_cl": ([vp, vp, i32, i32, i64, i32, i32, i32, f32, vp, vp, vp], i32),
+    "sp_dice_sums": ([vp, vp, i32, i32, i64, vp, vp], i32),
+    "sp_dice_bwd": ([vp, vp, vp, vp, i32, i32, i64, vp, vp], i32),
+    "sp_add_f64_to_f32": ([vp, vp, i64, f32, vp], i32),
+    "sp_axpby": ([vp, vp, vp, i32, i64, f32, f32, vp], i32),
+    "sp_lerp_batch": ([vp, vp, vp, vp, i32, i32, i64, vp], i32),
+    "sp_adam_step_flat": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp], i32),
+}
+EXPORTS = sorted(list(_SIGS) + ["sp_last_error"])
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "stroke_prediction_amd: %s is missing -- build it with `python -c \"import __graft_entry__ as g; "
+            "g.build()\"` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    lib.sp_last_error.argtypes = [C.c_char_p, C.c_size_t]
+    lib.sp_last_error.restype = None
+    _lib = lib
+    return lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    load().sp_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, last_error()))
+
+
+def call(name, *args):
+    """Call an ``int sp_*(...)`` entry point and raise on a non-zero return."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (rc=%d): %s" % (name, rc, last_error()))
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 into ``lib/libstroke_amd.so`` (cross-compiles without a GPU)."""
+    import subprocess
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC_DIR, "sp_common.h"),
+                   os.path.join(os.path.dirname(PKG_DIR), "include", "stroke_amd.h")]
+    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    global _lib
+    _lib = None
+    return LIB_PATH

@@ -1,0 +1,245 @@
+"""Thin Python drivers over the C ABI: torch owns device memory and the stream; every op below
+enqueues hand-written gfx950 kernels through ``libstroke_amd.so`` (no torch compute kernels)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import plan as P
+
+TORCH_DT = {L.SP_BF16: torch.bfloat16, L.SP_F32: torch.float32}
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("stroke_prediction_amd needs an AMD GPU (gfx950): the hot path has no CPU fallback")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def cpad(c, m=8):
+    return -(-c // m) * m
+
+
+def alloc_cl(batch, dims, cp, dtype, device, zero=False):
+    fn = torch.zeros if zero else torch.empty
+    return fn((batch,) + tuple(dims) + (cp,), dtype=TORCH_DT[dtype], device=device)
+
+
+def _dev_i32(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+
+
+class ConvRunner:
+    """One planned convolution-like op (see ``plan.ConvOp``) bound to device tables and weight fragments."""
+
+    def __init__(self, op: P.ConvOp, device):
+        self.op = op
+        self.device = device
+        self.subs = []
+        for sub in op.subs:
+            t = sub.tile
+            nsteps = t["ngroups"] * t["steps_per_group"]
+            frag_elems = nsteps * op.nttot * 64 * 8
+            hi = torch.empty(frag_elems, dtype=torch.bfloat16, device=device)
+            lo = torch.empty(frag_elems, dtype=torch.bfloat16, device=device) if op.dtype == L.SP_F32 else None
+            self.subs.append(dict(sub=sub, kmap=_dev_i32(sub.kmap, device), ktab=_dev_i32(sub.ktab, device),
+                                  hi=hi, lo=lo, nsteps=nsteps))
+        self.bias = torch.zeros(op.nttot * 16, dtype=torch.float32, device=device)
+        self.has_bias = False
+
+    def prep(self, w, b=None):
+        """Re-pack the current fp32 weights (any layout described by the plan's strides) and bias."""
+        op = self.op
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        for s in self.subs:
+            L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s["kmap"]), s["nsteps"],
+                   op.nttot, ptr(s["hi"]), ptr(s["lo"]), stream())
+        if b is not None:
+            self.bias[:op.cout].copy_(b.detach())
+            self.has_bias = True
+
+    def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
+            dtype_out=None, use_bias=True):
+        op = self.op
+        dtype_out = op.dtype if dtype_out is None else dtype_out
+        assert x.dtype == TORCH_DT[op.dtype] and y.dtype == TORCH_DT[dtype_out]
+        assert tuple(x.shape) == (batch,) + tuple(op.in_dims) + (op.cpi,), (tuple(x.shape), op.in_dims, op.cpi)
+        assert tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
+        a = L.ConvArgs()
+        a.x, a.y = ptr(x), ptr(y)
+        a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
+        a.bias = ptr(self.bias) if (self.has_bias and use_bias) else None
+        a.stats = ptr(stats)
+        a.dtype_in, a.dtype_out = op.dtype, dtype_out
+        a.B = batch
+        a.Di, a.Hi, a.Wi = op.in_dims
+        a.CPi = op.cpi
+        a.YD, a.YH, a.YW = op.y_dims
+        a.CPo = y.shape[4]
+        a.Cout = op.cout
+        a.sD, a.sH, a.sW = op.stride
+        a.NT, a.NTtot = op.nt, op.nttot
+        a.act, a.act_param = act, act_param
+        st = stream()
+        for s in self.subs:
+            sub = s["sub"]
+            t = sub.tile
+            a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(s["hi"]), ptr(s["lo"]), ptr(s["ktab"])
+            a.Do, a.Ho, a.Wo = sub.out_dims
+            a.osD, a.osH, a.osW = sub.out_stride
+            a.ooD, a.ooH, a.ooW = sub.out_off
+            a.o0D, a.o0H, a.o0W = sub.o0
+            for k in ("TD", "TH", "ITD", "ITH", "ITW", "MT", "ngroups", "octs_per_group", "opp", "vsb",
+                      "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes"):
+                setattr(a, k, t[k])
+            L.call("sp_conv3d_igemm", C.byref(a), st)
+
+
+class WgradRunner:
+    """Weight gradient of a convolution (or, with swapped roles, a transposed convolution)."""
+
+    def __init__(self, cin, cout, k, stride, pad, in_dims, out_dims, cpi, cpo, w_sco, w_sci, dtype, device,
+                 nblocks=512):
+        k, s, p = P._triple(k), P._triple(stride), P._triple(pad)
+        self.cin, self.cout, self.k = cin, cout, k
+        self.w_sco, self.w_sci = w_sco, w_sci
+        taps = [(a, b, c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])]
+        self.ntap = len(taps)
+        self.taps = _dev_i32(np.array(taps), device)
+        self.tapsrc = _dev_i32(np.arange(self.ntap), device)
+        self.cot, self.cit = -(-cpo // 16), -(-cpi // 16)
+        self.acc = torch.zeros(self.ntap * self.cot * 16 * self.cit * 16, dtype=torch.float32, device=device)
+        a = L.WgradArgs()
+        a.dtype = dtype
+        a.Di, a.Hi, a.Wi = in_dims
+        a.Do, a.Ho, a.Wo = out_dims
+        a.CPi, a.CPo = cpi, cpo
+        a.sD, a.sH, a.sW = s
+        a.o0D, a.o0H, a.o0W = (-p[0], -p[1], -p[2])
+        a.ntap = self.ntap
+        a.kD, a.kH, a.kW = k
+        a.CoT, a.CiT = self.cot, self.cit
+        a.nblocks = nblocks
+        self.args = a
+        self.dtype = dtype
+
+    def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None):
+        """dw (fp32, the parameter's own layout) += gradient."""
+        a = self.args
+        assert x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
+        assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi), (tuple(x.shape), (batch, a.Di, a.Hi, a.Wi, a.CPi))
+        assert tuple(dz.shape) == (batch, a.Do, a.Ho, a.Wo, a.CPo), (tuple(dz.shape), (batch, a.Do, a.Ho, a.Wo, a.CPo))
+        self.acc.zero_()
+        a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
+        a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
+        a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
+        a.B = batch
+        st = stream()
+        L.call("sp_conv3d_wgrad", C.byref(a), st)
+        L.call("sp_wgrad_finish", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
+               self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), st)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise drivers
+
+def ncdhw_to_cl(src, dst, dtype):
+    B, Cc = src.shape[:2]
+    dhw = int(np.prod(src.shape[2:]))
+    L.call("sp_ncdhw_to_cl", ptr(src), ptr(dst), dtype, B, Cc, dhw, dst.shape[-1], stream())
+
+
+def cl_to_ncdhw(src, dst, dtype):
+    B, Cc = dst.shape[:2]
+    dhw = int(np.prod(dst.shape[2:]))
+    L.call("sp_cl_to_ncdhw", ptr(src), ptr(dst), dtype, B, Cc, dhw, src.shape[-1], stream())
+
+
+def bn_stats(x, dtype, sums):
+    nvox = x.numel() // x.shape[-1]
+    L.call("sp_bn_stats", ptr(x), dtype, nvox, x.shape[-1], ptr(sums), stream())
+
+
+def bn_finalize(sums, count, gamma, beta, rmean, rvar, momentum, eps, training, c, cp, scale, shift, mean, invstd):
+    L.call("sp_bn_finalize", ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+           int(training), c, cp, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream())
+
+
+def bn_bwd_reduce(g, x, dtype, sums):
+    nvox = x.numel() // x.shape[-1]
+    L.call("sp_bn_bwd_reduce", ptr(g), ptr(x), dtype, nvox, x.shape[-1], ptr(sums), stream())
+
+
+def bn_bwd_finalize(sums, count, gamma, mean, invstd, c, cp, dgamma, dbeta, coef):
+    L.call("sp_bn_bwd_finalize", ptr(sums), float(count), ptr(gamma), ptr(mean), ptr(invstd), c, cp, ptr(dgamma),
+           ptr(dbeta), ptr(coef), stream())
+
+
+def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias):
+    nvox = y.numel() // y.shape[-1]
+    L.call("sp_bn_act_bwd", ptr(g), ptr(y), ptr(coef), dtype, nvox, y.shape[-1], act, act_param, ptr(dz),
+           ptr(dbias), stream())
+
+
+def maxpool2_fwd(x, y, dtype, stats=None):
+    B, D, H, W, CP = x.shape
+    L.call("sp_maxpool2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, ptr(stats), stream())
+
+
+def upsample2_fwd(x, y, dtype, stats=None):
+    B, D, H, W, CP = x.shape
+    L.call("sp_upsample2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, y.shape[-1], ptr(stats), stream())
+
+
+def crop_copy(src, dst, c0, dtype, stats=None):
+    B, Ds, Hs, Ws, CPs = src.shape
+    _, Dd, Hd, Wd, CPd = dst.shape
+    L.call("sp_crop_copy", ptr(src), ptr(dst), dtype, B, Ds, Hs, Ws, CPs, Dd, Hd, Wd, CPd, c0, ptr(stats), stream())
+
+
+def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias):
+    B, D, H, W, CP = y.shape
+    if cat is not None:
+        _, Dc, Hc, Wc, CPcat = cat.shape
+    else:
+        Dc = Hc = Wc = CPcat = 0
+    L.call("sp_pool_skip_act_bwd", ptr(y), ptr(gp), ptr(coefp), ptr(cat), ptr(gs), ptr(coefs), cs0, CPcat, dtype,
+           B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), stream())
+
+
+def upsample2_act_bwd(y, cat, g, coef, dtype, act, act_param, dz, dbias):
+    B, D, H, W, CP = y.shape
+    L.call("sp_upsample2_act_bwd", ptr(y), ptr(cat), ptr(g), ptr(coef), cat.shape[-1], dtype, B, D, H, W, CP, act,
+           act_param, ptr(dz), ptr(dbias), stream())
+
+
+def out_grad_to_cl(dout, out, dtype, act, act_param, dz, dbias):
+    B, Cc = out.shape[:2]
+    dhw = int(np.prod(out.shape[2:]))
+    L.call("sp_out_grad_to_cl", ptr(dout), ptr(out), B, Cc, dhw, dz.shape[-1], dtype, act, act_param, ptr(dz),
+           ptr(dbias), stream())
+
+
+def add_f64_to_f32(src, dst, n, scale=1.0):
+    L.call("sp_add_f64_to_f32", ptr(src), ptr(dst), n, scale, stream())
+
+
+def lerp_batch(c, p, step, out, dtype):
+    B = c.shape[0]
+    L.call("sp_lerp_batch", ptr(c), ptr(p), ptr(step), ptr(out), dtype, B, c.numel() // B, stream())
+
+
+def axpby(x, y, out, dtype, a, b):
+    L.call("sp_axpby", ptr(x), ptr(y), ptr(out), dtype, x.numel(), a, b, stream())
+
+
+def adam_step_flat(p, g, m, v, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    L.call("sp_adam_step_flat", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, wd, step,
+           grad_scale, stream())

@@ -1,0 +1,302 @@
+"""Kernel-level parity: each C-ABI entry point against plain torch (CPU, fp32/fp64) on the same
+seeded inputs.  SP_F32 (split-bf16 x3 MFMA) is held to ~1e-4; SP_BF16 to bf16 rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from stroke_prediction_amd.runtime import lib as L
+from stroke_prediction_amd.runtime import ops as O
+from stroke_prediction_amd.runtime import plan as P
+
+DEV = "cuda:0"
+TOL = {L.SP_F32: dict(rtol=2e-4, atol=2e-4), L.SP_BF16: dict(rtol=3e-2, atol=3e-2)}
+
+
+def to_cl(x, cp, dtype):
+    """NCDHW fp32 (cpu) -> channels-last device tensor via the HIP kernel."""
+    B, Cc = x.shape[:2]
+    dst = O.alloc_cl(B, x.shape[2:], cp, dtype, DEV)
+    O.ncdhw_to_cl(x.contiguous().to(DEV), dst, dtype)
+    return dst
+
+
+def from_cl(t, c, dtype):
+    B = t.shape[0]
+    out = torch.empty((B, c) + tuple(t.shape[1:4]), dtype=torch.float32, device=DEV)
+    O.cl_to_ncdhw(t, out, dtype)
+    return out.cpu()
+
+
+def rnd(dtype, x):
+    """round test inputs to what the storage dtype can hold, so both sides see the same numbers"""
+    return x.bfloat16().float() if dtype == L.SP_BF16 else x
+
+
+def test_layout_roundtrip():
+    x = torch.randn(2, 3, 5, 6, 7)
+    for dt in (L.SP_F32, L.SP_BF16):
+        y = from_cl(to_cl(x, 8, dt), 3, dt)
+        torch.testing.assert_close(y, rnd(dt, x), rtol=0, atol=0)
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, dims, batch
+    (2, 16, 3, 1, (0, 0, 0), (12, 13, 37), 2),
+    (16, 16, 3, 1, (0, 0, 0), (14, 20, 40), 2),
+    (16, 32, 3, 1, (0, 0, 0), (9, 11, 21), 1),
+    (32, 64, 3, 1, (0, 0, 0), (8, 9, 19), 1),
+    (96, 32, 3, 1, (0, 0, 0), (7, 10, 18), 1),
+    (48, 16, 3, 1, (0, 0, 0), (7, 12, 35), 1),
+    (16, 16, 3, 1, (1, 0, 0), (5, 12, 36), 2),
+    (16, 24, 3, 2, (1, 1, 1), (8, 22, 38), 2),
+    (32, 100, 3, 2, (0, 0, 0), (7, 25, 25), 1),
+    (32, 24, 3, 1, (1, 2, 2), (4, 9, 17), 1),
+    (16, 32, 1, 1, (0, 0, 0), (6, 7, 33), 2),
+    (32, 2, 1, 1, (0, 0, 0), (6, 7, 33), 2),
+]
+
+
+@pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
+@pytest.mark.parametrize("cin,cout,k,s,p,dims,B", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(dtype, cin, cout, k, s, p, dims, B):
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    x = rnd(dtype, torch.randn(B, cin, *dims, generator=g))
+    w = torch.randn(cout, cin, k, k, k, generator=g) / np.sqrt(cin * k ** 3)
+    b = torch.randn(cout, generator=g) * 0.1
+    scale = torch.rand(cin, generator=g) + 0.5
+    shift = torch.randn(cin, generator=g) * 0.2
+    cpi, cpo = O.cpad(cin), O.cpad(cout)
+    wq = rnd(dtype, w)   # the bf16 path rounds weights to bf16 inside prep; compare against that
+    xr = (x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)).requires_grad_(True)
+    if dtype == L.SP_BF16:
+        xr_q = rnd(dtype, xr.detach()).requires_grad_(True)   # kernel rounds the normalised input to bf16
+    else:
+        xr_q = xr
+    wr = wq.clone().requires_grad_(True)
+    zref = F.conv3d(xr_q, wr, b, stride=s, padding=p)
+    yref = F.leaky_relu(zref, 0.01)
+
+    op = P.conv_fwd_op(cin, cout, k, s, p, dims, cpi, cpo, dtype)
+    run = O.ConvRunner(op, DEV)
+    run.prep(w.to(DEV), b.to(DEV))
+    xs = to_cl(x, cpi, dtype)
+    sc = torch.zeros(cpi, device=DEV); sc[:cin] = scale.to(DEV)
+    sh = torch.zeros(cpi, device=DEV); sh[:cin] = shift.to(DEV)
+    y = O.alloc_cl(B, op.y_dims, cpo, dtype, DEV)
+    stats = torch.zeros(cpo, 2, dtype=torch.float64, device=DEV)
+    run.run(xs, y, B, sc, sh, L.ACT_LEAKY, 0.01, stats)
+    got = from_cl(y, cout, dtype)
+    torch.testing.assert_close(got, yref.detach(), **TOL[dtype])
+    # fused statistics describe what was stored
+    st = stats.cpu()
+    torch.testing.assert_close(st[:cout, 0], got.double().sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(st[:cout, 1], (got.double() ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    if cpo > cout:
+        assert float(y[..., cout:].float().abs().max()) == 0.0
+
+    # ---- data gradient
+    dz = rnd(dtype, torch.randn(zref.shape, generator=g))
+    gx_ref, gw_ref = torch.autograd.grad(zref, (xr_q, wr), dz)
+    dop = P.conv_dgrad_op(cin, cout, k, s, p, dims, cpo, cpi, dtype)
+    drun = O.ConvRunner(dop, DEV)
+    drun.prep(w.to(DEV))
+    dzs = to_cl(dz, cpo, dtype)
+    gbuf = O.alloc_cl(B, dims, cpi, dtype, DEV, zero=True)
+    drun.run(dzs, gbuf, B)
+    torch.testing.assert_close(from_cl(gbuf, cin, dtype), gx_ref, **TOL[dtype])
+
+    # ---- weight gradient (BatchNorm applied on load)
+    wg = O.WgradRunner(cin, cout, k, s, p, dims, op.y_dims, cpi, cpo, cin * k ** 3, k ** 3, dtype, DEV)
+    dw = torch.zeros_like(w, device=DEV)
+    wg.run(xs, dzs, B, dw, sc, sh)
+    scale_w = float(gw_ref.abs().max())
+    torch.testing.assert_close(dw.cpu(), gw_ref, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * max(1.0, scale_w))
+
+
+CONVT_CASES = [
+    (800, 100, 3, 1, 0, (1, 10, 10), 2),
+    (104, 32, 3, 2, 0, (3, 12, 12), 2),
+    (24, 24, 2, 2, 0, (7, 29, 29), 1),
+    (16, 16, 2, 2, 0, (6, 20, 22), 2),
+]
+
+
+@pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
+@pytest.mark.parametrize("cin,cout,k,s,p,dims,B", CONVT_CASES)
+def test_convT_fwd_dgrad_wgrad(dtype, cin, cout, k, s, p, dims, B):
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = rnd(dtype, torch.randn(B, cin, *dims, generator=g))
+    w = torch.randn(cin, cout, k, k, k, generator=g) / np.sqrt(cin * k ** 3 / s ** 3)
+    b = torch.randn(cout, generator=g) * 0.1
+    cpi, cpo = O.cpad(cin), O.cpad(cout)
+    xr = x.clone().requires_grad_(True)
+    wr = rnd(dtype, w).requires_grad_(True)
+    zref = F.conv_transpose3d(xr, wr, b, stride=s, padding=p)
+    yref = F.elu(zref, 1.0)
+    op = P.convT_fwd_op(cin, cout, k, s, p, dims, cpi, cpo, dtype)
+    run = O.ConvRunner(op, DEV)
+    run.prep(w.to(DEV), b.to(DEV))
+    xs = to_cl(x, cpi, dtype)
+    y = O.alloc_cl(B, op.y_dims, cpo, dtype, DEV)
+    run.run(xs, y, B, None, None, L.ACT_ELU, 1.0, None)
+    torch.testing.assert_close(from_cl(y, cout, dtype), yref.detach(), **TOL[dtype])
+    dz = rnd(dtype, torch.randn(zref.shape, generator=g))
+    gx_ref, gw_ref = torch.autograd.grad(zref, (xr, wr), dz)
+    dop = P.convT_dgrad_op(cin, cout, k, s, p, dims, cpo, cpi, dtype)
+    drun = O.ConvRunner(dop, DEV)
+    drun.prep(w.to(DEV))
+    dzs = to_cl(dz, cpo, dtype)
+    gbuf = O.alloc_cl(B, dims, cpi, dtype, DEV, zero=True)
+    drun.run(dzs, gbuf, B)
+    torch.testing.assert_close(from_cl(gbuf, cin, dtype), gx_ref, **TOL[dtype])
+    # weight gradient with swapped roles: shifted operand = dz (convT output grid), fixed operand = x
+    kk = k ** 3
+    wg = O.WgradRunner(cout, cin, k, s, p, op.y_dims, dims, cpo, cpi, cout * kk, kk, dtype, DEV)
+    dw = torch.zeros_like(w, device=DEV)
+    wg.run(dzs, xs, B, dw)
+    scale_w = float(gw_ref.abs().max())
+    torch.testing.assert_close(dw.cpu(), gw_ref, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * max(1.0, scale_w))
+
+
+@pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
+def test_bn_pieces(dtype):
+    g = torch.Generator().manual_seed(5)
+    B, Cc, dims = 2, 24, (5, 6, 17)
+    x = rnd(dtype, torch.randn(B, Cc, *dims, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g) * 0.1
+    rm, rv = torch.randn(Cc, generator=g) * 0.1, torch.rand(Cc, generator=g) + 0.5
+    cp = O.cpad(Cc)
+    xs = to_cl(x, cp, dtype)
+    sums = torch.zeros(cp, 2, dtype=torch.float64, device=DEV)
+    O.bn_stats(xs, dtype, sums)
+    n = B * int(np.prod(dims))
+    scale, shift, mean, invstd = (torch.empty(cp, device=DEV) for _ in range(4))
+    rm_d, rv_d = rm.clone().to(DEV), rv.clone().to(DEV)
+    O.bn_finalize(sums, n, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, 0.1, 1e-5, True, Cc, cp, scale, shift, mean, invstd)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yref = F.batch_norm(xr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    y = x * scale[:Cc].cpu().view(1, -1, 1, 1, 1) + shift[:Cc].cpu().view(1, -1, 1, 1, 1)
+    torch.testing.assert_close(y, yref.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(rm_d.cpu(), rm_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv_d.cpu(), rv_ref, rtol=1e-5, atol=1e-6)
+    # backward: dx = coef0*g + coef1*x + coef2 ; then * act'(x) as the previous layer's dz
+    gy = rnd(dtype, torch.randn(x.shape, generator=g))
+    gx_ref, gg_ref, gb_ref = torch.autograd.grad(yref, (xr, gr, br), gy)
+    gs = to_cl(gy, cp, dtype)
+    bsums = torch.zeros(cp, 2, dtype=torch.float64, device=DEV)
+    O.bn_bwd_reduce(gs, xs, dtype, bsums)
+    dgam, dbet = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    coef = torch.empty(3, cp, device=DEV)
+    O.bn_bwd_finalize(bsums, n, gamma.to(DEV), mean, invstd, Cc, cp, dgam, dbet, coef)
+    torch.testing.assert_close(dgam.cpu(), gg_ref, rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(dbet.cpu(), gb_ref, rtol=1e-3, atol=1e-2)
+    dz = O.alloc_cl(B, dims, cp, dtype, DEV)
+    dbias = torch.zeros(cp, dtype=torch.float64, device=DEV)
+    O.bn_act_bwd(gs, xs, coef, dtype, L.ACT_ELU, 1.0, dz, dbias)
+    elu_d = torch.where(x > 0, torch.ones_like(x), x + 1.0)
+    ref = gx_ref * elu_d
+    got = from_cl(dz, Cc, dtype)
+    torch.testing.assert_close(got, ref, **TOL[dtype])
+    torch.testing.assert_close(dbias[:Cc].cpu().float(), got.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
+def test_pool_upsample_crop_fwd_bwd(dtype):
+    """The U-Net wiring kernels against autograd on the same small graph (Unet3D.py:59-72)."""
+    g = torch.Generator().manual_seed(9)
+    B, C1, dims = 2, 16, (12, 10, 14)          # block output y (post-LeakyReLU)
+    ypre = rnd(dtype, torch.randn(B, C1, *dims, generator=g))
+    ypre = torch.where(ypre > 0, ypre, 0.01 * ypre)
+    ypre = rnd(dtype, ypre)
+    y = ypre.clone().requires_grad_(True)
+    ys = to_cl(ypre, C1, dtype)
+    # forward: pool
+    p_ref = F.max_pool3d(y, 2, 2)
+    ps = O.alloc_cl(B, p_ref.shape[2:], C1, dtype, DEV)
+    st = torch.zeros(C1, 2, dtype=torch.float64, device=DEV)
+    O.maxpool2_fwd(ys, ps, dtype, st)
+    torch.testing.assert_close(from_cl(ps, C1, dtype), p_ref.detach(), rtol=0, atol=0)
+    torch.testing.assert_close(st[:, 0].cpu(), p_ref.detach().double().sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-4)
+    # forward: low-res tensor upsampled into a concat buffer next to the cropped skip
+    C0, ldims = 8, (4, 3, 5)
+    low = rnd(dtype, torch.randn(B, C0, *ldims, generator=g))
+    lowr = low.clone().requires_grad_(True)
+    up_ref = F.interpolate(lowr, scale_factor=2, mode="trilinear", align_corners=False)
+    cdims = tuple(up_ref.shape[2:])            # (8, 6, 10) <= dims
+    off = [(dims[a] - cdims[a]) // 2 for a in range(3)]
+    crop_ref = y[:, :, off[0]:off[0] + cdims[0], off[1]:off[1] + cdims[1], off[2]:off[2] + cdims[2]]
+    cat_ref = torch.cat((up_ref, crop_ref), 1)
+    cat = O.alloc_cl(B, cdims, C0 + C1, dtype, DEV)
+    lows = to_cl(low, C0, dtype)
+    O.upsample2_fwd(lows, cat, dtype)
+    O.crop_copy(ys, cat, C0, dtype)
+    torch.testing.assert_close(from_cl(cat, C0 + C1, dtype), cat_ref.detach(), **TOL[dtype])
+    # backward: arbitrary affine "BN backward" forms on both consumers
+    cp_cat = C0 + C1
+    coefs = torch.randn(3, cp_cat, generator=g) * 0.5
+    coefp = torch.randn(3, C1, generator=g) * 0.5
+    g_cat = rnd(dtype, torch.randn(cat_ref.shape, generator=g))
+    g_p = rnd(dtype, torch.randn(p_ref.shape, generator=g))
+    v = lambda t: t.view(1, -1, 1, 1, 1)
+    catq = rnd(dtype, cat_ref.detach())
+    d_cat = v(coefs[0]) * g_cat + v(coefs[1]) * catq + v(coefs[2])
+    d_p = v(coefp[0]) * g_p + v(coefp[1]) * p_ref.detach() + v(coefp[2])
+    gy_ref, glow_ref = torch.autograd.grad([cat_ref, p_ref], (y, lowr), [d_cat, d_p])
+    lrelu_d = torch.where(ypre > 0, torch.ones_like(ypre), torch.full_like(ypre, 0.01))
+    dz = O.alloc_cl(B, dims, C1, dtype, DEV)
+    dbias = torch.zeros(C1, dtype=torch.float64, device=DEV)
+    gcs, gps = to_cl(g_cat, cp_cat, dtype), to_cl(g_p, C1, dtype)
+    O.pool_skip_act_bwd(ys, gps, coefp.to(DEV), cat, gcs, coefs.to(DEV), C0, dtype, L.ACT_LEAKY, 0.01, dz, dbias)
+    got = from_cl(dz, C1, dtype)
+    torch.testing.assert_close(got, gy_ref * lrelu_d, **TOL[dtype])
+    torch.testing.assert_close(dbias.cpu().float(), got.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
+    # upsample backward lands on the low-res producer (here with ELU as its activation)
+    dzl = O.alloc_cl(B, ldims, C0, dtype, DEV)
+    O.upsample2_act_bwd(lows, cat, gcs, coefs.to(DEV), dtype, L.ACT_ELU, 1.0, dzl, None)
+    elu_d = torch.where(low > 0, torch.ones_like(low), low + 1.0)
+    torch.testing.assert_close(from_cl(dzl, C0, dtype), glow_ref * elu_d, **TOL[dtype])
+
+
+def test_dice_and_output_grad():
+    from stroke_prediction_amd.runtime import lib
+    g = torch.Generator().manual_seed(3)
+    B, Cc, dims = 2, 2, (6, 7, 9)
+    o = torch.rand(B, Cc, *dims, generator=g)
+    t = (torch.rand(B, Cc, *dims, generator=g) > 0.7).float()
+    sums = torch.zeros(Cc, 3, dtype=torch.float64, device=DEV)
+    od, td = o.to(DEV), t.to(DEV)
+    lib.call("sp_dice_sums", O.ptr(od), O.ptr(td), B, Cc, int(np.prod(dims)), O.ptr(sums), O.stream())
+    ref = torch.stack([(o * t).sum(dim=(0, 2, 3, 4)), (o * o).sum(dim=(0, 2, 3, 4)), (t * t).sum(dim=(0, 2, 3, 4))], 1)
+    torch.testing.assert_close(sums.cpu().float(), ref, rtol=1e-5, atol=1e-4)
+    ca, cb = torch.randn(Cc), torch.randn(Cc)
+    d = torch.empty_like(od)
+    lib.call("sp_dice_bwd", O.ptr(od), O.ptr(td), O.ptr(ca.to(DEV)), O.ptr(cb.to(DEV)), B, Cc, int(np.prod(dims)),
+             O.ptr(d), O.stream())
+    torch.testing.assert_close(d.cpu(), ca.view(1, -1, 1, 1, 1) * t + cb.view(1, -1, 1, 1, 1) * o, rtol=1e-6, atol=1e-6)
+    dz = O.alloc_cl(B, dims, 8, L.SP_F32, DEV)
+    dbias = torch.zeros(8, dtype=torch.float64, device=DEV)
+    O.out_grad_to_cl(d, od, L.SP_F32, L.ACT_SIGMOID, 0.0, dz, dbias)
+    ref = d.cpu() * o * (1 - o)
+    torch.testing.assert_close(from_cl(dz, Cc, L.SP_F32), ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dbias[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4)
+
+
+def test_adam_matches_torch():
+    g = torch.Generator().manual_seed(4)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    p = p0.clone().to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 5):
+        gr = torch.randn(n, generator=g)
+        ref.grad = gr.clone()
+        opt.step()
+        O.adam_step_flat(p, gr.to(DEV), m, v, 1e-3, 0.99, 0.999, 1e-8, 1e-5, step)
+    torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)

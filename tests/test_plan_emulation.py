@@ -1,0 +1,134 @@
+"""Replay the conv planner's K tables (kmap / ktab) on the CPU and compare with
+torch.nn.functional: validates taps, padding, stride, parity classes of transposed
+convolutions, channel grouping and the weight-stride conventions without a GPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stroke_prediction_amd.runtime import plan as P
+
+
+def emulate(op, x_cl, w_flat, batch):
+    """x_cl: (B, D, H, W, CPi) float64; w_flat: 1-D weight storage. Returns y (B, *y_dims, CPo)."""
+    B = batch
+    y = torch.zeros((B,) + tuple(op.y_dims) + (op.cpo,), dtype=torch.float64)
+    Di, Hi, Wi = op.in_dims
+    xp = x_cl
+    for sub in op.subs:
+        t = sub.tile
+        steps, opg, opp = t["steps_per_group"], t["octs_per_group"], t["opp"]
+        qd, qh, qw = sub.out_dims
+        acc = torch.zeros((B, qd, qh, qw, op.cout), dtype=torch.float64)
+        qz, qy, qx = torch.meshgrid(torch.arange(qd), torch.arange(qh), torch.arange(qw), indexing="ij")
+        for g in range(t["ngroups"]):
+            for i in range(steps * 4):
+                km = int(sub.kmap[g * steps * 4 + i])
+                if km < 0:
+                    continue
+                src, oct_g = km >> 16, km & 0xffff
+                off = int(sub.ktab[i])
+                plane, rem = divmod(off, t["plane_bytes"])
+                vox, r2 = divmod(rem, t["vsb"])
+                po = r2 // 16
+                assert r2 % 16 == 0 and po < opp
+                assert oct_g == g * opg + plane * opp + po, "kmap/ktab disagree on the channel octet"
+                vz, r3 = divmod(vox, t["ITH"] * t["ITW"])
+                vy, vx = divmod(r3, t["ITW"])
+                iz = qz * op.stride[0] + sub.o0[0] + vz
+                iy = qy * op.stride[1] + sub.o0[1] + vy
+                ix = qx * op.stride[2] + sub.o0[2] + vx
+                ok = (iz >= 0) & (iz < Di) & (iy >= 0) & (iy < Hi) & (ix >= 0) & (ix < Wi)
+                xv = xp[:, iz.clamp(0, Di - 1), iy.clamp(0, Hi - 1), ix.clamp(0, Wi - 1), oct_g * 8:oct_g * 8 + 8]
+                xv = xv * ok[None, ..., None]
+                for j in range(8):
+                    ci = oct_g * 8 + j
+                    if ci >= op.cin:
+                        continue
+                    wv = torch.tensor([w_flat[co * op.w_sco + ci * op.w_sci + src] for co in range(op.cout)],
+                                      dtype=torch.float64)
+                    acc += xv[..., j:j + 1] * wv
+        oz = qz * sub.out_stride[0] + sub.out_off[0]
+        oy = qy * sub.out_stride[1] + sub.out_off[1]
+        ox = qx * sub.out_stride[2] + sub.out_off[2]
+        y[:, oz, oy, ox, :op.cout] = acc
+    return y
+
+
+def to_cl(x, cp):
+    B, C = x.shape[:2]
+    out = torch.zeros((B,) + tuple(x.shape[2:]) + (cp,), dtype=torch.float64)
+    out[..., :C] = x.permute(0, 2, 3, 4, 1).double()
+    return out
+
+
+def from_cl(y, c):
+    return y[..., :c].permute(0, 4, 1, 2, 3)
+
+
+CONV_CASES = [
+    (2, 16, 3, 1, (0, 0, 0), (6, 7, 19)),     # Unet3D.py:19 first layer
+    (16, 16, 3, 1, (1, 0, 0), (5, 6, 20)),    # Cae3D.py:44
+    (16, 24, 3, 2, (1, 1, 1), (6, 9, 21)),    # Cae3D.py:48
+    (24, 32, 3, 2, (0, 0, 0), (7, 9, 19)),    # Cae3D.py:70 style
+    (32, 24, 3, 1, (1, 2, 2), (4, 5, 17)),    # Cae3D.py:189
+    (16, 5, 1, 1, (0, 0, 0), (3, 4, 18)),     # 1x1x1 head
+    (40, 16, 3, 1, (0, 0, 0), (5, 5, 18)),    # multi-group-ish
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,dims", CONV_CASES)
+def test_conv_fwd_and_dgrad_tables(cin, cout, k, s, p, dims):
+    torch.manual_seed(0)
+    x = torch.randn(1, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, k, k, k, dtype=torch.float64)
+    ref = F.conv3d(x, w, None, stride=s, padding=p)
+    cpi, cpo = -(-cin // 8) * 8, -(-cout // 8) * 8
+    op = P.conv_fwd_op(cin, cout, k, s, p, dims, cpi, cpo)
+    y = emulate(op, to_cl(x.detach(), cpi), w.reshape(-1).tolist(), 1)
+    assert tuple(op.y_dims) == tuple(ref.shape[2:])
+    torch.testing.assert_close(from_cl(y, cout), ref.detach(), rtol=1e-10, atol=1e-10)
+    # data gradient
+    dz = torch.randn_like(ref)
+    (gref,) = torch.autograd.grad(ref, x, dz)
+    dop = P.conv_dgrad_op(cin, cout, k, s, p, dims, cpo, cpi)
+    g = emulate(dop, to_cl(dz, cpo), w.reshape(-1).tolist(), 1)
+    torch.testing.assert_close(from_cl(g, cin), gref, rtol=1e-10, atol=1e-10)
+
+
+CONVT_CASES = [
+    (24, 16, 3, 1, 0, (1, 4, 17)),   # Cae3D.py:178 style
+    (16, 8, 3, 2, 0, (3, 5, 17)),    # Cae3D.py:182
+    (8, 8, 2, 2, 0, (4, 5, 16)),     # Cae3D.py:193,204
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,dims", CONVT_CASES)
+def test_convT_fwd_and_dgrad_tables(cin, cout, k, s, p, dims):
+    torch.manual_seed(1)
+    x = torch.randn(1, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cin, cout, k, k, k, dtype=torch.float64)
+    ref = F.conv_transpose3d(x, w, None, stride=s, padding=p)
+    cpi, cpo = -(-cin // 8) * 8, -(-cout // 8) * 8
+    op = P.convT_fwd_op(cin, cout, k, s, p, dims, cpi, cpo)
+    assert tuple(op.y_dims) == tuple(ref.shape[2:])
+    y = emulate(op, to_cl(x.detach(), cpi), w.reshape(-1).tolist(), 1)
+    torch.testing.assert_close(from_cl(y, cout), ref.detach(), rtol=1e-10, atol=1e-10)
+    dz = torch.randn_like(ref)
+    (gref,) = torch.autograd.grad(ref, x, dz)
+    dop = P.convT_dgrad_op(cin, cout, k, s, p, dims, cpo, cpi)
+    g = emulate(dop, to_cl(dz, cpo), w.reshape(-1).tolist(), 1)
+    torch.testing.assert_close(from_cl(g, cin), gref, rtol=1e-10, atol=1e-10)
+
+
+def test_tiles_fit_lds_for_all_reference_layers():
+    """Every conv of the two BASELINE networks gets a plan that fits 160 KiB of LDS."""
+    for dt in (0, 1):
+        for ci, co, d in [(2, 16, 128), (16, 16, 126), (16, 32, 62), (32, 32, 60), (32, 64, 29), (64, 64, 27),
+                          (96, 32, 50), (32, 32, 48), (48, 16, 92), (16, 16, 90)]:
+            cpi = -(-ci // 8) * 8
+            op = P.conv_fwd_op(ci, co, 3, 1, 0, (d, d, d), cpi, co, dtype=dt)
+            assert op.subs[0].tile["lds_bytes"] <= 160 * 1024
+            assert op.subs[0].tile["read_cycles"] <= 4.5   # bank-conflict model: near conflict-free
+            dop = P.conv_dgrad_op(ci, co, 3, 1, 0, (d, d, d), co, cpi, dtype=dt)
+            assert dop.subs[0].tile["lds_bytes"] <= 160 * 1024
