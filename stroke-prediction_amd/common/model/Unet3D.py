@@ -1,0 +1,126 @@
+"""Drop-in ``Unet3D`` (reference ``common/model/Unet3D.py:30-84``) running on hand-written gfx950 kernels.
+
+Same constructor, ``forward(dto) -> dto``, ``freeze`` and ``state_dict`` keys
+(``block{1..5}.bn_conv_relu_2x.{0,1,3,4}.*``, ``classify.{0,2}.*``) as the reference, so weights
+interchange with it.  The ``torch.nn`` sub-modules below are parameter CONTAINERS only: the forward
+and backward passes are one ``torch.autograd.Function`` that drives ``runtime.unet_engine`` (MFMA
+implicit-GEMM convolutions with fused BatchNorm/bias/LeakyReLU, fused pool/upsample/skip kernels)
+through the C ABI.  There is no CPU path: calling it without the HIP library or a GPU raises.
+"""
+import torch
+import torch.nn as nn
+
+from common.dto.UnetDto import UnetDto
+from stroke_prediction_amd.runtime import lib as _L
+from stroke_prediction_amd.runtime.flat import FlatParamsMixin
+
+
+def crop(tensor_in, crop_as, dims=[]):
+    """Centre crop of ``tensor_in`` to ``crop_as`` along ``dims`` (reference Unet3D.py:6-11)."""
+    assert len(dims) > 0, "Specify dimensions to be cropped"
+    out = tensor_in
+    for d in dims:
+        n = crop_as.size(d)
+        out = out.narrow(d, (tensor_in.size(d) - n) // 2, n)
+    return out
+
+
+class Block3x3x3(nn.Module):
+    """Parameter container with the reference's key layout (Unet3D.py:14-27)."""
+
+    def __init__(self, n_input, n_channels):
+        super().__init__()
+        self.bn_conv_relu_2x = nn.ModuleDict({
+            "0": nn.BatchNorm3d(n_input),
+            "1": nn.Conv3d(n_input, n_channels, 3, stride=1, padding=0),
+            "3": nn.BatchNorm3d(n_channels),
+            "4": nn.Conv3d(n_channels, n_channels, 3, stride=1, padding=0),
+        })
+
+    def forward(self, *_):
+        raise RuntimeError("Block3x3x3 holds parameters only; Unet3D.forward runs the fused HIP path")
+
+
+class _UnetFn(torch.autograd.Function):
+    """Whole-network autograd node: forward and backward are sequences of HIP kernel launches."""
+
+    @staticmethod
+    def forward(ctx, model, images, *params):
+        engine = model._engine(images)
+        seg = engine.forward(images, model._param_dict(), model._buffer_dict(), model.training)
+        ctx.model, ctx.engine = model, engine
+        ctx.save_for_backward(seg)
+        return seg
+
+    @staticmethod
+    def backward(ctx, dseg):
+        model, engine = ctx.model, ctx.engine
+        (seg,) = ctx.saved_tensors
+        names, views, inplace = model._grad_targets()
+        engine.backward(dseg, seg, model._param_dict(), dict(zip(names, views)))
+        model._after_backward()
+        return (None, None) + tuple(None if inplace else v for v in views)
+
+
+class Unet3D(FlatParamsMixin, nn.Module):
+    def __init__(self, channels=[2, 32, 64, 128, 64, 32, 32, 2], channel_dim=1, channels_crop=[2, 3, 4],
+                 dtype="bf16"):
+        super().__init__()
+        n_ch_in, ch_b1, ch_b2, ch_b3, ch_b4, ch_b5, ch_bC, n_classes = channels
+        self.channels = list(channels)
+        self.channel_dim = channel_dim
+        self.channels_crop = channels_crop
+        self.compute_dtype = dtype           # "bf16" (fast) | "f32" (split-bf16 x3 MFMA, parity mode)
+
+        self.block1 = Block3x3x3(n_ch_in, ch_b1)
+        self.block2 = Block3x3x3(ch_b1, ch_b2)
+        self.block3 = Block3x3x3(ch_b2, ch_b3)
+        self.block4 = Block3x3x3(ch_b3 + ch_b2, ch_b4)
+        self.block5 = Block3x3x3(ch_b4 + ch_b1, ch_b5)
+        self.classify = nn.ModuleDict({
+            "0": nn.Conv3d(ch_b5, ch_bC, 1, stride=1, padding=0),
+            "2": nn.Conv3d(ch_bC, n_classes, 1, stride=1, padding=0),
+        })
+        self._engines = {}
+
+    # ------------------------------------------------------------------ engine cache
+    def _engine(self, images):
+        from stroke_prediction_amd.runtime.unet_engine import UnetEngine
+        if not images.is_cuda or not next(self.parameters()).is_cuda:
+            raise RuntimeError("Unet3D (stroke_prediction_amd) runs on the MI355X HIP path only: move the model "
+                               "and its inputs to the GPU (.cuda()); there is no CPU fallback")
+        self._ensure_flat()
+        dt = _L.SP_BF16 if self.compute_dtype == "bf16" else _L.SP_F32
+        key = (tuple(images.shape), dt, images.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            if len(self._engines) >= 4:
+                self._engines.clear()
+            eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device)
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, dto: UnetDto):
+        images = dto.given_variables.input_modalities
+        if images.dtype != torch.float32:
+            images = images.float()
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            segmentation = _UnetFn.apply(self, images, *params)
+        else:
+            segmentation = self._engine(images).forward(images, self._param_dict(), self._buffer_dict(), self.training)
+        dto.outputs.core = segmentation[:, 0, :, :, :].unsqueeze(1)
+        dto.outputs.penu = segmentation[:, 1, :, :, :].unsqueeze(1)
+        return dto
+
+    def freeze(self, freeze=False):
+        requires_grad = not freeze
+        for param in self.parameters():
+            param.requires_grad = requires_grad
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engines"] = {}          # engines hold device buffers and ctypes handles: rebuilt on demand
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device"):
+            state.pop(k, None)
+        return state

@@ -1,0 +1,77 @@
+"""Flat parameter / gradient storage for the drop-in models.
+
+All parameters of a model live in ONE contiguous fp32 buffer and their gradients in another
+(``Parameter.data`` / ``.grad`` are views).  That buffer pair is the operand of the fused Adam
+kernel (``sp_adam_step_flat``) and of the single RCCL all-reduce in data-parallel training
+(1.42 MB for the default U-Net, 18.9 MB for the CAE: SURVEY.md 5).
+"""
+import torch
+
+
+class FlatParamsMixin:
+    _flat_param = None
+    _flat_grad = None
+    _flat_views = None
+    _flat_names = None
+    _flat_device = None
+    grad_sync = None            # optional callable(flat_grad) -> None, installed by parallel.DataParallelSync
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flat_param = None       # .cuda()/.cpu()/.float() re-created the storages: re-flatten lazily
+        return out
+
+    def _ensure_flat(self):
+        named = list(self.named_parameters())
+        dev = named[0][1].device
+        if self._flat_param is not None and self._flat_device == dev and \
+                all(p.data_ptr() == v.data_ptr() for (_, p), v in zip(named, self._flat_pviews)):
+            return
+        total = sum(p.numel() for _, p in named)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off, pviews, gviews = 0, [], []
+        for _, p in named:
+            n = p.numel()
+            pv = flat[off:off + n].view(p.shape)
+            pv.copy_(p.data)
+            had_grad = p.grad is not None
+            p.data = pv
+            gv = gflat[off:off + n].view(p.shape)
+            if had_grad:
+                gv.copy_(p.grad)
+                p.grad = gv
+            pviews.append(pv)
+            gviews.append(gv)
+            off += n
+        self._flat_param, self._flat_grad = flat, gflat
+        self._flat_pviews, self._flat_views = pviews, gviews
+        self._flat_names = [n for n, _ in named]
+        self._flat_device = dev
+
+    def _param_dict(self):
+        self._ensure_flat()
+        return {n: p.data for n, p in self.named_parameters()}
+
+    def _buffer_dict(self):
+        return dict(self.named_buffers())
+
+    def _grad_targets(self):
+        """(names, gradient views, inplace).  inplace=True: every ``p.grad`` already IS its view of the flat
+        buffer -> kernels accumulate there and autograd gets ``None``; otherwise the flat buffer is zeroed,
+        filled, and its views are handed to autograd (which adopts them as ``p.grad``)."""
+        self._ensure_flat()
+        params = [p for _, p in self.named_parameters()]
+        inplace = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape
+                      for p, v in zip(params, self._flat_views))
+        if not inplace:
+            self._flat_grad.zero_()
+        return self._flat_names, self._flat_views, inplace
+
+    def _after_backward(self):
+        if self.grad_sync is not None:
+            self.grad_sync(self._flat_grad)
+
+    def flat_buffers(self):
+        self._ensure_flat()
+        return self._flat_param, self._flat_grad

@@ -1,0 +1,156 @@
+"""One fused network unit: [BatchNorm3d on load] -> Conv3d | ConvTranspose3d -> bias -> activation.
+
+This is the building block of both reference networks (``Block3x3x3`` Unet3D.py:14-27 and the
+BN-conv-ELU triples of Cae3D.py:39-76,176-220).  Forward is ONE kernel per sub-convolution
+(the BatchNorm is folded into the operand load, bias/activation/next-layer statistics into the
+epilogue); backward is wgrad + dgrad + one reduction, with the BatchNorm backward expressed as
+per-channel coefficients ``dx = c0*g + c1*x + c2`` that the consumer of ``g`` applies on load.
+"""
+import torch
+
+from . import lib as L
+from . import ops as O
+from . import plan as P
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class Scratch:
+    """A flat fp64 scratch arena for all per-step reduction accumulators: one memset per step."""
+
+    def __init__(self, device):
+        self.device = device
+        self.sizes = []
+        self.buf = None
+
+    def reserve(self, n):
+        self.sizes.append(n)
+        return len(self.sizes) - 1
+
+    def finalize(self):
+        self.offsets = [0]
+        for n in self.sizes:
+            self.offsets.append(self.offsets[-1] + n)
+        self.buf = torch.zeros(max(1, self.offsets[-1]), dtype=torch.float64, device=self.device)
+
+    def get(self, idx):
+        return self.buf[self.offsets[idx]:self.offsets[idx + 1]]
+
+    def zero(self):
+        self.buf.zero_()
+
+
+class ConvLayer:
+    def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
+                 bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
+                 need_input_grad=True):
+        self.name, self.kind = name, kind
+        self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
+        self.in_dims, self.batch, self.dtype, self.device = tuple(in_dims), batch, dtype, device
+        self.bn_prefix, self.conv_prefix = bn_prefix, conv_prefix
+        self.act, self.act_param = act, act_param
+        self.out_dtype = dtype if out_dtype is None else out_dtype
+        self.need_input_grad = need_input_grad
+        self.cpi, self.cpo = O.cpad(cin), O.cpad(cout)
+        mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
+        self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
+        self.out_dims = tuple(self.fwd_op.y_dims)
+        self.fwd = O.ConvRunner(self.fwd_op, device)
+        self.count = float(batch * in_dims[0] * in_dims[1] * in_dims[2])
+        self.scratch = scratch
+        if bn_prefix is not None:
+            self.scale = torch.zeros(self.cpi, device=device)
+            self.shift = torch.zeros(self.cpi, device=device)
+            self.mean = torch.zeros(self.cpi, device=device)
+            self.invstd = torch.zeros(self.cpi, device=device)
+            self.in_sums_id = scratch.reserve(self.cpi * 2)
+        else:
+            self.scale = self.shift = None
+        # backward side is created lazily (inference never pays for it)
+        self._bwd_ready = False
+        self.y = None
+
+    # ---------------------------------------------------------------- forward
+    @property
+    def in_sums(self):
+        return self.scratch.get(self.in_sums_id)
+
+    def alloc_out(self):
+        if self.y is None:
+            self.y = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.out_dtype, self.device)
+        return self.y
+
+    def forward(self, x, params, bufs, training, out_stats=None):
+        """x: channels-last input; returns the (cached) output tensor."""
+        if self.bn_prefix is not None:
+            p = self.bn_prefix
+            O.bn_finalize(self.in_sums if training else None, self.count, params[p + ".weight"], params[p + ".bias"],
+                          bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
+                          self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd)
+            if training:
+                bufs[p + ".num_batches_tracked"].add_(1)
+        c = self.conv_prefix
+        self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
+        y = self.alloc_out()
+        self.fwd.run(x, y, self.batch, self.scale, self.shift, self.act, self.act_param, out_stats,
+                     dtype_out=self.out_dtype)
+        return y
+
+    # ---------------------------------------------------------------- backward
+    def _init_bwd(self):
+        if self._bwd_ready:
+            return
+        kk = self.k ** 3
+        cin, cout, k, s, p = self.cin, self.cout, self.k, self.stride, self.pad
+        dev, dt = self.device, self.dtype
+        self.dz = O.alloc_cl(self.batch, self.out_dims, self.cpo, dt, dev)
+        self.dbias_id = None
+        if self.kind == "conv":
+            self.wgrad = O.WgradRunner(cin, cout, k, s, p, self.in_dims, self.out_dims, self.cpi, self.cpo,
+                                       cin * kk, kk, dt, dev)
+            dop = P.conv_dgrad_op(cin, cout, k, s, p, self.in_dims, self.cpo, self.cpi, dt)
+        else:
+            # roles swap: shifted operand = dz (output grid), fixed operand = normalised input
+            self.wgrad = O.WgradRunner(cout, cin, k, s, p, self.out_dims, self.in_dims, self.cpo, self.cpi,
+                                       cout * kk, kk, dt, dev)
+            dop = P.convT_dgrad_op(cin, cout, k, s, p, self.in_dims, self.cpo, self.cpi, dt)
+        if self.need_input_grad or self.bn_prefix is not None:
+            self.dgrad = O.ConvRunner(dop, dev)
+            self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
+        if self.bn_prefix is not None:
+            self.coef = torch.zeros(3, self.cpi, device=dev)
+        self._bwd_ready = True
+
+    def reserve_bwd_scratch(self):
+        self.dbias_sums_id = self.scratch.reserve(self.cpo)
+        if self.bn_prefix is not None:
+            self.bsums_id = self.scratch.reserve(self.cpi * 2)
+
+    @property
+    def dbias_sums(self):
+        return self.scratch.get(self.dbias_sums_id)
+
+    def backward(self, x, params, grads):
+        """Given self.dz (gradient at the pre-activation output) and self.dbias_sums already filled by the
+        producer of dz: accumulate parameter gradients, return (g, coef) describing the input gradient
+        dx = coef0*g + coef1*x + coef2 (coef None: dx = g)."""
+        c = self.conv_prefix
+        w = params[c + ".weight"]
+        O.add_f64_to_f32(self.dbias_sums, grads[c + ".bias"], self.cout)
+        if self.kind == "conv":
+            self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift)
+        else:
+            self.wgrad.run(self.dz, x, self.batch, grads[c + ".weight"], None, None, self.scale, self.shift)
+        if not (self.need_input_grad or self.bn_prefix is not None):
+            return None, None
+        self.dgrad.prep(w)
+        self.dgrad.run(self.dz, self.g, self.batch)
+        if self.bn_prefix is None:
+            return self.g, None
+        p = self.bn_prefix
+        bs = self.scratch.get(self.bsums_id)
+        O.bn_bwd_reduce(self.g, x, self.dtype, bs)
+        O.bn_bwd_finalize(bs, self.count, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
+                          grads[p + ".weight"], grads[p + ".bias"], self.coef)
+        return self.g, self.coef

@@ -168,24 +168,40 @@ def _pick_nt(nttot):
     return best[1], best[2]
 
 
-def _pick_rows(out_dims):
-    """(MT, TD, TH): 4*MT rows of 16 voxels per workgroup, shrunk for small volumes."""
+ROW_CONFIGS = ((8, 4, 8), (4, 4, 4), (4, 2, 8), (2, 2, 4), (2, 1, 8))   # (MT, TD, TH): 4*MT rows of 16 voxels
+
+
+def _pick_rows(out_dims, fits):
+    """Largest row blocking that suits the volume and whose staged plane fits LDS."""
     qd, qh, _ = out_dims
-    for mt, td, th in ((8, 4, 8), (4, 4, 4), (4, 2, 8), (2, 2, 4), (2, 1, 8)):
-        if qd >= td and qh >= th:
-            return mt, td, th
-    return 2, 2, 4
+    for limit in ("budget", "hard"):
+        ok = [c for c in ROW_CONFIGS if fits(c, limit)]
+        for c in ok:
+            if qd >= c[1] and qh >= c[2]:
+                return c
+        if ok:
+            return min(ok, key=lambda c: c[0] * 100 + c[1])
+    raise AssertionError("no tile configuration fits LDS")
 
 
 def _plan_sub(op: ConvOp, sub: SubConv):
     s = op.stride
     ext = sub.ext
-    mt, td, th = _pick_rows(sub.out_dims)
-    itd, ith, itw = (td - 1) * s[0] + ext[0], (th - 1) * s[1] + ext[1], 15 * s[2] + ext[2]
-    nvox = itd * ith * itw
     octs = op.cpi // 8
     opp = 2 if octs % 2 == 0 else 1
     np_planes = 2 if op.dtype == 1 else 1
+    budget = LDS_BUDGET[op.dtype]
+
+    def tile_dims(c):
+        return (c[1] - 1) * s[0] + ext[0], (c[2] - 1) * s[1] + ext[1], 15 * s[2] + ext[2]
+
+    def fits(c, limit):   # one plane at the widest candidate voxel stride must fit
+        d = tile_dims(c)
+        return d[0] * d[1] * d[2] * (opp + 1) * 16 * np_planes + 4096 <= (budget if limit == "budget" else 156 * 1024)
+
+    mt, td, th = _pick_rows(sub.out_dims, fits)
+    itd, ith, itw = tile_dims((mt, td, th))
+    nvox = itd * ith * itw
 
     def tap_vox(t):
         return (t[0] * ith + t[1]) * itw + t[2]
@@ -204,12 +220,11 @@ def _plan_sub(op: ConvOp, sub: SubConv):
             tot += _b128_cycles(addr)
         return tot / (len(seq) // 4)
 
-    cands = sorted(range(opp, opp + 5), key=lambda vs: (round(cost(vs), 2), vs))
+    cands = sorted(range(opp, opp + 2), key=lambda vs: (round(cost(vs), 2), vs))
     vs = cands[0]
     vsb = vs * 16
     plane_bytes = (nvox * vsb + 15) // 16 * 16
     # channel groups: as many planes as fit the LDS budget, dividing the octets evenly
-    budget = LDS_BUDGET[op.dtype]
     nplanes_total = octs // opp
     ppg = nplanes_total
     while ppg > 1 and (ppg * plane_bytes * np_planes > budget or nplanes_total % ppg):

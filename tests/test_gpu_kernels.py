@@ -12,6 +12,7 @@ from stroke_prediction_amd.runtime import ops as O
 from stroke_prediction_amd.runtime import plan as P
 
 DEV = "cuda:0"
+BIAS_ATOL = {L.SP_F32: 1e-2, L.SP_BF16: 0.3}   # sums of O(1000) values; bf16 inputs carry 2^-9 relative noise
 TOL = {L.SP_F32: dict(rtol=2e-4, atol=2e-4), L.SP_BF16: dict(rtol=3e-2, atol=3e-2)}
 
 
@@ -202,7 +203,8 @@ def test_bn_pieces(dtype):
     ref = gx_ref * elu_d
     got = from_cl(dz, Cc, dtype)
     torch.testing.assert_close(got, ref, **TOL[dtype])
-    torch.testing.assert_close(dbias[:Cc].cpu().float(), got.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
+    # the bias-gradient sums are taken before the storage rounding: compare with the exact reference
+    torch.testing.assert_close(dbias[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
 
 
 @pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
@@ -254,7 +256,8 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     O.pool_skip_act_bwd(ys, gps, coefp.to(DEV), cat, gcs, coefs.to(DEV), C0, dtype, L.ACT_LEAKY, 0.01, dz, dbias)
     got = from_cl(dz, C1, dtype)
     torch.testing.assert_close(got, gy_ref * lrelu_d, **TOL[dtype])
-    torch.testing.assert_close(dbias.cpu().float(), got.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=1e-2)
+    torch.testing.assert_close(dbias.cpu().float(), (gy_ref * lrelu_d).sum(dim=(0, 2, 3, 4)), rtol=1e-3,
+                               atol=BIAS_ATOL[dtype])
     # upsample backward lands on the low-res producer (here with ELU as its activation)
     dzl = O.alloc_cl(B, ldims, C0, dtype, DEV)
     O.upsample2_act_bwd(lows, cat, gcs, coefs.to(DEV), dtype, L.ACT_ELU, 1.0, dzl, None)
@@ -275,7 +278,8 @@ def test_dice_and_output_grad():
     torch.testing.assert_close(sums.cpu().float(), ref, rtol=1e-5, atol=1e-4)
     ca, cb = torch.randn(Cc), torch.randn(Cc)
     d = torch.empty_like(od)
-    lib.call("sp_dice_bwd", O.ptr(od), O.ptr(td), O.ptr(ca.to(DEV)), O.ptr(cb.to(DEV)), B, Cc, int(np.prod(dims)),
+    cad, cbd = ca.to(DEV), cb.to(DEV)
+    lib.call("sp_dice_bwd", O.ptr(od), O.ptr(td), O.ptr(cad), O.ptr(cbd), B, Cc, int(np.prod(dims)),
              O.ptr(d), O.stream())
     torch.testing.assert_close(d.cpu(), ca.view(1, -1, 1, 1, 1) * t + cb.view(1, -1, 1, 1, 1) * o, rtol=1e-6, atol=1e-6)
     dz = O.alloc_cl(B, dims, 8, L.SP_F32, DEV)

@@ -1,0 +1,128 @@
+"""End-to-end U-Net parity on the GPU: drop-in ``Unet3D`` (HIP path) vs the CPU oracle and vs the
+golden fixtures recorded from the real reference (forward, loss, every parameter gradient, BatchNorm
+running statistics).  Tolerances: parity mode ("f32", split-bf16 MFMA) 1e-3 relative as BASELINE.json's
+north_star asks; fast mode ("bf16") is held to bf16 storage noise and stated per assertion."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, weights as W
+from stroke_prediction_amd.common.model.Unet3D import Unet3D
+import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+
+CH = [2, 16, 32, 64, 32, 16, 32, 2]
+DEV = "cuda:0"
+
+
+def build(seed, dtype):
+    model = Unet3D(CH, dtype=dtype)
+    model.load_state_dict(W.make_state_dict(W.unet_spec(CH), seed))
+    return model.to(DEV)
+
+
+def oracle_step(seed, x, y):
+    sd = W.make_state_dict(W.unet_spec(CH), seed)
+    names = nets.trainable(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    seg = nets.unet_forward(sd, x, training=True)
+    loss = nets.unet_loss(seg, y)
+    grads = torch.autograd.grad(loss, [sd[k] for k in names])
+    return seg.detach(), loss.item(), dict(zip(names, grads)), sd
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("dtype,size,seed,tol_seg,tol_grad", [
+    ("f32", (44, 44, 44), 11, 1e-4, 2e-3),
+    ("f32", (44, 48, 52), 13, 1e-4, 2e-3),
+    ("bf16", (44, 44, 44), 11, 2e-2, 0.15),
+    ("bf16", (48, 48, 48), 12, 2e-2, 0.15),
+])
+def test_unet_train_step_matches_oracle(dtype, size, seed, tol_seg, tol_grad):
+    x, y = W.unet_inputs(2, size, seed)
+    seg_ref, loss_ref, g_ref, sd_ref = oracle_step(seed, x, y)
+    model = build(seed, dtype)
+    model.train()
+    dto = model(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    assert tuple(seg.shape) == tuple(seg_ref.shape)
+    # probabilities: absolute tolerance (values in (0,1)); logits relative tolerance for the parity mode
+    torch.testing.assert_close(seg.detach().cpu(), seg_ref, rtol=0, atol=tol_seg)
+    if dtype == "f32":
+        logit = lambda p: torch.log(p / (1 - p))
+        lr, lg = logit(seg_ref.double()), logit(seg.detach().cpu().double())
+        assert float((lg - lr).abs().max() / lr.abs().max()) < 1e-3     # north_star: logits within 1e-3 rel
+    loss = nets.unet_loss(seg, y.to(DEV))           # Dice recipe in torch (plumbing) on the HIP outputs
+    assert abs(loss.item() - loss_ref) < (1e-5 if dtype == "f32" else 5e-3)
+    loss.backward()
+    bad = []
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        e = rel_l2(p.grad.cpu(), g_ref[name])
+        if e > tol_grad:
+            bad.append((name, e))
+    assert not bad, bad
+    # BatchNorm running statistics followed the reference update rule (momentum 0.1, unbiased variance)
+    for name, b in model.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == 1
+        else:
+            torch.testing.assert_close(b.cpu(), sd_ref[name], rtol=5e-3 if dtype == "f32" else 3e-2,
+                                       atol=1e-4 if dtype == "f32" else 3e-3)
+
+
+@pytest.mark.parametrize("fname", ["unet_44.npz", "unet_48.npz", "unet_44x48x52.npz"])
+def test_unet_matches_reference_fixture(golden_dir, fname):
+    """HIP path (parity mode) directly against outputs/gradients recorded from the REAL reference."""
+    fx = np.load(os.path.join(golden_dir, fname))
+    seed = int(fx["seed"])
+    size = tuple(int(s) for s in np.atleast_1d(fx["size"]))
+    size = size * 3 if len(size) == 1 else size
+    x, y = W.unet_inputs(2, size, seed)
+    model = build(seed, "f32")
+    model.train()
+    dto = model(UnetDtoUtil.init_dto(x.to(DEV)))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    np.testing.assert_allclose(seg.detach().cpu().numpy(), fx["seg"], rtol=0, atol=1e-4)
+    loss = nets.unet_loss(seg, y.to(DEV))
+    assert abs(loss.item() - float(fx["loss/0"])) < 1e-5
+    loss.backward()
+    for name, p in model.named_parameters():
+        gn = float(fx["gnorm/" + name])
+        assert abs(float(p.grad.double().norm()) - gn) <= 2e-3 * gn + 1e-9, name
+        np.testing.assert_allclose(p.grad.reshape(-1)[:8].cpu().numpy(), fx["ghead/" + name], rtol=1e-2,
+                                   atol=2e-3 * gn + 1e-9)
+
+
+def test_unet_eval_mode_and_freeze():
+    seed = 11
+    x, _ = W.unet_inputs(1, 64, seed)
+    sd = W.make_state_dict(W.unet_spec(CH), seed)
+    with torch.no_grad():
+        ref = nets.unet_forward(sd, x, training=False)
+    model = build(seed, "f32")
+    model.freeze(True)
+    model.eval()
+    dto = model(UnetDtoUtil.init_dto(x.to(DEV)))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    assert not seg.requires_grad
+    torch.testing.assert_close(seg.cpu(), ref, rtol=0, atol=1e-4)
+    for name, b in model.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == 0
+
+
+def test_rejects_cpu_and_too_small_inputs():
+    model = Unet3D(CH)
+    with pytest.raises(RuntimeError):
+        model(UnetDtoUtil.init_dto(torch.zeros(1, 2, 44, 44, 44)))
+    model = model.to(DEV)
+    with pytest.raises(ValueError):          # BASELINE config #1 as written (32^3) cannot pass valid convs
+        model(UnetDtoUtil.init_dto(torch.zeros(2, 2, 32, 32, 32, device=DEV)))
