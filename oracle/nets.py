@@ -17,6 +17,26 @@ BN_MOMENTUM = 0.1
 LEAKY = 0.01         # Unet3D.py:20,23,51
 
 
+class _RoundBf16(torch.autograd.Function):
+    """Round to bf16 storage precision in the forward, identity in the backward."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_bf16(t):
+    return _RoundBf16.apply(t)
+
+
+def _ident(t):
+    return t
+
+
 def _bn(sd, prefix, x, training):
     """``nn.BatchNorm3d`` call sites; training mode normalises with biased batch
     variance and updates running stats with the unbiased one."""
@@ -34,13 +54,15 @@ def center_crop(t, like, dims=(2, 3, 4)):
     return t
 
 
-def unet_block(sd, p, x, training):
-    """``Block3x3x3`` Unet3D.py:14-27: BN-conv(3,p0)-lrelu twice."""
+def unet_block(sd, p, x, training, q=_ident):
+    """``Block3x3x3`` Unet3D.py:14-27: BN-conv(3,p0)-lrelu twice.
+    ``q`` models the storage rounding of the HIP bf16 path (identity for the reference semantics):
+    it is applied where that path rounds -- the normalised conv operand, the weights, the stored output."""
     for bn_i, cv_i in ((0, 1), (3, 4)):
-        x = _bn(sd, "%s.bn_conv_relu_2x.%d" % (p, bn_i), x, training)
-        x = F.conv3d(x, sd["%s.bn_conv_relu_2x.%d.weight" % (p, cv_i)],
+        x = q(_bn(sd, "%s.bn_conv_relu_2x.%d" % (p, bn_i), x, training))
+        x = F.conv3d(x, q(sd["%s.bn_conv_relu_2x.%d.weight" % (p, cv_i)]),
                      sd["%s.bn_conv_relu_2x.%d.bias" % (p, cv_i)])
-        x = F.leaky_relu(x, LEAKY)
+        x = q(F.leaky_relu(x, LEAKY))
     return x
 
 
@@ -50,17 +72,18 @@ def upsample2(x, align_corners=False):
     return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=align_corners)
 
 
-def unet_forward(sd, x, training=True, return_all=False):
-    """``Unet3D.forward`` Unet3D.py:56-79.  Returns sigmoid probs (B,2,...)."""
-    b1 = unet_block(sd, "block1", x, training)
-    b2 = unet_block(sd, "block2", F.max_pool3d(b1, 2, 2), training)
-    b3 = unet_block(sd, "block3", F.max_pool3d(b2, 2, 2), training)
-    u3 = upsample2(b3)
-    b4 = unet_block(sd, "block4", torch.cat((u3, center_crop(b2, u3)), dim=1), training)
-    u4 = upsample2(b4)
-    b5 = unet_block(sd, "block5", torch.cat((u4, center_crop(b1, u4)), dim=1), training)
-    h = F.leaky_relu(F.conv3d(b5, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY)
-    seg = torch.sigmoid(F.conv3d(h, sd["classify.2.weight"], sd["classify.2.bias"]))
+def unet_forward(sd, x, training=True, return_all=False, q=_ident):
+    """``Unet3D.forward`` Unet3D.py:56-79.  Returns sigmoid probs (B,2,...).
+    ``q=round_bf16`` emulates the bf16 storage points of the HIP fast path (see ``unet_block``)."""
+    b1 = unet_block(sd, "block1", q(x), training, q)
+    b2 = unet_block(sd, "block2", F.max_pool3d(b1, 2, 2), training, q)
+    b3 = unet_block(sd, "block3", F.max_pool3d(b2, 2, 2), training, q)
+    u3 = q(upsample2(b3))
+    b4 = unet_block(sd, "block4", torch.cat((u3, center_crop(b2, u3)), dim=1), training, q)
+    u4 = q(upsample2(b4))
+    b5 = unet_block(sd, "block5", torch.cat((u4, center_crop(b1, u4)), dim=1), training, q)
+    h = q(F.leaky_relu(F.conv3d(b5, q(sd["classify.0.weight"]), sd["classify.0.bias"]), LEAKY))
+    seg = torch.sigmoid(F.conv3d(h, q(sd["classify.2.weight"]), sd["classify.2.bias"]))
     if return_all:
         return seg, dict(b1=b1, b2=b2, b3=b3, b4=b4, b5=b5)
     return seg

@@ -11,6 +11,28 @@ from . import plan as P
 TORCH_DT = {L.SP_BF16: torch.bfloat16, L.SP_F32: torch.float32}
 
 
+# optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, tag, flops):
+        self.tag, self.flops = tag, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.tag, self.flops, self.e0, self.e1))
+        return False
+
+
 def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("stroke_prediction_amd needs an AMD GPU (gfx950): the hot path has no CPU fallback")
@@ -100,7 +122,8 @@ class ConvRunner:
             for k in ("TD", "TH", "ITD", "ITH", "ITW", "MT", "ngroups", "octs_per_group", "opp", "vsb",
                       "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes"):
                 setattr(a, k, t[k])
-            L.call("sp_conv3d_igemm", C.byref(a), st)
+            with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout):
+                L.call("sp_conv3d_igemm", C.byref(a), st)
 
 
 class WgradRunner:
@@ -143,7 +166,8 @@ class WgradRunner:
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
         st = stream()
-        L.call("sp_conv3d_wgrad", C.byref(a), st)
+        with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout):
+            L.call("sp_conv3d_wgrad", C.byref(a), st)
         L.call("sp_wgrad_finish", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), st)
 
