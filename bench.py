@@ -23,10 +23,10 @@ PEAK_TFLOPS = {"bf16": 2500.0, "f32": 2500.0 / 3.0}     # dense bf16 MFMA (MI355
 TRAIN_GFLOP_PER_SAMPLE_128 = 345.7                        # SURVEY.md 8d (fwd + dgrad + wgrad)
 
 
-def cpu_baseline(size, steps=2, batch=2):
+def cpu_baseline(size, steps=1, batch=2):
     """The CPU oracle (fp32 restatement of the reference path) timed on the host cores: 1 warm-up + `steps`."""
     from oracle import nets, weights as W
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))      # more threads than this only adds contention on this path
     sd = W.make_state_dict(W.unet_spec(CHANNELS), 1234)
     names = nets.trainable(sd)
     for k in names:

@@ -91,14 +91,14 @@ class FusedAdam(Optimizer):
         """Keeps ``p.grad`` attached (the flat gradient buffer is the kernels' accumulation target):
         one memset when the gradients are views of a flat buffer, per-tensor otherwise."""
         for gi, group in enumerate(self.param_groups):
-            st = self._flat.get(gi)
-            if st is not None and all(p.grad is not None for p in group["params"]) and \
-                    group["params"][0].grad.data_ptr() == st["key"][2]:
+            st = self._flat_group(gi, group)
+            if st is not None:
                 st["g"].zero_()
                 continue
             for p in group["params"]:
                 if p.grad is not None:
-                    p.grad.detach_()
+                    if p.grad.grad_fn is not None:
+                        p.grad = p.grad.detach()
                     p.grad.zero_()
 
 

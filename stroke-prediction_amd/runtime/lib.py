@@ -71,6 +71,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (libamdhip64): import it FIRST so that this library binds to the
+    # same runtime instance (streams and device pointers are shared with torch); loading ours first would
+    # pull a second copy from /opt/rocm that never sees torch's context.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "stroke_prediction_amd: %s is missing -- build it with `python -c \"import __graft_entry__ as g; "
