@@ -81,6 +81,10 @@ typedef struct sp_conv_args {
   int32_t lds_bytes;
   int32_t act;
   float act_param;
+  int32_t dma;                 /* 1: LDS-DMA staging (bf16 in, in_scale NULL, lane-linear planes, +1 KiB LDS slack) */
+  int32_t zfill;               /* dma only: taps can leave the input volume -> zero those chunks */
+  int32_t stats_nrep;          /* power of two >= 1: stats is [stats_nrep][CPo][2]; workgroup b adds to replica b % nrep
+                                  (tens of thousands of same-address fp64 atomics otherwise serialise at the memory side) */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -90,7 +94,13 @@ int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
  * element (co, ci, tap) is read from w[co*sCo + ci*sCi + tap]. */
 int sp_conv_prep_weights(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin,
                          const int32_t* kmap, int32_t nsteps, int32_t NTtot,
-                         void* wfrag_hi, void* wfrag_lo /* or NULL */, sp_stream_t stream);
+                         void* wfrag_hi, void* wfrag_lo /* or NULL */,
+                         const float* fold_scale /* [Cin] or NULL: w[co,ci,tap] *= fold_scale[ci] */,
+                         sp_stream_t stream);
+/* BatchNorm folded into an un-padded convolution: bias_out[co] = bias[co] + sum_{ci,tap} w[co,ci,tap]*shift[ci]
+ * (bias may be NULL = 0; bias_out has room for CoutPad entries, the tail is zeroed) */
+int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, int32_t ntaps,
+                      const float* bias, const float* shift, float* bias_out, int32_t CoutPad, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ weight gradient
  * dw[co,ci,tap] += sum_{b,o} dz[b,o,co] * xin[b, o*s + o0 + tapoff(tap), ci]   (fp32 atomics)
@@ -131,7 +141,8 @@ int sp_bn_stats(const void* x, int32_t dtype, int64_t nvox, int32_t CP, double* 
                 sp_stream_t stream);
 /* sums -> scale/shift for BN-on-load; updates running stats (momentum, unbiased var) like
  * nn.BatchNorm3d; writes mean/invstd for the backward.  training=0: use running stats. */
-int sp_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+int sp_bn_finalize(const double* sums /* [nrep][CP][2], replicas are added */, int32_t nrep, double count,
+                   const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int32_t training, int32_t C, int32_t CP,
                    float* scale, float* shift, float* mean, float* invstd, sp_stream_t stream);
 /* backward reductions: sums[c] = (sum g, sum g*x) over the tensor */

@@ -54,14 +54,40 @@ def center_crop(t, like, dims=(2, 3, 4)):
     return t
 
 
+def _bn_folded_conv(sd, bn_p, cv_p, x, training, q):
+    """The HIP bf16 path folds the BatchNorm of an un-padded convolution into weights and bias
+    (conv(s*x+t) = conv_{W*s}(x) + sum W*t) so the raw bf16 input can be staged by LDS-DMA: the weights are
+    rounded AFTER the fold, the input is not re-rounded.  Same function as BN -> conv, emulated here so that the
+    bf16 parity test compares like with like."""
+    w, b = sd[cv_p + ".weight"], sd[cv_p + ".bias"]
+    gamma, beta = sd[bn_p + ".weight"], sd[bn_p + ".bias"]
+    if training:
+        mean = x.mean(dim=(0, 2, 3, 4))
+        var = x.var(dim=(0, 2, 3, 4), unbiased=False)
+        with torch.no_grad():
+            n = x.numel() / x.shape[1]
+            sd[bn_p + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * mean)
+            sd[bn_p + ".running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * var * n / (n - 1))
+            sd[bn_p + ".num_batches_tracked"] += 1
+    else:
+        mean, var = sd[bn_p + ".running_mean"], sd[bn_p + ".running_var"]
+    scale = gamma / torch.sqrt(var + BN_EPS)
+    shift = beta - mean * scale
+    wf = q(w * scale.view(1, -1, 1, 1, 1))
+    bf = b + (w * shift.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
+    return F.conv3d(x, wf, bf)
+
+
 def unet_block(sd, p, x, training, q=_ident):
     """``Block3x3x3`` Unet3D.py:14-27: BN-conv(3,p0)-lrelu twice.
     ``q`` models the storage rounding of the HIP bf16 path (identity for the reference semantics):
     it is applied where that path rounds -- the normalised conv operand, the weights, the stored output."""
     for bn_i, cv_i in ((0, 1), (3, 4)):
-        x = q(_bn(sd, "%s.bn_conv_relu_2x.%d" % (p, bn_i), x, training))
-        x = F.conv3d(x, q(sd["%s.bn_conv_relu_2x.%d.weight" % (p, cv_i)]),
-                     sd["%s.bn_conv_relu_2x.%d.bias" % (p, cv_i)])
+        bn_p, cv_p = "%s.bn_conv_relu_2x.%d" % (p, bn_i), "%s.bn_conv_relu_2x.%d" % (p, cv_i)
+        if q is not _ident:
+            x = _bn_folded_conv(sd, bn_p, cv_p, x, training, q)
+        else:
+            x = F.conv3d(_bn(sd, bn_p, x, training), sd[cv_p + ".weight"], sd[cv_p + ".bias"])
         x = q(F.leaky_relu(x, LEAKY))
     return x
 

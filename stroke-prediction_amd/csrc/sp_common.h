@@ -135,6 +135,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane>>4), result in every lane of the row:
+// xor-1 / xor-2 inside quads, then the two mirrors -- 4 VALU ops, no LDS crossbar (ds_bpermute) traffic.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
 // XCD-aware bijective remap of a linear workgroup id: workgroups that share halo data get
 // consecutive ids on ONE XCD (b and b+8 share an XCD under round-robin dispatch; speed only).
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {

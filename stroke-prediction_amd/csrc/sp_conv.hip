@@ -19,6 +19,46 @@
 //     accumulate: ~2^-17 relative, used for parity against the fp32 CPU reference.
 #include "sp_common.h"
 
+// one 8-channel chunk as loaded from global memory, kept raw until every load of a batch is in flight
+template <typename T> struct RawChunk;
+template <> struct RawChunk<bf16_t> {
+  uint4 r;
+  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void unpack(float* v) const {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <> struct RawChunk<float> {
+  float4 a, b;
+  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void unpack(float* v) const {
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+#define SB 8   // staging loads in flight per thread
+
+// Diagnostic build only (-DSP_CONV_STAMPS): per-workgroup phase time stamps (shader clock) go to a buffer
+// that nothing else reads; the shipped library compiles this away.
+#ifdef SP_CONV_STAMPS
+#define SP_NSTAMP 6
+__device__ unsigned long long sp_stamp_buf[32768][SP_NSTAMP];   // shared with sp_conv_dma.hip (-fgpu-rdc in the stamp build)
+#define STAMP(k)                                                                              \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    unsigned long long t_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) sp_stamp_buf[blockIdx.x][k] = t_; \
+  } while (0)
+extern "C" int sp_debug_read_stamps(unsigned long long* host, int nblocks) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sp_stamp_buf), sizeof(unsigned long long) * SP_NSTAMP * nblocks);
+}
+#else
+#define STAMP(k)
+#endif
+
 struct ConvDev {
   sp_conv_args a;
   FastDiv d_octs, d_itw, d_ith;   // staging index math
@@ -70,80 +110,138 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
   const int nvox_tile = a.ITD * a.ITH * a.ITW;
   const int nchunks = nvox_tile * a.octs_per_group;
 
+  // a thread's channel octet is the same for every chunk it stages when the octets per group divide 256
+  const bool fixed_oc = (256 % a.octs_per_group) == 0;
+  const int my_oc = tid % a.octs_per_group;
+
+  STAMP(0);
   for (int grp = 0; grp < a.ngroups; ++grp) {
     if (grp > 0) __syncthreads();   // previous group's reads are done
     // ---- stage the halo tile: global (channels-last) -> norm -> bf16 (hi/lo) -> LDS planes ----
+    // SB independent 16-byte loads per thread are issued before any of them is consumed: the tile
+    // load is latency-bound otherwise (one 1 KiB wave-load in flight per wave).
     const int oct0 = grp * a.octs_per_group;
-    for (int i = tid; i < nchunks; i += 256) {
-      const uint32_t vox = fdiv(i, P.d_octs);
-      const int oc = i - vox * a.octs_per_group;
-      const uint32_t row = fdiv(vox, P.d_itw);
-      const int vx = vox - row * a.ITW;
-      const uint32_t vz = fdiv(row, P.d_ith);
-      const int vy = row - vz * a.ITH;
-      const int gz = iz0 + (int)vz, gy = iy0 + vy, gx = ix0 + vx;
-      float v[8];
-      const bool inb = (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
-      if (inb) {
-        const int c = (oct0 + oc) * 8;
-        Store<TIN>::ld8(xin + (((size_t)gz * a.Hi + gy) * a.Wi + gx) * a.CPi + c, v);
-        if (a.in_scale) {
-          const float4 s0 = *reinterpret_cast<const float4*>(a.in_scale + c), s1 = *reinterpret_cast<const float4*>(a.in_scale + c + 4);
-          const float4 h0 = *reinterpret_cast<const float4*>(a.in_shift + c), h1 = *reinterpret_cast<const float4*>(a.in_shift + c + 4);
-          v[0] = fmaf(v[0], s0.x, h0.x); v[1] = fmaf(v[1], s0.y, h0.y); v[2] = fmaf(v[2], s0.z, h0.z); v[3] = fmaf(v[3], s0.w, h0.w);
-          v[4] = fmaf(v[4], s1.x, h1.x); v[5] = fmaf(v[5], s1.y, h1.y); v[6] = fmaf(v[6], s1.z, h1.z); v[7] = fmaf(v[7], s1.w, h1.w);
-        }
-      } else {
+    float fsc[8], fsh[8];
+    if (a.in_scale && fixed_oc) {
+      const int c = (oct0 + my_oc) * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      for (int j = 0; j < 8; ++j) { fsc[j] = a.in_scale[c + j]; fsh[j] = a.in_shift[c + j]; }
+    }
+    for (int base = 0; base < nchunks; base += 256 * SB) {
+      RawChunk<TIN> raw[SB];
+      int dsto[SB], cch[SB];
+      unsigned valid = 0, inb = 0;
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        // no branch around the load (a divergent join would force vmcnt(0) per load): clamp the chunk
+        // index and the coordinates to something loadable, remember validity in bit masks
+        const int i0 = base + u * 256 + tid;
+        const int i = i0 < nchunks ? i0 : nchunks - 1;
+        const uint32_t vox = fdiv(i, P.d_octs);
+        const int oc = i - vox * a.octs_per_group;
+        const uint32_t row = fdiv(vox, P.d_itw);
+        const int vx = vox - row * a.ITW;
+        const uint32_t vz = fdiv(row, P.d_ith);
+        const int vy = row - vz * a.ITH;
+        const int gz = iz0 + (int)vz, gy = iy0 + vy, gx = ix0 + vx;
+        const int pl = oc / a.opp, po = oc - pl * a.opp;
+        dsto[u] = pl * a.plane_bytes + vox * a.vsb + po * 16;
+        cch[u] = (oct0 + oc) * 8;
+        const bool ok = (unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi;
+        valid |= (i0 < nchunks ? 1u : 0u) << u;
+        inb |= (ok ? 1u : 0u) << u;
+        const int cz = min(max(gz, 0), a.Di - 1), cy = min(max(gy, 0), a.Hi - 1), cx = min(max(gx, 0), a.Wi - 1);
+        raw[u].ld(xin + (((size_t)cz * a.Hi + cy) * a.Wi + cx) * a.CPi + cch[u]);
       }
-      const int pl = oc / a.opp, po = oc - pl * a.opp;
-      unsigned char* dst = tile + pl * a.plane_bytes + vox * a.vsb + po * 16;
-      uint32_t w[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
-      *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
-      if (NP == 2) {
-        uint32_t wl[4];
+      for (int u = 0; u < SB; ++u) {
+        if (valid & (1u << u)) {
+          float v[8];
+          if (inb & (1u << u)) {
+            raw[u].unpack(v);
+            if (a.in_scale) {
+              if (fixed_oc) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float r0 = v[2 * j] - __uint_as_float(w[j] << 16);
-          const float r1 = v[2 * j + 1] - __uint_as_float(w[j] & 0xffff0000u);
-          wl[j] = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], fsc[j], fsh[j]);
+              } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.in_scale[cch[u] + j], a.in_shift[cch[u] + j]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          }
+          unsigned char* dst = tile + dsto[u];
+          uint32_t w[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[2 * j]) | ((uint32_t)f2bf(v[2 * j + 1]) << 16);
+          *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+          if (NP == 2) {
+            uint32_t wl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float r0 = v[2 * j] - __uint_as_float(w[j] << 16);
+              const float r1 = v[2 * j + 1] - __uint_as_float(w[j] & 0xffff0000u);
+              wl[j] = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+            }
+            *reinterpret_cast<uint4*>(dst + a.lo_offset) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+          }
         }
-        *reinterpret_cast<uint4*>(dst + a.lo_offset) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
       }
     }
-    __syncthreads();
 
     // ---- K loop: taps x channel octets of this group ------------------------------------------
+    // weight fragments (L2/L1-resident, shared by every workgroup) and the ktab entry of step s+1 are
+    // fetched while step s computes; the first fetch is issued before the barrier that ends staging.
     const size_t gstep0 = (size_t)grp * a.steps_per_group;
-    for (int s = 0; s < a.steps_per_group; ++s) {
-      const int koff = ktab_l[s * 4 + lg];
-      const size_t fbase = ((gstep0 + s) * a.NTtot + nt0) * 64 + lane;
-      bf16x8 wa[NT], wl[NT];
+    const size_t fstride = (size_t)a.NTtot * 64;
+    const bf16x8* wp_hi = wf_hi + (gstep0 * a.NTtot + nt0) * 64 + lane;
+    const bf16x8* wp_lo = wf_lo + (gstep0 * a.NTtot + nt0) * 64 + lane;
+    bf16x8 wa_n[NT], wl_n[NT];
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        wa[n] = wf_hi[fbase + (size_t)n * 64];
-        if (NP == 2) wl[n] = wf_lo[fbase + (size_t)n * 64];
+    for (int n = 0; n < NT; ++n) {
+      wa_n[n] = wp_hi[(size_t)n * 64];
+      if (NP == 2) wl_n[n] = wp_lo[(size_t)n * 64];
+    }
+    if (grp == 0) STAMP(1);
+    __syncthreads();
+    if (grp == 0) STAMP(2);
+    int koff_n = ktab_l[lg];
+    for (int s = 0; s < a.steps_per_group; ++s) {
+      bf16x8 wa[NT], wl[NT];
+      const int koff = koff_n;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) { wa[n] = wa_n[n]; if (NP == 2) wl[n] = wl_n[n]; }
+      if (s + 1 < a.steps_per_group) {
+        koff_n = ktab_l[(s + 1) * 4 + lg];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          wa_n[n] = wp_hi[(s + 1) * fstride + (size_t)n * 64];
+          if (NP == 2) wl_n[n] = wp_lo[(s + 1) * fstride + (size_t)n * 64];
+        }
+      }
+      bf16x8 xb[MT], xl[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        xb[m] = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + koff);
+        if (NP == 2) xl[m] = *reinterpret_cast<const bf16x8*>(tile + a.lo_offset + vbase[m] + koff);
       }
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const bf16x8 xb = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + koff);
-        bf16x8 xl;
-        if (NP == 2) xl = *reinterpret_cast<const bf16x8*>(tile + a.lo_offset + vbase[m] + koff);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n], xb, acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n], xb[m], acc[n][m], 0, 0, 0);
           if (NP == 2) {
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n], xl, acc[n][m], 0, 0, 0);
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xb, acc[n][m], 0, 0, 0);
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n], xl[m], acc[n][m], 0, 0, 0);
+            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xb[m], acc[n][m], 0, 0, 0);
           }
         }
       }
     }
   }
 
+  STAMP(3);
   // ---- epilogue: bias, activation, statistics, channels-last store ----------------------------
   TOUT* __restrict__ yout = reinterpret_cast<TOUT*>(a.y) + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
   float s1[NT][4], s2[NT][4];
@@ -184,6 +282,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
     }
   }
 
+  STAMP(4);
   if (a.stats) {
     __syncthreads();                       // tile no longer needed: reuse LDS for the block reduction
     float* red = reinterpret_cast<float*>(lds);
@@ -193,9 +292,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float x1 = s1[n][j], x2 = s2[n][j];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { x1 += __shfl_xor(x1, o, 64); x2 += __shfl_xor(x2, o, 64); }
+        const float x1 = row16_sum(s1[n][j]), x2 = row16_sum(s2[n][j]);
         if (lv == 0) {
           atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1);
           atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2);
@@ -204,9 +301,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
     __syncthreads();
     for (int i = tid; i < NT * 16 * 2; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
     }
   }
+  STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -232,6 +330,8 @@ static int dispatch_dtype(const ConvDev& P, dim3 grid, hipStream_t st) {
   return SP_EINVAL;
 }
 
+int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream);   // sp_conv_dma.hip
+
 extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab, "sp_conv3d_igemm: null pointer");
   SP_CHECK_ARG(a->CPi % 8 == 0 && a->CPo % 8 == 0, "sp_conv3d_igemm: channel pitch must be a multiple of 8 (CPi=%d CPo=%d)", a->CPi, a->CPo);
@@ -240,6 +340,7 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->ngroups * a->octs_per_group * 8 == a->CPi, "sp_conv3d_igemm: groups (%d x %d octets) do not cover CPi=%d", a->ngroups, a->octs_per_group, a->CPi);
   SP_CHECK_ARG(a->dtype_in != SP_F32 || (a->wfrag_lo && a->lo_offset > 0), "sp_conv3d_igemm: f32 mode needs wfrag_lo and lo_offset");
   SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_igemm: empty output");
+  SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_igemm: stats_nrep must be a power of two");
   // the staged tile must cover every tap of every output row of the tile
   SP_CHECK_ARG(a->ITW >= 15 * a->sW + 1 && a->ITH >= (a->TH - 1) * a->sH + 1 && a->ITD >= (a->TD - 1) * a->sD + 1, "sp_conv3d_igemm: input tile smaller than output tile");
   {
@@ -250,6 +351,7 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
                  "sp_conv3d_igemm: LDS plan inconsistent (need %ld, lds_bytes %d)", need, a->lds_bytes);
     SP_CHECK_ARG(a->lds_bytes >= a->NT * 16 * 2 * 4, "sp_conv3d_igemm: LDS too small for the reduction");
   }
+  if (a->dma) return sp_conv3d_igemm_dma(a, stream);
   ConvDev P;
   P.a = *a;
   P.d_octs = make_fastdiv(a->octs_per_group);
@@ -279,7 +381,7 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
 // weight re-packing: fp32 (Cout,Cin,taps) -> MFMA A fragments [step][ntile][lane][8] (hi / lo bf16)
 __global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
                                   const int32_t* __restrict__ kmap, int nsteps, int NTtot,
-                                  bf16_t* __restrict__ hi, bf16_t* __restrict__ lo) {
+                                  bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, const float* __restrict__ fold) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (step, ntile, lane)
   const int64_t total = (int64_t)nsteps * NTtot * 64;
   if (idx >= total) return;
@@ -297,7 +399,7 @@ __global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int6
       float v = 0.f;
       if (km >= 0) {
         const int tap = km >> 16, ci = (km & 0xffff) * 8 + 2 * j + h;
-        if (co < Cout && ci < Cin) v = w[co * sCo + ci * sCi + tap];
+        if (co < Cout && ci < Cin) v = w[co * sCo + ci * sCi + tap] * (fold ? fold[ci] : 1.f);
       }
       f[h] = v;
     }
@@ -311,12 +413,35 @@ __global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int6
 
 extern "C" int sp_conv_prep_weights(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin,
                                     const int32_t* kmap, int32_t nsteps, int32_t NTtot, void* wfrag_hi,
-                                    void* wfrag_lo, sp_stream_t stream) {
+                                    void* wfrag_lo, const float* fold_scale, sp_stream_t stream) {
   SP_CHECK_ARG(w && kmap && wfrag_hi && nsteps > 0 && NTtot > 0, "sp_conv_prep_weights: bad arguments");
   const int64_t total = (int64_t)nsteps * NTtot * 64;
   hipLaunchKernelGGL(prep_wfrag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), w, sCo, sCi, Cout, Cin, kmap, nsteps, NTtot,
-                     reinterpret_cast<bf16_t*>(wfrag_hi), reinterpret_cast<bf16_t*>(wfrag_lo));
+                     reinterpret_cast<bf16_t*>(wfrag_hi), reinterpret_cast<bf16_t*>(wfrag_lo), fold_scale);
   SP_CHECK_LAUNCH("sp_conv_prep_weights");
+  return SP_OK;
+}
+
+__global__ void fold_bias_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin, int ntaps,
+                                 const float* __restrict__ bias, const float* __restrict__ shift,
+                                 float* __restrict__ out, int CoutPad) {
+  const int co = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  if (co < Cout)
+    for (int i = lane; i < Cin * ntaps; i += 64) {
+      const int ci = i / ntaps, tp = i - ci * ntaps;
+      s += w[co * sCo + ci * sCi + tp] * shift[ci];
+    }
+  s = wave_sum(s);
+  if (lane == 0) out[co] = co < Cout ? s + (bias ? bias[co] : 0.f) : 0.f;
+}
+extern "C" int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, int32_t ntaps,
+                                 const float* bias, const float* shift, float* bias_out, int32_t CoutPad,
+                                 sp_stream_t stream) {
+  SP_CHECK_ARG(w && shift && bias_out && CoutPad >= Cout, "sp_conv_fold_bias: bad arguments");
+  hipLaunchKernelGGL(fold_bias_kernel, dim3(CoutPad), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), w, sCo, sCi,
+                     Cout, Cin, ntaps, bias, shift, bias_out, CoutPad);
+  SP_CHECK_LAUNCH("sp_conv_fold_bias");
   return SP_OK;
 }

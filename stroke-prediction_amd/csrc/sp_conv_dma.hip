@@ -1,0 +1,361 @@
+// bf16 fast path of the implicit-GEMM convolution (see sp_conv.hip for the GEMM view and the tables).
+//
+// What the phase stamps of the register-staged kernel showed on the 16->16 @126^3 layer (29 K cycles per
+// workgroup: 51 % staging, 24 % K loop, 17 % epilogue, 7 % statistics) drives this variant:
+//   * the halo tile goes global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction,
+//     no VGPR round trip, no conversion): all of a workgroup's tile is in flight at once.  The plane
+//     layout [plane][voxel][opp x 16 B] is lane-linear, so chunk i of a group lands at byte 16*i;
+//   * BatchNorm cannot be applied on a DMA: the host folds it into the weights and the bias
+//     (conv(s*x+t) = conv_{W*s}(x) + sum W*t, exact for un-padded convolutions) -- in_scale must be NULL;
+//   * zero padding (data gradients, padded convolutions without a norm): a second pass overwrites the
+//     out-of-volume chunks with zeros, only in workgroups whose tile crosses the volume border;
+//   * layers whose K loop has <= 16 weight fragments per group keep them ALL in registers (loaded while
+//     the DMA is in flight); longer loops prefetch one step ahead.
+#include "sp_common.h"
+
+struct ConvDmaDev {
+  sp_conv_args a;
+  FastDiv d_itw, d_ith, d_plane;  // staging index math
+  FastDiv d_tx, d_ty, d_tz;       // block id -> tile
+  uint32_t ntx, nty, ntz, nblk;
+  int32_t plane_chunks, group_chunks, nruns, log2_opp;
+  int32_t row_chunks, segs_per_row, nrows, njobs;
+  FastDiv d_segs, d_rows;
+};
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+
+#ifdef SP_CONV_STAMPS
+#define SP_NSTAMP 6
+extern __device__ unsigned long long sp_stamp_buf[32768][SP_NSTAMP];
+#define STAMP(k)                                                                              \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    unsigned long long t_;                                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 32768) sp_stamp_buf[blockIdx.x][k] = t_; \
+  } while (0)
+#else
+#define STAMP(k)
+#endif
+
+// KS > 0: compile-time number of K steps per group, all weight fragments of the group resident in registers
+// (no guards inside the unrolled loop: guards make hipcc shuttle the accumulators between VGPRs and AGPRs
+// around every step).  KS == 0: run-time step count (even, the planner pads), fragments prefetched one step ahead.
+template <int NT, int MT, int KS, typename TOUT>
+__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvDmaDev P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const sp_conv_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lv = lane & 15, lg = lane >> 4;
+
+  uint32_t t = xcd_remap(blockIdx.x, P.nblk);
+  uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
+  q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; t = q;
+  q = fdiv(t, P.d_tz); const int tz = t - q * P.ntz; const int b = q;
+  const int oz0 = tz * a.TD, oy0 = ty * a.TH, ox0 = tx * 16;
+  const int nt0 = blockIdx.y * NT;
+  const int iz0 = oz0 * a.sD + a.o0D, iy0 = oy0 * a.sH + a.o0H, ix0 = ox0 * a.sW + a.o0W;
+
+  int* ktab_l = reinterpret_cast<int*>(lds);
+  const int ktab_bytes = (a.steps_per_group * 16 + 15) & ~15;
+  unsigned char* tile = lds + ktab_bytes;
+  for (int i = tid; i < a.steps_per_group * 4; i += 256) ktab_l[i] = a.ktab[i];
+
+  int vbase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int r = wave * MT + m;
+    const int rz = r / a.TH, ry = r - rz * a.TH;
+    vbase[m] = ((rz * a.sD * a.ITH + ry * a.sH) * a.ITW + lv * a.sW) * a.vsb;
+  }
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* __restrict__ xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * a.CPi;
+  const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
+  const bool border = a.zfill && (iz0 < 0 || iy0 < 0 || ix0 < 0 || iz0 + a.ITD > a.Di || iy0 + a.ITH > a.Hi || ix0 + a.ITW > a.Wi);
+  const int opp_mask = a.opp - 1;
+
+  // ---- DMA job table: job = (plane, tile row, 64-chunk segment); a tile row (ITW voxels x opp octets) is
+  // contiguous in global memory and in its LDS plane.  Lane L decodes job L (+64k) ONCE; the issue loop then
+  // only broadcasts (v_readlane) the row's element offset and LDS offset: the scalar unit is shared by every
+  // wave of the CU, per-job scalar index arithmetic serialises there.
+  int job_goff[2], job_loff[2];          // up to 128 jobs per group (host-checked)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int j = k * 64 + lane;
+    j = j < P.njobs ? j : P.njobs - 1;
+    const uint32_t prow = fdiv(j, P.d_segs);
+    const int seg = j - prow * P.segs_per_row;
+    const uint32_t pl = fdiv(prow, P.d_rows);
+    const int row = prow - pl * P.nrows;
+    const uint32_t vz = fdiv(row, P.d_ith);
+    const int vy = row - vz * a.ITH;
+    const int cz = min(max(iz0 + (int)vz, 0), a.Di - 1), cy = min(max(iy0 + vy, 0), a.Hi - 1);
+    job_goff[k] = ((cz * a.Hi + cy) * a.Wi) * a.CPi + (int)pl * a.opp * 8;     // elements; the x / octet part is per lane
+    job_loff[k] = (int)pl * a.plane_bytes + row * P.row_chunks * 16 + seg * 1024 + (seg << 24);   // seg kept in the top byte
+  }
+  STAMP(0);
+  for (int grp = 0; grp < a.ngroups; ++grp) {
+    if (grp > 0) __syncthreads();
+    const int oct0 = grp * a.octs_per_group;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int nj = min(64, P.njobs - k * 64);
+      for (int j = wave; j < nj; j += 4) {
+        const int goff = __builtin_amdgcn_readlane(job_goff[k], j);
+        const int lo = __builtin_amdgcn_readlane(job_loff[k], j);
+        const int seg = lo >> 24;
+        const int ch = seg * 64 + lane;
+        if (ch < P.row_chunks) {
+          const int cx = min(max(ix0 + (ch >> P.log2_opp), 0), a.Wi - 1);
+          const bf16_t* src = xin + goff + (cx * a.CPi + (oct0 + (ch & opp_mask)) * 8);
+#ifndef SP_NO_DMA
+          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + (lo & 0xffffff)), 16, 0, 0);
+#endif
+        }
+      }
+    }
+    // ---- weight fragments of this group: resident (KS > 0) or first step of the prefetch chain ------------
+    const size_t gstep0 = (size_t)grp * a.steps_per_group;
+    const size_t fstride = (size_t)a.NTtot * 64;
+    const bf16x8* wp = wf_hi + (gstep0 * a.NTtot + nt0) * 64 + lane;
+    bf16x8 wreg[KS > 0 ? KS : 1][NT];
+    bf16x8 wa0[NT], wa1[NT];
+    if (KS > 0) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wreg[s][n] = wp[s * fstride + (size_t)n * 64];
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) wa0[n] = wp[(size_t)n * 64];
+    }
+    if (grp == 0) STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (grp == 0) STAMP(2);
+    if (border) {
+      // zero the chunks that lie outside the input volume (padding); LDS byte of chunk i is 16*i
+      for (int r = wave; r < P.nruns; r += 4) {
+        const int i = r * 64 + lane;
+        if (i < P.group_chunks) {
+          const uint32_t pl = fdiv(i, P.d_plane);
+          const int ii = i - pl * P.plane_chunks;
+          const uint32_t vox = (uint32_t)ii >> P.log2_opp;
+          const uint32_t row = fdiv(vox, P.d_itw);
+          const int vx = vox - row * a.ITW;
+          const uint32_t vz = fdiv(row, P.d_ith);
+          const int vy = row - vz * a.ITH;
+          const int gz = iz0 + (int)vz, gy = iy0 + vy, gx = ix0 + vx;
+          if (!((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi))
+            *reinterpret_cast<uint4*>(tile + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+
+    // ---- K loop: the activation fragments of step s+1 are read from LDS while step s runs on the MFMA pipe;
+    // static ping-pong buffers (no register copies)
+    bf16x8 x0[MT], x1[MT];
+#define SP_LDX(dst, koff_)                                                                            \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + (koff_));
+#define SP_MMA(wv, xv)                                                                                \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                      \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[n], xv[m], acc[n][m], 0, 0, 0);
+    {
+      const int k0 = ktab_l[lg];
+      SP_LDX(x0, k0)
+    }
+    if (KS > 0) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+          const int kn = ktab_l[(s + 1) * 4 + lg];
+          if ((s & 1) == 0) { SP_LDX(x1, kn) } else { SP_LDX(x0, kn) }
+        }
+        if ((s & 1) == 0) { SP_MMA(wreg[s], x0) } else { SP_MMA(wreg[s], x1) }
+      }
+    } else {
+      // steps_per_group is even (host plan): two steps per iteration, fragments of s+1 / s+2 in flight
+      for (int s = 0; s < a.steps_per_group; s += 2) {
+        {
+          const int kn = ktab_l[(s + 1) * 4 + lg];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) wa1[n] = wp[(s + 1) * fstride + (size_t)n * 64];
+          SP_LDX(x1, kn)
+        }
+        SP_MMA(wa0, x0)
+        if (s + 2 < a.steps_per_group) {
+          const int kn = ktab_l[(s + 2) * 4 + lg];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) wa0[n] = wp[(s + 2) * fstride + (size_t)n * 64];
+          SP_LDX(x0, kn)
+        }
+        SP_MMA(wa1, x1)
+      }
+    }
+#undef SP_LDX
+#undef SP_MMA
+  }
+
+  STAMP(3);
+  // ---- epilogue -------------------------------------------------------------------------------------------
+  TOUT* __restrict__ yout = reinterpret_cast<TOUT*>(a.y) + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
+  const int ox = ox0 + lv;
+  int obase[MT];     // element offset of the voxel's channel 0, or -1 when the row/voxel is outside the output
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int r = wave * MT + m;
+    const int rz = r / a.TH, ry = r - rz * a.TH;
+    const int oz = oz0 + rz, oy = oy0 + ry;
+    const bool valid = oz < a.Do && oy < a.Ho && ox < a.Wo;
+    obase[m] = valid ? (((oz * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo : -1;
+  }
+  float s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int c0 = (nt0 + n) * 16 + lg * 4;
+    float bj[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + c0); bj[0] = bb.x; bj[1] = bb.y; bj[2] = bb.z; bj[3] = bb.w; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s1[n][j] = s2[n][j] = 0.f;
+    const bool cok = c0 < a.CPo;
+    const bool full = c0 + 4 <= a.Cout;        // partial channel tiles take the masked path
+    const bool lin = full && (a.act == SP_ACT_LEAKY || a.act == SP_ACT_NONE);
+    const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;
+    const bool want_stats = a.stats != nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      float v[4];
+      if (lin) {
+        // leaky(z) = max(z, slope*z) for 0 <= slope <= 1 ; identity is slope = 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float z = acc[n][m][j] + bj[j]; v[j] = fmaxf(z, slope * z); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = act_fwd(a.act, a.act_param, acc[n][m][j] + bj[j]);
+          v[j] = (c0 + j < a.Cout) ? z : 0.f;
+        }
+      }
+      if (obase[m] >= 0 && cok) {
+#ifdef SP_NO_STORE
+        if (v[0] == 123456.f)
+#endif
+        Store<TOUT>::st4(yout + (size_t)obase[m] + c0, v);
+        if (want_stats) {
+          if (sizeof(TOUT) == 2) {   // statistics of what is stored
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], v[j], s2[n][j]); }
+        }
+      }
+    }
+  }
+  STAMP(4);
+  if (a.stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < NT * 16 * 2; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1 = row16_sum(s1[n][j]), x2 = row16_sum(s2[n][j]);
+        if (lv == 0) {
+          atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1);
+          atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2);
+        }
+      }
+    __syncthreads();
+    // spread the global accumulators over 8 replicas (by workgroup) to keep same-address atomics apart
+    for (int i = tid; i < NT * 16 * 2; i += 256) {
+      const int c = nt0 * 16 + (i >> 1);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+    }
+  }
+  STAMP(5);
+}
+
+template <int NT, int MT, int KS, typename TOUT>
+static int launch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
+  auto kern = conv_igemm_dma_kernel<NT, MT, KS, TOUT>;
+  if (P.a.lds_bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P.a.lds_bytes);
+    if (e != hipSuccess) { sp_set_error("sp_conv3d_igemm(dma): LDS %d: %s", P.a.lds_bytes, hipGetErrorString(e)); return SP_EHIP; }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), P.a.lds_bytes, st, P);
+  SP_CHECK_LAUNCH("sp_conv3d_igemm(dma)");
+  return SP_OK;
+}
+
+template <int NT, int MT, int KS>
+static int launch_out(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
+  if (P.a.dtype_out == SP_F32) return launch_dma<NT, MT, KS, float>(P, grid, st);
+  return launch_dma<NT, MT, KS, bf16_t>(P, grid, st);
+}
+
+// resident-weight variants exist for KS*NT <= 16 and KS in {1, 2, 4, 7, 14}
+template <int NT, int MT>
+static int dispatch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
+  const int ks = P.a.steps_per_group;
+#define SP_KS(K_) if (ks == K_ && K_ * NT <= 16) return launch_out<NT, MT, (K_ * NT <= 16 ? K_ : 0)>(P, grid, st)
+  SP_KS(1); SP_KS(2); SP_KS(4); SP_KS(7); SP_KS(14);
+#undef SP_KS
+  if (ks % 2 != 0) { sp_set_error("sp_conv3d_igemm(dma): run-time K loop needs an even step count (got %d)", ks); return SP_EINVAL; }
+  return launch_out<NT, MT, 0>(P, grid, st);
+}
+
+int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
+  SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 input and no affine on load");
+  SP_CHECK_ARG(a->opp == 1 || a->opp == 2, "sp_conv3d_igemm(dma): octets per plane must be 1 or 2");
+  SP_CHECK_ARG(a->vsb == a->opp * 16 && a->plane_bytes == a->ITD * a->ITH * a->ITW * a->vsb, "sp_conv3d_igemm(dma): planes must be lane-linear (no padding)");
+  SP_CHECK_ARG(a->octs_per_group % a->opp == 0, "sp_conv3d_igemm(dma): group does not consist of whole planes");
+  ConvDmaDev P;
+  P.a = *a;
+  P.log2_opp = a->opp == 2 ? 1 : 0;
+  P.plane_chunks = a->ITD * a->ITH * a->ITW * a->opp;
+  P.group_chunks = P.plane_chunks * (a->octs_per_group / a->opp);
+  P.nruns = (P.group_chunks + 63) / 64;
+  P.row_chunks = a->ITW * a->opp;
+  P.segs_per_row = (P.row_chunks + 63) / 64;
+  P.nrows = a->ITD * a->ITH;
+  P.njobs = (a->octs_per_group / a->opp) * P.nrows * P.segs_per_row;
+  SP_CHECK_ARG(P.njobs <= 128, "sp_conv3d_igemm(dma): %d DMA jobs per group (max 128)", P.njobs);
+  P.d_segs = make_fastdiv(P.segs_per_row);
+  P.d_rows = make_fastdiv(P.nrows);
+  const long need = ((a->steps_per_group * 16 + 15) & ~15) + (long)P.nruns * 1024;
+  SP_CHECK_ARG(need <= a->lds_bytes && a->lds_bytes <= 160 * 1024, "sp_conv3d_igemm(dma): LDS plan too small (need %ld, have %d)", need, a->lds_bytes);
+  P.d_itw = make_fastdiv(a->ITW);
+  P.d_ith = make_fastdiv(a->ITH);
+  P.d_plane = make_fastdiv(P.plane_chunks);
+  P.ntx = (a->Wo + 15) / 16;
+  P.nty = (a->Ho + a->TH - 1) / a->TH;
+  P.ntz = (a->Do + a->TD - 1) / a->TD;
+  P.d_tx = make_fastdiv(P.ntx);
+  P.d_ty = make_fastdiv(P.nty);
+  P.d_tz = make_fastdiv(P.ntz);
+  const uint64_t nblk = (uint64_t)P.ntx * P.nty * P.ntz * a->B;
+  SP_CHECK_ARG(nblk < (1ull << 31), "sp_conv3d_igemm(dma): grid too large");
+  P.nblk = (uint32_t)nblk;
+  dim3 grid(P.nblk, a->NTtot / a->NT);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define SP_CASE(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return dispatch_dma<NT_, MT_>(P, grid, st)
+  SP_CASE(1, 8); SP_CASE(2, 8); SP_CASE(4, 8);
+  SP_CASE(1, 4); SP_CASE(2, 4); SP_CASE(4, 4);
+  SP_CASE(1, 2); SP_CASE(2, 2); SP_CASE(4, 2);
+#undef SP_CASE
+  sp_set_error("sp_conv3d_igemm(dma): no kernel for NT=%d MT=%d", a->NT, a->MT);
+  return SP_EINVAL;
+}

@@ -164,7 +164,7 @@ extern "C" int sp_bn_bwd_reduce(const void* g, const void* x, int32_t dtype, int
 
 // nn.BatchNorm3d (training): normalise with biased batch variance, update running stats with the
 // unbiased one (momentum); eval: running stats.  Pad channels (c >= C) get scale = shift = 0.
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float momentum, float eps, int training, int C, int CP, float* scale, float* shift,
                                    float* mean_out, float* invstd_out) {
@@ -173,8 +173,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; if (mean_out) { mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
   float mean, invstd;
   if (training) {
-    const double m = sums[2 * c] / count;
-    double var = sums[2 * c + 1] / count - m * m;
+    double s1 = 0, s2 = 0;
+    for (int r = 0; r < nrep; ++r) { s1 += sums[((size_t)r * CP + c) * 2]; s2 += sums[((size_t)r * CP + c) * 2 + 1]; }
+    const double m = s1 / count;
+    double var = s2 / count - m * m;
     if (var < 0) var = 0;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -192,13 +194,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
   shift[c] = beta[c] - mean * sc;
   if (mean_out) { mean_out[c] = mean; invstd_out[c] = invstd; }
 }
-extern "C" int sp_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, int32_t training,
                               int32_t C, int32_t CP, float* scale, float* shift, float* mean, float* invstd,
                               sp_stream_t stream) {
   SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP, "sp_bn_finalize: bad arguments");
   SP_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "sp_bn_finalize: missing statistics");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((CP + 63) / 64), dim3(64), 0, ST(stream), sums, count, gamma, beta,
+  SP_CHECK_ARG(nrep >= 1, "sp_bn_finalize: nrep");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((CP + 63) / 64), dim3(64), 0, ST(stream), sums, nrep, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, C, CP, scale, shift, mean, invstd);
   SP_CHECK_LAUNCH("sp_bn_finalize");
   return SP_OK;

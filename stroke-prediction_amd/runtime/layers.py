@@ -14,6 +14,7 @@ from . import plan as P
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+STATS_NREP = 64     # replicas of the conv-epilogue statistics accumulators (spreads same-address fp64 atomics)
 
 
 class Scratch:
@@ -58,13 +59,17 @@ class ConvLayer:
         self.out_dims = tuple(self.fwd_op.y_dims)
         self.fwd = O.ConvRunner(self.fwd_op, device)
         self.count = float(batch * in_dims[0] * in_dims[1] * in_dims[2])
+        # un-padded bf16 convolutions fold the BatchNorm into weights/bias so the tile can be staged by DMA
+        pads = pad if isinstance(pad, (tuple, list)) else (pad,) * 3
+        self.fold = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and max(pads) == 0
+                         and all(s.tile["dma"] for s in self.fwd_op.subs))
         self.scratch = scratch
         if bn_prefix is not None:
             self.scale = torch.zeros(self.cpi, device=device)
             self.shift = torch.zeros(self.cpi, device=device)
             self.mean = torch.zeros(self.cpi, device=device)
             self.invstd = torch.zeros(self.cpi, device=device)
-            self.in_sums_id = scratch.reserve(self.cpi * 2)
+            self.in_sums_id = scratch.reserve(self.cpi * 2 * STATS_NREP)
         else:
             self.scale = self.shift = None
         # backward side is created lazily (inference never pays for it)
@@ -87,14 +92,19 @@ class ConvLayer:
             p = self.bn_prefix
             O.bn_finalize(self.in_sums if training else None, self.count, params[p + ".weight"], params[p + ".bias"],
                           bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
-                          self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd)
+                          self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
             if training:
                 bufs[p + ".num_batches_tracked"].add_(1)
         c = self.conv_prefix
-        self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
         y = self.alloc_out()
-        self.fwd.run(x, y, self.batch, self.scale, self.shift, self.act, self.act_param, out_stats,
-                     dtype_out=self.out_dtype)
+        if self.fold:
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
+            self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
+                         stats_nrep=STATS_NREP)
+        else:
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
+            self.fwd.run(x, y, self.batch, self.scale, self.shift, self.act, self.act_param, out_stats,
+                         dtype_out=self.out_dtype, stats_nrep=STATS_NREP)
         return y
 
     # ---------------------------------------------------------------- backward

@@ -11,6 +11,8 @@ from . import plan as P
 TORCH_DT = {L.SP_BF16: torch.bfloat16, L.SP_F32: torch.float32}
 
 
+USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
+
 # optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
 PROFILE = None
 
@@ -77,19 +79,26 @@ class ConvRunner:
         self.bias = torch.zeros(op.nttot * 16, dtype=torch.float32, device=device)
         self.has_bias = False
 
-    def prep(self, w, b=None):
-        """Re-pack the current fp32 weights (any layout described by the plan's strides) and bias."""
+    def prep(self, w, b=None, fold_scale=None, fold_shift=None):
+        """Re-pack the current fp32 weights (any layout described by the plan's strides) and bias.
+        fold_scale / fold_shift: fold a BatchNorm (x*scale+shift on the input channels) into weights and bias
+        -- exact only for un-padded convolutions."""
         op = self.op
         assert w.dtype == torch.float32 and w.is_contiguous()
         for s in self.subs:
             L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s["kmap"]), s["nsteps"],
-                   op.nttot, ptr(s["hi"]), ptr(s["lo"]), stream())
-        if b is not None:
+                   op.nttot, ptr(s["hi"]), ptr(s["lo"]), ptr(fold_scale), stream())
+        if fold_shift is not None:
+            ntaps = w.numel() // (op.cin * op.cout)
+            L.call("sp_conv_fold_bias", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ntaps, ptr(b), ptr(fold_shift),
+                   ptr(self.bias), op.nttot * 16, stream())
+            self.has_bias = True
+        elif b is not None:
             self.bias[:op.cout].copy_(b.detach())
             self.has_bias = True
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
-            dtype_out=None, use_bias=True):
+            dtype_out=None, use_bias=True, stats_nrep=1):
         op = self.op
         dtype_out = op.dtype if dtype_out is None else dtype_out
         assert x.dtype == TORCH_DT[op.dtype] and y.dtype == TORCH_DT[dtype_out]
@@ -100,6 +109,7 @@ class ConvRunner:
         a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
         a.bias = ptr(self.bias) if (self.has_bias and use_bias) else None
         a.stats = ptr(stats)
+        a.stats_nrep = stats_nrep
         a.dtype_in, a.dtype_out = op.dtype, dtype_out
         a.B = batch
         a.Di, a.Hi, a.Wi = op.in_dims
@@ -120,8 +130,9 @@ class ConvRunner:
             a.ooD, a.ooH, a.ooW = sub.out_off
             a.o0D, a.o0H, a.o0W = sub.o0
             for k in ("TD", "TH", "ITD", "ITH", "ITW", "MT", "ngroups", "octs_per_group", "opp", "vsb",
-                      "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes"):
+                      "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "zfill"):
                 setattr(a, k, t[k])
+            a.dma = int(t["dma"] and in_scale is None and USE_DMA)
             with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout):
                 L.call("sp_conv3d_igemm", C.byref(a), st)
 
@@ -191,8 +202,9 @@ def bn_stats(x, dtype, sums):
     L.call("sp_bn_stats", ptr(x), dtype, nvox, x.shape[-1], ptr(sums), stream())
 
 
-def bn_finalize(sums, count, gamma, beta, rmean, rvar, momentum, eps, training, c, cp, scale, shift, mean, invstd):
-    L.call("sp_bn_finalize", ptr(sums), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
+def bn_finalize(sums, count, gamma, beta, rmean, rvar, momentum, eps, training, c, cp, scale, shift, mean, invstd,
+                nrep=1):
+    L.call("sp_bn_finalize", ptr(sums), nrep, float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), momentum, eps,
            int(training), c, cp, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), stream())
 
 

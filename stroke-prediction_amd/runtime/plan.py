@@ -231,10 +231,24 @@ def _plan_sub(op: ConvOp, sub: SubConv):
         ppg -= 1
     opg = ppg * opp
     ngroups = octs // opg
+    dma = int(op.dtype == 0 and vsb == opp * 16)
+    if dma:   # the DMA kernel's job table holds 128 (plane, row, segment) jobs per group
+        jobs_per_plane = itd * ith * (-(-(itw * opp) // 64))
+        while ppg > 1 and (ppg * jobs_per_plane > 128 or nplanes_total % ppg):
+            ppg -= 1
+        if ppg * jobs_per_plane > 128:
+            dma = 0
+        opg = ppg * opp
+        ngroups = octs // opg
     seq = [(ti, oc) for ti in range(len(sub.taps)) for oc in range(opg)]
     while len(seq) % 4:
         seq.append(None)
     steps = len(seq) // 4
+    nt_guess = _pick_nt(-(-op.cout // 16))[0]
+    resident = steps in (1, 2, 4, 7, 14) and steps * nt_guess <= 16
+    if dma and not resident and steps % 2:      # run-time K loop of the DMA kernel works on step pairs
+        seq += [None] * 4
+        steps += 1
     ktab = np.zeros(steps * 4, dtype=np.int32)
     kmap = np.full(ngroups * steps * 4, -1, dtype=np.int32)
     for i, e in enumerate(seq):
@@ -247,12 +261,16 @@ def _plan_sub(op: ConvOp, sub: SubConv):
             kmap[g * steps * 4 + i] = (t[3] << 16) | (g * opg + oc)
     ktab_bytes = (steps * 16 + 15) // 16 * 16
     tile_bytes = ppg * plane_bytes
-    lds = ktab_bytes + tile_bytes * np_planes
+    # LDS-DMA staging (bf16 fast path) needs lane-linear planes; zero-fill when taps can leave the volume
+    zfill = int(any(sub.o0[a] < 0 or (sub.out_dims[a] - 1) * s[a] + sub.o0[a] + ext[a] > op.in_dims[a]
+                    for a in range(3)))
+    lds = ktab_bytes + tile_bytes * np_planes + (1024 if dma else 0)
     lds = max(lds, 4 * 16 * 2 * 4)
     assert lds <= 160 * 1024, "LDS plan does not fit: %d bytes" % lds
     sub.tile = dict(MT=mt, TD=td, TH=th, ITD=itd, ITH=ith, ITW=itw, opp=opp, vsb=vsb, plane_bytes=plane_bytes,
                     octs_per_group=opg, ngroups=ngroups, steps_per_group=steps,
-                    lo_offset=tile_bytes if np_planes == 2 else 0, lds_bytes=lds, read_cycles=cost(vs))
+                    lo_offset=tile_bytes if np_planes == 2 else 0, lds_bytes=lds, read_cycles=cost(vs),
+                    dma=dma, zfill=zfill)
     sub.kmap, sub.ktab = kmap, ktab
 
 

@@ -98,6 +98,20 @@ def test_conv_fwd_dgrad_wgrad(dtype, cin, cout, k, s, p, dims, B):
     if cpo > cout:
         assert float(y[..., cout:].float().abs().max()) == 0.0
 
+    # ---- un-padded convolutions: BatchNorm folded into weights/bias + LDS-DMA staging (bf16 fast path)
+    if dtype == L.SP_BF16 and max(p) == 0 and all(sub.tile["dma"] for sub in op.subs):
+        run.prep(w.to(DEV), b.to(DEV), sc, sh)
+        y2 = O.alloc_cl(B, op.y_dims, cpo, dtype, DEV)
+        stats2 = torch.zeros(cpo, 2, dtype=torch.float64, device=DEV)
+        run.run(xs, y2, B, None, None, L.ACT_LEAKY, 0.01, stats2)
+        ref2 = F.leaky_relu(F.conv3d(x, rnd(dtype, w * scale.view(1, -1, 1, 1, 1)), None, stride=s, padding=p)
+                            + (b + (w * shift.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))).view(1, -1, 1, 1, 1), 0.01)
+        got2 = from_cl(y2, cout, dtype)
+        torch.testing.assert_close(got2, ref2, **TOL[dtype])
+        torch.testing.assert_close(got2, yref.detach(), rtol=5e-2, atol=5e-2)     # and it is the same function
+        torch.testing.assert_close(stats2.cpu()[:cout, 0], got2.double().sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+        run.prep(w.to(DEV), b.to(DEV))
+
     # ---- data gradient
     dz = rnd(dtype, torch.randn(zref.shape, generator=g))
     gx_ref, gw_ref = torch.autograd.grad(zref, (xr_q, wr), dz)
