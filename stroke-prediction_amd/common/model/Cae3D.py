@@ -1,0 +1,227 @@
+"""Drop-in convolutional auto-encoder (reference ``common/model/Cae3D.py``): ``Enc3D``, ``Dec3D``, ``Cae3D``
+with the reference constructors, ``forward(dto) -> dto``, ``freeze`` and ``state_dict`` keys
+(``encoder.{0,1,3,4,...}``, ``decoder.{...}``; ``enc.`` / ``dec.`` prefixes under ``Cae3D``).
+
+The ``torch.nn`` members are parameter containers; every encoder / decoder call is one
+``torch.autograd.Function`` running the fused HIP units of ``runtime.cae_engine`` (BatchNorm applied on
+the operand load, ELU / Sigmoid and the next layer's batch statistics fused into the conv epilogues,
+strided and transposed convolutions through the same table-driven implicit-GEMM kernel).  The latent
+interpolation (Cae3D.py:78-89) stays a three-operand torch expression on B x 800 x 1 x 10 x 10 values.
+``Enc3DStep`` / ``Enc3DCtp`` (learned step, CTP-conditioned encoder) are outside the accelerated path.
+"""
+import weakref
+
+import torch
+import torch.nn as nn
+
+import common.dto.CaeDto as CaeDtoUtil
+from common.dto.CaeDto import CaeDto
+from stroke_prediction_amd.runtime import lib as _L
+from stroke_prediction_amd.runtime.flat import FlatParamsMixin
+
+
+def _containers(table, cm):
+    mods = {}
+    for i, (kind, ci, co, k, s, p) in enumerate(table):
+        mods[str(3 * i)] = nn.BatchNorm3d(cm[ci])
+        if kind == "conv":
+            mods[str(3 * i + 1)] = nn.Conv3d(cm[ci], cm[co], k, stride=s, padding=p)
+        else:
+            mods[str(3 * i + 1)] = nn.ConvTranspose3d(cm[ci], cm[co], k, stride=s, padding=p, output_padding=0)
+    return nn.ModuleDict(mods)
+
+
+class _StackFn(torch.autograd.Function):
+    """One encoder or decoder call.  ``x`` needs a gradient only for the decoder (the latent)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        key, sc = module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device)
+        out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training)
+        ctx.module, ctx.key, ctx.sc = module, key, sc
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        module, sc = ctx.module, ctx.sc
+        (out,) = ctx.saved_tensors
+        names, views, inplace = module._grad_targets()
+        dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
+        module._pool().release(ctx.key, sc)
+        return (None, dx) + tuple(None if inplace else v for v in views)
+
+
+class CaeBase(FlatParamsMixin, nn.Module):
+    def __init__(self, size_input_xy=128, size_input_z=28, channels=[1, 16, 32, 64, 128, 1024, 128, 1], n_ch_global=2,
+                 alpha=0.01, inner_xy=12, inner_z=3, dtype="bf16"):
+        super().__init__()
+        assert size_input_xy % 4 == 0 and size_input_z % 4 == 0
+        self.channels = list(channels)
+        self.n_ch_origin = channels[1]
+        self.n_ch_down2x = channels[2]
+        self.n_ch_down4x = channels[3]
+        self.n_ch_down8x = channels[4]
+        self.n_ch_fc = channels[5]
+        self._inner_ch = self.n_ch_down8x
+        self._inner_xy = inner_xy
+        self._inner_z = inner_z
+        self.n_ch_global = n_ch_global
+        self.n_input = channels[0]
+        self.n_classes = channels[-1]
+        self.alpha = alpha
+        self.compute_dtype = dtype
+        self._stack_pool = None
+
+    # ------------------------------------------------------------------ HIP plumbing
+    _TABLE, _PREFIX, _LAST_SIGMOID = None, None, False
+
+    def _dtype_code(self):
+        return _L.SP_BF16 if self.compute_dtype == "bf16" else _L.SP_F32
+
+    def _pool(self):
+        from stroke_prediction_amd.runtime.cae_engine import StackPool
+        if self._stack_pool is None:
+            self._stack_pool = StackPool(self._TABLE, self._PREFIX, self.channels, self.alpha, self._LAST_SIGMOID)
+        return self._stack_pool
+
+    def _run_stack(self, x):
+        if x is None:
+            return None
+        if not x.is_cuda or not next(self.parameters()).is_cuda:
+            raise RuntimeError("%s (stroke_prediction_amd) runs on the MI355X HIP path only: move the model and its "
+                               "inputs to the GPU; there is no CPU fallback" % type(self).__name__)
+        self._ensure_flat()
+        if x.dtype != torch.float32:
+            x = x.float()
+        params = [p for _, p in self.named_parameters()]
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+            return _StackFn.apply(self, x, *params)
+        key, sc = self._pool().acquire(x.shape[0], tuple(x.shape[2:]), self._dtype_code(), x.device)
+        out = sc.forward(x, self._param_dict(), self._buffer_dict(), self.training)
+        self._pool().release(key, sc)
+        return out
+
+    def _grad_targets(self):
+        # an encoder / decoder runs 3-4 times per step: never hand the shared flat views to autograd twice
+        names, views, inplace = super()._grad_targets()
+        if not inplace and self._flat_root() is self:
+            self._flat_grad.zero_()
+            views = [torch.zeros_like(v) for v in views]
+        return names, views, inplace
+
+    def freeze(self, freeze=False):
+        requires_grad = not freeze
+        for param in self.parameters():
+            param.requires_grad = requires_grad
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_stack_pool"] = None
+        state["_flat_parent"] = None
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device"):
+            state.pop(k, None)
+        return state
+
+
+class Enc3D(CaeBase):
+    from stroke_prediction_amd.runtime.cae_engine import ENC_LAYERS as _TABLE
+    _PREFIX = "encoder"
+
+    def __init__(self, size_input_xy, size_input_z, channels, n_ch_global, alpha, dtype="bf16"):
+        super().__init__(size_input_xy, size_input_z, channels, n_ch_global, alpha, inner_xy=10, inner_z=3, dtype=dtype)
+        from stroke_prediction_amd.runtime.cae_engine import channel_map
+        self.encoder = _containers(self._TABLE, channel_map(channels))
+
+    def _interpolate(self, latent_core, latent_penu, step):
+        """core + step * (penu - core), per sample (reference Cae3D.py:78-89)."""
+        assert step is not None, 'Step must be given for interpolation!'
+        if latent_core is None or latent_penu is None:
+            return None
+        return latent_core + step * (latent_penu - latent_core)
+
+    def _forward_single(self, input_image):
+        return self._run_stack(input_image)
+
+    def _get_step(self, dto: CaeDto):
+        return dto.given_variables.time_to_treatment
+
+    def forward(self, dto: CaeDto):
+        step = self._get_step(dto)
+        if dto.flag == CaeDtoUtil.FLAG_GTRUTH or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
+            assert dto.latents.gtruth._is_empty()   # do not overwrite earlier results by mistake
+            gt, lat = dto.given_variables.gtruth, dto.latents.gtruth
+            lat.core = self._forward_single(gt.core)
+            lat.penu = self._forward_single(gt.penu)
+            lat.lesion = self._forward_single(gt.lesion)
+            lat.interpolation = self._interpolate(lat.core, lat.penu, step)
+        if dto.flag == CaeDtoUtil.FLAG_INPUTS or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
+            assert dto.latents.inputs._is_empty()
+            inp, lat = dto.given_variables.inputs, dto.latents.inputs
+            lat.core = self._forward_single(inp.core)
+            lat.penu = self._forward_single(inp.penu)
+            lat.interpolation = self._interpolate(lat.core, lat.penu, step)
+        return dto
+
+
+class Dec3D(CaeBase):
+    from stroke_prediction_amd.runtime.cae_engine import DEC_LAYERS as _TABLE
+    _PREFIX = "decoder"
+    _LAST_SIGMOID = True
+
+    def __init__(self, size_input_xy, size_input_z, channels, n_ch_global, alpha, dtype="bf16"):
+        super().__init__(size_input_xy, size_input_z, channels, n_ch_global, alpha, inner_xy=10, inner_z=3, dtype=dtype)
+        from stroke_prediction_amd.runtime.cae_engine import channel_map
+        self.decoder = _containers(self._TABLE, channel_map(channels))
+
+    def _forward_single(self, input_latent):
+        return self._run_stack(input_latent)
+
+    def forward(self, dto: CaeDto):
+        if dto.flag == CaeDtoUtil.FLAG_GTRUTH or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
+            assert dto.reconstructions.gtruth._is_empty()
+            lat, rec = dto.latents.gtruth, dto.reconstructions.gtruth
+            rec.core = self._forward_single(lat.core)
+            rec.penu = self._forward_single(lat.penu)
+            rec.lesion = self._forward_single(lat.lesion)
+            rec.interpolation = self._forward_single(lat.interpolation)
+        if dto.flag == CaeDtoUtil.FLAG_INPUTS or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
+            assert dto.reconstructions.inputs._is_empty()
+            lat, rec = dto.latents.inputs, dto.reconstructions.inputs
+            rec.core = self._forward_single(lat.core)
+            rec.penu = self._forward_single(lat.penu)
+            rec.interpolation = self._forward_single(lat.interpolation)
+        return dto
+
+
+class Cae3D(FlatParamsMixin, nn.Module):
+    """enc -> dec on the same DTO (reference Cae3D.py:242-255); owns the flat parameter / gradient buffers
+    of both halves so one fused Adam launch and one all-reduce cover the whole model."""
+
+    def __init__(self, enc: Enc3D, dec: Dec3D):
+        super().__init__()
+        self.enc = enc
+        self.dec = dec
+        self._adopt()
+
+    def _adopt(self):
+        ref = weakref.ref(self)
+        self.enc._flat_parent = ref
+        self.dec._flat_parent = ref
+
+    def forward(self, dto: CaeDto):
+        self._adopt()
+        dto = self.enc(dto)
+        dto = self.dec(dto)
+        return dto
+
+    def freeze(self, freeze: bool):
+        self.enc.freeze(freeze)
+        self.dec.freeze(freeze)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device"):
+            state.pop(k, None)
+        return state

@@ -1,0 +1,139 @@
+"""Encoder / decoder stacks of the convolutional auto-encoder (``Enc3D.encoder`` Cae3D.py:39-76,
+``Dec3D.decoder`` Cae3D.py:176-220) on the fused HIP units of ``layers.ConvLayer``.
+
+Every encoder/decoder CALL of a training step (three encoder passes, four decoder passes,
+Cae3D.py:105-107,230-233) owns a ``StackContext``: its activations stay alive until that call's
+backward has run, and its BatchNorm batch statistics are its own -- exactly as in the reference, where
+each ``nn.Sequential`` call normalises with the statistics of the tensor it is given.
+"""
+import torch
+
+from . import lib as L
+from . import ops as O
+from .layers import ConvLayer, Scratch
+
+# (kind, cin_key, cout_key, kernel, stride, padding) -- the layer tables of the reference modules
+ENC_LAYERS = [
+    ("conv", "in", "o", 3, 1, (1, 0, 0)), ("conv", "o", "o", 3, 1, (1, 0, 0)),
+    ("conv", "o", "d2", 3, 2, (1, 1, 1)),
+    ("conv", "d2", "d2", 3, 1, (1, 0, 0)), ("conv", "d2", "d2", 3, 1, (1, 0, 0)),
+    ("conv", "d2", "d4", 3, 2, (1, 1, 1)),
+    ("conv", "d4", "d4", 3, 1, (1, 0, 0)), ("conv", "d4", "d4", 3, 1, (1, 0, 0)),
+    ("conv", "d4", "d8", 3, 2, (0, 0, 0)),
+    ("conv", "d8", "fc", 3, 1, (0, 0, 0)),
+]
+DEC_LAYERS = [
+    ("convT", "fc", "d8", 3, 1, (0, 0, 0)), ("convT", "d8", "d4", 3, 2, (0, 0, 0)),
+    ("conv", "d4", "d4", 3, 1, (1, 2, 2)), ("conv", "d4", "d2", 3, 1, (1, 2, 2)),
+    ("convT", "d2", "d2", 2, 2, (0, 0, 0)),
+    ("conv", "d2", "d2", 3, 1, (1, 2, 2)), ("conv", "d2", "o", 3, 1, (1, 2, 2)),
+    ("convT", "o", "o", 2, 2, (0, 0, 0)),
+    ("conv", "o", "o", 3, 1, (1, 2, 2)), ("conv", "o", "o", 3, 1, (1, 2, 2)),
+    ("conv", "o", "o", 1, 1, (0, 0, 0)), ("conv", "o", "cls", 1, 1, (0, 0, 0)),
+]
+
+
+def channel_map(channels):
+    """``CaeBase.__init__`` Cae3D.py:14-26."""
+    return {"in": channels[0], "o": channels[1], "d2": channels[2], "d4": channels[3], "d8": channels[4],
+            "fc": channels[5], "cls": channels[-1]}
+
+
+class StackContext:
+    """One call of an encoder / decoder stack: layers (with their activations), scratch, I/O staging."""
+
+    def __init__(self, table, prefix, channels, alpha, batch, in_dims, dtype, device, last_sigmoid):
+        O.require_gpu()
+        L.load()
+        cm = channel_map(channels)
+        self.batch, self.dtype, self.device = batch, dtype, device
+        self.scratch = sc = Scratch(device)
+        self.layers = []
+        dims = tuple(in_dims)
+        n = len(table)
+        for i, (kind, ci, co, k, s, p) in enumerate(table):
+            last = last_sigmoid and i == n - 1
+            lay = ConvLayer("%s.%d" % (prefix, 3 * i + 1), kind, cm[ci], cm[co], k, s, p, dims, batch, dtype, device, sc,
+                            bn_prefix="%s.%d" % (prefix, 3 * i), conv_prefix="%s.%d" % (prefix, 3 * i + 1),
+                            act=L.ACT_SIGMOID if last else L.ACT_ELU, act_param=0.0 if last else alpha,
+                            out_dtype=L.SP_F32 if last else None, need_input_grad=True)
+            self.layers.append(lay)
+            dims = lay.out_dims
+        self.in_dims, self.out_dims = tuple(in_dims), dims
+        self.cin, self.cout = cm[table[0][1]], cm[table[-1][2]]
+        for lay in self.layers:
+            lay.reserve_bwd_scratch()
+        sc.finalize()
+        self.x0 = O.alloc_cl(batch, in_dims, O.cpad(self.cin), dtype, device)
+        self.out_dtype = self.layers[-1].out_dtype
+
+    def forward(self, x, params, bufs, training):
+        """x: (B, cin, D, H, W) fp32 on the device -> (B, cout, D', H', W') fp32."""
+        assert tuple(x.shape) == (self.batch, self.cin) + self.in_dims, (tuple(x.shape), self.in_dims)
+        self.scratch.zero()
+        O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)
+        if training:
+            O.bn_stats(self.x0, self.dtype, self.layers[0].in_sums)
+        h = self.x0
+        for i, lay in enumerate(self.layers):
+            nxt = self.layers[i + 1].in_sums if (training and i + 1 < len(self.layers)) else None
+            h = lay.forward(h, params, bufs, training, nxt)
+        out = torch.empty((self.batch, self.cout) + self.out_dims, dtype=torch.float32, device=self.device)
+        O.cl_to_ncdhw(h, out, self.out_dtype)
+        return out
+
+    def backward(self, dout, out, params, grads, need_input_grad):
+        """dout = dL/dout (NCDHW fp32).  Accumulates parameter gradients; returns dL/dx (NCDHW fp32) or None."""
+        dt = self.dtype
+        for lay in self.layers:
+            lay._init_bwd()
+        last = self.layers[-1]
+        dout = dout.contiguous()
+        if self.cout <= 8:
+            O.out_grad_to_cl(dout, out, dt, last.act, last.act_param, last.dz, last.dbias_sums)
+        else:
+            # wide outputs (the latent): channels-last copy of the gradient, then the activation derivative
+            if not hasattr(self, "_dy"):
+                self._dy = O.alloc_cl(self.batch, self.out_dims, last.cpo, dt, self.device)
+            O.ncdhw_to_cl(dout, self._dy, dt)
+            O.bn_act_bwd(self._dy, last.y, None, dt, last.act, last.act_param, last.dz, last.dbias_sums)
+        for i in range(len(self.layers) - 1, -1, -1):
+            lay = self.layers[i]
+            x = self.layers[i - 1].y if i > 0 else self.x0
+            g, coef = lay.backward(x, params, grads)
+            if i > 0:
+                prev = self.layers[i - 1]
+                O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums)
+            elif need_input_grad:
+                if not hasattr(self, "_dx"):
+                    self._dx = O.alloc_cl(self.batch, self.in_dims, lay.cpi, dt, self.device)
+                O.bn_act_bwd(g, self.x0, coef, dt, L.ACT_NONE, 0.0, self._dx, None)
+                dx = torch.empty((self.batch, self.cin) + self.in_dims, dtype=torch.float32, device=self.device)
+                O.cl_to_ncdhw(self._dx, dx, dt)
+                return dx
+        return None
+
+
+class StackPool:
+    """Contexts keyed by (batch, input dims, dtype, device); a context is busy from its forward until its
+    backward (or immediately released when no gradient is recorded)."""
+
+    def __init__(self, table, prefix, channels, alpha, last_sigmoid):
+        self.table, self.prefix, self.channels, self.alpha, self.last_sigmoid = table, prefix, channels, alpha, last_sigmoid
+        self.free = {}
+
+    def acquire(self, batch, in_dims, dtype, device):
+        key = (batch, tuple(in_dims), dtype, str(device))
+        lst = self.free.setdefault(key, [])
+        if lst:
+            return key, lst.pop()
+        return key, StackContext(self.table, self.prefix, self.channels, self.alpha, batch, in_dims, dtype, device,
+                                 self.last_sigmoid)
+
+    def release(self, key, ctx):
+        lst = self.free.setdefault(key, [])
+        if len(lst) < 8:
+            lst.append(ctx)
+
+    def clear(self):
+        self.free = {}

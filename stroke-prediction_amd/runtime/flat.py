@@ -15,13 +15,19 @@ class FlatParamsMixin:
     _flat_names = None
     _flat_device = None
     grad_sync = None            # optional callable(flat_grad) -> None, installed by parallel.DataParallelSync
+    _flat_parent = None         # set on sub-modules whose parameters live in a parent's flat buffer (Cae3D)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._flat_param = None       # .cuda()/.cpu()/.float() re-created the storages: re-flatten lazily
         return out
 
+    def _flat_root(self):
+        return self if self._flat_parent is None else self._flat_parent()._flat_root()
+
     def _ensure_flat(self):
+        if self._flat_parent is not None:
+            return self._flat_root()._ensure_flat()
         named = list(self.named_parameters())
         dev = named[0][1].device
         if self._flat_param is not None and self._flat_device == dev and \
@@ -61,6 +67,16 @@ class FlatParamsMixin:
         buffer -> kernels accumulate there and autograd gets ``None``; otherwise the flat buffer is zeroed,
         filled, and its views are handed to autograd (which adopts them as ``p.grad``)."""
         self._ensure_flat()
+        root = self._flat_root()
+        if root is not self:
+            # a sub-module of a flat parent: its own parameters' slices of the parent's gradient buffer
+            vmap = {id(p): v for (_, p), v in zip(root.named_parameters(), root._flat_views)}
+            named = list(self.named_parameters())
+            views = [vmap[id(p)] for _, p in named]
+            inplace = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for (_, p), v in zip(named, views))
+            if not inplace:      # cannot zero the shared buffer here (other sub-modules accumulate into it)
+                views = [torch.zeros_like(v) for v in views]
+            return [n for n, _ in named], views, inplace
         params = [p for _, p in self.named_parameters()]
         inplace = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() and p.grad.shape == v.shape
                       for p, v in zip(params, self._flat_views))
@@ -74,4 +90,5 @@ class FlatParamsMixin:
 
     def flat_buffers(self):
         self._ensure_flat()
-        return self._flat_param, self._flat_grad
+        root = self._flat_root()
+        return root._flat_param, root._flat_grad

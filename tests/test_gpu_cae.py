@@ -1,0 +1,158 @@
+"""End-to-end CAE parity on the GPU: drop-in ``Enc3D`` / ``Dec3D`` / ``Cae3D`` (HIP path) through the
+reference-shaped ``CaeReconstructionLearner`` vs the CPU oracle and the fixtures recorded from the real
+reference.  ELU(alpha=1) is C1, so unlike the U-Net there is no derivative kink: gradients are compared
+in relative L2 for both precisions."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, weights as W
+from stroke_prediction_amd.common.model.Cae3D import Cae3D, Enc3D, Dec3D
+from stroke_prediction_amd.common.metrics import BatchDiceLoss
+from stroke_prediction_amd.learner.CaeReconstructionLearner import CaeReconstructionLearner
+from stroke_prediction_amd.optim import FusedAdam
+
+DEV = "cuda:0"
+CH = [1, 16, 24, 32, 100, 200, 1]
+
+
+class _Loader:
+    batch_size = 2
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
+def build(ch, seed, dtype, d, hw):
+    cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype=dtype), Dec3D(hw, d, ch, 5, 1.0, dtype=dtype))
+    cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+    return cae.to(DEV)
+
+
+def learner_for(cae, batches, lr=1e-3):
+    opt = FusedAdam([p for p in cae.parameters() if p.requires_grad], lr=lr, weight_decay=1e-5, betas=(0.9, 0.999))
+    return CaeReconstructionLearner(_Loader(batches), None, cae, opt, None, n_epochs=1, path_previous_base=None,
+                                    path_outputs_base="/tmp/_cae_test", criterion=BatchDiceLoss([1.0]), verbose=False), opt
+
+
+def oracle_step(ch, seed, labels, clinical, epoch):
+    sd = W.make_state_dict(W.cae_spec(ch), seed)
+    names = nets.trainable(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    step = nets.time_to_treatment(clinical)
+    core, penu, lesion = labels[:, 0:1], labels[:, 1:2], labels[:, 2:3]
+    lat, rec = nets.cae_forward(sd, core, penu, lesion, step, alpha=1.0, training=True)
+    loss = nets.cae_loss(lat, rec, core, penu, lesion, epoch)
+    grads = torch.autograd.grad(loss, [sd[k] for k in names])
+    return lat, rec, loss.item(), dict(zip(names, grads)), sd
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("dtype,tol_out,tol_grad", [("f32", 2e-4, 5e-3), ("bf16", 5e-2, 0.12)])
+def test_cae_train_step_matches_oracle(dtype, tol_out, tol_grad):
+    seed, d, hw, epoch = 21, 28, 64, 30
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    lat_ref, rec_ref, loss_ref, g_ref, sd_ref = oracle_step(CH, seed, labels, clinical, epoch)
+    cae = build(CH, seed, dtype, d, hw).train()
+    learner, opt = learner_for(cae, [])
+    batch = {"case_id": [0, 1], "images": None, "labels": labels, "clinical": clinical}
+    dto = learner.inference_step(batch)
+    np.testing.assert_allclose(dto.given_variables.time_to_treatment.cpu().numpy(),
+                               nets.time_to_treatment(clinical).numpy(), rtol=1e-6)
+    for k in ("core", "penu", "lesion", "interpolation"):
+        lat = getattr(dto.latents.gtruth, k).detach().cpu()
+        rec = getattr(dto.reconstructions.gtruth, k).detach().cpu()
+        assert rel_l2(lat, lat_ref[k].detach()) < tol_out * 5, k
+        torch.testing.assert_close(rec, rec_ref[k].detach(), rtol=0, atol=tol_out)
+    loss = learner.loss_step(dto, epoch)
+    assert abs(float(loss) - loss_ref) < (2e-5 if dtype == "f32" else 3e-3)
+    opt.zero_grad()
+    loss.backward()
+    bad = [(n, rel_l2(p.grad.cpu(), g_ref[n])) for n, p in cae.named_parameters()
+           if rel_l2(p.grad.cpu(), g_ref[n]) > tol_grad]
+    assert not bad, bad
+    for n, b in cae.named_buffers():
+        if n.endswith("num_batches_tracked"):
+            assert int(b) == (3 if n.startswith("enc.") else 4)          # Cae3D.py:105-107,230-233
+        else:
+            torch.testing.assert_close(b.cpu(), sd_ref[n], rtol=5e-3 if dtype == "f32" else 5e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("fname", ["cae_200.npz", "cae_800.npz"])
+def test_cae_matches_reference_fixture(golden_dir, fname):
+    """Parity mode against latents / reconstructions / losses / gradient norms recorded from the reference's own
+    CaeReconstructionLearner.inference_step + loss_step at the native 28 x 128 x 128 size."""
+    fx = np.load(os.path.join(golden_dir, fname))
+    ch, seed = [int(c) for c in fx["channels"]], int(fx["seed"])
+    d, hw = int(fx["d"]), int(fx["hw"])
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    cae = build(ch, seed, "f32", d, hw).train()
+    learner, opt = learner_for(cae, [])
+    learner.adapt_betas(0)
+    assert abs(opt.param_groups[0]["betas"][0] - float(fx["betas_epoch0"][0])) < 1e-12
+    dto = learner.inference_step({"case_id": [0, 1], "images": None, "labels": labels, "clinical": clinical})
+    for k in ("core", "penu", "lesion", "interpolation"):
+        lat = getattr(dto.latents.gtruth, k).detach().cpu()
+        rec = getattr(dto.reconstructions.gtruth, k).detach().cpu()
+        np.testing.assert_allclose(lat.reshape(2, -1)[:, :64].numpy(), fx["lat_head/" + k], rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(rec[:, 0, d // 2, 60:68, 60:68].numpy(), fx["rec_crop/" + k], rtol=0, atol=2e-4)
+    for ep in (0, 30, 60):
+        assert abs(float(learner.loss_step(dto, ep)) - float(fx["loss_epoch/%d" % ep])) < 2e-5
+    loss = learner.loss_step(dto, 30)
+    opt.zero_grad()
+    loss.backward()
+    for n, p in cae.named_parameters():
+        gn = float(fx["gnorm/" + n])
+        tol = 5e-3 if p.numel() > 16 else 2e-2      # 1..16-element bias/BN gradients are sums over ~1e6 voxels
+        assert abs(float(p.grad.double().norm()) - gn) <= tol * gn + 1e-9, n
+    opt.step()
+    for n, p in list(cae.named_parameters())[:8]:
+        np.testing.assert_allclose(p.detach().reshape(-1)[:8].cpu().numpy(), fx["phead1/" + n], rtol=1e-3, atol=3e-5)
+
+
+def test_cae_learner_trains():
+    """Three optimiser steps through Learner.train_batch: loss follows the oracle trajectory."""
+    seed, d, hw = 23, 28, 64
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    batch = {"case_id": [0, 1], "images": None, "labels": labels, "clinical": clinical}
+    # oracle trajectory (fp32 CPU, torch.optim.Adam semantics restated in nets.adam_step)
+    sd = W.make_state_dict(W.cae_spec(CH), seed)
+    names = nets.trainable(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    m = [torch.zeros_like(sd[k]) for k in names]
+    v = [torch.zeros_like(sd[k]) for k in names]
+    ref_losses = []
+    core, penu, lesion = labels[:, 0:1], labels[:, 1:2], labels[:, 2:3]
+    for step in range(3):
+        lat, rec = nets.cae_forward(sd, core, penu, lesion, nets.time_to_treatment(clinical), 1.0, True)
+        loss = nets.cae_loss(lat, rec, core, penu, lesion, 0)
+        grads = torch.autograd.grad(loss, [sd[k] for k in names])
+        ref_losses.append(loss.item())
+        with torch.no_grad():
+            nets.adam_step([sd[k] for k in names], grads, m, v, step + 1, lr=1e-3, betas=(nets.cae_beta1(0), 0.999),
+                           weight_decay=1e-5)
+    cae = build(CH, seed, "f32", d, hw).train()
+    learner, opt = learner_for(cae, [batch])
+    learner.adapt_betas(0)
+    losses = []
+    for step in range(3):
+        mtr = learner.train_batch(batch, 0)
+        losses.append(mtr.loss)
+        assert 0.0 <= mtr.lesion.dc <= 1.0
+    np.testing.assert_allclose(losses, ref_losses, rtol=0, atol=2e-4)
+    assert losses[2] < losses[0]
