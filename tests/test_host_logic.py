@@ -1,0 +1,138 @@
+"""Host-side logic on the CPU: DTOs, metric accumulation, the Learner template (with an oracle-backed stand-in
+for the model -- the product models refuse to run without the GPU), checkpoint naming, evaluation measures."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import stroke_prediction_amd  # noqa: F401
+from oracle import nets, weights as W
+import stroke_prediction_amd.common.dto.MetricMeasuresDto as MM
+import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+import stroke_prediction_amd.common.dto.CaeDto as CaeDtoUtil
+from stroke_prediction_amd.common.dto.Dto import Dto
+from stroke_prediction_amd.common import metrics
+from stroke_prediction_amd.common.model.Unet3D import Unet3D, crop
+from stroke_prediction_amd.learner.Learner import Learner, _encode_metrics, _decode_metrics
+from stroke_prediction_amd.learner.UnetSegmentationLearner import UnetSegmentationLearner
+
+CH = [2, 16, 32, 64, 32, 16, 32, 2]
+
+
+def test_dto_contract():
+    d = UnetDtoUtil.init_dto(torch.zeros(1))
+    assert d.outputs._is_empty() and not d.given_variables._is_empty()
+    assert dict(d.outputs).keys() == {"core", "penu", "lesion"}
+    c = CaeDtoUtil.init_dto(*([None] * 9))
+    assert c.flag == CaeDtoUtil.FLAG_DEFAULT and c.latents.gtruth._is_empty()
+    c.latents.gtruth.core = 1
+    assert not c.latents.gtruth._is_empty() and "[x] core" in str(c.latents.gtruth)
+
+
+def test_metric_accumulators():
+    a, b = MM.init_dto(), MM.init_dto(loss=2.0, core_dc=0.5, core_hd=float("inf"))
+    a.add(b); a.add(b)
+    a.div(2)
+    assert a.loss == 2.0 and a.core.dc == 0.5 and math.isinf(a.core.hd)
+    with pytest.raises(Exception):
+        a.add(Dto())
+    hist = {"training": [a], "validate": [b]}
+    back = _decode_metrics(_encode_metrics(hist))
+    assert back["training"][0].core.dc == 0.5 and math.isinf(back["validate"][0].core.hd)
+
+
+def test_crop_matches_reference_semantics():
+    t, like = torch.arange(7 * 9 * 5.).reshape(1, 1, 7, 9, 5), torch.zeros(1, 1, 3, 4, 5)
+    out = crop(t, like, dims=[2, 3, 4])
+    assert tuple(out.shape) == (1, 1, 3, 4, 5)
+    assert torch.equal(out, t[:, :, 2:5, 2:6, :])       # offset (in - out) // 2, Unet3D.py:10
+
+
+def test_binary_measures():
+    r = np.zeros((8, 8, 8), np.float32); t = np.zeros((8, 8, 8), np.float32)
+    r[2:6, 2:6, 2:6] = 1; t[3:7, 2:6, 2:6] = 1
+    m = metrics.binary_measures_numpy(r, t)
+    assert abs(m.dc - 0.75) < 1e-9 and abs(m.precision - 0.75) < 1e-9 and abs(m.sensitivity - 0.75) < 1e-9
+    assert m.hd == 1.0 and 0 < m.assd < 1.0
+    empty = metrics.binary_measures_numpy(np.zeros((4, 4, 4)), t[:4, :4, :4] * 0)
+    assert math.isinf(empty.hd) and empty.dc == 0.0
+
+
+class _OracleUnet(nn.Module):
+    """CPU stand-in with the product model's interface, computing through the oracle (tests only)."""
+
+    def __init__(self, seed):
+        super().__init__()
+        self.sd = W.make_state_dict(W.unet_spec(CH), seed)
+        self.params = nn.ParameterList([nn.Parameter(self.sd[k]) for k in nets.trainable(self.sd)])
+        for k, p in zip(nets.trainable(self.sd), self.params):
+            self.sd[k] = p
+
+    def forward(self, dto):
+        seg = nets.unet_forward(self.sd, dto.given_variables.input_modalities, training=self.training)
+        dto.outputs.core, dto.outputs.penu = seg[:, 0:1], seg[:, 1:2]
+        return dto
+
+    def freeze(self, freeze=False):
+        for p in self.parameters():
+            p.requires_grad = not freeze
+
+
+class _Loader:
+    batch_size = 2
+
+    def __init__(self, batches):
+        self.b = batches
+
+    def __iter__(self):
+        return iter(self.b)
+
+    def __len__(self):
+        return len(self.b)
+
+
+class _CpuDice(nn.Module):
+    def forward(self, o, t):
+        return nets.batch_dice_loss(o, t)
+
+
+def test_learner_template_runs_two_epochs(tmp_path):
+    """BASELINE configs[0] (plumbing): the Learner loop end to end on the smallest valid volume (44^3)."""
+    x, y = W.unet_inputs(2, 44, 3)
+    batch = {"case_id": [0, 1], "images": x, "labels": y, "clinical": torch.zeros(2, 5, 1, 1, 1)}
+    model = _OracleUnet(3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    base = str(tmp_path / "run")
+    learner = UnetSegmentationLearner(_Loader([batch]), _Loader([batch]), model, opt, None, 2, _CpuDice(),
+                                      path_outputs_base=base)
+    # the stand-in lives on the CPU: keep save_model from calling .cuda()
+    learner.run_training()
+    hist = learner._metric_dtos
+    assert len(hist["training"]) == 2 and len(hist["validate"]) == 2
+    assert hist["training"][1].loss < hist["training"][0].loss
+    assert os.path.exists(base + "_unet.model") and os.path.exists(base + "_unet.optim") and os.path.exists(base + "_unet.json")
+    assert os.path.exists(base + "_unet_final.model")
+    assert learner.path("save", Learner.FNB_MODEL, "_final") == base + "_unet_final.model"
+    assert learner.path("nope", Learner.FNB_MODEL) is None
+    # resume: same history length, start epoch = 2
+    model2 = _OracleUnet(3)
+    opt2 = torch.optim.Adam(model2.parameters(), lr=1e-3)
+    l2 = UnetSegmentationLearner(_Loader([batch]), _Loader([batch]), model2, opt2, None, 2, _CpuDice(),
+                                 path_previous_base=base, path_outputs_base=base)
+    assert l2.get_start_epoch() == 2 and l2.get_start_min_loss() == min(m.loss for m in hist["validate"])
+
+
+def test_learner_requires_batch_gt_1():
+    class L1(_Loader):
+        batch_size = 1
+    with pytest.raises(AssertionError):
+        UnetSegmentationLearner(L1([]), None, _OracleUnet(1), None, None, 1, _CpuDice())
+
+
+def test_product_model_refuses_cpu():
+    model = Unet3D(CH)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(UnetDtoUtil.init_dto(torch.zeros(2, 2, 44, 44, 44)))
