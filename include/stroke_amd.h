@@ -122,8 +122,15 @@ typedef struct sp_wgrad_args {
   int32_t kD, kH, kW;    /* tap offsets satisfy 0 <= offset < k (sizes the staged halo) */
   int32_t CoT, CiT;      /* cout / cin tiles of 16 */
   int32_t nblocks;       /* persistent grid size */
+  int32_t dma;           /* 1: bf16 LDS-DMA double-buffered path (stride 1, padding 0, 3x3x3, no affine on load) */
+  int32_t tile_rows;     /* dma: 0 = choose, else force TZ*TY rows of 32 voxels per tile (tuning knob) */
 } sp_wgrad_args;
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
+/* BatchNorm folded out of the operand load (un-padded convolutions):
+ * dw[co,ci,tap] += scale[ci]*dw_acc[tap][co][ci] + shift[ci]*dbias_sums[co] */
+int sp_wgrad_finish_folded(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                           int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
+                           const float* shift, const double* dbias_sums, float* dw, sp_stream_t stream);
 /* dw[co*sCo + ci*sCi + tapsrc[t]] += dw_acc[t][co][ci] */
 int sp_wgrad_finish(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                     int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw, sp_stream_t stream);

@@ -226,12 +226,15 @@ static int wgrad_dispatch(const WgradDev& P, int COB, int CIB, dim3 grid, int ld
   return SP_EINVAL;
 }
 
+int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream);   // sp_wgrad_dma.hip
+
 extern "C" int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->dz && a->dw_acc && a->taps, "sp_conv3d_wgrad: null pointer");
   SP_CHECK_ARG(a->CPi % 8 == 0 && a->CPo % 8 == 0, "sp_conv3d_wgrad: channel pitch must be a multiple of 8");
   SP_CHECK_ARG(a->ntap >= 1 && a->ntap <= 4 * WG_TAPS_PER_WAVE, "sp_conv3d_wgrad: ntap=%d out of range", a->ntap);
   SP_CHECK_ARG(a->CoT * 16 >= a->CPo && a->CiT * 16 >= a->CPi, "sp_conv3d_wgrad: tile counts too small");
   SP_CHECK_ARG(a->nblocks >= 1, "sp_conv3d_wgrad: nblocks");
+  if (a->dma) return sp_conv3d_wgrad_dma(a, stream);
   WgradDev P;
   P.a = *a;
   // block tile blocking of (cout, cin) tiles: COB*CIB <= 6 accumulator tiles per tap

@@ -1,0 +1,327 @@
+// bf16 fast path of the weight gradient for un-padded, stride-1 3x3x3 convolutions (every Block3x3x3 conv of
+// the U-Net, Unet3D.py:19,22).  Same GEMM view as sp_wgrad.hip (K = 32 output voxels along x, both operands
+// through LDS and ds_read_b64_tr_b16), restructured after the conv kernel's phase analysis:
+//   * persistent workgroups, TWO LDS tile buffers: the LDS-DMA (global_load_lds_dwordx4) of tile t+1 is in
+//     flight while tile t feeds the MFMAs; one barrier per tile;
+//   * the chunk -> (plane, voxel) decode of every DMA a lane issues is tile-invariant: it is done once before the
+//     tile loop (NJ element offsets in registers); per tile a DMA costs one 64-bit add.  Tiles that cross the
+//     output border take a masked path (invalid chunks are written as zeros by ds_write);
+//   * every wave computes exactly 7 taps (wave 3 repeats tap 26 and drops it at the flush): no guards inside the
+//     unrolled MFMA loop (guards make hipcc shuttle accumulators between VGPRs and AGPRs);
+//   * the BatchNorm of the input is NOT applied on load (a DMA cannot): dw = scale[ci]*dw_raw + shift[ci]*sum(dz),
+//     exact for padding 0, applied by sp_wgrad_finish_folded.
+#include "sp_common.h"
+
+#ifdef SP_CONV_STAMPS
+extern __device__ unsigned long long sp_stamp_buf[32768][6];
+#define WSTAMP(var)                                                                           \
+  do {                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");               \
+    __builtin_amdgcn_sched_barrier(0);                                                        \
+  } while (0)
+#endif
+#define WD_TW 7
+#define WD_NJX 12
+#define WD_NJD 4
+#define WD_VSB 32
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
+struct WgradDmaDev {
+  sp_wgrad_args a;
+  FastDiv d_tx, d_ty, d_tz, d_xw, d_xh, d_xv, d_tv, d_ty_rows;
+  uint32_t ntx, nty, ntz, ntiles;
+  int32_t TZ, TY, XD, XH, XW, XV, TV;
+  int32_t nx_chunks, ndz_chunks, njx, njd, buf_bytes, dz_off;
+};
+
+__device__ __forceinline__ bf16x8 wd_tr_read2(const unsigned char* p0, const unsigned char* p1) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  bf16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p0));
+  bf16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p1));
+  return __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int COB, int CIB>
+__global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const sp_wgrad_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lg = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  const int co_t0 = blockIdx.y * COB, ci_t0 = blockIdx.z * CIB;
+  const bf16_t* __restrict__ xg = reinterpret_cast<const bf16_t*>(a.x);
+  const bf16_t* __restrict__ dzg = reinterpret_cast<const bf16_t*>(a.dz);
+
+  // zero both buffers once: chunks of channels beyond the pitch are never written by a DMA
+  for (int i = tid; i < (2 * P.buf_bytes) / 16; i += 256) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+
+  // ---- tile-invariant DMA plan of this lane.  The x region and the dz region are each padded to whole rounds of
+  // 256 chunks, so a DMA instruction never mixes the two tensors: source = wave-uniform tile base (SGPR pair) +
+  // per-lane 32-bit byte offset.  Chunks past the end of a region re-load its last chunk (same bytes, harmless).
+  uint32_t relx[WD_NJX], reld[WD_NJD];     // byte offsets relative to the tile origin
+  int crdx[WD_NJX], crdd[WD_NJD];          // packed tile coordinates (z | y<<8 | x<<16) for the border path
+#pragma unroll
+  for (int j = 0; j < WD_NJX; ++j) {
+    int c = (wave + 4 * j) * 64 + lane;
+    c = c < P.nx_chunks ? c : P.nx_chunks - 1;
+    const int half = c & 1, rest = c >> 1;
+    const uint32_t pl = fdiv(rest, P.d_xv);
+    const uint32_t vox = rest - pl * P.XV;
+    const uint32_t row = fdiv(vox, P.d_xw);
+    const int vx = vox - row * P.XW;
+    const uint32_t vz = fdiv(row, P.d_xh);
+    const int vy = row - vz * P.XH;
+    relx[j] = (uint32_t)(((((int)vz * a.Hi + vy) * a.Wi + vx) * a.CPi + (ci_t0 + (int)pl) * 16 + half * 8) * 2);
+    crdx[j] = (int)vz | (vy << 8) | (vx << 16);
+  }
+#pragma unroll
+  for (int j = 0; j < WD_NJD; ++j) {
+    int c = (wave + 4 * j) * 64 + lane;
+    c = c < P.ndz_chunks ? c : P.ndz_chunks - 1;
+    const int half = c & 1, rest = c >> 1;
+    const uint32_t pl = fdiv(rest, P.d_tv);
+    const uint32_t vox = rest - pl * P.TV;
+    const int rx = vox & 31, row = vox >> 5;
+    const uint32_t rz = fdiv(row, P.d_ty_rows);
+    const int ry = row - rz * P.TY;
+    reld[j] = (uint32_t)(((((int)rz * a.Ho + ry) * a.Wo + rx) * a.CPo + (co_t0 + (int)pl) * 16 + half * 8) * 2);
+    crdd[j] = (int)rz | (ry << 8) | (rx << 16);
+  }
+
+  // per-lane read offsets for the two transposed reads of a K step (quad = 2g+rd for even g, 2g+1-rd for odd g)
+  const int vq0 = ((lg & 1) ? 2 * lg + 1 : 2 * lg) * 4 + lq;
+  const int vq1 = ((lg & 1) ? 2 * lg : 2 * lg + 1) * 4 + lq;
+  const int off0 = vq0 * WD_VSB + lp * 8, off1 = vq1 * WD_VSB + lp * 8;
+  // taps of this wave: exactly WD_TW, indices clamped (the duplicate is dropped at the flush)
+  int tapoff[WD_TW];
+#pragma unroll
+  for (int t = 0; t < WD_TW; ++t) {
+    int ti = wave * WD_TW + t;
+    ti = ti < a.ntap ? ti : a.ntap - 1;
+    const int* tp = a.taps + ti * 3;
+    tapoff[t] = ((tp[0] * P.XH + tp[1]) * P.XW + tp[2]) * WD_VSB;
+  }
+
+  f32x4 acc[WD_TW][COB][CIB];
+#pragma unroll
+  for (int t = 0; t < WD_TW; ++t)
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+      for (int i = 0; i < CIB; ++i) acc[t][c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int xplane = P.XV * WD_VSB, dzplane = P.TV * WD_VSB;
+  __syncthreads();
+
+  // issue the DMAs of one tile into buffer `buf`
+  auto issue = [&](uint32_t tile, int buf) {
+    uint32_t t = tile;
+    uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
+    q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; t = q;
+    q = fdiv(t, P.d_tz); const int tz = t - q * P.ntz; const int b = q;
+    const int oz0 = tz * P.TZ, oy0 = ty * P.TY, ox0 = tx * 32;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xg + ((((size_t)b * a.Di + oz0) * a.Hi + oy0) * a.Wi + ox0) * a.CPi);
+    const unsigned char* db = reinterpret_cast<const unsigned char*>(dzg + ((((size_t)b * a.Do + oz0) * a.Ho + oy0) * a.Wo + ox0) * a.CPo);
+    const bool interior = oz0 + P.TZ <= a.Do && oy0 + P.TY <= a.Ho && ox0 + 32 <= a.Wo;
+    unsigned char* base = lds + buf * P.buf_bytes;
+    unsigned char* dbase = base + P.dz_off;
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < WD_NJX; ++j)
+        if (j < P.njx) __builtin_amdgcn_global_load_lds((gbl_void*)(xb + relx[j]), (lds_void*)(base + (wave + 4 * j) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < WD_NJD; ++j)
+        if (j < P.njd) __builtin_amdgcn_global_load_lds((gbl_void*)(db + reld[j]), (lds_void*)(dbase + (wave + 4 * j) * 1024), 16, 0, 0);
+    } else {
+      // border tile: chunks whose voxel lies outside the output grid (dz) or outside the input volume (x) are zeros
+#pragma unroll
+      for (int j = 0; j < WD_NJX; ++j) {
+        if (j < P.njx) {
+          const int cz = crdx[j] & 0xff, cy = (crdx[j] >> 8) & 0xff, cx = (crdx[j] >> 16) & 0xff;
+          unsigned char* dst = base + (wave + 4 * j) * 1024;
+          if (oz0 + cz < a.Di && oy0 + cy < a.Hi && ox0 + cx < a.Wi)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(xb + relx[j]), (lds_void*)dst, 16, 0, 0);
+          else
+            *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < WD_NJD; ++j) {
+        if (j < P.njd) {
+          const int cz = crdd[j] & 0xff, cy = (crdd[j] >> 8) & 0xff, cx = (crdd[j] >> 16) & 0xff;
+          unsigned char* dst = dbase + (wave + 4 * j) * 1024;
+          if (oz0 + cz < a.Do && oy0 + cy < a.Ho && ox0 + cx < a.Wo)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(db + reld[j]), (lds_void*)dst, 16, 0, 0);
+          else
+            *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  uint32_t tile = blockIdx.x;
+  int cur = 0;
+  if (tile < P.ntiles) issue(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int nrows = P.TZ * P.TY;
+#ifdef SP_CONV_STAMPS
+  unsigned long long t0, t1, t2, t3, s_issue = 0, s_comp = 0, s_wait = 0, ntl = 0;
+#endif
+  for (; tile < P.ntiles; tile += gridDim.x) {
+    const uint32_t nxt = tile + gridDim.x;
+#ifdef SP_CONV_STAMPS
+    WSTAMP(t0);
+#endif
+    if (nxt < P.ntiles) issue(nxt, cur ^ 1);
+#ifdef SP_CONV_STAMPS
+    WSTAMP(t1);
+#endif
+
+    const unsigned char* xt = lds + cur * P.buf_bytes;
+    const unsigned char* dzt = xt + P.dz_off;
+    for (int row = 0; row < nrows; ++row) {
+      const uint32_t rz = fdiv(row, P.d_ty_rows);
+      const int ry = row - rz * P.TY;
+      const unsigned char* arow = dzt + row * 32 * WD_VSB;
+      const unsigned char* brow = xt + (((int)rz * P.XH + ry) * P.XW) * WD_VSB;
+      bf16x8 af[COB];
+#pragma unroll
+      for (int c = 0; c < COB; ++c) af[c] = wd_tr_read2(arow + c * dzplane + off0, arow + c * dzplane + off1);
+#pragma unroll
+      for (int tt = 0; tt < WD_TW; ++tt) {
+#pragma unroll
+        for (int i = 0; i < CIB; ++i) {
+          const unsigned char* bp = brow + i * xplane + tapoff[tt];
+          const bf16x8 bf = wd_tr_read2(bp + off0, bp + off1);
+#pragma unroll
+          for (int c = 0; c < COB; ++c)
+            acc[tt][c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[tt][c][i], 0, 0, 0);
+        }
+      }
+    }
+#ifdef SP_CONV_STAMPS
+    WSTAMP(t2);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed (it had the whole compute phase)
+    __syncthreads();                                    // and everyone is done reading the current one
+#ifdef SP_CONV_STAMPS
+    WSTAMP(t3);
+    s_issue += t1 - t0; s_comp += t2 - t1; s_wait += t3 - t2; ntl += 1;
+#endif
+    cur ^= 1;
+  }
+#ifdef SP_CONV_STAMPS
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    sp_stamp_buf[blockIdx.x][0] = s_issue; sp_stamp_buf[blockIdx.x][1] = s_comp; sp_stamp_buf[blockIdx.x][2] = s_wait;
+    sp_stamp_buf[blockIdx.x][3] = ntl;
+  }
+#endif
+
+  // ---- flush: D[row = co = lg*4+j][col = ci = li] -> dw_acc[tap][co][ci] ---------------------------------------
+  const int CoP = a.CoT * 16, CiP = a.CiT * 16;
+#pragma unroll
+  for (int tt = 0; tt < WD_TW; ++tt) {
+    const int tap = wave * WD_TW + tt;
+    if (tap < a.ntap) {
+#pragma unroll
+      for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int i = 0; i < CIB; ++i) {
+          if (co_t0 + c < a.CoT && ci_t0 + i < a.CiT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int co = (co_t0 + c) * 16 + lg * 4 + j, ci = (ci_t0 + i) * 16 + li;
+              atomicAdd(&a.dw_acc[((size_t)tap * CoP + co) * CiP + ci], acc[tt][c][i][j]);
+            }
+          }
+        }
+    }
+  }
+}
+
+int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
+  SP_CHECK_ARG(a->dtype == SP_BF16 && !a->in_scale && !a->dz_scale, "sp_conv3d_wgrad(dma): bf16, no affine on load");
+  SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->o0D == 0 && a->o0H == 0 && a->o0W == 0, "sp_conv3d_wgrad(dma): stride 1, padding 0 only");
+  SP_CHECK_ARG(a->ntap > 21 && a->ntap <= 28, "sp_conv3d_wgrad(dma): expects 22..28 taps (7 per wave)");
+  SP_CHECK_ARG(a->Di == a->Do + a->kD - 1 && a->Hi == a->Ho + a->kH - 1 && a->Wi == a->Wo + a->kW - 1, "sp_conv3d_wgrad(dma): not an un-padded convolution");
+  WgradDmaDev P;
+  P.a = *a;
+  int COB = a->CoT >= 4 ? 4 : (a->CoT >= 2 ? 2 : 1);
+  int CIB = a->CiT >= 3 ? 3 : a->CiT;
+  if (COB == 4) CIB = 1;
+  // tile rows: the largest TZ x TY whose two buffers fit 150 KiB and whose chunk count fits the per-lane plan
+  SP_CHECK_ARG(a->CPi % 16 == 0 && a->CPo % 16 == 0, "sp_conv3d_wgrad(dma): channel pitches must be multiples of 16");
+  // tile rows: two buffers per workgroup; prefer a shape that lets TWO workgroups share a CU (<= 75 KiB each) so
+  // that every SIMD has two waves to overlap LDS latency with MFMA issue
+  static const int cand[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+  bool found = false;
+  for (int pass = 0; pass < 2 && !found; ++pass) {
+    for (auto& cz : cand) {
+      if (a->tile_rows > 0 && cz[0] * cz[1] != a->tile_rows) continue;
+      P.TZ = cz[0]; P.TY = cz[1];
+      P.XD = P.TZ - 1 + a->kD; P.XH = P.TY - 1 + a->kH; P.XW = 31 + a->kW;
+      P.XV = P.XD * P.XH * P.XW; P.TV = P.TZ * P.TY * 32;
+      P.nx_chunks = CIB * P.XV * 2; P.ndz_chunks = COB * P.TV * 2;
+      P.njx = (P.nx_chunks + 255) / 256; P.njd = (P.ndz_chunks + 255) / 256;
+      P.dz_off = P.njx * 256 * 16;
+      P.buf_bytes = P.dz_off + P.njd * 256 * 16;
+      const int limit = (pass == 0 && a->tile_rows == 0) ? 75 * 1024 : 150 * 1024;
+      if (P.njx <= WD_NJX && P.njd <= WD_NJD && 2 * P.buf_bytes <= limit) { found = true; break; }
+    }
+  }
+  SP_CHECK_ARG(found, "sp_conv3d_wgrad(dma): no tile fits");
+  P.ntx = (a->Wo + 31) / 32; P.nty = (a->Ho + P.TY - 1) / P.TY; P.ntz = (a->Do + P.TZ - 1) / P.TZ;
+  P.d_tx = make_fastdiv(P.ntx); P.d_ty = make_fastdiv(P.nty); P.d_tz = make_fastdiv(P.ntz);
+  P.d_xw = make_fastdiv(P.XW); P.d_xh = make_fastdiv(P.XH); P.d_xv = make_fastdiv(P.XV); P.d_tv = make_fastdiv(P.TV);
+  P.d_ty_rows = make_fastdiv(P.TY);
+  const uint64_t nt = (uint64_t)P.ntx * P.nty * P.ntz * a->B;
+  SP_CHECK_ARG(nt < (1ull << 31), "sp_conv3d_wgrad(dma): too many tiles");
+  P.ntiles = (uint32_t)nt;
+  const int lds_bytes = 2 * P.buf_bytes;
+  uint32_t gx = a->nblocks < (int64_t)nt ? a->nblocks : (uint32_t)nt;
+  dim3 grid(gx, (a->CoT + COB - 1) / COB, (a->CiT + CIB - 1) / CIB);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define WD_CASE(C_, I_)                                                                              \
+  if (COB == C_ && CIB == I_) {                                                                      \
+    auto kern = wgrad_dma_kernel<C_, I_>;                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    if (e != hipSuccess) { sp_set_error("sp_conv3d_wgrad(dma): LDS %d: %s", lds_bytes, hipGetErrorString(e)); return SP_EHIP; } \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, P);                                     \
+    SP_CHECK_LAUNCH("sp_conv3d_wgrad(dma)");                                                         \
+    return SP_OK;                                                                                    \
+  }
+  WD_CASE(1, 1) WD_CASE(1, 2) WD_CASE(1, 3) WD_CASE(2, 1) WD_CASE(2, 2) WD_CASE(2, 3) WD_CASE(4, 1)
+#undef WD_CASE
+  sp_set_error("sp_conv3d_wgrad(dma): no kernel for COB=%d CIB=%d", COB, CIB);
+  return SP_EINVAL;
+}
+
+// dw[co,ci,tap] += scale[ci]*acc[tap][co][ci] + shift[ci]*dbias[co]   (BatchNorm folded out of the operand load)
+__global__ void wgrad_finish_folded_kernel(const float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
+                                           int CoP, int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
+                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                           const double* __restrict__ dbias, float* __restrict__ dw) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)ntap * Cout * Cin;
+  if (idx >= total) return;
+  const int ci = idx % Cin;
+  const int co = (idx / Cin) % Cout;
+  const int t = idx / ((int64_t)Cin * Cout);
+  dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * acc[((size_t)t * CoP + co) * CiP + ci] + shift[ci] * (float)dbias[co];
+}
+
+extern "C" int sp_wgrad_finish_folded(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                                      int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
+                                      const float* shift, const double* dbias_sums, float* dw, sp_stream_t stream) {
+  SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
+  const int64_t total = (int64_t)ntap * Cout * Cin;
+  hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
+                     shift, dbias_sums, dw);
+  SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
+  return SP_OK;
+}

@@ -45,7 +45,7 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True):
+                 need_input_grad=True, cpi=None):
         self.name, self.kind = name, kind
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.in_dims, self.batch, self.dtype, self.device = tuple(in_dims), batch, dtype, device
@@ -53,7 +53,7 @@ class ConvLayer:
         self.act, self.act_param = act, act_param
         self.out_dtype = dtype if out_dtype is None else out_dtype
         self.need_input_grad = need_input_grad
-        self.cpi, self.cpo = O.cpad(cin), O.cpad(cout)
+        self.cpi, self.cpo = (cpi or O.cpad(cin)), O.cpad(cout)
         mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
         self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
         self.out_dims = tuple(self.fwd_op.y_dims)
@@ -149,7 +149,8 @@ class ConvLayer:
         w = params[c + ".weight"]
         O.add_f64_to_f32(self.dbias_sums, grads[c + ".bias"], self.cout)
         if self.kind == "conv":
-            self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift)
+            self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
+                           dbias_sums=self.dbias_sums)
         else:
             self.wgrad.run(self.dz, x, self.batch, grads[c + ".weight"], None, None, self.scale, self.shift)
         if not (self.need_input_grad or self.bn_prefix is not None):

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libstroke_amd.so")
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_elem.hip"]
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_elem.hip"]
 
 SP_BF16, SP_F32 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "dz", "in_scale", "in_shift", "dz_scale", "dz_shift", "dw_acc", "taps")] + \
                [(n, i32) for n in ("dtype", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "sD", "sH", "sW",
-                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks")]
+                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows")]
 
 
 _SIGS = {
@@ -41,6 +41,7 @@ _SIGS = {
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
     "sp_wgrad_finish": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp], i32),
+    "sp_wgrad_finish_folded": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp], i32),
     "sp_ncdhw_to_cl": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_cl_to_ncdhw": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),

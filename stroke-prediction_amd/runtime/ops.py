@@ -162,25 +162,43 @@ class WgradRunner:
         a.kD, a.kH, a.kW = k
         a.CoT, a.CiT = self.cot, self.cit
         a.nblocks = nblocks
+        # bf16 fast path: un-padded stride-1 3x3x3 convolution -> DMA double-buffered kernel, BatchNorm folded into finish
+        self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and p == (0, 0, 0)
+                        and tuple(in_dims) == tuple(d + 2 for d in out_dims) and cpi % 16 == 0 and cpo % 16 == 0
+                        and self.cot <= 2 and self.cit <= 3)   # wider layers: register-staged kernel measured faster
+        a.dma = int(self.dma)
+        if self.dma:
+            import os
+            a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", "512"))
+            a.tile_rows = int(os.environ.get("SP_WGRAD_ROWS", "0"))
         self.args = a
         self.dtype = dtype
 
-    def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None):
-        """dw (fp32, the parameter's own layout) += gradient."""
+    def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None):
+        """dw (fp32, the parameter's own layout) += gradient.  On the DMA path the BatchNorm (in_scale/in_shift) is
+        folded into the finish step and needs dbias_sums = sum over voxels of dz per output channel (fp64)."""
         a = self.args
         assert x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
         assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi), (tuple(x.shape), (batch, a.Di, a.Hi, a.Wi, a.CPi))
         assert tuple(dz.shape) == (batch, a.Do, a.Ho, a.Wo, a.CPo), (tuple(dz.shape), (batch, a.Do, a.Ho, a.Wo, a.CPo))
         self.acc.zero_()
         a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
-        a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
+        fold = self.dma and in_scale is not None
+        if fold:
+            assert dbias_sums is not None and dz_scale is None
+        a.dma = int(self.dma and dz_scale is None)
+        a.in_scale, a.in_shift = (None, None) if fold else (ptr(in_scale), ptr(in_shift))
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
         st = stream()
         with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout):
             L.call("sp_conv3d_wgrad", C.byref(a), st)
-        L.call("sp_wgrad_finish", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
-               self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), st)
+        if fold:
+            L.call("sp_wgrad_finish_folded", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
+                   self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw), st)
+        else:
+            L.call("sp_wgrad_finish", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
+                   self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), st)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise drivers

@@ -42,15 +42,17 @@ class UnetEngine:
                                  "convolutions (minimum 44 per axis)" % (tuple(dims),))
         self.scratch = sc = Scratch(device)
         mk = lambda name, ci, co, d, bn=True, k=3, act=L.ACT_LEAKY, ap=LEAKY, out_dtype=None, blk=None, idx=None, \
-            need_g=True: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc,
-                                   bn_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx)) if bn else None,
-                                   conv_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx + 1)) if bn else name,
-                                   act=act, act_param=ap, out_dtype=out_dtype, need_input_grad=need_g)
+            need_g=True, cpi=None: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc,
+                                             bn_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx)) if bn else None,
+                                             conv_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx + 1)) if bn else name,
+                                             act=act, act_param=ap, out_dtype=out_dtype, need_input_grad=need_g, cpi=cpi)
         sub = lambda d, k: tuple(x - k for x in d)
         half = lambda d: tuple(x // 2 for x in d)
         dbl = lambda d: tuple(2 * x for x in d)
         d0 = self.dims
-        self.c11 = mk("b1c1", n_in, b1, d0, blk="block1", idx=0, need_g=False)
+        # the network input gets a 16-channel pitch (not 8): every 3x3x3 layer then meets the 16-channel plane
+        # granularity of the DMA weight-gradient kernel
+        self.c11 = mk("b1c1", n_in, b1, d0, blk="block1", idx=0, need_g=False, cpi=O.cpad(n_in, 16))
         self.c12 = mk("b1c2", b1, b1, sub(d0, 2), blk="block1", idx=3)
         d12 = sub(d0, 4)
         dp1 = half(d12)
@@ -80,7 +82,7 @@ class UnetEngine:
             l.reserve_bwd_scratch()
         sc.finalize()
         dt = dtype
-        self.x0 = O.alloc_cl(batch, d0, O.cpad(n_in), dt, device)
+        self.x0 = O.alloc_cl(batch, d0, self.c11.cpi, dt, device)
         self.p1 = O.alloc_cl(batch, dp1, O.cpad(b1), dt, device)
         self.p2 = O.alloc_cl(batch, dp2, O.cpad(b2), dt, device)
         self.cat4 = O.alloc_cl(batch, dc4, b3 + O.cpad(b2), dt, device)

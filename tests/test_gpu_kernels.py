@@ -126,7 +126,11 @@ def test_conv_fwd_dgrad_wgrad(dtype, cin, cout, k, s, p, dims, B):
     # ---- weight gradient (BatchNorm applied on load)
     wg = O.WgradRunner(cin, cout, k, s, p, dims, op.y_dims, cpi, cpo, cin * k ** 3, k ** 3, dtype, DEV)
     dw = torch.zeros_like(w, device=DEV)
-    wg.run(xs, dzs, B, dw, sc, sh)
+    dbs = torch.zeros(cpo, dtype=torch.float64, device=DEV)
+    dbs[:cout] = dz.double().sum(dim=(0, 2, 3, 4)).to(DEV)
+    wg.run(xs, dzs, B, dw, sc, sh, dbias_sums=dbs)
+    if wg.dma:   # folded BatchNorm: the reference sees the un-rounded normalised input
+        gw_ref = torch.autograd.grad(F.conv3d(xr, wr, b, stride=s, padding=p), wr, dz)[0]
     scale_w = float(gw_ref.abs().max())
     torch.testing.assert_close(dw.cpu(), gw_ref, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * max(1.0, scale_w))
 

@@ -59,7 +59,8 @@ for name, ci, co, d in LAYERS:
     if "wgrad" in which:
         wg = O.WgradRunner(ci, co, 3, 1, 0, dims, op.y_dims, cpi, cpo, ci * 27, 27, dt, DEV)
         dw = torch.zeros_like(w)
-        t = timeit(lambda: wg.run(x, dz, B, dw, sc, sh))
+        dbs = torch.zeros(cpo, dtype=torch.float64, device=DEV)
+        t = timeit(lambda: wg.run(x, dz, B, dw, sc, sh, dbias_sums=dbs))
         line += " wgrad %7.1f us %6.1f TF/s" % (t, gf / t * 1e3)
         tot["wgrad"] = tot.get("wgrad", 0) + t
     print(line, flush=True)
