@@ -83,6 +83,10 @@ typedef struct sp_conv_args {
   float act_param;
   int32_t dma;                 /* 1: LDS-DMA staging (bf16 in, in_scale NULL, lane-linear planes, +1 KiB LDS slack) */
   int32_t zfill;               /* dma only: taps can leave the input volume -> zero those chunks */
+  int32_t persist;             /* dma only: allow the persistent double-buffered variant where it applies */
+  const void* aux;             /* stats_mode 1: tensor shaped like y (the layer input x of a data gradient) */
+  int32_t stats_mode;          /* 0: stats = (sum y, sum y^2);  1: stats = (sum y, sum y*aux) -- BatchNorm backward sums
+                                  fused into the dgrad epilogue (DMA kernel only) */
   int32_t stats_nrep;          /* power of two >= 1: stats is [stats_nrep][CPo][2]; workgroup b adds to replica b % nrep
                                   (tens of thousands of same-address fp64 atomics otherwise serialise at the memory side) */
 } sp_conv_args;
@@ -128,12 +132,16 @@ typedef struct sp_wgrad_args {
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 /* BatchNorm folded out of the operand load (un-padded convolutions):
  * dw[co,ci,tap] += scale[ci]*dw_acc[tap][co][ci] + shift[ci]*dbias_sums[co] */
-int sp_wgrad_finish_folded(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+int sp_wgrad_finish_folded(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                            int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
-                           const float* shift, const double* dbias_sums, float* dw, sp_stream_t stream);
-/* dw[co*sCo + ci*sCi + tapsrc[t]] += dw_acc[t][co][ci] */
-int sp_wgrad_finish(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
-                    int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw, sp_stream_t stream);
+                           const float* shift, const double* dbias_sums, float* dw, float* dbias_grad /* or NULL */,
+                           sp_stream_t stream);
+/* dw[co*sCo + ci*sCi + tapsrc[t]] += dw_acc[t][co][ci].  Both finish kernels also zero dw_acc for the next
+ * step and, when dbias_grad != NULL, add the bias gradient dbias_grad[co] += dbias_sums[co]. */
+int sp_wgrad_finish(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                    int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
+                    const double* dbias_sums /* or NULL */, float* dbias_grad /* or NULL */, int32_t nbias,
+                    sp_stream_t stream);
 
 /* ------------------------------------------------------------------ layout
  * NCDHW fp32 (reference layout, README.md:13 / data.py:305) <-> channels-last-3d */
@@ -157,7 +165,7 @@ int sp_bn_bwd_reduce(const void* g, const void* x, int32_t dtype, int64_t nvox, 
                      sp_stream_t stream);
 /* from (sum g, sum g*x): dgamma, dbeta (ACCUMULATED into the gradient buffers, may be NULL) and
  * coef[3][CP] with dx = coef0*g + coef1*x + coef2 */
-int sp_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* mean,
+int sp_bn_bwd_finalize(const double* sums /* [nrep][CP][2] */, int32_t nrep, double count, const float* gamma, const float* mean,
                        const float* invstd, int32_t C, int32_t CP, float* dgamma, float* dbeta, float* coef,
                        sp_stream_t stream);
 /* dz = (coef0*g + coef1*y + coef2) * act'(y)  (coef NULL: dz = g*act'(y));

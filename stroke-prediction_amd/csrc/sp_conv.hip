@@ -351,6 +351,7 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
                  "sp_conv3d_igemm: LDS plan inconsistent (need %ld, lds_bytes %d)", need, a->lds_bytes);
     SP_CHECK_ARG(a->lds_bytes >= a->NT * 16 * 2 * 4, "sp_conv3d_igemm: LDS too small for the reduction");
   }
+  SP_CHECK_ARG(a->stats_mode == 0 || (a->dma && a->aux), "sp_conv3d_igemm: stats_mode 1 needs the DMA kernel and aux");
   if (a->dma) return sp_conv3d_igemm_dma(a, stream);
   ConvDev P;
   P.a = *a;

@@ -19,7 +19,7 @@ struct ConvDmaDev {
   FastDiv d_tx, d_ty, d_tz;       // block id -> tile
   uint32_t ntx, nty, ntz, nblk;
   int32_t plane_chunks, group_chunks, nruns, log2_opp;
-  int32_t row_chunks, segs_per_row, nrows, njobs;
+  int32_t row_chunks, segs_per_row, nrows, njobs, buf_stride;
   FastDiv d_segs, d_rows;
 };
 
@@ -256,8 +256,15 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvDmaDev P)
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
           }
+          if (a.stats_mode == 1) {   // BatchNorm-backward sums: (sum g, sum g*x), x read at the same position
+            float xv[4];
+            Store<TOUT>::ld4(reinterpret_cast<const TOUT*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo + (size_t)obase[m] + c0, xv);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], v[j], s2[n][j]); }
+            for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], xv[j], s2[n][j]); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], v[j], s2[n][j]); }
+          }
         }
       }
     }
@@ -286,6 +293,247 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvDmaDev P)
     }
   }
   STAMP(5);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent variant for single-group layers with resident weights (the Cout = 16, Cin <= 16 layers that are
+// HBM/LDS- rather than MFMA-bound): a workgroup walks tiles blockIdx.x, +gridDim.x, ... with TWO LDS tile buffers.
+// Per workgroup ONCE: ktab, weight fragments, per-lane DMA job table.  Per tile: the DMA of tile t+1 is issued
+// before the K loop of tile t and lands behind it and the epilogue; BatchNorm statistics stay in registers until
+// the single flush at the end (a few hundred atomics per launch instead of ~500 K).
+template <int MT, int KS, typename TOUT>
+__global__ __launch_bounds__(256) void conv_igemm_persist_kernel(const ConvDmaDev P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const sp_conv_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lv = lane & 15, lg = lane >> 4;
+
+  int* ktab_l = reinterpret_cast<int*>(lds);
+  const int ktab_bytes = (KS * 16 + 15) & ~15;
+  unsigned char* tile0 = lds + ktab_bytes;
+  for (int i = tid; i < KS * 4; i += 256) ktab_l[i] = a.ktab[i];
+
+  int vbase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int r = wave * MT + m;
+    const int rz = r / a.TH, ry = r - rz * a.TH;
+    vbase[m] = ((rz * a.sD * a.ITH + ry * a.sH) * a.ITW + lv * a.sW) * a.vsb;
+  }
+  const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
+  bf16x8 wreg[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wreg[s] = wf_hi[(size_t)s * a.NTtot * 64 + lane];
+  const int opp_mask = a.opp - 1;
+
+  // tile-invariant DMA job table (one (plane,row) job per lane, njobs <= 128, one 64-chunk segment per row)
+  int job_goff[2], job_loff[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    int j = k * 64 + lane;
+    j = j < P.njobs ? j : P.njobs - 1;
+    const uint32_t pl = fdiv(j, P.d_rows);
+    const int row = j - pl * P.nrows;
+    const uint32_t vz = fdiv(row, P.d_ith);
+    const int vy = row - vz * a.ITH;
+    job_goff[k] = (((int)vz * a.Hi + vy) * a.Wi) * a.CPi + (int)pl * a.opp * 8;
+    job_loff[k] = (int)pl * a.plane_bytes + row * P.row_chunks * 16;
+  }
+  const int lane_goff = (lane >> P.log2_opp) * a.CPi + (lane & opp_mask) * 8;     // x / octet part of a row chunk
+  const int c0 = lg * 4;                                                             // NT == 1
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + c0); bj[0] = bb.x; bj[1] = bb.y; bj[2] = bb.z; bj[3] = bb.w; }
+  const bool cok = c0 < a.CPo;
+  const bool lin = (c0 + 4 <= a.Cout) && (a.act == SP_ACT_LEAKY || a.act == SP_ACT_NONE);
+  const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;
+  const bool want_stats = a.stats != nullptr;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  struct TileCo { int b, oz0, oy0, ox0, iz0, iy0, ix0; bool interior, border; };
+  auto decode = [&](uint32_t tile) {
+    TileCo c;
+    uint32_t t = tile;
+    uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
+    q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; t = q;
+    q = fdiv(t, P.d_tz); const int tz = t - q * P.ntz; c.b = q;
+    c.oz0 = tz * a.TD; c.oy0 = ty * a.TH; c.ox0 = tx * 16;
+    c.iz0 = c.oz0 * a.sD + a.o0D; c.iy0 = c.oy0 * a.sH + a.o0H; c.ix0 = c.ox0 * a.sW + a.o0W;
+    c.interior = c.iz0 >= 0 && c.iy0 >= 0 && c.ix0 >= 0 && c.iz0 + a.ITD <= a.Di && c.iy0 + a.ITH <= a.Hi && c.ix0 + a.ITW <= a.Wi;
+    c.border = a.zfill && !c.interior;
+    return c;
+  };
+  auto issue = [&](const TileCo& c, unsigned char* tile) {
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)c.b * a.Di * a.Hi * a.Wi * a.CPi;
+    if (c.interior) {
+      const bf16_t* org = xin + (((size_t)c.iz0 * a.Hi + c.iy0) * a.Wi + c.ix0) * a.CPi;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int nj = min(64, P.njobs - k * 64);
+        for (int j = wave; j < nj; j += 4) {
+          const int goff = __builtin_amdgcn_readlane(job_goff[k], j);
+          const int lo = __builtin_amdgcn_readlane(job_loff[k], j);
+          if (lane < P.row_chunks)
+            __builtin_amdgcn_global_load_lds((gbl_void*)(org + goff + lane_goff), (lds_void*)(tile + lo), 16, 0, 0);
+        }
+      }
+    } else {
+      // tiles touching the volume border: clamp every coordinate (the zero-fill pass fixes padded voxels)
+      for (int j = wave; j < P.njobs; j += 4) {
+        const int sj = __builtin_amdgcn_readfirstlane(j);
+        const uint32_t pl = fdiv(sj, P.d_rows);
+        const int row = sj - pl * P.nrows;
+        const uint32_t vz = fdiv(row, P.d_ith);
+        const int vy = row - vz * a.ITH;
+        const int cz = min(max(c.iz0 + (int)vz, 0), a.Di - 1), cy = min(max(c.iy0 + vy, 0), a.Hi - 1);
+        if (lane < P.row_chunks) {
+          const int cx = min(max(c.ix0 + (lane >> P.log2_opp), 0), a.Wi - 1);
+          const bf16_t* src = xin + (((size_t)cz * a.Hi + cy) * a.Wi + cx) * a.CPi + ((int)pl * a.opp + (lane & opp_mask)) * 8;
+          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + (int)pl * a.plane_bytes + row * P.row_chunks * 16), 16, 0, 0);
+        }
+      }
+    }
+  };
+
+  // consecutive tile ids on one XCD (halo re-reads hit that XCD's L2): blocks b, b+8, ... share an XCD
+  const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+  uint32_t tile = vb;
+  int cur = 0;
+  __syncthreads();
+  TileCo tc = decode(tile < P.nblk ? tile : 0);
+  if (tile < P.nblk) issue(tc, tile0);
+  for (; tile < P.nblk; tile += gridDim.x) {
+    unsigned char* tl = tile0 + cur * P.buf_stride;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                     // tile `tile` has landed for everyone; buffer cur^1 is free again
+    const uint32_t nxt = tile + gridDim.x;
+    TileCo tn = tc;
+    if (nxt < P.nblk) { tn = decode(nxt); issue(tn, tile0 + (cur ^ 1) * P.buf_stride); }
+    if (tc.border) {
+      for (int r = wave; r < P.nruns; r += 4) {
+        const int i = r * 64 + lane;
+        if (i < P.group_chunks) {
+          const uint32_t pl = fdiv(i, P.d_plane);
+          const int ii = i - pl * P.plane_chunks;
+          const uint32_t vox = (uint32_t)ii >> P.log2_opp;
+          const uint32_t row = fdiv(vox, P.d_itw);
+          const int vx = vox - row * a.ITW;
+          const uint32_t vz = fdiv(row, P.d_ith);
+          const int vy = row - vz * a.ITH;
+          const int gz = tc.iz0 + (int)vz, gy = tc.iy0 + vy, gx = tc.ix0 + vx;
+          if (!((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi))
+            *reinterpret_cast<uint4*>(tl + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    // ---- K loop (static ping-pong of the activation fragments) -------------------------------------------------
+    f32x4 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 x0[MT], x1[MT];
+    {
+      const int k0 = ktab_l[lg];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) x0[m] = *reinterpret_cast<const bf16x8*>(tl + vbase[m] + k0);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+        const int kn = ktab_l[(s + 1) * 4 + lg];
+        if ((s & 1) == 0) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) x1[m] = *reinterpret_cast<const bf16x8*>(tl + vbase[m] + kn);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) x0[m] = *reinterpret_cast<const bf16x8*>(tl + vbase[m] + kn);
+        }
+      }
+      if ((s & 1) == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x0[m], acc[m], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x1[m], acc[m], 0, 0, 0);
+      }
+    }
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    TOUT* __restrict__ yout = reinterpret_cast<TOUT*>(a.y) + (size_t)tc.b * a.YD * a.YH * a.YW * a.CPo;
+    const int ox = tc.ox0 + lv;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int r = wave * MT + m;
+      const int rz = r / a.TH, ry = r - rz * a.TH;
+      const int oz = tc.oz0 + rz, oy = tc.oy0 + ry;
+      const bool valid = oz < a.Do && oy < a.Ho && ox < a.Wo && cok;
+      float v[4];
+      if (lin) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float z = acc[m][j] + bj[j]; v[j] = fmaxf(z, slope * z); }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = act_fwd(a.act, a.act_param, acc[m][j] + bj[j]);
+          v[j] = (c0 + j < a.Cout) ? z : 0.f;
+        }
+      }
+      if (valid) {
+        const size_t off = (size_t)((((oz * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo) + c0;
+        Store<TOUT>::st4(yout + off, v);
+        if (want_stats) {
+          if (sizeof(TOUT) == 2) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
+          }
+          if (a.stats_mode == 1) {
+            float xv[4];
+            Store<TOUT>::ld4(reinterpret_cast<const TOUT*>(a.aux) + (size_t)tc.b * a.YD * a.YH * a.YW * a.CPo + off, xv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], xv[j], s2[j]); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+          }
+        }
+      }
+    }
+    tc = tn;
+    cur ^= 1;
+  }
+  if (want_stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < 32; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x1s = row16_sum(s1[j]), x2s = row16_sum(s2[j]);
+      if (lv == 0) { atomicAdd(&red[(lg * 4 + j) * 2], x1s); atomicAdd(&red[(lg * 4 + j) * 2 + 1], x2s); }
+    }
+    __syncthreads();
+    for (int i = tid; i < 32; i += 256) {
+      const int c = i >> 1;
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+    }
+  }
+}
+
+template <int MT, int KS>
+static int launch_persist(ConvDmaDev& P, hipStream_t st) {
+  const int buf = (((P.nruns * 1024) + 1023) / 1024) * 1024;
+  P.buf_stride = buf;
+  const int lds_bytes = ((KS * 16 + 15) & ~15) + 2 * buf;
+  const unsigned grid = P.nblk < 512u ? P.nblk : 512u;
+#define SP_PL(T_)                                                                                                  \
+  {                                                                                                                \
+    auto kern = conv_igemm_persist_kernel<MT, KS, T_>;                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
+    if (e != hipSuccess) { sp_set_error("sp_conv3d_igemm(persist): LDS %d: %s", lds_bytes, hipGetErrorString(e)); return SP_EHIP; } \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);                                             \
+  }
+  if (P.a.dtype_out == SP_F32) SP_PL(float) else SP_PL(bf16_t)
+#undef SP_PL
+  SP_CHECK_LAUNCH("sp_conv3d_igemm(persist)");
+  return SP_OK;
 }
 
 template <int NT, int MT, int KS, typename TOUT>
@@ -351,6 +599,13 @@ int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
   P.nblk = (uint32_t)nblk;
   dim3 grid(P.nblk, a->NTtot / a->NT);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // persistent double-buffered variant: single channel group, one cout tile, resident weights, whole rows per DMA
+  if (a->persist && a->NT == 1 && a->NTtot == 1 && a->ngroups == 1 && P.segs_per_row == 1 && a->MT == 8 &&
+      (a->steps_per_group == 14 || a->steps_per_group == 7) && P.nblk >= (a->persist >= 2 ? 2u : 1024u) &&
+      ((a->steps_per_group * 16 + 15) & ~15) + 2 * ((P.nruns * 1024 + 1023) / 1024 * 1024) <= 76 * 1024) {
+    if (a->steps_per_group == 14) return launch_persist<8, 14>(P, st);
+    return launch_persist<8, 7>(P, st);
+  }
 #define SP_CASE(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return dispatch_dma<NT_, MT_>(P, grid, st)
   SP_CASE(1, 8); SP_CASE(2, 8); SP_CASE(4, 8);
   SP_CASE(1, 4); SP_CASE(2, 4); SP_CASE(4, 4);

@@ -123,7 +123,10 @@ __global__ __launch_bounds__(256) void bn_sums_kernel(const T* __restrict__ x, c
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nvox; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nvox + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nvox, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       float a[8];
       Store<T>::ld8(x + v * CP + oc * 8, a);
       if (TWO) {
@@ -168,13 +171,18 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int nrep, do
                                    const float* __restrict__ beta, float* running_mean, float* running_var,
                                    float momentum, float eps, int training, int C, int CP, float* scale, float* shift,
                                    float* mean_out, float* invstd_out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= CP) return;
-  if (c >= C) { scale[c] = 0.f; shift[c] = 0.f; if (mean_out) { mean_out[c] = 0.f; invstd_out[c] = 0.f; } return; }
+  const int c = blockIdx.x;                 // one wave per channel; lanes gather the replicas
+  const int lane = threadIdx.x;
+  if (c >= C) {
+    if (lane == 0) { scale[c] = 0.f; shift[c] = 0.f; if (mean_out) { mean_out[c] = 0.f; invstd_out[c] = 0.f; } }
+    return;
+  }
   float mean, invstd;
   if (training) {
     double s1 = 0, s2 = 0;
-    for (int r = 0; r < nrep; ++r) { s1 += sums[((size_t)r * CP + c) * 2]; s2 += sums[((size_t)r * CP + c) * 2 + 1]; }
+    for (int r = lane; r < nrep; r += 64) { s1 += sums[((size_t)r * CP + c) * 2]; s2 += sums[((size_t)r * CP + c) * 2 + 1]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    if (lane != 0) return;
     const double m = s1 / count;
     double var = s2 / count - m * m;
     if (var < 0) var = 0;
@@ -186,6 +194,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int nrep, do
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
   } else {
+    if (lane != 0) return;
     mean = running_mean[c];
     invstd = 1.f / sqrtf(running_var[c] + eps);
   }
@@ -201,7 +210,7 @@ extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, co
   SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP, "sp_bn_finalize: bad arguments");
   SP_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "sp_bn_finalize: missing statistics");
   SP_CHECK_ARG(nrep >= 1, "sp_bn_finalize: nrep");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((CP + 63) / 64), dim3(64), 0, ST(stream), sums, nrep, count, gamma, beta,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, C, CP, scale, shift, mean, invstd);
   SP_CHECK_LAUNCH("sp_bn_finalize");
   return SP_OK;
@@ -209,13 +218,15 @@ extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, co
 
 // dgamma = (S2 - mean*S1)*invstd ; dbeta = S1 ; dx = coef0*g + coef1*x + coef2 with
 // coef0 = gamma*invstd, coef1 = -gamma*invstd^2*dgamma/N, coef2 = -coef0*dbeta/N - coef1*mean
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ invstd, int C, int CP,
                                        float* dgamma, float* dbeta, float* coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= CP) return;
-  if (c >= C) { coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f; return; }
-  const double s1 = sums[2 * c], s2 = sums[2 * c + 1];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  if (c >= C) { if (lane == 0) { coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f; } return; }
+  double s1 = 0, s2 = 0;
+  for (int r = lane; r < nrep; r += 64) { s1 += sums[((size_t)r * CP + c) * 2]; s2 += sums[((size_t)r * CP + c) * 2 + 1]; }
+  s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+  if (lane != 0) return;
   const double mu = mean[c], is = invstd[c], ga = gamma[c];
   const double dg = (s2 - mu * s1) * is, db = s1;
   if (dgamma) { dgamma[c] += (float)dg; dbeta[c] += (float)db; }
@@ -224,11 +235,11 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, double c
   coef[CP + c] = (float)c1;
   coef[2 * CP + c] = (float)(-c0 * db / count - c1 * mu);
 }
-extern "C" int sp_bn_bwd_finalize(const double* sums, double count, const float* gamma, const float* mean,
+extern "C" int sp_bn_bwd_finalize(const double* sums, int32_t nrep, double count, const float* gamma, const float* mean,
                                   const float* invstd, int32_t C, int32_t CP, float* dgamma, float* dbeta, float* coef,
                                   sp_stream_t stream) {
   SP_CHECK_ARG(sums && gamma && mean && invstd && coef && count > 0, "sp_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((CP + 63) / 64), dim3(64), 0, ST(stream), sums, count, gamma, mean, invstd, C, CP, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep < 1 ? 1 : nrep, count, gamma, mean, invstd, C, CP, dgamma, dbeta, coef);
   SP_CHECK_LAUNCH("sp_bn_bwd_finalize");
   return SP_OK;
 }
@@ -252,7 +263,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
     c2[j] = (coef && active) ? coef[2 * CP + oc * 8 + j] : 0.f;
   }
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nvox; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nvox + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nvox, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       float a[8], b[8], o[8];
       Store<T>::ld8(g + v * CP + oc * 8, a);
       Store<T>::ld8(y + v * CP + oc * 8, b);
@@ -299,7 +313,10 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nout; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
       unflatten(v, Do, Ho, Wo, b, z, yy, xx);
       float m[8];
@@ -355,7 +372,10 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict_
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nout; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
       unflatten(v, Do, Ho, Wo, b, z, yy, xx);
       int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
@@ -410,7 +430,10 @@ __global__ __launch_bounds__(256) void crop_copy_kernel(const T* __restrict__ sr
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nout; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
       unflatten(v, dd.D, dd.H, dd.W, b, z, yy, xx);
       float a[8];
@@ -463,7 +486,10 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
     s0[j] = (gs && active) ? coefs[cs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[CPcat + cs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * CPcat + cs0 + c] : 0.f;
   }
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nwin; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nwin + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nwin, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, wz, wy, wx;
       unflatten(v, Dw, Hw, Ww, b, wz, wy, wx);
       const bool pooled = gp && wz < Dp && wy < Hp && wx < Wp;
@@ -558,7 +584,10 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_kernel(const T* __restr
     c0[j] = active ? coef[c] : 0.f; c1[j] = active ? coef[CPcat + c] : 0.f; c2[j] = active ? coef[2 * CPcat + c] : 0.f;
   }
   if (active) {
-    for (int64_t v = (int64_t)blockIdx.x * om.vpb + slot; v < nin; v += (int64_t)gridDim.x * om.vpb) {
+    // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
+    const int64_t chunk_ = ((nin + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nin, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
       unflatten(v, di.D, di.H, di.W, b, z, yy, xx);
       int oz[4], oy[4], ox[4]; float wz[4], wy[4], wx[4];

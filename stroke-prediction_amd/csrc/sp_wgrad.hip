@@ -274,24 +274,31 @@ extern "C" int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream) {
   return SP_EINVAL;
 }
 
-__global__ void wgrad_finish_kernel(const float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
+__global__ void wgrad_finish_kernel(float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
                                     int CoP, int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
-                                    float* __restrict__ dw) {
+                                    float* __restrict__ dw, const double* __restrict__ dbias_sums,
+                                    float* __restrict__ dbias_grad, int nbias) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)ntap * Cout * Cin;
+  const int64_t total = (int64_t)ntap * CoP * CiP;       // every accumulator entry is visited (and cleared)
+  if (dbias_grad && idx < nbias) dbias_grad[idx] += (float)dbias_sums[idx];
   if (idx >= total) return;
-  const int ci = idx % Cin;
-  const int co = (idx / Cin) % Cout;
-  const int t = idx / ((int64_t)Cin * Cout);
-  dw[co * sCo + ci * sCi + tapsrc[t]] += acc[((size_t)t * CoP + co) * CiP + ci];
+  const int ci = idx % CiP;
+  const int co = (idx / CiP) % CoP;
+  const int t = idx / ((int64_t)CiP * CoP);
+  const float v = acc[idx];
+  acc[idx] = 0.f;                                        // ready for the next step: no separate memset
+  if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += v;
 }
 
-extern "C" int sp_wgrad_finish(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
-                               int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw, sp_stream_t stream) {
+extern "C" int sp_wgrad_finish(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                               int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
+                               const double* dbias_sums, float* dbias_grad, int32_t nbias, sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish: bad arguments");
-  const int64_t total = (int64_t)ntap * Cout * Cin;
+  SP_CHECK_ARG(!dbias_grad || (dbias_sums && nbias <= ntap * CoP * CiP), "sp_wgrad_finish: bias arguments");
+  const int64_t total = (int64_t)ntap * CoP * CiP;
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, dw);
+                     reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, dw,
+                     dbias_sums, dbias_grad, nbias);
   SP_CHECK_LAUNCH("sp_wgrad_finish");
   return SP_OK;
 }

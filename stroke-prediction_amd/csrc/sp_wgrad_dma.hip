@@ -301,27 +301,32 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
 }
 
 // dw[co,ci,tap] += scale[ci]*acc[tap][co][ci] + shift[ci]*dbias[co]   (BatchNorm folded out of the operand load)
-__global__ void wgrad_finish_folded_kernel(const float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
+__global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
                                            int CoP, int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                           const double* __restrict__ dbias, float* __restrict__ dw) {
+                                           const double* __restrict__ dbias, float* __restrict__ dw,
+                                           float* __restrict__ dbias_grad) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)ntap * Cout * Cin;
+  const int64_t total = (int64_t)ntap * CoP * CiP;
+  if (dbias_grad && idx < Cout) dbias_grad[idx] += (float)dbias[idx];
   if (idx >= total) return;
-  const int ci = idx % Cin;
-  const int co = (idx / Cin) % Cout;
-  const int t = idx / ((int64_t)Cin * Cout);
-  dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * acc[((size_t)t * CoP + co) * CiP + ci] + shift[ci] * (float)dbias[co];
+  const int ci = idx % CiP;
+  const int co = (idx / CiP) % CoP;
+  const int t = idx / ((int64_t)CiP * CoP);
+  const float v = acc[idx];
+  acc[idx] = 0.f;
+  if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * v + shift[ci] * (float)dbias[co];
 }
 
-extern "C" int sp_wgrad_finish_folded(const float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+extern "C" int sp_wgrad_finish_folded(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                       int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
-                                      const float* shift, const double* dbias_sums, float* dw, sp_stream_t stream) {
+                                      const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
+                                      sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
-  const int64_t total = (int64_t)ntap * Cout * Cin;
+  const int64_t total = (int64_t)ntap * CoP * CiP;
   hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
-                     shift, dbias_sums, dw);
+                     shift, dbias_sums, dw, dbias_grad);
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
   return SP_OK;
 }

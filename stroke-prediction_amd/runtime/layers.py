@@ -135,7 +135,7 @@ class ConvLayer:
     def reserve_bwd_scratch(self):
         self.dbias_sums_id = self.scratch.reserve(self.cpo)
         if self.bn_prefix is not None:
-            self.bsums_id = self.scratch.reserve(self.cpi * 2)
+            self.bsums_id = self.scratch.reserve(self.cpi * 2 * STATS_NREP)
 
     @property
     def dbias_sums(self):
@@ -147,21 +147,27 @@ class ConvLayer:
         dx = coef0*g + coef1*x + coef2 (coef None: dx = g)."""
         c = self.conv_prefix
         w = params[c + ".weight"]
-        O.add_f64_to_f32(self.dbias_sums, grads[c + ".bias"], self.cout)
+        # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
         if self.kind == "conv":
             self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
-                           dbias_sums=self.dbias_sums)
+                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
         else:
-            self.wgrad.run(self.dz, x, self.batch, grads[c + ".weight"], None, None, self.scale, self.shift)
+            self.wgrad.run(self.dz, x, self.batch, grads[c + ".weight"], None, None, self.scale, self.shift,
+                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
         if not (self.need_input_grad or self.bn_prefix is not None):
             return None, None
         self.dgrad.prep(w)
-        self.dgrad.run(self.dz, self.g, self.batch)
         if self.bn_prefix is None:
+            self.dgrad.run(self.dz, self.g, self.batch)
             return self.g, None
         p = self.bn_prefix
         bs = self.scratch.get(self.bsums_id)
-        O.bn_bwd_reduce(self.g, x, self.dtype, bs)
+        fused = all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA
+        if fused:      # (sum g, sum g*x) accumulated by the dgrad epilogue
+            self.dgrad.run(self.dz, self.g, self.batch, stats=bs, stats_nrep=STATS_NREP, stats_mode=1, aux=x)
+        else:
+            self.dgrad.run(self.dz, self.g, self.batch)
+            O.bn_bwd_reduce(self.g, x, self.dtype, bs)
         O.bn_bwd_finalize(bs, self.count, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
-                          grads[p + ".weight"], grads[p + ".bias"], self.coef)
+                          grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=STATS_NREP if fused else 1)
         return self.g, self.coef

@@ -25,7 +25,7 @@ class ConvArgs(C.Structure):
                    "dtype_in", "dtype_out", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "YD", "YH", "YW", "CPo",
                    "osD", "osH", "osW", "ooD", "ooH", "ooW", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
                    "TD", "TH", "ITD", "ITH", "ITW", "MT", "NT", "NTtot", "ngroups", "octs_per_group", "opp", "vsb",
-                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("stats_nrep", i32)]
+                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32)]
 
 
 class WgradArgs(C.Structure):
@@ -40,14 +40,14 @@ _SIGS = {
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
-    "sp_wgrad_finish": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp], i32),
-    "sp_wgrad_finish_folded": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp], i32),
+    "sp_wgrad_finish": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, vp], i32),
+    "sp_wgrad_finish_folded": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp], i32),
     "sp_ncdhw_to_cl": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_cl_to_ncdhw": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),
     "sp_bn_finalize": ([vp, i32, f64, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "sp_bn_bwd_reduce": ([vp, vp, i32, i64, i32, vp, vp], i32),
-    "sp_bn_bwd_finalize": ([vp, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp], i32),
+    "sp_bn_bwd_finalize": ([vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_bn_act_bwd": ([vp, vp, vp, i32, i64, i32, i32, f32, vp, vp, vp], i32),
     "sp_maxpool2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp, vp], i32),
     "sp_upsample2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),

@@ -11,6 +11,7 @@ from . import plan as P
 TORCH_DT = {L.SP_BF16: torch.bfloat16, L.SP_F32: torch.float32}
 
 
+USE_PERSIST = False  # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
 
 # optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
@@ -98,7 +99,7 @@ class ConvRunner:
             self.has_bias = True
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
-            dtype_out=None, use_bias=True, stats_nrep=1):
+            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None):
         op = self.op
         dtype_out = op.dtype if dtype_out is None else dtype_out
         assert x.dtype == TORCH_DT[op.dtype] and y.dtype == TORCH_DT[dtype_out]
@@ -110,6 +111,7 @@ class ConvRunner:
         a.bias = ptr(self.bias) if (self.has_bias and use_bias) else None
         a.stats = ptr(stats)
         a.stats_nrep = stats_nrep
+        a.stats_mode, a.aux = stats_mode, ptr(aux)
         a.dtype_in, a.dtype_out = op.dtype, dtype_out
         a.B = batch
         a.Di, a.Hi, a.Wi = op.in_dims
@@ -133,6 +135,7 @@ class ConvRunner:
                       "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "zfill"):
                 setattr(a, k, t[k])
             a.dma = int(t["dma"] and in_scale is None and USE_DMA)
+            a.persist = int(USE_PERSIST)
             with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout):
                 L.call("sp_conv3d_igemm", C.byref(a), st)
 
@@ -174,14 +177,14 @@ class WgradRunner:
         self.args = a
         self.dtype = dtype
 
-    def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None):
+    def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None,
+            dbias_grad=None, nbias=0):
         """dw (fp32, the parameter's own layout) += gradient.  On the DMA path the BatchNorm (in_scale/in_shift) is
         folded into the finish step and needs dbias_sums = sum over voxels of dz per output channel (fp64)."""
         a = self.args
         assert x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
         assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi), (tuple(x.shape), (batch, a.Di, a.Hi, a.Wi, a.CPi))
         assert tuple(dz.shape) == (batch, a.Do, a.Ho, a.Wo, a.CPo), (tuple(dz.shape), (batch, a.Do, a.Ho, a.Wo, a.CPo))
-        self.acc.zero_()
         a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
         fold = self.dma and in_scale is not None
         if fold:
@@ -195,10 +198,12 @@ class WgradRunner:
             L.call("sp_conv3d_wgrad", C.byref(a), st)
         if fold:
             L.call("sp_wgrad_finish_folded", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
-                   self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw), st)
+                   self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw),
+                   ptr(dbias_grad), st)
         else:
             L.call("sp_wgrad_finish", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
-                   self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), st)
+                   self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), ptr(dbias_sums) if dbias_grad is not None else None,
+                   ptr(dbias_grad), nbias, st)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise drivers
@@ -231,8 +236,8 @@ def bn_bwd_reduce(g, x, dtype, sums):
     L.call("sp_bn_bwd_reduce", ptr(g), ptr(x), dtype, nvox, x.shape[-1], ptr(sums), stream())
 
 
-def bn_bwd_finalize(sums, count, gamma, mean, invstd, c, cp, dgamma, dbeta, coef):
-    L.call("sp_bn_bwd_finalize", ptr(sums), float(count), ptr(gamma), ptr(mean), ptr(invstd), c, cp, ptr(dgamma),
+def bn_bwd_finalize(sums, count, gamma, mean, invstd, c, cp, dgamma, dbeta, coef, nrep=1):
+    L.call("sp_bn_bwd_finalize", ptr(sums), nrep, float(count), ptr(gamma), ptr(mean), ptr(invstd), c, cp, ptr(dgamma),
            ptr(dbeta), ptr(coef), stream())
 
 
