@@ -50,6 +50,90 @@ def cpu_baseline(size, steps=1, batch=2):
                       % (batch, size[0], steps, t)}
 
 
+def capture_step(step, enabled):
+    """Capture one optimiser step (hundreds of kernel launches) into a hipGraph; returns (graph, static_loss) or (None, None)."""
+    if not enabled:
+        return None, None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gloss = step()
+        graph.replay()
+        torch.cuda.synchronize()
+        return graph, gloss
+    except Exception as e:      # keep the measurement alive: fall back to eager launches
+        print("graph capture failed (%s): eager launches" % (str(e).splitlines()[0][:200]), file=sys.stderr)
+        torch.cuda.synchronize()
+        return None, None
+
+
+def bench_cae(args, world, rank, dev):
+    """BASELINE configs[2]: CAE --channelscae 1 16 24 32 100 800 1, batch 4, 1 x D x 128 x 128 (D = 28 native; the
+    reference cannot close the loss at D = 128), one Learner.train_batch without the CPU metrics."""
+    import torch.distributed as dist
+    from stroke_prediction_amd.common.model.Cae3D import Cae3D, Enc3D, Dec3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.CaeReconstructionLearner import CaeReconstructionLearner
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    from oracle import weights as W          # synthetic blob labels only (input generator, not the checker)
+    ch = [1, 16, 24, 32, 100, 800, 1]
+    d, hw = args.cae_depth, 128
+    torch.manual_seed(1234)
+    cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype=args.dtype), Dec3D(hw, d, ch, 5, 1.0, dtype=args.dtype)).to(dev).train()
+    use_graph = (world == 1) and not args.no_graph
+    opt = FusedAdam([p for p in cae.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999),
+                    grad_scale=1.0 / world, capturable=use_graph)
+    attach_flat_grads(cae)
+
+    class _L:
+        batch_size = args.batch
+    learner = CaeReconstructionLearner(_L(), None, cae, opt, None, 1, None, "/tmp/_bench_cae", BatchDiceLoss([1.0]), verbose=False)
+    labels, clinical = W.cae_inputs(args.batch, d, hw, 1234 + rank)
+    batch = {"case_id": list(range(args.batch)), "images": None, "labels": labels.to(dev), "clinical": clinical.to(dev)}
+
+    def step():
+        dto = learner.inference_step(batch)
+        loss = learner.loss_step(dto, 30)
+        opt.zero_grad()
+        loss.backward()
+        if world > 1:
+            dist.all_reduce(cae.flat_buffers()[1])
+        opt.step()
+        return loss
+
+    for _ in range(max(args.warmup, 3 if use_graph else 0)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    graph, gloss = capture_step(step, use_graph)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+            loss = gloss
+        else:
+            loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    vox = world * args.batch * d * hw * hw * args.steps
+    res = {"metric": "train-step voxels/sec, CAE Bx1xDx128x128 (3 encoder + 4 decoder passes)", "value": vox / dt,
+           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "CAE --channelscae 1 16 24 32 100 800 1, batch %d/GPU, 1x%dx128x128 (configs[2])" % (args.batch, d),
+                      "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss),
+                      "launch": "hipGraph" if graph is not None else "eager"}}
+    if rank == 0:
+        print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -58,8 +142,12 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--workload", default="unet", choices=["unet", "cae"],
+                    help="unet = BASELINE configs[1] (headline); cae = configs[2]: CAE 1 16 24 32 100 800 1, 3 enc + 4 dec passes")
+    ap.add_argument("--cae-depth", type=int, default=28, help="CAE volume depth (28 native, 124 = closest closed size to 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,13 +172,16 @@ def main():
     from stroke_prediction_amd.runtime import ops as O
     from stroke_prediction_amd.runtime.unet_engine import unet_out_dims
 
+    if args.workload == "cae":
+        return bench_cae(args, world, rank, dev)
     size = (args.size,) * 3
     out = unet_out_dims(size)
     torch.manual_seed(1234)                      # identical random-init weights on every rank
     model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).train()
     sync = DataParallelSync(model)
+    use_graph = (world == 1) and not args.no_graph
     opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5,
-                    betas=(0.99, 0.999), grad_scale=sync.grad_scale)   # train_unet_segmentation.py:13-14,32
+                    betas=(0.99, 0.999), grad_scale=sync.grad_scale, capturable=use_graph)   # train_unet_segmentation.py:13-14,32
     attach_flat_grads(model)
     sys.stdout = open(os.devnull, "w") if rank != 0 else sys.stdout
     crit = BatchDiceLoss([1.0])
@@ -111,17 +202,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 3 if use_graph else 0)):
         step()
     fence()
+    # the whole optimiser step (~330 launches) as ONE hipGraph: same kernels, same order, no Python between them
+    graph, gloss = capture_step(step, use_graph)
+    launch_mode = "hipGraph" if graph is not None else "eager"
+    fence()
+    prof = None
     if not args.no_kernel_timing:
+        # per-kernel HIP-event timing needs eager launches: a separate pass over the same steps, not the timed region
         O.PROFILE = []
+        for _ in range(min(args.steps, 3)):
+            step()
+        fence()
+        prof, O.PROFILE = O.PROFILE, None
+        prof_steps = min(args.steps, 3)
+    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        if graph is not None:
+            graph.replay()
+            loss = gloss
+        else:
+            loss = step()
     fence()
     dt = time.perf_counter() - t0
-    prof, O.PROFILE = O.PROFILE, None
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -133,7 +239,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, "
                                "fwd+Dice+bwd+Adam (configs[1])" % (args.batch, args.size, out[0]),
-                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss)},
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss),
+                   "launch": launch_mode},
     }
     # ---- roofline of the dominant kernel, from HIP events recorded around every launch of the timed region
     if prof:
@@ -145,11 +252,13 @@ def main():
             a[2] += 1
         dom = max(agg, key=lambda k: agg[k][0])
         t, fl, n = agg[dom]
+        dt_prof = dt / args.steps * prof_steps
         peak = PEAK_TFLOPS[args.dtype]
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": fl / t / 1e12 / peak, "traffic": None, "launches": n,
-                           "avg_launch_us": 1e6 * t / n, "share_of_step": t / dt}
-        res["kernels"] = {k: {"time_s_per_step": v[0] / args.steps, "tflops": v[1] / v[0] / 1e12, "launches_per_step": v[2] / args.steps}
+                           "avg_launch_us": 1e6 * t / n, "share_of_step": t / dt_prof,
+                           "timing": "HIP events around every launch, %d eager steps right before the timed region" % prof_steps}
+        res["kernels"] = {k: {"time_s_per_step": v[0] / prof_steps, "tflops": v[1] / v[0] / 1e12, "launches_per_step": v[2] / prof_steps}
                           for k, v in agg.items()}
         res["train_step_tflops"] = TRAIN_GFLOP_PER_SAMPLE_128 * (args.size / 128.0) ** 3 * 1e9 * world * args.batch * args.steps / dt / 1e12 \
             if args.size == 128 else None

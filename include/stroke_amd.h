@@ -220,6 +220,11 @@ int sp_lerp_batch(const void* c, const void* p, const float* step, void* out, in
 int sp_adam_step_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                       float eps, float weight_decay, int32_t step, float grad_scale, sp_stream_t stream);
 
+/* same, with the 1-based step count read from device memory (hipGraph-capturable training step) */
+int sp_adam_step_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, const int32_t* step_dev, float grad_scale,
+                          sp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

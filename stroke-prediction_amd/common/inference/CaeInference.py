@@ -30,20 +30,19 @@ class CaeInference(Inference):
             ta_to_tr = batch[data.KEY_GLOBAL][:, 1].reshape(-1, 1).float()
             ttt = ta_to_tr / normalization
         else:
-            ttt = (step * torch.ones(global_variables.size(0), 1)) / normalization
+            ttt = (step * torch.ones(global_variables.size(0), 1, device=normalization.device)) / normalization
         return ttt.reshape(-1, 1, 1, 1, 1)
 
     def init_clinical_variables(self, batch: dict, step):
         globals_incl_time = batch[data.KEY_GLOBAL].float()
         n = globals_incl_time.size(0)
-        type_core = torch.zeros(n, 1, 1, 1, 1)
-        type_penumbra = torch.ones(n, 1, 1, 1, 1)
         time_to_treatment = self.get_time_to_treatment(batch, globals_incl_time, step)
-        if self.is_cuda:
-            dev = self._device()
-            time_to_treatment = time_to_treatment.to(dev)
-            globals_incl_time = globals_incl_time.to(dev)
-            type_core, type_penumbra = type_core.to(dev), type_penumbra.to(dev)
+        dev = self._device() if self.is_cuda else globals_incl_time.device
+        # created on the target device: no host->device copy of constants inside the (graph-capturable) step
+        type_core = torch.zeros(n, 1, 1, 1, 1, device=dev)
+        type_penumbra = torch.ones(n, 1, 1, 1, 1, device=dev)
+        time_to_treatment = time_to_treatment.to(dev)
+        globals_incl_time = globals_incl_time.to(dev)
         return CaeDtoUtil.init_dto(globals_incl_time, time_to_treatment, type_core, type_penumbra,
                                    None, None, None, None, None)
 

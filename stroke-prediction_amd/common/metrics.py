@@ -13,6 +13,16 @@ from torch.nn.modules.loss import _Loss as LossModule
 from common.dto.MetricMeasuresDto import BinaryMeasuresDto
 
 
+_W_CACHE = {}
+
+
+def _weights_on(device, weights):
+    key = (str(device), weights)
+    if key not in _W_CACHE:
+        _W_CACHE[key] = torch.tensor(weights, dtype=torch.float64, device=device)
+    return _W_CACHE[key]
+
+
 class _DiceFn(torch.autograd.Function):
     """loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps); sums over batch and volume per channel."""
 
@@ -25,7 +35,7 @@ class _DiceFn(torch.autograd.Function):
         dhw = o.numel() // (B * C)
         sums = torch.zeros(C, 3, dtype=torch.float64, device=o.device)
         L.call("sp_dice_sums", O.ptr(o), O.ptr(t), B, C, dhw, O.ptr(sums), O.stream())
-        w = torch.tensor(weights, dtype=torch.float64, device=o.device)
+        w = _weights_on(o.device, weights)      # cached: no host->device copy inside a (graph-captured) step
         num = 2.0 * sums[:, 0] + eps
         den = sums[:, 1] + sums[:, 2] + eps
         ctx.save_for_backward(o, t, w, num, den)

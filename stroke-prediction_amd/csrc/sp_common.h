@@ -32,6 +32,17 @@ void sp_set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
+// raise a kernel's dynamic-LDS limit once per (kernel, size) instead of on every launch
+#define SP_ENSURE_LDS(kern, bytes, what)                                                                           \
+  do {                                                                                                             \
+    static int granted_ = 0;                                                                                       \
+    if ((bytes) > 48 * 1024 && (bytes) > granted_) {                                                               \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); \
+      if (e_ != hipSuccess) { sp_set_error("%s: cannot raise LDS limit to %d: %s", what, (int)(bytes), hipGetErrorString(e_)); return SP_EHIP; } \
+      granted_ = (bytes);                                                                                          \
+    }                                                                                                              \
+  } while (0)
+
 // ---- bf16 conversion ------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 

@@ -311,10 +311,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
 template <int NT, int MT, int NP, typename TIN, typename TOUT>
 static int launch_conv(const ConvDev& P, dim3 grid, hipStream_t st) {
   auto kern = conv_igemm_kernel<NT, MT, NP, TIN, TOUT>;
-  if (P.a.lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P.a.lds_bytes);
-    if (e != hipSuccess) { sp_set_error("sp_conv3d_igemm: cannot raise LDS limit to %d: %s", P.a.lds_bytes, hipGetErrorString(e)); return SP_EHIP; }
-  }
+  SP_ENSURE_LDS(kern, P.a.lds_bytes, "sp_conv3d_igemm");
   hipLaunchKernelGGL(kern, grid, dim3(256), P.a.lds_bytes, st, P);
   SP_CHECK_LAUNCH("sp_conv3d_igemm");
   return SP_OK;

@@ -526,8 +526,7 @@ static int launch_persist(ConvDmaDev& P, hipStream_t st) {
 #define SP_PL(T_)                                                                                                  \
   {                                                                                                                \
     auto kern = conv_igemm_persist_kernel<MT, KS, T_>;                                                             \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-    if (e != hipSuccess) { sp_set_error("sp_conv3d_igemm(persist): LDS %d: %s", lds_bytes, hipGetErrorString(e)); return SP_EHIP; } \
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv");                                                          \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);                                             \
   }
   if (P.a.dtype_out == SP_F32) SP_PL(float) else SP_PL(bf16_t)
@@ -539,10 +538,7 @@ static int launch_persist(ConvDmaDev& P, hipStream_t st) {
 template <int NT, int MT, int KS, typename TOUT>
 static int launch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
   auto kern = conv_igemm_dma_kernel<NT, MT, KS, TOUT>;
-  if (P.a.lds_bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, P.a.lds_bytes);
-    if (e != hipSuccess) { sp_set_error("sp_conv3d_igemm(dma): LDS %d: %s", P.a.lds_bytes, hipGetErrorString(e)); return SP_EHIP; }
-  }
+  SP_ENSURE_LDS(kern, P.a.lds_bytes, "sp_conv3d_igemm");
   hipLaunchKernelGGL(kern, grid, dim3(256), P.a.lds_bytes, st, P);
   SP_CHECK_LAUNCH("sp_conv3d_igemm(dma)");
   return SP_OK;

@@ -212,10 +212,7 @@ static int wgrad_dispatch(const WgradDev& P, int COB, int CIB, dim3 grid, int ld
 #define WG_CASE(C_, I_)                                                                              \
   if (COB == C_ && CIB == I_) {                                                                      \
     auto kern = wgrad_kernel<NP, C_, I_, T>;                                                         \
-    if (lds_bytes > 48 * 1024) {                                                                     \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-      if (e != hipSuccess) { sp_set_error("sp_conv3d_wgrad: LDS %d: %s", lds_bytes, hipGetErrorString(e)); return SP_EHIP; } \
-    }                                                                                                \
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_wgrad");                                               \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, P);                                     \
     SP_CHECK_LAUNCH("sp_conv3d_wgrad");                                                              \
     return SP_OK;                                                                                    \

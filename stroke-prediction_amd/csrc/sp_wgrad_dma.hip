@@ -288,8 +288,7 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
 #define WD_CASE(C_, I_)                                                                              \
   if (COB == C_ && CIB == I_) {                                                                      \
     auto kern = wgrad_dma_kernel<C_, I_>;                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
-    if (e != hipSuccess) { sp_set_error("sp_conv3d_wgrad(dma): LDS %d: %s", lds_bytes, hipGetErrorString(e)); return SP_EHIP; } \
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv");                                                          \
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, P);                                     \
     SP_CHECK_LAUNCH("sp_conv3d_wgrad(dma)");                                                         \
     return SP_OK;                                                                                    \

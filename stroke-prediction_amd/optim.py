@@ -14,10 +14,12 @@ from stroke_prediction_amd.runtime import ops as O
 
 
 class FusedAdam(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0,
+                 capturable=False):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.grad_scale = grad_scale
+        self.capturable = capturable      # step count in device memory: the step can be captured in a hipGraph
         self._flat = {}
 
     # ------------------------------------------------------------------ flat detection
@@ -52,7 +54,8 @@ class FusedAdam(Optimizer):
             # flat aliases of the parameter / gradient storage (torch owns the memory)
             pf = torch.as_strided(ps[0].data, (n,), (1,))
             gf = torch.as_strided(ps[0].grad, (n,), (1,))
-            st = dict(key=key, p=pf, g=gf, m=m, v=v)
+            st = dict(key=key, p=pf, g=gf, m=m, v=v,
+                      step_dev=torch.full((1,), int(self.state[ps[0]].get("step", 0)), dtype=torch.int32, device=dev))
             self._flat[gi] = st
         return st
 
@@ -65,6 +68,13 @@ class FusedAdam(Optimizer):
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             st = self._flat_group(gi, group)
+            if st is not None and self.capturable:
+                from stroke_prediction_amd.runtime import lib as L
+                st["step_dev"].add_(1)
+                L.call("sp_adam_step_flat_dev", O.ptr(st["p"]), O.ptr(st["g"]), O.ptr(st["m"]), O.ptr(st["v"]),
+                       st["p"].numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], O.ptr(st["step_dev"]),
+                       self.grad_scale, O.stream())
+                continue
             if st is not None:
                 step = int(self.state[group["params"][0]]["step"]) + 1
                 O.adam_step_flat(st["p"], st["g"], st["m"], st["v"], group["lr"], b1, b2, group["eps"],
@@ -86,6 +96,15 @@ class FusedAdam(Optimizer):
                 O.adam_step_flat(p.data, p.grad.contiguous(), s["exp_avg"], s["exp_avg_sq"], group["lr"], b1, b2,
                                  group["eps"], group["weight_decay"], s["step"], self.grad_scale)
         return loss
+
+    def sync_step_from_device(self):
+        """capturable mode: copy the device step counters into the per-parameter state (before state_dict())."""
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi)
+            if st is not None:
+                step = int(st["step_dev"].item())
+                for p in group["params"]:
+                    self.state[p]["step"] = step
 
     def zero_grad(self, set_to_none=False):
         """Keeps ``p.grad`` attached (the flat gradient buffer is the kernels' accumulation target):
