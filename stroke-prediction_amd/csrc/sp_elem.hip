@@ -62,24 +62,29 @@ __device__ __forceinline__ void block_channel_reduce(const float part[NS][8], in
 }
 
 // ------------------------------------------------------------------------------------------------ layout
+// one thread = one (voxel, 8-channel octet): wide-channel / few-voxel tensors (the CAE latent, 800 x 100) still
+// fill the chip; consecutive threads take consecutive voxels of one octet (coalesced NCDHW reads)
 template <typename T>
 __global__ void ncdhw_to_cl_kernel(const float* __restrict__ src, T* __restrict__ dst, int C, int64_t DHW, int CP,
                                    int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t b = i / DHW, v = i - b * DHW;
-    for (int c0 = 0; c0 < CP; c0 += 8) {
-      float f[8];
+  const int OC = CP / 8;
+  const int64_t items = total * OC;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t bo = it / DHW, v = it - bo * DHW;     // bo = b * OC + octet
+    const int64_t b = bo / OC;
+    const int c0 = (int)(bo - b * OC) * 8;
+    float f[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = (c0 + j < C) ? src[(b * C + c0 + j) * DHW + v] : 0.f;
-      Store<T>::st8(dst + i * CP + c0, f);
-    }
+    for (int j = 0; j < 8; ++j) f[j] = (c0 + j < C) ? src[(b * C + c0 + j) * DHW + v] : 0.f;
+    Store<T>::st8(dst + (b * DHW + v) * CP + c0, f);
   }
 }
 extern "C" int sp_ncdhw_to_cl(const float* src, void* dst, int32_t dtype, int32_t B, int32_t C, int64_t DHW,
                               int32_t CP, sp_stream_t stream) {
   SP_CHECK_ARG(src && dst && C <= CP && CP % 8 == 0, "sp_ncdhw_to_cl: bad arguments");
   const int64_t total = (int64_t)B * DHW;
-  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const int64_t items_ = total * (CP / 8);
+  const unsigned grid = (unsigned)((items_ + 255) / 256 > 8192 ? 8192 : (items_ + 255) / 256);
   if (dtype == SP_BF16) hipLaunchKernelGGL(ncdhw_to_cl_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), src, (bf16_t*)dst, C, DHW, CP, total);
   else hipLaunchKernelGGL(ncdhw_to_cl_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), src, (float*)dst, C, DHW, CP, total);
   SP_CHECK_LAUNCH("sp_ncdhw_to_cl");
@@ -89,22 +94,25 @@ extern "C" int sp_ncdhw_to_cl(const float* src, void* dst, int32_t dtype, int32_
 template <typename T>
 __global__ void cl_to_ncdhw_kernel(const T* __restrict__ src, float* __restrict__ dst, int C, int64_t DHW, int CP,
                                    int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t b = i / DHW, v = i - b * DHW;
-    for (int c0 = 0; c0 < C; c0 += 8) {
-      float f[8];
-      Store<T>::ld8(src + i * CP + c0, f);
+  const int OC = (C + 7) / 8;
+  const int64_t items = total * OC;
+  for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < items; it += (int64_t)gridDim.x * 256) {
+    const int64_t bo = it / DHW, v = it - bo * DHW;
+    const int64_t b = bo / OC;
+    const int c0 = (int)(bo - b * OC) * 8;
+    float f[8];
+    Store<T>::ld8(src + (b * DHW + v) * CP + c0, f);
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (c0 + j < C) dst[(b * C + c0 + j) * DHW + v] = f[j];
-    }
+    for (int j = 0; j < 8; ++j)
+      if (c0 + j < C) dst[(b * C + c0 + j) * DHW + v] = f[j];
   }
 }
 extern "C" int sp_cl_to_ncdhw(const void* src, float* dst, int32_t dtype, int32_t B, int32_t C, int64_t DHW,
                               int32_t CP, sp_stream_t stream) {
   SP_CHECK_ARG(src && dst && C <= CP && CP % 8 == 0, "sp_cl_to_ncdhw: bad arguments");
   const int64_t total = (int64_t)B * DHW;
-  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  const int64_t items_ = total * ((C + 7) / 8);
+  const unsigned grid = (unsigned)((items_ + 255) / 256 > 8192 ? 8192 : (items_ + 255) / 256);
   if (dtype == SP_BF16) hipLaunchKernelGGL(cl_to_ncdhw_kernel<bf16_t>, dim3(grid), dim3(256), 0, ST(stream), (const bf16_t*)src, dst, C, DHW, CP, total);
   else hipLaunchKernelGGL(cl_to_ncdhw_kernel<float>, dim3(grid), dim3(256), 0, ST(stream), (const float*)src, dst, C, DHW, CP, total);
   SP_CHECK_LAUNCH("sp_cl_to_ncdhw");

@@ -65,6 +65,7 @@ class FusedAdam(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        O.bump_param_epoch()          # packed weight fragments cached by the conv runners are stale after this
         for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
             st = self._flat_group(gi, group)

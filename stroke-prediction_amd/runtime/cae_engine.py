@@ -42,7 +42,7 @@ def channel_map(channels):
 class StackContext:
     """One call of an encoder / decoder stack: layers (with their activations), scratch, I/O staging."""
 
-    def __init__(self, table, prefix, channels, alpha, batch, in_dims, dtype, device, last_sigmoid):
+    def __init__(self, table, prefix, channels, alpha, batch, in_dims, dtype, device, last_sigmoid, bank=None):
         O.require_gpu()
         L.load()
         cm = channel_map(channels)
@@ -56,7 +56,7 @@ class StackContext:
             lay = ConvLayer("%s.%d" % (prefix, 3 * i + 1), kind, cm[ci], cm[co], k, s, p, dims, batch, dtype, device, sc,
                             bn_prefix="%s.%d" % (prefix, 3 * i), conv_prefix="%s.%d" % (prefix, 3 * i + 1),
                             act=L.ACT_SIGMOID if last else L.ACT_ELU, act_param=0.0 if last else alpha,
-                            out_dtype=L.SP_F32 if last else None, need_input_grad=True)
+                            out_dtype=L.SP_F32 if last else None, need_input_grad=True, bank=bank)
             self.layers.append(lay)
             dims = lay.out_dims
         self.in_dims, self.out_dims = tuple(in_dims), dims
@@ -121,6 +121,7 @@ class StackPool:
     def __init__(self, table, prefix, channels, alpha, last_sigmoid):
         self.table, self.prefix, self.channels, self.alpha, self.last_sigmoid = table, prefix, channels, alpha, last_sigmoid
         self.free = {}
+        self.banks = {}
 
     def acquire(self, batch, in_dims, dtype, device):
         key = (batch, tuple(in_dims), dtype, str(device))
@@ -128,7 +129,7 @@ class StackPool:
         if lst:
             return key, lst.pop()
         return key, StackContext(self.table, self.prefix, self.channels, self.alpha, batch, in_dims, dtype, device,
-                                 self.last_sigmoid)
+                                 self.last_sigmoid, bank=self.banks.setdefault(key, {}))
 
     def release(self, key, ctx):
         lst = self.free.setdefault(key, [])
@@ -137,3 +138,4 @@ class StackPool:
 
     def clear(self):
         self.free = {}
+        self.banks = {}

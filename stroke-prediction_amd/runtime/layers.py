@@ -45,7 +45,7 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True, cpi=None):
+                 need_input_grad=True, cpi=None, bank=None):
         self.name, self.kind = name, kind
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.in_dims, self.batch, self.dtype, self.device = tuple(in_dims), batch, dtype, device
@@ -57,7 +57,8 @@ class ConvLayer:
         mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
         self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
         self.out_dims = tuple(self.fwd_op.y_dims)
-        self.fwd = O.ConvRunner(self.fwd_op, device)
+        self.bank = bank            # optional dict shared by the layers of all contexts of one stack (packed weights)
+        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if bank is None else bank.setdefault((name, "fwd"), {}))
         self.count = float(batch * in_dims[0] * in_dims[1] * in_dims[2])
         # un-padded bf16 convolutions fold the BatchNorm into weights/bias so the tile can be staged by DMA
         pads = pad if isinstance(pad, (tuple, list)) else (pad,) * 3
@@ -126,7 +127,7 @@ class ConvLayer:
                                        cout * kk, kk, dt, dev)
             dop = P.convT_dgrad_op(cin, cout, k, s, p, self.in_dims, self.cpo, self.cpi, dt)
         if self.need_input_grad or self.bn_prefix is not None:
-            self.dgrad = O.ConvRunner(dop, dev)
+            self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}))
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
         if self.bn_prefix is not None:
             self.coef = torch.zeros(3, self.cpi, device=dev)
