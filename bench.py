@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--cae-depth", type=int, default=28, help="CAE volume depth (28 native, 124 = closest closed size to 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dp-mode", default="fast", choices=["fast", "exact"],
+                    help="multi-GPU: fast = local BatchNorm/Dice + gradient mean; exact = global-batch BatchNorm and Dice sums")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -178,7 +180,7 @@ def main():
     out = unet_out_dims(size)
     torch.manual_seed(1234)                      # identical random-init weights on every rank
     model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).train()
-    sync = DataParallelSync(model)
+    sync = DataParallelSync(model, mode=args.dp_mode)
     use_graph = (world == 1) and not args.no_graph
     opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5,
                     betas=(0.99, 0.999), grad_scale=sync.grad_scale, capturable=use_graph)   # train_unet_segmentation.py:13-14,32
@@ -240,7 +242,7 @@ def main():
         "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, "
                                "fwd+Dice+bwd+Adam (configs[1])" % (args.batch, args.size, out[0]),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss),
-                   "launch": launch_mode},
+                   "launch": launch_mode, "dp_mode": args.dp_mode if world > 1 else None},
     }
     # ---- roofline of the dominant kernel, from HIP events recorded around every launch of the timed region
     if prof:
@@ -254,8 +256,14 @@ def main():
         t, fl, n = agg[dom]
         dt_prof = dt / args.steps * prof_steps
         peak = PEAK_TFLOPS[args.dtype]
+        traffic = None
+        try:    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f)[dom]["bytes_per_launch"]
+        except Exception:
+            pass
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                           "frac": fl / t / 1e12 / peak, "traffic": None, "launches": n,
+                           "frac": fl / t / 1e12 / peak, "traffic": traffic, "launches": n,
                            "avg_launch_us": 1e6 * t / n, "share_of_step": t / dt_prof,
                            "timing": "HIP events around every launch, %d eager steps right before the timed region" % prof_steps}
         res["kernels"] = {k: {"time_s_per_step": v[0] / prof_steps, "tflops": v[1] / v[0] / 1e12, "launches_per_step": v[2] / prof_steps}

@@ -167,6 +167,7 @@ int sp_bn_bwd_reduce(const void* g, const void* x, int32_t dtype, int64_t nvox, 
  * coef[3][CP] with dx = coef0*g + coef1*x + coef2 */
 int sp_bn_bwd_finalize(const double* sums /* [nrep][CP][2] */, int32_t nrep, double count, const float* gamma, const float* mean,
                        const float* invstd, int32_t C, int32_t CP, float* dgamma, float* dbeta, float* coef,
+                       float param_grad_scale /* dgamma/dbeta += scale * value; 1/world when the sums are global */,
                        sp_stream_t stream);
 /* dz = (coef0*g + coef1*y + coef2) * act'(y)  (coef NULL: dz = g*act'(y));
  * dbias_sums[c] += sum_voxels dz (fp64, may be NULL) */

@@ -35,6 +35,9 @@ class _DiceFn(torch.autograd.Function):
         dhw = o.numel() // (B * C)
         sums = torch.zeros(C, 3, dtype=torch.float64, device=o.device)
         L.call("sp_dice_sums", O.ptr(o), O.ptr(t), B, C, dhw, O.ptr(sums), O.stream())
+        from stroke_prediction_amd.runtime.layers import SYNC, _allreduce
+        if SYNC["on"]:                  # Dice is a ratio of WHOLE-batch sums (metrics.py:24-27): make them global
+            _allreduce(sums)
         w = _weights_on(o.device, weights)      # cached: no host->device copy inside a (graph-captured) step
         num = 2.0 * sums[:, 0] + eps
         den = sums[:, 1] + sums[:, 2] + eps

@@ -228,7 +228,7 @@ extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, co
 // coef0 = gamma*invstd, coef1 = -gamma*invstd^2*dgamma/N, coef2 = -coef0*dbeta/N - coef1*mean
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
                                        const float* __restrict__ mean, const float* __restrict__ invstd, int C, int CP,
-                                       float* dgamma, float* dbeta, float* coef) {
+                                       float* dgamma, float* dbeta, float* coef, float pscale) {
   const int c = blockIdx.x, lane = threadIdx.x;
   if (c >= C) { if (lane == 0) { coef[c] = 0.f; coef[CP + c] = 0.f; coef[2 * CP + c] = 0.f; } return; }
   double s1 = 0, s2 = 0;
@@ -237,7 +237,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nrep
   if (lane != 0) return;
   const double mu = mean[c], is = invstd[c], ga = gamma[c];
   const double dg = (s2 - mu * s1) * is, db = s1;
-  if (dgamma) { dgamma[c] += (float)dg; dbeta[c] += (float)db; }
+  if (dgamma) { dgamma[c] += pscale * (float)dg; dbeta[c] += pscale * (float)db; }
   const double c0 = ga * is, c1 = -ga * is * is * dg / count;
   coef[c] = (float)c0;
   coef[CP + c] = (float)c1;
@@ -245,9 +245,9 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nrep
 }
 extern "C" int sp_bn_bwd_finalize(const double* sums, int32_t nrep, double count, const float* gamma, const float* mean,
                                   const float* invstd, int32_t C, int32_t CP, float* dgamma, float* dbeta, float* coef,
-                                  sp_stream_t stream) {
+                                  float param_grad_scale, sp_stream_t stream) {
   SP_CHECK_ARG(sums && gamma && mean && invstd && coef && count > 0, "sp_bn_bwd_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep < 1 ? 1 : nrep, count, gamma, mean, invstd, C, CP, dgamma, dbeta, coef);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep < 1 ? 1 : nrep, count, gamma, mean, invstd, C, CP, dgamma, dbeta, coef, param_grad_scale);
   SP_CHECK_LAUNCH("sp_bn_bwd_finalize");
   return SP_OK;
 }

@@ -5,24 +5,46 @@ fp32 gradient buffer (1.42 MB for the default U-Net -> latency-bound, a single a
 
 mode "fast" (default): local BatchNorm statistics and local Dice sums per rank, gradients averaged --
 what plain DDP would do; differs from the single-process reference at O(1/B_local).
+
+mode "exact": reproduces the single-process reference on the GLOBAL batch.  Three extra exchanges, all tiny:
+BatchNorm forward sums (sum x, sum x^2) before every normalisation, BatchNorm backward sums (sum g, sum g*x),
+and the three Dice sums per output; local gradients are then partial sums of the global gradient, so the flat
+all-reduce SUMS and the optimiser must NOT divide (``grad_scale`` = 1); BatchNorm gamma/beta gradients, which
+every rank already holds in full, are pre-scaled by 1/world.
 """
 import torch
 import torch.distributed as dist
 
 
 class DataParallelSync:
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, mode="fast"):
+        assert mode in ("fast", "exact")
         self.model = model
         self.group = process_group
+        self.mode = mode
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         if self.world > 1:
             model.grad_sync = self._sync
             self.broadcast_parameters()
+            if mode == "exact":
+                from stroke_prediction_amd.runtime import layers
+                layers.SYNC.update(group=process_group, world=self.world, on=True)
+
+    def close(self):
+        from stroke_prediction_amd.runtime import layers
+        layers.SYNC.update(group=None, world=1, on=False)
+        self.model.grad_sync = None
 
     @property
     def grad_scale(self):
-        """pass to FusedAdam(grad_scale=...): the all-reduce SUMS, the optimiser divides"""
-        return 1.0 / self.world
+        """pass to FusedAdam(grad_scale=...).  fast: the all-reduce SUMS local-mean gradients, the optimiser divides;
+        exact: the summed local gradients ARE the global gradient."""
+        return 1.0 if self.mode == "exact" else 1.0 / self.world
+
+    def sync(self):
+        """for models whose autograd node does not call ``grad_sync`` itself (the CAE: 7 nodes per step)"""
+        if self.world > 1:
+            self._sync(self.model.flat_buffers()[1])
 
     def broadcast_parameters(self, src=0):
         flat, _ = self.model.flat_buffers()

@@ -14,6 +14,16 @@ from . import plan as P
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# exact data-parallel mode (parallel.DataParallelSync(mode="exact")): BatchNorm sums are all-reduced so every rank
+# normalises with the statistics of the GLOBAL batch, as the single-process reference does
+SYNC = {"group": None, "world": 1, "on": False}
+
+
+def _allreduce(t):
+    import torch.distributed as dist
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=SYNC["group"])
+
+
 STATS_NREP = 64     # replicas of the conv-epilogue statistics accumulators (spreads same-address fp64 atomics)
 
 
@@ -91,7 +101,11 @@ class ConvLayer:
         """x: channels-last input; returns the (cached) output tensor."""
         if self.bn_prefix is not None:
             p = self.bn_prefix
-            O.bn_finalize(self.in_sums if training else None, self.count, params[p + ".weight"], params[p + ".bias"],
+            world = 1
+            if training and SYNC["on"]:
+                _allreduce(self.in_sums)
+                world = SYNC["world"]
+            O.bn_finalize(self.in_sums if training else None, self.count * world, params[p + ".weight"], params[p + ".bias"],
                           bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
                           self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
             if training:
@@ -169,6 +183,11 @@ class ConvLayer:
         else:
             self.dgrad.run(self.dz, self.g, self.batch)
             O.bn_bwd_reduce(self.g, x, self.dtype, bs)
-        O.bn_bwd_finalize(bs, self.count, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
-                          grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=STATS_NREP if fused else 1)
+        world = 1
+        if SYNC["on"]:
+            _allreduce(bs)
+            world = SYNC["world"]      # sums are global now: every rank holds the full dgamma/dbeta -> scale by 1/world
+        O.bn_bwd_finalize(bs, self.count * world, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
+                          grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=STATS_NREP if fused else 1,
+                          pscale=1.0 / world)
         return self.g, self.coef

@@ -47,7 +47,7 @@ _SIGS = {
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),
     "sp_bn_finalize": ([vp, i32, f64, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "sp_bn_bwd_reduce": ([vp, vp, i32, i64, i32, vp, vp], i32),
-    "sp_bn_bwd_finalize": ([vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, vp], i32),
+    "sp_bn_bwd_finalize": ([vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, f32, vp], i32),
     "sp_bn_act_bwd": ([vp, vp, vp, i32, i64, i32, i32, f32, vp, vp, vp], i32),
     "sp_maxpool2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp, vp], i32),
     "sp_upsample2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp], i32),

@@ -271,9 +271,9 @@ def bn_bwd_reduce(g, x, dtype, sums):
     L.call("sp_bn_bwd_reduce", ptr(g), ptr(x), dtype, nvox, x.shape[-1], ptr(sums), stream())
 
 
-def bn_bwd_finalize(sums, count, gamma, mean, invstd, c, cp, dgamma, dbeta, coef, nrep=1):
+def bn_bwd_finalize(sums, count, gamma, mean, invstd, c, cp, dgamma, dbeta, coef, nrep=1, pscale=1.0):
     L.call("sp_bn_bwd_finalize", ptr(sums), nrep, float(count), ptr(gamma), ptr(mean), ptr(invstd), c, cp, ptr(dgamma),
-           ptr(dbeta), ptr(coef), stream())
+           ptr(dbeta), ptr(coef), pscale, stream())
 
 
 def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias):

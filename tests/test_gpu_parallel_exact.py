@@ -1,0 +1,82 @@
+"""Exact global-batch data parallelism: two ranks, each with half of the batch, must reproduce the
+single-process run on the whole batch -- outputs, loss and every gradient -- because BatchNorm statistics and
+BatchDiceLoss are whole-batch quantities in the reference.  Both ranks share the one GPU of the test box and talk
+over gloo (RCCL refuses two ranks on one device); the exchange code path is the one used with RCCL."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CH = [2, 16, 32, 64, 32, 16, 32, 2]
+
+
+def _run(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stroke_prediction_amd  # noqa: F401
+    from oracle import weights as W
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    import stroke_prediction_amd.common.dto.UnetDto as UD
+    from stroke_prediction_amd.optim import attach_flat_grads
+    from stroke_prediction_amd.parallel import DataParallelSync
+    dev = "cuda:0"
+    x, y = W.unet_inputs(4, (44, 44, 44), 31)
+    crit = BatchDiceLoss([1.0])
+
+    def run(model, xs, ys):
+        attach_flat_grads(model)
+        dto = model(UD.init_dto(xs.to(dev), ys[:, 0:1].to(dev), ys[:, 1:2].to(dev)))
+        loss = (crit(dto.outputs.core, dto.given_variables.core) + crit(dto.outputs.penu, dto.given_variables.penu)) / 2
+        loss.backward()
+        seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1).detach().cpu()
+        return seg, float(loss.detach()), model.flat_buffers()[1].clone().cpu(), \
+            {n: b.detach().cpu().clone() for n, b in model.named_buffers()}
+
+    def fresh():
+        m = Unet3D(CH, dtype="f32")
+        m.load_state_dict(W.make_state_dict(W.unet_spec(CH), 31))
+        return m.to(dev).train()
+
+    # reference: the whole batch in one process (no sync installed yet)
+    ref = run(fresh(), x, y) if rank == 0 else None
+    dist.barrier()
+    model = fresh()
+    sync = DataParallelSync(model, mode="exact")
+    lo, hi = rank * 2, rank * 2 + 2
+    seg, loss, grad, bufs = run(model, x[lo:hi], y[lo:hi])
+    sync.close()
+    if rank == 0:
+        rseg, rloss, rgrad, rbufs = ref
+        out = dict(seg=float((seg - rseg[lo:hi]).abs().max()), loss=abs(loss - rloss),
+                   grad=float((grad - rgrad).norm() / rgrad.norm()),
+                   rm=max(float((bufs[n] - rbufs[n]).abs().max()) for n in bufs if n.endswith("running_mean")),
+                   rv=max(float((bufs[n] - rbufs[n]).abs().max()) for n in bufs if n.endswith("running_var")),
+                   scale=sync.grad_scale)
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_mode_two_ranks_equal_single_process():
+    world, port = 2, 29741
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res["scale"] == 1.0
+    assert res["seg"] < 1e-4 and res["loss"] < 1e-5, res
+    assert res["grad"] < 2e-2, res        # LeakyReLU-kink flips only (see test_gpu_unet.py); typical 1e-4
+    assert res["rm"] < 1e-4 and res["rv"] < 1e-3, res
