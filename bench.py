@@ -149,6 +149,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--dp-mode", default="fast", choices=["fast", "exact"],
                     help="multi-GPU: fast = local BatchNorm/Dice + gradient mean; exact = global-batch BatchNorm and Dice sums")
+    ap.add_argument("--layers", action="store_true", help="print per-layer conv kernel timings to stderr")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
 
@@ -247,11 +248,19 @@ def main():
     # ---- roofline of the dominant kernel, from HIP events recorded around every launch of the timed region
     if prof:
         agg = {}
-        for tag, flops, e0, e1 in prof:
+        per_layer = {}
+        for tag, flops, e0, e1, detail in prof:
             a = agg.setdefault(tag, [0.0, 0.0, 0])
-            a[0] += e0.elapsed_time(e1) * 1e-3
+            ms = e0.elapsed_time(e1)
+            a[0] += ms * 1e-3
             a[1] += flops
             a[2] += 1
+            pl = per_layer.setdefault((tag, detail), [0.0, 0.0, 0])
+            pl[0] += ms * 1e-3; pl[1] += flops; pl[2] += 1
+        if args.layers:
+            for (tag, detail), (tt, ff, nn) in sorted(per_layer.items(), key=lambda kv: -kv[1][0]):
+                print("  %-11s %-34s %7.1f us/launch  %6.1f TFLOP/s  x%d/step" % (tag, detail, 1e6 * tt / nn, ff / tt / 1e12, nn // prof_steps),
+                      file=sys.stderr)
         dom = max(agg, key=lambda k: agg[k][0])
         t, fl, n = agg[dom]
         dt_prof = dt / args.steps * prof_steps

@@ -208,6 +208,21 @@ int sp_dice_sums(const float* o, const float* t, int32_t B, int32_t C, int64_t D
 int sp_dice_bwd(const float* o, const float* t, const float* ca, const float* cb, int32_t B, int32_t C,
                 int64_t DHW, float* dout, sp_stream_t stream);
 
+/* ------------------------------------------------------------------ fused classify head (Unet3D.py:49-54,75-77)
+ * seg = sigmoid(W2 * lrelu(W1*x + b1) + b2): x channels-last [B*nvox][CP], seg NCDHW fp32 [B][NC][nvox].
+ * w1 is (CH, C), w2 is (NC, CH) row-major (the Conv3d 1x1x1 weights).  sp_head_supported lists the shapes with a
+ * fused kernel; other shapes run as two generic sp_conv3d_igemm layers. */
+int sp_head_supported(int32_t C, int32_t CH, int32_t NC);
+int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                const float* b1, int32_t CH, const float* w2, const float* b2, int32_t NC, float slope, float* seg,
+                sp_stream_t stream);
+/* backward: dz = dL/dx * act_x'(x) (x is the producing conv's post-activation output), dbias_sums[c] += sum dz,
+ * hgrad_sums (fp64, zeroed by the caller) += [dW1 (CH*C) | db1 (CH) | dW2 (NC*CH) | db2 (NC)] */
+int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
+                const float* dseg, int32_t act_x, float act_x_param, void* dz, double* dbias_sums,
+                double* hgrad_sums, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int sp_add_f64_to_f32(const double* src, float* dst, int64_t n, float scale, sp_stream_t stream); /* dst += scale*src */
 int sp_axpby(const void* x, const void* y, void* out, int32_t dtype, int64_t n, float a, float b, sp_stream_t stream);

@@ -603,9 +603,9 @@ int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
     return launch_persist<8, 7>(P, st);
   }
 #define SP_CASE(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return dispatch_dma<NT_, MT_>(P, grid, st)
-  SP_CASE(1, 8); SP_CASE(2, 8); SP_CASE(4, 8);
-  SP_CASE(1, 4); SP_CASE(2, 4); SP_CASE(4, 4);
-  SP_CASE(1, 2); SP_CASE(2, 2); SP_CASE(4, 2);
+  SP_CASE(1, 8); SP_CASE(2, 8); SP_CASE(3, 8); SP_CASE(4, 8);
+  SP_CASE(1, 4); SP_CASE(2, 4); SP_CASE(3, 4); SP_CASE(4, 4);
+  SP_CASE(1, 2); SP_CASE(2, 2); SP_CASE(3, 2); SP_CASE(4, 2);
 #undef SP_CASE
   sp_set_error("sp_conv3d_igemm(dma): no kernel for NT=%d MT=%d", a->NT, a->MT);
   return SP_EINVAL;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libstroke_amd.so")
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_elem.hip"]
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_head.hip", "sp_elem.hip"]
 
 SP_BF16, SP_F32 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -58,6 +58,9 @@ _SIGS = {
     "sp_out_grad_to_cl": ([vp, vp, i32, i32, i64, i32, i32, i32, f32, vp, vp, vp], i32),
     "sp_dice_sums": ([vp, vp, i32, i32, i64, vp, vp], i32),
     "sp_dice_bwd": ([vp, vp, vp, vp, i32, i32, i64, vp, vp], i32),
+    "sp_head_supported": ([i32, i32, i32], i32),
+    "sp_head_fwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, vp, i32, f32, vp, vp], i32),
+    "sp_head_bwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, i32, f32, vp, vp, i32, f32, vp, vp, vp, vp], i32),
     "sp_add_f64_to_f32": ([vp, vp, i64, f32, vp], i32),
     "sp_axpby": ([vp, vp, vp, i32, i64, f32, f32, vp], i32),
     "sp_lerp_batch": ([vp, vp, vp, vp, i32, i32, i64, vp], i32),

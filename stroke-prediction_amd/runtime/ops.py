@@ -27,8 +27,8 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, tag, flops):
-        self.tag, self.flops = tag, flops
+    def __init__(self, tag, flops, detail=""):
+        self.tag, self.flops, self.detail = tag, flops, detail
 
     def __enter__(self):
         if PROFILE is not None:
@@ -40,7 +40,7 @@ class _Timed:
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.tag, self.flops, self.e0, self.e1))
+            PROFILE.append((self.tag, self.flops, self.e0, self.e1, self.detail))
         return False
 
 
@@ -171,7 +171,8 @@ class ConvRunner:
                 setattr(a, k, t[k])
             a.dma = int(t["dma"] and in_scale is None and USE_DMA)
             a.persist = int(USE_PERSIST)
-            with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout):
+            with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout,
+                        "%d->%d @%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_igemm", C.byref(a), st)
 
 
@@ -229,7 +230,8 @@ class WgradRunner:
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
         st = stream()
-        with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout):
+        with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout,
+                    "%d->%d @%dx%dx%d %s" % (self.cin, self.cout, a.Di, a.Hi, a.Wi, "dma" if a.dma else "reg")):
             L.call("sp_conv3d_wgrad", C.byref(a), st)
         if fold:
             L.call("sp_wgrad_finish_folded", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,

@@ -160,9 +160,9 @@ def convT_dgrad_op(cin, cout, k, stride, pad, in_dims, cp_dz, cp_g, dtype=0):
 
 def _pick_nt(nttot):
     best = None
-    for nt in (4, 2, 1):
+    for nt in (4, 3, 2, 1):      # fewest passes over the input tile first, then least padding
         padded = -(-nttot // nt) * nt
-        key = (padded, -nt)
+        key = (padded // nt, padded)
         if best is None or key < best[0]:
             best = (key, nt, padded)
     return best[1], best[2]

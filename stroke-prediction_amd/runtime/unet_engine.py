@@ -75,6 +75,9 @@ class UnetEngine:
         self.h0 = mk("classify.0", b5, bc, d52, bn=False, k=1)
         self.h2 = mk("classify.2", bc, ncls, d52, bn=False, k=1, act=L.ACT_SIGMOID, ap=0.0, out_dtype=L.SP_F32)
         self.out_dims = d52
+        # fused pointwise head where a kernel exists for (C, CH, NC); the two generic 1x1 layers otherwise
+        self.fused_head = bool(L.load().sp_head_supported(b5, bc, ncls)) and b5 % 8 == 0
+        self.hgrad_id = sc.reserve(bc * b5 + bc + ncls * bc + ncls)
         self.d12, self.dp1, self.d22, self.dp2, self.d32, self.dc4, self.d42, self.dc5 = d12, dp1, d22, dp2, d32, dc4, d42, dc5
         self.layers = [self.c11, self.c12, self.c21, self.c22, self.c31, self.c32, self.c41, self.c42, self.c51,
                        self.c52, self.h0, self.h2]
@@ -121,9 +124,15 @@ class UnetEngine:
         O.crop_copy(y12, self.cat5, c4, dt, None if s5 is None else s5[2 * c4:])
         y51 = self.c51.forward(self.cat5, params, bufs, training, st(self.c52))
         y52 = self.c52.forward(y51, params, bufs, training)
+        seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)
+        if self.fused_head:
+            nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
+            L.call("sp_head_fwd", O.ptr(y52), dt, nv, B, y52.shape[-1], self.channels[5], O.ptr(params["classify.0.weight"]),
+                   O.ptr(params["classify.0.bias"]), self.channels[6], O.ptr(params["classify.2.weight"]),
+                   O.ptr(params["classify.2.bias"]), self.ncls, LEAKY, O.ptr(seg), O.stream())
+            return seg
         h = self.h0.forward(y52, params, bufs, training)
         o = self.h2.forward(h, params, bufs, training)
-        seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)
         O.cl_to_ncdhw(o, seg, L.SP_F32)
         return seg
 
@@ -133,15 +142,30 @@ class UnetEngine:
         Must follow a training-mode forward on the same engine (activations are kept in the layers)."""
         dt = self.dtype
         for l in self.layers:
-            l._init_bwd()
+            if not (self.fused_head and l in (self.h0, self.h2)):
+                l._init_bwd()
         c = self
         dseg = dseg.contiguous()
-        # output side: dz of the last 1x1 conv = dseg * sigmoid'(seg)
-        O.out_grad_to_cl(dseg, seg, dt, L.ACT_SIGMOID, 0.0, c.h2.dz, c.h2.dbias_sums)
-        g, _ = c.h2.backward(c.h0.y, params, grads)
-        O.bn_act_bwd(g, c.h0.y, None, dt, L.ACT_LEAKY, LEAKY, c.h0.dz, c.h0.dbias_sums)
-        g, _ = c.h0.backward(c.c52.y, params, grads)
-        O.bn_act_bwd(g, c.c52.y, None, dt, L.ACT_LEAKY, LEAKY, c.c52.dz, c.c52.dbias_sums)
+        if self.fused_head:
+            nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
+            b5, bc, ncls = self.channels[5], self.channels[6], self.ncls
+            hg = self.scratch.get(self.hgrad_id)
+            L.call("sp_head_bwd", O.ptr(c.c52.y), dt, nv, self.batch, c.c52.y.shape[-1], b5,
+                   O.ptr(params["classify.0.weight"]), O.ptr(params["classify.0.bias"]), bc,
+                   O.ptr(params["classify.2.weight"]), ncls, LEAKY, O.ptr(seg), O.ptr(dseg), L.ACT_LEAKY, LEAKY,
+                   O.ptr(c.c52.dz), O.ptr(c.c52.dbias_sums), O.ptr(hg), O.stream())
+            o0 = 0
+            for name, n in (("classify.0.weight", bc * b5), ("classify.0.bias", bc), ("classify.2.weight", ncls * bc),
+                            ("classify.2.bias", ncls)):
+                O.add_f64_to_f32(hg[o0:o0 + n], grads[name], n)
+                o0 += n
+        else:
+            # output side: dz of the last 1x1 conv = dseg * sigmoid'(seg)
+            O.out_grad_to_cl(dseg, seg, dt, L.ACT_SIGMOID, 0.0, c.h2.dz, c.h2.dbias_sums)
+            g, _ = c.h2.backward(c.h0.y, params, grads)
+            O.bn_act_bwd(g, c.h0.y, None, dt, L.ACT_LEAKY, LEAKY, c.h0.dz, c.h0.dbias_sums)
+            g, _ = c.h0.backward(c.c52.y, params, grads)
+            O.bn_act_bwd(g, c.c52.y, None, dt, L.ACT_LEAKY, LEAKY, c.c52.dz, c.c52.dbias_sums)
         g, coef = c.c52.backward(c.c51.y, params, grads)
         O.bn_act_bwd(g, c.c51.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c51.dz, c.c51.dbias_sums)
         g5, coef5 = c.c51.backward(c.cat5, params, grads)

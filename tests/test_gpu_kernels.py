@@ -324,3 +324,48 @@ def test_adam_matches_torch():
         opt.step()
         O.adam_step_flat(p, gr.to(DEV), m, v, 1e-3, 0.99, 0.999, 1e-8, 1e-5, step)
     torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
+@pytest.mark.parametrize("C,CH,NC,CP", [(16, 32, 2, 16), (16, 16, 2, 16), (16, 32, 1, 16)])
+def test_fused_head(dtype, C, CH, NC, CP):
+    """sp_head_fwd / sp_head_bwd against autograd of the classify Sequential (Unet3D.py:49-54)."""
+    assert L.load().sp_head_supported(C, CH, NC) == 1
+    assert L.load().sp_head_supported(24, 32, 2) == 0
+    torch.manual_seed(5)
+    B, dims = 2, (5, 9, 13)                      # 585 voxels / sample: ragged against the 256-voxel blocks
+    nv = dims[0] * dims[1] * dims[2]
+    y = rnd(dtype, F.leaky_relu(torch.randn(B, C, *dims), 0.01)).requires_grad_(True)   # the producing conv's output
+    w1 = (torch.randn(CH, C) * 0.3).requires_grad_(True)
+    b1 = (torch.randn(CH) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(NC, CH) * 0.3).requires_grad_(True)
+    b2 = (torch.randn(NC) * 0.1).requires_grad_(True)
+    h = F.leaky_relu(F.conv3d(y, w1.view(CH, C, 1, 1, 1), b1), 0.01)
+    seg_ref = torch.sigmoid(F.conv3d(h, w2.view(NC, CH, 1, 1, 1), b2))
+    dseg = torch.randn_like(seg_ref)
+    seg_ref.backward(dseg)
+    # reference dz: dL/dy times LeakyReLU'(pre-activation), recovered from the sign of y
+    dz_ref = y.grad * torch.where(y.detach() > 0, torch.tensor(1.0), torch.tensor(0.01))
+
+    x_cl = to_cl(y.detach(), CP, dtype)
+    dv = lambda t: t.detach().to(DEV).contiguous()
+    W1, B1, W2, B2 = dv(w1), dv(b1), dv(w2), dv(b2)
+    seg = torch.empty((B, NC) + dims, dtype=torch.float32, device=DEV)
+    L.call("sp_head_fwd", O.ptr(x_cl), dtype, nv, B, CP, C, O.ptr(W1), O.ptr(B1), CH, O.ptr(W2), O.ptr(B2), NC, 0.01,
+           O.ptr(seg), O.stream())
+    torch.testing.assert_close(seg.cpu(), seg_ref.detach(), rtol=1e-5, atol=1e-5)
+
+    dz = torch.full_like(x_cl, 7.0)
+    dbs = torch.zeros(CP, dtype=torch.float64, device=DEV)
+    hg = torch.zeros(CH * C + CH + NC * CH + NC, dtype=torch.float64, device=DEV)
+    DS = dv(dseg)
+    L.call("sp_head_bwd", O.ptr(x_cl), dtype, nv, B, CP, C, O.ptr(W1), O.ptr(B1), CH, O.ptr(W2), NC, 0.01, O.ptr(seg),
+           O.ptr(DS), L.ACT_LEAKY, 0.01, O.ptr(dz), O.ptr(dbs), O.ptr(hg), O.stream())
+    torch.testing.assert_close(from_cl(dz, C, dtype), dz_ref, **TOL[dtype])
+    torch.testing.assert_close(dbs[:C].cpu().float(), dz_ref.sum((0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
+    hg = hg.cpu().float()
+    o = 0
+    for ref in (w1.grad, b1.grad, w2.grad, b2.grad):
+        n = ref.numel()
+        torch.testing.assert_close(hg[o:o + n].view(ref.shape), ref, rtol=1e-4, atol=1e-3)
+        o += n
