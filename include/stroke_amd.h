@@ -107,9 +107,11 @@ int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, in
                       const float* bias, const float* shift, float* bias_out, int32_t CoutPad, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ weight gradient
- * dw[co,ci,tap] += sum_{b,o} dz[b,o,co] * xin[b, o*s + o0 + tapoff(tap), ci]   (fp32 atomics)
- * dw_acc layout: [ntap][CoutP16][CinP16] fp32 (zeroed by caller); sp_wgrad_finish scatters it
- * (accumulating) into the (Cout,Cin,k,k,k)-layout gradient buffer. */
+ * dw[co,ci,tap] += sum_{b,o} dz[b,o,co] * xin[b, o*s + o0 + tapoff(tap), ci]
+ * dw_acc layout: [ntap][CoutP16][CinP16] fp32.  parts == 0: one such block, zeroed by the caller, accumulated with
+ * fp32 atomics.  parts == 1: `nblocks` such blocks, one WRITTEN (not accumulated) by each of the nblocks persistent
+ * workgroups -- no atomics, deterministic; cross-XCD atomics cost 40-90 us per layer on MI355X.  sp_wgrad_finish
+ * adds the blocks up and scatters them (accumulating) into the (Cout,Cin,k,k,k)-layout gradient buffer. */
 typedef struct sp_wgrad_args {
   const void* x;         /* [B][Di][Hi][Wi][CPi] conv input (pre-norm) */
   const void* dz;        /* [B][Do][Ho][Wo][CPo] gradient at the conv output (pre-activation) */
@@ -128,17 +130,18 @@ typedef struct sp_wgrad_args {
   int32_t nblocks;       /* persistent grid size */
   int32_t dma;           /* 1: bf16 LDS-DMA double-buffered path (stride 1, padding 0, 3x3x3, no affine on load) */
   int32_t tile_rows;     /* dma: 0 = choose, else force TZ*TY rows of 32 voxels per tile (tuning knob) */
+  int32_t parts;         /* 1: dw_acc holds nblocks partial blocks (see above) */
 } sp_wgrad_args;
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 /* BatchNorm folded out of the operand load (un-padded convolutions):
  * dw[co,ci,tap] += scale[ci]*dw_acc[tap][co][ci] + shift[ci]*dbias_sums[co] */
-int sp_wgrad_finish_folded(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                            int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                            const float* shift, const double* dbias_sums, float* dw, float* dbias_grad /* or NULL */,
                            sp_stream_t stream);
-/* dw[co*sCo + ci*sCi + tapsrc[t]] += dw_acc[t][co][ci].  Both finish kernels also zero dw_acc for the next
- * step and, when dbias_grad != NULL, add the bias gradient dbias_grad[co] += dbias_sums[co]. */
-int sp_wgrad_finish(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+/* dw[co*sCo + ci*sCi + tapsrc[t]] += sum over the nparts blocks of dw_acc[t][co][ci].  With nparts == 1 (atomics
+ * mode) both finish kernels also zero dw_acc for the next step.  Both, when dbias_grad != NULL, add the bias gradient dbias_grad[co] += dbias_sums[co]. */
+int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                     int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
                     const double* dbias_sums /* or NULL */, float* dbias_grad /* or NULL */, int32_t nbias,
                     sp_stream_t stream);
@@ -216,12 +219,18 @@ int sp_head_supported(int32_t C, int32_t CH, int32_t NC);
 int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
                 const float* b1, int32_t CH, const float* w2, const float* b2, int32_t NC, float slope, float* seg,
                 sp_stream_t stream);
-/* backward: dz = dL/dx * act_x'(x) (x is the producing conv's post-activation output), dbias_sums[c] += sum dz,
- * hgrad_sums (fp64, zeroed by the caller) += [dW1 (CH*C) | db1 (CH) | dW2 (NC*CH) | db2 (NC)] */
+/* backward: dz = dL/dx * act_x'(x) (x is the producing conv's post-activation output).  Each workgroup WRITES one
+ * row of partial sums [dW1 (CH*C) | db1 (CH) | dW2 (NC*CH) | db2 (NC) | sum dz (C)] to partials
+ * (sp_head_bwd_rows(B*nvox_per_b) rows of sp_head_row_floats(C,CH,NC) floats; no atomics, run-to-run
+ * deterministic); sp_head_grad_finish adds the rows into the four parameter gradients (+=) and into the producing
+ * conv's bias-gradient sums. */
+int64_t sp_head_bwd_rows(int64_t total_voxels);
+int32_t sp_head_row_floats(int32_t C, int32_t CH, int32_t NC);
 int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
                 const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
-                const float* dseg, int32_t act_x, float act_x_param, void* dz, double* dbias_sums,
-                double* hgrad_sums, sp_stream_t stream);
+                const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials, sp_stream_t stream);
+int sp_head_grad_finish(const float* partials, int64_t rows, int32_t C, int32_t CH, int32_t NC, float* gW1, float* gb1,
+                        float* gW2, float* gb2, double* dbias_sums, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ small utilities */
 int sp_add_f64_to_f32(const double* src, float* dst, int64_t n, float scale, sp_stream_t stream); /* dst += scale*src */

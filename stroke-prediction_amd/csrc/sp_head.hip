@@ -5,36 +5,46 @@
 //   backward: given dL/dseg, recomputes the hidden layer, writes dz = dL/dx * act'(x) for the producing conv
 //             (x is that conv's post-activation output), sum(dz) for its bias gradient, and reduces
 //             dW1, db1, dW2, db2 in-kernel (per-wave register tiles over LDS-staged per-voxel vectors,
-//             persistent workgroups, one fp64 atomic flush each).
+//             persistent workgroups, one row of partial sums each, added up by sp_head_grad_finish).
 #include "sp_common.h"
+
+// weights are read through the constant address space: uniform addresses there always become s_load (the
+// parameters are not written while a head kernel runs)
+typedef const __attribute__((address_space(4))) float cfloat;
+
+__device__ __forceinline__ bf16x8 hd_tr_read2(const unsigned char* p0, const unsigned char* p1) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  bf16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p0));
+  bf16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p1));
+  return __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
 template <int C, int CH, int NC, typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int64_t nvox_per_b, int64_t total, int CP,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float slope, float* __restrict__ seg) {
-  __shared__ __attribute__((aligned(16))) float sw1[CH * C];
-  __shared__ float sb1[CH], sw2[NC * CH], sb2[NC];
-  for (int i = threadIdx.x; i < CH * C; i += 256) sw1[i] = w1[i];
-  for (int i = threadIdx.x; i < CH; i += 256) sb1[i] = b1[i];
-  for (int i = threadIdx.x; i < NC * CH; i += 256) sw2[i] = w2[i];
-  for (int i = threadIdx.x; i < NC; i += 256) sb2[i] = b2[i];
-  __syncthreads();
+  // weights are read at wave-uniform addresses through the constant address space: s_load into SGPR operands
+  cfloat *cw1 = (cfloat*)w1, *cb1 = (cfloat*)b1, *cw2 = (cfloat*)w2, *cb2 = (cfloat*)b2;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     float xv[C];
 #pragma unroll
     for (int c = 0; c < C; c += 8) Store<T>::ld8(x + v * CP + c, xv + c);
     float o[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) o[c] = sb2[c];
-#pragma unroll 4
-    for (int k = 0; k < CH; ++k) {
-      float h = sb1[k];
+    for (int c = 0; c < NC; ++c) o[c] = cb2[c];
+    // rolled on purpose: fully unrolled, all weight s_loads are hoisted to the top and spill (see the backward)
+#pragma unroll 1
+    for (int k = 0; k < CH; k += 2) {
 #pragma unroll
-      for (int i = 0; i < C; ++i) h = fmaf(sw1[k * C + i], xv[i], h);
-      h = fmaxf(h, slope * h);
+      for (int q = 0; q < 2; ++q) {
+        float h = cb1[k + q];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) o[c] = fmaf(sw2[c * CH + k], h, o[c]);
+        for (int i = 0; i < C; ++i) h = fmaf(cw1[(k + q) * C + i], xv[i], h);
+        h = fmaxf(h, slope * h);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c] = fmaf(cw2[c * CH + k + q], h, o[c]);
+      }
     }
     const int64_t b = v / nvox_per_b, r = v - b * nvox_per_b;
 #pragma unroll
@@ -48,8 +58,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                                                         const float* __restrict__ dseg, int64_t nvox_per_b, int64_t total,
                                                         int CP, const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, float slope, int act_x, float act_x_p,
-                                                        T* __restrict__ dz, double* __restrict__ dbias_sums,
-                                                        double* __restrict__ hgrad) {
+                                                        T* __restrict__ dz, float* __restrict__ part) {
   constexpr int REC = CH + CH + C + 4;            // floats per voxel record
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw1 = smem;                               // [CH][C]
@@ -137,22 +146,244 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
     }
     __syncthreads();
   }
-  // flush: hgrad layout = [W1 (CH x C) | b1 (CH) | W2 (NC x CH) | b2 (NC)]
+  // flush: one row of partial sums per workgroup, [W1 (CH x C) | b1 (CH) | W2 (NC x CH) | b2 (NC) | sum dz (C)];
+  // sp_head_grad_finish adds the rows up (no atomics: thousands of same-address fp64 atomics cost 300 us here)
+  constexpr int NQ0 = CH * C + CH + NC * CH + NC, NQ = NQ0 + C;
+  float* stage = rec + wave * NQ;                   // the record area is free after the loop's last barrier
   if (own_w1) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) atomicAdd(&hgrad[(k0 + a) * C + i0 + j], (double)aw1[a][j]);
+      for (int j = 0; j < 4; ++j) stage[(k0 + a) * C + i0 + j] = aw1[a][j];
   }
-  if (lane < CH) atomicAdd(&hgrad[CH * C + lane], (double)ab1);
-  if (own_w2) atomicAdd(&hgrad[CH * C + CH + c2 * CH + k2], (double)aw2);
-  if (lane < NC) atomicAdd(&hgrad[CH * C + CH + NC * CH + lane], (double)ab2);
-  if (dbias_sums) {
+  if (lane < CH) stage[CH * C + lane] = ab1;
+  if (own_w2) stage[CH * C + CH + c2 * CH + k2] = aw2;
+  if (lane < NC) stage[CH * C + CH + NC * CH + lane] = ab2;
 #pragma unroll
-    for (int i = 0; i < C; ++i) {
-      const float s = wave_sum(dbz[i]);
-      if (lane == 0) atomicAdd(&dbias_sums[i], (double)s);
+  for (int i = 0; i < C; ++i) {
+    const float s = wave_sum(dbz[i]);
+    if (lane == 0) stage[NQ0 + i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < NQ; i += 256) part[(size_t)blockIdx.x * NQ + i] = rec[i] + rec[NQ + i] + rec[2 * NQ + i] + rec[3 * NQ + i];
+}
+
+// ---- bf16 storage: the parameter gradients are 1-tap weight gradients, i.e. GEMMs with K = voxels.  Each wave owns
+// 64 voxels per iteration (lane = voxel) and its own LDS tiles [voxel][16 ch] (32 B rows, the layout
+// ds_read_b64_tr_b16 turns into MFMA fragments): X, DHP (CH/16 planes), H (CH/16 planes) and AUX = (do_0..do_{NC-1},
+// 1, 0...).  Per 32 voxels:  dW1[p] += DHP_p^T X,  [dW2; sum h][p] += AUX^T H_p,  [.; db1][p] += AUX^T DHP_p.
+// No workgroup barrier: a wave only reads what it wrote (LDS is in-order per wave).  Weights come through the
+// scalar cache (uniform addresses), not LDS.
+template <int CH, int NC>
+__global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ seg,
+                                                             const float* __restrict__ dseg, int64_t nvox_per_b,
+                                                             int64_t total, int CP, const float* __restrict__ w1,
+                                                             const float* __restrict__ b1, const float* __restrict__ w2,
+                                                             float slope, int act_x, float act_x_p,
+                                                             bf16_t* __restrict__ dz, float* __restrict__ part) {
+  constexpr int C = 16, NP = CH / 16, NPL = 2 + 2 * NP;      // planes: X, AUX, DHP[NP], H[NP]
+  constexpr int PLANE = 64 * 32;                              // bytes of one 64-voxel plane
+  __shared__ __attribute__((aligned(16))) unsigned char lds[4 * NPL * PLANE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  unsigned char* wt = lds + wave * NPL * PLANE;
+  unsigned char* tX = wt;
+  unsigned char* tA = wt + PLANE;
+  unsigned char* tD = wt + 2 * PLANE;
+  unsigned char* tH = wt + (2 + NP) * PLANE;
+  // transposed-read offsets inside a 32-voxel K block (same voxel permutation for both operands)
+  const int vq0 = ((lg & 1) ? 2 * lg + 1 : 2 * lg) * 4 + lq;
+  const int vq1 = ((lg & 1) ? 2 * lg : 2 * lg + 1) * 4 + lq;
+  const int off0 = vq0 * 32 + lp * 8, off1 = vq1 * 32 + lp * 8;
+
+  f32x4 accW1[NP], accW2[NP], accB1[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) accW1[p] = accW2[p] = accB1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float dbz[C], db2[NC];
+#pragma unroll
+  for (int i = 0; i < C; ++i) dbz[i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) db2[c] = 0.f;
+
+  cfloat *cw1 = (cfloat*)w1, *cb1 = (cfloat*)b1, *cw2 = (cfloat*)w2;
+  const int64_t niter = (total + 255) / 256;
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+    const int64_t v = it * 256 + tid;
+    uint32_t pa[2] = {0, 0};
+    uint4 xr0 = make_uint4(0, 0, 0, 0), xr1 = xr0;
+    if (v < total) {
+      xr0 = *reinterpret_cast<const uint4*>(x + v * CP);
+      xr1 = *reinterpret_cast<const uint4*>(x + v * CP + 8);
+      float xv[C];
+      {
+        const uint32_t w[8] = {xr0.x, xr0.y, xr0.z, xr0.w, xr1.x, xr1.y, xr1.z, xr1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xv[2 * i] = __uint_as_float(w[i] << 16); xv[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+      }
+      const int64_t b = v / nvox_per_b, r = v - b * nvox_per_b;
+      float dov[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int64_t o = (b * NC + c) * nvox_per_b + r;
+        const float sg = seg[o];
+        dov[c] = dseg[o] * sg * (1.f - sg);
+        db2[c] += dov[c];
+      }
+      // AUX row: do_0 .. do_{NC-1}, 1, 0 ...
+      {
+        float aux[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) aux[c] = dov[c];
+        aux[NC] = 1.f;
+        pa[0] = (uint32_t)f2bf(aux[0]) | ((uint32_t)f2bf(aux[1]) << 16);
+        pa[1] = (uint32_t)f2bf(aux[2]) | ((uint32_t)f2bf(aux[3]) << 16);
+      }
+      float dx[C];
+#pragma unroll
+      for (int i = 0; i < C; ++i) dx[i] = 0.f;
+      // k loop kept rolled (two hidden channels per trip, the next pair's weights prefetched into SGPRs): unrolled,
+      // the scheduler hoists all 600 weight s_loads to the top and spills them into VGPR lanes
+      float wc[2 * C], bc[2], vc[2 * NC];
+#pragma unroll
+      for (int i = 0; i < 2 * C; ++i) wc[i] = cw1[i];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        bc[q] = cb1[q];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) vc[q * NC + c] = cw2[c * CH + q];
+      }
+#pragma unroll 1
+      for (int k = 0; k < CH; k += 2) {
+        const int kn = (k + 2 < CH) ? k + 2 : 0;
+        float wn[2 * C], bn[2], vn[2 * NC];
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) wn[i] = cw1[kn * C + i];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          bn[q] = cb1[kn + q];
+#pragma unroll
+          for (int c = 0; c < NC; ++c) vn[q * NC + c] = cw2[c * CH + kn + q];
+        }
+        float dhp2[2], h2[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          float hp = bc[q];
+#pragma unroll
+          for (int i = 0; i < C; ++i) hp = fmaf(wc[q * C + i], xv[i], hp);
+          float dh = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) dh = fmaf(vc[q * NC + c], dov[c], dh);
+          dhp2[q] = dh * (hp > 0.f ? 1.f : slope);
+          h2[q] = fmaxf(hp, slope * hp);
+#pragma unroll
+          for (int i = 0; i < C; ++i) dx[i] = fmaf(wc[q * C + i], dhp2[q], dx[i]);
+        }
+        // channel pair k, k+1 of this voxel's DHP / H rows (plane k/16, 32-byte rows)
+        const int po = (k >> 4) * PLANE + lane * 32 + (k & 15) * 2;
+        *reinterpret_cast<uint32_t*>(tD + po) = (uint32_t)f2bf(dhp2[0]) | ((uint32_t)f2bf(dhp2[1]) << 16);
+        *reinterpret_cast<uint32_t*>(tH + po) = (uint32_t)f2bf(h2[0]) | ((uint32_t)f2bf(h2[1]) << 16);
+#pragma unroll
+        for (int i = 0; i < 2 * C; ++i) wc[i] = wn[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) bc[i] = bn[i];
+#pragma unroll
+        for (int i = 0; i < 2 * NC; ++i) vc[i] = vn[i];
+      }
+#pragma unroll
+      for (int i = 0; i < C; ++i) { dx[i] *= act_bwd_from_y(act_x, act_x_p, xv[i]); dbz[i] += dx[i]; }
+      Store<bf16_t>::st8(dz + v * CP, dx);
+      Store<bf16_t>::st8(dz + v * CP + 8, dx + 8);
+      for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        *reinterpret_cast<uint4*>(tD + p * PLANE + lane * 32) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(tD + p * PLANE + lane * 32 + 16) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(tH + p * PLANE + lane * 32) = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(tH + p * PLANE + lane * 32 + 16) = make_uint4(0, 0, 0, 0);
+      }
     }
+    // ---- this lane's voxel row into every plane
+    *reinterpret_cast<uint4*>(tX + lane * 32) = xr0;
+    *reinterpret_cast<uint4*>(tX + lane * 32 + 16) = xr1;
+    *reinterpret_cast<uint4*>(tA + lane * 32) = make_uint4(pa[0], pa[1], 0, 0);
+    *reinterpret_cast<uint4*>(tA + lane * 32 + 16) = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int ko = kb * 32 * 32;
+      const bf16x8 fx = hd_tr_read2(tX + ko + off0, tX + ko + off1);
+      const bf16x8 fa = hd_tr_read2(tA + ko + off0, tA + ko + off1);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const bf16x8 fd = hd_tr_read2(tD + p * PLANE + ko + off0, tD + p * PLANE + ko + off1);
+        const bf16x8 fh = hd_tr_read2(tH + p * PLANE + ko + off0, tH + p * PLANE + ko + off1);
+        accW1[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fx, accW1[p], 0, 0, 0);
+        accW2[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fh, accW2[p], 0, 0, 0);
+        accB1[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fd, accB1[p], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  // ---- flush (MFMA result: lane holds rows lg*4 + j (A side), column li (B side)): one row of partial sums per
+  // workgroup, [W1 (CH x C) | b1 (CH) | W2 (NC x CH) | b2 (NC) | sum dz (C)], added up by sp_head_grad_finish
+  constexpr int NQ0 = CH * C + CH + NC * CH + NC, NQ = NQ0 + C;
+  __syncthreads();                                   // every wave has left its tiles
+  float* st0 = reinterpret_cast<float*>(lds);
+  float* stage = st0 + wave * NQ;
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = lg * 4 + j;
+      stage[(p * 16 + row) * C + li] = accW1[p][j];
+      if (row < NC) stage[CH * C + CH + row * CH + p * 16 + li] = accW2[p][j];
+      if (row == NC) stage[CH * C + p * 16 + li] = accB1[p][j];
+    }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float s2 = wave_sum(db2[c]);
+    if (lane == 0) stage[CH * C + CH + NC * CH + c] = s2;
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    const float s = wave_sum(dbz[i]);
+    if (lane == 0) stage[NQ0 + i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < NQ; i += 256) part[(size_t)blockIdx.x * NQ + i] = st0[i] + st0[NQ + i] + st0[2 * NQ + i] + st0[3 * NQ + i];
+}
+
+// rows x NQ partial sums -> += into the four parameter gradients and the producing conv's bias-gradient sums
+__global__ __launch_bounds__(1024) void head_grad_finish_kernel(const float* __restrict__ part, int rows, int NQ, int nW1, int nb1,
+                                                                int nW2, int nb2, float* __restrict__ gW1,
+                                                                float* __restrict__ gb1, float* __restrict__ gW2,
+                                                                float* __restrict__ gb2, double* __restrict__ dbias_sums) {
+  __shared__ double red[16][64];
+  const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cl;
+  double acc = 0.0;
+  if (col < NQ)
+    for (int r = rg; r < rows; r += 16) acc += (double)part[(size_t)r * NQ + col];
+  red[rg][cl] = acc;
+  __syncthreads();
+  if (rg == 0 && col < NQ) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cl];
+    int i = col;
+    if (i < nW1) { gW1[i] += (float)t; return; }
+    i -= nW1;
+    if (i < nb1) { gb1[i] += (float)t; return; }
+    i -= nb1;
+    if (i < nW2) { gW2[i] += (float)t; return; }
+    i -= nW2;
+    if (i < nb2) { gb2[i] += (float)t; return; }
+    i -= nb2;
+    if (dbias_sums) dbias_sums[i] += t;
   }
 }
 
@@ -185,34 +416,50 @@ extern "C" int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
   return SP_OK;
 }
 
+static inline int64_t head_rows(int64_t total) {
+  const int64_t niter = (total + 255) / 256;
+  return niter < 768 ? niter : 768;
+}
+extern "C" int64_t sp_head_bwd_rows(int64_t total_voxels) { return head_rows(total_voxels); }
+extern "C" int32_t sp_head_row_floats(int32_t C, int32_t CH, int32_t NC) { return CH * C + CH + NC * CH + NC + C; }
+
 extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
                            const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
-                           const float* dseg, int32_t act_x, float act_x_param, void* dz, double* dbias_sums,
-                           double* hgrad_sums, sp_stream_t stream) {
-  SP_CHECK_ARG(x && w1 && b1 && w2 && seg && dseg && dz && hgrad_sums && CP >= C && CP % 8 == 0, "sp_head_bwd: bad arguments");
+                           const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials,
+                           sp_stream_t stream) {
+  SP_CHECK_ARG(x && w1 && b1 && w2 && seg && dseg && dz && partials && CP >= C && CP % 8 == 0, "sp_head_bwd: bad arguments");
   SP_CHECK_ARG(sp_head_supported(C, CH, NC), "sp_head_bwd: no fused kernel for C=%d CH=%d NC=%d", C, CH, NC);
   SP_CHECK_ARG(CH * C / 8 <= 64 && NC * CH <= 64 && CH <= 64, "sp_head_bwd: reduction tile does not fit a wave");
   const int64_t total = (int64_t)B * nvox_per_b;
+  SP_CHECK_ARG(total > 0, "sp_head_bwd: empty input");
   const int rec = CH + CH + C + 4;
   const int lds = (CH * C + CH + NC * CH + 256 * rec) * (int)sizeof(float);
   SP_CHECK_ARG(lds <= 160 * 1024, "sp_head_bwd: LDS %d", lds);
-  const int64_t niter = (total + 255) / 256;
-  const unsigned grid = (unsigned)(niter < 256 ? niter : 256);
+  const unsigned grid = (unsigned)head_rows(total);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(c, h, n)                                                                                                   \
   if (C == c && CH == h && NC == n) {                                                                                \
+    static_assert(c == 16, "head_bwd_mfma_kernel is written for 16 input channels");                                 \
     if (dtype == SP_BF16) {                                                                                          \
-      auto kern = head_bwd_kernel<c, h, n, bf16_t>;                                                                  \
-      SP_ENSURE_LDS(kern, lds, "sp_head_bwd");                                                                       \
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, dbias_sums, hgrad_sums); \
+      hipLaunchKernelGGL((head_bwd_mfma_kernel<h, n>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, partials); \
     } else {                                                                                                         \
       auto kern = head_bwd_kernel<c, h, n, float>;                                                                   \
       SP_ENSURE_LDS(kern, lds, "sp_head_bwd");                                                                       \
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const float*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (float*)dz, dbias_sums, hgrad_sums); \
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const float*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (float*)dz, partials); \
     }                                                                                                                \
   }
   HEAD_CASES(X)
 #undef X
   SP_CHECK_LAUNCH("sp_head_bwd");
+  return SP_OK;
+}
+
+extern "C" int sp_head_grad_finish(const float* partials, int64_t rows, int32_t C, int32_t CH, int32_t NC, float* gW1, float* gb1,
+                                   float* gW2, float* gb2, double* dbias_sums, sp_stream_t stream) {
+  SP_CHECK_ARG(partials && gW1 && gb1 && gW2 && gb2 && rows > 0 && rows <= 768, "sp_head_grad_finish: bad arguments");
+  const int NQ = sp_head_row_floats(C, CH, NC);
+  hipLaunchKernelGGL(head_grad_finish_kernel, dim3((NQ + 63) / 64), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream),
+                     partials, (int)rows, NQ, CH * C, CH, NC * CH, NC, gW1, gb1, gW2, gb2, dbias_sums);
+  SP_CHECK_LAUNCH("sp_head_grad_finish");
   return SP_OK;
 }

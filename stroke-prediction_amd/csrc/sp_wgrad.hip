@@ -188,6 +188,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradDev P) {
 
   // ---- flush: D[row = co = lg*4+j][col = ci = li] -> dw_acc[tap][co][ci] -------------------------------
   const int CoP = a.CoT * 16, CiP = a.CiT * 16;
+  // parts mode: this workgroup's own block of partial sums (plain stores), else fp32 atomics into the one block
+  float* prow = a.dw_acc + (a.parts ? (size_t)blockIdx.x * a.ntap * CoP * CiP : (size_t)0);
 #pragma unroll
   for (int tt = 0; tt < WG_TAPS_PER_WAVE; ++tt) {
     if (tt < ntw) {
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradDev P) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int co = (co_t0 + c) * 16 + lg * 4 + j, ci = (ci_t0 + i) * 16 + li;
-              atomicAdd(&a.dw_acc[((size_t)(tap0 + tt) * CoP + co) * CiP + ci], acc[tt][c][i][j]);
+              float* dst = prow + ((size_t)(tap0 + tt) * CoP + co) * CiP + ci;
+              if (a.parts) *dst = acc[tt][c][i][j]; else atomicAdd(dst, acc[tt][c][i][j]);
             }
           }
         }
@@ -262,13 +265,56 @@ extern "C" int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream) {
   const uint64_t nt = (uint64_t)P.ntx * P.nty * P.ntz * a->B;
   SP_CHECK_ARG(nt < (1ull << 31), "sp_conv3d_wgrad: too many tiles");
   P.ntiles = (uint32_t)nt;
-  uint32_t gx = a->nblocks < (int64_t)nt ? a->nblocks : (uint32_t)nt;
+  uint32_t gx = (a->parts || a->nblocks < (int64_t)nt) ? a->nblocks : (uint32_t)nt;   // parts: every block is written
   dim3 grid(gx, (a->CoT + COB - 1) / COB, (a->CiT + CIB - 1) / CIB);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (a->dtype == SP_BF16) return wgrad_dispatch<1, bf16_t>(P, COB, CIB, grid, lds_bytes, st);
   if (a->dtype == SP_F32) return wgrad_dispatch<2, float>(P, COB, CIB, grid, lds_bytes, st);
   sp_set_error("sp_conv3d_wgrad: bad dtype %d", a->dtype);
   return SP_EINVAL;
+}
+
+// sum over the nparts partial blocks of one accumulator entry: 32 consecutive entries x 8 row lanes per workgroup
+// (128-byte row segments), LDS-reduced; lane group 0 continues with the total
+__device__ __forceinline__ bool wgrad_part_sum(const float* __restrict__ acc, int nparts, int64_t total, int64_t& idx,
+                                               float& v) {
+  __shared__ float red[8][33];
+  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  idx = (int64_t)blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (idx < total) {
+    int r = rl;
+    for (; r + 24 < nparts; r += 32) {
+      const float a0 = acc[(size_t)r * total + idx], a1 = acc[(size_t)(r + 8) * total + idx];
+      const float a2 = acc[(size_t)(r + 16) * total + idx], a3 = acc[(size_t)(r + 24) * total + idx];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < nparts; r += 8) s += acc[(size_t)r * total + idx];
+  }
+  red[rl][el] = s;
+  __syncthreads();
+  if (rl != 0 || idx >= total) return false;
+  v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v += red[i][el];
+  return true;
+}
+
+__global__ __launch_bounds__(256) void wgrad_finish_parts_kernel(const float* __restrict__ acc, int nparts,
+                                                                 const int32_t* __restrict__ tapsrc, int ntap, int CoP,
+                                                                 int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
+                                                                 float* __restrict__ dw, const double* __restrict__ dbias_sums,
+                                                                 float* __restrict__ dbias_grad, int nbias) {
+  const int64_t total = (int64_t)ntap * CoP * CiP;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (dbias_grad && gid < nbias) dbias_grad[gid] += (float)dbias_sums[gid];
+  int64_t idx;
+  float v;
+  if (!wgrad_part_sum(acc, nparts, total, idx, v)) return;
+  const int ci = idx % CiP;
+  const int co = (idx / CiP) % CoP;
+  const int t = idx / ((int64_t)CiP * CoP);
+  if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += v;
 }
 
 __global__ void wgrad_finish_kernel(float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
@@ -287,12 +333,20 @@ __global__ void wgrad_finish_kernel(float* __restrict__ acc, const int32_t* __re
   if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += v;
 }
 
-extern "C" int sp_wgrad_finish(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+extern "C" int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
                                const double* dbias_sums, float* dbias_grad, int32_t nbias, sp_stream_t stream) {
-  SP_CHECK_ARG(dw_acc && tapsrc && dw && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish: bad arguments");
+  SP_CHECK_ARG(dw_acc && tapsrc && dw && Cout <= CoP && Cin <= CiP && nparts >= 1, "sp_wgrad_finish: bad arguments");
   SP_CHECK_ARG(!dbias_grad || (dbias_sums && nbias <= ntap * CoP * CiP), "sp_wgrad_finish: bias arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
+  if (nparts > 1) {
+    SP_CHECK_ARG(!dbias_grad || nbias <= (total + 31) / 32 * 256, "sp_wgrad_finish: bias arguments");
+    hipLaunchKernelGGL(wgrad_finish_parts_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
+                       dw, dbias_sums, dbias_grad, nbias);
+    SP_CHECK_LAUNCH("sp_wgrad_finish");
+    return SP_OK;
+  }
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, dw,
                      dbias_sums, dbias_grad, nbias);

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
 
   // ---- flush: D[row = co = lg*4+j][col = ci = li] -> dw_acc[tap][co][ci] ---------------------------------------
   const int CoP = a.CoT * 16, CiP = a.CiT * 16;
+  // parts mode: this workgroup's own block of partial sums (plain stores), else fp32 atomics into the one block
+  float* prow = a.dw_acc + (a.parts ? (size_t)blockIdx.x * a.ntap * CoP * CiP : (size_t)0);
 #pragma unroll
   for (int tt = 0; tt < WD_TW; ++tt) {
     const int tap = wave * WD_TW + tt;
@@ -235,7 +237,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int co = (co_t0 + c) * 16 + lg * 4 + j, ci = (ci_t0 + i) * 16 + li;
-              atomicAdd(&a.dw_acc[((size_t)tap * CoP + co) * CiP + ci], acc[tt][c][i][j]);
+              float* dst = prow + ((size_t)tap * CoP + co) * CiP + ci;
+              if (a.parts) *dst = acc[tt][c][i][j]; else atomicAdd(dst, acc[tt][c][i][j]);
             }
           }
         }
@@ -282,7 +285,7 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(nt < (1ull << 31), "sp_conv3d_wgrad(dma): too many tiles");
   P.ntiles = (uint32_t)nt;
   const int lds_bytes = 2 * P.buf_bytes;
-  uint32_t gx = a->nblocks < (int64_t)nt ? a->nblocks : (uint32_t)nt;
+  uint32_t gx = (a->parts || a->nblocks < (int64_t)nt) ? a->nblocks : (uint32_t)nt;   // parts: every block is written
   dim3 grid(gx, (a->CoT + COB - 1) / COB, (a->CiT + CIB - 1) / CIB);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define WD_CASE(C_, I_)                                                                              \
@@ -297,6 +300,42 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
 #undef WD_CASE
   sp_set_error("sp_conv3d_wgrad(dma): no kernel for COB=%d CIB=%d", COB, CIB);
   return SP_EINVAL;
+}
+
+// parts mode of the folded finish (same 32-entry x 8-row-lane reduction as wgrad_finish_parts_kernel)
+__global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const float* __restrict__ acc, int nparts,
+                                                                        const int32_t* __restrict__ tapsrc, int ntap,
+                                                                        int CoP, int CiP, int Cout, int Cin, int64_t sCo,
+                                                                        int64_t sCi, const float* __restrict__ scale,
+                                                                        const float* __restrict__ shift,
+                                                                        const double* __restrict__ dbias,
+                                                                        float* __restrict__ dw, float* __restrict__ dbias_grad) {
+  __shared__ float red[8][33];
+  const int64_t total = (int64_t)ntap * CoP * CiP;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (dbias_grad && gid < Cout) dbias_grad[gid] += (float)dbias[gid];
+  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t idx = (int64_t)blockIdx.x * 32 + el;
+  float s = 0.f;
+  if (idx < total) {
+    int r = rl;
+    for (; r + 24 < nparts; r += 32) {
+      const float a0 = acc[(size_t)r * total + idx], a1 = acc[(size_t)(r + 8) * total + idx];
+      const float a2 = acc[(size_t)(r + 16) * total + idx], a3 = acc[(size_t)(r + 24) * total + idx];
+      s += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < nparts; r += 8) s += acc[(size_t)r * total + idx];
+  }
+  red[rl][el] = s;
+  __syncthreads();
+  if (rl != 0 || idx >= total) return;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v += red[i][el];
+  const int ci = idx % CiP;
+  const int co = (idx / CiP) % CoP;
+  const int t = idx / ((int64_t)CiP * CoP);
+  if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * v + shift[ci] * (float)dbias[co];
 }
 
 // dw[co,ci,tap] += scale[ci]*acc[tap][co][ci] + shift[ci]*dbias[co]   (BatchNorm folded out of the operand load)
@@ -317,12 +356,20 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
   if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * v + shift[ci] * (float)dbias[co];
 }
 
-extern "C" int sp_wgrad_finish_folded(float* dw_acc, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                       int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                                       const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
                                       sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
+  SP_CHECK_ARG(nparts >= 1 && Cout <= (total + 31) / 32 * 256, "sp_wgrad_finish_folded: nparts");
+  if (nparts > 1) {
+    hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
+                       scale, shift, dbias_sums, dw, dbias_grad);
+    SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
+    return SP_OK;
+  }
   hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
                      shift, dbias_sums, dw, dbias_grad);

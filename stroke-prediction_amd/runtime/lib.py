@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "dz", "in_scale", "in_shift", "dz_scale", "dz_shift", "dw_acc", "taps")] + \
                [(n, i32) for n in ("dtype", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "sD", "sH", "sW",
-                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows")]
+                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts")]
 
 
 _SIGS = {
@@ -40,8 +40,8 @@ _SIGS = {
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
-    "sp_wgrad_finish": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, vp], i32),
-    "sp_wgrad_finish_folded": ([vp, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp], i32),
+    "sp_wgrad_finish": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, vp], i32),
+    "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp], i32),
     "sp_ncdhw_to_cl": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_cl_to_ncdhw": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),
@@ -60,7 +60,10 @@ _SIGS = {
     "sp_dice_bwd": ([vp, vp, vp, vp, i32, i32, i64, vp, vp], i32),
     "sp_head_supported": ([i32, i32, i32], i32),
     "sp_head_fwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, vp, i32, f32, vp, vp], i32),
-    "sp_head_bwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, i32, f32, vp, vp, i32, f32, vp, vp, vp, vp], i32),
+    "sp_head_bwd_rows": ([i64], i64),
+    "sp_head_row_floats": ([i32, i32, i32], i32),
+    "sp_head_bwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, i32, f32, vp, vp, i32, f32, vp, vp, vp], i32),
+    "sp_head_grad_finish": ([vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),
     "sp_add_f64_to_f32": ([vp, vp, i64, f32, vp], i32),
     "sp_axpby": ([vp, vp, vp, i32, i64, f32, f32, vp], i32),
     "sp_lerp_batch": ([vp, vp, vp, vp, i32, i32, i64, vp], i32),
@@ -124,10 +127,23 @@ def build(verbose=False):
     if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    # one object per source (rebuilt only when stale, compiled concurrently), then one link
+    objdir = os.path.join(os.path.dirname(LIB_PATH), "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = deps[len(srcs):]
+    jobs, objs = [], []
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs, check=True)
     global _lib
     _lib = None
     return LIB_PATH

@@ -19,7 +19,8 @@ def bump_param_epoch():
     PARAM_EPOCH[0] += 1
 
 
-USE_PERSIST = False  # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
+WGRAD_PARTS = True      # weight-gradient partial blocks + summing finish instead of fp32 atomics
+USE_PERSIST = False     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
 
 # optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
@@ -189,7 +190,8 @@ class WgradRunner:
         self.taps = _dev_i32(np.array(taps), device)
         self.tapsrc = _dev_i32(np.arange(self.ntap), device)
         self.cot, self.cit = -(-cpo // 16), -(-cpi // 16)
-        self.acc = torch.zeros(self.ntap * self.cot * 16 * self.cit * 16, dtype=torch.float32, device=device)
+        self.acc = None                      # allocated on first run (the partial-block count depends on the batch)
+        self.device = device
         a = L.WgradArgs()
         a.dtype = dtype
         a.Di, a.Hi, a.Wi = in_dims
@@ -213,6 +215,27 @@ class WgradRunner:
         self.args = a
         self.dtype = dtype
 
+    def _alloc_acc(self, batch):
+        """Accumulator block(s).  WGRAD_PARTS: one block per persistent workgroup, written with plain stores and summed
+        by the finish kernel (device-scope atomics from 8 XCDs cost 40-90 us per layer); the workgroup count is sized
+        so that every workgroup has >= ~768 output voxels and the (cout, cin) tile grid times it is ~2 per CU."""
+        import os
+        a = self.args
+        total = self.ntap * self.cot * 16 * self.cit * 16
+        if WGRAD_PARTS:
+            cob = 4 if self.cot >= 4 else (2 if self.cot >= 2 else 1)
+            cib = 1 if cob == 4 else min(self.cit, 3)
+            yz = -(-self.cot // cob) * -(-self.cit // cib)
+            vox = batch * a.Do * a.Ho * a.Wo
+            nb = max(8, min(512 // yz, vox // 768))
+            a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", nb))
+            a.parts, self.nparts = 1, a.nblocks
+            self.acc = torch.empty(self.nparts * total, dtype=torch.float32, device=self.device)
+        else:
+            a.parts, self.nparts = 0, 1
+            self.acc = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.acc_batch = batch
+
     def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None,
             dbias_grad=None, nbias=0):
         """dw (fp32, the parameter's own layout) += gradient.  On the DMA path the BatchNorm (in_scale/in_shift) is
@@ -221,6 +244,8 @@ class WgradRunner:
         assert x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
         assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi), (tuple(x.shape), (batch, a.Di, a.Hi, a.Wi, a.CPi))
         assert tuple(dz.shape) == (batch, a.Do, a.Ho, a.Wo, a.CPo), (tuple(dz.shape), (batch, a.Do, a.Ho, a.Wo, a.CPo))
+        if self.acc is None or self.acc_batch != batch:
+            self._alloc_acc(batch)
         a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
         fold = self.dma and in_scale is not None
         if fold:
@@ -234,11 +259,11 @@ class WgradRunner:
                     "%d->%d @%dx%dx%d %s" % (self.cin, self.cout, a.Di, a.Hi, a.Wi, "dma" if a.dma else "reg")):
             L.call("sp_conv3d_wgrad", C.byref(a), st)
         if fold:
-            L.call("sp_wgrad_finish_folded", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
+            L.call("sp_wgrad_finish_folded", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw),
                    ptr(dbias_grad), st)
         else:
-            L.call("sp_wgrad_finish", ptr(self.acc), ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
+            L.call("sp_wgrad_finish", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), ptr(dbias_sums) if dbias_grad is not None else None,
                    ptr(dbias_grad), nbias, st)
 

@@ -77,7 +77,6 @@ class UnetEngine:
         self.out_dims = d52
         # fused pointwise head where a kernel exists for (C, CH, NC); the two generic 1x1 layers otherwise
         self.fused_head = bool(L.load().sp_head_supported(b5, bc, ncls)) and b5 % 8 == 0
-        self.hgrad_id = sc.reserve(bc * b5 + bc + ncls * bc + ncls)
         self.d12, self.dp1, self.d22, self.dp2, self.d32, self.dc4, self.d42, self.dc5 = d12, dp1, d22, dp2, d32, dc4, d42, dc5
         self.layers = [self.c11, self.c12, self.c21, self.c22, self.c31, self.c32, self.c41, self.c42, self.c51,
                        self.c52, self.h0, self.h2]
@@ -149,16 +148,17 @@ class UnetEngine:
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
             b5, bc, ncls = self.channels[5], self.channels[6], self.ncls
-            hg = self.scratch.get(self.hgrad_id)
+            lib = L.load()
+            rows = lib.sp_head_bwd_rows(self.batch * nv)
+            if getattr(self, "_hpart", None) is None:
+                self._hpart = torch.empty(rows * lib.sp_head_row_floats(b5, bc, ncls), dtype=torch.float32, device=self.device)
             L.call("sp_head_bwd", O.ptr(c.c52.y), dt, nv, self.batch, c.c52.y.shape[-1], b5,
                    O.ptr(params["classify.0.weight"]), O.ptr(params["classify.0.bias"]), bc,
                    O.ptr(params["classify.2.weight"]), ncls, LEAKY, O.ptr(seg), O.ptr(dseg), L.ACT_LEAKY, LEAKY,
-                   O.ptr(c.c52.dz), O.ptr(c.c52.dbias_sums), O.ptr(hg), O.stream())
-            o0 = 0
-            for name, n in (("classify.0.weight", bc * b5), ("classify.0.bias", bc), ("classify.2.weight", ncls * bc),
-                            ("classify.2.bias", ncls)):
-                O.add_f64_to_f32(hg[o0:o0 + n], grads[name], n)
-                o0 += n
+                   O.ptr(c.c52.dz), O.ptr(self._hpart), O.stream())
+            L.call("sp_head_grad_finish", O.ptr(self._hpart), rows, b5, bc, ncls, O.ptr(grads["classify.0.weight"]),
+                   O.ptr(grads["classify.0.bias"]), O.ptr(grads["classify.2.weight"]), O.ptr(grads["classify.2.bias"]),
+                   O.ptr(c.c52.dbias_sums), O.stream())
         else:
             # output side: dz of the last 1x1 conv = dseg * sigmoid'(seg)
             O.out_grad_to_cl(dseg, seg, dt, L.ACT_SIGMOID, 0.0, c.h2.dz, c.h2.dbias_sums)

@@ -357,15 +357,24 @@ def test_fused_head(dtype, C, CH, NC, CP):
 
     dz = torch.full_like(x_cl, 7.0)
     dbs = torch.zeros(CP, dtype=torch.float64, device=DEV)
-    hg = torch.zeros(CH * C + CH + NC * CH + NC, dtype=torch.float64, device=DEV)
+    lib = L.load()
+    rows, nq = lib.sp_head_bwd_rows(B * nv), lib.sp_head_row_floats(C, CH, NC)
+    assert nq == CH * C + CH + NC * CH + NC + C and rows == (B * nv + 255) // 256
+    part = torch.full((rows * nq,), float("nan"), dtype=torch.float32, device=DEV)     # must be fully overwritten
     DS = dv(dseg)
     L.call("sp_head_bwd", O.ptr(x_cl), dtype, nv, B, CP, C, O.ptr(W1), O.ptr(B1), CH, O.ptr(W2), NC, 0.01, O.ptr(seg),
-           O.ptr(DS), L.ACT_LEAKY, 0.01, O.ptr(dz), O.ptr(dbs), O.ptr(hg), O.stream())
+           O.ptr(DS), L.ACT_LEAKY, 0.01, O.ptr(dz), O.ptr(part), O.stream())
+    gs = [torch.ones(CH * C, device=DEV), torch.ones(CH, device=DEV), torch.ones(NC * CH, device=DEV), torch.ones(NC, device=DEV)]
+    L.call("sp_head_grad_finish", O.ptr(part), rows, C, CH, NC, O.ptr(gs[0]), O.ptr(gs[1]), O.ptr(gs[2]), O.ptr(gs[3]),
+           O.ptr(dbs), O.stream())
+    hg = torch.cat(gs) - 1.0                       # the finish kernel accumulates (+=) into the gradients
     torch.testing.assert_close(from_cl(dz, C, dtype), dz_ref, **TOL[dtype])
     torch.testing.assert_close(dbs[:C].cpu().float(), dz_ref.sum((0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
     hg = hg.cpu().float()
     o = 0
     for ref in (w1.grad, b1.grad, w2.grad, b2.grad):
         n = ref.numel()
-        torch.testing.assert_close(hg[o:o + n].view(ref.shape), ref, rtol=1e-4, atol=1e-3)
+        # bf16 storage: the in-kernel GEMMs see bf16-rounded dh/h/do factors (2^-9 each, random sign over 1170 voxels)
+        tol = dict(rtol=1e-4, atol=1e-3) if dtype == L.SP_F32 else dict(rtol=1e-2, atol=0.02 * float(ref.abs().max()) + 1e-3)
+        torch.testing.assert_close(hg[o:o + n].view(ref.shape), ref, **tol)
         o += n
