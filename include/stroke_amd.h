@@ -138,7 +138,12 @@ int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                            int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                            const float* shift, const double* dbias_sums, float* dw, float* dbias_grad /* or NULL */,
+                           const float* w_for_bn /* or NULL */, double* bn_sums /* or NULL */, int32_t bn_nrep,
                            sp_stream_t stream);
+/* bn_sums != NULL (first layer of a network: no input gradient wanted, so no data-gradient convolution is run):
+ * also accumulate the BatchNorm-backward sums of the layer's input,  bn_sums[rep][ci][0] += sum_v g  and
+ * bn_sums[rep][ci][1] += sum_v g*x  with g = conv_transpose(dz, w_for_bn), computed from the weight-gradient
+ * accumulator:  sum_v g*x = sum_{co,tap} w*dw_acc,  sum_v g = sum_{co,tap} w*dbias_sums[co]  (un-padded conv). */
 /* dw[co*sCo + ci*sCi + tapsrc[t]] += sum over the nparts blocks of dw_acc[t][co][ci].  With nparts == 1 (atomics
  * mode) both finish kernels also zero dw_acc for the next step.  Both, when dbias_grad != NULL, add the bias gradient dbias_grad[co] += dbias_sums[co]. */
 int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,

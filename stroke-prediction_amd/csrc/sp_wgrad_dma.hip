@@ -302,6 +302,15 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   return SP_EINVAL;
 }
 
+// BatchNorm-backward sums of a layer whose input gradient is not needed (the network's first layer), taken from the
+// weight gradient instead of running the data-gradient convolution:  with g = conv_transpose(dz, W) over an
+// un-padded convolution,  sum_v g[v,ci] = sum_{co,tap} W[co,ci,tap] * sum_v dz[v,co]   and
+// sum_v g[v,ci]*x[v,ci] = sum_{co,tap} W[co,ci,tap] * acc[tap][co][ci]   (acc = the raw-input weight gradient).
+__device__ __forceinline__ void bn_sums_from_wgrad(float w, float acc, double dbias_co, double* sums2) {
+  atomicAdd(&sums2[0], (double)w * dbias_co);
+  atomicAdd(&sums2[1], (double)w * (double)acc);
+}
+
 // parts mode of the folded finish (same 32-entry x 8-row-lane reduction as wgrad_finish_parts_kernel)
 __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const float* __restrict__ acc, int nparts,
                                                                         const int32_t* __restrict__ tapsrc, int ntap,
@@ -309,7 +318,9 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const fl
                                                                         int64_t sCi, const float* __restrict__ scale,
                                                                         const float* __restrict__ shift,
                                                                         const double* __restrict__ dbias,
-                                                                        float* __restrict__ dw, float* __restrict__ dbias_grad) {
+                                                                        float* __restrict__ dw, float* __restrict__ dbias_grad,
+                                                                        const float* __restrict__ wbn,
+                                                                        double* __restrict__ bn_sums, int bn_nrep) {
   __shared__ float red[8][33];
   const int64_t total = (int64_t)ntap * CoP * CiP;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -335,7 +346,11 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const fl
   const int ci = idx % CiP;
   const int co = (idx / CiP) % CoP;
   const int t = idx / ((int64_t)CiP * CoP);
-  if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * v + shift[ci] * (float)dbias[co];
+  if (co < Cout && ci < Cin) {
+    const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
+    dw[wi] += scale[ci] * v + shift[ci] * (float)dbias[co];
+    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * CiP * 2 + ci * 2);
+  }
 }
 
 // dw[co,ci,tap] += scale[ci]*acc[tap][co][ci] + shift[ci]*dbias[co]   (BatchNorm folded out of the operand load)
@@ -343,7 +358,8 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
                                            int CoP, int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                            const double* __restrict__ dbias, float* __restrict__ dw,
-                                           float* __restrict__ dbias_grad) {
+                                           float* __restrict__ dbias_grad, const float* __restrict__ wbn,
+                                           double* __restrict__ bn_sums, int bn_nrep) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)ntap * CoP * CiP;
   if (dbias_grad && idx < Cout) dbias_grad[idx] += (float)dbias[idx];
@@ -353,26 +369,31 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
   const int t = idx / ((int64_t)CiP * CoP);
   const float v = acc[idx];
   acc[idx] = 0.f;
-  if (co < Cout && ci < Cin) dw[co * sCo + ci * sCi + tapsrc[t]] += scale[ci] * v + shift[ci] * (float)dbias[co];
+  if (co < Cout && ci < Cin) {
+    const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
+    dw[wi] += scale[ci] * v + shift[ci] * (float)dbias[co];
+    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * CiP * 2 + ci * 2);
+  }
 }
 
 extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                       int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                                       const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
-                                      sp_stream_t stream) {
+                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
   SP_CHECK_ARG(nparts >= 1 && Cout <= (total + 31) / 32 * 256, "sp_wgrad_finish_folded: nparts");
+  SP_CHECK_ARG(!bn_sums || (w_for_bn && bn_nrep >= 1), "sp_wgrad_finish_folded: bn_sums needs the weights and a replica count");
   if (nparts > 1) {
     hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
-                       scale, shift, dbias_sums, dw, dbias_grad);
+                       scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep);
     SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
     return SP_OK;
   }
   hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
-                     shift, dbias_sums, dw, dbias_grad);
+                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep);
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
   return SP_OK;
 }

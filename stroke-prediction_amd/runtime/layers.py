@@ -140,7 +140,11 @@ class ConvLayer:
             self.wgrad = O.WgradRunner(cout, cin, k, s, p, self.out_dims, self.in_dims, self.cpo, self.cpi,
                                        cout * kk, kk, dt, dev)
             dop = P.convT_dgrad_op(cin, cout, k, s, p, self.in_dims, self.cpo, self.cpi, dt)
-        if self.need_input_grad or self.bn_prefix is not None:
+        # first layer of a network (no input gradient wanted): on the folded DMA path the BatchNorm-backward sums come
+        # out of the weight-gradient accumulator and the whole data-gradient convolution is skipped
+        self.bn_from_wgrad = bool(not self.need_input_grad and self.bn_prefix is not None and self.kind == "conv"
+                                  and self.wgrad.folds(self.scale) and max(P._triple(p)) == 0)
+        if (self.need_input_grad or self.bn_prefix is not None) and not self.bn_from_wgrad:
             self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}))
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
         if self.bn_prefix is not None:
@@ -163,6 +167,13 @@ class ConvLayer:
         c = self.conv_prefix
         w = params[c + ".weight"]
         # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
+        if self.bn_from_wgrad:
+            bs = self.scratch.get(self.bsums_id)
+            self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
+                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
+                           bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP)
+            self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
+            return None, None
         if self.kind == "conv":
             self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
                            dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
@@ -183,11 +194,14 @@ class ConvLayer:
         else:
             self.dgrad.run(self.dz, self.g, self.batch)
             O.bn_bwd_reduce(self.g, x, self.dtype, bs)
+        self._bn_bwd_finalize(bs, params, grads, STATS_NREP if fused else 1)
+        return self.g, self.coef
+
+    def _bn_bwd_finalize(self, bs, params, grads, nrep):
+        p = self.bn_prefix
         world = 1
         if SYNC["on"]:
             _allreduce(bs)
             world = SYNC["world"]      # sums are global now: every rank holds the full dgamma/dbeta -> scale by 1/world
         O.bn_bwd_finalize(bs, self.count * world, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
-                          grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=STATS_NREP if fused else 1,
-                          pscale=1.0 / world)
-        return self.g, self.coef
+                          grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=nrep, pscale=1.0 / world)

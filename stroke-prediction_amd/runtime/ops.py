@@ -215,6 +215,9 @@ class WgradRunner:
         self.args = a
         self.dtype = dtype
 
+    def folds(self, in_scale):
+        return bool(self.dma and in_scale is not None)
+
     def _alloc_acc(self, batch):
         """Accumulator block(s).  WGRAD_PARTS: one block per persistent workgroup, written with plain stores and summed
         by the finish kernel (device-scope atomics from 8 XCDs cost 40-90 us per layer); the workgroup count is sized
@@ -237,9 +240,11 @@ class WgradRunner:
         self.acc_batch = batch
 
     def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None,
-            dbias_grad=None, nbias=0):
+            dbias_grad=None, nbias=0, bn_w=None, bn_sums=None, bn_nrep=1):
         """dw (fp32, the parameter's own layout) += gradient.  On the DMA path the BatchNorm (in_scale/in_shift) is
-        folded into the finish step and needs dbias_sums = sum over voxels of dz per output channel (fp64)."""
+        folded into the finish step and needs dbias_sums = sum over voxels of dz per output channel (fp64); there
+        bn_sums (with bn_w = the conv weight) also receives the BatchNorm-backward sums of the input, which
+        replaces the data-gradient convolution of a layer whose input gradient is not needed."""
         a = self.args
         assert x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
         assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi), (tuple(x.shape), (batch, a.Di, a.Hi, a.Wi, a.CPi))
@@ -261,8 +266,9 @@ class WgradRunner:
         if fold:
             L.call("sp_wgrad_finish_folded", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw),
-                   ptr(dbias_grad), st)
+                   ptr(dbias_grad), ptr(bn_w), ptr(bn_sums), bn_nrep, st)
         else:
+            assert bn_sums is None, "BatchNorm sums from the weight gradient need the folded (DMA) path"
             L.call("sp_wgrad_finish", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), ptr(dbias_sums) if dbias_grad is not None else None,
                    ptr(dbias_grad), nbias, st)

@@ -9,6 +9,8 @@ Data flow (channels-last tensors, BatchNorm folded into the consuming convolutio
 Batch statistics of every BatchNorm input are produced by the kernel that writes that tensor
 (conv / pool / upsample / crop epilogues); only the network input needs a stand-alone pass.
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -76,7 +78,7 @@ class UnetEngine:
         self.h2 = mk("classify.2", bc, ncls, d52, bn=False, k=1, act=L.ACT_SIGMOID, ap=0.0, out_dtype=L.SP_F32)
         self.out_dims = d52
         # fused pointwise head where a kernel exists for (C, CH, NC); the two generic 1x1 layers otherwise
-        self.fused_head = bool(L.load().sp_head_supported(b5, bc, ncls)) and b5 % 8 == 0
+        self.fused_head = bool(L.load().sp_head_supported(b5, bc, ncls)) and b5 % 8 == 0 and not os.environ.get("SP_GENERIC_HEAD")
         self.d12, self.dp1, self.d22, self.dp2, self.d32, self.dc4, self.d42, self.dc5 = d12, dp1, d22, dp2, d32, dc4, d42, dc5
         self.layers = [self.c11, self.c12, self.c21, self.c22, self.c31, self.c32, self.c41, self.c42, self.c51,
                        self.c52, self.h0, self.h2]

@@ -378,3 +378,38 @@ def test_fused_head(dtype, C, CH, NC, CP):
         tol = dict(rtol=1e-4, atol=1e-3) if dtype == L.SP_F32 else dict(rtol=1e-2, atol=0.02 * float(ref.abs().max()) + 1e-3)
         torch.testing.assert_close(hg[o:o + n].view(ref.shape), ref, **tol)
         o += n
+
+
+def test_bn_bwd_sums_from_wgrad():
+    """First-layer shortcut: sum_v g and sum_v g*x (g = conv_transpose(dz, W)) out of the weight-gradient accumulator
+    (sp_wgrad_finish_folded with bn_sums) against the explicit data-gradient convolution."""
+    torch.manual_seed(11)
+    B, cin, cout, dims = 2, 2, 16, (12, 14, 40)
+    od = tuple(d - 2 for d in dims)
+    dt = L.SP_BF16
+    x = rnd(dt, torch.randn(B, cin, *dims))
+    dz = rnd(dt, torch.randn(B, cout, *od))
+    w = torch.randn(cout, cin, 3, 3, 3) * 0.2
+    scale, shift = torch.rand(16) + 0.5, torch.randn(16) * 0.1
+    g = F.conv_transpose3d(dz.double(), w.double())
+    ref = torch.stack([g.sum((0, 2, 3, 4)), (g * x.double()).sum((0, 2, 3, 4))], 1)          # [cin][2]
+    xn = x * scale[:cin].view(1, -1, 1, 1, 1) + shift[:cin].view(1, -1, 1, 1, 1)
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(xn, wr).backward(dz)
+    x_cl, dz_cl = to_cl(x, 16, dt), to_cl(dz, 16, dt)
+    wg = O.WgradRunner(cin, cout, 3, 1, 0, dims, od, 16, 16, cin * 27, 27, dt, DEV)
+    assert wg.dma and wg.folds(scale)
+    dw = torch.zeros_like(w, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    dbs = torch.zeros(16, dtype=torch.float64, device=DEV)
+    dbs[:cout] = dz.double().sum((0, 2, 3, 4)).to(DEV)
+    nrep = 64
+    bs = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
+    wd = w.to(DEV)
+    wg.run(x_cl, dz_cl, B, dw, scale.to(DEV), shift.to(DEV), dbias_sums=dbs, dbias_grad=db, nbias=cout,
+           bn_w=wd, bn_sums=bs, bn_nrep=nrep)
+    got = bs.sum(0).cpu()
+    torch.testing.assert_close(got[:cin], ref, rtol=1e-4, atol=1e-2)
+    assert float(got[cin:].abs().max()) == 0.0
+    torch.testing.assert_close(dw.cpu(), wr.grad, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
