@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "sp_common.h"
 
@@ -632,12 +633,209 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_kernel(const T* __restr
   }
   if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
 }
+// ---- tiled variant (channel octets dividing 256).  The gather above re-reads every cat-gradient voxel up to 8 times
+// (4x4x4 overlapping windows; 1.6 GB fetched for 0.2 GB of data).  Here a workgroup owns a TY x TX patch of input
+// columns and marches along z: each output plane pair is staged ONCE in LDS ((2TY+2) x (2TX+2) voxels, halo 1.2-1.4x),
+// reduced in-plane (4x4 window) and folded into two running z accumulators.  The BatchNorm term c1 * sum_o w_o cat_o
+// needs no second tensor: cat = U y, so sum_o w_o cat_o = (U^T U y)[v], a 3x3x3 stencil on y with per-axis weights
+// (diag 1.25, 1.625 at the ends; off-diagonal 0.375), evaluated from a staged y patch; and sum_o w_o = 8.
+struct UpTile {
+  int TY, TX, RY, RX, nby, nbx, ZS, zchunk;
+  FastDiv d_tx, d_rx, d_yx, d_nbx, d_nby, d_zs;
+};
+__device__ __forceinline__ float upM_diag(int i, int N) {
+  int o[4]; float w[4];
+  upT_axis(i, N, o, w);
+  return w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* __restrict__ y, const T* __restrict__ g,
+                                                                       const float* __restrict__ coef, int CPcat, Dims di,
+                                                                       int CP, OctMap om, UpTile ut, int act, float ap,
+                                                                       T* __restrict__ dz, double* __restrict__ dbias) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int OC = om.OC, TY = ut.TY, TX = ut.TX, RY = ut.RY, RX = ut.RX;
+  const int pos = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - pos * OC;
+  const int ty = fdiv(pos, ut.d_tx), tx = pos - ty * TX;
+  // block -> (b, by, bx, zc)
+  uint32_t bid = blockIdx.x;
+  const uint32_t q1 = fdiv(bid, ut.d_zs); const int zc = bid - q1 * ut.ZS;
+  const uint32_t q2 = fdiv(q1, ut.d_nbx); const int bx = q1 - q2 * ut.nbx;
+  const uint32_t q3 = fdiv(q2, ut.d_nby); const int by = q2 - q3 * ut.nby;
+  const int b = q3;
+  const int D = di.D, H = di.H, W = di.W, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  const int z0 = zc * ut.zchunk, z1 = min(D, z0 + ut.zchunk);
+  const int y0 = by * TY, x0 = bx * TX;
+  const int yy = y0 + ty, xx = x0 + tx;
+  const bool valid = yy < H && xx < W;
+  const int yc_ = min(yy, H - 1), xc_ = min(xx, W - 1);      // clamped twin for the weights of idle threads
+
+  const size_t gplane = (size_t)RY * RX * CP * sizeof(T);     // one staged cat-gradient plane
+  T* gb0 = reinterpret_cast<T*>(smem);
+  T* gb1 = reinterpret_cast<T*>(smem + gplane);
+  T* yb = reinterpret_cast<T*>(smem + 2 * gplane);
+  float* red = reinterpret_cast<float*>(smem + 2 * gplane + (size_t)(TY + 2) * (TX + 2) * CP * sizeof(T));
+
+  int oy[4], ox[4]; float wy[4], wx[4];
+  upT_axis(yc_, H, oy, wy); upT_axis(xc_, W, ox, wx);
+  const float myc = upM_diag(yc_, H), mxc = upM_diag(xc_, W);
+  const float my[3] = {yc_ >= 1 ? 0.375f : 0.f, myc, yc_ < H - 1 ? 0.375f : 0.f};
+  const float mx[3] = {xc_ >= 1 ? 0.375f : 0.f, mxc, xc_ < W - 1 ? 0.375f : 0.f};
+  float c0[8], c1[8], c2[8], part[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = oc * 8 + j;
+    c0[j] = coef[c]; c1[j] = coef[CPcat + c]; c2[j] = 8.f * coef[2 * CPcat + c];
+    part[0][j] = 0.f;
+  }
+  float Acur[8], Anext[8], qprev[8], qcur[8], qnext[8], ycur[8], ynext[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) Acur[j] = Anext[j] = qprev[j] = qcur[j] = qnext[j] = ycur[j] = ynext[j] = 0.f;
+
+  const int nreg = RY * RX, nyp = (TY + 2) * (TX + 2), vstep = 256 / OC;
+  for (int m = z0 - 2; m < z1; ++m) {
+    // ---------------- stage: cat-gradient planes 2m+1, 2m+2 (clamped coordinates carry zero weight) and y plane m+1
+    if (m >= z0 - 1) {
+      const int oza = min(max(2 * m + 1, 0), Do - 1), ozb = min(max(2 * m + 2, 0), Do - 1);
+      for (int vi = pos; vi < nreg; vi += vstep) {
+        const int vy = fdiv(vi, ut.d_rx), vx = vi - vy * RX;
+        const int gy = min(max(2 * y0 - 1 + vy, 0), Ho - 1), gx = min(max(2 * x0 - 1 + vx, 0), Wo - 1);
+        const size_t o_a = ((((size_t)b * Do + oza) * Ho + gy) * Wo + gx) * CPcat + oc * 8;
+        const size_t o_b = ((((size_t)b * Do + ozb) * Ho + gy) * Wo + gx) * CPcat + oc * 8;
+        const int lo = vi * CP + oc * 8;
+        if constexpr (sizeof(T) == 2) {
+          const uint4 va = *reinterpret_cast<const uint4*>(g + o_a), vb = *reinterpret_cast<const uint4*>(g + o_b);
+          *reinterpret_cast<uint4*>(gb0 + lo) = va; *reinterpret_cast<uint4*>(gb1 + lo) = vb;
+        } else {
+          const uint4 va0 = *reinterpret_cast<const uint4*>(g + o_a), va1 = *reinterpret_cast<const uint4*>(g + o_a + 4);
+          const uint4 vb0 = *reinterpret_cast<const uint4*>(g + o_b), vb1 = *reinterpret_cast<const uint4*>(g + o_b + 4);
+          *reinterpret_cast<uint4*>(gb0 + lo) = va0; *reinterpret_cast<uint4*>(gb0 + lo + 4) = va1;
+          *reinterpret_cast<uint4*>(gb1 + lo) = vb0; *reinterpret_cast<uint4*>(gb1 + lo + 4) = vb1;
+        }
+      }
+    }
+    const bool yplane = m + 1 >= 0 && m + 1 < D;
+    if (yplane) {
+      for (int vi = pos; vi < nyp; vi += vstep) {
+        const int vy = fdiv(vi, ut.d_yx), vx = vi - vy * (TX + 2);
+        const int sy = min(max(y0 - 1 + vy, 0), H - 1), sx = min(max(x0 - 1 + vx, 0), W - 1);
+        const size_t o = ((((size_t)b * D + (m + 1)) * H + sy) * W + sx) * CP + oc * 8;
+        const int lo = vi * CP + oc * 8;
+        if constexpr (sizeof(T) == 2) {
+          *reinterpret_cast<uint4*>(yb + lo) = *reinterpret_cast<const uint4*>(y + o);
+        } else {
+          *reinterpret_cast<uint4*>(yb + lo) = *reinterpret_cast<const uint4*>(y + o);
+          *reinterpret_cast<uint4*>(yb + lo + 4) = *reinterpret_cast<const uint4*>(y + o + 4);
+        }
+      }
+    }
+    __syncthreads();
+    // ---------------- in-plane 4x4 reductions
+    if (m >= z0 - 1) {
+      float P1[8], P2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) P1[j] = P2[j] = 0.f;
+#pragma unroll
+      for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float w = wy[bb] * wx[cc];
+          const int lo = ((2 * ty + bb) * RX + 2 * tx + cc) * CP + oc * 8;
+          float a8[8], b8[8];
+          Store<T>::ld8(gb0 + lo, a8);
+          Store<T>::ld8(gb1 + lo, b8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { P1[j] = fmaf(w, a8[j], P1[j]); P2[j] = fmaf(w, b8[j], P2[j]); }
+        }
+      int oz[4]; float wz[4], wn[4];
+      upT_axis(max(m, 0), D, oz, wz);
+      upT_axis(min(m + 1, D - 1), D, oz, wn);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Acur[j] += wz[2] * P1[j] + wz[3] * P2[j];
+        Anext[j] = wn[0] * P1[j] + wn[1] * P2[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qnext[j] = ynext[j] = 0.f;
+    if (yplane) {
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float w = my[dy] * mx[dx];
+          float v8[8];
+          Store<T>::ld8(yb + ((ty + dy) * (TX + 2) + tx + dx) * CP + oc * 8, v8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) qnext[j] = fmaf(w, v8[j], qnext[j]);
+          if (dy == 1 && dx == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ynext[j] = v8[j];
+          }
+        }
+    }
+    // ---------------- input plane m is complete
+    if (m >= z0) {
+      const float mzc = upM_diag(m, D);
+      const float mzl = m >= 1 ? 0.375f : 0.f, mzr = m < D - 1 ? 0.375f : 0.f;
+      float o8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float my_ = mzl * qprev[j] + mzc * qcur[j] + mzr * qnext[j];
+        o8[j] = (c0[j] * Acur[j] + c1[j] * my_ + c2[j]) * act_bwd_from_y(act, ap, ycur[j]);
+      }
+      if (valid) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[0][j] += o8[j];
+        Store<T>::st8(dz + ((((size_t)b * D + m) * H + yy) * W + xx) * CP + oc * 8, o8);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Acur[j] = Anext[j]; qprev[j] = qcur[j]; qcur[j] = qnext[j]; ycur[j] = ynext[j];
+    }
+    __syncthreads();
+  }
+  if (dbias) block_channel_reduce<1>(part, oc, true, CP, dbias, red);
+}
+
 extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
                                     int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
   SP_CHECK_ARG(y && cat && g && coef && dz && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
+  if (256 % om.OC == 0 && D >= 2 && H >= 2 && W >= 2 && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
+    // tiled path: TY x TX input columns per workgroup, z split into chunks so that ~3 workgroups per CU exist
+    UpTile ut;
+    const int npos = 256 / om.OC;
+    ut.TX = npos < 16 ? npos : 16; ut.TY = npos / ut.TX;
+    ut.RY = 2 * ut.TY + 2; ut.RX = 2 * ut.TX + 2;
+    ut.nby = (H + ut.TY - 1) / ut.TY; ut.nbx = (W + ut.TX - 1) / ut.TX;
+    const int cols = B * ut.nby * ut.nbx;
+    int ZS = (768 + cols - 1) / cols;
+    if (ZS > D / 4) ZS = D / 4;
+    if (ZS < 1) ZS = 1;
+    ut.zchunk = (D + ZS - 1) / ZS; ut.ZS = (D + ut.zchunk - 1) / ut.zchunk;
+    ut.d_tx = make_fastdiv(ut.TX); ut.d_rx = make_fastdiv(ut.RX); ut.d_yx = make_fastdiv(ut.TX + 2);
+    ut.d_nbx = make_fastdiv(ut.nbx); ut.d_nby = make_fastdiv(ut.nby); ut.d_zs = make_fastdiv(ut.ZS);
+    const size_t esz = dtype == SP_BF16 ? 2 : 4;
+    const size_t sh2 = (2 * (size_t)ut.RY * ut.RX + (size_t)(ut.TY + 2) * (ut.TX + 2)) * CP * esz + (size_t)CP * sizeof(float);
+    if (sh2 <= 160 * 1024) {
+      const unsigned grid2 = (unsigned)(cols * ut.ZS);
+      if (dtype == SP_BF16) {
+        auto kern = upsample2_act_bwd_tiled_kernel<bf16_t>;
+        SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");
+        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, di, CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums);
+      } else {
+        auto kern = upsample2_act_bwd_tiled_kernel<float>;
+        SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");
+        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const float*)y, (const float*)g, coef, CPcat, di, CP, om, ut, act, act_param, (float*)dz, dbias_sums);
+      }
+      SP_CHECK_LAUNCH("sp_upsample2_act_bwd");
+      return SP_OK;
+    }
+  }
   const unsigned grid = grid_for((int64_t)B * D * H * W, om.vpb);
   const size_t sh = (size_t)CP * sizeof(float);
   if (dtype == SP_BF16) hipLaunchKernelGGL(upsample2_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)cat, (const bf16_t*)g, coef, CPcat, di, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);

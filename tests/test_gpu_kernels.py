@@ -413,3 +413,33 @@ def test_bn_bwd_sums_from_wgrad():
     assert float(got[cin:].abs().max()) == 0.0
     torch.testing.assert_close(dw.cpu(), wr.grad, rtol=2e-3, atol=2e-2)
     torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
+@pytest.mark.parametrize("C0,ldims", [(32, (9, 7, 21)), (64, (5, 6, 9)), (16, (3, 17, 18))])
+def test_upsample2_act_bwd_tiled(dtype, C0, ldims):
+    """sp_upsample2_act_bwd (tiled z-marching kernel; several patches, z chunks and ragged edges) against autograd of
+    F.interpolate(trilinear x2) composed with the BatchNorm-backward affine form (Unet3D.py:67-72 backward)."""
+    g = torch.Generator().manual_seed(21)
+    B, C1 = 2, 16
+    low = rnd(dtype, torch.randn(B, C0, *ldims, generator=g))
+    lowr = low.clone().requires_grad_(True)
+    up_ref = F.interpolate(lowr, scale_factor=2, mode="trilinear", align_corners=False)
+    cdims = tuple(up_ref.shape[2:])
+    cp_cat = C0 + C1
+    coefs = torch.randn(3, cp_cat, generator=g) * 0.5
+    g_cat = rnd(dtype, torch.randn(B, cp_cat, *cdims, generator=g))
+    v = lambda t: t.view(1, -1, 1, 1, 1)
+    d_up = v(coefs[0, :C0]) * g_cat[:, :C0] + v(coefs[1, :C0]) * up_ref.detach() + v(coefs[2, :C0])
+    (glow_ref,) = torch.autograd.grad([up_ref], (lowr,), [d_up])
+    lows = to_cl(low, C0, dtype)
+    cat = O.alloc_cl(B, cdims, cp_cat, dtype, DEV)
+    O.upsample2_fwd(lows, cat, dtype)
+    gcs = to_cl(g_cat, cp_cat, dtype)
+    dzl = O.alloc_cl(B, ldims, C0, dtype, DEV)
+    dbias = torch.zeros(C0, dtype=torch.float64, device=DEV)
+    O.upsample2_act_bwd(lows, cat, gcs, coefs.to(DEV), dtype, L.ACT_ELU, 1.0, dzl, dbias)
+    elu_d = torch.where(low > 0, torch.ones_like(low), low + 1.0)
+    want = glow_ref * elu_d
+    torch.testing.assert_close(from_cl(dzl, C0, dtype), want, **TOL[dtype])
+    torch.testing.assert_close(dbias.cpu().float(), want.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
