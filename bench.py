@@ -50,6 +50,37 @@ def cpu_baseline(size, steps=1, batch=2):
                       % (batch, size[0], steps, t)}
 
 
+def torch_gpu_baseline(size, batch, steps=3, bf16=True):
+    """Optional extra leg (--torch-gpu-baseline): the same torch restatement run by stock PyTorch-ROCm (MIOpen
+    convolutions, bf16 autocast, eager autograd, torch-style Adam) on this GPU.  A reference point for what the
+    reference code base itself would reach on an MI355X; never the thing shipped or the headline value."""
+    from oracle import nets, weights as W
+    dev = "cuda:0"
+    sd = {k: v.to(dev) for k, v in W.make_state_dict(W.unet_spec(CHANNELS), 1234).items()}
+    names = nets.trainable(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    x, y = W.unet_inputs(batch, size, 1234)
+    x, y = x.to(dev), y.to(dev)
+    opt = torch.optim.Adam([sd[k] for k in names], lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    times = []
+    for step in range(steps + 2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            seg = nets.unet_forward(sd, x, training=True)
+        loss = nets.unet_loss(seg.float(), y)
+        loss.backward()
+        opt.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[2:])[len(times[2:]) // 2]
+    vox = batch * size[0] * size[1] * size[2]
+    return {"value": vox / t, "unit": "voxels/s", "ms_per_step": 1e3 * t, "kind": "torch restatement on the same GPU (MIOpen, %s, eager)"
+            % ("bf16 autocast" if bf16 else "fp32"), "batch": batch}
+
+
 def capture_step(step, enabled):
     """Capture one optimiser step (hundreds of kernel launches) into a hipGraph; returns (graph, static_loss) or (None, None)."""
     if not enabled:
@@ -147,6 +178,8 @@ def main():
     ap.add_argument("--cae-depth", type=int, default=28, help="CAE volume depth (28 native, 124 = closest closed size to 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--torch-gpu-baseline", action="store_true",
+                    help="also time the torch restatement (MIOpen, bf16 autocast) on this GPU; reported beside cpu_baseline")
     ap.add_argument("--dp-mode", default="fast", choices=["fast", "exact"],
                     help="multi-GPU: fast = local BatchNorm/Dice + gradient mean; exact = global-batch BatchNorm and Dice sums")
     ap.add_argument("--layers", action="store_true", help="print per-layer conv kernel timings to stderr")
@@ -281,6 +314,11 @@ def main():
             if args.size == 128 else None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(size)
+    if rank == 0 and world == 1 and args.torch_gpu_baseline and args.workload == "unet":
+        try:
+            res["torch_gpu_baseline"] = torch_gpu_baseline(size, args.batch, bf16=(args.dtype == "bf16"))
+        except Exception as e:
+            res["torch_gpu_baseline"] = {"error": str(e).splitlines()[0][:200]}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:
