@@ -139,7 +139,7 @@ int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc,
                            int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                            const float* shift, const double* dbias_sums, float* dw, float* dbias_grad /* or NULL */,
                            const float* w_for_bn /* or NULL */, double* bn_sums /* or NULL */, int32_t bn_nrep,
-                           sp_stream_t stream);
+                           int32_t bn_cp /* channel pitch of a bn_sums replica; <= 0: CiP */, sp_stream_t stream);
 /* bn_sums != NULL (first layer of a network: no input gradient wanted, so no data-gradient convolution is run):
  * also accumulate the BatchNorm-backward sums of the layer's input,  bn_sums[rep][ci][0] += sum_v g  and
  * bn_sums[rep][ci][1] += sum_v g*x  with g = conv_transpose(dz, w_for_bn), computed from the weight-gradient
@@ -150,6 +150,25 @@ int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_
                     int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
                     const double* dbias_sums /* or NULL */, float* dbias_grad /* or NULL */, int32_t nbias,
                     sp_stream_t stream);
+
+/* ------------------------------------------------------------------ first layer, read from the NCDHW fp32 input
+ * (Unet3D.py:18-20 of block1: BatchNorm3d(2) -> Conv3d(2,16,3) -> LeakyReLU; train_unet_segmentation.py:22).  With two
+ * input channels the im2col K dimension is packed (9 (dz,dy) groups x (4 dx x 2 channels)) instead of padding the
+ * channels to a 16-wide plane; bf16 storage only.  sp_first_supported tells whether a layer shape has this path. */
+int sp_first_supported(int32_t Cin, int32_t Cout, int32_t k);
+/* sums[rep][CP][2] += (sum x, sum x^2) per input channel of x [B][C][DHW] (values rounded to bf16 first) */
+int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums, int32_t nrep,
+                      sp_stream_t stream);
+/* w (16,2,3,3,3), b (16), BatchNorm scale/shift (2) or NULL -> wfrag (3*64*8 bf16 MFMA fragments), bias_f (16) */
+int sp_first_prep(const float* w, const float* b, const float* scale, const float* shift, void* wfrag, float* bias_f,
+                  sp_stream_t stream);
+/* y [B][D-2][H-2][W-2][16] bf16 = act(conv + bias); stats[rep][16][2] += (sum y, sum y^2) when stats != NULL */
+int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag, const float* bias_f,
+                      int32_t act, float act_param, void* y, double* stats, int32_t nrep, sp_stream_t stream);
+/* partials [nblocks][27][16][2] fp32 (written): raw-input weight gradient blocks for
+ * sp_wgrad_finish_folded(partials, nblocks, tapsrc, 27, 16, 2, 16, 2, ...) */
+int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
+                   int32_t nblocks, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ layout
  * NCDHW fp32 (reference layout, README.md:13 / data.py:305) <-> channels-last-3d */

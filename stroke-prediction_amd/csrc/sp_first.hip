@@ -1,0 +1,314 @@
+// First layer of the U-Net (Unet3D.py:18-20 of block1: BatchNorm3d(2) -> Conv3d(2, 16, 3) -> LeakyReLU) read straight
+// from the network input.  The input has TWO channels (CBV and TTD maps, NCDHW fp32): pushed through the generic
+// 16-channel-plane kernels it is 8x zero padding in HBM, LDS and MFMA K (fwd 232 us, wgrad 359 us, layout copy 81 us,
+// statistics 82 us per step at 4 x 2 x 128^3).  Here the im2col K dimension is packed instead:
+//   K = 9 (dz,dy) groups x 8 = (4 dx x 2 channels), dx = 3 carrying zero weights  ->  3 MFMA 16x16x32 per 16 voxels,
+// the staged tile is one dword per voxel (both channels as bf16), and nothing but the fp32 NCDHW input is read.
+//   sp_bn_stats_ncdhw   batch statistics of the input for the first BatchNorm
+//   sp_first_prep       conv weights with the BatchNorm folded in -> MFMA A fragments, folded bias
+//   sp_first_conv_fwd   y = act(conv(W', x) + b'), channels-last bf16, plus the next BatchNorm's (sum, sum^2)
+//   sp_first_wgrad      raw-input weight gradient as per-workgroup partial blocks [27][16][2] for
+//                       sp_wgrad_finish_folded (which also yields the BatchNorm-backward sums: no data gradient)
+#include "sp_common.h"
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+namespace {
+constexpr int FT_TZ = 2, FT_TY = 4, FT_TX = 64;          // output voxels per tile
+constexpr int FT_XZ = FT_TZ + 2, FT_XY = FT_TY + 2;      // staged input rows
+constexpr int FT_XP = 72;                                 // staged row pitch in voxels (>= TX + 2 + read-ahead)
+constexpr int FT_ROWS = FT_XZ * FT_XY;
+
+struct FirstDev {
+  const float* x;                                         // [B][2][D][H][W] fp32
+  int B, D, H, W, Do, Ho, Wo;
+  int ntz, nty, ntx;
+  uint32_t ntiles;
+  FastDiv d_tx, d_ty, d_tz, d_xp, d_xy;
+};
+
+__device__ __forceinline__ void first_decode(const FirstDev& P, uint32_t tile, int& b, int& oz0, int& oy0, int& ox0) {
+  const uint32_t q1 = fdiv(tile, P.d_tx); const int tx = tile - q1 * P.ntx;
+  const uint32_t q2 = fdiv(q1, P.d_ty); const int ty = q1 - q2 * P.nty;
+  const uint32_t q3 = fdiv(q2, P.d_tz); const int tz = q2 - q3 * P.ntz;
+  b = q3; oz0 = tz * FT_TZ; oy0 = ty * FT_TY; ox0 = tx * FT_TX;
+}
+
+// stage the (TZ+2) x (TY+2) x XP input window of a tile; coordinates clamped (clamped voxels only ever meet
+// zero weights / zero-filled dz).  INTERLEAVED: one dword per voxel = (c0 | c1 << 16) bf16.  Planar: [c][row][x] bf16.
+template <bool INTERLEAVED>
+__device__ __forceinline__ void first_stage_x(const FirstDev& P, int b, int oz0, int oy0, int ox0, uint32_t* xt) {
+  const size_t plane = (size_t)P.D * P.H * P.W;
+  const float* x0 = P.x + (size_t)b * 2 * plane;
+  for (int i = threadIdx.x; i < FT_ROWS * FT_XP; i += 256) {
+    const int row = fdiv(i, P.d_xp), xo = i - row * FT_XP;
+    const int zz = fdiv(row, P.d_xy), yy = row - zz * FT_XY;
+    const int gz = min(oz0 + zz, P.D - 1), gy = min(oy0 + yy, P.H - 1), gx = min(ox0 + xo, P.W - 1);
+    const size_t o = ((size_t)gz * P.H + gy) * P.W + gx;
+    const uint32_t v0 = f2bf(x0[o]), v1 = f2bf(x0[plane + o]);
+    if (INTERLEAVED) {
+      xt[i] = v0 | (v1 << 16);
+    } else {
+      bf16_t* pl = reinterpret_cast<bf16_t*>(xt);
+      pl[i] = (bf16_t)v0;
+      pl[FT_ROWS * FT_XP + i] = (bf16_t)v1;
+    }
+  }
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ input statistics
+__global__ __launch_bounds__(256) void bn_stats_ncdhw_kernel(const float* __restrict__ x, int C, int64_t DHW, int CP,
+                                                              double* __restrict__ sums, int nrep, int chunks) {
+  // grid (chunks, B*C): one contiguous chunk of one (b, c) plane per workgroup; values rounded to bf16 first (the
+  // convolution consumes the rounded input)
+  const int bc = blockIdx.y, c = bc % C;
+  const float* p = x + (size_t)bc * DHW;
+  const int64_t per = (DHW + chunks - 1) / chunks, i0 = (int64_t)blockIdx.x * per, i1 = min(DHW, i0 + per);
+  float s1 = 0.f, s2 = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float v = bf2f(f2bf(p[i]));
+    s1 += v; s2 = fmaf(v, v, s2);
+  }
+  __shared__ double r1[4], r2[4];
+  const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
+  if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = d1; r2[threadIdx.x >> 6] = d2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double* dst = sums + (size_t)((blockIdx.x + blockIdx.y) % nrep) * CP * 2 + c * 2;
+    atomicAdd(dst, r1[0] + r1[1] + r1[2] + r1[3]);
+    atomicAdd(dst + 1, r2[0] + r2[1] + r2[2] + r2[3]);
+  }
+}
+
+extern "C" int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums,
+                                 int32_t nrep, sp_stream_t stream) {
+  SP_CHECK_ARG(x && sums && B >= 1 && C >= 1 && C <= CP && DHW >= 1 && nrep >= 1, "sp_bn_stats_ncdhw: bad arguments");
+  int chunks = (int)((DHW + 16383) / 16384);
+  if (chunks > 1024) chunks = 1024;
+  hipLaunchKernelGGL(bn_stats_ncdhw_kernel, dim3(chunks, B * C), dim3(256), 0, ST(stream), x, C, DHW, CP, sums, nrep, chunks);
+  SP_CHECK_LAUNCH("sp_bn_stats_ncdhw");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weights
+// A fragment of MFMA step s (0..2), lane l: row co = l % 16, K slice j = l / 16 -> group g = 4s + j = (dz, dy),
+// elements e = 0..7 = (dx = e / 2, c = e % 2);  W' = W * scale[c],  b' = b + sum W * shift[c]
+__global__ void first_prep_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f) {
+  const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes
+  const int s = t >> 6, l = t & 63, co = l & 15, g = 4 * s + (l >> 4);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int dx = e >> 1, c = e & 1;
+    float v = 0.f;
+    if (g < 9 && dx < 3) v = w[(co * 2 + c) * 27 + g * 3 + dx] * (scale ? scale[c] : 1.f);
+    wfrag[(size_t)t * 8 + e] = f2bf(v);
+  }
+  if (t < 16) {
+    float acc = b ? b[t] : 0.f;
+    if (shift)
+      for (int c = 0; c < 2; ++c)
+        for (int k = 0; k < 27; ++k) acc = fmaf(w[(t * 2 + c) * 27 + k], shift[c], acc);
+    bias_f[t] = acc;
+  }
+}
+
+extern "C" int sp_first_supported(int32_t Cin, int32_t Cout, int32_t k) { return Cin == 2 && Cout == 16 && k == 3; }
+
+extern "C" int sp_first_prep(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
+                             float* bias_f, sp_stream_t stream) {
+  SP_CHECK_ARG(w && wfrag && bias_f, "sp_first_prep: null pointer");
+  hipLaunchKernelGGL(first_prep_kernel, dim3(1), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f);
+  SP_CHECK_LAUNCH("sp_first_prep");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const bf16x8* __restrict__ wfrag,
+                                                         const float* __restrict__ bias, int act, float ap,
+                                                         bf16_t* __restrict__ y, double* __restrict__ stats, int nrep) {
+  __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];
+  __shared__ float red[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
+  bf16x8 af[3];
+  int goff[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    af[s] = wfrag[s * 64 + lane];
+    const int g = min(4 * s + lg, 8);                       // groups 9..11 carry zero weights: any finite data will do
+    goff[s] = ((g / 3) * FT_XY + (g % 3)) * FT_XP;
+  }
+  float bj[4], s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { bj[j] = bias[lg * 4 + j]; s1[j] = s2[j] = 0.f; }
+  const float slope = act == SP_ACT_LEAKY ? ap : 1.f;
+  const bool lin = act == SP_ACT_LEAKY || act == SP_ACT_NONE;
+
+  for (uint32_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+    int b, oz0, oy0, ox0;
+    first_decode(P, tile, b, oz0, oy0, ox0);
+    __syncthreads();                                        // the previous tile has been consumed
+    first_stage_x<true>(P, b, oz0, oy0, ox0, xt);
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wave + rr, zz = row >> 2, yy = row & 3;
+      const int oz = oz0 + zz, oy = oy0 + yy;
+      const bool rok = oz < P.Do && oy < P.Ho;
+      const int rbase = (zz * FT_XY + yy) * FT_XP + n;
+      bf16_t* yrow = y + ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo) * 16 + lg * 4;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const uint32_t* p = xt + goff[s] + rbase + t * 16;
+          union { uint32_t u[4]; bf16x8 v; } bq;
+          bq.u[0] = p[0]; bq.u[1] = p[1]; bq.u[2] = p[2]; bq.u[3] = p[3];
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bq.v, acc, 0, 0, 0);
+        }
+        const int ox = ox0 + t * 16 + n;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = acc[j] + bj[j];
+          v[j] = lin ? fmaxf(z, slope * z) : act_fwd(act, ap, z);
+        }
+        if (rok && ox < P.Wo) {
+          Store<bf16_t>::st4(yrow + (size_t)ox * 16, v);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float q = bf2f(f2bf(v[j]));               // statistics of what is stored
+            s1[j] += q; s2[j] = fmaf(q, q, s2[j]);
+          }
+        }
+      }
+    }
+  }
+  if (stats) {
+    if (tid < 32) red[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x1 = row16_sum(s1[j]), x2 = row16_sum(s2[j]);
+      if (n == 0) { atomicAdd(&red[(lg * 4 + j) * 2], x1); atomicAdd(&red[(lg * 4 + j) * 2 + 1], x2); }
+    }
+    __syncthreads();
+    if (tid < 32) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * 32 + tid], (double)red[tid]);
+  }
+}
+
+static int first_geometry(FirstDev& P, const float* x, int B, int D, int H, int W) {
+  P.x = x; P.B = B; P.D = D; P.H = H; P.W = W; P.Do = D - 2; P.Ho = H - 2; P.Wo = W - 2;
+  P.ntz = (P.Do + FT_TZ - 1) / FT_TZ; P.nty = (P.Ho + FT_TY - 1) / FT_TY; P.ntx = (P.Wo + FT_TX - 1) / FT_TX;
+  const uint64_t nt = (uint64_t)P.ntz * P.nty * P.ntx * B;
+  if (nt >= (1ull << 31)) return -1;
+  P.ntiles = (uint32_t)nt;
+  P.d_tx = make_fastdiv(P.ntx); P.d_ty = make_fastdiv(P.nty); P.d_tz = make_fastdiv(P.ntz);
+  P.d_xp = make_fastdiv(FT_XP); P.d_xy = make_fastdiv(FT_XY);
+  return 0;
+}
+
+extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag,
+                                 const float* bias_f, int32_t act, float act_param, void* y, double* stats, int32_t nrep,
+                                 sp_stream_t stream) {
+  SP_CHECK_ARG(x && wfrag && bias_f && y && B >= 1 && D >= 3 && H >= 3 && W >= 3, "sp_first_conv_fwd: bad arguments");
+  SP_CHECK_ARG(!stats || nrep >= 1, "sp_first_conv_fwd: stats replicas");
+  FirstDev P;
+  SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_conv_fwd: too many tiles");
+  const unsigned grid = P.ntiles < 2048 ? P.ntiles : 2048;
+  hipLaunchKernelGGL(first_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
+                     (bf16_t*)y, stats, nrep);
+  SP_CHECK_LAUNCH("sp_first_conv_fwd");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[co][c][dz,dy,dx] = sum_v dz[v][co] * x[c][v + (dz,dy,dx)].  MFMA with K = 32 voxels along x:
+//   A = dz^T (rows co), transposed out of the staged channels-last dz tile by ds_read_b64_tr_b16 (natural K order);
+//   B = columns r = (dz,dy) (9 of 16 used), one column tile per channel c, eight consecutive x voxels per lane from
+//       the planar staged input; the three dx taps are the same five dwords shifted by 0, 1 and 2 elements.
+__global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, const bf16_t* __restrict__ dzg,
+                                                           float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];        // planar: [c][row][x] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char dzt[FT_TZ * FT_TY * FT_TX * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
+  const int lq = n >> 2, lp = n & 3;
+  const int r = n < 9 ? n : 0;                             // idle columns read tap 0 (their results are never flushed)
+  const int boff = ((r / 3) * FT_XY + (r % 3)) * FT_XP + 8 * lg;        // elements, per channel plane
+  const int aoff0 = (8 * lg + lq) * 32 + lp * 8, aoff1 = aoff0 + 4 * 32;   // bytes inside a 32-voxel K block
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) acc[d][0] = acc[d][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* xpl = reinterpret_cast<const bf16_t*>(xt);
+  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+
+  for (uint32_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+    int b, oz0, oy0, ox0;
+    first_decode(P, tile, b, oz0, oy0, ox0);
+    __syncthreads();
+    first_stage_x<false>(P, b, oz0, oy0, ox0, xt);
+    // dz tile: [row = zz*TY + yy][x][16 ch], zero where the output voxel does not exist
+    for (int i = tid; i < FT_TZ * FT_TY * FT_TX * 2; i += 256) {
+      const int half = i & 1, vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
+      const int oz = oz0 + (row >> 2), oy = oy0 + (row & 3), ox = ox0 + vx;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (oz < P.Do && oy < P.Ho && ox < P.Wo)
+        v = *reinterpret_cast<const uint4*>(dzg + ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * 16 + half * 8);
+      *reinterpret_cast<uint4*>(dzt + (size_t)i * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wave + rr, zz = row >> 2, yy = row & 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const unsigned char* ab = dzt + (row * FT_TX + ks * 32) * 32;
+        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + aoff0));
+        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + aoff1));
+        const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const bf16_t* bp = xpl + c * (FT_ROWS * FT_XP) + (zz * FT_XY + yy) * FT_XP + ks * 32 + boff;
+          const uint4 q = *reinterpret_cast<const uint4*>(bp);
+          const uint32_t q4 = *reinterpret_cast<const uint32_t*>(bp + 8);
+          union { uint32_t u[4]; bf16x8 v; } b0, b1, b2;
+          b0.u[0] = q.x; b0.u[1] = q.y; b0.u[2] = q.z; b0.u[3] = q.w;
+          b1.u[0] = __builtin_amdgcn_alignbit(q.y, q.x, 16); b1.u[1] = __builtin_amdgcn_alignbit(q.z, q.y, 16);
+          b1.u[2] = __builtin_amdgcn_alignbit(q.w, q.z, 16); b1.u[3] = __builtin_amdgcn_alignbit(q4, q.w, 16);
+          b2.u[0] = q.y; b2.u[1] = q.z; b2.u[2] = q.w; b2.u[3] = q4;
+          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b0.v, acc[0][c], 0, 0, 0);
+          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b1.v, acc[1][c], 0, 0, 0);
+          acc[2][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b2.v, acc[2][c], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // ---- flush: D[row = co = lg*4 + j][col = r = n]; one partial block [tap = r*3 + dx][co][c] per workgroup, the four
+  // waves' tiles added through LDS
+  __syncthreads();
+  float* st = reinterpret_cast<float*>(dzt);
+  for (int i = tid; i < 27 * 16 * 2; i += 256) st[i] = 0.f;
+  __syncthreads();
+  if (n < 9) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&st[((n * 3 + d) * 16 + lg * 4 + j) * 2 + c], acc[d][c][j]);
+  }
+  __syncthreads();
+  for (int i = tid; i < 27 * 16 * 2; i += 256) part[(size_t)blockIdx.x * (27 * 16 * 2) + i] = st[i];
+}
+
+extern "C" int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
+                              int32_t nblocks, sp_stream_t stream) {
+  SP_CHECK_ARG(x && dz && partials && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1, "sp_first_wgrad: bad arguments");
+  FirstDev P;
+  SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad: too many tiles");
+  hipLaunchKernelGGL(first_wgrad_kernel, dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, partials);
+  SP_CHECK_LAUNCH("sp_first_wgrad");
+  return SP_OK;
+}

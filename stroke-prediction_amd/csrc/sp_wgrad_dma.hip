@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const fl
                                                                         const double* __restrict__ dbias,
                                                                         float* __restrict__ dw, float* __restrict__ dbias_grad,
                                                                         const float* __restrict__ wbn,
-                                                                        double* __restrict__ bn_sums, int bn_nrep) {
+                                                                        double* __restrict__ bn_sums, int bn_nrep, int bn_cp) {
   __shared__ float red[8][33];
   const int64_t total = (int64_t)ntap * CoP * CiP;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const fl
   if (co < Cout && ci < Cin) {
     const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
     dw[wi] += scale[ci] * v + shift[ci] * (float)dbias[co];
-    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * CiP * 2 + ci * 2);
+    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * bn_cp * 2 + ci * 2);
   }
 }
 
@@ -359,7 +359,7 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                            const double* __restrict__ dbias, float* __restrict__ dw,
                                            float* __restrict__ dbias_grad, const float* __restrict__ wbn,
-                                           double* __restrict__ bn_sums, int bn_nrep) {
+                                           double* __restrict__ bn_sums, int bn_nrep, int bn_cp) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)ntap * CoP * CiP;
   if (dbias_grad && idx < Cout) dbias_grad[idx] += (float)dbias[idx];
@@ -372,28 +372,29 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
   if (co < Cout && ci < Cin) {
     const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
     dw[wi] += scale[ci] * v + shift[ci] * (float)dbias[co];
-    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * CiP * 2 + ci * 2);
+    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * bn_cp * 2 + ci * 2);
   }
 }
 
 extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                       int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                                       const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
-                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, sp_stream_t stream) {
+                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
   SP_CHECK_ARG(nparts >= 1 && Cout <= (total + 31) / 32 * 256, "sp_wgrad_finish_folded: nparts");
   SP_CHECK_ARG(!bn_sums || (w_for_bn && bn_nrep >= 1), "sp_wgrad_finish_folded: bn_sums needs the weights and a replica count");
+  if (bn_cp <= 0) bn_cp = CiP;
   if (nparts > 1) {
     hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
-                       scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep);
+                       scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp);
     SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
     return SP_OK;
   }
   hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
-                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep);
+                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp);
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
   return SP_OK;
 }

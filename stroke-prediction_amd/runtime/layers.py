@@ -97,19 +97,23 @@ class ConvLayer:
             self.y = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.out_dtype, self.device)
         return self.y
 
+    def _bn_fwd(self, params, bufs, training):
+        """Finalize the input BatchNorm (batch statistics from in_sums, running buffers) into scale/shift."""
+        p = self.bn_prefix
+        world = 1
+        if training and SYNC["on"]:
+            _allreduce(self.in_sums)
+            world = SYNC["world"]
+        O.bn_finalize(self.in_sums if training else None, self.count * world, params[p + ".weight"], params[p + ".bias"],
+                      bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
+                      self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
+        if training:
+            bufs[p + ".num_batches_tracked"].add_(1)
+
     def forward(self, x, params, bufs, training, out_stats=None):
         """x: channels-last input; returns the (cached) output tensor."""
         if self.bn_prefix is not None:
-            p = self.bn_prefix
-            world = 1
-            if training and SYNC["on"]:
-                _allreduce(self.in_sums)
-                world = SYNC["world"]
-            O.bn_finalize(self.in_sums if training else None, self.count * world, params[p + ".weight"], params[p + ".bias"],
-                          bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
-                          self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
-            if training:
-                bufs[p + ".num_batches_tracked"].add_(1)
+            self._bn_fwd(params, bufs, training)
         c = self.conv_prefix
         y = self.alloc_out()
         if self.fold:
@@ -205,3 +209,65 @@ class ConvLayer:
             world = SYNC["world"]      # sums are global now: every rank holds the full dgamma/dbeta -> scale by 1/world
         O.bn_bwd_finalize(bs, self.count * world, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
                           grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=nrep, pscale=1.0 / world)
+
+
+class FirstConvLayer(ConvLayer):
+    """First layer of a network on the packed-K kernels of sp_first.hip: BatchNorm(2) -> Conv3d(2, 16, 3) -> act read
+    straight from the NCDHW fp32 input (no channels-last copy, no padded channels), and a backward that needs no
+    data-gradient convolution (the BatchNorm-backward sums come out of the weight gradient).  bf16 storage only."""
+
+    @staticmethod
+    def supported(cin, cout, k, stride, pad, dtype, bn):
+        return bool(bn and dtype == L.SP_BF16 and stride == 1 and pad == 0 and L.load().sp_first_supported(cin, cout, k))
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        assert FirstConvLayer.supported(self.cin, self.cout, self.k, self.stride, self.pad, self.dtype, self.bn_prefix)
+        self.wfrag = torch.zeros(3 * 64 * 8, dtype=torch.bfloat16, device=self.device)
+        self.bias_f = torch.zeros(16, device=self.device)
+        self.flops = 2.0 * self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2] * 27 * self.cin * self.cout
+
+    def input_stats(self, images):
+        """Batch statistics of the network input for the first BatchNorm (replaces bn_stats on a channels-last copy)."""
+        B, Cc = images.shape[:2]
+        L.call("sp_bn_stats_ncdhw", O.ptr(images), B, Cc, images[0, 0].numel(), self.cpi, O.ptr(self.in_sums), STATS_NREP,
+               O.stream())
+
+    def forward(self, images, params, bufs, training, out_stats=None):
+        assert images.dtype == torch.float32 and images.is_contiguous()
+        self._bn_fwd(params, bufs, training)
+        c = self.conv_prefix
+        y = self.alloc_out()
+        st = O.stream()
+        L.call("sp_first_prep", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
+               O.ptr(self.wfrag), O.ptr(self.bias_f), st)
+        D, H, W = self.in_dims
+        with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
+            L.call("sp_first_conv_fwd", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.bias_f), self.act,
+                   self.act_param, O.ptr(y), O.ptr(out_stats), STATS_NREP, st)
+        return y
+
+    def _init_bwd(self):
+        if self._bwd_ready:
+            return
+        self.dz = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.dtype, self.device)
+        vox = self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
+        self.nparts = max(8, min(1024, vox // 8192))
+        self.partials = torch.empty(self.nparts * 27 * 16 * 2, dtype=torch.float32, device=self.device)
+        self.tapsrc = torch.arange(27, dtype=torch.int32, device=self.device)
+        self.coef = torch.zeros(3, self.cpi, device=self.device)
+        self._bwd_ready = True
+
+    def backward(self, images, params, grads):
+        c = self.conv_prefix
+        st = O.stream()
+        D, H, W = self.in_dims
+        bs = self.scratch.get(self.bsums_id)
+        with O._Timed("conv_wgrad", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
+            L.call("sp_first_wgrad", O.ptr(images), O.ptr(self.dz), self.batch, D, H, W, O.ptr(self.partials), self.nparts, st)
+        L.call("sp_wgrad_finish_folded", O.ptr(self.partials), self.nparts, O.ptr(self.tapsrc), 27, 16, 2, self.cout,
+               self.cin, self.cin * 27, 27, O.ptr(self.scale), O.ptr(self.shift), O.ptr(self.dbias_sums),
+               O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(params[c + ".weight"]), O.ptr(bs), STATS_NREP,
+               self.cpi, st)
+        self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
+        return None, None

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libstroke_amd.so")
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_head.hip", "sp_elem.hip"]
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip"]
 
 SP_BF16, SP_F32 = 0, 1
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
@@ -41,7 +41,12 @@ _SIGS = {
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
     "sp_wgrad_finish": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, vp], i32),
-    "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
+    "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
+    "sp_first_supported": ([i32, i32, i32], i32),
+    "sp_bn_stats_ncdhw": ([vp, i32, i32, i64, i32, vp, i32, vp], i32),
+    "sp_first_prep": ([vp, vp, vp, vp, vp, vp, vp], i32),
+    "sp_first_conv_fwd": ([vp, i32, i32, i32, i32, vp, vp, i32, f32, vp, vp, i32, vp], i32),
+    "sp_first_wgrad": ([vp, vp, i32, i32, i32, i32, vp, i32, vp], i32),
     "sp_ncdhw_to_cl": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_cl_to_ncdhw": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),

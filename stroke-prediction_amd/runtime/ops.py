@@ -266,7 +266,7 @@ class WgradRunner:
         if fold:
             L.call("sp_wgrad_finish_folded", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw),
-                   ptr(dbias_grad), ptr(bn_w), ptr(bn_sums), bn_nrep, st)
+                   ptr(dbias_grad), ptr(bn_w), ptr(bn_sums), bn_nrep, 0, st)
         else:
             assert bn_sums is None, "BatchNorm sums from the weight gradient need the folded (DMA) path"
             L.call("sp_wgrad_finish", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,

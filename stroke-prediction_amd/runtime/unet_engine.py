@@ -15,7 +15,7 @@ import torch
 
 from . import lib as L
 from . import ops as O
-from .layers import ConvLayer, Scratch
+from .layers import ConvLayer, FirstConvLayer, Scratch
 
 LEAKY = 0.01
 
@@ -54,7 +54,13 @@ class UnetEngine:
         d0 = self.dims
         # the network input gets a 16-channel pitch (not 8): every 3x3x3 layer then meets the 16-channel plane
         # granularity of the DMA weight-gradient kernel
-        self.c11 = mk("b1c1", n_in, b1, d0, blk="block1", idx=0, need_g=False, cpi=O.cpad(n_in, 16))
+        self.first_packed = FirstConvLayer.supported(n_in, b1, 3, 1, 0, dtype, True) and not os.environ.get("SP_GENERIC_FIRST")
+        if self.first_packed:   # two-channel input: packed-K kernels reading the NCDHW fp32 input directly
+            self.c11 = FirstConvLayer("b1c1", "conv", n_in, b1, 3, 1, 0, d0, batch, dtype, device, sc,
+                                      bn_prefix="block1.bn_conv_relu_2x.0", conv_prefix="block1.bn_conv_relu_2x.1",
+                                      act=L.ACT_LEAKY, act_param=LEAKY, need_input_grad=False, cpi=O.cpad(n_in, 16))
+        else:
+            self.c11 = mk("b1c1", n_in, b1, d0, blk="block1", idx=0, need_g=False, cpi=O.cpad(n_in, 16))
         self.c12 = mk("b1c2", b1, b1, sub(d0, 2), blk="block1", idx=3)
         d12 = sub(d0, 4)
         dp1 = half(d12)
@@ -86,7 +92,7 @@ class UnetEngine:
             l.reserve_bwd_scratch()
         sc.finalize()
         dt = dtype
-        self.x0 = O.alloc_cl(batch, d0, self.c11.cpi, dt, device)
+        self.x0 = None if self.first_packed else O.alloc_cl(batch, d0, self.c11.cpi, dt, device)
         self.p1 = O.alloc_cl(batch, dp1, O.cpad(b1), dt, device)
         self.p2 = O.alloc_cl(batch, dp2, O.cpad(b2), dt, device)
         self.cat4 = O.alloc_cl(batch, dc4, b3 + O.cpad(b2), dt, device)
@@ -102,9 +108,14 @@ class UnetEngine:
         images = images.contiguous()
         self.scratch.zero()
         st = (lambda l: l.in_sums) if training else (lambda l: None)
-        O.ncdhw_to_cl(images, self.x0, dt)
-        if training:
-            O.bn_stats(self.x0, dt, self.c11.in_sums)
+        if self.first_packed:
+            self.x0 = images                  # the packed first-layer kernels read the NCDHW fp32 input itself
+            if training:
+                self.c11.input_stats(images)
+        else:
+            O.ncdhw_to_cl(images, self.x0, dt)
+            if training:
+                O.bn_stats(self.x0, dt, self.c11.in_sums)
         y11 = self.c11.forward(self.x0, params, bufs, training, st(self.c12))
         y12 = self.c12.forward(y11, params, bufs, training)
         O.maxpool2_fwd(y12, self.p1, dt, st(self.c21))

@@ -443,3 +443,67 @@ def test_upsample2_act_bwd_tiled(dtype, C0, ldims):
     want = glow_ref * elu_d
     torch.testing.assert_close(from_cl(dzl, C0, dtype), want, **TOL[dtype])
     torch.testing.assert_close(dbias.cpu().float(), want.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
+
+
+def test_first_layer_packed():
+    """sp_first.hip: BatchNorm-folded Conv3d(2,16,3)+LeakyReLU, its statistics, the input statistics and the weight
+    gradient (+ BatchNorm-backward sums) straight from the NCDHW input, against torch on bf16-rounded operands."""
+    torch.manual_seed(17)
+    lib = L.load()
+    assert lib.sp_first_supported(2, 16, 3) == 1 and lib.sp_first_supported(3, 16, 3) == 0
+    B, dims = 2, (9, 11, 70)                      # ragged against the 2 x 4 x 64 tile, two x tiles
+    od = tuple(d - 2 for d in dims)
+    x = torch.randn(B, 2, *dims) * 1.5 + 0.3
+    xq = x.bfloat16().float()
+    w = torch.randn(16, 2, 3, 3, 3) * 0.2
+    b = torch.randn(16) * 0.1
+    scale, shift = torch.rand(16) + 0.5, torch.randn(16) * 0.1
+    xd = x.to(DEV).contiguous()
+    nrep = 64
+    # input statistics
+    sums = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
+    L.call("sp_bn_stats_ncdhw", O.ptr(xd), B, 2, dims[0] * dims[1] * dims[2], 16, O.ptr(sums), nrep, O.stream())
+    got = sums.sum(0).cpu()
+    ref = torch.stack([xq.double().sum((0, 2, 3, 4)), (xq.double() ** 2).sum((0, 2, 3, 4))], 1)
+    torch.testing.assert_close(got[:2], ref, rtol=1e-6, atol=1e-3)
+    # forward
+    wfrag = torch.zeros(3 * 64 * 8, dtype=torch.bfloat16, device=DEV)
+    bias_f = torch.zeros(16, device=DEV)
+    wd, bd, sc, sh = w.to(DEV), b.to(DEV), scale.to(DEV), shift.to(DEV)
+    L.call("sp_first_prep", O.ptr(wd), O.ptr(bd), O.ptr(sc), O.ptr(sh), O.ptr(wfrag), O.ptr(bias_f), O.stream())
+    y = O.alloc_cl(B, od, 16, L.SP_BF16, DEV)
+    st = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
+    L.call("sp_first_conv_fwd", O.ptr(xd), B, dims[0], dims[1], dims[2], O.ptr(wfrag), O.ptr(bias_f), L.ACT_LEAKY, 0.01,
+           O.ptr(y), O.ptr(st), nrep, O.stream())
+    wf = (w * scale[:2].view(1, 2, 1, 1, 1)).bfloat16().float()
+    bf = b + (w * shift[:2].view(1, 2, 1, 1, 1)).sum((1, 2, 3, 4))
+    y_ref = F.leaky_relu(F.conv3d(xq, wf, bf), 0.01)
+    yg = from_cl(y, 16, L.SP_BF16)
+    torch.testing.assert_close(yg, y_ref, rtol=1e-2, atol=1e-2)
+    sg = st.sum(0).cpu()
+    torch.testing.assert_close(sg[:, 0].float(), yg.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    torch.testing.assert_close(sg[:, 1].float(), (yg ** 2).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    # weight gradient + BatchNorm-backward sums
+    dz = rnd(L.SP_BF16, torch.randn(B, 16, *od))
+    dz_cl = to_cl(dz, 16, L.SP_BF16)
+    nparts = 24
+    part = torch.full((nparts * 27 * 16 * 2,), float("nan"), device=DEV)
+    L.call("sp_first_wgrad", O.ptr(xd), O.ptr(dz_cl), B, dims[0], dims[1], dims[2], O.ptr(part), nparts, O.stream())
+    dw = torch.zeros(16, 2, 3, 3, 3, device=DEV)
+    db = torch.zeros(16, device=DEV)
+    dbs = torch.zeros(16, dtype=torch.float64, device=DEV)
+    dbs[:] = dz.double().sum((0, 2, 3, 4)).to(DEV)
+    bs = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
+    tapsrc = torch.arange(27, dtype=torch.int32, device=DEV)
+    L.call("sp_wgrad_finish_folded", O.ptr(part), nparts, O.ptr(tapsrc), 27, 16, 2, 16, 2, 54, 27, O.ptr(sc), O.ptr(sh),
+           O.ptr(dbs), O.ptr(dw), O.ptr(db), O.ptr(wd), O.ptr(bs), nrep, 16, O.stream())
+    xn = xq * scale[:2].view(1, 2, 1, 1, 1) + shift[:2].view(1, 2, 1, 1, 1)
+    wr = w.clone().requires_grad_(True)
+    F.conv3d(xn, wr).backward(dz)
+    torch.testing.assert_close(dw.cpu(), wr.grad, rtol=2e-3, atol=2e-2)
+    torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    g = F.conv_transpose3d(dz.double(), w.double())
+    ref = torch.stack([g.sum((0, 2, 3, 4)), (g * xq.double()).sum((0, 2, 3, 4))], 1)
+    got = bs.sum(0).cpu()
+    torch.testing.assert_close(got[:2], ref, rtol=1e-4, atol=1e-2)
+    assert float(got[2:].abs().max()) == 0.0
