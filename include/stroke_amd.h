@@ -131,6 +131,8 @@ typedef struct sp_wgrad_args {
   int32_t dma;           /* 1: bf16 LDS-DMA double-buffered path (stride 1, padding 0, 3x3x3, no affine on load) */
   int32_t tile_rows;     /* dma: 0 = choose, else force TZ*TY rows of 32 voxels per tile (tuning knob) */
   int32_t parts;         /* 1: dw_acc holds nblocks partial blocks (see above) */
+  int32_t cib;           /* 0 = choose, else cin tiles (of 16) per workgroup: fewer planes per tile leave room for a
+                            larger spatial tile (less halo re-read) at the price of re-reading dz per cin group */
 } sp_wgrad_args;
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 /* BatchNorm folded out of the operand load (un-padded convolutions):

@@ -241,6 +241,7 @@ extern "C" int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream) {
   int COB = a->CoT >= 4 ? 4 : (a->CoT >= 2 ? 2 : 1);
   int CIB = a->CiT >= 3 ? 3 : a->CiT;
   if (COB == 4) CIB = 1;
+  if (a->cib > 0 && a->cib <= CIB) CIB = a->cib;          // caller's blocking of the cin tiles (grid.z grows accordingly)
   P.mdz = P.mdy = P.mdx = 0;
   const int kD = a->kD, kH = a->kH, kW = a->kW;
   SP_CHECK_ARG(kD >= 1 && kH >= 1 && kW >= 1 && kD <= 8 && kH <= 8 && kW <= 8, "sp_conv3d_wgrad: tap extent");

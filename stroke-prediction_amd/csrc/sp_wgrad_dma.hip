@@ -256,6 +256,7 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   int COB = a->CoT >= 4 ? 4 : (a->CoT >= 2 ? 2 : 1);
   int CIB = a->CiT >= 3 ? 3 : a->CiT;
   if (COB == 4) CIB = 1;
+  if (a->cib > 0 && a->cib <= CIB) CIB = a->cib;          // caller's blocking of the cin tiles (grid.z grows accordingly)
   // tile rows: the largest TZ x TY whose two buffers fit 150 KiB and whose chunk count fits the per-lane plan
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->CPo % 16 == 0, "sp_conv3d_wgrad(dma): channel pitches must be multiples of 16");
   // tile rows: two buffers per workgroup; prefer a shape that lets TWO workgroups share a CU (<= 75 KiB each) so

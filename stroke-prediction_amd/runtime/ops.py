@@ -1,5 +1,6 @@
 """Thin Python drivers over the C ABI: torch owns device memory and the stream; every op below
 enqueues hand-written gfx950 kernels through ``libstroke_amd.so`` (no torch compute kernels)."""
+import os
 import ctypes as C
 
 import numpy as np
@@ -206,12 +207,14 @@ class WgradRunner:
         # bf16 fast path: un-padded stride-1 3x3x3 convolution -> DMA double-buffered kernel, BatchNorm folded into finish
         self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and p == (0, 0, 0)
                         and tuple(in_dims) == tuple(d + 2 for d in out_dims) and cpi % 16 == 0 and cpo % 16 == 0
-                        and self.cot <= 2 and self.cit <= 3)   # wider layers: register-staged kernel measured faster
+                        and self.cot <= 2 and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))   # 64-wide outputs: register-staged kernel measured faster
         a.dma = int(self.dma)
         if self.dma:
-            import os
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", "512"))
             a.tile_rows = int(os.environ.get("SP_WGRAD_ROWS", "0"))
+        # DMA kernel: ONE 16-channel input plane per workgroup (grid.z = cin tiles).  With 2-3 planes the staged tile
+        # shrinks to 64 voxels and its halo is re-read 6x (48->16 @92^3: 505 -> 372 us, 96->32 @50^3: 363 -> 203 us)
+        a.cib = int(os.environ.get("SP_WGRAD_CIB", "1" if self.dma else "0"))
         self.args = a
         self.dtype = dtype
 
@@ -228,6 +231,8 @@ class WgradRunner:
         if WGRAD_PARTS:
             cob = 4 if self.cot >= 4 else (2 if self.cot >= 2 else 1)
             cib = 1 if cob == 4 else min(self.cit, 3)
+            if a.cib > 0:
+                cib = min(cib, a.cib)
             yz = -(-self.cot // cob) * -(-self.cit // cib)
             vox = batch * a.Do * a.Ho * a.Wo
             nb = max(8, min(512 // yz, vox // 768))
