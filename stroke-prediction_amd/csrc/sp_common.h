@@ -162,3 +162,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
   uint32_t q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): lane l lands at lds_dst + 16*l, lds_dst wave-uniform.
+// Issued through inline asm ON PURPOSE: with the builtin the compiler knows that a VMEM op writes LDS and, unable to
+// tell the two tile buffers apart, puts `s_waitcnt vmcnt(0)` in front of every LDS read that follows -- inside the MFMA
+// loop, where it drains the prefetch of the NEXT tile and serialises DMA and compute (found in the ISA of the
+// double-buffered weight-gradient kernel).  The kernels order DMA and reads themselves: s_waitcnt vmcnt(0) + barrier
+// before a buffer is read.  m0 is not otherwise used by these kernels (no other LDS-DMA / GWS / movrel).
+__device__ __forceinline__ void sp_dma16(const void* src, const void* lds_dst) {
+  typedef __attribute__((address_space(3))) void sp_lds_void;
+  const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(sp_lds_void*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "memory");
+}
+
+

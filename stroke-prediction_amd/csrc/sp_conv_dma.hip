@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvDmaDev P)
           const int cx = min(max(ix0 + (ch >> P.log2_opp), 0), a.Wi - 1);
           const bf16_t* src = xin + goff + (cx * a.CPi + (oct0 + (ch & opp_mask)) * 8);
 #ifndef SP_NO_DMA
-          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + (lo & 0xffffff)), 16, 0, 0);
+          sp_dma16(src, tile + (lo & 0xffffff));
 #endif
         }
       }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void conv_igemm_persist_kernel(const ConvDmaDe
           const int goff = __builtin_amdgcn_readlane(job_goff[k], j);
           const int lo = __builtin_amdgcn_readlane(job_loff[k], j);
           if (lane < P.row_chunks)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(org + goff + lane_goff), (lds_void*)(tile + lo), 16, 0, 0);
+            sp_dma16(org + goff + lane_goff, tile + lo);
         }
       }
     } else {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void conv_igemm_persist_kernel(const ConvDmaDe
         if (lane < P.row_chunks) {
           const int cx = min(max(c.ix0 + (lane >> P.log2_opp), 0), a.Wi - 1);
           const bf16_t* src = xin + (((size_t)cz * a.Hi + cy) * a.Wi + cx) * a.CPi + ((int)pl * a.opp + (lane & opp_mask)) * 8;
-          __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(tile + (int)pl * a.plane_bytes + row * P.row_chunks * 16), 16, 0, 0);
+          sp_dma16(src, tile + (int)pl * a.plane_bytes + row * P.row_chunks * 16);
         }
       }
     }

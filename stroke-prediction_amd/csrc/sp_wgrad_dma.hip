@@ -10,6 +10,7 @@
 //     unrolled MFMA loop (guards make hipcc shuttle accumulators between VGPRs and AGPRs);
 //   * the BatchNorm of the input is NOT applied on load (a DMA cannot): dw = scale[ci]*dw_raw + shift[ci]*sum(dz),
 //     exact for padding 0, applied by sp_wgrad_finish_folded.
+#include <stdlib.h>
 #include "sp_common.h"
 
 #ifdef SP_CONV_STAMPS
@@ -34,7 +35,7 @@ struct WgradDmaDev {
   FastDiv d_tx, d_ty, d_tz, d_xw, d_xh, d_xv, d_tv, d_ty_rows;
   uint32_t ntx, nty, ntz, ntiles;
   int32_t TZ, TY, XD, XH, XW, XV, TV;
-  int32_t nx_chunks, ndz_chunks, njx, njd, buf_bytes, dz_off;
+  int32_t nx_chunks, ndz_chunks, njx, njd, buf_bytes, dz_off, xcd;
 };
 
 __device__ __forceinline__ bf16x8 wd_tr_read2(const unsigned char* p0, const unsigned char* p1) {
@@ -130,10 +131,10 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
     if (interior) {
 #pragma unroll
       for (int j = 0; j < WD_NJX; ++j)
-        if (j < P.njx) __builtin_amdgcn_global_load_lds((gbl_void*)(xb + relx[j]), (lds_void*)(base + (wave + 4 * j) * 1024), 16, 0, 0);
+        if (j < P.njx) sp_dma16(xb + relx[j], base + (wave + 4 * j) * 1024);
 #pragma unroll
       for (int j = 0; j < WD_NJD; ++j)
-        if (j < P.njd) __builtin_amdgcn_global_load_lds((gbl_void*)(db + reld[j]), (lds_void*)(dbase + (wave + 4 * j) * 1024), 16, 0, 0);
+        if (j < P.njd) sp_dma16(db + reld[j], dbase + (wave + 4 * j) * 1024);
     } else {
       // border tile: chunks whose voxel lies outside the output grid (dz) or outside the input volume (x) are zeros
 #pragma unroll
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
           const int cz = crdx[j] & 0xff, cy = (crdx[j] >> 8) & 0xff, cx = (crdx[j] >> 16) & 0xff;
           unsigned char* dst = base + (wave + 4 * j) * 1024;
           if (oz0 + cz < a.Di && oy0 + cy < a.Hi && ox0 + cx < a.Wi)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(xb + relx[j]), (lds_void*)dst, 16, 0, 0);
+            sp_dma16(xb + relx[j], dst);
           else
             *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
         }
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
           const int cz = crdd[j] & 0xff, cy = (crdd[j] >> 8) & 0xff, cx = (crdd[j] >> 16) & 0xff;
           unsigned char* dst = dbase + (wave + 4 * j) * 1024;
           if (oz0 + cz < a.Do && oy0 + cy < a.Ho && ox0 + cx < a.Wo)
-            __builtin_amdgcn_global_load_lds((gbl_void*)(db + reld[j]), (lds_void*)dst, 16, 0, 0);
+            sp_dma16(db + reld[j], dst);
           else
             *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
         }
@@ -161,9 +162,18 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
     }
   };
 
-  uint32_t tile = blockIdx.x;
+  // tile walk.  XCD-aware when the grid is a multiple of 8: workgroup b runs on XCD b % 8 (round-robin dispatch), so
+  // XCD j takes the j-th contiguous eighth of the tile list and its 64-odd resident workgroups sit on neighbouring
+  // tiles -- their shared halos hit that XCD's L2 instead of being fetched once per XCD.
+  uint32_t tile = blockIdx.x, tend = P.ntiles, tstep = gridDim.x;
+  if (P.xcd) {
+    const uint32_t xcd = blockIdx.x & 7, per = (P.ntiles + 7) >> 3;
+    tile = xcd * per + (blockIdx.x >> 3);
+    tend = min(P.ntiles, (xcd + 1) * per);
+    tstep = gridDim.x >> 3;
+  }
   int cur = 0;
-  if (tile < P.ntiles) issue(tile, 0);
+  if (tile < tend) issue(tile, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -171,12 +181,12 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
 #ifdef SP_CONV_STAMPS
   unsigned long long t0, t1, t2, t3, s_issue = 0, s_comp = 0, s_wait = 0, ntl = 0;
 #endif
-  for (; tile < P.ntiles; tile += gridDim.x) {
-    const uint32_t nxt = tile + gridDim.x;
+  for (; tile < tend; tile += tstep) {
+    const uint32_t nxt = tile + tstep;
 #ifdef SP_CONV_STAMPS
     WSTAMP(t0);
 #endif
-    if (nxt < P.ntiles) issue(nxt, cur ^ 1);
+    if (nxt < tend) issue(nxt, cur ^ 1);
 #ifdef SP_CONV_STAMPS
     WSTAMP(t1);
 #endif
@@ -288,6 +298,7 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   const int lds_bytes = 2 * P.buf_bytes;
   uint32_t gx = (a->parts || a->nblocks < (int64_t)nt) ? a->nblocks : (uint32_t)nt;   // parts: every block is written
   dim3 grid(gx, (a->CoT + COB - 1) / COB, (a->CiT + CIB - 1) / CIB);
+  P.xcd = (gx % 8 == 0 && gx >= 8 && !getenv("SP_WGRAD_NOXCD")) ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define WD_CASE(C_, I_)                                                                              \
   if (COB == C_ && CIB == I_) {                                                                      \

@@ -21,7 +21,7 @@ def bump_param_epoch():
 
 
 WGRAD_PARTS = True      # weight-gradient partial blocks + summing finish instead of fp32 atomics
-USE_PERSIST = False     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
+USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
 
 # optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
@@ -235,7 +235,7 @@ class WgradRunner:
                 cib = min(cib, a.cib)
             yz = -(-self.cot // cob) * -(-self.cit // cib)
             vox = batch * a.Do * a.Ho * a.Wo
-            nb = max(8, min(512 // yz, vox // 768))
+            nb = max(8, min(512 // yz, vox // 768)) // 8 * 8     # multiple of 8: XCD-aware tile walk
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", nb))
             a.parts, self.nparts = 1, a.nblocks
             self.acc = torch.empty(self.nparts * total, dtype=torch.float32, device=self.device)

@@ -80,11 +80,17 @@ def test_unet_train_step_matches_oracle(dtype, size, seed, tol_seg, tol_grad):
                                                           g_ref[name].reshape(1, -1).double()))
         small = p.numel() <= 64 and dtype == "bf16"      # 2..64-element BatchNorm / bias gradients are noisier
         if e > (0.6 if small else tol_grad) or cos < (0.88 if small else 0.95):
-            # The storage-point emulation is not the truth: where the HIP path is MORE exact than it (the first
-            # BatchNorm's gamma/beta come from fp32 weights and the fp32 weight-gradient accumulator, no bf16 data
-            # gradient in between) a small cancellation-heavy gradient may sit closer to the pure-fp32 oracle.
-            if small and rel_l2(p.grad.cpu(), g32[name]) <= 0.6:
-                continue
+            # Noise floor of a small, cancellation-heavy gradient under bf16 storage = how far the storage-point
+            # emulation itself lands from the pure-fp32 oracle.  (The first BatchNorm's gamma is the extreme case: the
+            # following conv -> BatchNorm makes the loss nearly invariant to it, its true gradient is ~0 and the
+            # emulated and fp32 oracles differ by 2.5x / 27x per element at 48^3.)  Within twice that floor of either
+            # reference the HIP value carries as much information as the emulation does.
+            if small:
+                noise = float((g_ref[name].double() - g32[name].double()).norm())
+                d_emul = float((p.grad.cpu().double() - g_ref[name].double()).norm())
+                d_fp32 = float((p.grad.cpu().double() - g32[name].double()).norm())
+                if min(d_emul, d_fp32) <= 2.0 * noise:
+                    continue
             bad.append((name, e, cos, rel_l2(p.grad.cpu(), g32[name]) if dtype == "bf16" else None))
     assert not bad, bad
     # BatchNorm running statistics followed the reference update rule (momentum 0.1, unbiased variance)
