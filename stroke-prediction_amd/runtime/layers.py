@@ -144,11 +144,13 @@ class ConvLayer:
             self.wgrad = O.WgradRunner(cout, cin, k, s, p, self.out_dims, self.in_dims, self.cpo, self.cpi,
                                        cout * kk, kk, dt, dev)
             dop = P.convT_dgrad_op(cin, cout, k, s, p, self.in_dims, self.cpo, self.cpi, dt)
-        # first layer of a network (no input gradient wanted): on the folded DMA path the BatchNorm-backward sums come
-        # out of the weight-gradient accumulator and the whole data-gradient convolution is skipped
-        self.bn_from_wgrad = bool(not self.need_input_grad and self.bn_prefix is not None and self.kind == "conv"
-                                  and self.wgrad.folds(self.scale) and max(P._triple(p)) == 0)
-        if (self.need_input_grad or self.bn_prefix is not None) and not self.bn_from_wgrad:
+        # Folded DMA weight-gradient path: the BatchNorm-backward sums (sum g, sum g*x) come out of the raw-input
+        # weight-gradient accumulator (sum_v g*x = sum W*acc, sum_v g = sum W*dbias for an un-padded convolution), so
+        # the data-gradient convolution needs no statistics epilogue (no second read of x, no atomics) -- and is not
+        # run at all for the first layer of a network, whose input gradient nobody wants.
+        self.bn_from_wgrad = bool(self.bn_prefix is not None and self.kind == "conv" and self.wgrad.folds(self.scale)
+                                  and max(P._triple(p)) == 0 and O.BN_SUMS_FROM_WGRAD)
+        if self.need_input_grad or (self.bn_prefix is not None and not self.bn_from_wgrad):
             self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}))
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
         if self.bn_prefix is not None:
@@ -176,8 +178,11 @@ class ConvLayer:
             self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
                            dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
                            bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP)
+            if self.need_input_grad:
+                self.dgrad.prep(w)
+                self.dgrad.run(self.dz, self.g, self.batch)
             self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
-            return None, None
+            return (self.g, self.coef) if self.need_input_grad else (None, None)
         if self.kind == "conv":
             self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
                            dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
