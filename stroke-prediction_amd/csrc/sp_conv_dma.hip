@@ -46,7 +46,7 @@ extern __device__ unsigned long long sp_stamp_buf[32768][SP_NSTAMP];
 // (no guards inside the unrolled loop: guards make hipcc shuttle the accumulators between VGPRs and AGPRs
 // around every step).  KS == 0: run-time step count (even, the planner pads), fragments prefetched one step ahead.
 template <int NT, int MT, int KS, typename TOUT>
-__global__ __launch_bounds__(256) void conv_igemm_dma_kernel(const ConvDmaDev P) {
+__global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm_dma_kernel(const ConvDmaDev P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

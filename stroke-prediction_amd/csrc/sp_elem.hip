@@ -534,11 +534,11 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
           const int qz = iz - cz, qy = iy - cy, qx = ix - cx;
           if (gs && (unsigned)qz < (unsigned)dc.D && (unsigned)qy < (unsigned)dc.H && (unsigned)qx < (unsigned)dc.W) {
             const int64_t o = ((((int64_t)b * dc.D + qz) * dc.H + qy) * dc.W + qx) * CPcat + cs0 + oc * 8;
-            float g8[8], c8[8];
+            float g8[8];
             Store<T>::ld8(gs + o, g8);
-            Store<T>::ld8(cat + o, c8);
+            // the skip half of the concat buffer is a verbatim crop of y: its value is the y just loaded
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * c8[j] + s2[j];
+            for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * yv[k][j] + s2[j];
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_from_y(act, ap, yv[k][j]); part[0][j] += d[j]; }

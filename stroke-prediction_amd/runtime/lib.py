@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libstroke_amd.so")
+LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip"]
 
