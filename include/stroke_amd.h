@@ -214,6 +214,11 @@ int sp_upsample2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D
 int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B, int32_t Ds, int32_t Hs, int32_t Ws,
                  int32_t CPs, int32_t Dd, int32_t Hd, int32_t Wd, int32_t CPd, int32_t c0, double* stats,
                  sp_stream_t stream);
+/* both of the above in one pass over the concat buffer (full-line writes): cat[..., 0:CPu) = upsample2(low),
+ * cat[..., CPu:CPu+CPs) = centre crop of skip; stats[c][2] over all CPd = CPu + CPs channels (Unet3D.py:67-72) */
+int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
+                              int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs, int32_t Ws,
+                              double* stats, sp_stream_t stream);
 /* gradient of a block output y that feeds (a) MaxPool3d(2,2) -> BN -> ... and (b) the cropped skip:
  * dz = [ poolbwd(coefp0*gp + coefp1*pool(y) + coefp2) + crop-region(coefs0*gs + coefs1*cat + coefs2) ] * act'(y)
  * either source may be NULL */

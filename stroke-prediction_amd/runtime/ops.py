@@ -331,6 +331,15 @@ def upsample2_fwd(x, y, dtype, stats=None):
     L.call("sp_upsample2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, y.shape[-1], ptr(stats), stream())
 
 
+def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None):
+    """cat = concat(upsample2(low), centre_crop(skip)) in one pass (+ per-channel (sum, sum^2) of cat into stats)."""
+    B, D, H, W, CPu = low.shape
+    _, Ds, Hs, Ws, CPs = skip.shape
+    assert tuple(cat.shape) == (B, 2 * D, 2 * H, 2 * W, CPu + CPs), (tuple(cat.shape), tuple(low.shape), tuple(skip.shape))
+    L.call("sp_upsample2_crop_cat_fwd", ptr(low), CPu, ptr(skip), CPs, ptr(cat), CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
+           ptr(stats), stream())
+
+
 def crop_copy(src, dst, c0, dtype, stats=None):
     B, Ds, Hs, Ws, CPs = src.shape
     _, Dd, Hd, Wd, CPd = dst.shape

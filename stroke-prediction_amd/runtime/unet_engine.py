@@ -126,14 +126,12 @@ class UnetEngine:
         y32 = self.c32.forward(y31, params, bufs, training)
         c3 = self.channels[3]
         s4 = st(self.c41)
-        O.upsample2_fwd(y32, self.cat4, dt, s4)
-        O.crop_copy(y22, self.cat4, c3, dt, None if s4 is None else s4[2 * c3:])
+        O.upsample2_crop_cat_fwd(y32, y22, self.cat4, dt, s4)
         y41 = self.c41.forward(self.cat4, params, bufs, training, st(self.c42))
         y42 = self.c42.forward(y41, params, bufs, training)
         c4 = self.channels[4]
         s5 = st(self.c51)
-        O.upsample2_fwd(y42, self.cat5, dt, s5)
-        O.crop_copy(y12, self.cat5, c4, dt, None if s5 is None else s5[2 * c4:])
+        O.upsample2_crop_cat_fwd(y42, y12, self.cat5, dt, s5)
         y51 = self.c51.forward(self.cat5, params, bufs, training, st(self.c52))
         y52 = self.c52.forward(y51, params, bufs, training)
         seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)

@@ -258,6 +258,14 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     O.upsample2_fwd(lows, cat, dtype)
     O.crop_copy(ys, cat, C0, dtype)
     torch.testing.assert_close(from_cl(cat, C0 + C1, dtype), cat_ref.detach(), **TOL[dtype])
+    # the one-pass variant writes the same buffer bit for bit and accumulates the statistics of all its channels
+    cat2 = torch.full_like(cat, 3.0)
+    st2 = torch.zeros(C0 + C1, 2, dtype=torch.float64, device=DEV)
+    O.upsample2_crop_cat_fwd(lows, ys, cat2, dtype, st2)
+    assert torch.equal(cat2, cat)
+    cf = cat.double()
+    torch.testing.assert_close(st2[:, 0].cpu(), cf.sum(dim=(0, 1, 2, 3)).cpu(), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st2[:, 1].cpu(), (cf * cf).sum(dim=(0, 1, 2, 3)).cpu(), rtol=1e-5, atol=1e-3)
     # backward: arbitrary affine "BN backward" forms on both consumers
     cp_cat = C0 + C1
     coefs = torch.randn(3, cp_cat, generator=g) * 0.5
