@@ -126,7 +126,7 @@ __device__ __forceinline__ float act_bwd_from_y(int act, float p, float y) {
 // ---- exact unsigned division by a runtime constant (host computes mul/shift) --------------------
 struct FastDiv { uint32_t mul, shift; };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }
-static inline FastDiv make_fastdiv(uint32_t d) {
+__host__ __device__ static inline FastDiv make_fastdiv(uint32_t d) {
   FastDiv r; uint32_t s = 0;
   while ((1ull << s) < d) ++s;
   r.shift = s;

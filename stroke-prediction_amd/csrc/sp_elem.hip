@@ -303,11 +303,21 @@ extern "C" int sp_bn_act_bwd(const void* g, const void* y, const float* coef, in
 
 // ------------------------------------------------------------------------------------------------ pool / upsample / crop fwd
 struct Dims { int B, D, H, W; };
-__device__ __forceinline__ void unflatten(int64_t v, int D, int H, int W, int& b, int& z, int& y, int& x) {
-  x = (int)(v % W); v /= W;
-  y = (int)(v % H); v /= H;
-  z = (int)(v % D); b = (int)(v / D);
-}
+// flat voxel index -> (b, z, y, x).  Three 64-bit divisions per call cost more ALU than the rest of an elementwise
+// kernel's iteration: the magic numbers are built once per thread, a call is then three mul-hi/shift pairs.  Entry
+// points reject tensors of 2^31 voxels or more (SP_CHECK_VOX).
+struct Unflat {
+  int D, H, W;
+  FastDiv fD, fH, fW;
+  __device__ __forceinline__ Unflat(int D_, int H_, int W_) : D(D_), H(H_), W(W_), fD(make_fastdiv(D_)), fH(make_fastdiv(H_)), fW(make_fastdiv(W_)) {}
+  __device__ __forceinline__ void operator()(int64_t v64, int& b, int& z, int& y, int& x) const {
+    uint32_t v = (uint32_t)v64;
+    uint32_t q = fdiv(v, fW); x = (int)(v - q * W); v = q;
+    q = fdiv(v, fH); y = (int)(v - q * H); v = q;
+    q = fdiv(v, fD); z = (int)(v - q * D); b = (int)q;
+  }
+};
+#define SP_CHECK_VOX(n, what) SP_CHECK_ARG((int64_t)(n) < (1ll << 31), what ": 2^31 voxels or more")
 
 // MaxPool3d(2,2), floor mode (Unet3D.py:39,41)
 template <typename T>
@@ -321,13 +331,14 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
   float part[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  const Unflat uf_(Do, Ho, Wo);
   if (active) {
     // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
     const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
-      unflatten(v, Do, Ho, Wo, b, z, yy, xx);
+      uf_(v, b, z, yy, xx);
       float m[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
@@ -349,6 +360,7 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
 extern "C" int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
                                int32_t CP, double* stats, sp_stream_t stream) {
   SP_CHECK_ARG(x && y && CP % 8 == 0 && D >= 2 && H >= 2 && W >= 2, "sp_maxpool2_fwd: bad arguments");
+  SP_CHECK_VOX((int64_t)B * D * H * W, "sp_maxpool2_fwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
   const int64_t nout = (int64_t)B * (D / 2) * (H / 2) * (W / 2);
@@ -380,13 +392,14 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict_
   float part[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  const Unflat uf_(Do, Ho, Wo);
   if (active) {
     // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
     const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
-      unflatten(v, Do, Ho, Wo, b, z, yy, xx);
+      uf_(v, b, z, yy, xx);
       int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
       up_src(z, di.D, z0, z1, lz); up_src(yy, di.H, y0, y1, ly); up_src(xx, di.W, x0, x1, lx);
       float o[8];
@@ -415,6 +428,7 @@ __global__ __launch_bounds__(256) void upsample2_fwd_kernel(const T* __restrict_
 extern "C" int sp_upsample2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
                                 int32_t CP, int32_t CPd, double* stats, sp_stream_t stream) {
   SP_CHECK_ARG(x && y && CP % 8 == 0 && CPd >= CP && CPd % 8 == 0, "sp_upsample2_fwd: bad arguments");
+  SP_CHECK_VOX((int64_t)B * D * H * W * 8, "sp_upsample2_fwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
   const int64_t nout = (int64_t)B * D * H * W * 8;
@@ -438,13 +452,14 @@ __global__ __launch_bounds__(256) void crop_copy_kernel(const T* __restrict__ sr
   float part[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  const Unflat uf_(dd.D, dd.H, dd.W);
   if (active) {
     // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
     const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
-      unflatten(v, dd.D, dd.H, dd.W, b, z, yy, xx);
+      uf_(v, b, z, yy, xx);
       float a[8];
       Store<T>::ld8(src + ((((int64_t)b * ds.D + z + oz) * ds.H + yy + oy) * ds.W + xx + ox) * CPs + oc * 8, a);
       Store<T>::st8(dst + v * CPd + c0 + oc * 8, a);
@@ -458,6 +473,7 @@ extern "C" int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B
                             int32_t CPs, int32_t Dd, int32_t Hd, int32_t Wd, int32_t CPd, int32_t c0, double* stats,
                             sp_stream_t stream) {
   SP_CHECK_ARG(src && dst && CPs % 8 == 0 && CPd % 8 == 0 && c0 % 8 == 0 && c0 + CPs <= CPd, "sp_crop_copy: bad channels");
+  SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_crop_copy");
   SP_CHECK_ARG(Dd <= Ds && Hd <= Hs && Wd <= Ws, "sp_crop_copy: crop larger than source");
   OctMap om = make_octmap(CPs);
   Dims ds{B, Ds, Hs, Ws}, dd{B, Dd, Hd, Wd};
@@ -487,12 +503,13 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
   float part[2][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  const Unflat uf_(Do, Ho, Wo);
   if (active) {
     const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
-      unflatten(v, Do, Ho, Wo, b, z, yy, xx);
+      uf_(v, b, z, yy, xx);
       float o[8];
       if (oc < ocu) {
         int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
@@ -526,6 +543,7 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
                                          int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
                                          int32_t Ws, double* stats, sp_stream_t stream) {
   SP_CHECK_ARG(low && skip && cat && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
+  SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_upsample2_crop_cat_fwd");
   SP_CHECK_ARG(2 * D <= Ds && 2 * H <= Hs && 2 * W <= Ws, "sp_upsample2_crop_cat_fwd: skip smaller than the upsampled grid");
   SP_CHECK_ARG(CPd <= 2048, "sp_upsample2_crop_cat_fwd: too many channels");
   OctMap om = make_octmap(CPd);
@@ -564,13 +582,14 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
     p0[j] = (gp && active) ? coefp[c] : 0.f; p1[j] = (gp && active) ? coefp[CP + c] : 0.f; p2[j] = (gp && active) ? coefp[2 * CP + c] : 0.f;
     s0[j] = (gs && active) ? coefs[cs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[CPcat + cs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * CPcat + cs0 + c] : 0.f;
   }
+  const Unflat uf_(Dw, Hw, Ww);
   if (active) {
     // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
     const int64_t chunk_ = ((nwin + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nwin, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, wz, wy, wx;
-      unflatten(v, Dw, Hw, Ww, b, wz, wy, wx);
+      uf_(v, b, wz, wy, wx);
       const bool pooled = gp && wz < Dp && wy < Hp && wx < Wp;
       float yv[8][8];
       float m[8]; int am[8];
@@ -624,6 +643,7 @@ extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* 
                                     int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
   SP_CHECK_ARG(y && dz && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
+  SP_CHECK_VOX((int64_t)B * D * H * W, "sp_pool_skip_act_bwd");
   SP_CHECK_ARG(!gp || coefp, "sp_pool_skip_act_bwd: pool gradient without coefficients");
   SP_CHECK_ARG(!gs || (cat && coefs && cs0 % 8 == 0 && cs0 + CP <= CPcat && Dc <= D && Hc <= H && Wc <= W), "sp_pool_skip_act_bwd: bad skip arguments");
   OctMap om = make_octmap(CP);
@@ -662,13 +682,14 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_kernel(const T* __restr
     const int c = oc * 8 + j;
     c0[j] = active ? coef[c] : 0.f; c1[j] = active ? coef[CPcat + c] : 0.f; c2[j] = active ? coef[2 * CPcat + c] : 0.f;
   }
+  const Unflat uf_(di.D, di.H, di.W);
   if (active) {
     // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
     const int64_t chunk_ = ((nin + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nin, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
-      unflatten(v, di.D, di.H, di.W, b, z, yy, xx);
+      uf_(v, b, z, yy, xx);
       int oz[4], oy[4], ox[4]; float wz[4], wy[4], wx[4];
       upT_axis(z, di.D, oz, wz); upT_axis(yy, di.H, oy, wy); upT_axis(xx, di.W, ox, wx);
       float d[8];
@@ -873,6 +894,7 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
                                     int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
   SP_CHECK_ARG(y && cat && g && coef && dz && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
+  SP_CHECK_VOX((int64_t)B * D * H * W * 8, "sp_upsample2_act_bwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
   if (256 % om.OC == 0 && D >= 2 && H >= 2 && W >= 2 && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
