@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
   const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
   const int oz = (ds.D - Do) / 2, oy = (ds.H - Ho) / 2, ox = (ds.W - Wo) / 2;
   const int ocu = CPu / 8;
+  const bool isup = oc < ocu;
   const int64_t nout = (int64_t)dl.B * Do * Ho * Wo;
   float part[2][8];
 #pragma unroll
@@ -510,23 +511,27 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
       uf_(v, b, z, yy, xx);
+      // one code path for both halves (a lane-divergent branch around the loads would serialise them): skip lanes
+      // read their single source voxel with weight 1 and repeat it with weight 0
+      int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
+      up_src(z, dl.D, z0, z1, lz); up_src(yy, dl.H, y0, y1, ly); up_src(xx, dl.W, x0, x1, lx);
+      const int64_t so = ((((int64_t)b * ds.D + z + oz) * ds.H + yy + oy) * ds.W + xx + ox) * CPs + (oc - ocu) * 8;
+      float a[8][8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = (k & 4) ? z1 : z0, iy = (k & 2) ? y1 : y0, ix = (k & 1) ? x1 : x0;
+        const int64_t uo = ((((int64_t)b * dl.D + iz) * dl.H + iy) * dl.W + ix) * CPu + oc * 8;
+        Store<T>::ld8(isup ? low + uo : skip + so, a[k]);
+      }
       float o[8];
-      if (oc < ocu) {
-        int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
-        up_src(z, dl.D, z0, z1, lz); up_src(yy, dl.H, y0, y1, ly); up_src(xx, dl.W, x0, x1, lx);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = 0.f;
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int iz = (k & 4) ? z1 : z0, iy = (k & 2) ? y1 : y0, ix = (k & 1) ? x1 : x0;
-          const float w = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
-          float a[8];
-          Store<T>::ld8(low + ((((int64_t)b * dl.D + iz) * dl.H + iy) * dl.W + ix) * CPu + oc * 8, a);
+      for (int k = 0; k < 8; ++k) {
+        const float wu = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
+        const float w = isup ? wu : (k == 0 ? 1.f : 0.f);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = fmaf(w, a[j], o[j]);
-        }
-      } else {
-        Store<T>::ld8(skip + ((((int64_t)b * ds.D + z + oz) * ds.H + yy + oy) * ds.W + xx + ox) * CPs + (oc - ocu) * 8, o);
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(w, a[k][j], o[j]);
       }
       Store<T>::st8(cat + v * CPd + oc * 8, o);
       if (sizeof(T) == 2) {
@@ -561,25 +566,47 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
 // Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
 // One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
 // (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
+// eight elements kept as loaded (bf16: 4 VGPRs instead of 8) and unpacked where used
+template <typename T> struct RawOct;
+template <> struct RawOct<bf16_t> {
+  uint4 r;
+  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void get(float* v) const {
+    const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+  }
+};
+template <> struct RawOct<float> {
+  float f[8];
+  __device__ __forceinline__ void load(const float* p) { Store<float>::ld8(p, f); }
+  __device__ __forceinline__ void get(float* v) const {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = f[i];
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
     const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, Dims di, int CP, Dims dc,
     OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias) {
   extern __shared__ float red[];
+  float* cpl = red + CP;                              // pool-side coefficients [3][CP]: used once per window -> LDS, not VGPRs
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
   const int Dw = (di.D + 1) / 2, Hw = (di.H + 1) / 2, Ww = (di.W + 1) / 2;      // windows incl. ragged edge
   const int Dp = di.D / 2, Hp = di.H / 2, Wp = di.W / 2;                        // pooled dims (floor)
   const int cz = (di.D - dc.D) / 2, cy = (di.H - dc.H) / 2, cx = (di.W - dc.W) / 2;
   const int64_t nwin = (int64_t)di.B * Dw * Hw * Ww;
+  for (int i = threadIdx.x; i < 3 * CP; i += 256) cpl[i] = gp ? coefp[i] : 0.f;
+  __syncthreads();
   float part[1][8];
-  float p0[8], p1[8], p2[8], s0[8], s1[8], s2[8];
+  float s0[8], s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     part[0][j] = 0.f;
     const int c = oc * 8 + j;
-    p0[j] = (gp && active) ? coefp[c] : 0.f; p1[j] = (gp && active) ? coefp[CP + c] : 0.f; p2[j] = (gp && active) ? coefp[2 * CP + c] : 0.f;
     s0[j] = (gs && active) ? coefs[cs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[CPcat + cs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * CPcat + cs0 + c] : 0.f;
   }
   const Unflat uf_(Dw, Hw, Ww);
@@ -591,17 +618,24 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
       int b, wz, wy, wx;
       uf_(v, b, wz, wy, wx);
       const bool pooled = gp && wz < Dp && wy < Hp && wx < Wp;
-      float yv[8][8];
+      RawOct<T> yr[8];
       float m[8]; int am[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = 0; }
+      // the eight loads first (clamped coordinates: a branch around a load serialises it), then the scan
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int iz = min(2 * wz + (k >> 2), di.D - 1), iy = min(2 * wy + ((k >> 1) & 1), di.H - 1), ix = min(2 * wx + (k & 1), di.W - 1);
+        yr[k].load(y + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8);
+      }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int iz = 2 * wz + (k >> 2), iy = 2 * wy + ((k >> 1) & 1), ix = 2 * wx + (k & 1);
         if (iz < di.D && iy < di.H && ix < di.W) {
-          Store<T>::ld8(y + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, yv[k]);
+          float yv[8];
+          yr[k].get(yv);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) if (yv[k][j] > m[j]) { m[j] = yv[k][j]; am[j] = k; }
+          for (int j = 0; j < 8; ++j) if (yv[j] > m[j]) { m[j] = yv[j]; am[j] = k; }
         }
       }
       float dp[8];
@@ -611,13 +645,17 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
         float g8[8];
         Store<T>::ld8(gp + ((((int64_t)b * Dp + wz) * Hp + wy) * Wp + wx) * CP + oc * 8, g8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dp[j] = p0[j] * g8[j] + p1[j] * m[j] + p2[j];
+        for (int j = 0; j < 8; ++j) {
+          const int c = oc * 8 + j;
+          dp[j] = cpl[c] * g8[j] + cpl[CP + c] * m[j] + cpl[2 * CP + c];
+        }
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int iz = 2 * wz + (k >> 2), iy = 2 * wy + ((k >> 1) & 1), ix = 2 * wx + (k & 1);
         if (iz < di.D && iy < di.H && ix < di.W) {
-          float d[8];
+          float d[8], yv[8];
+          yr[k].get(yv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) d[j] = (pooled && am[j] == k) ? dp[j] : 0.f;
           const int qz = iz - cz, qy = iy - cy, qx = ix - cx;
@@ -627,10 +665,10 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
             Store<T>::ld8(gs + o, g8);
             // the skip half of the concat buffer is a verbatim crop of y: its value is the y just loaded
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * yv[k][j] + s2[j];
+            for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * yv[j] + s2[j];
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_from_y(act, ap, yv[k][j]); part[0][j] += d[j]; }
+          for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_from_y(act, ap, yv[j]); part[0][j] += d[j]; }
           Store<T>::st8(dz + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, d);
         }
       }
@@ -650,7 +688,7 @@ extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* 
   Dims di{B, D, H, W}, dc{B, Dc, Hc, Wc};
   const int64_t nwin = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   const unsigned grid = grid_for(nwin, om.vpb);
-  const size_t sh = (size_t)CP * sizeof(float);
+  const size_t sh = (size_t)CP * 4 * sizeof(float);
   if (dtype == SP_BF16) hipLaunchKernelGGL(pool_skip_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);
   else hipLaunchKernelGGL(pool_skip_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, di, CP, dc, om, act, act_param, (float*)dz, dbias_sums);
   SP_CHECK_LAUNCH("sp_pool_skip_act_bwd");
@@ -785,52 +823,57 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
 
   const int nreg = RY * RX, nyp = (TY + 2) * (TX + 2), vstep = 256 / OC;
   for (int m = z0 - 2; m < z1; ++m) {
-    // ---------------- stage: cat-gradient planes 2m+1, 2m+2 (clamped coordinates carry zero weight) and y plane m+1
-    if (m >= z0 - 1) {
-      const int oza = min(max(2 * m + 1, 0), Do - 1), ozb = min(max(2 * m + 2, 0), Do - 1);
-      for (int vi = pos; vi < nreg; vi += vstep) {
-        const int vy = fdiv(vi, ut.d_rx), vx = vi - vy * RX;
-        const int gy = min(max(2 * y0 - 1 + vy, 0), Ho - 1), gx = min(max(2 * x0 - 1 + vx, 0), Wo - 1);
-        const size_t o_a = ((((size_t)b * Do + oza) * Ho + gy) * Wo + gx) * CPcat + oc * 8;
-        const size_t o_b = ((((size_t)b * Do + ozb) * Ho + gy) * Wo + gx) * CPcat + oc * 8;
-        const int lo = vi * CP + oc * 8;
-        if constexpr (sizeof(T) == 2) {
-          const uint4 va = *reinterpret_cast<const uint4*>(g + o_a), vb = *reinterpret_cast<const uint4*>(g + o_b);
-          *reinterpret_cast<uint4*>(gb0 + lo) = va; *reinterpret_cast<uint4*>(gb1 + lo) = vb;
-        } else {
-          const uint4 va0 = *reinterpret_cast<const uint4*>(g + o_a), va1 = *reinterpret_cast<const uint4*>(g + o_a + 4);
-          const uint4 vb0 = *reinterpret_cast<const uint4*>(g + o_b), vb1 = *reinterpret_cast<const uint4*>(g + o_b + 4);
-          *reinterpret_cast<uint4*>(gb0 + lo) = va0; *reinterpret_cast<uint4*>(gb0 + lo + 4) = va1;
-          *reinterpret_cast<uint4*>(gb1 + lo) = vb0; *reinterpret_cast<uint4*>(gb1 + lo + 4) = vb1;
-        }
-      }
-    }
     const bool yplane = m + 1 >= 0 && m + 1 < D;
-    if (yplane) {
-      for (int vi = pos; vi < nyp; vi += vstep) {
-        const int vy = fdiv(vi, ut.d_yx), vx = vi - vy * (TX + 2);
-        const int sy = min(max(y0 - 1 + vy, 0), H - 1), sx = min(max(x0 - 1 + vx, 0), W - 1);
-        const size_t o = ((((size_t)b * D + (m + 1)) * H + sy) * W + sx) * CP + oc * 8;
-        const int lo = vi * CP + oc * 8;
-        if constexpr (sizeof(T) == 2) {
-          *reinterpret_cast<uint4*>(yb + lo) = *reinterpret_cast<const uint4*>(y + o);
-        } else {
-          *reinterpret_cast<uint4*>(yb + lo) = *reinterpret_cast<const uint4*>(y + o);
-          *reinterpret_cast<uint4*>(yb + lo + 4) = *reinterpret_cast<const uint4*>(y + o + 4);
+    {
+      // ---------------- stage: cat-gradient planes 2m+1, 2m+2 (clamped coordinates carry zero weight) and y plane m+1
+      if (m >= z0 - 1) {
+        const int oza = min(max(2 * m + 1, 0), Do - 1), ozb = min(max(2 * m + 2, 0), Do - 1);
+        for (int vi = pos; vi < nreg; vi += vstep) {
+          const int vy = fdiv(vi, ut.d_rx), vx = vi - vy * RX;
+          const int gy = min(max(2 * y0 - 1 + vy, 0), Ho - 1), gx = min(max(2 * x0 - 1 + vx, 0), Wo - 1);
+          const size_t o_a = ((((size_t)b * Do + oza) * Ho + gy) * Wo + gx) * CPcat + oc * 8;
+          const size_t o_b = ((((size_t)b * Do + ozb) * Ho + gy) * Wo + gx) * CPcat + oc * 8;
+          const int lo = vi * CP + oc * 8;
+          if constexpr (sizeof(T) == 2) {
+            const uint4 va = *reinterpret_cast<const uint4*>(g + o_a), vb = *reinterpret_cast<const uint4*>(g + o_b);
+            *reinterpret_cast<uint4*>(gb0 + lo) = va; *reinterpret_cast<uint4*>(gb1 + lo) = vb;
+          } else {
+            const uint4 va0 = *reinterpret_cast<const uint4*>(g + o_a), va1 = *reinterpret_cast<const uint4*>(g + o_a + 4);
+            const uint4 vb0 = *reinterpret_cast<const uint4*>(g + o_b), vb1 = *reinterpret_cast<const uint4*>(g + o_b + 4);
+            *reinterpret_cast<uint4*>(gb0 + lo) = va0; *reinterpret_cast<uint4*>(gb0 + lo + 4) = va1;
+            *reinterpret_cast<uint4*>(gb1 + lo) = vb0; *reinterpret_cast<uint4*>(gb1 + lo + 4) = vb1;
+          }
         }
       }
+      if (yplane) {
+        for (int vi = pos; vi < nyp; vi += vstep) {
+          const int vy = fdiv(vi, ut.d_yx), vx = vi - vy * (TX + 2);
+          const int sy = min(max(y0 - 1 + vy, 0), H - 1), sx = min(max(x0 - 1 + vx, 0), W - 1);
+          const size_t o = ((((size_t)b * D + (m + 1)) * H + sy) * W + sx) * CP + oc * 8;
+          const int lo = vi * CP + oc * 8;
+          if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(yb + lo) = *reinterpret_cast<const uint4*>(y + o);
+          } else {
+            *reinterpret_cast<uint4*>(yb + lo) = *reinterpret_cast<const uint4*>(y + o);
+            *reinterpret_cast<uint4*>(yb + lo + 4) = *reinterpret_cast<const uint4*>(y + o + 4);
+          }
+        }
+      }
+      __syncthreads();
     }
-    __syncthreads();
     // ---------------- in-plane 4x4 reductions
     if (m >= z0 - 1) {
       float P1[8], P2[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) P1[j] = P2[j] = 0.f;
-#pragma unroll
-      for (int bb = 0; bb < 4; ++bb)
+      // rows rolled on purpose (weight picked by selects): fully unrolled, hipcc hoists all 32 LDS reads and the kernel
+      // needs 294 VGPRs -- one workgroup per CU, every plane pair then waits out its own HBM latency
+#pragma unroll 1
+      for (int bb = 0; bb < 4; ++bb) {
+        const float wyb = bb == 0 ? wy[0] : (bb == 1 ? wy[1] : (bb == 2 ? wy[2] : wy[3]));
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
-          const float w = wy[bb] * wx[cc];
+          const float w = wyb * wx[cc];
           const int lo = ((2 * ty + bb) * RX + 2 * tx + cc) * CP + oc * 8;
           float a8[8], b8[8];
           Store<T>::ld8(gb0 + lo, a8);
@@ -838,6 +881,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
 #pragma unroll
           for (int j = 0; j < 8; ++j) { P1[j] = fmaf(w, a8[j], P1[j]); P2[j] = fmaf(w, b8[j], P2[j]); }
         }
+      }
       int oz[4]; float wz[4], wn[4];
       upT_axis(max(m, 0), D, oz, wz);
       upT_axis(min(m + 1, D - 1), D, oz, wn);
@@ -850,11 +894,12 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
 #pragma unroll
     for (int j = 0; j < 8; ++j) qnext[j] = ynext[j] = 0.f;
     if (yplane) {
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll 1
+      for (int dy = 0; dy < 3; ++dy) {
+        const float myd = dy == 0 ? my[0] : (dy == 1 ? my[1] : my[2]);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-          const float w = my[dy] * mx[dx];
+          const float w = myd * mx[dx];
           float v8[8];
           Store<T>::ld8(yb + ((ty + dy) * (TX + 2) + tx + dx) * CP + oc * 8, v8);
 #pragma unroll
@@ -864,6 +909,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
             for (int j = 0; j < 8; ++j) ynext[j] = v8[j];
           }
         }
+      }
     }
     // ---------------- input plane m is complete
     if (m >= z0) {
