@@ -21,7 +21,7 @@ def bump_param_epoch():
 
 
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
-WGRAD_PARTS = True      # weight-gradient partial blocks + summing finish instead of fp32 atomics
+WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
 
