@@ -92,7 +92,8 @@ def capture_step(step, enabled):
             step()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: the RCCL watchdog thread may query events while this thread captures
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             gloss = step()
         graph.replay()
         torch.cuda.synchronize()
@@ -116,7 +117,10 @@ def bench_cae(args, world, rank, dev):
     d, hw = args.cae_depth, 128
     torch.manual_seed(1234)
     cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype=args.dtype), Dec3D(hw, d, ch, 5, 1.0, dtype=args.dtype)).to(dev).train()
-    use_graph = (world == 1) and not args.no_graph
+    # N = 1: the step is replayed as one hipGraph.  N > 1: eager launches by default -- measured equal on this path
+    # (the GPU, not the launching thread, is the bottleneck: 5.11 ms either way) and an RCCL collective inside a
+    # capture is the one thing that cannot be rehearsed on a 1-GPU box; SP_DIST_GRAPH=1 captures it too.
+    use_graph = not args.no_graph and (world == 1 or bool(os.environ.get("SP_DIST_GRAPH")))
     opt = FusedAdam([p for p in cae.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999),
                     grad_scale=1.0 / world, capturable=use_graph)
     attach_flat_grads(cae)
@@ -195,8 +199,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or os.environ.get("SP_FORCE_SYNC"):      # SP_FORCE_SYNC: 1-rank RCCL group, rehearses capture on one GPU
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     import stroke_prediction_amd  # noqa: F401  (puts the drop-in packages on sys.path)
@@ -215,7 +221,10 @@ def main():
     torch.manual_seed(1234)                      # identical random-init weights on every rank
     model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).train()
     sync = DataParallelSync(model, mode=args.dp_mode)
-    use_graph = (world == 1) and not args.no_graph
+    # N = 1: the step is replayed as one hipGraph.  N > 1: eager launches by default -- measured equal on this path
+    # (the GPU, not the launching thread, is the bottleneck: 5.11 ms either way) and an RCCL collective inside a
+    # capture is the one thing that cannot be rehearsed on a 1-GPU box; SP_DIST_GRAPH=1 captures it too.
+    use_graph = not args.no_graph and (world == 1 or bool(os.environ.get("SP_DIST_GRAPH")))
     opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5,
                     betas=(0.99, 0.999), grad_scale=sync.grad_scale, capturable=use_graph)   # train_unet_segmentation.py:13-14,32
     attach_flat_grads(model)

@@ -12,6 +12,8 @@ and the three Dice sums per output; local gradients are then partial sums of the
 all-reduce SUMS and the optimiser must NOT divide (``grad_scale`` = 1); BatchNorm gamma/beta gradients, which
 every rank already holds in full, are pre-scaled by 1/world.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -23,7 +25,8 @@ class DataParallelSync:
         self.group = process_group
         self.mode = mode
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        if self.world > 1:
+        # SP_FORCE_SYNC: install the exchange even on a 1-rank group (rehearses RCCL + hipGraph capture on one GPU)
+        if self.world > 1 or (dist.is_initialized() and os.environ.get("SP_FORCE_SYNC")):
             model.grad_sync = self._sync
             self.broadcast_parameters()
             if mode == "exact":
@@ -43,7 +46,7 @@ class DataParallelSync:
 
     def sync(self):
         """for models whose autograd node does not call ``grad_sync`` itself (the CAE: 7 nodes per step)"""
-        if self.world > 1:
+        if self.model.grad_sync is not None:
             self._sync(self.model.flat_buffers()[1])
 
     def broadcast_parameters(self, src=0):
