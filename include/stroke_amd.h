@@ -263,6 +263,11 @@ int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int
 int sp_head_grad_finish(const float* partials, int64_t rows, int32_t C, int32_t CH, int32_t NC, float* gW1, float* gb1,
                         float* gW2, float* gb2, double* dbias_sums, sp_stream_t stream);
 
+/* ------------------------------------------------------------------ batch metrics (metrics.py:31-62)
+ * counts[4] (zeroed by the caller) += tp, fp, fn, tn of (result > threshold) vs (target > threshold), n fp32 elements */
+int sp_confusion_counts(const float* result, const float* target, float threshold, int64_t n,
+                        unsigned long long* counts, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int sp_add_f64_to_f32(const double* src, float* dst, int64_t n, float scale, sp_stream_t stream); /* dst += scale*src */
 int sp_axpby(const void* x, const void* y, void* out, int32_t dtype, int64_t n, float a, float b, sp_stream_t stream);

@@ -1083,6 +1083,38 @@ extern "C" int sp_dice_bwd(const float* o, const float* t, const float* ca, cons
 }
 
 // ------------------------------------------------------------------------------------------------ utilities
+// tp / fp / fn / tn of (result > thr) against (target > thr) -- the counts behind Dice / precision / sensitivity /
+// specificity of the reference's batch metrics (metrics.py:31-62), without copying the volumes to the host
+__global__ __launch_bounds__(256) void confusion_kernel(const float* __restrict__ r, const float* __restrict__ t, float thr,
+                                                         int64_t n, unsigned long long* __restrict__ counts) {
+  unsigned int c[4] = {0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const bool a = r[i] > thr, b = t[i] > thr;
+    c[0] += a && b; c[1] += a && !b; c[2] += !a && b; c[3] += !a && !b;
+  }
+  __shared__ unsigned int red[4];
+  if (threadIdx.x < 4) red[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unsigned int v = c[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], v);
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(&counts[threadIdx.x], (unsigned long long)red[threadIdx.x]);
+}
+extern "C" int sp_confusion_counts(const float* result, const float* target, float threshold, int64_t n,
+                                   unsigned long long* counts, sp_stream_t stream) {
+  SP_CHECK_ARG(result && target && counts && n >= 0, "sp_confusion_counts: bad arguments");
+  if (n == 0) return SP_OK;
+  const unsigned grid = (unsigned)((n + 256 * 16 - 1) / (256 * 16) > 1024 ? 1024 : (n + 256 * 16 - 1) / (256 * 16));
+  hipLaunchKernelGGL(confusion_kernel, dim3(grid), dim3(256), 0, ST(stream), result, target, threshold, n, counts);
+  SP_CHECK_LAUNCH("sp_confusion_counts");
+  return SP_OK;
+}
+
 __global__ void add_f64_to_f32_kernel(const double* __restrict__ src, float* __restrict__ dst, int64_t n, float scale) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] += scale * (float)src[i];

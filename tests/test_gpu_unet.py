@@ -150,3 +150,57 @@ def test_rejects_cpu_and_too_small_inputs():
     model = model.to(DEV)
     with pytest.raises(ValueError):          # BASELINE config #1 as written (32^3) cannot pass valid convs
         model(UnetDtoUtil.init_dto(torch.zeros(2, 2, 32, 32, 32, device=DEV)))
+
+
+def test_checkpoint_round_trip_and_tester(tmp_path):
+    """N3 / N1 of SURVEY 8f: the whole module pickles like the reference's (``torch.save(model)`` in
+    ``Learner.save_model`` ``Learner.py:93,113``), reloads under the reference's import path and gives the same
+    outputs; ``Tester`` (``tester/Tester.py:16-28``) drives it forward-only, one case at a time, on a non-cubic volume."""
+    from stroke_prediction_amd.tester.Tester import Tester
+    seed = 13
+    model = build(seed, "f32")
+    x, y = W.unet_inputs(2, (44, 48, 52), seed)
+    model.train()
+    dto = model(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))   # engines + BatchNorm buffers now live
+    nets.unet_loss(torch.cat((dto.outputs.core, dto.outputs.penu), 1), y.to(DEV)).backward()
+    path = str(tmp_path / "ckpt_unet.model")
+    torch.save(model.cpu(), path)                                 # Learner.save_model moves to the CPU first
+    model.to(DEV)
+    loaded = torch.load(path, weights_only=False)
+    assert type(loaded).__module__.endswith("common.model.Unet3D") and type(loaded).__name__ == "Unet3D"
+    for (n1, a), (n2, b) in zip(sorted(model.state_dict().items()), sorted(loaded.state_dict().items())):
+        assert n1 == n2 and torch.equal(a.cpu(), b.cpu()), n1
+
+    class Loader(list):
+        batch_size = 1
+
+    class UnetTester(Tester):
+        def inference_step(self, batch):
+            from stroke_prediction_amd.common.inference.UnetInference import UnetInference
+            return UnetInference.inference_step(self, batch)
+
+    batches = Loader({"images": x[i:i + 1], "labels": y[i:i + 1], "case_id": [i]} for i in range(2))
+    tester = UnetTester(batches, path)
+    tester._model.to(DEV)                                          # the reference's scripts move the loaded model to the GPU
+    assert not any(p.requires_grad for p in tester._model.parameters()) and not tester._model.training
+    model.eval()
+    for i, batch in enumerate(batches):
+        _, out = tester.infer_batch(batch)
+        with torch.no_grad():
+            ref = model(UnetDtoUtil.init_dto(x[i:i + 1].to(DEV)))
+        torch.testing.assert_close(out.outputs.core, ref.outputs.core, rtol=0, atol=1e-6)
+        torch.testing.assert_close(out.outputs.penu, ref.outputs.penu, rtol=0, atol=1e-6)
+
+
+def test_metrics_on_device_match_numpy():
+    """N2: confusion counts from the HIP reduction equal the numpy restatement of medpy's measures."""
+    from stroke_prediction_amd.common import metrics as M
+    g = torch.Generator().manual_seed(5)
+    res = torch.rand(2, 1, 20, 24, 28, generator=g)
+    tgt = (torch.rand(2, 1, 20, 24, 28, generator=g) > 0.6).float()
+    ref = M.binary_measures_numpy(res.numpy(), tgt.numpy(), distances=True)
+    got = M.binary_measures_torch(res.to(DEV), tgt.to(DEV), True, distances=True)
+    fast = M.binary_measures_torch(res.to(DEV), tgt.to(DEV), True, distances=False)
+    for k in ("dc", "precision", "sensitivity", "specificity", "hd", "assd"):
+        assert abs(getattr(ref, k) - getattr(got, k)) < 1e-12, k
+    assert fast.dc == ref.dc and fast.hd == np.inf
