@@ -175,13 +175,18 @@ class ConvLayer:
         # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
         if self.bn_from_wgrad:
             bs = self.scratch.get(self.bsums_id)
-            self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
-                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
-                           bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP)
+            finish = self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
+                                    dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
+                                    bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True)
+            # finish + BatchNorm-backward finalize on the side stream, beside the data-gradient convolution
+            f = O.fork()
+            with f:
+                finish()
+                self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
             if self.need_input_grad:
                 self.dgrad.prep(w)
                 self.dgrad.run(self.dz, self.g, self.batch)
-            self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
+            f.join()
             return (self.g, self.coef) if self.need_input_grad else (None, None)
         if self.kind == "conv":
             self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,

@@ -56,6 +56,43 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- a second stream for the bookkeeping kernels of the backward pass (weight re-packs, weight-gradient finish,
+# BatchNorm-backward finalize: ~5-10 us each, ~0.25 ms per step when serialised between the big kernels).  fork():
+# the side stream waits for everything enqueued so far; join(): the main stream waits for the side work.  Under
+# hipGraph capture the two become parallel branches of the graph.  MEASURED SLOWER (5.20 vs 5.12 ms per step: the
+# small kernels take workgroup slots from the convolution they run beside), so it is opt-in: SP_OVERLAP=1.
+OVERLAP = bool(os.environ.get("SP_OVERLAP"))
+_SIDE = {}
+
+
+class fork:
+    def __init__(self):
+        self.main = torch.cuda.current_stream()
+        if OVERLAP:
+            key = self.main.device.index
+            if key not in _SIDE:
+                _SIDE[key] = torch.cuda.Stream(device=self.main.device)
+            self.side = _SIDE[key]
+            self.side.wait_stream(self.main)
+        self.ctx = None
+
+    def __enter__(self):
+        if OVERLAP:
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self):
+        if OVERLAP:
+            self.main.wait_stream(self.side)
+
+
 def ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -246,7 +283,7 @@ class WgradRunner:
         self.acc_batch = batch
 
     def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None,
-            dbias_grad=None, nbias=0, bn_w=None, bn_sums=None, bn_nrep=1):
+            dbias_grad=None, nbias=0, bn_w=None, bn_sums=None, bn_nrep=1, defer_finish=False):
         """dw (fp32, the parameter's own layout) += gradient.  On the DMA path the BatchNorm (in_scale/in_shift) is
         folded into the finish step and needs dbias_sums = sum over voxels of dz per output channel (fp64); there
         bn_sums (with bn_w = the conv weight) also receives the BatchNorm-backward sums of the input, which
@@ -265,10 +302,16 @@ class WgradRunner:
         a.in_scale, a.in_shift = (None, None) if fold else (ptr(in_scale), ptr(in_shift))
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
-        st = stream()
         with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout,
                     "%d->%d @%dx%dx%d %s" % (self.cin, self.cout, a.Di, a.Hi, a.Wi, "dma" if a.dma else "reg")):
-            L.call("sp_conv3d_wgrad", C.byref(a), st)
+            L.call("sp_conv3d_wgrad", C.byref(a), stream())
+        finish = lambda: self._finish(fold, dw, in_scale, in_shift, dbias_sums, dbias_grad, nbias, bn_w, bn_sums, bn_nrep)
+        if defer_finish:
+            return finish          # the caller runs it (e.g. on the side stream, next to the data-gradient conv)
+        finish()
+
+    def _finish(self, fold, dw, in_scale, in_shift, dbias_sums, dbias_grad, nbias, bn_w, bn_sums, bn_nrep):
+        st = stream()
         if fold:
             L.call("sp_wgrad_finish_folded", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw),

@@ -156,6 +156,12 @@ class UnetEngine:
                 l._init_bwd()
         c = self
         dseg = dseg.contiguous()
+        # all data-gradient weight re-packs depend on the parameters only: side stream, beside the head's backward
+        pre = O.fork()
+        with pre:
+            for l in self.layers:
+                if getattr(l, "dgrad", None) is not None and l.need_input_grad:
+                    l.dgrad.prep(params[l.conv_prefix + ".weight"])
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
             b5, bc, ncls = self.channels[5], self.channels[6], self.ncls
@@ -177,6 +183,7 @@ class UnetEngine:
             O.bn_act_bwd(g, c.h0.y, None, dt, L.ACT_LEAKY, LEAKY, c.h0.dz, c.h0.dbias_sums)
             g, _ = c.h0.backward(c.c52.y, params, grads)
             O.bn_act_bwd(g, c.c52.y, None, dt, L.ACT_LEAKY, LEAKY, c.c52.dz, c.c52.dbias_sums)
+        pre.join()
         g, coef = c.c52.backward(c.c51.y, params, grads)
         O.bn_act_bwd(g, c.c51.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c51.dz, c.c51.dbias_sums)
         g5, coef5 = c.c51.backward(c.cat5, params, grads)
