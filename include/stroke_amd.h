@@ -236,11 +236,18 @@ int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const fl
 int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C, int64_t DHW, int32_t CP,
                       int32_t dtype, int32_t act, float act_param, void* dz, double* dbias_sums,
                       sp_stream_t stream);
-/* sums[c] = (sum o*t, sum o*o, sum t*t) per channel c of NCDHW fp32 tensors */
-int sp_dice_sums(const float* o, const float* t, int32_t B, int32_t C, int64_t DHW, double* sums, sp_stream_t stream);
-/* dout[b,c,v] = ca[c]*t + cb[c]*o */
-int sp_dice_bwd(const float* o, const float* t, const float* ca, const float* cb, int32_t B, int32_t C,
-                int64_t DHW, float* dout, sp_stream_t stream);
+/* ------------------------------------------------------------------ BatchDiceLoss (metrics.py:16-28)
+ * o, t: (B, C, DHW) fp32, contiguous per sample, arbitrary batch stride (elements) so that channel-slice views
+ * (dto.outputs.core / .penu, UnetDto) are read in place.  sums[c][3] (fp64, zeroed by the caller) +=
+ * (sum o*t, sum o*o, sum t*t) over batch and volume. */
+int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, int32_t B, int32_t C, int64_t DHW,
+                 double* sums, sp_stream_t stream);
+/* loss = 1 - sum_c w_c (2 I_c + eps)/(O_c + T_c + eps);  coef[c] = (ca, cb): d loss/d o = ca*t + cb*o */
+int sp_dice_finalize(const double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
+                     sp_stream_t stream);
+/* dout (contiguous) = *upstream * (ca[c]*t + cb[c]*o); upstream: device pointer to the scalar gradient (NULL = 1) */
+int sp_dice_bwd(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, const float* coef,
+                const float* upstream, int32_t B, int32_t C, int64_t DHW, float* dout, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ fused classify head (Unet3D.py:49-54,75-77)
  * seg = sigmoid(W2 * lrelu(W1*x + b1) + b2): x channels-last [B*nvox][CP], seg NCDHW fp32 [B][NC][nvox].

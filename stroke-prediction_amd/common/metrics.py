@@ -19,41 +19,61 @@ _W_CACHE = {}
 def _weights_on(device, weights):
     key = (str(device), weights)
     if key not in _W_CACHE:
-        _W_CACHE[key] = torch.tensor(weights, dtype=torch.float64, device=device)
+        _W_CACHE[key] = torch.tensor(weights, dtype=torch.float32, device=device)
     return _W_CACHE[key]
 
 
+def _batch_strided(x):
+    """(tensor, batch stride in elements) for a (B, C, ...) fp32 tensor that is contiguous within each sample --
+    channel-slice views such as ``dto.outputs.core`` qualify and are read in place; anything else is copied."""
+    x = x if x.dtype == torch.float32 else x.float()
+    inner = 1
+    ok = True
+    for size, stride in zip(reversed(x.shape[1:]), reversed(x.stride()[1:])):
+        if size != 1 and stride != inner:
+            ok = False
+            break
+        inner *= size
+    if not ok or (x.shape[0] > 1 and x.stride(0) < inner):
+        x = x.contiguous()
+        return x, inner
+    return x, (x.stride(0) if x.shape[0] > 1 else inner)
+
+
 class _DiceFn(torch.autograd.Function):
-    """loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps); sums over batch and volume per channel."""
+    """loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps); sums over batch and volume per channel.  Three HIP
+    launches forward (sums, finalize) and one backward; the scalar algebra never leaves the device."""
 
     @staticmethod
     def forward(ctx, outputs, targets, weights, eps):
         from stroke_prediction_amd.runtime import lib as L, ops as O
-        o = outputs.contiguous().float()
-        t = targets.contiguous().float()
+        o, obs = _batch_strided(outputs)
+        t, tbs = _batch_strided(targets)
         B, C = o.shape[0], o.shape[1]
         dhw = o.numel() // (B * C)
         sums = torch.zeros(C, 3, dtype=torch.float64, device=o.device)
-        L.call("sp_dice_sums", O.ptr(o), O.ptr(t), B, C, dhw, O.ptr(sums), O.stream())
+        L.call("sp_dice_sums", O.ptr(o), obs, O.ptr(t), tbs, B, C, dhw, O.ptr(sums), O.stream())
         from stroke_prediction_amd.runtime.layers import SYNC, _allreduce
         if SYNC["on"]:                  # Dice is a ratio of WHOLE-batch sums (metrics.py:24-27): make them global
             _allreduce(sums)
         w = _weights_on(o.device, weights)      # cached: no host->device copy inside a (graph-captured) step
-        num = 2.0 * sums[:, 0] + eps
-        den = sums[:, 1] + sums[:, 2] + eps
-        ctx.save_for_backward(o, t, w, num, den)
-        return (1.0 - (w * num / den).sum()).float()
+        loss = torch.empty((), dtype=torch.float32, device=o.device)
+        coef = torch.empty(2 * C, dtype=torch.float32, device=o.device)
+        L.call("sp_dice_finalize", O.ptr(sums), O.ptr(w), float(eps), C, O.ptr(loss), O.ptr(coef), O.stream())
+        ctx.save_for_backward(o, t, coef)
+        ctx.strides = (obs, tbs)
+        return loss
 
     @staticmethod
     def backward(ctx, gloss):
         from stroke_prediction_amd.runtime import lib as L, ops as O
-        o, t, w, num, den = ctx.saved_tensors
+        o, t, coef = ctx.saved_tensors
+        obs, tbs = ctx.strides
         B, C = o.shape[0], o.shape[1]
-        up = gloss.double()
-        ca = (-2.0 * w / den * up).float().contiguous()
-        cb = (2.0 * w * num / (den * den) * up).float().contiguous()
-        d = torch.empty_like(o)
-        L.call("sp_dice_bwd", O.ptr(o), O.ptr(t), O.ptr(ca), O.ptr(cb), B, C, o.numel() // (B * C), O.ptr(d), O.stream())
+        up = gloss if (gloss.dtype == torch.float32 and gloss.is_contiguous()) else gloss.float().contiguous()
+        d = torch.empty(o.shape, dtype=torch.float32, device=o.device)
+        L.call("sp_dice_bwd", O.ptr(o), obs, O.ptr(t), tbs, O.ptr(coef), O.ptr(up), B, C, o.numel() // (B * C), O.ptr(d),
+               O.stream())
         return d, None, None, None
 
 

@@ -1032,17 +1032,19 @@ extern "C" int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B,
   return SP_OK;
 }
 
-// BatchDiceLoss pieces (metrics.py:16-28): sums[c] = (sum o*t, sum o*o, sum t*t) over batch and volume
-__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ o, const float* __restrict__ t, int C,
-                                                         int64_t DHW, int64_t chunks_per_c, double* __restrict__ sums) {
+// BatchDiceLoss pieces (metrics.py:16-28): sums[c] = (sum o*t, sum o*o, sum t*t) over batch and volume.
+// o / t are (B, C, DHW) with an arbitrary BATCH stride (elements): dto.outputs.core / .penu are channel slices of one
+// (B, 2, DHW) tensor and are read in place.
+__global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict__ o, int64_t obs, const float* __restrict__ t,
+                                                         int64_t tbs, int C, int64_t DHW, double* __restrict__ sums) {
   // grid.y = b*C + c ; grid.x strides over the volume
-  const int bc = blockIdx.y, c = bc % C;
-  const float* op = o + (int64_t)bc * DHW;
-  const float* tp = t + (int64_t)bc * DHW;
+  const int bc = blockIdx.y, c = bc % C, b = bc / C;
+  const float* op = o + (int64_t)b * obs + (int64_t)c * DHW;
+  const float* tp = t + (int64_t)b * tbs + (int64_t)c * DHW;
   float s[3] = {0.f, 0.f, 0.f};
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < DHW; i += (int64_t)gridDim.x * 256) {
-    const float a = op[i], b = tp[i];
-    s[0] += a * b; s[1] += a * a; s[2] += b * b;
+    const float a = op[i], bb = tp[i];
+    s[0] += a * bb; s[1] += a * a; s[2] += bb * bb;
   }
   __shared__ float red[3];
   if (threadIdx.x < 3) red[threadIdx.x] = 0.f;
@@ -1055,29 +1057,55 @@ __global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict_
   __syncthreads();
   if (threadIdx.x < 3) atomicAdd(&sums[c * 3 + threadIdx.x], (double)red[threadIdx.x]);
 }
-extern "C" int sp_dice_sums(const float* o, const float* t, int32_t B, int32_t C, int64_t DHW, double* sums,
-                            sp_stream_t stream) {
-  SP_CHECK_ARG(o && t && sums && B >= 1 && C >= 1, "sp_dice_sums: bad arguments");
+extern "C" int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, int32_t B, int32_t C,
+                            int64_t DHW, double* sums, sp_stream_t stream) {
+  SP_CHECK_ARG(o && t && sums && B >= 1 && C >= 1 && o_bstride >= C * DHW && t_bstride >= C * DHW, "sp_dice_sums: bad arguments");
   int64_t gx = (DHW + 256 * 8 - 1) / (256 * 8);
   if (gx > 256) gx = 256;
-  hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, ST(stream), o, t, C, DHW, gx, sums);
+  hipLaunchKernelGGL(dice_sums_kernel, dim3((unsigned)gx, B * C), dim3(256), 0, ST(stream), o, o_bstride, t, t_bstride, C, DHW, sums);
   SP_CHECK_LAUNCH("sp_dice_sums");
   return SP_OK;
 }
-// do[b,c,v] = ca[c]*t + cb[c]*o   (ca = -w*2/den*up, cb = +w*2*num/den^2*up formed by the caller)
-__global__ void dice_bwd_kernel(const float* __restrict__ o, const float* __restrict__ t, const float* __restrict__ ca,
-                                const float* __restrict__ cb, int C, int64_t DHW, int64_t total, float* __restrict__ d) {
+// loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps);  coef[c] = (ca, cb) with d loss / d o = ca*t + cb*o:
+// ca = -2 w / den, cb = 2 w num / den^2.  One launch instead of a dozen one-element torch kernels.
+__global__ void dice_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ w, double eps, int C,
+                                     float* __restrict__ loss, float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double acc = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double num = 2.0 * sums[c * 3] + eps, den = sums[c * 3 + 1] + sums[c * 3 + 2] + eps;
+    acc += (double)w[c] * num / den;
+    coef[2 * c] = (float)(-2.0 * w[c] / den);
+    coef[2 * c + 1] = (float)(2.0 * w[c] * num / (den * den));
+  }
+  *loss = (float)(1.0 - acc);
+}
+extern "C" int sp_dice_finalize(const double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
+                                sp_stream_t stream) {
+  SP_CHECK_ARG(sums && weights && loss && coef && C >= 1, "sp_dice_finalize: bad arguments");
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), sums, weights, eps, C, loss, coef);
+  SP_CHECK_LAUNCH("sp_dice_finalize");
+  return SP_OK;
+}
+// do[b,c,v] = up * (ca[c]*t + cb[c]*o), up = *upstream (the scalar gradient of the loss, read on the device)
+__global__ void dice_bwd_kernel(const float* __restrict__ o, int64_t obs, const float* __restrict__ t, int64_t tbs,
+                                const float* __restrict__ coef, const float* __restrict__ upstream, int C, int64_t DHW,
+                                int64_t total, float* __restrict__ d) {
+  const float up = upstream ? *upstream : 1.f;
+  const int64_t per_b = (int64_t)C * DHW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c = (int)((i / DHW) % C);
-    d[i] = ca[c] * t[i] + cb[c] * o[i];
+    const int64_t b = i / per_b, r = i - b * per_b;
+    const int c = (int)(r / DHW);
+    d[i] = up * (coef[2 * c] * t[b * tbs + r] + coef[2 * c + 1] * o[b * obs + r]);
   }
 }
-extern "C" int sp_dice_bwd(const float* o, const float* t, const float* ca, const float* cb, int32_t B, int32_t C,
-                           int64_t DHW, float* dout, sp_stream_t stream) {
-  SP_CHECK_ARG(o && t && ca && cb && dout, "sp_dice_bwd: null pointer");
+extern "C" int sp_dice_bwd(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, const float* coef,
+                           const float* upstream, int32_t B, int32_t C, int64_t DHW, float* dout, sp_stream_t stream) {
+  SP_CHECK_ARG(o && t && coef && dout, "sp_dice_bwd: null pointer");
   const int64_t total = (int64_t)B * C * DHW;
   const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-  hipLaunchKernelGGL(dice_bwd_kernel, dim3(grid), dim3(256), 0, ST(stream), o, t, ca, cb, C, DHW, total, dout);
+  hipLaunchKernelGGL(dice_bwd_kernel, dim3(grid), dim3(256), 0, ST(stream), o, o_bstride, t, t_bstride, coef, upstream, C, DHW,
+                     total, dout);
   SP_CHECK_LAUNCH("sp_dice_bwd");
   return SP_OK;
 }

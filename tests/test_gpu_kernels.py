@@ -301,15 +301,27 @@ def test_dice_and_output_grad():
     t = (torch.rand(B, Cc, *dims, generator=g) > 0.7).float()
     sums = torch.zeros(Cc, 3, dtype=torch.float64, device=DEV)
     od, td = o.to(DEV), t.to(DEV)
-    lib.call("sp_dice_sums", O.ptr(od), O.ptr(td), B, Cc, int(np.prod(dims)), O.ptr(sums), O.stream())
+    dhw = int(np.prod(dims))
+    lib.call("sp_dice_sums", O.ptr(od), Cc * dhw, O.ptr(td), Cc * dhw, B, Cc, dhw, O.ptr(sums), O.stream())
     ref = torch.stack([(o * t).sum(dim=(0, 2, 3, 4)), (o * o).sum(dim=(0, 2, 3, 4)), (t * t).sum(dim=(0, 2, 3, 4))], 1)
     torch.testing.assert_close(sums.cpu().float(), ref, rtol=1e-5, atol=1e-4)
-    ca, cb = torch.randn(Cc), torch.randn(Cc)
+    # channel-slice views (batch stride = all channels) are read in place
+    s1 = torch.zeros(1, 3, dtype=torch.float64, device=DEV)
+    lib.call("sp_dice_sums", O.ptr(od[:, 1:2]), Cc * dhw, O.ptr(td[:, 1:2]), Cc * dhw, B, 1, dhw, O.ptr(s1), O.stream())
+    torch.testing.assert_close(s1.cpu().float(), ref[1:2], rtol=1e-5, atol=1e-4)
+    # finalize: loss and backward coefficients
+    w = torch.tensor([0.3, 0.7])
+    loss, coef = torch.empty((), device=DEV), torch.empty(2 * Cc, device=DEV)
+    wd = w.to(DEV)
+    lib.call("sp_dice_finalize", O.ptr(sums), O.ptr(wd), 1e-7, Cc, O.ptr(loss), O.ptr(coef), O.stream())
+    num, den = 2 * ref[:, 0].double() + 1e-7, ref[:, 1].double() + ref[:, 2].double() + 1e-7
+    assert abs(float(loss) - float(1 - (w.double() * num / den).sum())) < 1e-6
+    ca, cb = (-2 * w.double() / den).float(), (2 * w.double() * num / den ** 2).float()
+    torch.testing.assert_close(coef.cpu().view(Cc, 2), torch.stack([ca, cb], 1), rtol=1e-5, atol=1e-9)
     d = torch.empty_like(od)
-    cad, cbd = ca.to(DEV), cb.to(DEV)
-    lib.call("sp_dice_bwd", O.ptr(od), O.ptr(td), O.ptr(cad), O.ptr(cbd), B, Cc, int(np.prod(dims)),
-             O.ptr(d), O.stream())
-    torch.testing.assert_close(d.cpu(), ca.view(1, -1, 1, 1, 1) * t + cb.view(1, -1, 1, 1, 1) * o, rtol=1e-6, atol=1e-6)
+    up = torch.tensor(0.5, device=DEV)
+    lib.call("sp_dice_bwd", O.ptr(od), Cc * dhw, O.ptr(td), Cc * dhw, O.ptr(coef), O.ptr(up), B, Cc, dhw, O.ptr(d), O.stream())
+    torch.testing.assert_close(d.cpu(), 0.5 * (ca.view(1, -1, 1, 1, 1) * t + cb.view(1, -1, 1, 1, 1) * o), rtol=1e-5, atol=1e-9)
     dz = O.alloc_cl(B, dims, 8, L.SP_F32, DEV)
     dbias = torch.zeros(8, dtype=torch.float64, device=DEV)
     O.out_grad_to_cl(d, od, L.SP_F32, L.ACT_SIGMOID, 0.0, dz, dbias)

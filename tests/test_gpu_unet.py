@@ -79,7 +79,10 @@ def test_unet_train_step_matches_oracle(dtype, size, seed, tol_seg, tol_grad):
         cos = float(torch.nn.functional.cosine_similarity(p.grad.cpu().reshape(1, -1).double(),
                                                           g_ref[name].reshape(1, -1).double()))
         small = p.numel() <= 64 and dtype == "bf16"      # 2..64-element BatchNorm / bias gradients are noisier
-        if e > (0.6 if small else tol_grad) or cos < (0.88 if small else 0.95):
+        # parity mode: a single LeakyReLU branch flip (run-to-run: the fp64 BatchNorm atomics change the last bit of a
+        # scale, see test_gpu_parallel_exact.py) moves a 16..64-element BatchNorm gradient by up to ~4 %: 2x head-room
+        tol = 0.6 if small else (2 * tol_grad if (dtype == "f32" and p.numel() <= 64) else tol_grad)
+        if e > tol or cos < (0.88 if small else 0.95):
             # Noise floor of a small, cancellation-heavy gradient under bf16 storage = how far the storage-point
             # emulation itself lands from the pure-fp32 oracle.  (The first BatchNorm's gamma is the extreme case: the
             # following conv -> BatchNorm makes the loss nearly invariant to it, its true gradient is ~0 and the
