@@ -105,6 +105,11 @@ int sp_conv_prep_weights(const float* w, int64_t sCo, int64_t sCi, int32_t Cout,
  * (bias may be NULL = 0; bias_out has room for CoutPad entries, the tail is zeroed) */
 int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, int32_t ntaps,
                       const float* bias, const float* shift, float* bias_out, int32_t CoutPad, sp_stream_t stream);
+/* sp_conv_prep_weights (with fold_scale) and sp_conv_fold_bias in one launch */
+int sp_conv_prep_folded(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,
+                        int32_t nsteps, int32_t NTtot, void* wfrag_hi, void* wfrag_lo, const float* fold_scale,
+                        int32_t ntaps, const float* bias, const float* fold_shift, float* bias_out, int32_t CoutPad,
+                        sp_stream_t stream);
 
 /* ------------------------------------------------------------------ weight gradient
  * dw[co,ci,tap] += sum_{b,o} dz[b,o,co] * xin[b, o*s + o0 + tapoff(tap), ci]

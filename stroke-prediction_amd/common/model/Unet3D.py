@@ -63,6 +63,8 @@ class _UnetFn(torch.autograd.Function):
 
 
 class Unet3D(FlatParamsMixin, nn.Module):
+    FLAT_NBT = True      # every BatchNorm runs exactly once per forward: their step counters advance together
+
     def __init__(self, channels=[2, 32, 64, 128, 64, 32, 32, 2], channel_dim=1, channels_crop=[2, 3, 4],
                  dtype="bf16"):
         super().__init__()
@@ -121,6 +123,6 @@ class Unet3D(FlatParamsMixin, nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engines"] = {}          # engines hold device buffers and ctypes handles: rebuilt on demand
-        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device"):
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt"):
             state.pop(k, None)
         return state

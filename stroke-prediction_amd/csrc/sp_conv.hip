@@ -434,6 +434,71 @@ __global__ void fold_bias_kernel(const float* __restrict__ w, int64_t sCo, int64
   s = wave_sum(s);
   if (lane == 0) out[co] = co < Cout ? s + (bias ? bias[co] : 0.f) : 0.f;
 }
+// re-pack + BatchNorm fold of the weights AND of the bias in one launch (the two kernels above, blocks [0, nprep)
+// and [nprep, nprep + CoutPad/4)): one ~5 us dispatch less per layer and step
+__global__ __launch_bounds__(256) void prep_folded_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
+                                                           const int32_t* __restrict__ kmap, int nsteps, int NTtot,
+                                                           bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                                           const float* __restrict__ fold, int nprep, int ntaps,
+                                                           const float* __restrict__ bias, const float* __restrict__ shift,
+                                                           float* __restrict__ out, int CoutPad) {
+  if ((int)blockIdx.x < nprep) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (step, ntile, lane)
+    const int64_t total = (int64_t)nsteps * NTtot * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63;
+    const int nt = (idx >> 6) % NTtot;
+    const int st = (idx >> 6) / NTtot;
+    const int co = nt * 16 + (lane & 15), g = lane >> 4;
+    const int km = kmap[st * 4 + g];
+    uint32_t wh[4], wl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float f[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float v = 0.f;
+        if (km >= 0) {
+          const int tap = km >> 16, ci = (km & 0xffff) * 8 + 2 * j + h;
+          if (co < Cout && ci < Cin) v = w[co * sCo + ci * sCi + tap] * fold[ci];
+        }
+        f[h] = v;
+      }
+      const bf16_t h0 = f2bf(f[0]), h1 = f2bf(f[1]);
+      wh[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+      wl[j] = (uint32_t)f2bf(f[0] - bf2f(h0)) | ((uint32_t)f2bf(f[1] - bf2f(h1)) << 16);
+    }
+    reinterpret_cast<uint4*>(hi)[idx] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
+    if (lo) reinterpret_cast<uint4*>(lo)[idx] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+    return;
+  }
+  const int co = ((int)blockIdx.x - nprep) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (co >= CoutPad) return;
+  float acc = 0.f;
+  if (co < Cout)
+    for (int i = lane; i < Cin * ntaps; i += 64) {
+      const int ci = i / ntaps, tp = i - ci * ntaps;
+      acc += w[co * sCo + ci * sCi + tp] * shift[ci];
+    }
+  acc = wave_sum(acc);
+  if (lane == 0) out[co] = co < Cout ? acc + (bias ? bias[co] : 0.f) : 0.f;
+}
+extern "C" int sp_conv_prep_folded(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,
+                                   int32_t nsteps, int32_t NTtot, void* wfrag_hi, void* wfrag_lo, const float* fold_scale,
+                                   int32_t ntaps, const float* bias, const float* fold_shift, float* bias_out,
+                                   int32_t CoutPad, sp_stream_t stream) {
+  SP_CHECK_ARG(w && kmap && wfrag_hi && fold_scale && fold_shift && bias_out && nsteps > 0 && NTtot > 0 && CoutPad >= Cout,
+               "sp_conv_prep_folded: bad arguments");
+  const int64_t total = (int64_t)nsteps * NTtot * 64;
+  const int nprep = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(prep_folded_kernel, dim3((unsigned)(nprep + (CoutPad + 3) / 4)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, sCo, sCi, Cout, Cin, kmap, nsteps, NTtot,
+                     reinterpret_cast<bf16_t*>(wfrag_hi), reinterpret_cast<bf16_t*>(wfrag_lo), fold_scale, nprep, ntaps, bias,
+                     fold_shift, bias_out, CoutPad);
+  SP_CHECK_LAUNCH("sp_conv_prep_folded");
+  return SP_OK;
+}
+
 extern "C" int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, int32_t ntaps,
                                  const float* bias, const float* shift, float* bias_out, int32_t CoutPad,
                                  sp_stream_t stream) {

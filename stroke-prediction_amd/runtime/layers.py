@@ -107,7 +107,7 @@ class ConvLayer:
         O.bn_finalize(self.in_sums if training else None, self.count * world, params[p + ".weight"], params[p + ".bias"],
                       bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
                       self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
-        if training:
+        if training and "__nbt_flat__" not in bufs:      # else: one increment for all BatchNorms (UnetEngine.forward)
             bufs[p + ".num_batches_tracked"].add_(1)
 
     def forward(self, x, params, bufs, training, out_stats=None):

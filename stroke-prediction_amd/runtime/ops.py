@@ -161,6 +161,14 @@ class ConvRunner:
             self._st["prep_key"] = key
         else:
             self._st["prep_key"] = None
+        if fold_scale is not None and fold_shift is not None and len(self.subs) == 1:
+            s0 = self.subs[0]
+            ntaps = w.numel() // (op.cin * op.cout)
+            L.call("sp_conv_prep_folded", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s0["kmap"]), s0["nsteps"], op.nttot,
+                   ptr(s0["hi"]), ptr(s0["lo"]), ptr(fold_scale), ntaps, ptr(b), ptr(fold_shift), ptr(self.bias), op.nttot * 16,
+                   stream())
+            self.has_bias = True
+            return
         for s in self.subs:
             L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s["kmap"]), s["nsteps"],
                    op.nttot, ptr(s["hi"]), ptr(s["lo"]), ptr(fold_scale), stream())

@@ -107,6 +107,8 @@ class UnetEngine:
         assert tuple(images.shape) == (B, self.channels[0]) + self.dims and images.dtype == torch.float32
         images = images.contiguous()
         self.scratch.zero()
+        if training and "__nbt_flat__" in bufs:
+            bufs["__nbt_flat__"].add_(1)
         st = (lambda l: l.in_sums) if training else (lambda l: None)
         if self.first_packed:
             self.x0 = images                  # the packed first-layer kernels read the NCDHW fp32 input itself
