@@ -176,6 +176,12 @@ int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H, int32_t W
  * sp_wgrad_finish_folded(partials, nblocks, tapsrc, 27, 16, 2, 16, 2, ...) */
 int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
                    int32_t nblocks, sp_stream_t stream);
+/* the same with dz formed on the fly: dz = (coef[0][c]*g + coef[1][c]*y + coef[2][c]) * act'(y) (coef: [3][16], the
+ * BatchNorm-backward triple of the NEXT layer; g its data gradient, y this layer's output; both [..][16] bf16), and
+ * dbias_sums[c] (fp64, zeroed by the caller) += sum dz -- replaces sp_bn_act_bwd + sp_first_wgrad for this layer */
+int sp_first_wgrad_fused(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
+                         int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks, double* dbias_sums,
+                         sp_stream_t stream);
 
 /* ------------------------------------------------------------------ layout
  * NCDHW fp32 (reference layout, README.md:13 / data.py:305) <-> channels-last-3d */

@@ -229,8 +229,14 @@ extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H
 //   A = dz^T (rows co), transposed out of the staged channels-last dz tile by ds_read_b64_tr_b16 (natural K order);
 //   B = columns r = (dz,dy) (9 of 16 used), one column tile per channel c, eight consecutive x voxels per lane from
 //       the planar staged input; the three dx taps are the same five dwords shifted by 0, 1 and 2 elements.
+// FUSED: dz is not read but formed on the fly, dz = (c0*g + c1*y + c2) * act'(y) (BatchNorm backward of the NEXT layer
+// and the activation derivative, i.e. sp_bn_act_bwd), and its per-channel sum is accumulated for the bias gradient --
+// the 2 x 256 MB round trip of dz through HBM and one launch disappear (nobody else reads this layer's dz).
+template <bool FUSED>
 __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, const bf16_t* __restrict__ dzg,
-                                                           float* __restrict__ part) {
+                                                           const bf16_t* __restrict__ gg, const bf16_t* __restrict__ yg,
+                                                           const float* __restrict__ coef, int act, float ap,
+                                                           double* __restrict__ dbias, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];        // planar: [c][row][x] bf16
   __shared__ __attribute__((aligned(16))) unsigned char dzt[FT_TZ * FT_TY * FT_TX * 32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
@@ -243,6 +249,15 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
   for (int d = 0; d < 3; ++d) acc[d][0] = acc[d][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16_t* xpl = reinterpret_cast<const bf16_t*>(xt);
   typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  // fused mode: this thread always stages the same channel half (i & 1 == tid & 1)
+  float k0[8], k1[8], k2[8], dsum[8];
+  if (FUSED) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (tid & 1) * 8 + j;
+      k0[j] = coef[c]; k1[j] = coef[16 + c]; k2[j] = coef[32 + c]; dsum[j] = 0.f;
+    }
+  }
 
   for (uint32_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
     int b, oz0, oy0, ox0;
@@ -254,8 +269,25 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
       const int half = i & 1, vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
       const int oz = oz0 + (row >> 2), oy = oy0 + (row & 3), ox = ox0 + vx;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (oz < P.Do && oy < P.Ho && ox < P.Wo)
-        v = *reinterpret_cast<const uint4*>(dzg + ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * 16 + half * 8);
+      if (oz < P.Do && oy < P.Ho && ox < P.Wo) {
+        const size_t o = ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * 16 + half * 8;
+        if (FUSED) {
+          float g8[8], y8[8], d8[8];
+          Store<bf16_t>::ld8(gg + o, g8);
+          Store<bf16_t>::ld8(yg + o, y8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            d8[j] = (k0[j] * g8[j] + k1[j] * y8[j] + k2[j]) * act_bwd_from_y(act, ap, y8[j]);
+            dsum[j] += d8[j];
+          }
+          uint32_t w4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)f2bf(d8[2 * j]) | ((uint32_t)f2bf(d8[2 * j + 1]) << 16);
+          v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        } else {
+          v = *reinterpret_cast<const uint4*>(dzg + o);
+        }
+      }
       *reinterpret_cast<uint4*>(dzt + (size_t)i * 16) = v;
     }
     __syncthreads();
@@ -301,6 +333,22 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
   }
   __syncthreads();
   for (int i = tid; i < 27 * 16 * 2; i += 256) part[(size_t)blockIdx.x * (27 * 16 * 2) + i] = st[i];
+  if (FUSED && dbias) {       // sum of dz per output channel: threads with equal parity hold the same eight channels
+    __syncthreads();
+    float* rd = st;           // 16 floats
+    if (tid < 16) rd[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = dsum[j];
+      // lanes of one parity: xor-reduce over the other 5 lane bits
+#pragma unroll
+      for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane < 2) atomicAdd(&rd[(lane & 1) * 8 + j], v);
+    }
+    __syncthreads();
+    if (tid < 16) atomicAdd(&dbias[tid], (double)rd[tid]);
+  }
 }
 
 extern "C" int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
@@ -308,7 +356,21 @@ extern "C" int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t
   SP_CHECK_ARG(x && dz && partials && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1, "sp_first_wgrad: bad arguments");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad: too many tiles");
-  hipLaunchKernelGGL(first_wgrad_kernel, dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, partials);
+  hipLaunchKernelGGL(first_wgrad_kernel<false>, dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, nullptr, nullptr,
+                     nullptr, 0, 0.f, nullptr, partials);
   SP_CHECK_LAUNCH("sp_first_wgrad");
+  return SP_OK;
+}
+
+extern "C" int sp_first_wgrad_fused(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
+                                    int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks,
+                                    double* dbias_sums, sp_stream_t stream) {
+  SP_CHECK_ARG(x && g && y && coef && partials && dbias_sums && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1,
+               "sp_first_wgrad_fused: bad arguments");
+  FirstDev P;
+  SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad_fused: too many tiles");
+  hipLaunchKernelGGL(first_wgrad_kernel<true>, dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,
+                     (const bf16_t*)y, coef, act, act_param, dbias_sums, partials);
+  SP_CHECK_LAUNCH("sp_first_wgrad_fused");
   return SP_OK;
 }

@@ -268,13 +268,19 @@ class FirstConvLayer(ConvLayer):
         self.coef = torch.zeros(3, self.cpi, device=self.device)
         self._bwd_ready = True
 
-    def backward(self, images, params, grads):
+    def backward(self, images, params, grads, g=None, coef=None):
+        """g / coef given: the output gradient is formed inside the weight-gradient kernel (dz = (c0*g + c1*y + c2)*act'(y),
+        the caller skips its sp_bn_act_bwd); else self.dz / self.dbias_sums were filled by the caller."""
         c = self.conv_prefix
         st = O.stream()
         D, H, W = self.in_dims
         bs = self.scratch.get(self.bsums_id)
         with O._Timed("conv_wgrad", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
-            L.call("sp_first_wgrad", O.ptr(images), O.ptr(self.dz), self.batch, D, H, W, O.ptr(self.partials), self.nparts, st)
+            if g is not None:
+                L.call("sp_first_wgrad_fused", O.ptr(images), O.ptr(g), O.ptr(self.y), O.ptr(coef), self.act, self.act_param,
+                       self.batch, D, H, W, O.ptr(self.partials), self.nparts, O.ptr(self.dbias_sums), st)
+            else:
+                L.call("sp_first_wgrad", O.ptr(images), O.ptr(self.dz), self.batch, D, H, W, O.ptr(self.partials), self.nparts, st)
         L.call("sp_wgrad_finish_folded", O.ptr(self.partials), self.nparts, O.ptr(self.tapsrc), 27, 16, 2, self.cout,
                self.cin, self.cin * 27, 27, O.ptr(self.scale), O.ptr(self.shift), O.ptr(self.dbias_sums),
                O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(params[c + ".weight"]), O.ptr(bs), STATS_NREP,

@@ -205,5 +205,8 @@ class UnetEngine:
         O.pool_skip_act_bwd(c.c12.y, gp1, coefp1, c.cat5, g5, coef5, self.channels[4], dt, L.ACT_LEAKY, LEAKY,
                             c.c12.dz, c.c12.dbias_sums)
         g, coef = c.c12.backward(c.c11.y, params, grads)
-        O.bn_act_bwd(g, c.c11.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c11.dz, c.c11.dbias_sums)
-        c.c11.backward(c.x0, params, grads)       # only the first BatchNorm's gamma/beta need this dgrad
+        if self.first_packed and coef is not None and c.c11.cpo == 16:
+            c.c11.backward(c.x0, params, grads, g=g, coef=coef)     # dz formed inside the weight-gradient kernel
+        else:
+            O.bn_act_bwd(g, c.c11.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c11.dz, c.c11.dbias_sums)
+            c.c11.backward(c.x0, params, grads)       # only the first BatchNorm's gamma/beta need this dgrad

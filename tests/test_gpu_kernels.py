@@ -527,3 +527,19 @@ def test_first_layer_packed():
     got = bs.sum(0).cpu()
     torch.testing.assert_close(got[:2], ref, rtol=1e-4, atol=1e-2)
     assert float(got[2:].abs().max()) == 0.0
+    # fused variant: dz = (c0*g + c1*y + c2) * LeakyReLU'(y) formed inside the kernel == sp_bn_act_bwd followed by the above
+    gq = rnd(L.SP_BF16, torch.randn(B, 16, *od))
+    coef = torch.randn(3, 16) * 0.5
+    g_cl = to_cl(gq, 16, L.SP_BF16)
+    dz2 = torch.empty_like(dz_cl)
+    dbs2 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    O.bn_act_bwd(g_cl, y, coef.to(DEV), L.SP_BF16, L.ACT_LEAKY, 0.01, dz2, dbs2)
+    p_ref = torch.empty(nparts * 27 * 16 * 2, device=DEV)
+    L.call("sp_first_wgrad", O.ptr(xd), O.ptr(dz2), B, dims[0], dims[1], dims[2], O.ptr(p_ref), nparts, O.stream())
+    p_fus = torch.full_like(p_ref, float("nan"))
+    dbs3 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    cd = coef.to(DEV)
+    L.call("sp_first_wgrad_fused", O.ptr(xd), O.ptr(g_cl), O.ptr(y), O.ptr(cd), L.ACT_LEAKY, 0.01, B, dims[0], dims[1], dims[2],
+           O.ptr(p_fus), nparts, O.ptr(dbs3), O.stream())
+    torch.testing.assert_close(p_fus.view(nparts, -1).sum(0), p_ref.view(nparts, -1).sum(0), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dbs3, dbs2, rtol=1e-5, atol=1e-4)
