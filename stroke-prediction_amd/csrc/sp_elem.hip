@@ -485,87 +485,6 @@ extern "C" int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B
   return SP_OK;
 }
 
-// Upsample + crop + concat in ONE pass (Unet3D.py:67-72): every voxel row of the concat buffer (all CPd channels) is
-// written by neighbouring lanes -- full 128-byte lines -- instead of two kernels each writing a slice of every row
-// (partial-line writes: 280 us for the 92^3 x 48-channel buffer against 100 us of traffic).  Channels [0, CPu) are the
-// trilinear x2 upsample of `low`, channels [CPu, CPu + CPs) the centre crop of `skip`; stats[c][2] += (sum, sum^2).
-template <typename T>
-__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
-                                                         Dims ds, int CPs, T* __restrict__ cat, int CPd, OctMap om,
-                                                         double* __restrict__ stats) {
-  extern __shared__ float red[];
-  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
-  const bool active = slot < om.vpb;
-  const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
-  const int oz = (ds.D - Do) / 2, oy = (ds.H - Ho) / 2, ox = (ds.W - Wo) / 2;
-  const int ocu = CPu / 8;
-  const bool isup = oc < ocu;
-  const int64_t nout = (int64_t)dl.B * Do * Ho * Wo;
-  float part[2][8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
-  const Unflat uf_(Do, Ho, Wo);
-  if (active) {
-    const int64_t chunk_ = ((nout + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
-    const int64_t vend_ = min((int64_t)nout, ((int64_t)blockIdx.x + 1) * chunk_);
-    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
-      int b, z, yy, xx;
-      uf_(v, b, z, yy, xx);
-      // one code path for both halves (a lane-divergent branch around the loads would serialise them): skip lanes
-      // read their single source voxel with weight 1 and repeat it with weight 0
-      int z0, z1, y0, y1, x0, x1; float lz, ly, lx;
-      up_src(z, dl.D, z0, z1, lz); up_src(yy, dl.H, y0, y1, ly); up_src(xx, dl.W, x0, x1, lx);
-      const int64_t so = ((((int64_t)b * ds.D + z + oz) * ds.H + yy + oy) * ds.W + xx + ox) * CPs + (oc - ocu) * 8;
-      float a[8][8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int iz = (k & 4) ? z1 : z0, iy = (k & 2) ? y1 : y0, ix = (k & 1) ? x1 : x0;
-        const int64_t uo = ((((int64_t)b * dl.D + iz) * dl.H + iy) * dl.W + ix) * CPu + oc * 8;
-        Store<T>::ld8(isup ? low + uo : skip + so, a[k]);
-      }
-      float o[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float wu = ((k & 4) ? lz : 1.f - lz) * ((k & 2) ? ly : 1.f - ly) * ((k & 1) ? lx : 1.f - lx);
-        const float w = isup ? wu : (k == 0 ? 1.f : 0.f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fmaf(w, a[k][j], o[j]);
-      }
-      Store<T>::st8(cat + v * CPd + oc * 8, o);
-      if (sizeof(T) == 2) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = bf2f(f2bf(o[j]));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { part[0][j] += o[j]; part[1][j] += o[j] * o[j]; }
-    }
-  }
-  if (stats) block_channel_reduce<2>(part, oc, active, CPd, stats, red);
-}
-extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
-                                         int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
-                                         int32_t Ws, double* stats, sp_stream_t stream) {
-  SP_CHECK_ARG(low && skip && cat && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
-  SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_upsample2_crop_cat_fwd");
-  SP_CHECK_ARG(2 * D <= Ds && 2 * H <= Hs && 2 * W <= Ws, "sp_upsample2_crop_cat_fwd: skip smaller than the upsampled grid");
-  SP_CHECK_ARG(CPd <= 2048, "sp_upsample2_crop_cat_fwd: too many channels");
-  OctMap om = make_octmap(CPd);
-  Dims dl{B, D, H, W}, ds{B, Ds, Hs, Ws};
-  const int64_t nout = (int64_t)B * D * H * W * 8;
-  const unsigned grid = grid_for(nout, om.vpb * 4);
-  const size_t sh = (size_t)CPd * 2 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, om, stats);
-  else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, om, stats);
-  SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd");
-  return SP_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ fused backward pieces
-// Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
-// One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
-// (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
 // eight elements kept as loaded (bf16: 4 VGPRs instead of 8) and unpacked where used
 template <typename T> struct RawOct;
 template <> struct RawOct<bf16_t> {
@@ -586,6 +505,123 @@ template <> struct RawOct<float> {
   }
 };
 
+// Upsample + crop + concat in ONE pass (Unet3D.py:67-72): every voxel row of the concat buffer (all CPd channels) is
+// written by neighbouring lanes -- full lines -- instead of two kernels each writing a slice of every row.  Channels
+// [0, CPu) are the trilinear x2 upsample of `low`, channels [CPu, CPu + CPs) the centre crop of `skip`;
+// stats[c][2] += (sum, sum^2).
+// One thread = one 2x2x2 OUTPUT block x 8 channels.  The block's eight upsampled voxels depend on the 3x3x3 source
+// neighbourhood (i-1, i, i+1 per axis, clamped): out(2i) = .25 s(i-1) + .75 s(i), out(2i+1) = .75 s(i) + .25 s(i+1),
+// evaluated separably (x, then y, then z) -- 27 loads and ~80 vector FMAs for eight outputs instead of 64 and 64
+// (the one-voxel-per-thread version was ALU-bound: ~400 instructions per output octet).
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
+                                                         Dims ds, int CPs, T* __restrict__ cat, int CPd, OctMap om,
+                                                         double* __restrict__ stats) {
+  extern __shared__ float red[];
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
+  const int oz = (ds.D - Do) / 2, oy = (ds.H - Ho) / 2, ox = (ds.W - Wo) / 2;
+  const int ocu = CPu / 8;
+  const bool isup = oc < ocu;
+  const int64_t nblk = (int64_t)dl.B * dl.D * dl.H * dl.W;       // one block per source voxel
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  const Unflat uf_(dl.D, dl.H, dl.W);
+  if (active) {
+    const int64_t chunk_ = ((nblk + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t vend_ = min((int64_t)nblk, ((int64_t)blockIdx.x + 1) * chunk_);
+    for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
+      int b, z, yy, xx;
+      uf_(v, b, z, yy, xx);
+      float out[8][8];                                             // [zo*4 + yo*2 + xo][channel]
+      if (isup) {
+        const int xs[3] = {max(xx - 1, 0), xx, min(xx + 1, dl.W - 1)};
+        const int ys[3] = {max(yy - 1, 0), yy, min(yy + 1, dl.H - 1)};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) out[q][j] = 0.f;
+#pragma unroll 1
+        for (int dz = 0; dz < 3; ++dz) {
+          const int zs = dz == 0 ? max(z - 1, 0) : (dz == 1 ? z : min(z + 1, dl.D - 1));
+          const float wz0 = dz == 0 ? 0.25f : (dz == 1 ? 0.75f : 0.f);      // weight into output plane 2z
+          const float wz1 = dz == 0 ? 0.f : (dz == 1 ? 0.75f : 0.25f);      // ... and 2z + 1
+          const T* pz = low + (((int64_t)b * dl.D + zs) * dl.H) * dl.W * CPu + oc * 8;
+          float ye[2][8], yo[2][8];                                          // [x parity][channel] for the even / odd output y
+#pragma unroll
+          for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ye[xo][j] = yo[xo][j] = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            RawOct<T> r0, r1, r2;
+            const T* py = pz + (int64_t)ys[dy] * dl.W * CPu;
+            r0.load(py + (int64_t)xs[0] * CPu); r1.load(py + (int64_t)xs[1] * CPu); r2.load(py + (int64_t)xs[2] * CPu);
+            float a0[8], a1[8], a2[8];
+            r0.get(a0); r1.get(a1); r2.get(a2);
+            const float wy0 = dy == 0 ? 0.25f : (dy == 1 ? 0.75f : 0.f), wy1 = dy == 0 ? 0.f : (dy == 1 ? 0.75f : 0.25f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float xe = 0.25f * a0[j] + 0.75f * a1[j], xo_ = 0.75f * a1[j] + 0.25f * a2[j];
+              ye[0][j] = fmaf(wy0, xe, ye[0][j]); ye[1][j] = fmaf(wy0, xo_, ye[1][j]);
+              yo[0][j] = fmaf(wy1, xe, yo[0][j]); yo[1][j] = fmaf(wy1, xo_, yo[1][j]);
+            }
+          }
+#pragma unroll
+          for (int xo = 0; xo < 2; ++xo)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              out[0 + 0 + xo][j] = fmaf(wz0, ye[xo][j], out[0 + 0 + xo][j]);
+              out[0 + 2 + xo][j] = fmaf(wz0, yo[xo][j], out[0 + 2 + xo][j]);
+              out[4 + 0 + xo][j] = fmaf(wz1, ye[xo][j], out[4 + 0 + xo][j]);
+              out[4 + 2 + xo][j] = fmaf(wz1, yo[xo][j], out[4 + 2 + xo][j]);
+            }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
+          Store<T>::ld8(skip + ((((int64_t)b * ds.D + zo + oz) * ds.H + yo + oy) * ds.W + xo + ox) * CPs + (oc - ocu) * 8, out[q]);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
+        Store<T>::st8(cat + ((((int64_t)b * Do + zo) * Ho + yo) * Wo + xo) * CPd + oc * 8, out[q]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float o = sizeof(T) == 2 ? bf2f(f2bf(out[q][j])) : out[q][j];
+          part[0][j] += o; part[1][j] += o * o;
+        }
+      }
+    }
+  }
+  if (stats) block_channel_reduce<2>(part, oc, active, CPd, stats, red);
+}
+extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
+                                         int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
+                                         int32_t Ws, double* stats, sp_stream_t stream) {
+  SP_CHECK_ARG(low && skip && cat && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
+  SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_upsample2_crop_cat_fwd");
+  SP_CHECK_ARG(2 * D <= Ds && 2 * H <= Hs && 2 * W <= Ws, "sp_upsample2_crop_cat_fwd: skip smaller than the upsampled grid");
+  SP_CHECK_ARG(CPd <= 2048, "sp_upsample2_crop_cat_fwd: too many channels");
+  OctMap om = make_octmap(CPd);
+  Dims dl{B, D, H, W}, ds{B, Ds, Hs, Ws};
+  const int64_t nblk = (int64_t)B * D * H * W;          // one thread-slot per 2x2x2 output block
+  const unsigned grid = grid_for(nblk, om.vpb);
+  const size_t sh = (size_t)CPd * 2 * sizeof(float);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, om, stats);
+  else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, om, stats);
+  SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd");
+  return SP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ fused backward pieces
+// Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
+// One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
+// (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,

@@ -262,7 +262,7 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     cat2 = torch.full_like(cat, 3.0)
     st2 = torch.zeros(C0 + C1, 2, dtype=torch.float64, device=DEV)
     O.upsample2_crop_cat_fwd(lows, ys, cat2, dtype, st2)
-    assert torch.equal(cat2, cat)
+    torch.testing.assert_close(cat2.float(), cat.float(), **TOL[dtype])      # separable evaluation: last-bit differences
     cf = cat.double()
     torch.testing.assert_close(st2[:, 0].cpu(), cf.sum(dim=(0, 1, 2, 3)).cpu(), rtol=1e-5, atol=1e-3)
     torch.testing.assert_close(st2[:, 1].cpu(), (cf * cf).sum(dim=(0, 1, 2, 3)).cpu(), rtol=1e-5, atol=1e-3)
