@@ -163,7 +163,7 @@ def bench_cae(args, world, rank, dev):
            "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
            "config": {"workload": "CAE --channelscae 1 16 24 32 100 800 1, batch %d/GPU, 1x%dx128x128 (configs[2])" % (args.batch, d),
-                      "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss),
+                      "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.detach()),
                       "launch": "hipGraph" if graph is not None else "eager"}}
     if rank == 0:
         print(json.dumps(res))
@@ -284,7 +284,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, "
                                "fwd+Dice+bwd+Adam (configs[1])" % (args.batch, args.size, out[0]),
-                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss),
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.detach()),
                    "launch": launch_mode, "dp_mode": args.dp_mode if world > 1 else None},
     }
     # ---- roofline of the dominant kernel, from HIP events recorded around every launch of the timed region
@@ -330,7 +330,7 @@ def main():
             res["torch_gpu_baseline"] = {"error": str(e).splitlines()[0][:200]}
     if rank == 0:
         print(json.dumps(res))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
