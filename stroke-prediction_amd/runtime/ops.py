@@ -253,7 +253,7 @@ class WgradRunner:
         # bf16 fast path: un-padded stride-1 3x3x3 convolution -> DMA double-buffered kernel, BatchNorm folded into finish
         self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and p == (0, 0, 0)
                         and tuple(in_dims) == tuple(d + 2 for d in out_dims) and cpi % 16 == 0 and cpo % 16 == 0
-                        and self.cot <= 2 and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))   # 64-wide outputs: register-staged kernel measured faster
+                        and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "4")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))   # 64-wide outputs: register-staged kernel measured faster
         a.dma = int(self.dma)
         if self.dma:
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", "512"))
