@@ -233,13 +233,21 @@ int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, in
 /* gradient of a block output y that feeds (a) MaxPool3d(2,2) -> BN -> ... and (b) the cropped skip:
  * dz = [ poolbwd(coefp0*gp + coefp1*pool(y) + coefp2) + crop-region(coefs0*gs + coefs1*cat + coefs2) ] * act'(y)
  * either source may be NULL */
+/* (gs, cs0, CPcat): the skip gradient is channels [cs0, cs0+CP) of a tensor with channel pitch CPcat -- the concat
+ * gradient itself, or a dense tensor holding only the skip part (cs0 = 0, CPcat = CP).  (coefs, coef_c0, coef_stride):
+ * its BatchNorm-backward triple is coefs[k*coef_stride + coef_c0 + c]; coef_stride <= 0: (cs0, CPcat) apply.  cat is
+ * unused (the skip half of the concat buffer is a copy of y) and may be NULL. */
 int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
-                         const float* coefs, int32_t cs0, int32_t CPcat, int32_t dtype, int32_t B, int32_t D,
+                         const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                         int32_t dtype, int32_t B, int32_t D,
                          int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
                          float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
 /* gradient through trilinear x2: dz[lowres] = upsample^T(coef0*g + coef1*cat + coef2)[channels 0..CP) * act'(y) */
+/* g: channel pitch CPcat, the upsampled part in channels [0, CP); coef[k*coef_stride + c] (coef_stride <= 0: CPcat).
+ * cat (the concat buffer, same pitch as g) is only read by the gather fallback (channel counts whose octets do not
+ * divide 256); NULL otherwise. */
 int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
-                         int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
+                         int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                          float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ network output side + Dice (Unet3D.py:53,75-77;

@@ -625,7 +625,7 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
 template <typename T>
 __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
-    const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, Dims di, int CP, Dims dc,
+    const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, int ccs0, int cstride, Dims di, int CP, Dims dc,
     OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias) {
   extern __shared__ float red[];
   float* cpl = red + CP;                              // pool-side coefficients [3][CP]: used once per window -> LDS, not VGPRs
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
   for (int j = 0; j < 8; ++j) {
     part[0][j] = 0.f;
     const int c = oc * 8 + j;
-    s0[j] = (gs && active) ? coefs[cs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[CPcat + cs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * CPcat + cs0 + c] : 0.f;
+    s0[j] = (gs && active) ? coefs[ccs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[cstride + ccs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * cstride + ccs0 + c] : 0.f;
   }
   const Unflat uf_(Dw, Hw, Ww);
   if (active) {
@@ -713,20 +713,22 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
   if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
 }
 extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
-                                    const float* coefs, int32_t cs0, int32_t CPcat, int32_t dtype, int32_t B, int32_t D,
+                                    const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                                    int32_t dtype, int32_t B, int32_t D,
                                     int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
   SP_CHECK_ARG(y && dz && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
   SP_CHECK_VOX((int64_t)B * D * H * W, "sp_pool_skip_act_bwd");
   SP_CHECK_ARG(!gp || coefp, "sp_pool_skip_act_bwd: pool gradient without coefficients");
-  SP_CHECK_ARG(!gs || (cat && coefs && cs0 % 8 == 0 && cs0 + CP <= CPcat && Dc <= D && Hc <= H && Wc <= W), "sp_pool_skip_act_bwd: bad skip arguments");
+  SP_CHECK_ARG(!gs || (coefs && cs0 % 8 == 0 && cs0 + CP <= CPcat && Dc <= D && Hc <= H && Wc <= W), "sp_pool_skip_act_bwd: bad skip arguments");
+  if (coef_stride <= 0) { coef_stride = CPcat; coef_c0 = cs0; }      // coefficients laid out like the gradient tensor
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W}, dc{B, Dc, Hc, Wc};
   const int64_t nwin = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   const unsigned grid = grid_for(nwin, om.vpb);
   const size_t sh = (size_t)CP * 4 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(pool_skip_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);
-  else hipLaunchKernelGGL(pool_skip_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, di, CP, dc, om, act, act_param, (float*)dz, dbias_sums);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(pool_skip_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);
+  else hipLaunchKernelGGL(pool_skip_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act, act_param, (float*)dz, dbias_sums);
   SP_CHECK_LAUNCH("sp_pool_skip_act_bwd");
   return SP_OK;
 }
@@ -742,7 +744,7 @@ __device__ __forceinline__ void upT_axis(int i, int N, int o[4], float w[4]) {
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2_act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ cat,
                                                                  const T* __restrict__ g, const float* __restrict__ coef,
-                                                                 int CPcat, Dims di, int CP, OctMap om, int act, float ap,
+                                                                 int CPcat, int cstride, Dims di, int CP, OctMap om, int act, float ap,
                                                                  T* __restrict__ dz, double* __restrict__ dbias) {
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
@@ -754,7 +756,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_kernel(const T* __restr
   for (int j = 0; j < 8; ++j) {
     part[0][j] = 0.f;
     const int c = oc * 8 + j;
-    c0[j] = active ? coef[c] : 0.f; c1[j] = active ? coef[CPcat + c] : 0.f; c2[j] = active ? coef[2 * CPcat + c] : 0.f;
+    c0[j] = active ? coef[c] : 0.f; c1[j] = active ? coef[cstride + c] : 0.f; c2[j] = active ? coef[2 * cstride + c] : 0.f;
   }
   const Unflat uf_(di.D, di.H, di.W);
   if (active) {
@@ -815,7 +817,7 @@ __device__ __forceinline__ float upM_diag(int i, int N) {
 }
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* __restrict__ y, const T* __restrict__ g,
-                                                                       const float* __restrict__ coef, int CPcat, Dims di,
+                                                                       const float* __restrict__ coef, int CPcat, int cstride, Dims di,
                                                                        int CP, OctMap om, UpTile ut, int act, float ap,
                                                                        T* __restrict__ dz, double* __restrict__ dbias) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = oc * 8 + j;
-    c0[j] = coef[c]; c1[j] = coef[CPcat + c]; c2[j] = 8.f * coef[2 * CPcat + c];
+    c0[j] = coef[c]; c1[j] = coef[cstride + c]; c2[j] = 8.f * coef[2 * cstride + c];
     part[0][j] = 0.f;
   }
   float Acur[8], Anext[8], qprev[8], qcur[8], qnext[8], ycur[8], ynext[8];
@@ -973,9 +975,10 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
 }
 
 extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
-                                    int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
+                                    int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
-  SP_CHECK_ARG(y && cat && g && coef && dz && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
+  SP_CHECK_ARG(y && g && coef && dz && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
+  if (coef_stride <= 0) coef_stride = CPcat;
   SP_CHECK_VOX((int64_t)B * D * H * W * 8, "sp_upsample2_act_bwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
@@ -1000,20 +1003,21 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
       if (dtype == SP_BF16) {
         auto kern = upsample2_act_bwd_tiled_kernel<bf16_t>;
         SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");
-        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, di, CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums);
+        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, coef_stride, di, CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums);
       } else {
         auto kern = upsample2_act_bwd_tiled_kernel<float>;
         SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");
-        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const float*)y, (const float*)g, coef, CPcat, di, CP, om, ut, act, act_param, (float*)dz, dbias_sums);
+        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const float*)y, (const float*)g, coef, CPcat, coef_stride, di, CP, om, ut, act, act_param, (float*)dz, dbias_sums);
       }
       SP_CHECK_LAUNCH("sp_upsample2_act_bwd");
       return SP_OK;
     }
   }
+  SP_CHECK_ARG(cat, "sp_upsample2_act_bwd: the gather fallback needs the concat buffer (same pitch as g)");
   const unsigned grid = grid_for((int64_t)B * D * H * W, om.vpb);
   const size_t sh = (size_t)CP * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(upsample2_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)cat, (const bf16_t*)g, coef, CPcat, di, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);
-  else hipLaunchKernelGGL(upsample2_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)cat, (const float*)g, coef, CPcat, di, CP, om, act, act_param, (float*)dz, dbias_sums);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(upsample2_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)cat, (const bf16_t*)g, coef, CPcat, coef_stride, di, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);
+  else hipLaunchKernelGGL(upsample2_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)cat, (const float*)g, coef, CPcat, coef_stride, di, CP, om, act, act_param, (float*)dz, dbias_sums);
   SP_CHECK_LAUNCH("sp_upsample2_act_bwd");
   return SP_OK;
 }

@@ -55,7 +55,7 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True, cpi=None, bank=None):
+                 need_input_grad=True, cpi=None, bank=None, split_g=None):
         self.name, self.kind = name, kind
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.in_dims, self.batch, self.dtype, self.device = tuple(in_dims), batch, dtype, device
@@ -63,6 +63,7 @@ class ConvLayer:
         self.act, self.act_param = act, act_param
         self.out_dtype = dtype if out_dtype is None else out_dtype
         self.need_input_grad = need_input_grad
+        self.split_g = split_g      # channel count of the first part of a concatenated input: its gradient and the rest's go to two dense tensors
         self.cpi, self.cpo = (cpi or O.cpad(cin)), O.cpad(cout)
         mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
         self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
@@ -150,7 +151,16 @@ class ConvLayer:
         # run at all for the first layer of a network, whose input gradient nobody wants.
         self.bn_from_wgrad = bool(self.bn_prefix is not None and self.kind == "conv" and self.wgrad.folds(self.scale)
                                   and max(P._triple(p)) == 0 and O.BN_SUMS_FROM_WGRAD)
-        if self.need_input_grad or (self.bn_prefix is not None and not self.bn_from_wgrad):
+        if self.split_g and self.kind == "conv" and self.need_input_grad and self.bn_from_wgrad:
+            # gradient of a channel-concatenated input as one dense tensor per part: both consumers (upsample backward,
+            # pool/skip backward) then read whole lines instead of 64 / 32 bytes of every 96-byte row
+            self.dgrad_parts, self.g_parts = [], []
+            for ci0, cn in ((0, self.split_g), (self.split_g, cin - self.split_g)):
+                pop = P.conv_dgrad_op(cn, cout, k, s, p, self.in_dims, self.cpo, O.cpad(cn), dt, cin_total=cin)
+                self.dgrad_parts.append((O.ConvRunner(pop, dev), ci0 * kk))
+                self.g_parts.append(O.alloc_cl(self.batch, self.in_dims, O.cpad(cn), dt, dev))
+            self.g = tuple(self.g_parts)
+        elif self.need_input_grad or (self.bn_prefix is not None and not self.bn_from_wgrad):
             self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}))
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
         if self.bn_prefix is not None:
@@ -184,8 +194,7 @@ class ConvLayer:
                 finish()
                 self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
             if self.need_input_grad:
-                self.dgrad.prep(w)
-                self.dgrad.run(self.dz, self.g, self.batch)
+                self._run_dgrad(w)
             f.join()
             return (self.g, self.coef) if self.need_input_grad else (None, None)
         if self.kind == "conv":
@@ -210,6 +219,15 @@ class ConvLayer:
             O.bn_bwd_reduce(self.g, x, self.dtype, bs)
         self._bn_bwd_finalize(bs, params, grads, STATS_NREP if fused else 1)
         return self.g, self.coef
+
+    def _run_dgrad(self, w):
+        if getattr(self, "dgrad_parts", None):
+            for (runner, woff), g in zip(self.dgrad_parts, self.g_parts):
+                runner.prep(w.view(-1)[woff:])
+                runner.run(self.dz, g, self.batch)
+        else:
+            self.dgrad.prep(w)
+            self.dgrad.run(self.dz, self.g, self.batch)
 
     def _bn_bwd_finalize(self, bs, params, grads, nrep):
         p = self.bn_prefix

@@ -397,19 +397,21 @@ def crop_copy(src, dst, c0, dtype, stats=None):
     L.call("sp_crop_copy", ptr(src), ptr(dst), dtype, B, Ds, Hs, Ws, CPs, Dd, Hd, Wd, CPd, c0, ptr(stats), stream())
 
 
-def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias):
+def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias, coef_c0=0, coef_stride=0):
+    """gs: gradient tensor holding the skip part in channels [cs0, cs0+CP) (pitch gs.shape[-1]); coefs indexed with
+    (coef_c0, coef_stride) when the gradient is a dense tensor of the skip part only (else like the gradient)."""
     B, D, H, W, CP = y.shape
-    if cat is not None:
-        _, Dc, Hc, Wc, CPcat = cat.shape
+    if gs is not None:
+        _, Dc, Hc, Wc, CPcat = gs.shape
     else:
         Dc = Hc = Wc = CPcat = 0
-    L.call("sp_pool_skip_act_bwd", ptr(y), ptr(gp), ptr(coefp), ptr(cat), ptr(gs), ptr(coefs), cs0, CPcat, dtype,
-           B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), stream())
+    L.call("sp_pool_skip_act_bwd", ptr(y), ptr(gp), ptr(coefp), ptr(cat), ptr(gs), ptr(coefs), cs0, CPcat, coef_c0, coef_stride,
+           dtype, B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), stream())
 
 
-def upsample2_act_bwd(y, cat, g, coef, dtype, act, act_param, dz, dbias):
+def upsample2_act_bwd(y, cat, g, coef, dtype, act, act_param, dz, dbias, coef_stride=0):
     B, D, H, W, CP = y.shape
-    L.call("sp_upsample2_act_bwd", ptr(y), ptr(cat), ptr(g), ptr(coef), cat.shape[-1], dtype, B, D, H, W, CP, act,
+    L.call("sp_upsample2_act_bwd", ptr(y), ptr(cat), ptr(g), ptr(coef), g.shape[-1], coef_stride, dtype, B, D, H, W, CP, act,
            act_param, ptr(dz), ptr(dbias), stream())
 
 

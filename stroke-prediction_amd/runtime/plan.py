@@ -124,15 +124,17 @@ def _transposed_subs(k, s, p, in_dims, y_dims):
     return subs
 
 
-def conv_dgrad_op(cin, cout, k, stride, pad, in_dims, cp_dz, cp_g, dtype=0):
+def conv_dgrad_op(cin, cout, k, stride, pad, in_dims, cp_dz, cp_g, dtype=0, cin_total=None):
     """Data gradient of nn.Conv3d(cin->cout): dz (on the conv's output grid) -> g (on ``in_dims``).
-    Output positions no tap reaches (strided convs) are NOT written: caller zero-fills g."""
+    Output positions no tap reaches (strided convs) are NOT written: caller zero-fills g.
+    cin_total: the op covers ``cin`` consecutive input channels of a weight with ``cin_total`` of them (the caller
+    offsets the weight pointer): gradient of ONE part of a channel-concatenated input into its own dense tensor."""
     k, s, p = _triple(k), _triple(stride), _triple(pad)
     out = tuple((in_dims[a] + 2 * p[a] - k[a]) // s[a] + 1 for a in range(3))
     kk = k[0] * k[1] * k[2]
     subs = _transposed_subs(k, s, p, out, tuple(in_dims))
     # roles swap: "cout" of this op is the conv's cin.  element (co'=ci, ci'=co, tap) = w[co, ci, tap]
-    return _finish(ConvOp(cout, cin, cp_dz, cp_g, out, tuple(in_dims), (1, 1, 1), kk, cin * kk, subs, dtype))
+    return _finish(ConvOp(cout, cin, cp_dz, cp_g, out, tuple(in_dims), (1, 1, 1), kk, (cin_total or cin) * kk, subs, dtype))
 
 
 def convT_fwd_op(cin, cout, k, stride, pad, in_dims, cpi, cpo, dtype=0):

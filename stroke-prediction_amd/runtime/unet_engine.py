@@ -44,10 +44,11 @@ class UnetEngine:
                                  "convolutions (minimum 44 per axis)" % (tuple(dims),))
         self.scratch = sc = Scratch(device)
         mk = lambda name, ci, co, d, bn=True, k=3, act=L.ACT_LEAKY, ap=LEAKY, out_dtype=None, blk=None, idx=None, \
-            need_g=True, cpi=None: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc,
+            need_g=True, cpi=None, split=None: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc,
                                              bn_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx)) if bn else None,
                                              conv_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx + 1)) if bn else name,
-                                             act=act, act_param=ap, out_dtype=out_dtype, need_input_grad=need_g, cpi=cpi)
+                                             act=act, act_param=ap, out_dtype=out_dtype, need_input_grad=need_g, cpi=cpi,
+                                             split_g=split)
         sub = lambda d, k: tuple(x - k for x in d)
         half = lambda d: tuple(x // 2 for x in d)
         dbl = lambda d: tuple(2 * x for x in d)
@@ -73,11 +74,12 @@ class UnetEngine:
         d32 = sub(dp2, 4)
         dc4 = dbl(d32)
         assert b3 % 8 == 0 and b4 % 8 == 0, "up-path channel counts must be multiples of 8"
-        self.c41 = mk("b4c1", b3 + b2, b4, dc4, blk="block4", idx=0)
+        split_ok = lambda cu, cs: cu if (256 % (cu // 8) == 0 and cu % 16 == 0 and cs % 16 == 0 and os.environ.get("SP_SPLIT_G")) else None   # measured: two data-gradient launches cost more (+45 us) than the dense reads save -> opt-in
+        self.c41 = mk("b4c1", b3 + b2, b4, dc4, blk="block4", idx=0, split=split_ok(b3, O.cpad(b2)))
         self.c42 = mk("b4c2", b4, b4, sub(dc4, 2), blk="block4", idx=3)
         d42 = sub(dc4, 4)
         dc5 = dbl(d42)
-        self.c51 = mk("b5c1", b4 + b1, b5, dc5, blk="block5", idx=0)
+        self.c51 = mk("b5c1", b4 + b1, b5, dc5, blk="block5", idx=0, split=split_ok(b4, O.cpad(b1)))
         self.c52 = mk("b5c2", b5, b5, sub(dc5, 2), blk="block5", idx=3)
         d52 = sub(dc5, 4)
         self.h0 = mk("classify.0", b5, bc, d52, bn=False, k=1)
@@ -148,6 +150,23 @@ class UnetEngine:
         O.cl_to_ncdhw(o, seg, L.SP_F32)
         return seg
 
+    def _up_bwd(self, low, cat, g, coef):
+        """gradient of the upsampled half of a concat input -> dz of the low-resolution producer `low`"""
+        dt = self.dtype
+        if isinstance(g, tuple):      # dense per-part gradient tensors (ConvLayer split_g)
+            O.upsample2_act_bwd(low.y, None, g[0], coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums, coef_stride=cat.shape[-1])
+        else:
+            O.upsample2_act_bwd(low.y, cat, g, coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums)
+
+    def _skip_bwd(self, prod, gp, coefp, cat, g, coef, c_up):
+        """pool gradient + skip half of the concat gradient -> dz of the block output `prod`"""
+        dt = self.dtype
+        if isinstance(g, tuple):
+            O.pool_skip_act_bwd(prod.y, gp, coefp, None, g[1], coef, 0, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums,
+                                coef_c0=c_up, coef_stride=cat.shape[-1])
+        else:
+            O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums)
+
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dseg, seg, params, grads):
         """dseg: dL/dseg (NCDHW fp32).  Accumulates into ``grads[name]`` (fp32 tensors, parameter layout).
@@ -189,21 +208,19 @@ class UnetEngine:
         g, coef = c.c52.backward(c.c51.y, params, grads)
         O.bn_act_bwd(g, c.c51.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c51.dz, c.c51.dbias_sums)
         g5, coef5 = c.c51.backward(c.cat5, params, grads)
-        O.upsample2_act_bwd(c.c42.y, c.cat5, g5, coef5, dt, L.ACT_LEAKY, LEAKY, c.c42.dz, c.c42.dbias_sums)
+        self._up_bwd(c.c42, c.cat5, g5, coef5)
         g, coef = c.c42.backward(c.c41.y, params, grads)
         O.bn_act_bwd(g, c.c41.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c41.dz, c.c41.dbias_sums)
         g4, coef4 = c.c41.backward(c.cat4, params, grads)
-        O.upsample2_act_bwd(c.c32.y, c.cat4, g4, coef4, dt, L.ACT_LEAKY, LEAKY, c.c32.dz, c.c32.dbias_sums)
+        self._up_bwd(c.c32, c.cat4, g4, coef4)
         g, coef = c.c32.backward(c.c31.y, params, grads)
         O.bn_act_bwd(g, c.c31.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c31.dz, c.c31.dbias_sums)
         gp2, coefp2 = c.c31.backward(c.p2, params, grads)
-        O.pool_skip_act_bwd(c.c22.y, gp2, coefp2, c.cat4, g4, coef4, self.channels[3], dt, L.ACT_LEAKY, LEAKY,
-                            c.c22.dz, c.c22.dbias_sums)
+        self._skip_bwd(c.c22, gp2, coefp2, c.cat4, g4, coef4, self.channels[3])
         g, coef = c.c22.backward(c.c21.y, params, grads)
         O.bn_act_bwd(g, c.c21.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c21.dz, c.c21.dbias_sums)
         gp1, coefp1 = c.c21.backward(c.p1, params, grads)
-        O.pool_skip_act_bwd(c.c12.y, gp1, coefp1, c.cat5, g5, coef5, self.channels[4], dt, L.ACT_LEAKY, LEAKY,
-                            c.c12.dz, c.c12.dbias_sums)
+        self._skip_bwd(c.c12, gp1, coefp1, c.cat5, g5, coef5, self.channels[4])
         g, coef = c.c12.backward(c.c11.y, params, grads)
         if self.first_packed and coef is not None and c.c11.cpo == 16:
             c.c11.backward(c.x0, params, grads, g=g, coef=coef)     # dz formed inside the weight-gradient kernel

@@ -291,6 +291,13 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     O.upsample2_act_bwd(lows, cat, gcs, coefs.to(DEV), dtype, L.ACT_ELU, 1.0, dzl, None)
     elu_d = torch.where(low > 0, torch.ones_like(low), low + 1.0)
     torch.testing.assert_close(from_cl(dzl, C0, dtype), glow_ref * elu_d, **TOL[dtype])
+    # the same two kernels fed with one DENSE gradient tensor per concat part (coefficients indexed separately)
+    g_up, g_skip = to_cl(g_cat[:, :C0], C0, dtype), to_cl(g_cat[:, C0:], C1, dtype)
+    dz2, dzl2 = torch.zeros_like(dz), torch.zeros_like(dzl)
+    O.pool_skip_act_bwd(ys, gps, coefp.to(DEV), None, g_skip, coefs.to(DEV), 0, dtype, L.ACT_LEAKY, 0.01, dz2, None,
+                        coef_c0=C0, coef_stride=cp_cat)
+    O.upsample2_act_bwd(lows, None, g_up, coefs.to(DEV), dtype, L.ACT_ELU, 1.0, dzl2, None, coef_stride=cp_cat)
+    assert torch.equal(dz2, dz) and torch.equal(dzl2, dzl)
 
 
 def test_dice_and_output_grad():
