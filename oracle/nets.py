@@ -108,8 +108,9 @@ def unet_forward(sd, x, training=True, return_all=False, q=_ident):
     b4 = unet_block(sd, "block4", torch.cat((u3, center_crop(b2, u3)), dim=1), training, q)
     u4 = q(upsample2(b4))
     b5 = unet_block(sd, "block5", torch.cat((u4, center_crop(b1, u4)), dim=1), training, q)
-    # (the HIP path fuses the classify head: fp32 weights, hidden layer never stored -> no rounding point here)
-    h = F.leaky_relu(F.conv3d(b5, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY)
+    # (the HIP path fuses the classify head: weights enter as hi + lo bf16 pairs = fp32 accuracy; the hidden layer is
+    # never stored but is rounded to bf16 as the operand of the second matrix product)
+    h = q(F.leaky_relu(F.conv3d(b5, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY))
     seg = torch.sigmoid(F.conv3d(h, sd["classify.2.weight"], sd["classify.2.bias"]))
     if return_all:
         return seg, dict(b1=b1, b2=b2, b3=b3, b4=b4, b5=b5)

@@ -168,12 +168,86 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
   for (int i = tid; i < NQ; i += 256) part[(size_t)blockIdx.x * NQ + i] = rec[i] + rec[NQ + i] + rec[2 * NQ + i] + rec[3 * NQ + i];
 }
 
-// ---- bf16 storage: the parameter gradients are 1-tap weight gradients, i.e. GEMMs with K = voxels.  Each wave owns
-// 64 voxels per iteration (lane = voxel) and its own LDS tiles [voxel][16 ch] (32 B rows, the layout
-// ds_read_b64_tr_b16 turns into MFMA fragments): X, DHP (CH/16 planes), H (CH/16 planes) and AUX = (do_0..do_{NC-1},
-// 1, 0...).  Per 32 voxels:  dW1[p] += DHP_p^T X,  [dW2; sum h][p] += AUX^T H_p,  [.; db1][p] += AUX^T DHP_p.
-// No workgroup barrier: a wave only reads what it wrote (LDS is in-order per wave).  Weights come through the
-// scalar cache (uniform addresses), not LDS.
+// ---- bf16 storage: everything on the matrix pipe.  A wave owns 64 voxels per iteration as 4 column groups of 16
+// (MFMA column = voxel n = lane % 16, K slice / row quad lg = lane / 16):
+//   hp = W1 x      v_mfma 16x16x16, B operand = the lane's own 8 bytes x[v][4lg..4lg+3] straight from global memory;
+//   o  = W2 h,  dx = W1^T dhp   chained: the D layout of the first product (rows 4lg..4lg+3 of each 16-row tile)
+//                  IS a valid B operand once the weights' K order is permuted to match (no shuffle, no LDS);
+//   dW1, db1, dW2  K = voxels: the per-voxel vectors go through per-wave LDS tiles [voxel][16 ch] and come back
+//                  transposed (ds_read_b64_tr_b16); AUX = (do_0..do_{NC-1}, 1, 0..) yields dW2 and db1 from one operand.
+// Weights enter as hi + lo bf16 pairs (two MFMAs per product): fp32-weight accuracy at bf16 activation precision.
+typedef __attribute__((ext_vector_type(4))) short hd_bf16x4;
+
+template <int NP> struct HeadK;      // second-stage operand: 8 (CH = 32) or 4 (CH = 16) K elements per lane
+template <> struct HeadK<2> {
+  typedef bf16x8 vec;
+  static __device__ __forceinline__ int k_of(int lg, int e) { return e < 4 ? 4 * lg + e : 16 + 4 * lg + (e - 4); }
+  static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct HeadK<1> {
+  typedef hd_bf16x4 vec;
+  static __device__ __forceinline__ int k_of(int lg, int e) { return 4 * lg + e; }
+  static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+};
+__device__ __forceinline__ void hd_split(float w, short& hi, short& lo) {
+  const bf16_t h = f2bf(w);
+  hi = (short)h; lo = (short)f2bf(w - bf2f(h));
+}
+
+template <int CH, int NC>
+__global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const bf16_t* __restrict__ x, int64_t nvox_per_b, int64_t total,
+                                                             int CP, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float slope, float* __restrict__ seg) {
+  constexpr int C = 16, NP = CH / 16, KV = 4 * NP;
+  typedef typename HeadK<NP>::vec kvec;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
+  hd_bf16x4 a1h[NP], a1l[NP];
+#pragma unroll
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { short h, l; hd_split(w1[(16 * t + n) * C + 4 * lg + e], h, l); a1h[t][e] = h; a1l[t][e] = l; }
+  kvec a2h, a2l;
+#pragma unroll
+  for (int e = 0; e < KV; ++e) { short h, l; hd_split(n < NC ? w2[n * CH + HeadK<NP>::k_of(lg, e)] : 0.f, h, l); a2h[e] = h; a2l[e] = l; }
+  float b1k[NP][4];
+#pragma unroll
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b1k[t][j] = b1[16 * t + 4 * lg + j];
+  const FastDiv dnv = make_fastdiv((uint32_t)nvox_per_b);      // total < 2^31 (host-checked): 32-bit magic division
+  const int64_t niter = (total + 255) / 256;
+  for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t v = it * 256 + wave * 64 + g * 16 + n;
+      const bool valid = v < total;
+      hd_bf16x4 xb = {0, 0, 0, 0};
+      if (valid) xb = *reinterpret_cast<const hd_bf16x4*>(x + v * CP + 4 * lg);
+      short hb[KV];
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        f32x4 hp = {b1k[t][0], b1k[t][1], b1k[t][2], b1k[t][3]};
+        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1h[t], xb, hp, 0, 0, 0);
+        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1l[t], xb, hp, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hb[4 * t + j] = (short)f2bf(fmaxf(hp[j], slope * hp[j]));
+      }
+      kvec hv;
+#pragma unroll
+      for (int e = 0; e < KV; ++e) hv[e] = hb[e];
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+      o = HeadK<NP>::mma(a2h, hv, o);
+      o = HeadK<NP>::mma(a2l, hv, o);
+      if (valid && lg == 0) {                              // rows 0..3 = classes 0..3 of voxel v
+        const int64_t b = fdiv((uint32_t)v, dnv), r = v - b * nvox_per_b;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) seg[(b * NC + c) * nvox_per_b + r] = 1.f / (1.f + __expf(-(o[c] + b2[c])));
+      }
+    }
+  }
+}
+
 template <int CH, int NC>
 __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ seg,
                                                              const float* __restrict__ dseg, int64_t nvox_per_b,
@@ -181,11 +255,13 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __rest
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              float slope, int act_x, float act_x_p,
                                                              bf16_t* __restrict__ dz, float* __restrict__ part) {
-  constexpr int C = 16, NP = CH / 16, NPL = 2 + 2 * NP;      // planes: X, AUX, DHP[NP], H[NP]
-  constexpr int PLANE = 64 * 32;                              // bytes of one 64-voxel plane
+  constexpr int C = 16, NP = CH / 16, NPL = 2 + 2 * NP, KV = 4 * NP;      // planes: X, AUX, DHP[NP], H[NP]
+  constexpr int PLANE = 64 * 32;                                          // bytes of one 64-voxel plane
+  typedef typename HeadK<NP>::vec kvec;
+  static_assert(NC <= 3, "AUX row = (do_0..do_{NC-1}, 1) packs into four bf16");
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * NPL * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lg = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3;
+  const int lg = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3, n = li;
   unsigned char* wt = lds + wave * NPL * PLANE;
   unsigned char* tX = wt;
   unsigned char* tA = wt + PLANE;
@@ -196,118 +272,121 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __rest
   const int vq1 = ((lg & 1) ? 2 * lg : 2 * lg + 1) * 4 + lq;
   const int off0 = vq0 * 32 + lp * 8, off1 = vq1 * 32 + lp * 8;
 
+  hd_bf16x4 a1h[NP], a1l[NP];                         // hp = W1 x
+#pragma unroll
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { short h, l; hd_split(w1[(16 * t + n) * C + 4 * lg + e], h, l); a1h[t][e] = h; a1l[t][e] = l; }
+  kvec aTh, aTl;                                      // dx = W1^T dhp, K order of the chained operand
+#pragma unroll
+  for (int e = 0; e < KV; ++e) { short h, l; hd_split(w1[HeadK<NP>::k_of(lg, e) * C + n], h, l); aTh[e] = h; aTl[e] = l; }
+  float b1k[NP][4], w2k[NC][NP][4];
+#pragma unroll
+  for (int t = 0; t < NP; ++t)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      b1k[t][j] = b1[16 * t + 4 * lg + j];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) w2k[c][t][j] = w2[c * CH + 16 * t + 4 * lg + j];
+    }
+
   f32x4 accW1[NP], accW2[NP], accB1[NP];
 #pragma unroll
   for (int p = 0; p < NP; ++p) accW1[p] = accW2[p] = accB1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbz[C], db2[NC];
-#pragma unroll
-  for (int i = 0; i < C; ++i) dbz[i] = 0.f;
+  float dbz[4] = {0.f, 0.f, 0.f, 0.f}, db2[NC];       // dbz: channels 4lg..4lg+3 of this lane's voxels
 #pragma unroll
   for (int c = 0; c < NC; ++c) db2[c] = 0.f;
 
-  cfloat *cw1 = (cfloat*)w1, *cb1 = (cfloat*)b1, *cw2 = (cfloat*)w2;
+  const FastDiv dnv = make_fastdiv((uint32_t)nvox_per_b);      // total < 2^31 (host-checked): 32-bit magic division
   const int64_t niter = (total + 255) / 256;
   for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
-    const int64_t v = it * 256 + tid;
-    uint32_t pa[2] = {0, 0};
-    uint4 xr0 = make_uint4(0, 0, 0, 0), xr1 = xr0;
-    if (v < total) {
-      xr0 = *reinterpret_cast<const uint4*>(x + v * CP);
-      xr1 = *reinterpret_cast<const uint4*>(x + v * CP + 8);
-      float xv[C];
-      {
-        const uint32_t w[8] = {xr0.x, xr0.y, xr0.z, xr0.w, xr1.x, xr1.y, xr1.z, xr1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { xv[2 * i] = __uint_as_float(w[i] << 16); xv[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
-      }
-      const int64_t b = v / nvox_per_b, r = v - b * nvox_per_b;
+    for (int g = 0; g < 4; ++g) {
+      const int64_t v = it * 256 + wave * 64 + g * 16 + n;
+      const bool valid = v < total;
+      hd_bf16x4 xb = {0, 0, 0, 0};
       float dov[NC];
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        const int64_t o = (b * NC + c) * nvox_per_b + r;
-        const float sg = seg[o];
-        dov[c] = dseg[o] * sg * (1.f - sg);
-        db2[c] += dov[c];
+      for (int c = 0; c < NC; ++c) dov[c] = 0.f;
+      if (valid) {
+        xb = *reinterpret_cast<const hd_bf16x4*>(x + v * CP + 4 * lg);
+        const int64_t b = fdiv((uint32_t)v, dnv), r = v - b * nvox_per_b;
+        if (NC == 2) {      // the four lanes of a voxel share the loads: even quads read class 0, odd quads class 1
+          const int64_t o = (b * NC + (lg & 1)) * nvox_per_b + r;
+          const float sg = seg[o];
+          dov[lg & 1] = dseg[o] * sg * (1.f - sg);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const int64_t o = (b * NC + c) * nvox_per_b + r;
+            const float sg = seg[o];
+            dov[c] = dseg[o] * sg * (1.f - sg);
+          }
+        }
       }
-      // AUX row: do_0 .. do_{NC-1}, 1, 0 ...
-      {
+      if (NC == 2) {        // exchange with the neighbouring quad (lane ^ 16 holds the other class of the same voxel)
+        const float mine = (lg & 1) ? dov[NC - 1] : dov[0];
+        const float other = __shfl_xor(mine, 16, 64);
+        dov[0] = (lg & 1) ? other : mine;
+        dov[NC - 1] = (lg & 1) ? mine : other;
+      }
+      short db_[KV], hb_[KV];
+#pragma unroll
+      for (int t = 0; t < NP; ++t) {
+        f32x4 hp = {b1k[t][0], b1k[t][1], b1k[t][2], b1k[t][3]};
+        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1h[t], xb, hp, 0, 0, 0);
+        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1l[t], xb, hp, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float dh = 0.f;
+#pragma unroll
+          for (int c = 0; c < NC; ++c) dh = fmaf(w2k[c][t][j], dov[c], dh);
+          db_[4 * t + j] = (short)f2bf(dh * (hp[j] > 0.f ? 1.f : slope));
+          hb_[4 * t + j] = (short)f2bf(fmaxf(hp[j], slope * hp[j]));
+        }
+      }
+      kvec dv;
+#pragma unroll
+      for (int e = 0; e < KV; ++e) dv[e] = db_[e];
+      f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+      dx = HeadK<NP>::mma(aTh, dv, dx);
+      dx = HeadK<NP>::mma(aTl, dv, dx);
+      if (valid) {
+        float o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xv = bf2f((bf16_t)xb[j]);
+          o4[j] = dx[j] * act_bwd_from_y(act_x, act_x_p, xv);
+          dbz[j] += o4[j];
+        }
+        Store<bf16_t>::st4(dz + v * CP + 4 * lg, o4);
+        if (lg == 0) {
+          for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < NC; ++c) db2[c] += dov[c];
+        }
+      }
+      // ---- this lane's 8 bytes of its voxel's row in every plane
+      const int ro = (g * 16 + n) * 32 + 8 * lg;
+      *reinterpret_cast<hd_bf16x4*>(tX + ro) = xb;
+      uint32_t a0 = 0, a1 = 0;
+      if (lg == 0) {
         float aux[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NC; ++c) aux[c] = dov[c];
-        aux[NC] = 1.f;
-        pa[0] = (uint32_t)f2bf(aux[0]) | ((uint32_t)f2bf(aux[1]) << 16);
-        pa[1] = (uint32_t)f2bf(aux[2]) | ((uint32_t)f2bf(aux[3]) << 16);
+        aux[NC] = valid ? 1.f : 0.f;
+        a0 = (uint32_t)f2bf(aux[0]) | ((uint32_t)f2bf(aux[1]) << 16);
+        a1 = (uint32_t)f2bf(aux[2]) | ((uint32_t)f2bf(aux[3]) << 16);
       }
-      float dx[C];
+      *reinterpret_cast<uint2*>(tA + ro) = make_uint2(a0, a1);
 #pragma unroll
-      for (int i = 0; i < C; ++i) dx[i] = 0.f;
-      // k loop kept rolled (two hidden channels per trip, the next pair's weights prefetched into SGPRs): unrolled,
-      // the scheduler hoists all 600 weight s_loads to the top and spills them into VGPR lanes
-      float wc[2 * C], bc[2], vc[2 * NC];
-#pragma unroll
-      for (int i = 0; i < 2 * C; ++i) wc[i] = cw1[i];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        bc[q] = cb1[q];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) vc[q * NC + c] = cw2[c * CH + q];
-      }
-#pragma unroll 1
-      for (int k = 0; k < CH; k += 2) {
-        const int kn = (k + 2 < CH) ? k + 2 : 0;
-        float wn[2 * C], bn[2], vn[2 * NC];
-#pragma unroll
-        for (int i = 0; i < 2 * C; ++i) wn[i] = cw1[kn * C + i];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          bn[q] = cb1[kn + q];
-#pragma unroll
-          for (int c = 0; c < NC; ++c) vn[q * NC + c] = cw2[c * CH + kn + q];
-        }
-        float dhp2[2], h2[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          float hp = bc[q];
-#pragma unroll
-          for (int i = 0; i < C; ++i) hp = fmaf(wc[q * C + i], xv[i], hp);
-          float dh = 0.f;
-#pragma unroll
-          for (int c = 0; c < NC; ++c) dh = fmaf(vc[q * NC + c], dov[c], dh);
-          dhp2[q] = dh * (hp > 0.f ? 1.f : slope);
-          h2[q] = fmaxf(hp, slope * hp);
-#pragma unroll
-          for (int i = 0; i < C; ++i) dx[i] = fmaf(wc[q * C + i], dhp2[q], dx[i]);
-        }
-        // channel pair k, k+1 of this voxel's DHP / H rows (plane k/16, 32-byte rows)
-        const int po = (k >> 4) * PLANE + lane * 32 + (k & 15) * 2;
-        *reinterpret_cast<uint32_t*>(tD + po) = (uint32_t)f2bf(dhp2[0]) | ((uint32_t)f2bf(dhp2[1]) << 16);
-        *reinterpret_cast<uint32_t*>(tH + po) = (uint32_t)f2bf(h2[0]) | ((uint32_t)f2bf(h2[1]) << 16);
-#pragma unroll
-        for (int i = 0; i < 2 * C; ++i) wc[i] = wn[i];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) bc[i] = bn[i];
-#pragma unroll
-        for (int i = 0; i < 2 * NC; ++i) vc[i] = vn[i];
-      }
-#pragma unroll
-      for (int i = 0; i < C; ++i) { dx[i] *= act_bwd_from_y(act_x, act_x_p, xv[i]); dbz[i] += dx[i]; }
-      Store<bf16_t>::st8(dz + v * CP, dx);
-      Store<bf16_t>::st8(dz + v * CP + 8, dx + 8);
-      for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<uint4*>(tD + p * PLANE + lane * 32) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(tD + p * PLANE + lane * 32 + 16) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(tH + p * PLANE + lane * 32) = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(tH + p * PLANE + lane * 32 + 16) = make_uint4(0, 0, 0, 0);
+      for (int t = 0; t < NP; ++t) {
+        hd_bf16x4 d4 = {db_[4 * t], db_[4 * t + 1], db_[4 * t + 2], db_[4 * t + 3]};
+        hd_bf16x4 h4 = {hb_[4 * t], hb_[4 * t + 1], hb_[4 * t + 2], hb_[4 * t + 3]};
+        *reinterpret_cast<hd_bf16x4*>(tD + t * PLANE + ro) = d4;
+        *reinterpret_cast<hd_bf16x4*>(tH + t * PLANE + ro) = h4;
       }
     }
-    // ---- this lane's voxel row into every plane
-    *reinterpret_cast<uint4*>(tX + lane * 32) = xr0;
-    *reinterpret_cast<uint4*>(tX + lane * 32 + 16) = xr1;
-    *reinterpret_cast<uint4*>(tA + lane * 32) = make_uint4(pa[0], pa[1], 0, 0);
-    *reinterpret_cast<uint4*>(tA + lane * 32 + 16) = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -349,9 +428,9 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __rest
     if (lane == 0) stage[CH * C + CH + NC * CH + c] = s2;
   }
 #pragma unroll
-  for (int i = 0; i < C; ++i) {
-    const float s = wave_sum(dbz[i]);
-    if (lane == 0) stage[NQ0 + i] = s;
+  for (int j = 0; j < 4; ++j) {
+    const float sj = row16_sum(dbz[j]);              // over the 16 voxel lanes of this channel quad
+    if (n == 0) stage[NQ0 + 4 * lg + j] = sj;
   }
   __syncthreads();
   for (int i = tid; i < NQ; i += 256) part[(size_t)blockIdx.x * NQ + i] = st0[i] + st0[NQ + i] + st0[2 * NQ + i] + st0[3 * NQ + i];
@@ -401,13 +480,14 @@ extern "C" int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
                            const float* b1, int32_t CH, const float* w2, const float* b2, int32_t NC, float slope,
                            float* seg, sp_stream_t stream) {
   SP_CHECK_ARG(x && w1 && b1 && w2 && b2 && seg && CP >= C && CP % 8 == 0, "sp_head_fwd: bad arguments");
+  SP_CHECK_ARG((int64_t)B * nvox_per_b < (1ll << 31), "sp_head_fwd: 2^31 voxels or more");
   SP_CHECK_ARG(sp_head_supported(C, CH, NC), "sp_head_fwd: no fused kernel for C=%d CH=%d NC=%d", C, CH, NC);
   const int64_t total = (int64_t)B * nvox_per_b;
   const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(c, h, n)                                                                                                   \
   if (C == c && CH == h && NC == n) {                                                                                \
-    if (dtype == SP_BF16) hipLaunchKernelGGL((head_fwd_kernel<c, h, n, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg); \
+    if (dtype == SP_BF16) hipLaunchKernelGGL((head_fwd_mfma_kernel<h, n>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg); \
     else hipLaunchKernelGGL((head_fwd_kernel<c, h, n, float>), dim3(grid), dim3(256), 0, st, (const float*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg); \
   }
   HEAD_CASES(X)
@@ -431,7 +511,7 @@ extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
   SP_CHECK_ARG(sp_head_supported(C, CH, NC), "sp_head_bwd: no fused kernel for C=%d CH=%d NC=%d", C, CH, NC);
   SP_CHECK_ARG(CH * C / 8 <= 64 && NC * CH <= 64 && CH <= 64, "sp_head_bwd: reduction tile does not fit a wave");
   const int64_t total = (int64_t)B * nvox_per_b;
-  SP_CHECK_ARG(total > 0, "sp_head_bwd: empty input");
+  SP_CHECK_ARG(total > 0 && total < (1ll << 31), "sp_head_bwd: empty input or 2^31 voxels or more");
   const int rec = CH + CH + C + 4;
   const int lds = (CH * C + CH + NC * CH + 256 * rec) * (int)sizeof(float);
   SP_CHECK_ARG(lds <= 160 * 1024, "sp_head_bwd: LDS %d", lds);

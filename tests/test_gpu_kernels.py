@@ -380,7 +380,8 @@ def test_fused_head(dtype, C, CH, NC, CP):
     seg = torch.empty((B, NC) + dims, dtype=torch.float32, device=DEV)
     L.call("sp_head_fwd", O.ptr(x_cl), dtype, nv, B, CP, C, O.ptr(W1), O.ptr(B1), CH, O.ptr(W2), O.ptr(B2), NC, 0.01,
            O.ptr(seg), O.stream())
-    torch.testing.assert_close(seg.cpu(), seg_ref.detach(), rtol=1e-5, atol=1e-5)
+    # bf16 storage: the hidden layer is the bf16 operand of the second matrix product (2^-9 relative per element)
+    torch.testing.assert_close(seg.cpu(), seg_ref.detach(), rtol=1e-5, atol=1e-5 if dtype == L.SP_F32 else 3e-3)
 
     dz = torch.full_like(x_cl, 7.0)
     dbs = torch.zeros(CP, dtype=torch.float64, device=DEV)
