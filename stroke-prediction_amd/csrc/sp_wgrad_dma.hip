@@ -123,9 +123,14 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
     q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; t = q;
     q = fdiv(t, P.d_tz); const int tz = t - q * P.ntz; const int b = q;
     const int oz0 = tz * P.TZ, oy0 = ty * P.TY, ox0 = tx * 32;
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xg + ((((size_t)b * a.Di + oz0) * a.Hi + oy0) * a.Wi + ox0) * a.CPi);
+    // input origin of the tile: output origin + o0 (o0 = -padding <= 0: the origin may lie before the volume; such
+    // chunks are zero-filled below and their addresses never dereferenced)
+    const int iz0 = oz0 + a.o0D, iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(xg) +
+                              ((((int64_t)b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * a.CPi * 2;
     const unsigned char* db = reinterpret_cast<const unsigned char*>(dzg + ((((size_t)b * a.Do + oz0) * a.Ho + oy0) * a.Wo + ox0) * a.CPo);
-    const bool interior = oz0 + P.TZ <= a.Do && oy0 + P.TY <= a.Ho && ox0 + 32 <= a.Wo;
+    const bool interior = oz0 + P.TZ <= a.Do && oy0 + P.TY <= a.Ho && ox0 + 32 <= a.Wo &&
+                          iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + P.XD <= a.Di && iy0 + P.XH <= a.Hi && ix0 + P.XW <= a.Wi;
     unsigned char* base = lds + buf * P.buf_bytes;
     unsigned char* dbase = base + P.dz_off;
     if (interior) {
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
         if (j < P.njx) {
           const int cz = crdx[j] & 0xff, cy = (crdx[j] >> 8) & 0xff, cx = (crdx[j] >> 16) & 0xff;
           unsigned char* dst = base + (wave + 4 * j) * 1024;
-          if (oz0 + cz < a.Di && oy0 + cy < a.Hi && ox0 + cx < a.Wi)
+          if ((unsigned)(iz0 + cz) < (unsigned)a.Di && (unsigned)(iy0 + cy) < (unsigned)a.Hi && (unsigned)(ix0 + cx) < (unsigned)a.Wi)
             sp_dma16(xb + relx[j], dst);
           else
             *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);
@@ -258,9 +263,11 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
 
 int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype == SP_BF16 && !a->in_scale && !a->dz_scale, "sp_conv3d_wgrad(dma): bf16, no affine on load");
-  SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->o0D == 0 && a->o0H == 0 && a->o0W == 0, "sp_conv3d_wgrad(dma): stride 1, padding 0 only");
+  SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->o0D <= 0 && a->o0H <= 0 && a->o0W <= 0 && a->o0D >= -2 && a->o0H >= -2 && a->o0W >= -2,
+               "sp_conv3d_wgrad(dma): stride 1, padding 0..2 only");
   SP_CHECK_ARG(a->ntap > 21 && a->ntap <= 28, "sp_conv3d_wgrad(dma): expects 22..28 taps (7 per wave)");
-  SP_CHECK_ARG(a->Di == a->Do + a->kD - 1 && a->Hi == a->Ho + a->kH - 1 && a->Wi == a->Wo + a->kW - 1, "sp_conv3d_wgrad(dma): not an un-padded convolution");
+  SP_CHECK_ARG(a->Di - 2 * a->o0D == a->Do + a->kD - 1 && a->Hi - 2 * a->o0H == a->Ho + a->kH - 1 && a->Wi - 2 * a->o0W == a->Wo + a->kW - 1,
+               "sp_conv3d_wgrad(dma): input / output extents do not match a stride-1 convolution with this padding");
   WgradDmaDev P;
   P.a = *a;
   int COB = a->CoT >= 4 ? 4 : (a->CoT >= 2 ? 2 : 1);

@@ -76,9 +76,19 @@ class ConvLayer:
         self.fold = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and max(pads) == 0
                          and all(s.tile["dma"] for s in self.fwd_op.subs))
         self.scratch = scratch
+        # Padded bf16 convolutions behind a BatchNorm (the CAE): zero padding applies AFTER the normalisation, so the
+        # BatchNorm cannot be folded into the weights, and a DMA cannot normalise on load.  The normalised input is
+        # therefore written once (one elementwise pass) and both the forward conv and the weight gradient run on the
+        # DMA kernels with plain zero-fill (register-staged kernels: 2-2.5x slower per voxel).
+        strides = stride if isinstance(stride, (tuple, list)) else (stride,) * 3
+        self.materialize = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and not self.fold
+                                and max(pads) > 0 and max(pads) <= 2 and max(strides) == 1 and k == 3 and self.cpi % 16 == 0
+                                and self.cpo % 16 == 0 and all(s.tile["dma"] for s in self.fwd_op.subs) and O.MATERIALIZE_BN)
+        self.xhat = None
         if bn_prefix is not None:
-            self.scale = torch.zeros(self.cpi, device=device)
-            self.shift = torch.zeros(self.cpi, device=device)
+            self.apply_coef = torch.zeros(3, self.cpi, device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift
+            self.scale = self.apply_coef[0]
+            self.shift = self.apply_coef[2]
             self.mean = torch.zeros(self.cpi, device=device)
             self.invstd = torch.zeros(self.cpi, device=device)
             self.in_sums_id = scratch.reserve(self.cpi * 2 * STATS_NREP)
@@ -117,6 +127,14 @@ class ConvLayer:
             self._bn_fwd(params, bufs, training)
         c = self.conv_prefix
         y = self.alloc_out()
+        if self.materialize:
+            if self.xhat is None:
+                self.xhat = torch.empty_like(x)
+            O.bn_act_bwd(x, x, self.apply_coef, self.dtype, L.ACT_NONE, 0.0, self.xhat, None)      # xhat = scale*x + shift
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
+            self.fwd.run(self.xhat, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
+                         stats_nrep=STATS_NREP)
+            return y
         if self.fold:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
@@ -197,7 +215,10 @@ class ConvLayer:
                 self._run_dgrad(w)
             f.join()
             return (self.g, self.coef) if self.need_input_grad else (None, None)
-        if self.kind == "conv":
+        if self.kind == "conv" and self.materialize:
+            self.wgrad.run(self.xhat, self.dz, self.batch, grads[c + ".weight"], None, None,
+                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+        elif self.kind == "conv":
             self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
                            dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
         else:

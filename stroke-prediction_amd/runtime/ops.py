@@ -21,6 +21,7 @@ def bump_param_epoch():
 
 
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
+MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
 WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
@@ -231,6 +232,7 @@ class WgradRunner:
                  nblocks=512):
         k, s, p = P._triple(k), P._triple(stride), P._triple(pad)
         self.cin, self.cout, self.k = cin, cout, k
+        self.unpadded = max(p) == 0
         self.w_sco, self.w_sci = w_sco, w_sci
         taps = [(a, b, c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])]
         self.ntap = len(taps)
@@ -251,8 +253,8 @@ class WgradRunner:
         a.CoT, a.CiT = self.cot, self.cit
         a.nblocks = nblocks
         # bf16 fast path: un-padded stride-1 3x3x3 convolution -> DMA double-buffered kernel, BatchNorm folded into finish
-        self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and p == (0, 0, 0)
-                        and tuple(in_dims) == tuple(d + 2 for d in out_dims) and cpi % 16 == 0 and cpo % 16 == 0
+        self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and max(p) <= 2
+                        and tuple(in_dims) == tuple(d + 2 - 2 * q for d, q in zip(out_dims, p)) and cpi % 16 == 0 and cpo % 16 == 0
                         and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "4")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))   # 64-wide outputs: register-staged kernel measured faster
         a.dma = int(self.dma)
         if self.dma:
@@ -265,7 +267,8 @@ class WgradRunner:
         self.dtype = dtype
 
     def folds(self, in_scale):
-        return bool(self.dma and in_scale is not None)
+        """BatchNorm folded into the finish step (raw x in the kernel): exact only without padding"""
+        return bool(self.dma and in_scale is not None and self.unpadded)
 
     def _alloc_acc(self, batch):
         """Accumulator block(s).  WGRAD_PARTS: one block per persistent workgroup, written with plain stores and summed
@@ -303,10 +306,10 @@ class WgradRunner:
         if self.acc is None or self.acc_batch != batch:
             self._alloc_acc(batch)
         a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
-        fold = self.dma and in_scale is not None
+        fold = self.folds(in_scale)
         if fold:
             assert dbias_sums is not None and dz_scale is None
-        a.dma = int(self.dma and dz_scale is None)
+        a.dma = int(self.dma and dz_scale is None and (fold or in_scale is None))   # a padded conv behind a BatchNorm cannot fold: register-staged kernel
         a.in_scale, a.in_shift = (None, None) if fold else (ptr(in_scale), ptr(in_shift))
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
