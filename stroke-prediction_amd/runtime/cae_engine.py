@@ -12,6 +12,9 @@ from . import lib as L
 from . import ops as O
 from .layers import ConvLayer, Scratch
 
+import os
+PITCH16 = not os.environ.get("SP_CAE_PITCH8")     # bf16: 16-channel pitches everywhere (24 -> 32 ...) so that the DMA kernels apply
+
 # (kind, cin_key, cout_key, kernel, stride, padding) -- the layer tables of the reference modules
 ENC_LAYERS = [
     ("conv", "in", "o", 3, 1, (1, 0, 0)), ("conv", "o", "o", 3, 1, (1, 0, 0)),
@@ -56,7 +59,8 @@ class StackContext:
             lay = ConvLayer("%s.%d" % (prefix, 3 * i + 1), kind, cm[ci], cm[co], k, s, p, dims, batch, dtype, device, sc,
                             bn_prefix="%s.%d" % (prefix, 3 * i), conv_prefix="%s.%d" % (prefix, 3 * i + 1),
                             act=L.ACT_SIGMOID if last else L.ACT_ELU, act_param=0.0 if last else alpha,
-                            out_dtype=L.SP_F32 if last else None, need_input_grad=True, bank=bank)
+                            out_dtype=L.SP_F32 if last else None, need_input_grad=True, bank=bank,
+                            pitch=16 if (dtype == L.SP_BF16 and PITCH16) else 8)
             self.layers.append(lay)
             dims = lay.out_dims
         self.in_dims, self.out_dims = tuple(in_dims), dims
@@ -64,7 +68,7 @@ class StackContext:
         for lay in self.layers:
             lay.reserve_bwd_scratch()
         sc.finalize()
-        self.x0 = O.alloc_cl(batch, in_dims, O.cpad(self.cin), dtype, device)
+        self.x0 = O.alloc_cl(batch, in_dims, self.layers[0].cpi, dtype, device)
         self.out_dtype = self.layers[-1].out_dtype
 
     def forward(self, x, params, bufs, training):

@@ -55,7 +55,7 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True, cpi=None, bank=None, split_g=None):
+                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8):
         self.name, self.kind = name, kind
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.in_dims, self.batch, self.dtype, self.device = tuple(in_dims), batch, dtype, device
@@ -64,7 +64,8 @@ class ConvLayer:
         self.out_dtype = dtype if out_dtype is None else out_dtype
         self.need_input_grad = need_input_grad
         self.split_g = split_g      # channel count of the first part of a concatenated input: its gradient and the rest's go to two dense tensors
-        self.cpi, self.cpo = (cpi or O.cpad(cin)), O.cpad(cout)
+        # channel pitch of this layer's tensors: multiples of `pitch` (16 lets every 3x3x3 layer use the DMA kernels)
+        self.cpi, self.cpo = (cpi or O.cpad(cin, pitch)), O.cpad(cout, pitch)
         mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
         self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
         self.out_dims = tuple(self.fwd_op.y_dims)
