@@ -54,6 +54,8 @@ class _StackFn(torch.autograd.Function):
 
 
 class CaeBase(FlatParamsMixin, nn.Module):
+    FLAT_NBT = True      # every BatchNorm of a stack runs once per stack call: their step counters advance together
+
     def __init__(self, size_input_xy=128, size_input_z=28, channels=[1, 16, 32, 64, 128, 1024, 128, 1], n_ch_global=2,
                  alpha=0.01, inner_xy=12, inner_z=3, dtype="bf16"):
         super().__init__()
@@ -120,7 +122,7 @@ class CaeBase(FlatParamsMixin, nn.Module):
         state = self.__dict__.copy()
         state["_stack_pool"] = None
         state["_flat_parent"] = None
-        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device"):
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt"):
             state.pop(k, None)
         return state
 
@@ -222,6 +224,6 @@ class Cae3D(FlatParamsMixin, nn.Module):
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device"):
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt"):
             state.pop(k, None)
         return state

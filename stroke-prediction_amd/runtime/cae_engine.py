@@ -75,6 +75,8 @@ class StackContext:
         """x: (B, cin, D, H, W) fp32 on the device -> (B, cout, D', H', W') fp32."""
         assert tuple(x.shape) == (self.batch, self.cin) + self.in_dims, (tuple(x.shape), self.in_dims)
         self.scratch.zero()
+        if training and "__nbt_flat__" in bufs:
+            bufs["__nbt_flat__"].add_(1)
         O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)
         if training:
             O.bn_stats(self.x0, self.dtype, self.layers[0].in_sums)

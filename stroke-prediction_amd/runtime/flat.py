@@ -16,6 +16,7 @@ class FlatParamsMixin:
     _flat_device = None
     grad_sync = None            # optional callable(flat_grad) -> None, installed by parallel.DataParallelSync
     _flat_parent = None         # set on sub-modules whose parameters live in a parent's flat buffer (Cae3D)
+    _flat_nbt = None
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -54,26 +55,27 @@ class FlatParamsMixin:
         self._flat_pviews, self._flat_views = pviews, gviews
         self._flat_names = [n for n, _ in named]
         self._flat_device = dev
-        # BatchNorm step counters: one int64 vector, the modules' buffers are its elements -> one increment per
-        # forward instead of one tiny kernel per BatchNorm (models that opt in with FLAT_NBT)
-        self._flat_nbt = None
-        if getattr(self, "FLAT_NBT", False):
-            mods = [(n, m) for n, m in self.named_modules() if "num_batches_tracked" in getattr(m, "_buffers", {})
-                    and m._buffers["num_batches_tracked"] is not None]
-            if mods:
-                nbt = torch.zeros(len(mods), dtype=torch.int64, device=dev)
-                for i, (_, m) in enumerate(mods):
-                    nbt[i] = m._buffers["num_batches_tracked"].to(dev)
-                    m._buffers["num_batches_tracked"] = nbt[i]
-                self._flat_nbt = nbt
+        # BatchNorm step counters: one int64 vector per module that opts in with FLAT_NBT (every BatchNorm under it runs
+        # exactly once per forward call of that module); the BatchNorms' buffers are its elements -> one increment per
+        # call instead of one tiny kernel per BatchNorm
+        for mod in self.modules():
+            if getattr(mod, "FLAT_NBT", False):
+                bns = [m for m in mod.modules() if m._buffers.get("num_batches_tracked") is not None]
+                if bns:
+                    nbt = torch.zeros(len(bns), dtype=torch.int64, device=dev)
+                    for i, m in enumerate(bns):
+                        nbt[i] = m._buffers["num_batches_tracked"].to(dev)
+                        m._buffers["num_batches_tracked"] = nbt[i]
+                    mod._flat_nbt = nbt
 
     def _param_dict(self):
         self._ensure_flat()
         return {n: p.data for n, p in self.named_parameters()}
 
     def _buffer_dict(self):
+        self._ensure_flat()
         d = dict(self.named_buffers())
-        if getattr(self, "_flat_nbt", None) is not None:
+        if getattr(self, "FLAT_NBT", False) and getattr(self, "_flat_nbt", None) is not None:
             d["__nbt_flat__"] = self._flat_nbt
         return d
 
