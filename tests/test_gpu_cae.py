@@ -156,3 +156,38 @@ def test_cae_learner_trains():
         assert 0.0 <= mtr.lesion.dc <= 1.0
     np.testing.assert_allclose(losses, ref_losses, rtol=0, atol=2e-4)
     assert losses[2] < losses[0]
+
+
+def test_cae_full_size_directional_derivative():
+    """BASELINE.json configs[2] at the closed full depth (1 x 124 x 128 x 128, fc = 800), where the CPU oracle takes
+    minutes: the analytic gradient of the whole 3-encoder / 4-decoder step must reproduce the central finite difference
+    of the loss along a random parameter direction (parity mode).  ELU is C1, so the quotient is smooth."""
+    from stroke_prediction_amd.runtime import ops as O
+    ch = [1, 16, 24, 32, 100, 800, 1]
+    seed, d, hw, epoch = 23, 124, 128, 30
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    cae = build(ch, seed, "f32", d, hw).train()
+    learner, opt = learner_for(cae, [])
+    batch = {"case_id": [0, 1], "images": None, "labels": labels, "clinical": clinical}
+
+    def loss_now():
+        return learner.loss_step(learner.inference_step(batch), epoch)
+
+    loss = loss_now()
+    opt.zero_grad()
+    loss.backward()
+    params = [p for p in cae.parameters()]
+    g = torch.Generator().manual_seed(seed)
+    dirs = [torch.randn(p.shape, generator=g).to(DEV) * p.detach().abs().mean() for p in params]
+    analytic = float(sum((p.grad.double() * dd.double()).sum() for p, dd in zip(params, dirs)))
+    eps, vals = 1e-3, []
+    with torch.no_grad():
+        for sgn in (+1.0, -1.0):
+            for p, dd in zip(params, dirs):
+                p.add_(sgn * eps * dd)
+            O.bump_param_epoch()
+            vals.append(float(loss_now().detach()))
+            for p, dd in zip(params, dirs):
+                p.add_(-sgn * eps * dd)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(analytic - numeric) <= 0.03 * abs(numeric) + 1e-6, (analytic, numeric)

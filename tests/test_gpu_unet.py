@@ -207,3 +207,50 @@ def test_metrics_on_device_match_numpy():
     for k in ("dc", "precision", "sensitivity", "specificity", "hd", "assd"):
         assert abs(getattr(ref, k) - getattr(got, k)) < 1e-12, k
     assert fast.dc == ref.dc and fast.hd == np.inf
+
+
+def test_full_size_directional_derivative():
+    """BASELINE.json configs[1] volume size (2 x 128^3 -> 2 x 88^3), where the CPU oracle is too slow to run in a test:
+    a size-independent property instead.  For a random direction d in parameter space the analytic gradient must
+    reproduce the central finite difference of the loss, <grad L, d> ~= (L(p + e d) - L(p - e d)) / 2e -- this checks
+    every backward kernel against the forward kernels at the full tile / grid configuration of the headline workload
+    (parity mode: the difference quotient needs fp32 forward accuracy).  Also: the bf16 fast path agrees with the
+    parity path on loss and outputs at this size."""
+    seed = 21
+    torch.manual_seed(seed)
+    x, y = W.unet_inputs(1, (128, 128, 128), seed)
+    xd, yd = x.to(DEV), y.to(DEV)
+    model = build(seed, "f32")
+    model.train()
+
+    def loss_of(m):
+        dto = m(UnetDtoUtil.init_dto(xd))
+        seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+        return nets.unet_loss(seg, yd), seg
+
+    loss, seg32 = loss_of(model)
+    loss.backward()
+    params = [p for p in model.parameters()]
+    g = torch.Generator().manual_seed(seed)
+    dirs = [torch.randn(p.shape, generator=g).to(DEV) * p.detach().abs().mean() for p in params]
+    analytic = float(sum((p.grad.double() * d.double()).sum() for p, d in zip(params, dirs)))
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sgn in (+1.0, -1.0):
+            for p, d in zip(params, dirs):
+                p.add_(sgn * eps * d)
+            model._ensure_flat()
+            from stroke_prediction_amd.runtime import ops as O
+            O.bump_param_epoch()                       # weights changed behind the re-pack cache's back
+            vals.append(float(loss_of(model)[0].detach()))
+            for p, d in zip(params, dirs):
+                p.add_(-sgn * eps * d)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(analytic - numeric) <= 0.03 * abs(numeric) + 1e-6, (analytic, numeric)
+    # fast path at the same size: same loss to bf16 accuracy, outputs within 2e-2
+    fast = build(seed, "bf16")
+    fast.train()
+    lf, segf = loss_of(fast)
+    assert abs(float(lf.detach()) - float(loss.detach())) < 5e-3
+    assert float((segf - seg32).abs().max()) < 3e-2
