@@ -196,6 +196,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+    # SP_BENCH_DEVICE / SP_BENCH_BACKEND: rehearsal of the multi-rank code path on a one-GPU box (all ranks on one
+    # device, gloo instead of RCCL, which refuses two ranks per device); never set in a measured run
+    if os.environ.get("SP_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["SP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -203,7 +207,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if os.environ.get("SP_BENCH_BACKEND"):
+            dist.init_process_group(os.environ["SP_BENCH_BACKEND"])
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import stroke_prediction_amd  # noqa: F401  (puts the drop-in packages on sys.path)
     from stroke_prediction_amd.common.model.Unet3D import Unet3D
