@@ -83,12 +83,15 @@ typedef struct sp_conv_args {
   float act_param;
   int32_t dma;                 /* 1: LDS-DMA staging (bf16 in, in_scale NULL, lane-linear planes, +1 KiB LDS slack) */
   int32_t zfill;               /* dma only: taps can leave the input volume -> zero those chunks */
-  int32_t persist;             /* dma only: allow the persistent double-buffered variant where it applies */
+  int32_t persist;             /* dma only: 1/2 allow the persistent double-buffered variant where it applies;
+                                  3: z-marching ring variant -- ktab then holds (in-plane byte offset | dz) per entry and
+                                  ITH_zs the staged plane height (32 output rows + kernel extent - 1) */
   const void* aux;             /* stats_mode 1: tensor shaped like y (the layer input x of a data gradient) */
   int32_t stats_mode;          /* 0: stats = (sum y, sum y^2);  1: stats = (sum y, sum y*aux) -- BatchNorm backward sums
                                   fused into the dgrad epilogue (DMA kernel only) */
   int32_t stats_nrep;          /* power of two >= 1: stats is [stats_nrep][CPo][2]; workgroup b adds to replica b % nrep
                                   (tens of thousands of same-address fp64 atomics otherwise serialise at the memory side) */
+  int32_t ITH_zs;              /* persist == 3 only */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);

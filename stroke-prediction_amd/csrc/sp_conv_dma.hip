@@ -517,6 +517,221 @@ __global__ __launch_bounds__(256) void conv_igemm_persist_kernel(const ConvDmaDe
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// z-marching variant for the 16-channel-in, 16-channel-out stride-1 layers (the largest volumes of the U-Net):
+// a workgroup owns a column of 32 output rows x 16 voxels and walks it in z.  The input lives in a RING of four
+// z-plane slots ((32 + kH - 1) x (15 + kW) voxels x 32 B each): per output plane exactly ONE new input plane is
+// fetched (halo 1.2x instead of 2.1x per tile of the kernel above), its DMA is issued a whole step ahead, the
+// weight fragments and the per-lane DMA plan are set up once per workgroup, the BatchNorm statistics are flushed
+// once.  ktab entries of this variant: in-plane byte offset | dz (low two bits).
+struct ConvZsDev {
+  sp_conv_args a;
+  int32_t ITH, ITW, S, nchunks, ZC, nzc, nty, ntx;
+  uint32_t ncols;
+  FastDiv d_itw, d_tx, d_ty, d_zc;
+};
+
+template <int MT, int KS, typename TOUT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int NJ = 5;                                   // 16-byte chunks of one plane per lane (host-checked)
+  const sp_conv_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lv = lane & 15, lg = lane >> 4;
+  unsigned char* ring = lds;
+
+  int kv[KS];                                             // this lane group's (in-plane offset | dz) per K step
+#pragma unroll
+  for (int s = 0; s < KS; ++s) kv[s] = a.ktab[s * 4 + lg];
+  int vbase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) vbase[m] = ((wave * MT + m) * P.ITW + lv) * 32;
+  const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
+  bf16x8 wreg[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wreg[s] = wf_hi[(size_t)s * a.NTtot * 64 + lane];
+
+  // per-lane DMA plan of one plane: chunk c = (wave + 4j)*64 + lane -> (row vy, voxel vx, half)
+  uint32_t rel[NJ];
+  int crd[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + 4 * j) * 64 + lane;
+    const int cc = c < P.nchunks ? c : P.nchunks - 1;
+    const int half = cc & 1, vox = cc >> 1;
+    const int vy = fdiv(vox, P.d_itw), vx = vox - vy * P.ITW;
+    rel[j] = (uint32_t)(((vy * a.Wi + vx) * a.CPi + half * 8) * 2);
+    crd[j] = vy | (vx << 8) | (c < P.nchunks ? 0 : (1 << 30));       // bit 30: no such chunk (tail of the last round)
+  }
+  const int c0 = lg * 4;
+  float bj[4] = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + c0); bj[0] = bb.x; bj[1] = bb.y; bj[2] = bb.z; bj[3] = bb.w; }
+  const bool cok = c0 < a.CPo;
+  const bool lin = (c0 + 4 <= a.Cout) && (a.act == SP_ACT_LEAKY || a.act == SP_ACT_NONE);
+  const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;
+  const bool want_stats = a.stats != nullptr;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  for (uint32_t col = xcd_remap(blockIdx.x, gridDim.x); col < P.ncols; col += gridDim.x) {
+    uint32_t t = col;
+    uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
+    q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; t = q;
+    q = fdiv(t, P.d_zc); const int zc = t - q * P.nzc; const int b = q;
+    const int oy0 = ty * (4 * MT), ox0 = tx * 16, z0 = zc * P.ZC, z1 = min(a.Do, z0 + P.ZC);
+    const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * a.CPi;
+    // in-plane validity of this lane's chunks (column-invariant): bit j set = inside the volume
+    int vmask = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int vy = crd[j] & 0xff, vx = (crd[j] >> 8) & 0xff;
+      if (!(crd[j] >> 30) && (unsigned)(iy0 + vy) < (unsigned)a.Hi && (unsigned)(ix0 + vx) < (unsigned)a.Wi) vmask |= 1 << j;
+    }
+    auto load_plane = [&](int iz, int slot) {
+      unsigned char* dst0 = ring + slot * P.S;
+      const bool zin = (unsigned)iz < (unsigned)a.Di;
+      const unsigned char* src0 = reinterpret_cast<const unsigned char*>(xin) + (((int64_t)iz * a.Hi + iy0) * a.Wi + ix0) * a.CPi * 2;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        unsigned char* dst = dst0 + (wave + 4 * j) * 1024;
+        if (!(crd[j] >> 30)) {
+          if (zin && ((vmask >> j) & 1)) sp_dma16(src0 + rel[j], dst);
+          else *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);      // padding
+        }
+      }
+    };
+    __syncthreads();                                      // the previous column has been consumed
+    load_plane(z0 + a.o0D, 0);
+    load_plane(z0 + a.o0D + 1, 1);
+    load_plane(z0 + a.o0D + 2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    TOUT* __restrict__ yout = reinterpret_cast<TOUT*>(a.y) + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
+    const int ox = ox0 + lv;
+    for (int z = z0; z < z1; ++z) {
+      const int sl = (z - z0) & 3;
+      if (z + 1 < z1) load_plane(z + a.o0D + 3, (sl + 3) & 3);         // lands behind this step's MFMAs
+      // ---- K loop over the three resident planes
+      f32x4 acc[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 x0[MT], x1[MT];
+#define ZS_OFF(s_) ((((sl + (kv[s_] & 3)) & 3) * P.S) + (kv[s_] & ~15))
+      {
+        const int k0 = ZS_OFF(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) x0[m] = *reinterpret_cast<const bf16x8*>(ring + vbase[m] + k0);
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
+          const int kn = ZS_OFF(s + 1 < KS ? s + 1 : s);
+          if ((s & 1) == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) x1[m] = *reinterpret_cast<const bf16x8*>(ring + vbase[m] + kn);
+          } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) x0[m] = *reinterpret_cast<const bf16x8*>(ring + vbase[m] + kn);
+          }
+        }
+        if ((s & 1) == 0) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x0[m], acc[m], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x1[m], acc[m], 0, 0, 0);
+        }
+      }
+#undef ZS_OFF
+      // ---- epilogue of output plane z
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + wave * MT + m;
+        const bool valid = oy < a.Ho && ox < a.Wo && cok;
+        float v[4];
+        if (lin) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { const float zz = acc[m][j] + bj[j]; v[j] = fmaxf(zz, slope * zz); }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float zz = act_fwd(a.act, a.act_param, acc[m][j] + bj[j]);
+            v[j] = (c0 + j < a.Cout) ? zz : 0.f;
+          }
+        }
+        if (valid) {
+          const size_t off = (size_t)((((z * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo) + c0;
+          Store<TOUT>::st4(yout + off, v);
+          if (want_stats) {
+            if (sizeof(TOUT) == 2) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the plane issued at the top of this step has landed
+      __syncthreads();                                    // and every wave is done with the oldest slot
+    }
+  }
+  if (want_stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < 32; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x1s = row16_sum(s1[j]), x2s = row16_sum(s2[j]);
+      if (lv == 0) { atomicAdd(&red[(lg * 4 + j) * 2], x1s); atomicAdd(&red[(lg * 4 + j) * 2 + 1], x2s); }
+    }
+    __syncthreads();
+    for (int i = tid; i < 32; i += 256) {
+      const int c = i >> 1;
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+    }
+  }
+}
+
+static int launch_zs(const sp_conv_args* a, hipStream_t st) {
+  SP_CHECK_ARG(a->NT == 1 && a->NTtot == 1 && a->ngroups == 1 && a->MT == 8 && a->opp == 2 && a->vsb == 32 && a->octs_per_group == 2,
+               "sp_conv3d_igemm(zs): one 16-channel plane in, one 16-channel tile out");
+  SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->stats_mode == 0 && a->in_scale == nullptr && a->dtype_in == SP_BF16,
+               "sp_conv3d_igemm(zs): stride 1, plain statistics, bf16 input without affine on load");
+  SP_CHECK_ARG(a->steps_per_group == 14 || a->steps_per_group == 7, "sp_conv3d_igemm(zs): 7 or 14 resident K steps");
+  ConvZsDev P;
+  P.a = *a;
+  P.ITH = a->ITH_zs; P.ITW = a->ITW;
+  SP_CHECK_ARG(P.ITH >= 32 && P.ITH <= 40 && P.ITW >= 16 && P.ITW <= 24, "sp_conv3d_igemm(zs): plane extent");
+  P.S = P.ITH * P.ITW * 32;
+  P.nchunks = P.ITH * P.ITW * 2;
+  SP_CHECK_ARG(P.nchunks <= 5 * 256 && 4 * P.S <= 160 * 1024, "sp_conv3d_igemm(zs): plane does not fit the per-lane plan");
+  P.ntx = (a->Wo + 15) / 16; P.nty = (a->Ho + 31) / 32;
+  const int cols_xy = a->B * P.nty * P.ntx;
+  // z chunks: as many columns as fit ONE round of resident workgroups (2 per CU): a second, mostly empty round
+  // would double the kernel time (576 columns on 512 slots: 80 -> 108 us on the 88^3 layer)
+  int nzc = 512 / cols_xy;
+  if (nzc > a->Do / 4) nzc = a->Do / 4;
+  if (nzc < 1) nzc = 1;
+  P.ZC = (a->Do + nzc - 1) / nzc; P.nzc = (a->Do + P.ZC - 1) / P.ZC;
+  P.ncols = (uint32_t)cols_xy * P.nzc;
+  P.d_itw = make_fastdiv(P.ITW); P.d_tx = make_fastdiv(P.ntx); P.d_ty = make_fastdiv(P.nty); P.d_zc = make_fastdiv(P.nzc);
+  const int lds_bytes = 4 * P.S;
+  const unsigned grid = P.ncols < 512u ? P.ncols : 512u;
+#define SP_ZS(K_, T_)                                                                                                \
+  {                                                                                                                  \
+    auto kern = conv_igemm_zs_kernel<8, K_, T_>;                                                                     \
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv");                                                                       \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);                                               \
+  }
+  if (a->steps_per_group == 14) { if (a->dtype_out == SP_F32) SP_ZS(14, float) else SP_ZS(14, bf16_t) }
+  else { if (a->dtype_out == SP_F32) SP_ZS(7, float) else SP_ZS(7, bf16_t) }
+#undef SP_ZS
+  SP_CHECK_LAUNCH("sp_conv3d_igemm(zs)");
+  return SP_OK;
+}
+
 template <int MT, int KS>
 static int launch_persist(ConvDmaDev& P, hipStream_t st) {
   const int buf = (((P.nruns * 1024) + 1023) / 1024) * 1024;
@@ -563,6 +778,7 @@ static int dispatch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
 
 int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 input and no affine on load");
+  if (a->persist == 3) return launch_zs(a, reinterpret_cast<hipStream_t>(stream));      // z-marching plan (ktab in its format)
   SP_CHECK_ARG(a->opp == 1 || a->opp == 2, "sp_conv3d_igemm(dma): octets per plane must be 1 or 2");
   SP_CHECK_ARG(a->vsb == a->opp * 16 && a->plane_bytes == a->ITD * a->ITH * a->ITW * a->vsb, "sp_conv3d_igemm(dma): planes must be lane-linear (no padding)");
   SP_CHECK_ARG(a->octs_per_group % a->opp == 0, "sp_conv3d_igemm(dma): group does not consist of whole planes");

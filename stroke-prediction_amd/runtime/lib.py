@@ -25,7 +25,7 @@ class ConvArgs(C.Structure):
                    "dtype_in", "dtype_out", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "YD", "YH", "YW", "CPo",
                    "osD", "osH", "osW", "ooD", "ooH", "ooW", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
                    "TD", "TH", "ITD", "ITH", "ITW", "MT", "NT", "NTtot", "ngroups", "octs_per_group", "opp", "vsb",
-                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32)]
+                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32)]
 
 
 class WgradArgs(C.Structure):

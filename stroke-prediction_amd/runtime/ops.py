@@ -24,6 +24,7 @@ BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backwa
 MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
 WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
+USE_ZS = bool(int(os.environ.get("SP_CONV_ZS", "1")))     # z-marching ring conv variant for the 16->16-channel stride-1 layers (-20 %)
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
 
 # optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
@@ -129,6 +130,7 @@ class ConvRunner:
                 hi = torch.empty(frag_elems, dtype=torch.bfloat16, device=device)
                 lo = torch.empty(frag_elems, dtype=torch.bfloat16, device=device) if op.dtype == L.SP_F32 else None
                 subs.append(dict(sub=sub, kmap=_dev_i32(sub.kmap, device), ktab=_dev_i32(sub.ktab, device),
+                                 ktab_zs=None if getattr(sub, "ktab_zs", None) is None else _dev_i32(sub.ktab_zs, device),
                                  hi=hi, lo=lo, nsteps=nsteps))
             st["subs"] = subs
             st["bias"] = torch.zeros(op.nttot * 16, dtype=torch.float32, device=device)
@@ -220,6 +222,8 @@ class ConvRunner:
                 setattr(a, k, t[k])
             a.dma = int(t["dma"] and in_scale is None and USE_DMA)
             a.persist = int(USE_PERSIST)
+            if USE_ZS and a.dma and s.get("ktab_zs") is not None and stats_mode == 0 and a.CPo >= 16:
+                a.persist, a.ktab, a.ITH_zs = 3, ptr(s["ktab_zs"]), t["ITH_zs"]     # z-marching ring variant
             with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout,
                         "%d->%d @%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_igemm", C.byref(a), st)

@@ -274,6 +274,22 @@ def _plan_sub(op: ConvOp, sub: SubConv):
                     lo_offset=tile_bytes if np_planes == 2 else 0, lds_bytes=lds, read_cycles=cost(vs),
                     dma=dma, zfill=zfill)
     sub.kmap, sub.ktab = kmap, ktab
+    # z-marching ring variant of the DMA kernel (sp_conv_dma.hip, conv_igemm_zs_kernel): one 16-channel plane in, one
+    # 16-channel tile out, stride 1, resident weights.  Same K order (same weight fragments); its table holds the
+    # in-plane offset inside a (32 + ext_y - 1) x ITW plane slot, with the tap's z index in the low two bits.
+    sub.ktab_zs = None
+    if (dma and s == (1, 1, 1) and ngroups == 1 and opg == 2 and op.cpi == 16 and resident and steps in (7, 14)
+            and -(-op.cout // 16) == 1 and ext[0] <= 3 and mt == 8 and sub.out_dims[1] >= 32):
+        kz = np.zeros(steps * 4, dtype=np.int32)
+        for i, e in enumerate(seq):
+            if e is None:
+                kz[i] = kz[i - 1] if i else 0          # padding entries carry zero weights: any valid address
+                continue
+            ti, oc = e
+            t = sub.taps[ti]
+            kz[i] = ((t[1] * itw + t[2]) * vsb + (oc % opp) * 16) | t[0]
+        sub.ktab_zs = kz
+        sub.tile["ITH_zs"] = 31 * s[1] + ext[1]
 
 
 def _finish(op: ConvOp):
