@@ -531,8 +531,8 @@ struct ConvZsDev {
   FastDiv d_itw, d_tx, d_ty, d_zc;
 };
 
-template <int MT, int KS, typename TOUT>
-__global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P) {
+template <int NT, int MT, int KS, typename TOUT>
+__global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void conv_igemm_zs_kernel(const ConvZsDev P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int NJ = 5;                                   // 16-byte chunks of one plane per lane (host-checked)
   const sp_conv_args& a = P.a;
@@ -547,9 +547,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
 #pragma unroll
   for (int m = 0; m < MT; ++m) vbase[m] = ((wave * MT + m) * P.ITW + lv) * 32;
   const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
-  bf16x8 wreg[KS];
+  bf16x8 wreg[KS][NT];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) wreg[s] = wf_hi[(size_t)s * a.NTtot * 64 + lane];
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wreg[s][n] = wf_hi[((size_t)s * a.NTtot + n) * 64 + lane];
 
   // per-lane DMA plan of one plane: chunk c = (wave + 4j)*64 + lane -> (row vy, voxel vx, half)
   uint32_t rel[NJ];
@@ -563,14 +565,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
     rel[j] = (uint32_t)(((vy * a.Wi + vx) * a.CPi + half * 8) * 2);
     crd[j] = vy | (vx << 8) | (c < P.nchunks ? 0 : (1 << 30));       // bit 30: no such chunk (tail of the last round)
   }
-  const int c0 = lg * 4;
-  float bj[4] = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) { const float4 bb = *reinterpret_cast<const float4*>(a.bias + c0); bj[0] = bb.x; bj[1] = bb.y; bj[2] = bb.z; bj[3] = bb.w; }
-  const bool cok = c0 < a.CPo;
-  const bool lin = (c0 + 4 <= a.Cout) && (a.act == SP_ACT_LEAKY || a.act == SP_ACT_NONE);
+  float bj[NT][4], s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bj[n][j] = a.bias ? a.bias[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
+  const bool linact = a.act == SP_ACT_LEAKY || a.act == SP_ACT_NONE;
   const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;
   const bool want_stats = a.stats != nullptr;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 
   for (uint32_t col = xcd_remap(blockIdx.x, gridDim.x); col < P.ncols; col += gridDim.x) {
     uint32_t t = col;
@@ -612,9 +614,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
       const int sl = (z - z0) & 3;
       if (z + 1 < z1) load_plane(z + a.o0D + 3, (sl + 3) & 3);         // lands behind this step's MFMAs
       // ---- K loop over the three resident planes
-      f32x4 acc[MT];
+      f32x4 acc[NT][MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
       bf16x8 x0[MT], x1[MT];
 #define ZS_OFF(s_) ((((sl + (kv[s_] & 3)) & 3) * P.S) + (kv[s_] & ~15))
       {
@@ -636,10 +640,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
         }
         if ((s & 1) == 0) {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x0[m], acc[m], 0, 0, 0);
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s][n], x0[m], acc[n][m], 0, 0, 0);
         } else {
 #pragma unroll
-          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x1[m], acc[m], 0, 0, 0);
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s][n], x1[m], acc[n][m], 0, 0, 0);
         }
       }
 #undef ZS_OFF
@@ -647,28 +655,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
         const int oy = oy0 + wave * MT + m;
-        const bool valid = oy < a.Ho && ox < a.Wo && cok;
-        float v[4];
-        if (lin) {
+        const bool inside = oy < a.Ho && ox < a.Wo;
+        const size_t vo = (size_t)((((z * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float zz = acc[m][j] + bj[j]; v[j] = fmaxf(zz, slope * zz); }
-        } else {
+        for (int n = 0; n < NT; ++n) {
+          const int c0 = n * 16 + lg * 4;
+          const bool lin = linact && (c0 + 4 <= a.Cout);
+          float v[4];
+          if (lin) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float zz = act_fwd(a.act, a.act_param, acc[m][j] + bj[j]);
-            v[j] = (c0 + j < a.Cout) ? zz : 0.f;
-          }
-        }
-        if (valid) {
-          const size_t off = (size_t)((((z * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo) + c0;
-          Store<TOUT>::st4(yout + off, v);
-          if (want_stats) {
-            if (sizeof(TOUT) == 2) {
+            for (int j = 0; j < 4; ++j) { const float zz = acc[n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); }
+          } else {
 #pragma unroll
-              for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
+            for (int j = 0; j < 4; ++j) {
+              const float zz = act_fwd(a.act, a.act_param, acc[n][m][j] + bj[n][j]);
+              v[j] = (c0 + j < a.Cout) ? zz : 0.f;
             }
+          }
+          if (inside && c0 < a.CPo) {
+            Store<TOUT>::st4(yout + vo + c0, v);
+            if (want_stats) {
+              if (sizeof(TOUT) == 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { s1[j] += v[j]; s2[j] = fmaf(v[j], v[j], s2[j]); }
+                for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], v[j], s2[n][j]); }
+            }
           }
         }
       }
@@ -679,15 +692,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
   if (want_stats) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < 32; i += 256) red[i] = 0.f;
+    for (int i = tid; i < NT * 32; i += 256) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float x1s = row16_sum(s1[j]), x2s = row16_sum(s2[j]);
-      if (lv == 0) { atomicAdd(&red[(lg * 4 + j) * 2], x1s); atomicAdd(&red[(lg * 4 + j) * 2 + 1], x2s); }
-    }
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
+        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+      }
     __syncthreads();
-    for (int i = tid; i < 32; i += 256) {
+    for (int i = tid; i < NT * 32; i += 256) {
       const int c = i >> 1;
       if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
     }
@@ -695,38 +710,44 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zs_kernel(const ConvZsDev P
 }
 
 static int launch_zs(const sp_conv_args* a, hipStream_t st) {
-  SP_CHECK_ARG(a->NT == 1 && a->NTtot == 1 && a->ngroups == 1 && a->MT == 8 && a->opp == 2 && a->vsb == 32 && a->octs_per_group == 2,
-               "sp_conv3d_igemm(zs): one 16-channel plane in, one 16-channel tile out");
+  SP_CHECK_ARG(a->NT == a->NTtot && a->NT >= 1 && a->NT <= 3 && a->ngroups == 1 && a->opp == 2 && a->vsb == 32 && a->octs_per_group == 2,
+               "sp_conv3d_igemm(zs): one 16-channel plane in, up to three 16-channel tiles out");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->stats_mode == 0 && a->in_scale == nullptr && a->dtype_in == SP_BF16,
                "sp_conv3d_igemm(zs): stride 1, plain statistics, bf16 input without affine on load");
-  SP_CHECK_ARG(a->steps_per_group == 14 || a->steps_per_group == 7, "sp_conv3d_igemm(zs): 7 or 14 resident K steps");
+  SP_CHECK_ARG(a->steps_per_group == 14 || (a->steps_per_group == 7 && a->NT == 1), "sp_conv3d_igemm(zs): 14 (or 7) resident K steps");
   ConvZsDev P;
   P.a = *a;
-  P.ITH = a->ITH_zs; P.ITW = a->ITW;
-  SP_CHECK_ARG(P.ITH >= 32 && P.ITH <= 40 && P.ITW >= 16 && P.ITW <= 24, "sp_conv3d_igemm(zs): plane extent");
+  const int MT = a->NT == 3 ? 4 : 8;                   // rows per wave: three resident weight tiles leave room for 4
+  P.ITH = 4 * MT + (a->ITH_zs - 32); P.ITW = a->ITW;   // ITH_zs = 32 + kernel extent - 1 (planner)
+  SP_CHECK_ARG(a->ITH_zs >= 32 && a->ITH_zs <= 40 && P.ITW >= 16 && P.ITW <= 24, "sp_conv3d_igemm(zs): plane extent");
   P.S = P.ITH * P.ITW * 32;
   P.nchunks = P.ITH * P.ITW * 2;
   SP_CHECK_ARG(P.nchunks <= 5 * 256 && 4 * P.S <= 160 * 1024, "sp_conv3d_igemm(zs): plane does not fit the per-lane plan");
-  P.ntx = (a->Wo + 15) / 16; P.nty = (a->Ho + 31) / 32;
+  P.ntx = (a->Wo + 15) / 16; P.nty = (a->Ho + 4 * MT - 1) / (4 * MT);
   const int cols_xy = a->B * P.nty * P.ntx;
-  // z chunks: as many columns as fit ONE round of resident workgroups (2 per CU): a second, mostly empty round
-  // would double the kernel time (576 columns on 512 slots: 80 -> 108 us on the 88^3 layer)
-  int nzc = 512 / cols_xy;
+  // z chunks: as many columns as fit ONE round of resident workgroups: a second, mostly empty round would double the
+  // kernel time (576 columns on 512 slots: 80 -> 108 us on the 88^3 layer)
+  const int slots = a->NT == 1 ? 512 : 256;
+  int nzc = slots / cols_xy;
   if (nzc > a->Do / 4) nzc = a->Do / 4;
   if (nzc < 1) nzc = 1;
   P.ZC = (a->Do + nzc - 1) / nzc; P.nzc = (a->Do + P.ZC - 1) / P.ZC;
   P.ncols = (uint32_t)cols_xy * P.nzc;
   P.d_itw = make_fastdiv(P.ITW); P.d_tx = make_fastdiv(P.ntx); P.d_ty = make_fastdiv(P.nty); P.d_zc = make_fastdiv(P.nzc);
   const int lds_bytes = 4 * P.S;
-  const unsigned grid = P.ncols < 512u ? P.ncols : 512u;
-#define SP_ZS(K_, T_)                                                                                                \
+  const unsigned grid = P.ncols < (unsigned)slots ? P.ncols : (unsigned)slots;
+#define SP_ZS(N_, M_, K_, T_)                                                                                        \
   {                                                                                                                  \
-    auto kern = conv_igemm_zs_kernel<8, K_, T_>;                                                                     \
+    auto kern = conv_igemm_zs_kernel<N_, M_, K_, T_>;                                                                \
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv");                                                                       \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);                                               \
   }
-  if (a->steps_per_group == 14) { if (a->dtype_out == SP_F32) SP_ZS(14, float) else SP_ZS(14, bf16_t) }
-  else { if (a->dtype_out == SP_F32) SP_ZS(7, float) else SP_ZS(7, bf16_t) }
+#define SP_ZS_T(N_, M_, K_) { if (a->dtype_out == SP_F32) SP_ZS(N_, M_, K_, float) else SP_ZS(N_, M_, K_, bf16_t) }
+  if (a->NT == 1 && a->steps_per_group == 14) SP_ZS_T(1, 8, 14)
+  else if (a->NT == 1) SP_ZS_T(1, 8, 7)
+  else if (a->NT == 2) SP_ZS_T(2, 8, 14)
+  else SP_ZS_T(3, 4, 14)
+#undef SP_ZS_T
 #undef SP_ZS
   SP_CHECK_LAUNCH("sp_conv3d_igemm(zs)");
   return SP_OK;

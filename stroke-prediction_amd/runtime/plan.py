@@ -248,6 +248,7 @@ def _plan_sub(op: ConvOp, sub: SubConv):
     steps = len(seq) // 4
     nt_guess = _pick_nt(-(-op.cout // 16))[0]
     resident = steps in (1, 2, 4, 7, 14) and steps * nt_guess <= 16
+    zs_steps = steps in (7, 14)       # the z-marching variant keeps up to 14 x 3 weight fragments itself
     if dma and not resident and steps % 2:      # run-time K loop of the DMA kernel works on step pairs
         seq += [None] * 4
         steps += 1
@@ -278,8 +279,9 @@ def _plan_sub(op: ConvOp, sub: SubConv):
     # 16-channel tile out, stride 1, resident weights.  Same K order (same weight fragments); its table holds the
     # in-plane offset inside a (32 + ext_y - 1) x ITW plane slot, with the tap's z index in the low two bits.
     sub.ktab_zs = None
-    if (dma and s == (1, 1, 1) and ngroups == 1 and opg == 2 and op.cpi == 16 and resident and steps in (7, 14)
-            and -(-op.cout // 16) == 1 and ext[0] <= 3 and mt == 8 and sub.out_dims[1] >= 32):
+    if (dma and s == (1, 1, 1) and ngroups == 1 and opg == 2 and op.cpi == 16 and zs_steps
+            and -(-op.cout // 16) <= 2 and ext[0] <= 3 and mt == 8      # (three output tiles: 359 VGPRs, measured 1.7x slower)
+            and sub.out_dims[1] >= 32):
         kz = np.zeros(steps * 4, dtype=np.int32)
         for i, e in enumerate(seq):
             if e is None:

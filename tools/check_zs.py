@@ -8,35 +8,37 @@ torch.manual_seed(0)
 def run(op, x, w, b, zs, stats):
     O.USE_ZS = zs
     r = O.ConvRunner(op, dev); r.prep(w, b)
-    y = O.alloc_cl(x.shape[0], op.y_dims, 16, dt, dev); y.fill_(7.0)
-    st = torch.zeros(64, 16, 2, dtype=torch.float64, device=dev) if stats else None
+    y = O.alloc_cl(x.shape[0], op.y_dims, CPO, dt, dev); y.fill_(7.0)
+    st = torch.zeros(64, CPO, 2, dtype=torch.float64, device=dev) if stats else None
     r.run(x, y, x.shape[0], None, None, L.ACT_LEAKY, 0.01, st, stats_nrep=64)
     torch.cuda.synchronize()
     return y, (st.sum(0) if stats else None)
-for dims, B in (((40, 70, 50), 2), ((37, 45, 17), 1), ((126, 126, 126), 4)):
+CO = int(os.environ.get("CO", "16"))
+CPO = -(-CO // 16) * 16
+for dims, B in (((40, 70, 50), 2), ((37, 45, 17), 1), ((int(os.environ.get("D", "126")),) * 3, 4)):
     for mode in ("fwd", "dgrad"):
         if mode == "fwd":
-            op = P.conv_fwd_op(16, 16, 3, 1, 0, dims, 16, 16, dt)
+            op = P.conv_fwd_op(16, CO, 3, 1, 0, dims, 16, CPO, dt)
             xin = dims
         else:
-            op = P.conv_dgrad_op(16, 16, 3, 1, 0, dims, 16, 16, dt)
+            op = P.conv_dgrad_op(CO, 16, 3, 1, 0, dims, 16, CPO, dt)      # gradient wrt a CO-channel input, dz has 16
             xin = tuple(d - 2 for d in dims)
         if getattr(op.subs[0], "ktab_zs", None) is None:
             print(dims, mode, "not eligible"); continue
         x = torch.randn((B,) + xin + (16,), device=dev).bfloat16()
-        w = torch.randn(16, 16, 3, 3, 3, device=dev) * 0.1
-        b = torch.randn(16, device=dev) * 0.1 if mode == "fwd" else None
+        w = (torch.randn(CO, 16, 3, 3, 3, device=dev) if mode == "fwd" else torch.randn(16, CO, 3, 3, 3, device=dev)) * 0.1
+        b = torch.randn(CO, device=dev) * 0.1 if mode == "fwd" else None
         y0, s0 = run(op, x, w, b, False, mode == "fwd")
         y1, s1 = run(op, x, w, b, True, mode == "fwd")
         ok = torch.equal(y0, y1)
         print(dims, B, mode, "equal" if ok else "MISMATCH max %.3e" % float((y0.float() - y1.float()).abs().max()),
               "" if s0 is None else "stats diff %.2e" % float((s0 - s1).abs().max()))
-        if dims[0] == 126:
+        if dims[0] >= 60:
             for zs in (False, True):
                 O.USE_ZS = zs
                 r = O.ConvRunner(op, dev); r.prep(w, b)
-                y = O.alloc_cl(B, op.y_dims, 16, dt, dev)
-                st = torch.zeros(64, 16, 2, dtype=torch.float64, device=dev) if mode == "fwd" else None
+                y = O.alloc_cl(B, op.y_dims, CPO, dt, dev)
+                st = torch.zeros(64, CPO, 2, dtype=torch.float64, device=dev) if mode == "fwd" else None
                 f = lambda: r.run(x, y, B, None, None, L.ACT_LEAKY, 0.01, st, stats_nrep=64)
                 for _ in range(3): f()
                 torch.cuda.synchronize()
