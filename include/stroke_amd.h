@@ -92,6 +92,8 @@ typedef struct sp_conv_args {
   int32_t stats_nrep;          /* power of two >= 1: stats is [stats_nrep][CPo][2]; workgroup b adds to replica b % nrep
                                   (tens of thousands of same-address fp64 atomics otherwise serialise at the memory side) */
   int32_t ITH_zs;              /* persist == 3 only */
+  int64_t x_plane;             /* dma kernel: != 0 -> x is plane-major [CPi/16][B][D][H][W][16] with this many elements per
+                                  plane (concat buffers written by sp_upsample2_crop_cat_fwd); 0 -> channels-last */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -141,6 +143,7 @@ typedef struct sp_wgrad_args {
   int32_t parts;         /* 1: dw_acc holds nblocks partial blocks (see above) */
   int32_t cib;           /* 0 = choose, else cin tiles (of 16) per workgroup: fewer planes per tile leave room for a
                             larger spatial tile (less halo re-read) at the price of re-reading dz per cin group */
+  int64_t x_plane;       /* dma kernel, cib == 1: != 0 -> x is plane-major [CPi/16][B][D][H][W][16], elements per plane */
 } sp_wgrad_args;
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 /* BatchNorm folded out of the operand load (un-padded convolutions):
@@ -232,7 +235,8 @@ int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B, int32_t D
  * cat[..., CPu:CPu+CPs) = centre crop of skip; stats[c][2] over all CPd = CPu + CPs channels (Unet3D.py:67-72) */
 int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                               int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs, int32_t Ws,
-                              double* stats, sp_stream_t stream);
+                              int64_t cat_plane /* != 0: plane-major output, elements per 16-channel plane */, double* stats,
+                              sp_stream_t stream);
 /* gradient of a block output y that feeds (a) MaxPool3d(2,2) -> BN -> ... and (b) the cropped skip:
  * dz = [ poolbwd(coefp0*gp + coefp1*pool(y) + coefp2) + crop-region(coefs0*gs + coefs1*cat + coefs2) ] * act'(y)
  * either source may be NULL */

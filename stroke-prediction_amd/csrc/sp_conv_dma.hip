@@ -78,7 +78,10 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bf16_t* __restrict__ xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * a.CPi;
+  // x_plane != 0: plane-major input [plane][B][D][H][W][16] (concat buffers: each 16-channel plane dense, so a
+  // single-plane pass fetches only its own bytes instead of 32-byte slices of 96-byte rows)
+  const int xpitch = a.x_plane ? 16 : a.CPi;
+  const bf16_t* __restrict__ xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * xpitch;
   const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
   const bool border = a.zfill && (iz0 < 0 || iy0 < 0 || ix0 < 0 || iz0 + a.ITD > a.Di || iy0 + a.ITH > a.Hi || ix0 + a.ITW > a.Wi);
   const int opp_mask = a.opp - 1;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
     const uint32_t vz = fdiv(row, P.d_ith);
     const int vy = row - vz * a.ITH;
     const int cz = min(max(iz0 + (int)vz, 0), a.Di - 1), cy = min(max(iy0 + vy, 0), a.Hi - 1);
-    job_goff[k] = ((cz * a.Hi + cy) * a.Wi) * a.CPi + (int)pl * a.opp * 8;     // elements; the x / octet part is per lane
+    job_goff[k] = ((cz * a.Hi + cy) * a.Wi) * xpitch + (a.x_plane ? (int)pl * (int)a.x_plane : (int)pl * a.opp * 8);   // elements; the x / octet part is per lane
     job_loff[k] = (int)pl * a.plane_bytes + row * P.row_chunks * 16 + seg * 1024 + (seg << 24);   // seg kept in the top byte
   }
   STAMP(0);
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
         const int ch = seg * 64 + lane;
         if (ch < P.row_chunks) {
           const int cx = min(max(ix0 + (ch >> P.log2_opp), 0), a.Wi - 1);
-          const bf16_t* src = xin + goff + (cx * a.CPi + (oct0 + (ch & opp_mask)) * 8);
+          const bf16_t* src = a.x_plane ? xin + goff + (size_t)(oct0 >> 1) * a.x_plane + (cx * 16 + (ch & opp_mask) * 8)
+                                        : xin + goff + (cx * a.CPi + (oct0 + (ch & opp_mask)) * 8);
 #ifndef SP_NO_DMA
           sp_dma16(src, tile + (lo & 0xffffff));
 #endif
@@ -800,6 +804,7 @@ static int dispatch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
 int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 input and no affine on load");
   if (a->persist == 3) return launch_zs(a, reinterpret_cast<hipStream_t>(stream));      // z-marching plan (ktab in its format)
+  SP_CHECK_ARG(a->x_plane == 0 || (a->opp == 2 && !a->persist && a->x_plane < (1ll << 31)), "sp_conv3d_igemm(dma): plane-major input needs 16-channel planes");
   SP_CHECK_ARG(a->opp == 1 || a->opp == 2, "sp_conv3d_igemm(dma): octets per plane must be 1 or 2");
   SP_CHECK_ARG(a->vsb == a->opp * 16 && a->plane_bytes == a->ITD * a->ITH * a->ITW * a->vsb, "sp_conv3d_igemm(dma): planes must be lane-linear (no padding)");
   SP_CHECK_ARG(a->octs_per_group % a->opp == 0, "sp_conv3d_igemm(dma): group does not consist of whole planes");

@@ -515,7 +515,7 @@ template <> struct RawOct<float> {
 // (the one-voxel-per-thread version was ALU-bound: ~400 instructions per output octet).
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
-                                                         Dims ds, int CPs, T* __restrict__ cat, int CPd, OctMap om,
+                                                         Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane, OctMap om,
                                                          double* __restrict__ stats) {
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
@@ -589,7 +589,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
-        Store<T>::st8(cat + ((((int64_t)b * Do + zo) * Ho + yo) * Wo + xo) * CPd + oc * 8, out[q]);
+        const int64_t vo = (((int64_t)b * Do + zo) * Ho + yo) * Wo + xo;
+        // cat_plane != 0: plane-major concat buffer [plane][B][D][H][W][16] (dense 16-channel planes for the consumers)
+        Store<T>::st8(cat_plane ? cat + (int64_t)(oc >> 1) * cat_plane + vo * 16 + (oc & 1) * 8 : cat + vo * CPd + oc * 8, out[q]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float o = sizeof(T) == 2 ? bf2f(f2bf(out[q][j])) : out[q][j];
@@ -602,18 +604,19 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
 }
 extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                                          int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
-                                         int32_t Ws, double* stats, sp_stream_t stream) {
+                                         int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream) {
   SP_CHECK_ARG(low && skip && cat && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
   SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_upsample2_crop_cat_fwd");
   SP_CHECK_ARG(2 * D <= Ds && 2 * H <= Hs && 2 * W <= Ws, "sp_upsample2_crop_cat_fwd: skip smaller than the upsampled grid");
   SP_CHECK_ARG(CPd <= 2048, "sp_upsample2_crop_cat_fwd: too many channels");
+  SP_CHECK_ARG(cat_plane == 0 || CPd % 16 == 0, "sp_upsample2_crop_cat_fwd: plane-major output needs whole 16-channel planes");
   OctMap om = make_octmap(CPd);
   Dims dl{B, D, H, W}, ds{B, Ds, Hs, Ws};
   const int64_t nblk = (int64_t)B * D * H * W;          // one thread-slot per 2x2x2 output block
   const unsigned grid = grid_for(nblk, om.vpb);
   const size_t sh = (size_t)CPd * 2 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, om, stats);
-  else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, om, stats);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, om, stats);
+  else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, om, stats);
   SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd");
   return SP_OK;
 }

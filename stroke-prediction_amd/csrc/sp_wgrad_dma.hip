@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
     const int vx = vox - row * P.XW;
     const uint32_t vz = fdiv(row, P.d_xh);
     const int vy = row - vz * P.XH;
-    relx[j] = (uint32_t)(((((int)vz * a.Hi + vy) * a.Wi + vx) * a.CPi + (ci_t0 + (int)pl) * 16 + half * 8) * 2);
+    relx[j] = a.x_plane ? (uint32_t)(((((int)vz * a.Hi + vy) * a.Wi + vx) * 16 + half * 8) * 2)       // plane-major input
+                        : (uint32_t)(((((int)vz * a.Hi + vy) * a.Wi + vx) * a.CPi + (ci_t0 + (int)pl) * 16 + half * 8) * 2);
     crdx[j] = (int)vz | (vy << 8) | (vx << 16);
   }
 #pragma unroll
@@ -127,7 +128,8 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
     // chunks are zero-filled below and their addresses never dereferenced)
     const int iz0 = oz0 + a.o0D, iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(xg) +
-                              ((((int64_t)b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * a.CPi * 2;
+                              (a.x_plane ? (((((int64_t)b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * 16 + (int64_t)ci_t0 * a.x_plane) * 2
+                                         : ((((int64_t)b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * a.CPi * 2);
     const unsigned char* db = reinterpret_cast<const unsigned char*>(dzg + ((((size_t)b * a.Do + oz0) * a.Ho + oy0) * a.Wo + ox0) * a.CPo);
     const bool interior = oz0 + P.TZ <= a.Do && oy0 + P.TY <= a.Ho && ox0 + 32 <= a.Wo &&
                           iz0 >= 0 && iy0 >= 0 && ix0 >= 0 && iz0 + P.XD <= a.Di && iy0 + P.XH <= a.Hi && ix0 + P.XW <= a.Wi;
@@ -276,6 +278,7 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   if (a->cib > 0 && a->cib <= CIB) CIB = a->cib;          // caller's blocking of the cin tiles (grid.z grows accordingly)
   // tile rows: the largest TZ x TY whose two buffers fit 150 KiB and whose chunk count fits the per-lane plan
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->CPo % 16 == 0, "sp_conv3d_wgrad(dma): channel pitches must be multiples of 16");
+  SP_CHECK_ARG(a->x_plane == 0 || a->cib == 1, "sp_conv3d_wgrad(dma): plane-major input needs one input plane per workgroup (cib = 1)");
   // tile rows: two buffers per workgroup; prefer a shape that lets TWO workgroups share a CU (<= 75 KiB each) so
   // that every SIMD has two waves to overlap LDS latency with MFMA issue
   static const int cand[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};

@@ -63,6 +63,7 @@ class ConvLayer:
         self.act, self.act_param = act, act_param
         self.out_dtype = dtype if out_dtype is None else out_dtype
         self.need_input_grad = need_input_grad
+        self.x_planar = False       # set by the engine: the input is a plane-major concat buffer
         self.split_g = split_g      # channel count of the first part of a concatenated input: its gradient and the rest's go to two dense tensors
         # channel pitch of this layer's tensors: multiples of `pitch` (16 lets every 3x3x3 layer use the DMA kernels)
         self.cpi, self.cpo = (cpi or O.cpad(cin, pitch)), O.cpad(cout, pitch)
@@ -139,7 +140,7 @@ class ConvLayer:
         if self.fold:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
-                         stats_nrep=STATS_NREP)
+                         stats_nrep=STATS_NREP, x_planar=self.x_planar)
         else:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
             self.fwd.run(x, y, self.batch, self.scale, self.shift, self.act, self.act_param, out_stats,
@@ -206,7 +207,7 @@ class ConvLayer:
             bs = self.scratch.get(self.bsums_id)
             finish = self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
                                     dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
-                                    bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True)
+                                    bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True, x_planar=self.x_planar)
             # finish + BatchNorm-backward finalize on the side stream, beside the data-gradient convolution
             f = O.fork()
             with f:

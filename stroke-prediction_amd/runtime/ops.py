@@ -24,6 +24,7 @@ BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backwa
 MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
 WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
+CAT_PLANAR = bool(int(os.environ.get("SP_CAT_PLANAR", "1")))   # plane-major concat buffers (dense 16-channel planes for the DMA consumers)
 USE_ZS = bool(int(os.environ.get("SP_CONV_ZS", "1")))     # z-marching ring conv variant for the 16->16-channel stride-1 layers (-20 %)
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
 
@@ -185,7 +186,9 @@ class ConvRunner:
             self.has_bias = True
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
-            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None):
+            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False):
+        """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
+        buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only."""
         op = self.op
         dtype_out = op.dtype if dtype_out is None else dtype_out
         assert x.dtype == TORCH_DT[op.dtype] and y.dtype == TORCH_DT[dtype_out]
@@ -222,6 +225,11 @@ class ConvRunner:
                 setattr(a, k, t[k])
             a.dma = int(t["dma"] and in_scale is None and USE_DMA)
             a.persist = int(USE_PERSIST)
+            a.x_plane = 0
+            if x_planar:
+                assert a.dma and t["opp"] == 2, "plane-major input: DMA kernel with 16-channel planes only"
+                a.x_plane = batch * int(np.prod(op.in_dims)) * 16
+                a.persist = 0               # (the persistent variants address channels-last rows)
             if USE_ZS and a.dma and s.get("ktab_zs") is not None and stats_mode == 0 and a.CPo >= 16:
                 a.persist, a.ktab, a.ITH_zs = 3, ptr(s["ktab_zs"]), t["ITH_zs"]     # z-marching ring variant
             with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout,
@@ -298,7 +306,7 @@ class WgradRunner:
         self.acc_batch = batch
 
     def run(self, x, dz, batch, dw, in_scale=None, in_shift=None, dz_scale=None, dz_shift=None, dbias_sums=None,
-            dbias_grad=None, nbias=0, bn_w=None, bn_sums=None, bn_nrep=1, defer_finish=False):
+            dbias_grad=None, nbias=0, bn_w=None, bn_sums=None, bn_nrep=1, defer_finish=False, x_planar=False):
         """dw (fp32, the parameter's own layout) += gradient.  On the DMA path the BatchNorm (in_scale/in_shift) is
         folded into the finish step and needs dbias_sums = sum over voxels of dz per output channel (fp64); there
         bn_sums (with bn_w = the conv weight) also receives the BatchNorm-backward sums of the input, which
@@ -317,6 +325,10 @@ class WgradRunner:
         a.in_scale, a.in_shift = (None, None) if fold else (ptr(in_scale), ptr(in_shift))
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
+        a.x_plane = 0
+        if x_planar:
+            assert a.dma and a.cib == 1, "plane-major input: DMA weight-gradient kernel, one plane per workgroup"
+            a.x_plane = batch * a.Di * a.Hi * a.Wi * 16
         with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout,
                     "%d->%d @%dx%dx%d %s" % (self.cin, self.cout, a.Di, a.Hi, a.Wi, "dma" if a.dma else "reg")):
             L.call("sp_conv3d_wgrad", C.byref(a), stream())
@@ -389,13 +401,14 @@ def upsample2_fwd(x, y, dtype, stats=None):
     L.call("sp_upsample2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, y.shape[-1], ptr(stats), stream())
 
 
-def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None):
-    """cat = concat(upsample2(low), centre_crop(skip)) in one pass (+ per-channel (sum, sum^2) of cat into stats)."""
+def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False):
+    """cat = concat(upsample2(low), centre_crop(skip)) in one pass (+ per-channel (sum, sum^2) of cat into stats).
+    planar: cat (same shape) is written plane-major [C/16][B][D][H][W][16] for the DMA consumers (x_planar=True)."""
     B, D, H, W, CPu = low.shape
     _, Ds, Hs, Ws, CPs = skip.shape
     assert tuple(cat.shape) == (B, 2 * D, 2 * H, 2 * W, CPu + CPs), (tuple(cat.shape), tuple(low.shape), tuple(skip.shape))
     L.call("sp_upsample2_crop_cat_fwd", ptr(low), CPu, ptr(skip), CPs, ptr(cat), CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
-           ptr(stats), stream())
+           (B * 8 * D * H * W * 16) if planar else 0, ptr(stats), stream())
 
 
 def crop_copy(src, dst, c0, dtype, stats=None):

@@ -101,6 +101,10 @@ class UnetEngine:
         self.cat5 = O.alloc_cl(batch, dc5, b4 + O.cpad(b1), dt, device)
         assert self.cat4.shape[-1] == self.c41.cpi and self.cat5.shape[-1] == self.c51.cpi
         self.ncls = ncls
+        # plane-major concat buffers when both consumers of each are the DMA kernels (bf16, folded BatchNorm)
+        self.cat_planar = bool(O.CAT_PLANAR and O.BN_SUMS_FROM_WGRAD and O.USE_DMA and dtype == L.SP_BF16 and self.c41.fold and self.c51.fold
+                               and self.cat4.shape[-1] % 16 == 0 and self.cat5.shape[-1] % 16 == 0)
+        self.c41.x_planar = self.c51.x_planar = self.cat_planar
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, images, params, bufs, training):
@@ -130,12 +134,12 @@ class UnetEngine:
         y32 = self.c32.forward(y31, params, bufs, training)
         c3 = self.channels[3]
         s4 = st(self.c41)
-        O.upsample2_crop_cat_fwd(y32, y22, self.cat4, dt, s4)
+        O.upsample2_crop_cat_fwd(y32, y22, self.cat4, dt, s4, planar=self.cat_planar)
         y41 = self.c41.forward(self.cat4, params, bufs, training, st(self.c42))
         y42 = self.c42.forward(y41, params, bufs, training)
         c4 = self.channels[4]
         s5 = st(self.c51)
-        O.upsample2_crop_cat_fwd(y42, y12, self.cat5, dt, s5)
+        O.upsample2_crop_cat_fwd(y42, y12, self.cat5, dt, s5, planar=self.cat_planar)
         y51 = self.c51.forward(self.cat5, params, bufs, training, st(self.c52))
         y52 = self.c52.forward(y51, params, bufs, training)
         seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)
@@ -156,7 +160,7 @@ class UnetEngine:
         if isinstance(g, tuple):      # dense per-part gradient tensors (ConvLayer split_g)
             O.upsample2_act_bwd(low.y, None, g[0], coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums, coef_stride=cat.shape[-1])
         else:
-            O.upsample2_act_bwd(low.y, cat, g, coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums)
+            O.upsample2_act_bwd(low.y, None if self.cat_planar else cat, g, coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums)
 
     def _skip_bwd(self, prod, gp, coefp, cat, g, coef, c_up):
         """pool gradient + skip half of the concat gradient -> dz of the block output `prod`"""
