@@ -144,6 +144,7 @@ typedef struct sp_wgrad_args {
   int32_t cib;           /* 0 = choose, else cin tiles (of 16) per workgroup: fewer planes per tile leave room for a
                             larger spatial tile (less halo re-read) at the price of re-reading dz per cin group */
   int64_t x_plane;       /* dma kernel, cib == 1: != 0 -> x is plane-major [CPi/16][B][D][H][W][16], elements per plane */
+  int32_t zs;            /* dma kernel: 1 = allow the z-marching ring variant (cib == 1, parts == 1, Cout <= 32 per group) */
 } sp_wgrad_args;
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 /* BatchNorm folded out of the operand load (un-padded convolutions):

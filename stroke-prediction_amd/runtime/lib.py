@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "dz", "in_scale", "in_shift", "dz_scale", "dz_shift", "dw_acc", "taps")] + \
                [(n, i32) for n in ("dtype", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "sD", "sH", "sW",
-                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64)]
+                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64), ("zs", i32)]
 
 
 _SIGS = {

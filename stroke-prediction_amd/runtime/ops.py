@@ -24,6 +24,7 @@ BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backwa
 MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
 WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
+WGRAD_ZS = int(os.environ.get("SP_WGRAD_ZS", "1"))   # z-marching ring variant of the DMA weight gradient (0 off, 1 where it pays, 2 wherever it applies)
 CAT_PLANAR = bool(int(os.environ.get("SP_CAT_PLANAR", "1")))   # plane-major concat buffers (dense 16-channel planes for the DMA consumers)
 USE_ZS = bool(int(os.environ.get("SP_CONV_ZS", "1")))     # z-marching ring conv variant for the 16->16-channel stride-1 layers (-20 %)
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
@@ -325,6 +326,7 @@ class WgradRunner:
         a.in_scale, a.in_shift = (None, None) if fold else (ptr(in_scale), ptr(in_shift))
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
+        a.zs = int(WGRAD_ZS)
         a.x_plane = 0
         if x_planar:
             assert a.dma and a.cib == 1, "plane-major input: DMA weight-gradient kernel, one plane per workgroup"
