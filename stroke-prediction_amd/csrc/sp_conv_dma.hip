@@ -578,12 +578,21 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void conv_igemm_zs_kernel(c
   const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;
   const bool want_stats = a.stats != nullptr;
 
-  for (uint32_t col = xcd_remap(blockIdx.x, gridDim.x); col < P.ncols; col += gridDim.x) {
+  // Work = (column, output plane) pairs cut into gridDim.x equal pieces of the flattened sequence (perfect balance for
+  // any volume; a piece that crosses a column boundary pays one more three-plane prologue).  XCD-aware piece id.
+  const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+  const uint64_t T = (uint64_t)P.ncols * a.Do;
+  uint64_t pos = T * vb / gridDim.x;
+  const uint64_t pend = T * (vb + 1) / gridDim.x;
+  while (pos < pend) {
+    const uint32_t col = (uint32_t)(pos / (uint32_t)a.Do);
+    const int z0 = (int)(pos - (uint64_t)col * a.Do);
+    const int z1 = (int)min((uint64_t)a.Do, (uint64_t)z0 + (pend - pos));
+    pos += (uint64_t)(z1 - z0);
     uint32_t t = col;
     uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
-    q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; t = q;
-    q = fdiv(t, P.d_zc); const int zc = t - q * P.nzc; const int b = q;
-    const int oy0 = ty * (4 * MT), ox0 = tx * 16, z0 = zc * P.ZC, z1 = min(a.Do, z0 + P.ZC);
+    q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; const int b = q;
+    const int oy0 = ty * (4 * MT), ox0 = tx * 16;
     const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
     const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * a.CPi;
     // in-plane validity of this lane's chunks (column-invariant): bit j set = inside the volume
@@ -729,17 +738,13 @@ static int launch_zs(const sp_conv_args* a, hipStream_t st) {
   SP_CHECK_ARG(P.nchunks <= 5 * 256 && 4 * P.S <= 160 * 1024, "sp_conv3d_igemm(zs): plane does not fit the per-lane plan");
   P.ntx = (a->Wo + 15) / 16; P.nty = (a->Ho + 4 * MT - 1) / (4 * MT);
   const int cols_xy = a->B * P.nty * P.ntx;
-  // z chunks: as many columns as fit ONE round of resident workgroups: a second, mostly empty round would double the
-  // kernel time (576 columns on 512 slots: 80 -> 108 us on the 88^3 layer)
-  const int slots = a->NT == 1 ? 512 : 256;
-  int nzc = slots / cols_xy;
-  if (nzc > a->Do / 4) nzc = a->Do / 4;
-  if (nzc < 1) nzc = 1;
-  P.ZC = (a->Do + nzc - 1) / nzc; P.nzc = (a->Do + P.ZC - 1) / P.ZC;
-  P.ncols = (uint32_t)cols_xy * P.nzc;
+  const int slots = a->NT == 1 ? 512 : 256;            // resident workgroups (2 / 1 per CU)
+  P.nzc = 1; P.ZC = a->Do;
+  P.ncols = (uint32_t)cols_xy;
   P.d_itw = make_fastdiv(P.ITW); P.d_tx = make_fastdiv(P.ntx); P.d_ty = make_fastdiv(P.nty); P.d_zc = make_fastdiv(P.nzc);
   const int lds_bytes = 4 * P.S;
-  const unsigned grid = P.ncols < (unsigned)slots ? P.ncols : (unsigned)slots;
+  const uint64_t planes = (uint64_t)cols_xy * a->Do;
+  const unsigned grid = planes / 4 < (uint64_t)slots ? (unsigned)(planes / 4 > 0 ? planes / 4 : 1) : (unsigned)slots;   // >= 4 planes per piece
 #define SP_ZS(N_, M_, K_, T_)                                                                                        \
   {                                                                                                                  \
     auto kern = conv_igemm_zs_kernel<N_, M_, K_, T_>;                                                                \
