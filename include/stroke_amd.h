@@ -16,6 +16,12 @@
  *    convolutions then run split-bf16 x3 MFMA, ~fp32 accurate);
  *  - statistics / parameter buffers are fp32 unless stated; reduction
  *    accumulators are fp64 ("sums" arguments) and must be zeroed by the caller.
+ *    The elementwise kernels (sp_bn_stats, sp_bn_bwd_reduce, sp_bn_act_bwd, sp_maxpool2_fwd, sp_upsample2_*,
+ *    sp_crop_copy, sp_pool_skip_act_bwd, sp_out_grad_to_cl, sp_first_wgrad_fused) add into SP_REDUCE_ROWS replica
+ *    rows of their accumulator, sums[SP_REDUCE_ROWS][CP (x2 for statistics)] with CP the channel pitch of the tensor
+ *    reduced over (same-line fp64 atomics from different workgroups serialise at ~20 ns each on the 8-XCD part);
+ *    the consumers (sp_bn_finalize / sp_bn_bwd_finalize with nrep >= SP_REDUCE_ROWS, sp_wgrad_finish* with
+ *    dbias_stride = CP) add the rows.
  */
 #ifndef STROKE_AMD_H
 #define STROKE_AMD_H
@@ -30,6 +36,7 @@ extern "C" {
 typedef void* sp_stream_t; /* hipStream_t */
 
 enum { SP_OK = 0, SP_EINVAL = -1, SP_EHIP = -2 };
+enum { SP_REDUCE_ROWS = 8 };
 enum { SP_BF16 = 0, SP_F32 = 1 };
 enum { SP_ACT_NONE = 0, SP_ACT_LEAKY = 1, SP_ACT_ELU = 2, SP_ACT_SIGMOID = 3 };
 
@@ -153,7 +160,9 @@ int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc,
                            int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                            const float* shift, const double* dbias_sums, float* dw, float* dbias_grad /* or NULL */,
                            const float* w_for_bn /* or NULL */, double* bn_sums /* or NULL */, int32_t bn_nrep,
-                           int32_t bn_cp /* channel pitch of a bn_sums replica; <= 0: CiP */, sp_stream_t stream);
+                           int32_t bn_cp /* channel pitch of a bn_sums replica; <= 0: CiP */,
+                           int32_t dbias_stride /* row pitch of the SP_REDUCE_ROWS replica rows of dbias_sums; <= 0: one row */,
+                           sp_stream_t stream);
 /* bn_sums != NULL (first layer of a network: no input gradient wanted, so no data-gradient convolution is run):
  * also accumulate the BatchNorm-backward sums of the layer's input,  bn_sums[rep][ci][0] += sum_v g  and
  * bn_sums[rep][ci][1] += sum_v g*x  with g = conv_transpose(dz, w_for_bn), computed from the weight-gradient
@@ -163,7 +172,7 @@ int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc,
 int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                     int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
                     const double* dbias_sums /* or NULL */, float* dbias_grad /* or NULL */, int32_t nbias,
-                    sp_stream_t stream);
+                    int32_t dbias_stride /* as above */, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ first layer, read from the NCDHW fp32 input
  * (Unet3D.py:18-20 of block1: BatchNorm3d(2) -> Conv3d(2,16,3) -> LeakyReLU; train_unet_segmentation.py:22).  With two

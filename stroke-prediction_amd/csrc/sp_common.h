@@ -123,6 +123,16 @@ __device__ __forceinline__ float act_bwd_from_y(int act, float p, float y) {
   }
 }
 
+// ---- replica rows of the fp64 accumulators the elementwise kernels reduce into (include/stroke_amd.h) ---------------
+// sum over the replica rows of accumulator column c (stride <= 0: a single row)
+__device__ __forceinline__ double sp_rows_sum(const double* __restrict__ d, int c, int stride) {
+  if (stride <= 0) return d[c];
+  double t = 0.0;
+#pragma unroll
+  for (int r = 0; r < SP_REDUCE_ROWS; ++r) t += d[(size_t)r * stride + c];
+  return t;
+}
+
 // ---- exact unsigned division by a runtime constant (host computes mul/shift) --------------------
 struct FastDiv { uint32_t mul, shift; };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }

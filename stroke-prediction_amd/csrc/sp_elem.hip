@@ -46,20 +46,56 @@ static inline unsigned grid_for(int64_t nvox, int vpb) {
   return (unsigned)(nb < 1 ? 1 : (nb > MAX_BLOCKS ? MAX_BLOCKS : nb));
 }
 
-// block-level per-channel reduction of NS partial sums per channel (8 channels per thread)
+// block-level per-channel reduction of NS partial sums per channel (8 channels per thread; thread = slot * OC + octet).
+// Every thread parks its 8*NS partials in LDS (row = slot, conflict-free 16-byte stores), the columns are summed by all
+// 256 threads in two conflict-free passes and ONE fp64 atomic per (workgroup, column) goes to memory, into replica row
+// (workgroup % SP_REDUCE_ROWS) of out[SP_REDUCE_ROWS][CP*NS]; the consumers add the rows.  Why: (1) LDS float atomics
+// (the first version) put 128 threads on each address for 2 octets, ~4096 serialised LDS operations per workgroup;
+// (2) fp64 atomics from different workgroups onto one 128-byte line are serialised at ~15-20 ns each, and the 2048
+// workgroups of a launch all arrive at the kernel's tail: MaxPool 124^3 x16 took 80 us with statistics against 46 us
+// without; 4 replica rows already remove that (47 us).  Replicas interleaved within a line do not help.
 template <int NS>
 __device__ __forceinline__ void block_channel_reduce(const float part[NS][8], int oc, bool active, int CP,
                                                      double* __restrict__ out, float* red) {
-  for (int i = threadIdx.x; i < CP * NS; i += 256) red[i] = 0.f;
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) float s_tr[256 * 8 * NS];
+  (void)oc; (void)red;
+  const int n = CP * NS, OC = CP >> 3;
+  const int rows = 256 / OC;                                   // active threads = rows * OC
   if (active) {
+    float4* d = reinterpret_cast<float4*>(s_tr + (size_t)threadIdx.x * 8 * NS);
+    if (NS == 1) {
+      d[0] = make_float4(part[0][0], part[0][1], part[0][2], part[0][3]);
+      d[1] = make_float4(part[0][4], part[0][5], part[0][6], part[0][7]);
+    } else {
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&red[(oc * 8 + j) * NS + s], part[s][j]);
+      for (int j = 0; j < 8; j += 2) d[j >> 1] = make_float4(part[0][j], part[NS - 1][j], part[0][j + 1], part[NS - 1][j + 1]);
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < CP * NS; i += 256) atomicAdd(&out[i], (double)red[i]);
+  double* o = out + (size_t)(blockIdx.x % SP_REDUCE_ROWS) * n;
+  if (n <= 256) {
+    const int S = 256 / n, col = threadIdx.x % n, grp = threadIdx.x / n;
+    float a0 = 0.f, a1 = 0.f;
+    if (grp < S) {
+      int k = grp;
+      for (; k + S < rows; k += 2 * S) { a0 += s_tr[k * n + col]; a1 += s_tr[(k + S) * n + col]; }
+      if (k < rows) a0 += s_tr[k * n + col];
+    }
+    __syncthreads();
+    s_tr[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if (threadIdx.x < n) {
+      float t = 0.f;
+      for (int g = 0; g < S; ++g) t += s_tr[g * n + threadIdx.x];
+      atomicAdd(&o[threadIdx.x], (double)t);
+    }
+  } else {
+    for (int col = threadIdx.x; col < n; col += 256) {
+      float t = 0.f;
+      for (int k = 0; k < rows; ++k) t += s_tr[k * n + col];
+      atomicAdd(&o[col], (double)t);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ layout
@@ -1001,7 +1037,7 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
     ut.d_nbx = make_fastdiv(ut.nbx); ut.d_nby = make_fastdiv(ut.nby); ut.d_zs = make_fastdiv(ut.ZS);
     const size_t esz = dtype == SP_BF16 ? 2 : 4;
     const size_t sh2 = (2 * (size_t)ut.RY * ut.RX + (size_t)(ut.TY + 2) * (ut.TX + 2)) * CP * esz + (size_t)CP * sizeof(float);
-    if (sh2 <= 160 * 1024) {
+    if (sh2 <= 150 * 1024) {      // + 8 KB static (block_channel_reduce)
       const unsigned grid2 = (unsigned)(cols * ut.ZS);
       if (dtype == SP_BF16) {
         auto kern = upsample2_act_bwd_tiled_kernel<bf16_t>;
@@ -1061,7 +1097,7 @@ __global__ __launch_bounds__(256) void out_grad_to_cl_kernel(const float* __rest
     if ((threadIdx.x & 63) == 0 && j < C) atomicAdd(&red[j], s);
   }
   __syncthreads();
-  if (dbias && threadIdx.x < C) atomicAdd(&dbias[threadIdx.x], (double)red[threadIdx.x]);
+  if (dbias && threadIdx.x < C) atomicAdd(&dbias[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CP + threadIdx.x], (double)red[threadIdx.x]);
 }
 extern "C" int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C, int64_t DHW, int32_t CP,
                                  int32_t dtype, int32_t act, float act_param, void* dz, double* dbias_sums,

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
       if (lane < 2) atomicAdd(&rd[(lane & 1) * 8 + j], v);
     }
     __syncthreads();
-    if (tid < 16) atomicAdd(&dbias[tid], (double)rd[tid]);
+    if (tid < 16) atomicAdd(&dbias[(blockIdx.x % SP_REDUCE_ROWS) * 16 + tid], (double)rd[tid]);
   }
 }
 

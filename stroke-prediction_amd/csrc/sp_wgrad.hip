@@ -305,10 +305,10 @@ __global__ __launch_bounds__(256) void wgrad_finish_parts_kernel(const float* __
                                                                  const int32_t* __restrict__ tapsrc, int ntap, int CoP,
                                                                  int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
                                                                  float* __restrict__ dw, const double* __restrict__ dbias_sums,
-                                                                 float* __restrict__ dbias_grad, int nbias) {
+                                                                 float* __restrict__ dbias_grad, int nbias, int dbs) {
   const int64_t total = (int64_t)ntap * CoP * CiP;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (dbias_grad && gid < nbias) dbias_grad[gid] += (float)dbias_sums[gid];
+  if (dbias_grad && gid < nbias) dbias_grad[gid] += (float)sp_rows_sum(dbias_sums, (int)gid, dbs);
   int64_t idx;
   float v;
   if (!wgrad_part_sum(acc, nparts, total, idx, v)) return;
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(256) void wgrad_finish_parts_kernel(const float* __
 __global__ void wgrad_finish_kernel(float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
                                     int CoP, int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
                                     float* __restrict__ dw, const double* __restrict__ dbias_sums,
-                                    float* __restrict__ dbias_grad, int nbias) {
+                                    float* __restrict__ dbias_grad, int nbias, int dbs) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)ntap * CoP * CiP;       // every accumulator entry is visited (and cleared)
-  if (dbias_grad && idx < nbias) dbias_grad[idx] += (float)dbias_sums[idx];
+  if (dbias_grad && idx < nbias) dbias_grad[idx] += (float)sp_rows_sum(dbias_sums, (int)idx, dbs);
   if (idx >= total) return;
   const int ci = idx % CiP;
   const int co = (idx / CiP) % CoP;
@@ -336,7 +336,7 @@ __global__ void wgrad_finish_kernel(float* __restrict__ acc, const int32_t* __re
 
 extern "C" int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, float* dw,
-                               const double* dbias_sums, float* dbias_grad, int32_t nbias, sp_stream_t stream) {
+                               const double* dbias_sums, float* dbias_grad, int32_t nbias, int32_t dbias_stride, sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && Cout <= CoP && Cin <= CiP && nparts >= 1, "sp_wgrad_finish: bad arguments");
   SP_CHECK_ARG(!dbias_grad || (dbias_sums && nbias <= ntap * CoP * CiP), "sp_wgrad_finish: bias arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
@@ -344,13 +344,13 @@ extern "C" int sp_wgrad_finish(float* dw_acc, int32_t nparts, const int32_t* tap
     SP_CHECK_ARG(!dbias_grad || nbias <= (total + 31) / 32 * 256, "sp_wgrad_finish: bias arguments");
     hipLaunchKernelGGL(wgrad_finish_parts_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
-                       dw, dbias_sums, dbias_grad, nbias);
+                       dw, dbias_sums, dbias_grad, nbias, dbias_stride);
     SP_CHECK_LAUNCH("sp_wgrad_finish");
     return SP_OK;
   }
   hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, dw,
-                     dbias_sums, dbias_grad, nbias);
+                     dbias_sums, dbias_grad, nbias, dbias_stride);
   SP_CHECK_LAUNCH("sp_wgrad_finish");
   return SP_OK;
 }

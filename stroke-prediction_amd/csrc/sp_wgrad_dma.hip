@@ -546,11 +546,11 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const fl
                                                                         const double* __restrict__ dbias,
                                                                         float* __restrict__ dw, float* __restrict__ dbias_grad,
                                                                         const float* __restrict__ wbn,
-                                                                        double* __restrict__ bn_sums, int bn_nrep, int bn_cp) {
+                                                                        double* __restrict__ bn_sums, int bn_nrep, int bn_cp, int dbs) {
   __shared__ float red[8][33];
   const int64_t total = (int64_t)ntap * CoP * CiP;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (dbias_grad && gid < Cout) dbias_grad[gid] += (float)dbias[gid];
+  if (dbias_grad && gid < Cout) dbias_grad[gid] += (float)sp_rows_sum(dbias, (int)gid, dbs);
   const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int64_t idx = (int64_t)blockIdx.x * 32 + el;
   float s = 0.f;
@@ -574,8 +574,9 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_parts_kernel(const fl
   const int t = idx / ((int64_t)CiP * CoP);
   if (co < Cout && ci < Cin) {
     const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
-    dw[wi] += scale[ci] * v + shift[ci] * (float)dbias[co];
-    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * bn_cp * 2 + ci * 2);
+    const double db = sp_rows_sum(dbias, co, dbs);
+    dw[wi] += scale[ci] * v + shift[ci] * (float)db;
+    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, db, bn_sums + (size_t)(blockIdx.x % bn_nrep) * bn_cp * 2 + ci * 2);
   }
 }
 
@@ -585,10 +586,10 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                            const double* __restrict__ dbias, float* __restrict__ dw,
                                            float* __restrict__ dbias_grad, const float* __restrict__ wbn,
-                                           double* __restrict__ bn_sums, int bn_nrep, int bn_cp) {
+                                           double* __restrict__ bn_sums, int bn_nrep, int bn_cp, int dbs) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)ntap * CoP * CiP;
-  if (dbias_grad && idx < Cout) dbias_grad[idx] += (float)dbias[idx];
+  if (dbias_grad && idx < Cout) dbias_grad[idx] += (float)sp_rows_sum(dbias, (int)idx, dbs);
   if (idx >= total) return;
   const int ci = idx % CiP;
   const int co = (idx / CiP) % CoP;
@@ -597,15 +598,16 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
   acc[idx] = 0.f;
   if (co < Cout && ci < Cin) {
     const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
-    dw[wi] += scale[ci] * v + shift[ci] * (float)dbias[co];
-    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, dbias[co], bn_sums + (size_t)(blockIdx.x % bn_nrep) * bn_cp * 2 + ci * 2);
+    const double db = sp_rows_sum(dbias, co, dbs);
+    dw[wi] += scale[ci] * v + shift[ci] * (float)db;
+    if (bn_sums) bn_sums_from_wgrad(wbn[wi], v, db, bn_sums + (size_t)(blockIdx.x % bn_nrep) * bn_cp * 2 + ci * 2);
   }
 }
 
 extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                       int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                                       const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
-                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, sp_stream_t stream) {
+                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, int32_t dbias_stride, sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
   SP_CHECK_ARG(nparts >= 1 && Cout <= (total + 31) / 32 * 256, "sp_wgrad_finish_folded: nparts");
@@ -614,13 +616,13 @@ extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32
   if (nparts > 1) {
     hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
-                       scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp);
+                       scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride);
     SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
     return SP_OK;
   }
   hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
-                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp);
+                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride);
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
   return SP_OK;
 }

@@ -188,13 +188,13 @@ class ConvLayer:
         self._bwd_ready = True
 
     def reserve_bwd_scratch(self):
-        self.dbias_sums_id = self.scratch.reserve(self.cpo)
+        self.dbias_sums_id = self.scratch.reserve(self.cpo * L.SP_REDUCE_ROWS)     # replica rows, see include/stroke_amd.h
         if self.bn_prefix is not None:
             self.bsums_id = self.scratch.reserve(self.cpi * 2 * STATS_NREP)
 
     @property
     def dbias_sums(self):
-        return self.scratch.get(self.dbias_sums_id)
+        return self.scratch.get(self.dbias_sums_id).view(L.SP_REDUCE_ROWS, self.cpo)
 
     def backward(self, x, params, grads):
         """Given self.dz (gradient at the pre-activation output) and self.dbias_sums already filled by the
@@ -240,7 +240,7 @@ class ConvLayer:
         else:
             self.dgrad.run(self.dz, self.g, self.batch)
             O.bn_bwd_reduce(self.g, x, self.dtype, bs)
-        self._bn_bwd_finalize(bs, params, grads, STATS_NREP if fused else 1)
+        self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
         return self.g, self.coef
 
     def _run_dgrad(self, w):
@@ -325,6 +325,6 @@ class FirstConvLayer(ConvLayer):
         L.call("sp_wgrad_finish_folded", O.ptr(self.partials), self.nparts, O.ptr(self.tapsrc), 27, 16, 2, self.cout,
                self.cin, self.cin * 27, 27, O.ptr(self.scale), O.ptr(self.shift), O.ptr(self.dbias_sums),
                O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(params[c + ".weight"]), O.ptr(bs), STATS_NREP,
-               self.cpi, st)
+               self.cpi, self.cpo, st)
         self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
         return None, None

@@ -14,6 +14,7 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip"]
 
 SP_BF16, SP_F32 = 0, 1
+SP_REDUCE_ROWS = 8    # replica rows of the accumulators the elementwise kernels reduce into (include/stroke_amd.h)
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
@@ -41,8 +42,8 @@ _SIGS = {
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv_prep_folded": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
-    "sp_wgrad_finish": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, vp], i32),
-    "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp], i32),
+    "sp_wgrad_finish": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, i32, vp], i32),
+    "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "sp_upsample2_crop_cat_fwd": ([vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, vp], i32),
     "sp_confusion_counts": ([vp, vp, f32, i64, vp, vp], i32),
     "sp_first_supported": ([i32, i32, i32], i32),

@@ -344,12 +344,25 @@ class WgradRunner:
         if fold:
             L.call("sp_wgrad_finish_folded", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(in_scale), ptr(in_shift), ptr(dbias_sums), ptr(dw),
-                   ptr(dbias_grad), ptr(bn_w), ptr(bn_sums), bn_nrep, 0, st)
+                   ptr(dbias_grad), ptr(bn_w), ptr(bn_sums), bn_nrep, 0, _dbias_stride(dbias_sums), st)
         else:
             assert bn_sums is None, "BatchNorm sums from the weight gradient need the folded (DMA) path"
             L.call("sp_wgrad_finish", ptr(self.acc), self.nparts, ptr(self.tapsrc), self.ntap, self.cot * 16, self.cit * 16,
                    self.cout, self.cin, self.w_sco, self.w_sci, ptr(dw), ptr(dbias_sums) if dbias_grad is not None else None,
-                   ptr(dbias_grad), nbias, st)
+                   ptr(dbias_grad), nbias, _dbias_stride(dbias_sums), st)
+
+
+def _dbias_stride(dbias_sums):
+    """dbias_sums: [SP_REDUCE_ROWS][CP] replica rows as the elementwise kernels fill them (2-D), or one row (1-D)."""
+    if dbias_sums is None or dbias_sums.dim() == 1:
+        return 0
+    assert dbias_sums.shape[0] == L.SP_REDUCE_ROWS and dbias_sums.is_contiguous(), tuple(dbias_sums.shape)
+    return dbias_sums.shape[1]
+
+
+def reduce_rows(c, n=1, device="cuda"):
+    """Zeroed fp64 accumulator for the elementwise kernels: SP_REDUCE_ROWS replica rows of c channels x n sums."""
+    return torch.zeros((L.SP_REDUCE_ROWS, c) if n == 1 else (L.SP_REDUCE_ROWS, c, n), dtype=torch.float64, device=device)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise drivers

@@ -191,12 +191,13 @@ def test_bn_pieces(dtype):
     rm, rv = torch.randn(Cc, generator=g) * 0.1, torch.rand(Cc, generator=g) + 0.5
     cp = O.cpad(Cc)
     xs = to_cl(x, cp, dtype)
-    sums = torch.zeros(cp, 2, dtype=torch.float64, device=DEV)
+    sums = O.reduce_rows(cp, 2, DEV)         # SP_REDUCE_ROWS replica rows, added up by the finalize kernel
     O.bn_stats(xs, dtype, sums)
     n = B * int(np.prod(dims))
     scale, shift, mean, invstd = (torch.empty(cp, device=DEV) for _ in range(4))
     rm_d, rv_d = rm.clone().to(DEV), rv.clone().to(DEV)
-    O.bn_finalize(sums, n, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, 0.1, 1e-5, True, Cc, cp, scale, shift, mean, invstd)
+    O.bn_finalize(sums, n, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, 0.1, 1e-5, True, Cc, cp, scale, shift, mean, invstd,
+                  nrep=L.SP_REDUCE_ROWS)
     rm_ref, rv_ref = rm.clone(), rv.clone()
     xr = x.clone().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
@@ -209,22 +210,22 @@ def test_bn_pieces(dtype):
     gy = rnd(dtype, torch.randn(x.shape, generator=g))
     gx_ref, gg_ref, gb_ref = torch.autograd.grad(yref, (xr, gr, br), gy)
     gs = to_cl(gy, cp, dtype)
-    bsums = torch.zeros(cp, 2, dtype=torch.float64, device=DEV)
+    bsums = O.reduce_rows(cp, 2, DEV)
     O.bn_bwd_reduce(gs, xs, dtype, bsums)
     dgam, dbet = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
     coef = torch.empty(3, cp, device=DEV)
-    O.bn_bwd_finalize(bsums, n, gamma.to(DEV), mean, invstd, Cc, cp, dgam, dbet, coef)
+    O.bn_bwd_finalize(bsums, n, gamma.to(DEV), mean, invstd, Cc, cp, dgam, dbet, coef, nrep=L.SP_REDUCE_ROWS)
     torch.testing.assert_close(dgam.cpu(), gg_ref, rtol=1e-3, atol=1e-2)
     torch.testing.assert_close(dbet.cpu(), gb_ref, rtol=1e-3, atol=1e-2)
     dz = O.alloc_cl(B, dims, cp, dtype, DEV)
-    dbias = torch.zeros(cp, dtype=torch.float64, device=DEV)
+    dbias = O.reduce_rows(cp, 1, DEV)
     O.bn_act_bwd(gs, xs, coef, dtype, L.ACT_ELU, 1.0, dz, dbias)
     elu_d = torch.where(x > 0, torch.ones_like(x), x + 1.0)
     ref = gx_ref * elu_d
     got = from_cl(dz, Cc, dtype)
     torch.testing.assert_close(got, ref, **TOL[dtype])
     # the bias-gradient sums are taken before the storage rounding: compare with the exact reference
-    torch.testing.assert_close(dbias[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
+    torch.testing.assert_close(dbias.sum(0)[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
 
 
 @pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
@@ -240,8 +241,9 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     # forward: pool
     p_ref = F.max_pool3d(y, 2, 2)
     ps = O.alloc_cl(B, p_ref.shape[2:], C1, dtype, DEV)
-    st = torch.zeros(C1, 2, dtype=torch.float64, device=DEV)
+    st = O.reduce_rows(C1, 2, DEV)
     O.maxpool2_fwd(ys, ps, dtype, st)
+    st = st.sum(0)
     torch.testing.assert_close(from_cl(ps, C1, dtype), p_ref.detach(), rtol=0, atol=0)
     torch.testing.assert_close(st[:, 0].cpu(), p_ref.detach().double().sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-4)
     # forward: low-res tensor upsampled into a concat buffer next to the cropped skip
@@ -260,8 +262,9 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     torch.testing.assert_close(from_cl(cat, C0 + C1, dtype), cat_ref.detach(), **TOL[dtype])
     # the one-pass variant writes the same buffer bit for bit and accumulates the statistics of all its channels
     cat2 = torch.full_like(cat, 3.0)
-    st2 = torch.zeros(C0 + C1, 2, dtype=torch.float64, device=DEV)
+    st2 = O.reduce_rows(C0 + C1, 2, DEV)
     O.upsample2_crop_cat_fwd(lows, ys, cat2, dtype, st2)
+    st2 = st2.sum(0)
     torch.testing.assert_close(cat2.float(), cat.float(), **TOL[dtype])      # separable evaluation: last-bit differences
     cf = cat.double()
     torch.testing.assert_close(st2[:, 0].cpu(), cf.sum(dim=(0, 1, 2, 3)).cpu(), rtol=1e-5, atol=1e-3)
@@ -279,12 +282,12 @@ def test_pool_upsample_crop_fwd_bwd(dtype):
     gy_ref, glow_ref = torch.autograd.grad([cat_ref, p_ref], (y, lowr), [d_cat, d_p])
     lrelu_d = torch.where(ypre > 0, torch.ones_like(ypre), torch.full_like(ypre, 0.01))
     dz = O.alloc_cl(B, dims, C1, dtype, DEV)
-    dbias = torch.zeros(C1, dtype=torch.float64, device=DEV)
+    dbias = O.reduce_rows(C1, 1, DEV)
     gcs, gps = to_cl(g_cat, cp_cat, dtype), to_cl(g_p, C1, dtype)
     O.pool_skip_act_bwd(ys, gps, coefp.to(DEV), cat, gcs, coefs.to(DEV), C0, dtype, L.ACT_LEAKY, 0.01, dz, dbias)
     got = from_cl(dz, C1, dtype)
     torch.testing.assert_close(got, gy_ref * lrelu_d, **TOL[dtype])
-    torch.testing.assert_close(dbias.cpu().float(), (gy_ref * lrelu_d).sum(dim=(0, 2, 3, 4)), rtol=1e-3,
+    torch.testing.assert_close(dbias.sum(0).cpu().float(), (gy_ref * lrelu_d).sum(dim=(0, 2, 3, 4)), rtol=1e-3,
                                atol=BIAS_ATOL[dtype])
     # upsample backward lands on the low-res producer (here with ELU as its activation)
     dzl = O.alloc_cl(B, ldims, C0, dtype, DEV)
@@ -330,11 +333,11 @@ def test_dice_and_output_grad():
     lib.call("sp_dice_bwd", O.ptr(od), Cc * dhw, O.ptr(td), Cc * dhw, O.ptr(coef), O.ptr(up), B, Cc, dhw, O.ptr(d), O.stream())
     torch.testing.assert_close(d.cpu(), 0.5 * (ca.view(1, -1, 1, 1, 1) * t + cb.view(1, -1, 1, 1, 1) * o), rtol=1e-5, atol=1e-9)
     dz = O.alloc_cl(B, dims, 8, L.SP_F32, DEV)
-    dbias = torch.zeros(8, dtype=torch.float64, device=DEV)
+    dbias = O.reduce_rows(8, 1, DEV)
     O.out_grad_to_cl(d, od, L.SP_F32, L.ACT_SIGMOID, 0.0, dz, dbias)
     ref = d.cpu() * o * (1 - o)
     torch.testing.assert_close(from_cl(dz, Cc, L.SP_F32), ref, rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(dbias[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dbias.sum(0)[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4)
 
 
 def test_adam_matches_torch():
@@ -465,12 +468,12 @@ def test_upsample2_act_bwd_tiled(dtype, C0, ldims):
     O.upsample2_fwd(lows, cat, dtype)
     gcs = to_cl(g_cat, cp_cat, dtype)
     dzl = O.alloc_cl(B, ldims, C0, dtype, DEV)
-    dbias = torch.zeros(C0, dtype=torch.float64, device=DEV)
+    dbias = O.reduce_rows(C0, 1, DEV)
     O.upsample2_act_bwd(lows, cat, gcs, coefs.to(DEV), dtype, L.ACT_ELU, 1.0, dzl, dbias)
     elu_d = torch.where(low > 0, torch.ones_like(low), low + 1.0)
     want = glow_ref * elu_d
     torch.testing.assert_close(from_cl(dzl, C0, dtype), want, **TOL[dtype])
-    torch.testing.assert_close(dbias.cpu().float(), want.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
+    torch.testing.assert_close(dbias.sum(0).cpu().float(), want.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
 
 
 def test_first_layer_packed():
@@ -524,7 +527,7 @@ def test_first_layer_packed():
     bs = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
     tapsrc = torch.arange(27, dtype=torch.int32, device=DEV)
     L.call("sp_wgrad_finish_folded", O.ptr(part), nparts, O.ptr(tapsrc), 27, 16, 2, 16, 2, 54, 27, O.ptr(sc), O.ptr(sh),
-           O.ptr(dbs), O.ptr(dw), O.ptr(db), O.ptr(wd), O.ptr(bs), nrep, 16, O.stream())
+           O.ptr(dbs), O.ptr(dw), O.ptr(db), O.ptr(wd), O.ptr(bs), nrep, 16, 0, O.stream())
     xn = xq * scale[:2].view(1, 2, 1, 1, 1) + shift[:2].view(1, 2, 1, 1, 1)
     wr = w.clone().requires_grad_(True)
     F.conv3d(xn, wr).backward(dz)
@@ -540,14 +543,14 @@ def test_first_layer_packed():
     coef = torch.randn(3, 16) * 0.5
     g_cl = to_cl(gq, 16, L.SP_BF16)
     dz2 = torch.empty_like(dz_cl)
-    dbs2 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    dbs2 = O.reduce_rows(16, 1, DEV)
     O.bn_act_bwd(g_cl, y, coef.to(DEV), L.SP_BF16, L.ACT_LEAKY, 0.01, dz2, dbs2)
     p_ref = torch.empty(nparts * 27 * 16 * 2, device=DEV)
     L.call("sp_first_wgrad", O.ptr(xd), O.ptr(dz2), B, dims[0], dims[1], dims[2], O.ptr(p_ref), nparts, O.stream())
     p_fus = torch.full_like(p_ref, float("nan"))
-    dbs3 = torch.zeros(16, dtype=torch.float64, device=DEV)
+    dbs3 = O.reduce_rows(16, 1, DEV)
     cd = coef.to(DEV)
     L.call("sp_first_wgrad_fused", O.ptr(xd), O.ptr(g_cl), O.ptr(y), O.ptr(cd), L.ACT_LEAKY, 0.01, B, dims[0], dims[1], dims[2],
            O.ptr(p_fus), nparts, O.ptr(dbs3), O.stream())
     torch.testing.assert_close(p_fus.view(nparts, -1).sum(0), p_ref.view(nparts, -1).sum(0), rtol=1e-4, atol=1e-3)
-    torch.testing.assert_close(dbs3, dbs2, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(dbs3.sum(0), dbs2.sum(0), rtol=1e-5, atol=1e-4)
