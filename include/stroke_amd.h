@@ -37,6 +37,8 @@ typedef void* sp_stream_t; /* hipStream_t */
 
 enum { SP_OK = 0, SP_EINVAL = -1, SP_EHIP = -2 };
 enum { SP_REDUCE_ROWS = 8 };
+/* row pitch (doubles) of the Dice accumulator sums[SP_REDUCE_ROWS][SP_DICE_PITCH(C)]: whole 128-byte lines */
+#define SP_DICE_PITCH(C) ((3 * (C) + 15) / 16 * 16)
 enum { SP_BF16 = 0, SP_F32 = 1 };
 enum { SP_ACT_NONE = 0, SP_ACT_LEAKY = 1, SP_ACT_ELU = 2, SP_ACT_SIGMOID = 3 };
 
@@ -274,7 +276,8 @@ int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C,
                       sp_stream_t stream);
 /* ------------------------------------------------------------------ BatchDiceLoss (metrics.py:16-28)
  * o, t: (B, C, DHW) fp32, contiguous per sample, arbitrary batch stride (elements) so that channel-slice views
- * (dto.outputs.core / .penu, UnetDto) are read in place.  sums[c][3] (fp64, zeroed by the caller) +=
+ * (dto.outputs.core / .penu, UnetDto) are read in place.  sums[row][3*c + k] (fp64, zeroed by the caller;
+ * SP_REDUCE_ROWS replica rows of SP_DICE_PITCH(C) doubles, added up by sp_dice_finalize) +=
  * (sum o*t, sum o*o, sum t*t) over batch and volume. */
 int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, int32_t B, int32_t C, int64_t DHW,
                  double* sums, sp_stream_t stream);

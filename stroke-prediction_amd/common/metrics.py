@@ -51,7 +51,7 @@ class _DiceFn(torch.autograd.Function):
         t, tbs = _batch_strided(targets)
         B, C = o.shape[0], o.shape[1]
         dhw = o.numel() // (B * C)
-        sums = torch.zeros(C, 3, dtype=torch.float64, device=o.device)
+        sums = torch.zeros(L.SP_REDUCE_ROWS, (3 * C + 15) // 16 * 16, dtype=torch.float64, device=o.device)   # replica rows
         L.call("sp_dice_sums", O.ptr(o), obs, O.ptr(t), tbs, B, C, dhw, O.ptr(sums), O.stream())
         from stroke_prediction_amd.runtime.layers import SYNC, _allreduce
         if SYNC["on"]:                  # Dice is a ratio of WHOLE-batch sums (metrics.py:24-27): make them global

@@ -1134,7 +1134,9 @@ __global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], w);
   }
   __syncthreads();
-  if (threadIdx.x < 3) atomicAdd(&sums[c * 3 + threadIdx.x], (double)red[threadIdx.x]);
+  // replica row per workgroup (rows 128 bytes or more apart): 1024 same-line fp64 atomics cost ~20 us at the tail
+  if (threadIdx.x < 3)
+    atomicAdd(&sums[(size_t)((blockIdx.x + blockIdx.y) % SP_REDUCE_ROWS) * SP_DICE_PITCH(C) + c * 3 + threadIdx.x], (double)red[threadIdx.x]);
 }
 extern "C" int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, int32_t B, int32_t C,
                             int64_t DHW, double* sums, sp_stream_t stream) {
@@ -1151,8 +1153,10 @@ __global__ void dice_finalize_kernel(const double* __restrict__ sums, const floa
                                      float* __restrict__ loss, float* __restrict__ coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   double acc = 0.0;
+  const int pitch = SP_DICE_PITCH(C);
   for (int c = 0; c < C; ++c) {
-    const double num = 2.0 * sums[c * 3] + eps, den = sums[c * 3 + 1] + sums[c * 3 + 2] + eps;
+    const double num = 2.0 * sp_rows_sum(sums, c * 3, pitch) + eps;
+    const double den = sp_rows_sum(sums, c * 3 + 1, pitch) + sp_rows_sum(sums, c * 3 + 2, pitch) + eps;
     acc += (double)w[c] * num / den;
     coef[2 * c] = (float)(-2.0 * w[c] / den);
     coef[2 * c + 1] = (float)(2.0 * w[c] * num / (den * den));

@@ -309,16 +309,16 @@ def test_dice_and_output_grad():
     B, Cc, dims = 2, 2, (6, 7, 9)
     o = torch.rand(B, Cc, *dims, generator=g)
     t = (torch.rand(B, Cc, *dims, generator=g) > 0.7).float()
-    sums = torch.zeros(Cc, 3, dtype=torch.float64, device=DEV)
+    sums = torch.zeros(L.SP_REDUCE_ROWS, 16, dtype=torch.float64, device=DEV)      # replica rows of SP_DICE_PITCH(C) doubles
     od, td = o.to(DEV), t.to(DEV)
     dhw = int(np.prod(dims))
     lib.call("sp_dice_sums", O.ptr(od), Cc * dhw, O.ptr(td), Cc * dhw, B, Cc, dhw, O.ptr(sums), O.stream())
     ref = torch.stack([(o * t).sum(dim=(0, 2, 3, 4)), (o * o).sum(dim=(0, 2, 3, 4)), (t * t).sum(dim=(0, 2, 3, 4))], 1)
-    torch.testing.assert_close(sums.cpu().float(), ref, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(sums.sum(0)[:3 * Cc].view(Cc, 3).cpu().float(), ref, rtol=1e-5, atol=1e-4)
     # channel-slice views (batch stride = all channels) are read in place
-    s1 = torch.zeros(1, 3, dtype=torch.float64, device=DEV)
+    s1 = torch.zeros(L.SP_REDUCE_ROWS, 16, dtype=torch.float64, device=DEV)
     lib.call("sp_dice_sums", O.ptr(od[:, 1:2]), Cc * dhw, O.ptr(td[:, 1:2]), Cc * dhw, B, 1, dhw, O.ptr(s1), O.stream())
-    torch.testing.assert_close(s1.cpu().float(), ref[1:2], rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(s1.sum(0)[:3].view(1, 3).cpu().float(), ref[1:2], rtol=1e-5, atol=1e-4)
     # finalize: loss and backward coefficients
     w = torch.tensor([0.3, 0.7])
     loss, coef = torch.empty((), device=DEV), torch.empty(2 * Cc, device=DEV)
