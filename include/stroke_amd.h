@@ -115,6 +115,20 @@ int sp_conv_prep_weights(const float* w, int64_t sCo, int64_t sCi, int32_t Cout,
                          void* wfrag_hi, void* wfrag_lo /* or NULL */,
                          const float* fold_scale /* [Cin] or NULL: w[co,ci,tap] *= fold_scale[ci] */,
                          sp_stream_t stream);
+/* The same for `n` weight tensors in one launch (the data-gradient re-packs of a whole network depend on the parameters
+ * only: one dispatch per step instead of one per layer).  items_dev: DEVICE array; max_blocks = max over the items of
+ * ceil(nsteps*NTtot*64 / 256). */
+typedef struct sp_prep_item {
+  const float* w;
+  int64_t sCo, sCi;
+  int32_t Cout, Cin;
+  const int32_t* kmap;
+  int32_t nsteps, NTtot;
+  void* wfrag_hi;
+  void* wfrag_lo;            /* or NULL */
+  const float* fold_scale;   /* or NULL */
+} sp_prep_item;
+int sp_conv_prep_weights_batch(const sp_prep_item* items_dev, int32_t n, int32_t max_blocks, sp_stream_t stream);
 /* BatchNorm folded into an un-padded convolution: bias_out[co] = bias[co] + sum_{ci,tap} w[co,ci,tap]*shift[ci]
  * (bias may be NULL = 0; bias_out has room for CoutPad entries, the tail is zeroed) */
 int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, int32_t ntaps,

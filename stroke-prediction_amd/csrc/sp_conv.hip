@@ -377,10 +377,10 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
 
 // ------------------------------------------------------------------------------------------------
 // weight re-packing: fp32 (Cout,Cin,taps) -> MFMA A fragments [step][ntile][lane][8] (hi / lo bf16)
-__global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
-                                  const int32_t* __restrict__ kmap, int nsteps, int NTtot,
-                                  bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, const float* __restrict__ fold) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (step, ntile, lane)
+__device__ __forceinline__ void prep_wfrag_one(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
+                                               const int32_t* __restrict__ kmap, int nsteps, int NTtot,
+                                               bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
+                                               const float* __restrict__ fold, int64_t idx) {   // idx = (step, ntile, lane)
   const int64_t total = (int64_t)nsteps * NTtot * 64;
   if (idx >= total) return;
   const int lane = idx & 63;
@@ -407,6 +407,24 @@ __global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int6
   }
   reinterpret_cast<uint4*>(hi)[idx] = make_uint4(wh[0], wh[1], wh[2], wh[3]);
   if (lo) reinterpret_cast<uint4*>(lo)[idx] = make_uint4(wl[0], wl[1], wl[2], wl[3]);
+}
+__global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
+                                  const int32_t* __restrict__ kmap, int nsteps, int NTtot,
+                                  bf16_t* __restrict__ hi, bf16_t* __restrict__ lo, const float* __restrict__ fold) {
+  prep_wfrag_one(w, sCo, sCi, Cout, Cin, kmap, nsteps, NTtot, hi, lo, fold, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// all re-packs that depend on the parameters only (the data-gradient weights of every layer) in ONE launch: grid.y = item
+__global__ void prep_wfrag_batch_kernel(const sp_prep_item* __restrict__ items) {
+  const sp_prep_item it = items[blockIdx.y];
+  prep_wfrag_one(it.w, it.sCo, it.sCi, it.Cout, it.Cin, it.kmap, it.nsteps, it.NTtot, reinterpret_cast<bf16_t*>(it.wfrag_hi),
+                 reinterpret_cast<bf16_t*>(it.wfrag_lo), it.fold_scale, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+extern "C" int sp_conv_prep_weights_batch(const sp_prep_item* items_dev, int32_t n, int32_t max_blocks, sp_stream_t stream) {
+  SP_CHECK_ARG(items_dev && n >= 1 && n <= 65535 && max_blocks >= 1, "sp_conv_prep_weights_batch: bad arguments");
+  hipLaunchKernelGGL(prep_wfrag_batch_kernel, dim3((unsigned)max_blocks, (unsigned)n), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), items_dev);
+  SP_CHECK_LAUNCH("sp_conv_prep_weights_batch");
+  return SP_OK;
 }
 
 extern "C" int sp_conv_prep_weights(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin,

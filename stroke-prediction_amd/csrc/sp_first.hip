@@ -66,9 +66,38 @@ __global__ __launch_bounds__(256) void bn_stats_ncdhw_kernel(const float* __rest
   const float* p = x + (size_t)bc * DHW;
   const int64_t per = (DHW + chunks - 1) / chunks, i0 = (int64_t)blockIdx.x * per, i1 = min(DHW, i0 + per);
   float s1 = 0.f, s2 = 0.f;
-  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-    const float v = bf2f(f2bf(p[i]));
-    s1 += v; s2 = fmaf(v, v, s2);
+  if (((uintptr_t)(p + i0) & 15) == 0) {       // 16-byte loads, four per thread in flight (4-byte loads: 2.2 TB/s)
+    const int64_t n4 = (i1 - i0) >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p + i0);
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = p4[i + 256 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v0 = bf2f(f2bf(q[u].x)), v1 = bf2f(f2bf(q[u].y)), v2 = bf2f(f2bf(q[u].z)), v3 = bf2f(f2bf(q[u].w));
+        a1[u] += (v0 + v1) + (v2 + v3);
+        a2[u] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, a2[u]))));
+      }
+    }
+    for (; i < n4; i += 256) {
+      const float4 q = p4[i];
+      const float v0 = bf2f(f2bf(q.x)), v1 = bf2f(f2bf(q.y)), v2 = bf2f(f2bf(q.z)), v3 = bf2f(f2bf(q.w));
+      a1[0] += (v0 + v1) + (v2 + v3);
+      a2[0] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, a2[0]))));
+    }
+    for (int64_t j = i0 + 4 * n4 + threadIdx.x; j < i1; j += 256) {
+      const float v = bf2f(f2bf(p[j]));
+      a1[1] += v; a2[1] = fmaf(v, v, a2[1]);
+    }
+    s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]); s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+  } else {
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float v = bf2f(f2bf(p[i]));
+      s1 += v; s2 = fmaf(v, v, s2);
+    }
   }
   __shared__ double r1[4], r2[4];
   const double d1 = wave_sum_d((double)s1), d2 = wave_sum_d((double)s2);
@@ -84,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_stats_ncdhw_kernel(const float* __rest
 extern "C" int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums,
                                  int32_t nrep, sp_stream_t stream) {
   SP_CHECK_ARG(x && sums && B >= 1 && C >= 1 && C <= CP && DHW >= 1 && nrep >= 1, "sp_bn_stats_ncdhw: bad arguments");
-  int chunks = (int)((DHW + 16383) / 16384);
+  int chunks = (int)((DHW + 8191) / 8192);          // ~2048 workgroups at B*C = 8, 128^3
   if (chunks > 1024) chunks = 1024;
   hipLaunchKernelGGL(bn_stats_ncdhw_kernel, dim3(chunks, B * C), dim3(256), 0, ST(stream), x, C, DHW, CP, sums, nrep, chunks);
   SP_CHECK_LAUNCH("sp_bn_stats_ncdhw");

@@ -37,6 +37,7 @@ class WgradArgs(C.Structure):
 
 _SIGS = {
     "sp_version": ([], i32),
+    "sp_conv_prep_weights_batch": ([vp, i32, i32, vp], i32),
     "sp_conv3d_igemm": ([C.POINTER(ConvArgs), vp], i32),
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),

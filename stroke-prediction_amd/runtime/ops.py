@@ -352,6 +352,41 @@ class WgradRunner:
                    ptr(dbias_grad), nbias, _dbias_stride(dbias_sums), st)
 
 
+_PREP_ITEM = np.dtype([("w", "<u8"), ("sCo", "<i8"), ("sCi", "<i8"), ("Cout", "<i4"), ("Cin", "<i4"), ("kmap", "<u8"),
+                       ("nsteps", "<i4"), ("NTtot", "<i4"), ("hi", "<u8"), ("lo", "<u8"), ("fold", "<u8")])   # sp_prep_item
+_prep_tables = {}
+
+
+def prep_batch(pairs):
+    """Re-pack the (un-folded) weights of many ConvRunners in ONE launch (sp_conv_prep_weights_batch).
+    pairs: [(runner, w)]; runners whose fragments are current (same key as ConvRunner.prep) are skipped, and after
+    the call every runner's key is current, so a later runner.prep(w) is a no-op."""
+    todo = []
+    for r, w in pairs:
+        key = (w.data_ptr(), w._version, PARAM_EPOCH[0], None)
+        if r._st["prep_key"] != key:
+            todo.append((r, w, key))
+    if not todo:
+        return
+    tkey = tuple((id(r._st), w.data_ptr()) for r, w, _ in todo)
+    tab = _prep_tables.get(tkey)
+    if tab is None:
+        items = []
+        for r, w, _ in todo:
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            for sub in r.subs:
+                items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, sub["kmap"].data_ptr(), sub["nsteps"],
+                              r.op.nttot, sub["hi"].data_ptr(), 0 if sub["lo"] is None else sub["lo"].data_ptr(), 0))
+        arr = np.array(items, dtype=_PREP_ITEM)
+        dev = torch.from_numpy(arr.view(np.uint8).copy()).to(todo[0][1].device)
+        maxb = max((int(it[6]) * int(it[7]) * 64 + 255) // 256 for it in items)
+        tab = _prep_tables[tkey] = (dev, len(items), maxb)
+    dev, n, maxb = tab
+    L.call("sp_conv_prep_weights_batch", dev.data_ptr(), n, maxb, stream())
+    for r, _, key in todo:
+        r._st["prep_key"] = key
+
+
 def _dbias_stride(dbias_sums):
     """dbias_sums: [SP_REDUCE_ROWS][CP] replica rows as the elementwise kernels fill them (2-D), or one row (1-D)."""
     if dbias_sums is None or dbias_sums.dim() == 1:

@@ -183,10 +183,9 @@ class UnetEngine:
         dseg = dseg.contiguous()
         # all data-gradient weight re-packs depend on the parameters only: side stream, beside the head's backward
         pre = O.fork()
-        with pre:
-            for l in self.layers:
-                if getattr(l, "dgrad", None) is not None and l.need_input_grad:
-                    l.dgrad.prep(params[l.conv_prefix + ".weight"])
+        with pre:      # ... and ONE launch for all of them
+            O.prep_batch([(l.dgrad, params[l.conv_prefix + ".weight"]) for l in self.layers
+                          if getattr(l, "dgrad", None) is not None and l.need_input_grad])
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
             b5, bc, ncls = self.channels[5], self.channels[6], self.ncls
