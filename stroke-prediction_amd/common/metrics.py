@@ -94,6 +94,41 @@ class BatchDiceLoss(LossModule):
         return _DiceFn.apply(outputs, targets, tuple(float(w) for w in self._label_weights), float(self._epsilon))
 
 
+def _stacked_base(parts):
+    """The (B, n, ...) fp32 tensor whose consecutive channel slices are exactly ``parts`` (each (B, 1, ...)), or None."""
+    base = getattr(parts[0], "_base", None)
+    n = len(parts)
+    if base is None or base.dtype != torch.float32 or not base.is_contiguous() or base.dim() != parts[0].dim() \
+            or base.shape[1] != n or base.shape[0] != parts[0].shape[0] or tuple(base.shape[2:]) != tuple(parts[0].shape[2:]):
+        return None
+    per = base[0, 0].numel()
+    for i, p in enumerate(parts):
+        if getattr(p, "_base", None) is not base or p.shape[1] != 1 or p.dtype != torch.float32 \
+                or p.data_ptr() != base.data_ptr() + 4 * i * per or _batch_strided(p)[1] != n * per:
+            return None
+    return base
+
+
+def mean_of_channel_losses(criterion, outputs, targets):
+    """mean_i criterion(outputs[i], targets[i]) -- the reference's ``(Dice(core) + Dice(penu)) / 2``
+    (learner/UnetSegmentationLearner.py:21-28).  When the criterion is a single-label BatchDiceLoss and the pairs are the
+    consecutive channel slices of one segmentation tensor and one label tensor (what Unet3D.forward / UnetInference
+    produce), this is BatchDiceLoss over n channels with weights w/n: evaluated in one sums / finalize / backward
+    launch on the base tensors, and the gradient lands on the segmentation directly (no slice-backward zero-fill,
+    copy and add per channel).  Anything else: the literal sum of calls."""
+    n = len(outputs)
+    if isinstance(criterion, BatchDiceLoss) and len(criterion._label_weights) == 1 and criterion._dim == 1 and n > 1 \
+            and outputs[0].is_cuda:
+        ob, tb = _stacked_base(outputs), _stacked_base(targets)
+        if ob is not None and tb is not None:
+            w = float(criterion._label_weights[0]) / n
+            return _DiceFn.apply(ob, tb, (w,) * n, float(criterion._epsilon))
+    total = criterion(outputs[0], targets[0])
+    for o, t in zip(outputs[1:], targets[1:]):
+        total = total + criterion(o, t)
+    return total / n
+
+
 # ---------------------------------------------------------------------------------------------- evaluation measures
 
 def _surface_distances(result, reference):

@@ -22,9 +22,8 @@ class UnetSegmentationLearner(Learner, UnetInference):
 
     def loss_step(self, dto: UnetDto, epoch):
         """(Dice(core) + Dice(penu)) / 2, UnetSegmentationLearner.py:21-28."""
-        loss = self._criterion(dto.outputs.core, dto.given_variables.core)
-        loss = loss + self._criterion(dto.outputs.penu, dto.given_variables.penu)
-        return loss / 2
+        return metrics.mean_of_channel_losses(self._criterion, (dto.outputs.core, dto.outputs.penu),
+                                              (dto.given_variables.core, dto.given_variables.penu))
 
     def batch_metrics_step(self, dto: UnetDto, epoch):
         batch_metrics = MetricMeasuresDtoInit.init_dto()

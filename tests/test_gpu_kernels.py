@@ -340,6 +340,35 @@ def test_dice_and_output_grad():
     torch.testing.assert_close(dbias.sum(0)[:Cc].cpu().float(), ref.sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-4)
 
 
+def test_mean_of_channel_losses_fused_equals_literal():
+    """(Dice(core) + Dice(penu)) / 2 on channel-slice views (UnetSegmentationLearner.py:21-28): the one-launch evaluation
+    on the base tensors against the literal two calls, value and gradient."""
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss, mean_of_channel_losses, _stacked_base
+    g = torch.Generator().manual_seed(5)
+    B, dims = 3, (5, 6, 7)
+    seg = torch.rand(B, 2, *dims, generator=g).to(DEV).requires_grad_(True)
+    lab = (torch.rand(B, 2, *dims, generator=g) > 0.6).float().to(DEV)
+    crit = BatchDiceLoss([1.0])
+
+    def views(s):
+        return s[:, 0, :, :, :].unsqueeze(1), s[:, 1, :, :, :].unsqueeze(1)       # Unet3D.forward :76-77
+    s2 = seg * 1.0                                   # non-leaf, like the network output
+    outs, tgts = views(s2), (lab[:, 0:1], lab[:, 1:2])
+    assert _stacked_base(outs) is s2 and _stacked_base(tgts) is lab
+    fused = mean_of_channel_losses(crit, outs, tgts)
+    gf, = torch.autograd.grad(fused, seg)
+    s3 = seg * 1.0
+    o3 = views(s3)
+    lit = (crit(o3[0], tgts[0]) + crit(o3[1], tgts[1])) / 2
+    gl, = torch.autograd.grad(lit, seg)
+    assert abs(float(fused) - float(lit)) < 1e-6
+    torch.testing.assert_close(gf, gl, rtol=1e-5, atol=1e-9)
+    # not slices of one tensor: falls back to the literal sum
+    other = torch.rand(B, 1, *dims, generator=g).to(DEV)
+    fb = mean_of_channel_losses(crit, (outs[0], other), tgts)
+    assert abs(float(fb) - float((crit(outs[0], tgts[0]) + crit(other, tgts[1])) / 2)) < 1e-6
+
+
 def test_adam_matches_torch():
     g = torch.Generator().manual_seed(4)
     n = 10007
