@@ -346,6 +346,19 @@ int sp_adam_step_flat_dev(float* p, const float* g, float* m, float* v, int64_t 
                           float eps, float weight_decay, const int32_t* step_dev, float grad_scale,
                           sp_stream_t stream);
 
+/* ------------------------------------------------------------------ input pipeline (SURVEY.md 8 "next" row N4)
+ * ElasticDeform.elastic_transform (common/data.py:326-339) on the device.  Volumes are C-ordered (n0, n1, n2) fp32
+ * arrays, the reference's (x, y, z) numpy layout.
+ * sp_gaussian_filter3d = scipy.ndimage.gaussian_filter(src, sigma, mode="constant", cval=0, truncate) (data.py:332-334):
+ * radius int(truncate*sigma + 0.5) (<= 64), normalised weights, axis 0 then 1 then 2; tmp = scratch of the same size;
+ * src, dst, tmp: three different buffers. */
+int sp_gaussian_filter3d(const float* src, float* dst, float* tmp, int32_t n0, int32_t n1, int32_t n2, float sigma,
+                         float truncate, sp_stream_t stream);
+/* sp_map_coordinates_linear = scipy.ndimage.map_coordinates(image, (i + s0*d0, j + s1*d1, k + s2*d2), order=1,
+ * mode="constant", cval) (data.py:336-339): cval wherever a coordinate leaves [0, n-1], else trilinear interpolation */
+int sp_map_coordinates_linear(const float* image, const float* d0, const float* d1, const float* d2, float s0, float s1, float s2,
+                              float cval, float* out, int32_t n0, int32_t n1, int32_t n2, sp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
