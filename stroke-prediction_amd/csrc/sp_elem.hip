@@ -541,6 +541,34 @@ template <> struct RawOct<float> {
   }
 };
 
+// ---- packed fp32 pairs: v_pk_fma_f32 / v_pk_mul_f32 do two fp32 operations per lane and instruction on gfx950; the
+// gather kernels below are VALU-bound (the 4-channels-per-thread variant of upcat_fwd, 126 instead of 213 VGPRs and twice
+// the occupancy, was 10 % SLOWER), so their interpolation arithmetic runs on channel pairs
+typedef float f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2_t f2_fma(f2_t a, f2_t b, f2_t c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2_t f2_splat(float v) { f2_t r = {v, v}; return r; }
+__device__ __forceinline__ void raw_get2(const RawOct<bf16_t>& r, f2_t* v) {
+  const uint32_t w[4] = {r.r.x, r.r.y, r.r.z, r.r.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f2_t t = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)}; v[i] = t; }
+}
+__device__ __forceinline__ void raw_get2(const RawOct<float>& r, f2_t* v) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f2_t t = {r.f[2 * i], r.f[2 * i + 1]}; v[i] = t; }
+}
+__device__ __forceinline__ void st8_f2(bf16_t* p, const f2_t* v) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void st8_f2(float* p, const f2_t* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+}
+__device__ __forceinline__ f2_t round_like(const bf16_t*, f2_t v) { f2_t r = {bf2f(f2bf(v.x)), bf2f(f2bf(v.y))}; return r; }
+__device__ __forceinline__ f2_t round_like(const float*, f2_t v) { return v; }
+
 // Upsample + crop + concat in ONE pass (Unet3D.py:67-72): every voxel row of the concat buffer (all CPd channels) is
 // written by neighbouring lanes -- full lines -- instead of two kernels each writing a slice of every row.  Channels
 // [0, CPu) are the trilinear x2 upsample of `low`, channels [CPu, CPu + CPs) the centre crop of `skip`;
@@ -561,9 +589,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
   const int ocu = CPu / 8;
   const bool isup = oc < ocu;
   const int64_t nblk = (int64_t)dl.B * dl.D * dl.H * dl.W;       // one block per source voxel
-  float part[2][8];
+  f2_t part2[2][4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) part[0][j] = part[1][j] = 0.f;
+  for (int j = 0; j < 4; ++j) part2[0][j] = part2[1][j] = f2_splat(0.f);
   const Unflat uf_(dl.D, dl.H, dl.W);
   if (active) {
     const int64_t chunk_ = ((nblk + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
@@ -571,55 +599,54 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
       int b, z, yy, xx;
       uf_(v, b, z, yy, xx);
-      float out[8][8];                                             // [zo*4 + yo*2 + xo][channel]
+      f2_t out[8][4];                                              // [zo*4 + yo*2 + xo][channel pair]
       if (isup) {
         const int xs[3] = {max(xx - 1, 0), xx, min(xx + 1, dl.W - 1)};
         const int ys[3] = {max(yy - 1, 0), yy, min(yy + 1, dl.H - 1)};
 #pragma unroll
         for (int q = 0; q < 8; ++q)
 #pragma unroll
-          for (int j = 0; j < 8; ++j) out[q][j] = 0.f;
+          for (int j = 0; j < 4; ++j) out[q][j] = f2_splat(0.f);
 #pragma unroll 1
         for (int dz = 0; dz < 3; ++dz) {
           const int zs = dz == 0 ? max(z - 1, 0) : (dz == 1 ? z : min(z + 1, dl.D - 1));
-          const float wz0 = dz == 0 ? 0.25f : (dz == 1 ? 0.75f : 0.f);      // weight into output plane 2z
-          const float wz1 = dz == 0 ? 0.f : (dz == 1 ? 0.75f : 0.25f);      // ... and 2z + 1
+          const f2_t wz0 = f2_splat(dz == 0 ? 0.25f : (dz == 1 ? 0.75f : 0.f));      // weight into output plane 2z
+          const f2_t wz1 = f2_splat(dz == 0 ? 0.f : (dz == 1 ? 0.75f : 0.25f));      // ... and 2z + 1
           const T* pz = low + (((int64_t)b * dl.D + zs) * dl.H) * dl.W * CPu + oc * 8;
-          float ye[2][8], yo[2][8];                                          // [x parity][channel] for the even / odd output y
-#pragma unroll
-          for (int xo = 0; xo < 2; ++xo)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ye[xo][j] = yo[xo][j] = 0.f;
+          // x-interpolated rows (even / odd output x) of the three source rows, then the two output y
+          f2_t xe[3][4], xo[3][4];
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             RawOct<T> r0, r1, r2;
             const T* py = pz + (int64_t)ys[dy] * dl.W * CPu;
             r0.load(py + (int64_t)xs[0] * CPu); r1.load(py + (int64_t)xs[1] * CPu); r2.load(py + (int64_t)xs[2] * CPu);
-            float a0[8], a1[8], a2[8];
-            r0.get(a0); r1.get(a1); r2.get(a2);
-            const float wy0 = dy == 0 ? 0.25f : (dy == 1 ? 0.75f : 0.f), wy1 = dy == 0 ? 0.f : (dy == 1 ? 0.75f : 0.25f);
+            f2_t a0[4], a1[4], a2[4];
+            raw_get2(r0, a0); raw_get2(r1, a1); raw_get2(r2, a2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              const float xe = 0.25f * a0[j] + 0.75f * a1[j], xo_ = 0.75f * a1[j] + 0.25f * a2[j];
-              ye[0][j] = fmaf(wy0, xe, ye[0][j]); ye[1][j] = fmaf(wy0, xo_, ye[1][j]);
-              yo[0][j] = fmaf(wy1, xe, yo[0][j]); yo[1][j] = fmaf(wy1, xo_, yo[1][j]);
+            for (int j = 0; j < 4; ++j) {
+              const f2_t m = a1[j] * 0.75f;
+              xe[dy][j] = f2_fma(f2_splat(0.25f), a0[j], m);
+              xo[dy][j] = f2_fma(f2_splat(0.25f), a2[j], m);
             }
           }
 #pragma unroll
-          for (int xo = 0; xo < 2; ++xo)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              out[0 + 0 + xo][j] = fmaf(wz0, ye[xo][j], out[0 + 0 + xo][j]);
-              out[0 + 2 + xo][j] = fmaf(wz0, yo[xo][j], out[0 + 2 + xo][j]);
-              out[4 + 0 + xo][j] = fmaf(wz1, ye[xo][j], out[4 + 0 + xo][j]);
-              out[4 + 2 + xo][j] = fmaf(wz1, yo[xo][j], out[4 + 2 + xo][j]);
-            }
+          for (int j = 0; j < 4; ++j) {
+            const f2_t me = xe[1][j] * 0.75f, mo = xo[1][j] * 0.75f;
+            const f2_t ye0 = f2_fma(f2_splat(0.25f), xe[0][j], me), ye1 = f2_fma(f2_splat(0.25f), xo[0][j], mo);   // even output y
+            const f2_t yo0 = f2_fma(f2_splat(0.25f), xe[2][j], me), yo1 = f2_fma(f2_splat(0.25f), xo[2][j], mo);   // odd output y
+            out[0][j] = f2_fma(wz0, ye0, out[0][j]); out[1][j] = f2_fma(wz0, ye1, out[1][j]);
+            out[2][j] = f2_fma(wz0, yo0, out[2][j]); out[3][j] = f2_fma(wz0, yo1, out[3][j]);
+            out[4][j] = f2_fma(wz1, ye0, out[4][j]); out[5][j] = f2_fma(wz1, ye1, out[5][j]);
+            out[6][j] = f2_fma(wz1, yo0, out[6][j]); out[7][j] = f2_fma(wz1, yo1, out[7][j]);
+          }
         }
       } else {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
-          Store<T>::ld8(skip + ((((int64_t)b * ds.D + zo + oz) * ds.H + yo + oy) * ds.W + xo + ox) * CPs + (oc - ocu) * 8, out[q]);
+          RawOct<T> r;
+          r.load(skip + ((((int64_t)b * ds.D + zo + oz) * ds.H + yo + oy) * ds.W + xo + ox) * CPs + (oc - ocu) * 8);
+          raw_get2(r, out[q]);
         }
       }
 #pragma unroll
@@ -627,14 +654,20 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
         const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
         const int64_t vo = (((int64_t)b * Do + zo) * Ho + yo) * Wo + xo;
         // cat_plane != 0: plane-major concat buffer [plane][B][D][H][W][16] (dense 16-channel planes for the consumers)
-        Store<T>::st8(cat_plane ? cat + (int64_t)(oc >> 1) * cat_plane + vo * 16 + (oc & 1) * 8 : cat + vo * CPd + oc * 8, out[q]);
+        st8_f2(cat_plane ? cat + (int64_t)(oc >> 1) * cat_plane + vo * 16 + (oc & 1) * 8 : cat + vo * CPd + oc * 8, out[q]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float o = sizeof(T) == 2 ? bf2f(f2bf(out[q][j])) : out[q][j];
-          part[0][j] += o; part[1][j] += o * o;
+        for (int j = 0; j < 4; ++j) {
+          const f2_t o = round_like(cat, out[q][j]);
+          part2[0][j] += o; part2[1][j] = f2_fma(o, o, part2[1][j]);
         }
       }
     }
+  }
+  float part[2][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    part[0][2 * j] = part2[0][j].x; part[0][2 * j + 1] = part2[0][j].y;
+    part[1][2 * j] = part2[1][j].x; part[1][2 * j + 1] = part2[1][j].y;
   }
   if (stats) block_channel_reduce<2>(part, oc, active, CPd, stats, red);
 }
