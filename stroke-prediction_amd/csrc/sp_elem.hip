@@ -98,6 +98,18 @@ __device__ __forceinline__ void block_channel_reduce(const float part[NS][8], in
   }
 }
 
+// act'(y) with the activation fixed at compile time (ACT >= 0) -- with a run-time `act` hipcc keeps the switch inside the
+// innermost loops: one scalar compare-and-branch chain per ELEMENT (pool/skip backward: 405 s_cbranch in the loop body)
+template <int ACT> __device__ __forceinline__ float act_bwd_t(int act, float p, float y) {
+  return act_bwd_from_y(ACT >= 0 ? ACT : act, p, y);
+}
+#define SP_ACT_DISPATCH(act, LAUNCH)                 \
+  switch (act) {                                      \
+    case SP_ACT_LEAKY: { LAUNCH(SP_ACT_LEAKY); } break; \
+    case SP_ACT_ELU: { LAUNCH(SP_ACT_ELU); } break;     \
+    default: { LAUNCH(-1); } break;                     \
+  }
+
 // ------------------------------------------------------------------------------------------------ layout
 // one thread = one (voxel, 8-channel octet): wide-channel / few-voxel tensors (the CAE latent, 800 x 100) still
 // fill the chip; consecutive threads take consecutive voxels of one octet (coalesced NCDHW reads)
@@ -290,7 +302,7 @@ extern "C" int sp_bn_bwd_finalize(const double* sums, int32_t nrep, double count
 }
 
 // dz = (coef0*g + coef1*y + coef2) * act'(y)  [coef == NULL: dz = g*act'(y)] ; dbias_sums[c] += sum dz
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                           const float* __restrict__ coef, int64_t nvox, int CP,
                                                           OctMap om, int act, float ap, T* __restrict__ dz,
@@ -317,7 +329,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
       Store<T>::ld8(y + v * CP + oc * 8, b);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        o[j] = (c0[j] * a[j] + c1[j] * b[j] + c2[j]) * act_bwd_from_y(act, ap, b[j]);
+        o[j] = (c0[j] * a[j] + c1[j] * b[j] + c2[j]) * act_bwd_t<ACT>(act, ap, b[j]);
         part[0][j] += o[j];
       }
       Store<T>::st8(dz + v * CP + oc * 8, o);
@@ -331,8 +343,13 @@ extern "C" int sp_bn_act_bwd(const void* g, const void* y, const float* coef, in
   OctMap om = make_octmap(CP);
   const unsigned grid = grid_for(nvox, om.vpb * 4);
   const size_t sh = (size_t)CP * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(bn_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)g, (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);
-  else hipLaunchKernelGGL(bn_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)g, (const float*)y, coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums);
+#define SP_L(A_)                                                                                                                   \
+  if (dtype == SP_BF16) hipLaunchKernelGGL((bn_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)g, \
+                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);           \
+  else hipLaunchKernelGGL((bn_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)g, (const float*)y,   \
+                          coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums)
+  SP_ACT_DISPATCH(act, SP_L)
+#undef SP_L
   SP_CHECK_LAUNCH("sp_bn_act_bwd");
   return SP_OK;
 }
@@ -694,7 +711,7 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
 // Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
 // One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
 // (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
     const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, int ccs0, int cstride, Dims di, int CP, Dims dc,
@@ -776,7 +793,7 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
             for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * yv[j] + s2[j];
           }
 #pragma unroll
-          for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_from_y(act, ap, yv[j]); part[0][j] += d[j]; }
+          for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_t<ACT>(act, ap, yv[j]); part[0][j] += d[j]; }
           Store<T>::st8(dz + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, d);
         }
       }
@@ -799,8 +816,15 @@ extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* 
   const int64_t nwin = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   const unsigned grid = grid_for(nwin, om.vpb);
   const size_t sh = (size_t)CP * 4 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(pool_skip_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);
-  else hipLaunchKernelGGL(pool_skip_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act, act_param, (float*)dz, dbias_sums);
+#define SP_L(A_)                                                                                                                          \
+  if (dtype == SP_BF16) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
+                                           (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0,   \
+                                           coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);                          \
+  else hipLaunchKernelGGL((pool_skip_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, \
+                          coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act,       \
+                          act_param, (float*)dz, dbias_sums)
+  SP_ACT_DISPATCH(act, SP_L)
+#undef SP_L
   SP_CHECK_LAUNCH("sp_pool_skip_act_bwd");
   return SP_OK;
 }
@@ -887,7 +911,7 @@ __device__ __forceinline__ float upM_diag(int i, int N) {
   upT_axis(i, N, o, w);
   return w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3];
 }
-template <typename T>
+template <typename T, int ACT>
 __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* __restrict__ y, const T* __restrict__ g,
                                                                        const float* __restrict__ coef, int CPcat, int cstride, Dims di,
                                                                        int CP, OctMap om, UpTile ut, int act, float ap,
@@ -1029,7 +1053,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float my_ = mzl * qprev[j] + mzc * qcur[j] + mzr * qnext[j];
-        o8[j] = (c0[j] * Acur[j] + c1[j] * my_ + c2[j]) * act_bwd_from_y(act, ap, ycur[j]);
+        o8[j] = (c0[j] * Acur[j] + c1[j] * my_ + c2[j]) * act_bwd_t<ACT>(act, ap, ycur[j]);
       }
       if (valid) {
 #pragma unroll
@@ -1072,15 +1096,20 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
     const size_t sh2 = (2 * (size_t)ut.RY * ut.RX + (size_t)(ut.TY + 2) * (ut.TX + 2)) * CP * esz + (size_t)CP * sizeof(float);
     if (sh2 <= 150 * 1024) {      // + 8 KB static (block_channel_reduce)
       const unsigned grid2 = (unsigned)(cols * ut.ZS);
-      if (dtype == SP_BF16) {
-        auto kern = upsample2_act_bwd_tiled_kernel<bf16_t>;
-        SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");
-        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, coef_stride, di, CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums);
-      } else {
-        auto kern = upsample2_act_bwd_tiled_kernel<float>;
-        SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");
-        hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const float*)y, (const float*)g, coef, CPcat, coef_stride, di, CP, om, ut, act, act_param, (float*)dz, dbias_sums);
-      }
+#define SP_L(A_)                                                                                                                      \
+  if (dtype == SP_BF16) {                                                                                                             \
+    auto kern = upsample2_act_bwd_tiled_kernel<bf16_t, A_>;                                                                           \
+    SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");                                                                            \
+    hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, coef_stride, di, \
+                       CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums);                                                         \
+  } else {                                                                                                                            \
+    auto kern = upsample2_act_bwd_tiled_kernel<float, A_>;                                                                            \
+    SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");                                                                            \
+    hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const float*)y, (const float*)g, coef, CPcat, coef_stride, di,  \
+                       CP, om, ut, act, act_param, (float*)dz, dbias_sums);                                                          \
+  }
+      SP_ACT_DISPATCH(act, SP_L)
+#undef SP_L
       SP_CHECK_LAUNCH("sp_upsample2_act_bwd");
       return SP_OK;
     }
