@@ -261,7 +261,7 @@ extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H
 // FUSED: dz is not read but formed on the fly, dz = (c0*g + c1*y + c2) * act'(y) (BatchNorm backward of the NEXT layer
 // and the activation derivative, i.e. sp_bn_act_bwd), and its per-channel sum is accumulated for the bias gradient --
 // the 2 x 256 MB round trip of dz through HBM and one launch disappear (nobody else reads this layer's dz).
-template <bool FUSED>
+template <bool FUSED, int ACT>      // ACT >= 0: activation fixed at compile time (no per-element branch chain)
 __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, const bf16_t* __restrict__ dzg,
                                                            const bf16_t* __restrict__ gg, const bf16_t* __restrict__ yg,
                                                            const float* __restrict__ coef, int act, float ap,
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
           Store<bf16_t>::ld8(yg + o, y8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            d8[j] = (k0[j] * g8[j] + k1[j] * y8[j] + k2[j]) * act_bwd_from_y(act, ap, y8[j]);
+            d8[j] = (k0[j] * g8[j] + k1[j] * y8[j] + k2[j]) * act_bwd_from_y(ACT >= 0 ? ACT : act, ap, y8[j]);
             dsum[j] += d8[j];
           }
           uint32_t w4[4];
@@ -385,7 +385,7 @@ extern "C" int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t
   SP_CHECK_ARG(x && dz && partials && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1, "sp_first_wgrad: bad arguments");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad: too many tiles");
-  hipLaunchKernelGGL(first_wgrad_kernel<false>, dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, nullptr, nullptr,
+  hipLaunchKernelGGL((first_wgrad_kernel<false, -1>), dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, nullptr, nullptr,
                      nullptr, 0, 0.f, nullptr, partials);
   SP_CHECK_LAUNCH("sp_first_wgrad");
   return SP_OK;
@@ -398,8 +398,12 @@ extern "C" int sp_first_wgrad_fused(const float* x, const void* g, const void* y
                "sp_first_wgrad_fused: bad arguments");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad_fused: too many tiles");
-  hipLaunchKernelGGL(first_wgrad_kernel<true>, dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,
-                     (const bf16_t*)y, coef, act, act_param, dbias_sums, partials);
+  if (act == SP_ACT_LEAKY)
+    hipLaunchKernelGGL((first_wgrad_kernel<true, SP_ACT_LEAKY>), dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,
+                       (const bf16_t*)y, coef, act, act_param, dbias_sums, partials);
+  else
+    hipLaunchKernelGGL((first_wgrad_kernel<true, -1>), dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,
+                       (const bf16_t*)y, coef, act, act_param, dbias_sums, partials);
   SP_CHECK_LAUNCH("sp_first_wgrad_fused");
   return SP_OK;
 }

@@ -59,6 +59,8 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
                                                         int CP, const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, float slope, int act_x, float act_x_p,
                                                         T* __restrict__ dz, float* __restrict__ part) {
+  const bool lin_x = act_x == SP_ACT_LEAKY || act_x == SP_ACT_NONE;
+  const float slope_x = act_x == SP_ACT_LEAKY ? act_x_p : 1.f;
   constexpr int REC = CH + CH + C + 4;            // floats per voxel record
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sw1 = smem;                               // [CH][C]
@@ -119,7 +121,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const T* __restrict__ x, 
         for (int i = 0; i < C; ++i) dx[i] = fmaf(sw1[k * C + i], dhp, dx[i]);
       }
 #pragma unroll
-      for (int i = 0; i < C; ++i) { dx[i] *= act_bwd_from_y(act_x, act_x_p, xv[i]); dbz[i] += dx[i]; }
+      for (int i = 0; i < C; ++i) {       // leaky / identity without the per-element switch (wave-uniform `lin_x`)
+        dx[i] *= lin_x ? (xv[i] > 0.f ? 1.f : slope_x) : act_bwd_from_y(act_x, act_x_p, xv[i]);
+        dbz[i] += dx[i];
+      }
 #pragma unroll
       for (int c = 0; c < C; c += 8) Store<T>::st8(dz + v * CP + c, dx + c);
       for (int c = C; c < CP; c += 8) { float z8[8] = {0, 0, 0, 0, 0, 0, 0, 0}; Store<T>::st8(dz + v * CP + c, z8); }
@@ -255,6 +260,8 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __rest
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              float slope, int act_x, float act_x_p,
                                                              bf16_t* __restrict__ dz, float* __restrict__ part) {
+  const bool lin_x = act_x == SP_ACT_LEAKY || act_x == SP_ACT_NONE;
+  const float slope_x = act_x == SP_ACT_LEAKY ? act_x_p : 1.f;
   constexpr int C = 16, NP = CH / 16, NPL = 2 + 2 * NP, KV = 4 * NP;      // planes: X, AUX, DHP[NP], H[NP]
   constexpr int PLANE = 64 * 32;                                          // bytes of one 64-voxel plane
   typedef typename HeadK<NP>::vec kvec;
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void head_bwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float xv = bf2f((bf16_t)xb[j]);
-          o4[j] = dx[j] * act_bwd_from_y(act_x, act_x_p, xv);
+          o4[j] = dx[j] * (lin_x ? (xv > 0.f ? 1.f : slope_x) : act_bwd_from_y(act_x, act_x_p, xv));
           dbz[j] += o4[j];
         }
         Store<bf16_t>::st4(dz + v * CP + 4 * lg, o4);
