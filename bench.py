@@ -81,6 +81,62 @@ def torch_gpu_baseline(size, batch, steps=3, bf16=True):
             % ("bf16 autocast" if bf16 else "fp32"), "batch": batch}
 
 
+def bench_unet_infer(args, world, rank, dev):
+    """Tester.infer_batch / Learner.validate_batch -- eval-mode forward (running BatchNorm statistics),
+    torch.no_grad, reference call path model(dto) (Tester.py:16-28, Learner.py:132-142)."""
+    import torch.distributed as dist
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+    from stroke_prediction_amd.runtime.unet_engine import unet_out_dims
+    size = (args.size,) * 3
+    out = unet_out_dims(size)
+    torch.manual_seed(1234)
+    model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).eval()
+    model.freeze(True)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
+    labels = torch.zeros((args.batch, 2) + out, device=dev)
+
+    def step():
+        with torch.no_grad():
+            dto = model(UnetDtoUtil.init_dto(images, labels[:, 0:1], labels[:, 1:2]))
+        return dto.outputs.core
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 3)):
+        step()
+    fence()
+    graph, _ = capture_step(step, not args.no_graph and world == 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
+    res = {"metric": "inference voxels/sec, 3D U-Net Bx2x%d^3 (eval forward)" % args.size, "value": vox / dt, "unit": "voxels/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, eval forward "
+                                  "(SURVEY 8 row N1)" % (args.batch, args.size, out[0]),
+                      "launch": "hipGraph" if graph is not None else "eager"}}
+    if rank == 0:
+        print(json.dumps(res))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def capture_step(step, enabled):
     """Capture one optimiser step (hundreds of kernel launches) into a hipGraph; returns (graph, static_loss) or (None, None)."""
     if not enabled:
@@ -177,8 +233,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--workload", default="unet", choices=["unet", "cae"],
-                    help="unet = BASELINE configs[1] (headline); cae = configs[2]: CAE 1 16 24 32 100 800 1, 3 enc + 4 dec passes")
+    ap.add_argument("--workload", default="unet", choices=["unet", "cae", "unet-infer"],
+                    help="unet = BASELINE configs[1] (headline); cae = configs[2]: CAE 1 16 24 32 100 800 1, 3 enc + 4 dec passes; "
+                         "unet-infer = SURVEY 8 row N1: eval-mode forward only (Tester / validate_batch), no gradients")
     ap.add_argument("--cae-depth", type=int, default=28, help="CAE volume depth (28 native, 124 = closest closed size to 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -223,6 +280,8 @@ def main():
 
     if args.workload == "cae":
         return bench_cae(args, world, rank, dev)
+    if args.workload == "unet-infer":
+        return bench_unet_infer(args, world, rank, dev)
     size = (args.size,) * 3
     out = unet_out_dims(size)
     torch.manual_seed(1234)                      # identical random-init weights on every rank

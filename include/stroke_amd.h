@@ -359,6 +359,18 @@ int sp_gaussian_filter3d(const float* src, float* dst, float* tmp, int32_t n0, i
 int sp_map_coordinates_linear(const float* image, const float* d0, const float* d1, const float* d2, float s0, float s1, float s2,
                               float cval, float* out, int32_t n0, int32_t n1, int32_t n2, sp_stream_t stream);
 
+/* ------------------------------------------------------------------ surface distances of the batch metrics
+ * metrics.py:42-44 -> medpy 0.3.0 metric.binary.hd / assd (__surface_distances): border = mask XOR binary_erosion(mask)
+ * with the cross structure of the array's rank (out-of-bounds = background), exact Euclidean distance transform of the
+ * complement of the other mask's border (unit spacing), sampled at this mask's border.  result / reference: fp32 arrays
+ * of rank ndim <= 5 (the reference passes the whole (B,1,D,H,W) tensors: the transform then runs across the batch axis
+ * too, and the extent-1 channel axis makes every voxel a border voxel -- reproduced), mask = value > threshold.
+ * ws: 4*prod(dims) floats; out[6] (fp64, zeroed by the caller) = {max SQUARED distance (an exact integer), sum of the
+ * distances, count} result-border -> reference-border, then the same for reference -> result:
+ * hd = sqrt(max(out[0], out[3])),  assd = (out[1]/out[2] + out[4]/out[5]) / 2. */
+int sp_surface_distances(const float* result, const float* reference, float threshold, int32_t ndim, const int32_t* dims,
+                         float* ws, double* out, sp_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

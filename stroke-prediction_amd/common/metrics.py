@@ -168,7 +168,31 @@ def binary_measures_numpy(result, target, binary_threshold=0.5, distances=True):
     return out
 
 
-DISTANCE_METRICS = True      # Hausdorff / ASSD (CPU distance transforms, as medpy does); False keeps the metrics on the GPU
+DISTANCE_METRICS = True      # Hausdorff / ASSD as the reference's batch metrics report them (metrics.py:42-44)
+DEVICE_DISTANCES = True      # ... from the HIP distance transform (sp_surface_distances); False: scipy on the host, like medpy
+
+
+_SD_WS = {}
+
+
+def _surface_distances_launch(r, t, threshold):
+    """Enqueue sp_surface_distances; returns the fp64[6] result tensor (no synchronisation)."""
+    from stroke_prediction_amd.runtime import lib as L, ops as O
+    dims = torch.tensor(list(r.shape), dtype=torch.int32)            # host array: read by the launcher, not the kernels
+    key = (r.device, r.numel())
+    if key not in _SD_WS:
+        _SD_WS.clear()                                               # one workspace (4 volumes) alive at a time
+        _SD_WS[key] = torch.empty(4 * r.numel(), dtype=torch.float32, device=r.device)
+    out = torch.zeros(6, dtype=torch.float64, device=r.device)
+    L.call("sp_surface_distances", O.ptr(r), O.ptr(t), float(threshold), r.dim(), dims.data_ptr(), O.ptr(_SD_WS[key]), O.ptr(out),
+           O.stream())
+    return out
+
+
+def _surface_metrics_device(r, t, threshold):
+    """(hd, assd) of two CUDA fp32 tensors of equal shape (rank <= 5), medpy semantics -- see sp_surface_distances."""
+    mx_rt, sm_rt, n_r, mx_tr, sm_tr, n_t = _surface_distances_launch(r, t, threshold).tolist()
+    return float(numpy.sqrt(max(mx_rt, mx_tr))), 0.5 * (sm_rt / n_r + sm_tr / n_t)
 
 
 def binary_measures_torch(result, target, cuda, binary_threshold=0.5, distances=None):
@@ -182,12 +206,18 @@ def binary_measures_torch(result, target, cuda, binary_threshold=0.5, distances=
         t = target.detach().float().contiguous()
         counts = torch.zeros(4, dtype=torch.int64, device=r.device)
         L.call("sp_confusion_counts", O.ptr(r), O.ptr(t), float(binary_threshold), r.numel(), O.ptr(counts), O.stream())
+        on_device = distances and DEVICE_DISTANCES and r.dim() <= 5
+        sd = _surface_distances_launch(r, t, binary_threshold) if on_device else None    # enqueued before the one sync below
         tp, fp, fn, tn = (float(v) for v in counts.tolist())
         out = _measures_from_counts(tp, fp, fn, tn)
         if distances and tp + fp > 0 and tp + fn > 0:
-            rn, tn_ = r.cpu().numpy() > binary_threshold, t.cpu().numpy() > binary_threshold
-            out.hd = _hd(rn, tn_)
-            out.assd = _assd(rn, tn_)
+            if on_device:
+                mx_rt, sm_rt, n_r, mx_tr, sm_tr, n_t = sd.tolist()
+                out.hd, out.assd = float(numpy.sqrt(max(mx_rt, mx_tr))), 0.5 * (sm_rt / n_r + sm_tr / n_t)
+            else:
+                rn, tn_ = r.cpu().numpy() > binary_threshold, t.cpu().numpy() > binary_threshold
+                out.hd = _hd(rn, tn_)
+                out.assd = _assd(rn, tn_)
         return out
     result = result.detach().cpu().numpy() if isinstance(result, torch.Tensor) else result
     target = target.detach().cpu().numpy() if isinstance(target, torch.Tensor) else target

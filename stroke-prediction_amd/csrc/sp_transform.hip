@@ -100,3 +100,131 @@ extern "C" int sp_map_coordinates_linear(const float* image, const float* d0, co
   SP_CHECK_LAUNCH("sp_map_coordinates_linear");
   return SP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ surface distances
+// Hausdorff / average symmetric surface distance of the batch metrics (metrics.py:31-44 -> medpy 0.3.0
+// metric.binary.hd / assd -> __surface_distances): border = mask XOR binary_erosion(mask, cross structure of the array's
+// rank, border_value 0), distances = Euclidean distance transform of the complement of the reference border, sampled at
+// the result border.  The reference hands medpy the whole (B, 1, D, H, W) tensor, so the structure and the transform
+// are FIVE-dimensional: an axis of extent 1 makes every voxel a border voxel, and neighbouring batch entries are one
+// voxel apart.  All of that is reproduced: arrays of rank <= 5, unit spacing.
+// Exact EDT, separable: g <- min_j g[.., j, ..] + (i - j)^2 along each axis in turn.  With extents <= 128 the plain
+// O(n) scan per voxel is ~270 fused min-adds per voxel for 4 x 88^3 -- less than a millisecond, no lower-envelope stack.
+#define SP_SD_BIG 1.0e30f
+struct Dims5 { int n[5]; };
+
+__global__ __launch_bounds__(256) void sd_border_kernel(const float* __restrict__ x, float thr, Dims5 d, int a0, int64_t total,
+                                                        float* __restrict__ border) {   // a0: first axis the array really has
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int c[5];
+  int64_t r = idx;
+#pragma unroll
+  for (int a = 4; a >= 0; --a) { c[a] = (int)(r % d.n[a]); r /= d.n[a]; }
+  const bool m = x[idx] > thr;
+  bool interior = m;
+  int64_t stride = 1;
+#pragma unroll
+  for (int a = 4; a >= 0; --a) {
+    // out-of-bounds neighbours count as background (scipy binary_erosion, border_value = 0)
+    if (a >= a0) {
+      const bool lo = c[a] > 0 && x[idx - stride] > thr, hi = c[a] < d.n[a] - 1 && x[idx + stride] > thr;
+      interior = interior && lo && hi;
+    }
+    stride *= d.n[a];
+  }
+  border[idx] = (m && !interior) ? 1.f : 0.f;
+}
+__global__ __launch_bounds__(256) void sd_seed_kernel(const float* __restrict__ border, int64_t total, float* __restrict__ g) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < total) g[idx] = border[idx] != 0.f ? 0.f : SP_SD_BIG;
+}
+// one axis: element (o, i, k) of an (outer, n, inner) view
+__global__ __launch_bounds__(256) void sd_edt_axis_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t total, int n,
+                                                          int64_t inner) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t k = idx % inner, oi = idx / inner;
+  const int i = (int)(oi % n);
+  const float* line = src + (oi - i) * inner + k;
+  float best = SP_SD_BIG;
+  for (int j = 0; j < n; ++j) {
+    const float dj = (float)(i - j);
+    best = fminf(best, fmaf(dj, dj, line[(int64_t)j * inner]));
+  }
+  dst[idx] = best;
+}
+// out[0] = max of g (the SQUARED distance: an exact integer, the host takes the root in double), out[1] = sum of sqrt(g)
+// in double, out[2] = count, over the voxels where `at` is set
+__global__ __launch_bounds__(256) void sd_stats_kernel(const float* __restrict__ g, const float* __restrict__ at, int64_t total,
+                                                       double* __restrict__ out) {
+  float mx = 0.f;
+  double sm = 0.0, cnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    if (at[i] != 0.f) { const float gi = g[i]; mx = fmaxf(mx, gi); sm += sqrt((double)gi); cnt += 1.0; }
+  }
+  __shared__ float rm[4];
+  __shared__ double rs[2][4];
+  float wm = mx;
+  for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+  const double ws = wave_sum_d(sm), wc = wave_sum_d(cnt);
+  if ((threadIdx.x & 63) == 0) { rm[threadIdx.x >> 6] = wm; rs[0][threadIdx.x >> 6] = ws; rs[1][threadIdx.x >> 6] = wc; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float m4 = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+    // non-negative floats order like their bit patterns: the maximum through an integer atomic on the double's slot
+    atomicMax(reinterpret_cast<unsigned long long*>(&out[0]), (unsigned long long)__float_as_uint(m4));
+    atomicAdd(&out[1], rs[0][0] + rs[0][1] + rs[0][2] + rs[0][3]);
+    atomicAdd(&out[2], rs[1][0] + rs[1][1] + rs[1][2] + rs[1][3]);
+  }
+}
+__global__ void sd_finish_kernel(double* out) {      // the two maxima were accumulated as float bit patterns
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    out[0] = (double)__uint_as_float((unsigned)*reinterpret_cast<unsigned long long*>(&out[0]));
+    out[3] = (double)__uint_as_float((unsigned)*reinterpret_cast<unsigned long long*>(&out[3]));
+  }
+}
+
+// out[6] (zeroed by the caller) = { max SQUARED distance, sum of distances, count: result-border -> reference-border;  the
+// same three for reference-border -> result-border }:  hd = sqrt(max(out[0], out[3])),  assd = (out[1]/out[2] + out[4]/out[5]) / 2.
+// ws: 4 * prod(dims) floats.  A mask without voxels gives count 0 (the caller decides, as medpy raises).
+extern "C" int sp_surface_distances(const float* result, const float* reference, float threshold, int32_t ndim, const int32_t* dims,
+                                    float* ws, double* out, sp_stream_t stream) {
+  SP_CHECK_ARG(result && reference && dims && ws && out && ndim >= 1 && ndim <= 5, "sp_surface_distances: bad arguments");
+  Dims5 d;
+  int64_t total = 1;
+  for (int a = 0; a < 5; ++a) {
+    const int src = a - (5 - ndim);
+    d.n[a] = src >= 0 ? dims[src] : 1;
+    SP_CHECK_ARG(d.n[a] >= 1, "sp_surface_distances: empty axis");
+    total *= d.n[a];
+  }
+  SP_CHECK_ARG(total < (1ll << 31), "sp_surface_distances: 2^31 voxels or more");
+  // an axis of extent 1 that the array HAS makes every voxel a border voxel (both neighbours are out of bounds); the
+  // leading axes added here to reach rank 5 must not: the border kernel tests axes a0.. only
+  const int a0 = 5 - ndim;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  float* br = ws; float* bt = ws + total; float* g0 = ws + 2 * total; float* g1 = ws + 3 * total;
+  hipStream_t st = ST(stream);
+  hipLaunchKernelGGL(sd_border_kernel, dim3(grid), dim3(256), 0, st, result, threshold, d, a0, total, br);
+  hipLaunchKernelGGL(sd_border_kernel, dim3(grid), dim3(256), 0, st, reference, threshold, d, a0, total, bt);
+  for (int dir = 0; dir < 2; ++dir) {
+    const float* seed = dir == 0 ? bt : br;
+    const float* at = dir == 0 ? br : bt;
+    hipLaunchKernelGGL(sd_seed_kernel, dim3(grid), dim3(256), 0, st, seed, total, g0);
+    float* a_ = g0; float* b_ = g1;
+    int64_t inner = 1;
+    for (int a = 4; a >= 0; --a) {
+      if (d.n[a] > 1) {
+        hipLaunchKernelGGL(sd_edt_axis_kernel, dim3(grid), dim3(256), 0, st, (const float*)a_, b_, total, d.n[a], inner);
+        float* t_ = a_; a_ = b_; b_ = t_;
+      }
+      inner *= d.n[a];
+    }
+    const unsigned sg = grid < 1024 ? grid : 1024;
+    hipLaunchKernelGGL(sd_stats_kernel, dim3(sg), dim3(256), 0, st, (const float*)a_, at, total, out + 3 * dir);
+  }
+  hipLaunchKernelGGL(sd_finish_kernel, dim3(1), dim3(64), 0, st, out);
+  SP_CHECK_LAUNCH("sp_surface_distances");
+  return SP_OK;
+}

@@ -38,6 +38,7 @@ class WgradArgs(C.Structure):
 
 _SIGS = {
     "sp_version": ([], i32),
+    "sp_surface_distances": ([vp, vp, f32, i32, vp, vp, vp, vp], i32),
     "sp_gaussian_filter3d": ([vp, vp, vp, i32, i32, i32, f32, f32, vp], i32),
     "sp_map_coordinates_linear": ([vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, i32, i32, vp], i32),
     "sp_conv_prep_weights_batch": ([vp, i32, i32, vp], i32),
