@@ -205,12 +205,16 @@ class ConvLayer:
         # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
         if self.bn_from_wgrad:
             bs = self.scratch.get(self.bsums_id)
-            finish = self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
-                                    dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
-                                    bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True, x_planar=self.x_planar)
+            run_wgrad = lambda: self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
+                                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
+                                               bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True, x_planar=self.x_planar)
+            whole = O.overlap_level() == 2      # the weight-gradient kernel itself runs beside the data gradient
+            finish = None if whole else run_wgrad()
             # finish + BatchNorm-backward finalize on the side stream, beside the data-gradient convolution
             f = O.fork()
             with f:
+                if whole:
+                    finish = run_wgrad()
                 finish()
                 self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
             if self.need_input_grad:

@@ -60,19 +60,37 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-# ---- a second stream for the bookkeeping kernels of the backward pass (weight re-packs, weight-gradient finish,
-# BatchNorm-backward finalize: ~5-10 us each, ~0.25 ms per step when serialised between the big kernels).  fork():
-# the side stream waits for everything enqueued so far; join(): the main stream waits for the side work.  Under
-# hipGraph capture the two become parallel branches of the graph.  MEASURED SLOWER (5.20 vs 5.12 ms per step: the
-# small kernels take workgroup slots from the convolution they run beside), so it is opt-in: SP_OVERLAP=1.
-OVERLAP = bool(os.environ.get("SP_OVERLAP"))
+# ---- a second stream for the backward pass.  fork(): the side stream waits for everything enqueued so far; join():
+# the main stream waits for the side work.  Under hipGraph capture the two become parallel branches of the graph.
+# SP_OVERLAP=2 (default): every folded layer's WEIGHT-GRADIENT kernel (+ its finish and the BatchNorm-backward finalize)
+# runs on the side stream beside the layer's data-gradient convolution -- both read dz, neither feeds the other, and on
+# the small layers (blocks 2-4: 200-500 workgroups on 256 CUs) each alone leaves the chip half empty: 3.98 -> 3.86 ms per
+# step.  SP_OVERLAP=1: only the ~5-10 us bookkeeping kernels (finish, finalize, re-packs) go to the side stream --
+# measured neutral to slightly slower (they take workgroup slots from the convolution they run beside).  SP_OVERLAP=0:
+# one stream.
+# Only while a hipGraph is being captured (the fork / join become graph edges): launched eagerly from Python, the stream
+# switches and event record / wait pairs cost more CPU time than the overlap saves (4.15 vs 3.98 ms); SP_OVERLAP_EAGER=1
+# forces it there too.
+_OV = os.environ.get("SP_OVERLAP", "2")
+_OV_EAGER = bool(os.environ.get("SP_OVERLAP_EAGER"))
+
+
+def overlap_level():
+    if _OV in ("0", ""):
+        return 0
+    if not _OV_EAGER and not torch.cuda.is_current_stream_capturing():
+        return 0
+    return 2 if _OV == "2" else 1
+
+
 _SIDE = {}
 
 
 class fork:
     def __init__(self):
         self.main = torch.cuda.current_stream()
-        if OVERLAP:
+        self.on = overlap_level() > 0
+        if self.on:
             key = self.main.device.index
             if key not in _SIDE:
                 _SIDE[key] = torch.cuda.Stream(device=self.main.device)
@@ -81,7 +99,7 @@ class fork:
         self.ctx = None
 
     def __enter__(self):
-        if OVERLAP:
+        if self.on:
             self.ctx = torch.cuda.stream(self.side)
             self.ctx.__enter__()
         return self
@@ -93,7 +111,7 @@ class fork:
         return False
 
     def join(self):
-        if OVERLAP:
+        if self.on:
             self.main.wait_stream(self.side)
 
 
