@@ -221,15 +221,31 @@ class ConvLayer:
                 self._run_dgrad(w)
             f.join()
             return (self.g, self.coef) if self.need_input_grad else (None, None)
-        if self.kind == "conv" and self.materialize:
-            self.wgrad.run(self.xhat, self.dz, self.batch, grads[c + ".weight"], None, None,
-                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
-        elif self.kind == "conv":
-            self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
-                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
-        else:
-            self.wgrad.run(self.dz, x, self.batch, grads[c + ".weight"], None, None, self.scale, self.shift,
-                           dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+        # every other layer: the weight gradient (kernel + finish) is independent of the data gradient as well -- second
+        # stream while a graph is captured (ops.overlap_level)
+        f = O.fork() if O.overlap_level() == 2 else None
+        if f is not None:
+            f.__enter__()
+        try:
+            if self.kind == "conv" and self.materialize:
+                self.wgrad.run(self.xhat, self.dz, self.batch, grads[c + ".weight"], None, None,
+                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+            elif self.kind == "conv":
+                self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
+                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+            else:
+                self.wgrad.run(self.dz, x, self.batch, grads[c + ".weight"], None, None, self.scale, self.shift,
+                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+        finally:
+            if f is not None:
+                f.__exit__(None, None, None)
+        try:
+            return self._backward_input(x, w, params, grads)
+        finally:
+            if f is not None:
+                f.join()
+
+    def _backward_input(self, x, w, params, grads):
         if not (self.need_input_grad or self.bn_prefix is not None):
             return None, None
         self.dgrad.prep(w)
