@@ -6,6 +6,8 @@ BN-conv-ELU triples of Cae3D.py:39-76,176-220).  Forward is ONE kernel per sub-c
 epilogue); backward is wgrad + dgrad + one reduction, with the BatchNorm backward expressed as
 per-channel coefficients ``dx = c0*g + c1*x + c2`` that the consumer of ``g`` applies on load.
 """
+import os
+
 import torch
 
 from . import lib as L
@@ -24,7 +26,7 @@ def _allreduce(t):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=SYNC["group"])
 
 
-STATS_NREP = 64     # replicas of the conv-epilogue statistics accumulators (spreads same-address fp64 atomics)
+STATS_NREP = int(os.environ.get("SP_STATS_NREP", "64"))     # replicas of the conv-epilogue statistics accumulators (spreads same-address fp64 atomics)
 
 
 class Scratch:
