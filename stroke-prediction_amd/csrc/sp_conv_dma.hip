@@ -722,12 +722,215 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void conv_igemm_zs_kernel(c
   }
 }
 
+// ROW-REUSE variant of the z-marching kernel for one output tile (Cout <= 16), 3x3x3, one 16-channel input plane.
+// With 16 output channels every activation fragment read from LDS (1 KB) feeds ONE MFMA in the kernels above, which
+// makes them LDS-bandwidth bound at <= 50 % of the matrix pipe.  Here the K steps are ordered so that both taps of a
+// step share dy (5 steps per dy, 15 in all, one half-step of zero weights): the fragment of input row r and step type t
+// then serves the output rows r, r-1, r-2 (dy = 0, 1, 2) -- a wave owns 8 consecutive output rows, loads the 10 x 5
+// fragments of its input rows once and issues 120 MFMAs from them: 2.4 MFMAs per LDS read instead of 1.
+// ktab = 5 x 4 entries (in-plane offset of the step type at dy = 0 | dz); weights: 15 fragments in (dy, type) order.
+template <typename TOUT>
+__global__ __launch_bounds__(256, 2) void conv_igemm_zr_kernel(const ConvZsDev P) {
+  constexpr int NT = 1, MT = 8, KS = 15, NTY = 5;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int NJ = 5;                                   // 16-byte chunks of one plane per lane (host-checked)
+  const sp_conv_args& a = P.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lv = lane & 15, lg = lane >> 4;
+  unsigned char* ring = lds;
+
+  int kv[NTY];                                            // this lane group's (in-plane offset at dy = 0 | dz) per step type
+#pragma unroll
+  for (int t = 0; t < NTY; ++t) kv[t] = a.ktab[t * 4 + lg];
+  int vbase[MT + 2];                                      // the wave's ten input rows
+#pragma unroll
+  for (int r = 0; r < MT + 2; ++r) vbase[r] = ((wave * MT + r) * P.ITW + lv) * 32;
+  const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
+  bf16x8 wreg[KS][NT];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wreg[s][n] = wf_hi[((size_t)s * a.NTtot + n) * 64 + lane];
+
+  // per-lane DMA plan of one plane: chunk c = (wave + 4j)*64 + lane -> (row vy, voxel vx, half)
+  uint32_t rel[NJ];
+  int crd[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + 4 * j) * 64 + lane;
+    const int cc = c < P.nchunks ? c : P.nchunks - 1;
+    const int half = cc & 1, vox = cc >> 1;
+    const int vy = fdiv(vox, P.d_itw), vx = vox - vy * P.ITW;
+    rel[j] = (uint32_t)(((vy * a.Wi + vx) * a.CPi + half * 8) * 2);
+    crd[j] = vy | (vx << 8) | (c < P.nchunks ? 0 : (1 << 30));       // bit 30: no such chunk (tail of the last round)
+  }
+  float bj[NT][4], s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bj[n][j] = a.bias ? a.bias[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
+  const bool linact = a.act == SP_ACT_LEAKY || a.act == SP_ACT_NONE;
+  const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;
+  const bool want_stats = a.stats != nullptr;
+
+  // Work = (column, output plane) pairs cut into gridDim.x equal pieces of the flattened sequence (perfect balance for
+  // any volume; a piece that crosses a column boundary pays one more three-plane prologue).  XCD-aware piece id.
+  const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+  const uint64_t T = (uint64_t)P.ncols * a.Do;
+  uint64_t pos = T * vb / gridDim.x;
+  const uint64_t pend = T * (vb + 1) / gridDim.x;
+  while (pos < pend) {
+    const uint32_t col = (uint32_t)(pos / (uint32_t)a.Do);
+    const int z0 = (int)(pos - (uint64_t)col * a.Do);
+    const int z1 = (int)min((uint64_t)a.Do, (uint64_t)z0 + (pend - pos));
+    pos += (uint64_t)(z1 - z0);
+    uint32_t t = col;
+    uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
+    q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; const int b = q;
+    const int oy0 = ty * (4 * MT), ox0 = tx * 16;
+    const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
+    const bf16_t* xin = reinterpret_cast<const bf16_t*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * a.CPi;
+    // in-plane validity of this lane's chunks (column-invariant): bit j set = inside the volume
+    int vmask = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int vy = crd[j] & 0xff, vx = (crd[j] >> 8) & 0xff;
+      if (!(crd[j] >> 30) && (unsigned)(iy0 + vy) < (unsigned)a.Hi && (unsigned)(ix0 + vx) < (unsigned)a.Wi) vmask |= 1 << j;
+    }
+    auto load_plane = [&](int iz, int slot) {
+      unsigned char* dst0 = ring + slot * P.S;
+      const bool zin = (unsigned)iz < (unsigned)a.Di;
+      const unsigned char* src0 = reinterpret_cast<const unsigned char*>(xin) + (((int64_t)iz * a.Hi + iy0) * a.Wi + ix0) * a.CPi * 2;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        unsigned char* dst = dst0 + (wave + 4 * j) * 1024;
+        if (!(crd[j] >> 30)) {
+          if (zin && ((vmask >> j) & 1)) sp_dma16(src0 + rel[j], dst);
+          else *reinterpret_cast<uint4*>(dst + lane * 16) = make_uint4(0, 0, 0, 0);      // padding
+        }
+      }
+    };
+    __syncthreads();                                      // the previous column has been consumed
+    load_plane(z0 + a.o0D, 0);
+    load_plane(z0 + a.o0D + 1, 1);
+    load_plane(z0 + a.o0D + 2, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    TOUT* __restrict__ yout = reinterpret_cast<TOUT*>(a.y) + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
+    const int ox = ox0 + lv;
+    // The stores of plane z are issued at the top of iteration z + 1 (after the next plane's DMA): the s_waitcnt vmcnt(0)
+    // that closes an iteration also waits for outstanding STORES on gfx9, and issued right before it their whole latency
+    // was exposed once per plane; one K loop later they have long been acknowledged.
+    float pend[MT][4];
+    auto flush = [&](int zp) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + wave * MT + m;
+        const int c0 = lg * 4;
+        if (oy < a.Ho && ox < a.Wo && c0 < a.CPo) {
+          const size_t vo = (size_t)((((zp * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo);
+          Store<TOUT>::st4(yout + vo + c0, pend[m]);
+        }
+      }
+    };
+    for (int z = z0; z < z1; ++z) {
+      const int sl = (z - z0) & 3;
+      if (z + 1 < z1) load_plane(z + a.o0D + 3, (sl + 3) & 3);         // lands behind this step's MFMAs
+      if (z > z0) flush(z - 1);
+      // ---- K loop over the three resident planes
+      f32x4 acc[NT][MT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8 xr[2][NTY];                                    // the five fragments of an input row, double-buffered by row
+#define ZS_OFF(t_) ((((sl + (kv[t_] & 3)) & 3) * P.S) + (kv[t_] & ~15))
+#pragma unroll
+      for (int t = 0; t < NTY; ++t) xr[0][t] = *reinterpret_cast<const bf16x8*>(ring + vbase[0] + ZS_OFF(t));
+#pragma unroll
+      for (int r = 0; r < MT + 2; ++r) {
+        if (r + 1 < MT + 2) {                                 // next row's fragments: 15 MFMAs (240 cycles) cover their latency
+#pragma unroll
+          for (int t = 0; t < NTY; ++t) xr[(r + 1) & 1][t] = *reinterpret_cast<const bf16x8*>(ring + vbase[r + 1] + ZS_OFF(t));
+        }
+#pragma unroll
+        for (int t = 0; t < NTY; ++t) {
+#pragma unroll
+          for (int dy = 0; dy < 3; ++dy) {
+            const int m = r - dy;                             // output row served through tap row dy
+            if (m >= 0 && m < MT) acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[dy * NTY + t][0], xr[r & 1][t], acc[0][m], 0, 0, 0);
+          }
+        }
+      }
+#undef ZS_OFF
+      // ---- epilogue of output plane z
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + wave * MT + m;
+        const bool inside = oy < a.Ho && ox < a.Wo;
+        const size_t vo = (size_t)((((z * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int c0 = n * 16 + lg * 4;
+          const bool lin = linact && (c0 + 4 <= a.Cout);
+          float v[4];
+          if (lin) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float zz = acc[n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float zz = act_fwd(a.act, a.act_param, acc[n][m][j] + bj[n][j]);
+              v[j] = (c0 + j < a.Cout) ? zz : 0.f;
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) pend[m][j] = v[j];
+          if (inside && c0 < a.CPo) {
+            if (want_stats) {
+              if (sizeof(TOUT) == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
+              }
+#pragma unroll
+              for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], v[j], s2[n][j]); }
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the plane issued at the top of this step has landed
+      __syncthreads();                                    // and every wave is done with the oldest slot
+    }
+    if (z1 > z0) flush(z1 - 1);
+  }
+  if (want_stats) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int i = tid; i < NT * 32; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
+        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+      }
+    __syncthreads();
+    for (int i = tid; i < NT * 32; i += 256) {
+      const int c = i >> 1;
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+    }
+  }
+}
+
 static int launch_zs(const sp_conv_args* a, hipStream_t st) {
   SP_CHECK_ARG(a->NT == a->NTtot && a->NT >= 1 && a->NT <= 3 && a->ngroups == 1 && a->opp == 2 && a->vsb == 32 && a->octs_per_group == 2,
                "sp_conv3d_igemm(zs): one 16-channel plane in, up to three 16-channel tiles out");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->stats_mode == 0 && a->in_scale == nullptr && a->dtype_in == SP_BF16,
                "sp_conv3d_igemm(zs): stride 1, plain statistics, bf16 input without affine on load");
-  SP_CHECK_ARG(a->steps_per_group == 14 || (a->steps_per_group == 7 && a->NT == 1), "sp_conv3d_igemm(zs): 14 (or 7) resident K steps");
+  const bool zr = a->persist == 4;                     // row-reuse variant: 15 weight fragments in (dy, type) order, 5 x 4 table
+  SP_CHECK_ARG(zr ? (a->NT == 1 && a->ITH_zs == 34) : (a->steps_per_group == 14 || (a->steps_per_group == 7 && a->NT == 1)),
+               "sp_conv3d_igemm(zs): 14 (or 7) resident K steps; row-reuse: one output tile, 3x3x3");
   ConvZsDev P;
   P.a = *a;
   const int MT = a->NT == 3 ? 4 : 8;                   // rows per wave: three resident weight tiles leave room for 4
@@ -752,7 +955,17 @@ static int launch_zs(const sp_conv_args* a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);                                               \
   }
 #define SP_ZS_T(N_, M_, K_) { if (a->dtype_out == SP_F32) SP_ZS(N_, M_, K_, float) else SP_ZS(N_, M_, K_, bf16_t) }
-  if (a->NT == 1 && a->steps_per_group == 14) SP_ZS_T(1, 8, 14)
+  if (zr) {
+    if (a->dtype_out == SP_F32) {
+      auto kern = conv_igemm_zr_kernel<float>;
+      SP_ENSURE_LDS(kern, lds_bytes, "sp_conv");
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);
+    } else {
+      auto kern = conv_igemm_zr_kernel<bf16_t>;
+      SP_ENSURE_LDS(kern, lds_bytes, "sp_conv");
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_bytes, st, P);
+    }
+  } else if (a->NT == 1 && a->steps_per_group == 14) SP_ZS_T(1, 8, 14)
   else if (a->NT == 1) SP_ZS_T(1, 8, 7)
   else if (a->NT == 2) SP_ZS_T(2, 8, 14)
   else SP_ZS_T(3, 4, 14)
@@ -808,7 +1021,7 @@ static int dispatch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
 
 int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 input and no affine on load");
-  if (a->persist == 3) return launch_zs(a, reinterpret_cast<hipStream_t>(stream));      // z-marching plan (ktab in its format)
+  if (a->persist == 3 || a->persist == 4) return launch_zs(a, reinterpret_cast<hipStream_t>(stream));      // z-marching plans (ktab in their format)
   SP_CHECK_ARG(a->x_plane == 0 || (a->opp == 2 && !a->persist && a->x_plane < (1ll << 31)), "sp_conv3d_igemm(dma): plane-major input needs 16-channel planes");
   SP_CHECK_ARG(a->opp == 1 || a->opp == 2, "sp_conv3d_igemm(dma): octets per plane must be 1 or 2");
   SP_CHECK_ARG(a->vsb == a->opp * 16 && a->plane_bytes == a->ITD * a->ITH * a->ITW * a->vsb, "sp_conv3d_igemm(dma): planes must be lane-linear (no padding)");

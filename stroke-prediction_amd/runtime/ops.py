@@ -23,6 +23,11 @@ def bump_param_epoch():
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
 MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
 WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
+# Row-reuse z-marching kernel for single-tile 3x3x3 layers (conv_igemm_zr_kernel: 2.4 MFMAs per LDS fragment read
+# instead of 1).  Opt-in: it removes the LDS-read bound of the 16 -> 16 layers (forward 178 -> 162 us, data gradient
+# 157 -> 157 us at 126^3) but those layers sit at the HBM ridge (216 FLOP per byte of activations in + out), and the
+# second set of weight fragments costs what the forward gains: 4.00 vs 4.00 ms per step.
+USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 WGRAD_ZS = int(os.environ.get("SP_WGRAD_ZS", "1"))   # z-marching ring variant of the DMA weight gradient (0 off, 1 where it pays, 2 wherever it applies)
 CAT_PLANAR = bool(int(os.environ.get("SP_CAT_PLANAR", "1")))   # plane-major concat buffers (dense 16-channel planes for the DMA consumers)
@@ -149,9 +154,14 @@ class ConvRunner:
                 frag_elems = nsteps * op.nttot * 64 * 8
                 hi = torch.empty(frag_elems, dtype=torch.bfloat16, device=device)
                 lo = torch.empty(frag_elems, dtype=torch.bfloat16, device=device) if op.dtype == L.SP_F32 else None
-                subs.append(dict(sub=sub, kmap=_dev_i32(sub.kmap, device), ktab=_dev_i32(sub.ktab, device),
-                                 ktab_zs=None if getattr(sub, "ktab_zs", None) is None else _dev_i32(sub.ktab_zs, device),
-                                 hi=hi, lo=lo, nsteps=nsteps))
+                d = dict(sub=sub, kmap=_dev_i32(sub.kmap, device), ktab=_dev_i32(sub.ktab, device),
+                         ktab_zs=None if getattr(sub, "ktab_zs", None) is None else _dev_i32(sub.ktab_zs, device),
+                         hi=hi, lo=lo, nsteps=nsteps, ktab_zr=None)
+                if USE_ZR and getattr(sub, "ktab_zr", None) is not None and op.dtype == L.SP_BF16:
+                    # second set of weight fragments in the row-reuse order (15 steps: dy-major)
+                    d.update(ktab_zr=_dev_i32(sub.ktab_zr, device), kmap_zr=_dev_i32(sub.kmap_zr, device),
+                             hi_zr=torch.empty(15 * op.nttot * 64 * 8, dtype=torch.bfloat16, device=device))
+                subs.append(d)
             st["subs"] = subs
             st["bias"] = torch.zeros(op.nttot * 16, dtype=torch.float32, device=device)
             st["has_bias"] = False
@@ -191,10 +201,12 @@ class ConvRunner:
                    ptr(s0["hi"]), ptr(s0["lo"]), ptr(fold_scale), ntaps, ptr(b), ptr(fold_shift), ptr(self.bias), op.nttot * 16,
                    stream())
             self.has_bias = True
+            self._prep_zr(w, fold_scale)
             return
         for s in self.subs:
             L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s["kmap"]), s["nsteps"],
                    op.nttot, ptr(s["hi"]), ptr(s["lo"]), ptr(fold_scale), stream())
+        self._prep_zr(w, fold_scale)
         if fold_shift is not None:
             ntaps = w.numel() // (op.cin * op.cout)
             L.call("sp_conv_fold_bias", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ntaps, ptr(b), ptr(fold_shift),
@@ -203,6 +215,13 @@ class ConvRunner:
         elif b is not None:
             self.bias[:op.cout].copy_(b.detach())
             self.has_bias = True
+
+    def _prep_zr(self, w, fold_scale):
+        op = self.op
+        for s in self.subs:
+            if s.get("ktab_zr") is not None:
+                L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s["kmap_zr"]), 15, op.nttot,
+                       ptr(s["hi_zr"]), None, ptr(fold_scale), stream())
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
             dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False):
@@ -251,6 +270,8 @@ class ConvRunner:
                 a.persist = 0               # (the persistent variants address channels-last rows)
             if USE_ZS and a.dma and s.get("ktab_zs") is not None and stats_mode == 0 and a.CPo >= 16:
                 a.persist, a.ktab, a.ITH_zs = 3, ptr(s["ktab_zs"]), t["ITH_zs"]     # z-marching ring variant
+                if s.get("ktab_zr") is not None and not x_planar:
+                    a.persist, a.ktab, a.wfrag_hi = 4, ptr(s["ktab_zr"]), ptr(s["hi_zr"])   # ... with row reuse
             with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout,
                         "%d->%d @%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_igemm", C.byref(a), st)
@@ -395,6 +416,9 @@ def prep_batch(pairs):
             for sub in r.subs:
                 items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, sub["kmap"].data_ptr(), sub["nsteps"],
                               r.op.nttot, sub["hi"].data_ptr(), 0 if sub["lo"] is None else sub["lo"].data_ptr(), 0))
+                if sub.get("ktab_zr") is not None:
+                    items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, sub["kmap_zr"].data_ptr(), 15,
+                                  r.op.nttot, sub["hi_zr"].data_ptr(), 0, 0))
         arr = np.array(items, dtype=_PREP_ITEM)
         dev = torch.from_numpy(arr.view(np.uint8).copy()).to(todo[0][1].device)
         maxb = max((int(it[6]) * int(it[7]) * 64 + 255) // 256 for it in items)

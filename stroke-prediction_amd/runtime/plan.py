@@ -279,6 +279,7 @@ def _plan_sub(op: ConvOp, sub: SubConv):
     # 16-channel tile out, stride 1, resident weights.  Same K order (same weight fragments); its table holds the
     # in-plane offset inside a (32 + ext_y - 1) x ITW plane slot, with the tap's z index in the low two bits.
     sub.ktab_zs = None
+    sub.kmap_zr = sub.ktab_zr = None
     if (dma and s == (1, 1, 1) and ngroups == 1 and opg == 2 and op.cpi == 16 and zs_steps
             and -(-op.cout // 16) <= 2 and ext[0] <= 3 and mt == 8      # (three output tiles: 359 VGPRs, measured 1.7x slower)
             and sub.out_dims[1] >= 32):
@@ -292,6 +293,22 @@ def _plan_sub(op: ConvOp, sub: SubConv):
             kz[i] = ((t[1] * itw + t[2]) * vsb + (oc % opp) * 16) | t[0]
         sub.ktab_zs = kz
         sub.tile["ITH_zs"] = 31 * s[1] + ext[1]
+        # row-reuse variant (conv_igemm_zr_kernel): one output tile, 3x3x3.  K steps grouped by dy: for every dy the nine
+        # (dz, dx) taps in ONE fixed order, two octets each -> 18 entries = 4.5 steps, padded to 5; step dy*5 + t.  The
+        # fragment of step type t read at input row r then serves dy = 0, 1, 2 (output rows r, r-1, r-2).
+        if -(-op.cout // 16) == 1 and tuple(ext) == (3, 3, 3) and len(sub.taps) == 27:
+            by_dy = {dy: sorted([t for t in sub.taps if t[1] == dy], key=lambda t: (t[0], t[2])) for dy in range(3)}
+            if all(len(v) == 9 for v in by_dy.values()) and \
+                    all([(t[0], t[2]) for t in by_dy[dy]] == [(t[0], t[2]) for t in by_dy[0]] for dy in range(3)):
+                kmap_zr = np.full(15 * 4, -1, dtype=np.int32)
+                ktab_zr = np.zeros(5 * 4, dtype=np.int32)
+                for dy in range(3):
+                    for i, (t, oc) in enumerate([(t, oc) for t in by_dy[dy] for oc in range(2)]):
+                        kmap_zr[dy * 20 + i] = (t[3] << 16) | oc
+                        if dy == 0:
+                            ktab_zr[i] = ((t[2]) * vsb + oc * 16) | t[0]
+                ktab_zr[18] = ktab_zr[16]; ktab_zr[19] = ktab_zr[17]      # zero-weight half step: any valid address
+                sub.kmap_zr, sub.ktab_zr = kmap_zr, ktab_zr
 
 
 def _finish(op: ConvOp):
