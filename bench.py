@@ -384,6 +384,9 @@ def main():
                            "frac": fl / t / 1e12 / peak, "traffic": traffic, "launches": n,
                            "avg_launch_us": 1e6 * t / n, "share_of_step": t / dt_prof,
                            "timing": "HIP events around every launch, %d eager steps right before the timed region" % prof_steps}
+        if traffic:     # the same launches against the HBM roof (PMC bytes per launch / measured launch time; peak 8 TB/s)
+            gbps = traffic / (t / n) / 1e9
+            res["roofline"]["hbm"] = {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0}
         res["kernels"] = {k: {"time_s_per_step": v[0] / prof_steps, "tflops": v[1] / v[0] / 1e12, "launches_per_step": v[2] / prof_steps}
                           for k, v in agg.items()}
         res["train_step_tflops"] = TRAIN_GFLOP_PER_SAMPLE_128 * (args.size / 128.0) ** 3 * 1e9 * world * args.batch * args.steps / dt / 1e12 \
