@@ -698,7 +698,9 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void conv_igemm_zs_kernel(c
           }
         }
       }
+#ifndef SP_ZS_NOWAIT       // diagnostic variant (tools/build_variant.sh): wrong results, shows what the DMA wait costs
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the plane issued at the top of this step has landed
+#endif
       __syncthreads();                                    // and every wave is done with the oldest slot
     }
   }
@@ -898,7 +900,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zr_kernel(const ConvZsDev P
           }
         }
       }
+#ifndef SP_ZS_NOWAIT       // diagnostic variant (tools/build_variant.sh): wrong results, shows what the DMA wait costs
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the plane issued at the top of this step has landed
+#endif
       __syncthreads();                                    // and every wave is done with the oldest slot
     }
     if (z1 > z0) flush(z1 - 1);
