@@ -188,23 +188,33 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
         if ((s & 1) == 0) { SP_MMA(wreg[s], x0) } else { SP_MMA(wreg[s], x1) }
       }
     } else {
-      // steps_per_group is even (host plan): two steps per iteration, fragments of s+1 / s+2 in flight
-      for (int s = 0; s < a.steps_per_group; s += 2) {
-        {
-          const int kn = ktab_l[(s + 1) * 4 + lg];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) wa1[n] = wp[(s + 1) * fstride + (size_t)n * 64];
-          SP_LDX(x1, kn)
-        }
+      // Weight fragments stream from global memory (L2): one step of MFMAs (NT*MT x 16 cycles = 256 cycles for two output
+      // tiles) does not cover an L2 round trip (500+ cycles), so the fragments are fetched THREE steps ahead (four register
+      // sets); the activation fragments come from LDS one step ahead as before.  steps_per_group is even (host plan).
+      const int nst = a.steps_per_group;
+      bf16x8 wa2[NT], wa3[NT];
+#define SP_LDW(dst, step_)                                                                            \
+  { const int st_ = (step_) < nst ? (step_) : nst - 1;                                                \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) dst[n] = wp[(size_t)st_ * fstride + (size_t)n * 64]; }
+      SP_LDW(wa1, 1)
+      SP_LDW(wa2, 2)
+      for (int s = 0; s < nst; s += 4) {
+        SP_LDW(wa3, s + 3)
+        { const int kn = ktab_l[(s + 1) * 4 + lg]; SP_LDX(x1, kn) }
         SP_MMA(wa0, x0)
-        if (s + 2 < a.steps_per_group) {
-          const int kn = ktab_l[(s + 2) * 4 + lg];
-#pragma unroll
-          for (int n = 0; n < NT; ++n) wa0[n] = wp[(s + 2) * fstride + (size_t)n * 64];
-          SP_LDX(x0, kn)
-        }
+        SP_LDW(wa0, s + 4)
+        if (s + 2 < nst) { const int kn = ktab_l[(s + 2) * 4 + lg]; SP_LDX(x0, kn) }
         SP_MMA(wa1, x1)
+        if (s + 2 < nst) {
+          SP_LDW(wa1, s + 5)
+          { const int kn = ktab_l[(s + 3) * 4 + lg]; SP_LDX(x1, kn) }
+          SP_MMA(wa2, x0)
+          SP_LDW(wa2, s + 6)
+          if (s + 4 < nst) { const int kn = ktab_l[(s + 4) * 4 + lg]; SP_LDX(x0, kn) }
+          SP_MMA(wa3, x1)
+        }
       }
+#undef SP_LDW
     }
 #undef SP_LDX
 #undef SP_MMA
