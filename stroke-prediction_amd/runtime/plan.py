@@ -15,6 +15,8 @@ tables against ``torch.nn.functional`` on the CPU).
 from dataclasses import dataclass, field
 from typing import List, Tuple
 
+import os
+
 import numpy as np
 
 LDS_BUDGET = {0: 72 * 1024, 1: 144 * 1024}   # per workgroup, by dtype (bf16 / f32 split)
@@ -202,6 +204,17 @@ def _plan_sub(op: ConvOp, sub: SubConv):
         return d[0] * d[1] * d[2] * (opp + 1) * 16 * np_planes + 4096 <= (budget if limit == "budget" else 156 * 1024)
 
     mt, td, th = _pick_rows(sub.out_dims, fits)
+    # Layers with two or more output tiles and at most four 16-channel input planes: 4x4x16-voxel tiles (MT = 4) instead of
+    # 4x8x16.  The staged halo tile shrinks from 70 KB to ~41 KB for two planes, three or four workgroups fit a CU, and
+    # their stage / MFMA / store phases overlap (tools/stamp_conv.py: each phase leaves the matrix pipe idle for its own
+    # workgroup): 32->32 @58^3 85 -> 79 us, 32->96 @48^3 158 -> 138 us, 64->64 @25^3 56 -> 41 us; with six input planes
+    # (96->32) the larger halo re-read costs more than the overlap gains (100 -> 114 us).  SP_PLAN_ROWS_WIDE=MT,TD,TH
+    # overrides, SP_PLAN_ROWS_WIDE=0 restores the large tile.
+    _force = os.environ.get("SP_PLAN_ROWS_WIDE", "4,4,4")
+    if _force not in ("", "0") and -(-op.cout // 16) >= 2 and op.dtype == 0 and op.cpi <= 64 and s == (1, 1, 1):
+        c = tuple(int(v) for v in _force.split(","))
+        if fits(c, "hard") and sub.out_dims[0] >= c[1] and sub.out_dims[1] >= c[2]:
+            mt, td, th = c
     itd, ith, itw = tile_dims((mt, td, th))
     nvox = itd * ith * itw
 
