@@ -325,7 +325,7 @@ class WgradRunner:
     def _alloc_acc(self, batch):
         """Accumulator block(s).  WGRAD_PARTS: one block per persistent workgroup, written with plain stores and summed
         by the finish kernel (device-scope atomics from 8 XCDs cost 40-90 us per layer); the workgroup count is sized
-        so that every workgroup has >= ~768 output voxels and the (cout, cin) tile grid times it is ~2 per CU."""
+        so that every workgroup has >= ~512 output voxels and the (cout, cin) tile grid times it is ~2 per CU."""
         import os
         a = self.args
         total = self.ntap * self.cot * 16 * self.cit * 16
@@ -336,7 +336,7 @@ class WgradRunner:
                 cib = min(cib, a.cib)
             yz = -(-self.cot // cob) * -(-self.cit // cib)
             vox = batch * a.Do * a.Ho * a.Wo
-            nb = max(8, min(512 // yz, vox // 768)) // 8 * 8     # multiple of 8: XCD-aware tile walk
+            nb = max(8, min(512 // yz, vox // 512)) // 8 * 8     # multiple of 8: XCD-aware tile walk (floor 512 voxels: tools/wg_sweep.sh)
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", nb))
             a.parts, self.nparts = 1, a.nblocks
             self.acc = torch.empty(self.nparts * total, dtype=torch.float32, device=self.device)
