@@ -27,7 +27,9 @@ extern "C" void sp_last_error(char* buf, size_t n) {
 extern "C" int sp_version(void) { return 100; }
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
-#define MAX_BLOCKS 2048
+// grid cap of the grid-stride elementwise kernels: 4096 measured best (2048: +1 % step time, 8192+: +0.5 %; SP_ELEM_BLOCKS)
+static int max_blocks_() { static int v = getenv("SP_ELEM_BLOCKS") ? atoi(getenv("SP_ELEM_BLOCKS")) : 4096; return v; }
+#define MAX_BLOCKS max_blocks_()
 
 // thread -> (voxel slot, octet) for CP/8 octets; threads beyond vpb*OC idle
 struct OctMap {
