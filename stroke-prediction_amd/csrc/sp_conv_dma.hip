@@ -955,7 +955,8 @@ static int launch_zs(const sp_conv_args* a, hipStream_t st) {
   SP_CHECK_ARG(P.nchunks <= 5 * 256 && 4 * P.S <= 160 * 1024, "sp_conv3d_igemm(zs): plane does not fit the per-lane plan");
   P.ntx = (a->Wo + 15) / 16; P.nty = (a->Ho + 4 * MT - 1) / (4 * MT);
   const int cols_xy = a->B * P.nty * P.ntx;
-  const int slots = a->NT == 1 ? 512 : 256;            // resident workgroups (2 / 1 per CU)
+  static const int zs_mult_ = getenv("SP_ZS_SLOTS") ? atoi(getenv("SP_ZS_SLOTS")) : 1;
+  const int slots = (a->NT == 1 ? 512 : 256) * zs_mult_;            // resident workgroups (2 / 1 per CU)
   P.nzc = 1; P.ZC = a->Do;
   P.ncols = (uint32_t)cols_xy;
   P.d_itw = make_fastdiv(P.ITW); P.d_tx = make_fastdiv(P.ntx); P.d_ty = make_fastdiv(P.nty); P.d_zc = make_fastdiv(P.nzc);

@@ -246,7 +246,8 @@ extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H
   SP_CHECK_ARG(!stats || nrep >= 1, "sp_first_conv_fwd: stats replicas");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_conv_fwd: too many tiles");
-  const unsigned grid = P.ntiles < 2048 ? P.ntiles : 2048;
+  static const unsigned cap_ = getenv("SP_FIRST_BLOCKS") ? (unsigned)atoi(getenv("SP_FIRST_BLOCKS")) : 2048u;
+  const unsigned grid = P.ntiles < cap_ ? P.ntiles : cap_;
   hipLaunchKernelGGL(first_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
                      (bf16_t*)y, stats, nrep);
   SP_CHECK_LAUNCH("sp_first_conv_fwd");
