@@ -207,6 +207,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
     if (grp == 0) STAMP(1);
     __syncthreads();
     if (grp == 0) STAMP(2);
+    if constexpr (NP == 1) {
+      // bf16: weight fragments fetched THREE steps ahead (an L2 round trip is longer than one step's MFMAs; the FC-like CAE
+      // layers stream 750 KB of fragments per workgroup and were latency-bound on them)
+      const int nst = a.steps_per_group;
+      bf16x8 w1[NT], w2[NT], w3[NT];
+#define SP_LDW(dst, step_)                                                                            \
+  { const int st_ = (step_) < nst ? (step_) : nst - 1;                                                \
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) dst[n] = wp_hi[(size_t)st_ * fstride + (size_t)n * 64]; }
+#define SP_STEP(wv, step_)                                                                            \
+  { const int koff = ktab_l[(step_) * 4 + lg];                                                        \
+    bf16x8 xb[MT];                                                                                    \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + koff); \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                    \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[n], xb[m], acc[n][m], 0, 0, 0); }
+      SP_LDW(w1, 1)
+      SP_LDW(w2, 2)
+      for (int s = 0; s < nst; s += 4) {
+        SP_LDW(w3, s + 3)
+        SP_STEP(wa_n, s)
+        if (s + 1 < nst) { SP_LDW(wa_n, s + 4) SP_STEP(w1, s + 1) }
+        if (s + 2 < nst) { SP_LDW(w1, s + 5) SP_STEP(w2, s + 2) }
+        if (s + 3 < nst) { SP_LDW(w2, s + 6) SP_STEP(w3, s + 3) }
+      }
+#undef SP_LDW
+#undef SP_STEP
+    } else {
     int koff_n = ktab_l[lg];
     for (int s = 0; s < a.steps_per_group; ++s) {
       bf16x8 wa[NT], wl[NT];
@@ -238,6 +264,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
           }
         }
       }
+    }
     }
   }
 
