@@ -8,6 +8,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`
 HIP-event timed inside the timed region) and ``cpu_baseline`` (the CPU oracle on the host cores).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -183,7 +184,8 @@ def bench_cae(args, world, rank, dev):
 
     class _L:
         batch_size = args.batch
-    learner = CaeReconstructionLearner(_L(), None, cae, opt, None, 1, None, "/tmp/_bench_cae", BatchDiceLoss([1.0]), verbose=False)
+    with contextlib.redirect_stdout(sys.stderr):
+        learner = CaeReconstructionLearner(_L(), None, cae, opt, None, 1, None, "/tmp/_bench_cae", BatchDiceLoss([1.0]), verbose=False)
     labels, clinical = W.cae_inputs(args.batch, d, hw, 1234 + rank)
     batch = {"case_id": list(range(args.batch)), "images": None, "labels": labels.to(dev), "clinical": clinical.to(dev)}
 
@@ -295,7 +297,8 @@ def main():
                     betas=(0.99, 0.999), grad_scale=sync.grad_scale, capturable=use_graph)   # train_unet_segmentation.py:13-14,32
     attach_flat_grads(model)
     sys.stdout = open(os.devnull, "w") if rank != 0 else sys.stdout
-    crit = BatchDiceLoss([1.0])
+    with contextlib.redirect_stdout(sys.stderr):      # the reference's constructor prints; stdout carries the JSON line only
+        crit = BatchDiceLoss([1.0])
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
     labels = (torch.rand((args.batch, 2) + out, generator=g, device=dev) > 0.7).float()
