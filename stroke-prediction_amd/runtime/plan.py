@@ -327,6 +327,13 @@ def _plan_sub(op: ConvOp, sub: SubConv):
 def _finish(op: ConvOp):
     assert op.cpi % 8 == 0 and op.cpo % 8 == 0 and op.cin <= op.cpi and op.cout <= op.cpo
     op.nt, op.nttot = _pick_nt(-(-op.cout // 16))
+    # Tiny output volumes (the FC-like 100 <-> 800 layers of the CAE: 1 x 10 x 10 / 3 x 12 x 12 voxels per sample) give one
+    # M tile per sample: with four output tiles per workgroup only a handful of workgroups exist (8 for 800 -> 100 at
+    # batch 4).  One output tile per workgroup multiplies the workgroup count by up to four; the input they re-stage is
+    # small.  SP_PLAN_NT_SMALL=0 restores the wide tiles.
+    nvox_out = max(int(np.prod(sub.out_dims)) for sub in op.subs)      # threshold swept: 512 .. 32768, 8192 best for the CAE
+    if os.environ.get("SP_PLAN_NT_SMALL", "1") != "0" and nvox_out <= int(os.environ.get("SP_PLAN_NT_SMALL_VOX", "8192")) and op.dtype == 0:
+        op.nt, op.nttot = 1, -(-op.cout // 16)
     for sub in op.subs:
         _plan_sub(op, sub)
     return op
