@@ -2,15 +2,25 @@
 """Headline benchmark: train-step voxels/sec of the 3-D U-Net (BASELINE.json configs[1]):
 channels 2 16 32 64 32 16 32 2, batch 4 per GPU, 2x128^3 synthetic volumes, bf16 storage / MFMA.
 
-A step = forward + (Dice+Dice)/2 + zero_grad + backward + [RCCL all-reduce] + Adam, i.e.
-``Learner.train_batch`` without the CPU-side medpy metrics (excluded on both sides).
-Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` (dominant kernel,
-HIP-event timed inside the timed region) and ``cpu_baseline`` (the CPU oracle on the host cores).
+A step = ``Learner.train_batch`` (learner/Learner.py:116-130 of the reference): forward + (Dice+Dice)/2 + zero_grad +
+backward + [RCCL all-reduce, bucketed, overlapped with backward] + Adam, without the CPU-side medpy metrics
+(excluded on both sides).  The product's own ``Learner(graph=True)`` replays the step as one hipGraph.
+Prints ONE JSON line on rank 0 (contract in the task statement) with ``roofline`` (dominant kernel family,
+HIP-event timed) and ``cpu_baseline`` (the CPU oracle on the host cores; all cores and 8 threads).
+
+``--gpus N`` with no WORLD_SIZE in the environment launches its own N ranks (``python -m torch.distributed.run``)
+BEFORE anything touches the GPU, forwards rank 0's JSON line and exits with the children's status.
+
+Other workloads: ``--workload cae`` (configs[2]), ``--workload unet4`` (configs[4] topology: 4-scale U-Net),
+``--workload unet-infer``.
 """
 import argparse
 import contextlib
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,35 +30,98 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 CHANNELS = [2, 16, 32, 64, 32, 16, 32, 2]
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 2500.0 / 3.0}     # dense bf16 MFMA (MI355X_MICROARCH.md); f32 mode = 3 MFMAs/product
+CHANNELS4 = [2, 32, 64, 128, 256, 128, 64, 32, 32, 2]       # configs[4] with ch_bC = 32
+CAE_CHANNELS = [1, 16, 24, 32, 100, 800, 1]
+# dense MFMA peaks (MI355X_MICROARCH.md): bf16 2.5 PFLOP/s; f32 mode = 3 bf16 MFMAs per product; fp8 (MX-scaled) 5 PFLOP/s
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 2500.0 / 3.0, "fp8": 5000.0}
+HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_SAMPLE_128 = 345.7                        # SURVEY.md 8d (fwd + dgrad + wgrad)
+CAE_TRAIN_GFLOP_PER_SAMPLE = {28: 305.5, 124: 1431.0}     # SURVEY.md 8d (3 enc + 4 dec passes)
 
 
-def cpu_baseline(size, steps=1, batch=2):
-    """The CPU oracle (fp32 restatement of the reference path) timed on the host cores: 1 warm-up + `steps`."""
-    from oracle import nets, weights as W
-    torch.set_num_threads(min(32, os.cpu_count() or 1))      # more threads than this only adds contention on this path
-    sd = W.make_state_dict(W.unet_spec(CHANNELS), 1234)
-    names = nets.trainable(sd)
-    for k in names:
-        sd[k].requires_grad_(True)
-    x, y = W.unet_inputs(batch, size, 1234)
-    m = [torch.zeros_like(sd[k]) for k in names]
-    v = [torch.zeros_like(sd[k]) for k in names]
+# ------------------------------------------------------------------------------------------------ CPU baselines
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _timed_cpu_steps(step, threads, steps):
+    torch.set_num_threads(threads)
     times = []
-    for step in range(steps + 1):
+    for i in range(steps + 1):          # 1 warm-up + `steps` timed, median
         t0 = time.perf_counter()
-        seg = nets.unet_forward(sd, x, training=True)
-        loss = nets.unet_loss(seg, y)
-        grads = torch.autograd.grad(loss, [sd[k] for k in names])
-        with torch.no_grad():
-            nets.adam_step([sd[k] for k in names], grads, m, v, step + 1, lr=1e-3, betas=(0.99, 0.999), weight_decay=1e-5)
+        step(i)
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
-    vox = batch * size[0] * size[1] * size[2]
-    return {"value": vox / t, "unit": "voxels/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "CPU oracle (fp32), batch %d x 2x%d^3, 1 warm-up + %d timed steps, median %.2f s/step"
-                      % (batch, size[0], steps, t)}
+    return sorted(times[1:])[len(times[1:]) // 2]
+
+
+def _cpu_report(vox, make_step, desc, steps):
+    ncpu = os.cpu_count() or 1
+    prev = torch.get_num_threads()
+    t_all = _timed_cpu_steps(make_step(), ncpu, steps)
+    res = {"value": vox / t_all, "unit": "voxels/s", "cores": ncpu, "kind": "port",
+           "os_cpu_count": ncpu, "cpu_model": _cpu_model(), "s_per_step": t_all,
+           "sample": "%s, 1 warm-up + %d timed steps, median; all %d host threads" % (desc, steps, ncpu)}
+    if ncpu != 8:
+        t8 = _timed_cpu_steps(make_step(), 8, steps)
+        res["threads_8"] = {"value": vox / t8, "s_per_step": t8, "cores": 8}
+    torch.set_num_threads(prev)
+    return res
+
+
+def cpu_baseline_unet(size, steps=3, batch=2, channels=CHANNELS):
+    """The CPU oracle (fp32 restatement of the reference path, oracle/nets.py) timed on the host cores."""
+    from oracle import nets, weights as W
+
+    def make_step():
+        sd = W.make_state_dict(W.unet_spec(channels), 1234)
+        names = nets.trainable(sd)
+        for k in names:
+            sd[k].requires_grad_(True)
+        x, y = W.unet_inputs(batch, size, 1234)
+        m = [torch.zeros_like(sd[k]) for k in names]
+        v = [torch.zeros_like(sd[k]) for k in names]
+
+        def step(i):
+            seg = nets.unet_forward(sd, x, training=True)
+            loss = nets.unet_loss(seg, y)
+            grads = torch.autograd.grad(loss, [sd[k] for k in names])
+            with torch.no_grad():
+                nets.adam_step([sd[k] for k in names], grads, m, v, i + 1, lr=1e-3, betas=(0.99, 0.999), weight_decay=1e-5)
+        return step
+    return _cpu_report(batch * size[0] * size[1] * size[2], make_step,
+                       "CPU oracle (fp32), U-Net train step, batch %d x 2x%dx%dx%d" % ((batch,) + tuple(size)), steps)
+
+
+def cpu_baseline_cae(d, hw, steps=3, batch=2):
+    from oracle import nets, weights as W
+
+    def make_step():
+        sd = W.make_state_dict(W.cae_spec(CAE_CHANNELS), 1234)
+        names = nets.trainable(sd)
+        for k in names:
+            sd[k].requires_grad_(True)
+        labels, clinical = W.cae_inputs(batch, d, hw, 1234)
+        ttt = nets.time_to_treatment(clinical)
+        core, penu, lesion = labels[:, 0:1], labels[:, 1:2], labels[:, 2:3]
+        m = [torch.zeros_like(sd[k]) for k in names]
+        v = [torch.zeros_like(sd[k]) for k in names]
+
+        def step(i):
+            lat, rec = nets.cae_forward(sd, core, penu, lesion, ttt, alpha=1.0, training=True)
+            loss = nets.cae_loss(lat, rec, core, penu, lesion, 30)
+            grads = torch.autograd.grad(loss, [sd[k] for k in names])
+            with torch.no_grad():
+                nets.adam_step([sd[k] for k in names], grads, m, v, i + 1, lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-5)
+        return step
+    return _cpu_report(batch * d * hw * hw, make_step,
+                       "CPU oracle (fp32), CAE train step (3 enc + 4 dec passes), batch %d x 1x%dx%dx%d" % (batch, d, hw, hw), steps)
 
 
 def torch_gpu_baseline(size, batch, steps=3, bf16=True):
@@ -82,49 +155,291 @@ def torch_gpu_baseline(size, batch, steps=3, bf16=True):
             % ("bf16 autocast" if bf16 else "fp32"), "batch": batch}
 
 
-def bench_unet_infer(args, world, rank, dev):
-    """SURVEY 8 row N1: Tester.infer_batch / Learner.validate_batch -- eval-mode forward (running BatchNorm statistics),
-    torch.no_grad, reference call path model(dto) (Tester.py:16-28, Learner.py:132-142)."""
-    import torch.distributed as dist
-    from stroke_prediction_amd.common.model.Unet3D import Unet3D
-    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
-    from stroke_prediction_amd.runtime.unet_engine import unet_out_dims
-    size = (args.size,) * 3
-    out = unet_out_dims(size)
-    torch.manual_seed(1234)
-    model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).eval()
-    model.freeze(True)
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
-    labels = torch.zeros((args.batch, 2) + out, device=dev)
+# ------------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
-    def step():
-        with torch.no_grad():
-            dto = model(UnetDtoUtil.init_dto(images, labels[:, 0:1], labels[:, 1:2]))
-        return dto.outputs.core
+
+def self_launch(args):
+    """No WORLD_SIZE and --gpus N > 1: start N ranks of this script with torch.distributed.run.  This process has not
+    touched the GPU (and never will): it only relays the children's output and exit status."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, args.gpus))))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
+def dryrun(args, world, rank):
+    """SP_BENCH_DRYRUN (tests/test_parallel_gloo.py): ranks rendezvous, all-reduce one value, rank 0 prints a skeleton
+    line.  No GPU, no workload: exercises the launcher and the env plumbing only; never a measurement."""
+    import torch.distributed as dist
+    seen = torch.ones(1)
+    if world > 1:
+        dist.init_process_group(os.environ.get("SP_BENCH_BACKEND", "gloo"))
+        dist.all_reduce(seen)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "train-step voxels/sec, 3D U-Net Bx2x128^3", "value": 0.0, "unit": "voxels/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dryrun": True, "ranks_seen": int(seen.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------ timing harness
+class _LoaderStub:
+    """Learner only asks a loader for its batch size before training starts (Learner.py:40)"""
+
+    def __init__(self, batch_size):
+        self.batch_size = batch_size
+
+
+def timed_steps(step, args, world, dev):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    import torch.distributed as dist
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 3)):
+    for _ in range(args.warmup):
         step()
-    fence()
-    graph, _ = capture_step(step, not args.no_graph and world == 1)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            step()
+        out = step()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
+    return dt, out
+
+
+def kernel_profile(eager_step, nsteps, world):
+    """Per-launch HIP-event timing of the conv / weight-gradient kernels (ops._Timed) over `nsteps` EAGER steps on the
+    launch stream: per-kernel events cannot live inside a replayed graph.  Returns {tag: [seconds, flops, launches]} and
+    the per-layer table."""
+    import torch.distributed as dist
+    from stroke_prediction_amd.runtime import ops as O
+    O.PROFILE = []
+    for _ in range(nsteps):
+        eager_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof, O.PROFILE = O.PROFILE, None
+    agg, per_layer = {}, {}
+    for tag, flops, e0, e1, detail in prof:
+        ms = e0.elapsed_time(e1)
+        for d, k in ((agg, tag), (per_layer, (tag, detail))):
+            a = d.setdefault(k, [0.0, 0.0, 0])
+            a[0] += ms * 1e-3
+            a[1] += flops
+            a[2] += 1
+    return agg, per_layer
+
+
+def roofline_from(agg, per_layer, nsteps, ms_per_step, dtype, layers_to=None, traffic_key=None):
+    if not agg:
+        return None, None
+    if layers_to is not None:
+        for (tag, detail), (tt, ff, nn) in sorted(per_layer.items(), key=lambda kv: -kv[1][0]):
+            print("  %-11s %-40s %7.1f us/launch  %6.1f TFLOP/s  x%d/step" % (tag, detail, 1e6 * tt / nn, ff / tt / 1e12, nn // nsteps),
+                  file=layers_to)
+    dom = max(agg, key=lambda k: agg[k][0])
+    t, fl, n = agg[dom]
+    peak = PEAK_TFLOPS[dtype]
+    traffic = None
+    try:    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/*.md)
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f)[traffic_key or dom]["bytes_per_launch"]
+    except Exception:
+        pass
+    roof = {"bound": "mfma", "kernel": dom, "achieved": fl / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+            "frac": fl / t / 1e12 / peak, "traffic": traffic, "launches": n, "avg_launch_us": 1e6 * t / n,
+            "share_of_step": (t / nsteps) / (ms_per_step * 1e-3),
+            "flops": "algorithmic: 2 x taps x Cin x Cout per output voxel of the convolution (data gradients: the forward's output voxels)",
+            "timing": "HIP events on the launch stream around every launch, %d eager steps" % nsteps}
+    if traffic:
+        gbps = traffic / (t / n) / 1e9
+        roof["hbm"] = {"achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS}
+    kernels = {k: {"time_s_per_step": v[0] / nsteps, "tflops": v[1] / v[0] / 1e12, "launches_per_step": v[2] / nsteps}
+               for k, v in agg.items()}
+    return roof, kernels
+
+
+def init_dist(world, dev):
+    import torch.distributed as dist
+    if world > 1 or os.environ.get("SP_FORCE_SYNC"):      # SP_FORCE_SYNC: 1-rank RCCL group, rehearses capture on one GPU
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if os.environ.get("SP_BENCH_BACKEND"):
+            dist.init_process_group(os.environ["SP_BENCH_BACKEND"])
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+
+def finish(res, rank):
+    import torch.distributed as dist
+    if rank == 0:
+        print(json.dumps(res))
+        sys.stdout.flush()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return 0
+
+
+def use_graph_for(args, world):
+    # N = 1: the step is replayed as one hipGraph (Learner(graph=True)).  N > 1: eager launches by default -- the RCCL
+    # collectives inside a capture are the one thing that cannot be rehearsed on a 1-GPU box; SP_DIST_GRAPH=1 captures too.
+    return not args.no_graph and (world == 1 or bool(os.environ.get("SP_DIST_GRAPH")))
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def bench_unet(args, world, rank, dev, four_scale=False):
+    import torch.distributed as dist
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.UnetSegmentationLearner import UnetSegmentationLearner
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    from stroke_prediction_amd.parallel import DataParallelSync
+    size = (args.size,) * 3
+    torch.manual_seed(1234)                      # identical random-init weights on every rank
+    if four_scale:
+        from stroke_prediction_amd.common.model.Unet3D import LargeUnet3D
+        model = LargeUnet3D(CHANNELS4, dtype=args.dtype).to(dev).train()
+        channels = CHANNELS4
+    else:
+        model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).train()
+        channels = CHANNELS
+    out = model.output_size(size)
+    sync = DataParallelSync(model, mode=args.dp_mode, bucketed=not args.no_buckets)
+    use_graph = use_graph_for(args, world)
+    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5,
+                    betas=(0.99, 0.999), grad_scale=sync.grad_scale, capturable=True)   # train_unet_segmentation.py:13-14,32
+    attach_flat_grads(model)
+    with contextlib.redirect_stdout(sys.stderr):      # stdout carries the JSON line only
+        learner = UnetSegmentationLearner(_LoaderStub(args.batch), None, model, opt, None, 1, BatchDiceLoss([1.0]),
+                                          None, "/tmp/_bench_unet", graph=use_graph, batch_metrics=False, sync_loss=False)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
+    labels = (torch.rand((args.batch, 2) + tuple(out), generator=g, device=dev) > 0.7).float()
+    batch = {"case_id": list(range(args.batch)), "images": images, "labels": labels, "clinical": None}
+
+    def step():
+        return learner.train_batch(batch, 0)
+
+    for _ in range(learner.GRAPH_WARMUP + 1 if use_graph else 0):      # eager warm-ups + capture happen before the timed region
+        step()
+    dt, last = timed_steps(step, args, world, dev)
+    ms = 1e3 * dt / args.steps
+    vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
+    launch_mode = "hipGraph (Learner(graph=True))" if use_graph else "eager"
+    name = ("4-scale 3D U-Net --channels %s" % " ".join(map(str, CHANNELS4))) if four_scale else \
+        "3D U-Net --channels 2 16 32 64 32 16 32 2"
+    res = {
+        "metric": "train-step voxels/sec, 3D U-Net Bx2x%d^3" % args.size, "value": vox / dt, "unit": "voxels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "%s, batch %d/GPU, 2x%d^3 -> 2x%d^3, Learner.train_batch = fwd+Dice+bwd+Adam (%s)"
+                               % (name, args.batch, args.size, out[0], "configs[4] topology" if four_scale else "configs[1]"),
+                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(last.loss),
+                   "launch": launch_mode, "dp_mode": args.dp_mode if world > 1 else None,
+                   "grad_exchange": (("%d buckets, reverse layer order, async on the RCCL stream" % sync.nbuckets_last)
+                                     if not args.no_buckets else "one blocking all-reduce") if world > 1 else None},
+    }
+    if not args.no_kernel_timing:
+        nprof = min(args.steps, 3)
+        agg, per_layer = kernel_profile(lambda: learner._optimise(batch, 0), nprof, world)
+        roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None)
+        if roof:
+            res["roofline"], res["kernels"] = roof, kernels
+        if args.size == 128 and not four_scale:
+            res["train_step_tflops"] = TRAIN_GFLOP_PER_SAMPLE_128 * 1e9 * world * args.batch * args.steps / dt / 1e12
+    if rank == 0 and world == 1 and not args.no_parity and not four_scale and args.dtype == "bf16":
+        res["parity"] = parity_vs_f32(model, images)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_unet(size, channels=channels) if not four_scale else \
+            cpu_baseline_unet(size, steps=1, channels=channels)
+    if rank == 0 and world == 1 and args.torch_gpu_baseline and not four_scale:
+        try:
+            res["torch_gpu_baseline"] = torch_gpu_baseline(size, args.batch, bf16=(args.dtype == "bf16"))
+        except Exception as e:
+            res["torch_gpu_baseline"] = {"error": str(e).splitlines()[0][:200]}
+    return finish(res, rank)
+
+
+def parity_vs_f32(model, images):
+    """What the fast mode costs in accuracy at the headline size: the SAME weights and inputs through the bf16 path and
+    through the f32 (split-bf16 x3, the mode that meets the 1e-3 logit tolerance against the CPU oracle,
+    tests/test_gpu_unet.py) path; eval-mode forward, logits = logit(probability)."""
+    import copy
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+    try:
+        with torch.no_grad():
+            m32 = Unet3D(model.channels, dtype="f32").to(images.device)
+            m32.load_state_dict(copy.deepcopy(model.state_dict()))
+            x = images[:1].contiguous()
+            outs = []
+            for m in (model, m32):
+                was = m.training
+                m.eval()
+                dto = m(UnetDtoUtil.init_dto(x, None, None))
+                outs.append(torch.cat((dto.outputs.core, dto.outputs.penu), 1).double().clamp(1e-7, 1 - 1e-7))
+                m.train(was)
+            p16, p32 = outs
+            l16, l32 = torch.log(p16 / (1 - p16)), torch.log(p32 / (1 - p32))
+            rel = float(((l16 - l32).abs() / l32.abs().clamp_min(1.0)).max())
+            return {"bf16_vs_f32_mode": {"max_abs_prob": float((p16 - p32).abs().max()), "max_rel_logit": rel,
+                                         "rms_logit": float((l16 - l32).pow(2).mean().sqrt())},
+                    "note": "eval-mode forward, batch 1, same weights; rel = |dlogit| / max(|logit|, 1).  The f32 mode is held to "
+                            "<= 1e-3 rel vs the CPU oracle (north_star); bf16 storage cannot reach it (8 mantissa bits per "
+                            "activation), see README / DESIGN 2"}
+    except Exception as e:      # the parity leg must never take the measurement down
+        return {"error": str(e).splitlines()[0][:200]}
+
+
+def bench_unet_infer(args, world, rank, dev):
+    """SURVEY 8 row N1: Tester.infer_batch / Learner.validate_batch -- eval-mode forward (running BatchNorm statistics),
+    torch.no_grad, reference call path model(dto) (Tester.py:16-28, Learner.py:132-142)."""
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+    size = (args.size,) * 3
+    torch.manual_seed(1234)
+    model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).eval()
+    out = model.output_size(size)
+    model.freeze(True)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
+    labels = torch.zeros((args.batch, 2) + tuple(out), device=dev)
+
+    def step():
+        with torch.no_grad():
+            dto = model(UnetDtoUtil.init_dto(images, labels[:, 0:1], labels[:, 1:2]))
+        return dto.outputs.core
+
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph and world == 1:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+    dt, _ = timed_steps((lambda: graph.replay()) if graph is not None else step, args, world, dev)
     vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
     res = {"metric": "inference voxels/sec, 3D U-Net Bx2x%d^3 (eval forward)" % args.size, "value": vox / dt, "unit": "voxels/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
@@ -132,280 +447,120 @@ def bench_unet_infer(args, world, rank, dev):
            "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, eval forward "
                                   "(SURVEY 8 row N1)" % (args.batch, args.size, out[0]),
                       "launch": "hipGraph" if graph is not None else "eager"}}
-    if rank == 0:
-        print(json.dumps(res))
-    if dist.is_initialized():
-        dist.destroy_process_group()
-
-
-def capture_step(step, enabled):
-    """Capture one optimiser step (hundreds of kernel launches) into a hipGraph; returns (graph, static_loss) or (None, None)."""
-    if not enabled:
-        return None, None
-    try:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread may query events while this thread captures
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            gloss = step()
-        graph.replay()
-        torch.cuda.synchronize()
-        return graph, gloss
-    except Exception as e:      # keep the measurement alive: fall back to eager launches
-        print("graph capture failed (%s): eager launches" % (str(e).splitlines()[0][:200]), file=sys.stderr)
-        torch.cuda.synchronize()
-        return None, None
+    return finish(res, rank)
 
 
 def bench_cae(args, world, rank, dev):
     """BASELINE configs[2]: CAE --channelscae 1 16 24 32 100 800 1, batch 4, 1 x D x 128 x 128 (D = 28 native; the
     reference cannot close the loss at D = 128), one Learner.train_batch without the CPU metrics."""
-    import torch.distributed as dist
     from stroke_prediction_amd.common.model.Cae3D import Cae3D, Enc3D, Dec3D
     from stroke_prediction_amd.common.metrics import BatchDiceLoss
     from stroke_prediction_amd.learner.CaeReconstructionLearner import CaeReconstructionLearner
     from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
-    from oracle import weights as W          # synthetic blob labels only (input generator, not the checker)
-    ch = [1, 16, 24, 32, 100, 800, 1]
+    from stroke_prediction_amd.parallel import DataParallelSync
+    from stroke_prediction_amd.common import data as D
+    ch = CAE_CHANNELS
     d, hw = args.cae_depth, 128
     torch.manual_seed(1234)
     cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype=args.dtype), Dec3D(hw, d, ch, 5, 1.0, dtype=args.dtype)).to(dev).train()
-    # N = 1: the step is replayed as one hipGraph.  N > 1: eager launches by default -- measured equal on this path
-    # (the GPU, not the launching thread, is the bottleneck: 5.11 ms either way) and an RCCL collective inside a
-    # capture is the one thing that cannot be rehearsed on a 1-GPU box; SP_DIST_GRAPH=1 captures it too.
-    use_graph = not args.no_graph and (world == 1 or bool(os.environ.get("SP_DIST_GRAPH")))
+    use_graph = use_graph_for(args, world)
     opt = FusedAdam([p for p in cae.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999),
-                    grad_scale=1.0 / world, capturable=use_graph)
+                    grad_scale=1.0 / world, capturable=True)          # train_shape_reconstruction.py:11-13,40
+    sync = DataParallelSync(cae, optimizer=opt, bucketed=not args.no_buckets)
     attach_flat_grads(cae)
-
-    class _L:
-        batch_size = args.batch
     with contextlib.redirect_stdout(sys.stderr):
-        learner = CaeReconstructionLearner(_L(), None, cae, opt, None, 1, None, "/tmp/_bench_cae", BatchDiceLoss([1.0]), verbose=False)
-    labels, clinical = W.cae_inputs(args.batch, d, hw, 1234 + rank)
+        learner = CaeReconstructionLearner(_LoaderStub(args.batch), None, cae, opt, None, 1, None, "/tmp/_bench_cae",
+                                           BatchDiceLoss([1.0]), verbose=False, graph=use_graph, batch_metrics=False,
+                                           sync_loss=False)
+    labels, clinical = D.synthetic_shape_batch(args.batch, d, hw, 1234 + rank)
     batch = {"case_id": list(range(args.batch)), "images": None, "labels": labels.to(dev), "clinical": clinical.to(dev)}
+    epoch = 30                                                          # latent-loss ramp factor 0.2 (SURVEY 8d)
 
     def step():
-        dto = learner.inference_step(batch)
-        loss = learner.loss_step(dto, 30)
-        opt.zero_grad()
-        loss.backward()
-        if world > 1:
-            dist.all_reduce(cae.flat_buffers()[1])
-        opt.step()
-        return loss
+        return learner.train_batch(batch, epoch)
 
-    for _ in range(max(args.warmup, 3 if use_graph else 0)):
+    for _ in range(learner.GRAPH_WARMUP + 1 if use_graph else 0):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    graph, gloss = capture_step(step, use_graph)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-            loss = gloss
-        else:
-            loss = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt, last = timed_steps(step, args, world, dev)
+    ms = 1e3 * dt / args.steps
     vox = world * args.batch * d * hw * hw * args.steps
     res = {"metric": "train-step voxels/sec, CAE Bx1xDx128x128 (3 encoder + 4 decoder passes)", "value": vox / dt,
-           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "unit": "voxels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-           "config": {"workload": "CAE --channelscae 1 16 24 32 100 800 1, batch %d/GPU, 1x%dx128x128 (configs[2])" % (args.batch, d),
-                      "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.detach()),
-                      "launch": "hipGraph" if graph is not None else "eager"}}
-    if rank == 0:
-        print(json.dumps(res))
+           "config": {"workload": "CAE shape reconstruction --channelscae 1 16 24 32 100 800 1, batch %d/GPU, 1x%dx128x128, "
+                                  "Learner.train_batch (configs[2]; 128^3 itself does not close the reference's loss, SURVEY 8d)"
+                                  % (args.batch, d),
+                      "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(last.loss),
+                      "launch": "hipGraph (Learner(graph=True))" if use_graph else "eager"}}
+    if not args.no_kernel_timing:
+        nprof = min(args.steps, 3)
+        agg, per_layer = kernel_profile(lambda: learner._optimise(batch, epoch), nprof, world)
+        roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None, traffic_key="cae_conv_igemm")
+        if roof:
+            res["roofline"], res["kernels"] = roof, kernels
+        if d in CAE_TRAIN_GFLOP_PER_SAMPLE:
+            res["train_step_tflops"] = CAE_TRAIN_GFLOP_PER_SAMPLE[d] * 1e9 * world * args.batch * args.steps / dt / 1e12
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_cae(d, hw, steps=3 if d <= 28 else 1)
+    return finish(res, rank)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch")
-    ap.add_argument("--size", type=int, default=128)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--workload", default="unet", choices=["unet", "cae", "unet-infer"],
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 4; unet4: 1)")
+    ap.add_argument("--size", type=int, default=None, help="cubic input size (default 128; unet4: 256)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
+    ap.add_argument("--workload", default="unet", choices=["unet", "cae", "unet-infer", "unet4"],
                     help="unet = BASELINE configs[1] (headline); cae = configs[2]: CAE 1 16 24 32 100 800 1, 3 enc + 4 dec passes; "
+                         "unet4 = configs[4] topology (4-scale U-Net 2 32 64 128 256 128 64 32 [32] 2, default 256^3); "
                          "unet-infer = SURVEY 8 row N1: eval-mode forward only (Tester / validate_batch), no gradients")
     ap.add_argument("--cae-depth", type=int, default=28, help="CAE volume depth (28 native, 124 = closest closed size to 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-f32-mode logit comparison leg")
     ap.add_argument("--torch-gpu-baseline", action="store_true",
                     help="also time the torch restatement (MIOpen, bf16 autocast) on this GPU; reported beside cpu_baseline")
     ap.add_argument("--dp-mode", default="fast", choices=["fast", "exact"],
                     help="multi-GPU: fast = local BatchNorm/Dice + gradient mean; exact = global-batch BatchNorm and Dice sums")
+    ap.add_argument("--no-buckets", action="store_true", help="multi-GPU: one blocking all-reduce after backward instead of overlapped buckets")
     ap.add_argument("--layers", action="store_true", help="print per-layer conv kernel timings to stderr")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 1 if args.workload == "unet4" else 4
+    if args.size is None:
+        args.size = 256 if args.workload == "unet4" else 128
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return self_launch(args)              # nothing below runs in the launcher process: it never touches the GPU
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks with --gpus N, or unset WORLD_SIZE and let "
+                         "bench.py start them)" % (args.gpus, world))
+    if rank != 0:
+        sys.stdout = open(os.devnull, "w")
+    if os.environ.get("SP_BENCH_DRYRUN"):
+        return dryrun(args, world, rank)
     # SP_BENCH_DEVICE / SP_BENCH_BACKEND: rehearsal of the multi-rank code path on a one-GPU box (all ranks on one
     # device, gloo instead of RCCL, which refuses two ranks per device); never set in a measured run
     if os.environ.get("SP_BENCH_DEVICE") is not None:
         local_rank = int(os.environ["SP_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    import torch.distributed as dist
-    if world > 1 or os.environ.get("SP_FORCE_SYNC"):      # SP_FORCE_SYNC: 1-rank RCCL group, rehearses capture on one GPU
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        if os.environ.get("SP_BENCH_BACKEND"):
-            dist.init_process_group(os.environ["SP_BENCH_BACKEND"])
-        else:
-            dist.init_process_group("nccl", device_id=dev)
-
+    init_dist(world, dev)
     import stroke_prediction_amd  # noqa: F401  (puts the drop-in packages on sys.path)
-    from stroke_prediction_amd.common.model.Unet3D import Unet3D
-    from stroke_prediction_amd.common.metrics import BatchDiceLoss, mean_of_channel_losses
-    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
-    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
-    from stroke_prediction_amd.parallel import DataParallelSync
-    from stroke_prediction_amd.runtime import ops as O
-    from stroke_prediction_amd.runtime.unet_engine import unet_out_dims
-
     if args.workload == "cae":
         return bench_cae(args, world, rank, dev)
     if args.workload == "unet-infer":
         return bench_unet_infer(args, world, rank, dev)
-    size = (args.size,) * 3
-    out = unet_out_dims(size)
-    torch.manual_seed(1234)                      # identical random-init weights on every rank
-    model = Unet3D(CHANNELS, dtype=args.dtype).to(dev).train()
-    sync = DataParallelSync(model, mode=args.dp_mode)
-    # N = 1: the step is replayed as one hipGraph.  N > 1: eager launches by default -- measured equal on this path
-    # (the GPU, not the launching thread, is the bottleneck: 5.11 ms either way) and an RCCL collective inside a
-    # capture is the one thing that cannot be rehearsed on a 1-GPU box; SP_DIST_GRAPH=1 captures it too.
-    use_graph = not args.no_graph and (world == 1 or bool(os.environ.get("SP_DIST_GRAPH")))
-    opt = FusedAdam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5,
-                    betas=(0.99, 0.999), grad_scale=sync.grad_scale, capturable=use_graph)   # train_unet_segmentation.py:13-14,32
-    attach_flat_grads(model)
-    sys.stdout = open(os.devnull, "w") if rank != 0 else sys.stdout
-    with contextlib.redirect_stdout(sys.stderr):      # the reference's constructor prints; stdout carries the JSON line only
-        crit = BatchDiceLoss([1.0])
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
-    labels = (torch.rand((args.batch, 2) + out, generator=g, device=dev) > 0.7).float()
-
-    def step():
-        dto = model(UnetDtoUtil.init_dto(images, labels[:, 0:1], labels[:, 1:2]))
-        # UnetSegmentationLearner.loss_step: (Dice(core) + Dice(penu)) / 2
-        loss = mean_of_channel_losses(crit, (dto.outputs.core, dto.outputs.penu), (dto.given_variables.core, dto.given_variables.penu))
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        return loss
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(max(args.warmup, 3 if use_graph else 0)):
-        step()
-    fence()
-    # the whole optimiser step (~330 launches) as ONE hipGraph: same kernels, same order, no Python between them
-    graph, gloss = capture_step(step, use_graph)
-    launch_mode = "hipGraph" if graph is not None else "eager"
-    fence()
-    prof = None
-    if not args.no_kernel_timing:
-        # per-kernel HIP-event timing needs eager launches: a separate pass over the same steps, not the timed region
-        O.PROFILE = []
-        for _ in range(min(args.steps, 3)):
-            step()
-        fence()
-        prof, O.PROFILE = O.PROFILE, None
-        prof_steps = min(args.steps, 3)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-            loss = gloss
-        else:
-            loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax)
-    vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
-    res = {
-        "metric": "train-step voxels/sec, 3D U-Net Bx2x128^3", "value": vox / dt, "unit": "voxels/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, "
-                               "fwd+Dice+bwd+Adam (configs[1])" % (args.batch, args.size, out[0]),
-                   "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(loss.detach()),
-                   "launch": launch_mode, "dp_mode": args.dp_mode if world > 1 else None},
-    }
-    # ---- roofline of the dominant kernel, from HIP events recorded around every launch of the timed region
-    if prof:
-        agg = {}
-        per_layer = {}
-        for tag, flops, e0, e1, detail in prof:
-            a = agg.setdefault(tag, [0.0, 0.0, 0])
-            ms = e0.elapsed_time(e1)
-            a[0] += ms * 1e-3
-            a[1] += flops
-            a[2] += 1
-            pl = per_layer.setdefault((tag, detail), [0.0, 0.0, 0])
-            pl[0] += ms * 1e-3; pl[1] += flops; pl[2] += 1
-        if args.layers:
-            for (tag, detail), (tt, ff, nn) in sorted(per_layer.items(), key=lambda kv: -kv[1][0]):
-                print("  %-11s %-34s %7.1f us/launch  %6.1f TFLOP/s  x%d/step" % (tag, detail, 1e6 * tt / nn, ff / tt / 1e12, nn // prof_steps),
-                      file=sys.stderr)
-        dom = max(agg, key=lambda k: agg[k][0])
-        t, fl, n = agg[dom]
-        dt_prof = dt / args.steps * prof_steps
-        peak = PEAK_TFLOPS[args.dtype]
-        traffic = None
-        try:    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE)
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f)[dom]["bytes_per_launch"]
-        except Exception:
-            pass
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": fl / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                           "frac": fl / t / 1e12 / peak, "traffic": traffic, "launches": n,
-                           "avg_launch_us": 1e6 * t / n, "share_of_step": t / dt_prof,
-                           "timing": "HIP events around every launch, %d eager steps right before the timed region" % prof_steps}
-        if traffic:     # the same launches against the HBM roof (PMC bytes per launch / measured launch time; peak 8 TB/s)
-            gbps = traffic / (t / n) / 1e9
-            res["roofline"]["hbm"] = {"achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0}
-        res["kernels"] = {k: {"time_s_per_step": v[0] / prof_steps, "tflops": v[1] / v[0] / 1e12, "launches_per_step": v[2] / prof_steps}
-                          for k, v in agg.items()}
-        res["train_step_tflops"] = TRAIN_GFLOP_PER_SAMPLE_128 * (args.size / 128.0) ** 3 * 1e9 * world * args.batch * args.steps / dt / 1e12 \
-            if args.size == 128 else None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline(size)
-    if rank == 0 and world == 1 and args.torch_gpu_baseline and args.workload == "unet":
-        try:
-            res["torch_gpu_baseline"] = torch_gpu_baseline(size, args.batch, bf16=(args.dtype == "bf16"))
-        except Exception as e:
-            res["torch_gpu_baseline"] = {"error": str(e).splitlines()[0][:200]}
-    if rank == 0:
-        print(json.dumps(res))
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    return bench_unet(args, world, rank, dev, four_scale=(args.workload == "unet4"))
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -346,6 +346,11 @@ int sp_adam_step_flat_dev(float* p, const float* g, float* m, float* v, int64_t 
                           float eps, float weight_decay, const int32_t* step_dev, float grad_scale,
                           sp_stream_t stream);
 
+/* same, with {lr, beta1, beta2, eps, weight_decay} read from device memory too: a captured step keeps following
+ * Learner.adapt_lr (learner/Learner.py:156-158, MultiStepLR) and adapt_betas (CaeReconstructionLearner.py:28-40) */
+int sp_adam_step_flat_hyp(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                          const int32_t* step_dev, float grad_scale, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ input pipeline (SURVEY.md 8 "next" row N4)
  * ElasticDeform.elastic_transform (common/data.py:326-339) on the device.  Volumes are C-ordered (n0, n1, n2) fp32
  * arrays, the reference's (x, y, z) numpy layout.

@@ -99,21 +99,27 @@ def upsample2(x, align_corners=False):
 
 
 def unet_forward(sd, x, training=True, return_all=False, q=_ident):
-    """``Unet3D.forward`` Unet3D.py:56-79.  Returns sigmoid probs (B,2,...).
+    """``Unet3D.forward`` Unet3D.py:56-79 (three scales) and ``LargeUnet3D.forward`` Unet3D.py:118-146 (four): the number
+    of scales S follows from the block count of the state dict (2S - 1 blocks).  Returns sigmoid probs (B,2,...).
     ``q=round_bf16`` emulates the bf16 storage points of the HIP fast path (see ``unet_block``)."""
-    b1 = unet_block(sd, "block1", q(x), training, q)
-    b2 = unet_block(sd, "block2", F.max_pool3d(b1, 2, 2), training, q)
-    b3 = unet_block(sd, "block3", F.max_pool3d(b2, 2, 2), training, q)
-    u3 = q(upsample2(b3))
-    b4 = unet_block(sd, "block4", torch.cat((u3, center_crop(b2, u3)), dim=1), training, q)
-    u4 = q(upsample2(b4))
-    b5 = unet_block(sd, "block5", torch.cat((u4, center_crop(b1, u4)), dim=1), training, q)
+    nblocks = len({k.split(".")[0] for k in sd if k.startswith("block")})
+    S = (nblocks + 1) // 2
+    outs = {}
+    h = q(x)
+    for i in range(1, S + 1):                              # down: block, pool (Unet3D.py:57-63 / :119-128)
+        outs[i] = unet_block(sd, "block%d" % i, h, training, q)
+        if i < S:
+            h = F.max_pool3d(outs[i], 2, 2)
+    low = outs[S]
+    for u in range(S + 1, 2 * S):                          # up: upsample, crop + cat, block (Unet3D.py:64-73 / :129-141)
+        up = q(upsample2(low))
+        outs[u] = low = unet_block(sd, "block%d" % u, torch.cat((up, center_crop(outs[2 * S - u], up)), dim=1), training, q)
     # (the HIP path fuses the classify head: weights enter as hi + lo bf16 pairs = fp32 accuracy; the hidden layer is
     # never stored but is rounded to bf16 as the operand of the second matrix product)
-    h = q(F.leaky_relu(F.conv3d(b5, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY))
+    h = q(F.leaky_relu(F.conv3d(low, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY))
     seg = torch.sigmoid(F.conv3d(h, sd["classify.2.weight"], sd["classify.2.bias"]))
     if return_all:
-        return seg, dict(b1=b1, b2=b2, b3=b3, b4=b4, b5=b5)
+        return seg, {"b%d" % i: v for i, v in outs.items()}
     return seg
 
 

@@ -1,9 +1,10 @@
 """CPU oracle of the reference's sample transforms (TEST INFRASTRUCTURE ONLY: imported by tests/ and nowhere in the
-product path).  Restates ``common/data.py`` of the reference on numpy + scipy.ndimage -- the reference's own
-third-party dependency for this path (``scipy.ndimage.gaussian_filter`` / ``map_coordinates``, data.py:14-15; the
-reference pins no version, this image has scipy 1.15).  ``common/data.py`` itself is not importable here (it imports
-nibabel, absent from the image), so the restatement is pinned by scipy -- the library that defines the algorithm --
-plus the fixture ``tests/golden/transforms.npz`` recorded from it (``tests/golden/make_golden_transforms.py``).
+product path).  Restates ``common/data.py:215-351`` of the reference on numpy + scipy.ndimage (the reference's own
+third-party dependency for this path: ``scipy.ndimage.gaussian_filter`` / ``map_coordinates``, data.py:14-15).
+Parity status: PINNED -- ``tests/golden/transforms.npz`` holds inputs and outputs of the reference's own classes
+(``ElasticDeform`` incl. its ``__call__``, ``PadImages``, ``RandomPatch``, ``HemisphericFlip[FixedToCaseId]``, ``ToTensor``),
+recorded by ``tests/golden/make_golden_transforms.py`` from the imported reference module; ``tests/test_transforms.py``
+replays them through these functions.
 """
 import random
 

@@ -37,14 +37,18 @@ def _conv_entries(prefix, cout, cin, k, transposed=False):
 
 
 def unet_spec(channels):
-    """(name, shape, kind) list in state_dict order, ``Unet3D.py:31-54``."""
-    n_in, b1, b2, b3, b4, b5, bc, ncls = channels
+    """(name, shape, kind) list in state_dict order: ``Unet3D.py:31-54`` for 8 channel counts (three scales),
+    ``LargeUnet3D`` ``Unet3D.py:88-116`` for 10 (four scales)."""
+    S = (len(channels) - 2) // 2
+    n_in, w, bc, ncls = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
+    pairs = [(n_in if i == 1 else w[i - 2], w[i - 1]) for i in range(1, S + 1)]
+    pairs += [(w[u - 2] + w[2 * S - u - 1], w[u - 1]) for u in range(S + 1, 2 * S)]
     spec = []
-    for i, (ci, co) in enumerate([(n_in, b1), (b1, b2), (b2, b3), (b3 + b2, b4), (b4 + b1, b5)], start=1):
+    for i, (ci, co) in enumerate(pairs, start=1):
         p = "block%d.bn_conv_relu_2x." % i
         spec += _bn_entries(p + "0", ci) + _conv_entries(p + "1", co, ci, (3, 3, 3))
         spec += _bn_entries(p + "3", co) + _conv_entries(p + "4", co, co, (3, 3, 3))
-    spec += _conv_entries("classify.0", bc, b5, (1, 1, 1))
+    spec += _conv_entries("classify.0", bc, w[-1], (1, 1, 1))
     spec += _conv_entries("classify.2", ncls, bc, (1, 1, 1))
     return spec
 
@@ -121,22 +125,27 @@ def make_state_dict(spec, seed=0, dtype=torch.float32):
     return sd
 
 
-def unet_inputs(batch, size, seed=0, n_in=2, out_size=None):
+def unet_inputs(batch, size, seed=0, n_in=2, out_size=None, scales=3):
     """images ~N(0,1) (B,n_in,*size); labels (B,2,*out) = U(0,1)>0.7."""
     if isinstance(size, int):
         size = (size,) * 3
     g = _rng(seed, "unet.images")
     x = g.standard_normal((batch, n_in) + tuple(size)).astype(np.float32)
-    out = out_size or tuple(unet_out_size(s) for s in size)
+    out = out_size or tuple(unet_out_size(s, scales) for s in size)
     gl = _rng(seed, "unet.labels")
     y = (gl.uniform(0, 1, (batch, 2) + tuple(out)) > 0.7).astype(np.float32)
     return torch.from_numpy(x), torch.from_numpy(y)
 
 
-def unet_out_size(n):
-    """valid 3x3x3 x2 per block, pool/2, upsample x2."""
-    b3 = ((n - 4) // 2 - 4) // 2 - 4
-    return 4 * b3 - 12
+def unet_out_size(n, scales=3):
+    """valid 3x3x3 x2 per block, pool/2, upsample x2 (scales=4: 256 -> 164)."""
+    m = n
+    for _ in range(scales - 1):
+        m = (m - 4) // 2
+    m -= 4
+    for _ in range(scales - 1):
+        m = 2 * m - 4
+    return m
 
 
 def cae_inputs(batch, d=28, hw=128, seed=0):

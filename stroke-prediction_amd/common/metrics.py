@@ -2,9 +2,10 @@
 
 ``BatchDiceLoss`` (metrics.py:8-28) keeps its constructor and call signature; on GPU tensors the three
 whole-batch reductions and the backward run as two fused HIP kernels (``sp_dice_sums``, ``sp_dice_bwd``)
-instead of six torch reductions plus temporaries.  The binary measures (metrics.py:31-62) are restated
-on numpy/scipy because medpy is not a dependency here: Dice, precision, sensitivity, specificity and
-the surface distances HD / ASSD (definitions of ``medpy.metric.binary`` 0.3.0).
+instead of six torch reductions plus temporaries.  The binary measures (metrics.py:31-62: Dice, precision,
+sensitivity, specificity, Hausdorff distance and ASSD as ``medpy.metric.binary`` 0.3.0 defines them) run on the device:
+``sp_confusion_counts`` and ``sp_surface_distances`` (border extraction + exact Euclidean distance transform).  There is
+no host implementation here; the checker is ``oracle/measures.py``.
 """
 import numpy
 import torch
@@ -131,24 +132,6 @@ def mean_of_channel_losses(criterion, outputs, targets):
 
 # ---------------------------------------------------------------------------------------------- evaluation measures
 
-def _surface_distances(result, reference):
-    """Distances from the border voxels of ``result`` to the border of ``reference`` (medpy definition)."""
-    from scipy.ndimage import binary_erosion, distance_transform_edt, generate_binary_structure
-    footprint = generate_binary_structure(result.ndim, 1)
-    rb = result ^ binary_erosion(result, structure=footprint, iterations=1)
-    fb = reference ^ binary_erosion(reference, structure=footprint, iterations=1)
-    dt = distance_transform_edt(~fb)
-    return dt[rb]
-
-
-def _hd(a, b):
-    return max(_surface_distances(a, b).max(), _surface_distances(b, a).max())
-
-
-def _assd(a, b):
-    return numpy.mean((_surface_distances(a, b).mean(), _surface_distances(b, a).mean()))
-
-
 def _measures_from_counts(tp, fp, fn, tn):
     size = (tp + fp) + (tp + fn)
     return BinaryMeasuresDto(2.0 * tp / size if size > 0 else 0.0, numpy.inf, numpy.inf,
@@ -158,18 +141,17 @@ def _measures_from_counts(tp, fp, fn, tn):
 
 
 def binary_measures_numpy(result, target, binary_threshold=0.5, distances=True):
-    r = result > binary_threshold
-    t = target > binary_threshold
-    out = _measures_from_counts(float(numpy.count_nonzero(r & t)), float(numpy.count_nonzero(r & ~t)),
-                                float(numpy.count_nonzero(~r & t)), float(numpy.count_nonzero(~r & ~t)))
-    if distances and r.any() and t.any():
-        out.hd = _hd(r, t)
-        out.assd = _assd(r, t)
-    return out
+    """``metrics.py:31-46`` of the reference for host arrays: uploaded once and measured on the device like
+    ``binary_measures_torch`` (there is no CPU implementation in this package; MedPy, which the reference calls, is
+    restated only as the test oracle ``oracle/measures.py``)."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("binary_measures_numpy (stroke_prediction_amd) measures on the GPU: no CUDA device available")
+    r = torch.from_numpy(numpy.ascontiguousarray(result, dtype=numpy.float32)).cuda()
+    t = torch.from_numpy(numpy.ascontiguousarray(target, dtype=numpy.float32)).cuda()
+    return binary_measures_torch(r, t, True, binary_threshold=binary_threshold, distances=distances)
 
 
 DISTANCE_METRICS = True      # Hausdorff / ASSD as the reference's batch metrics report them (metrics.py:42-44)
-DEVICE_DISTANCES = True      # ... from the HIP distance transform (sp_surface_distances); False: scipy on the host, like medpy
 
 
 _SD_WS = {}
@@ -206,19 +188,16 @@ def binary_measures_torch(result, target, cuda, binary_threshold=0.5, distances=
         t = target.detach().float().contiguous()
         counts = torch.zeros(4, dtype=torch.int64, device=r.device)
         L.call("sp_confusion_counts", O.ptr(r), O.ptr(t), float(binary_threshold), r.numel(), O.ptr(counts), O.stream())
-        on_device = distances and DEVICE_DISTANCES and r.dim() <= 5
-        sd = _surface_distances_launch(r, t, binary_threshold) if on_device else None    # enqueued before the one sync below
+        if distances and r.dim() > 5:
+            raise ValueError("surface distances: tensors of rank <= 5 (got %d)" % r.dim())
+        sd = _surface_distances_launch(r, t, binary_threshold) if distances else None    # enqueued before the one sync below
         tp, fp, fn, tn = (float(v) for v in counts.tolist())
         out = _measures_from_counts(tp, fp, fn, tn)
         if distances and tp + fp > 0 and tp + fn > 0:
-            if on_device:
-                mx_rt, sm_rt, n_r, mx_tr, sm_tr, n_t = sd.tolist()
-                out.hd, out.assd = float(numpy.sqrt(max(mx_rt, mx_tr))), 0.5 * (sm_rt / n_r + sm_tr / n_t)
-            else:
-                rn, tn_ = r.cpu().numpy() > binary_threshold, t.cpu().numpy() > binary_threshold
-                out.hd = _hd(rn, tn_)
-                out.assd = _assd(rn, tn_)
+            mx_rt, sm_rt, n_r, mx_tr, sm_tr, n_t = sd.tolist()
+            out.hd, out.assd = float(numpy.sqrt(max(mx_rt, mx_tr))), 0.5 * (sm_rt / n_r + sm_tr / n_t)
         return out
+    # host tensors / arrays: same measures, on the device
     result = result.detach().cpu().numpy() if isinstance(result, torch.Tensor) else result
     target = target.detach().cpu().numpy() if isinstance(target, torch.Tensor) else target
     return binary_measures_numpy(result, target, binary_threshold=binary_threshold, distances=distances)

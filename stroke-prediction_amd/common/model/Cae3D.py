@@ -31,6 +31,25 @@ def _containers(table, cm):
     return nn.ModuleDict(mods)
 
 
+class _Lease:
+    """A StackContext on loan from the pool to one autograd node: returned by backward, or -- when the graph is dropped
+    without a backward (a grad-enabled forward whose loss is never differentiated) -- when the node is collected."""
+
+    def __init__(self, pool, key, sc):
+        self.pool, self.key, self.sc = pool, key, sc
+
+    def release(self):
+        if self.sc is not None:
+            self.pool.release(self.key, self.sc)
+            self.sc = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
 class _StackFn(torch.autograd.Function):
     """One encoder or decoder call.  ``x`` needs a gradient only for the decoder (the latent)."""
 
@@ -38,7 +57,11 @@ class _StackFn(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         key, sc = module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device)
         out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training)
-        ctx.module, ctx.key, ctx.sc = module, key, sc
+        ctx.module, ctx.sc = module, sc
+        ctx.lease = _Lease(module._pool(), key, sc)
+        module._begin_step()
+        module._n_out = getattr(module, "_n_out", 0) + 1       # passes of this stack whose backward is still to come
+        ctx.training = module.training
         ctx.need_dx = x.requires_grad
         ctx.save_for_backward(out)
         return out
@@ -47,9 +70,16 @@ class _StackFn(torch.autograd.Function):
     def backward(ctx, dout):
         module, sc = ctx.module, ctx.sc
         (out,) = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("%s.backward after an eval-mode forward is not supported: the fused backward uses the "
+                               "batch-statistics BatchNorm formula; call model.train() for passes that need gradients"
+                               % type(module).__name__)
         names, views, inplace = module._grad_targets()
         dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
-        module._pool().release(ctx.key, sc)
+        ctx.lease.release()
+        module._n_out = max(0, getattr(module, "_n_out", 1) - 1)
+        if module._n_out == 0:
+            module._stack_grads_final()
         return (None, dx) + tuple(None if inplace else v for v in views)
 
 
@@ -105,6 +135,27 @@ class CaeBase(FlatParamsMixin, nn.Module):
         self._pool().release(key, sc)
         return out
 
+    def _stack_grads_final(self):
+        """every pass of this stack recorded in the current step has run its backward: its parameter gradients are
+        final.  Data-parallel training starts the all-reduce of that part of the flat buffer now (the decoder's four
+        backward passes come first, so its bucket travels while the encoder's three run), the rest at the latest in the
+        optimiser's step pre-hook (parallel.DataParallelSync)."""
+        root = self._flat_root()
+        if root is self:
+            self._after_backward()
+            return
+        stacks = [m for m in root.children() if isinstance(m, CaeBase)]
+        if all(getattr(m, "_n_out", 0) == 0 for m in stacks):
+            root._after_backward()
+        else:
+            for name, m in root.named_children():
+                if m is self and root._flat_grad is not None:
+                    # only the segment at the END of what is still pending may go (the flat buffer is exchanged back to front)
+                    lo = root._flat_offset_of(name + ".")
+                    hi = root._flat_grad.numel() if root._bucket_hi is None else root._bucket_hi
+                    if lo + sum(p.numel() for p in self.parameters()) == hi:
+                        self._grads_ready_from(name + ".")
+
     def _grad_targets(self):
         # an encoder / decoder runs 3-4 times per step: never hand the shared flat views to autograd twice
         names, views, inplace = super()._grad_targets()
@@ -118,11 +169,25 @@ class CaeBase(FlatParamsMixin, nn.Module):
         for param in self.parameters():
             param.requires_grad = requires_grad
 
+    def __setstate__(self, state):
+        """see ``Unet3D.__setstate__``: a ``.model`` file written by the reference's ``Enc3D`` / ``Dec3D`` carries the
+        reference's attributes (``n_ch_*``, ``n_input``, ``n_classes``, ``alpha``, CaeBase Cae3D.py:13-26); the channel list
+        and the precision mode of this implementation are rebuilt from them."""
+        super().__setstate__(state)
+        d = self.__dict__
+        if "channels" not in d:
+            d["channels"] = [d["n_input"], d["n_ch_origin"], d["n_ch_down2x"], d["n_ch_down4x"], d["n_ch_down8x"], d["n_ch_fc"],
+                             d["n_classes"]]
+        d.setdefault("compute_dtype", "bf16")
+        d["_stack_pool"] = None
+        d.setdefault("_flat_parent", None)
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_stack_pool"] = None
         state["_flat_parent"] = None
-        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt"):
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt",
+                  "grad_sync", "grad_bucket_ready", "_bucket_hi", "_grads_synced", "_n_out"):
             state.pop(k, None)
         return state
 
@@ -165,6 +230,37 @@ class Enc3D(CaeBase):
             lat.penu = self._forward_single(inp.penu)
             lat.interpolation = self._interpolate(lat.core, lat.penu, step)
         return dto
+
+
+class Enc3DStep(Enc3D):
+    """Encoder that can LEARN the interpolation step from the clinical globals when no time to treatment is given
+    (reference Cae3D.py:121-142): two 1x1x1 convolutions + ELU reduce the B x n_global x 1 x 1 x 1 vector, a third one
+    and a sigmoid yield ``step``.  The three convolutions see B x 5 values: they stay plain ``torch.nn`` modules on the
+    device (their gradient reaches them through the torch-side latent interpolation); the encoder stack itself is the
+    fused HIP path of ``Enc3D``."""
+
+    def __init__(self, size_input_xy, size_input_z, channels, n_ch_global, alpha, dtype="bf16"):
+        super().__init__(size_input_xy, size_input_z, channels, n_ch_global, alpha, dtype=dtype)
+        g = self.n_ch_global
+        self.reduce = nn.Sequential(nn.Conv3d(g, g, 1), nn.ELU(self.alpha, True), nn.Conv3d(g, g // 2, 1), nn.ELU(self.alpha, True))
+        self.step = nn.Conv3d(g // 2, 1, 1)
+        nn.init.normal_(self.step.weight, 0, 0.001)      # the reference stresses this initialisation (Cae3D.py:133-134)
+        nn.init.normal_(self.step.bias, 0.5, 0.01)
+        self.sigmoid = nn.Sigmoid()
+
+    def _get_step(self, dto: CaeDto):
+        step = dto.given_variables.time_to_treatment
+        if step is None:
+            step = self.sigmoid(self.step(self.reduce(dto.given_variables.globals)))
+        return step
+
+
+class Enc3DCtp(Enc3D):
+    """CTP-conditioned encoder (reference Cae3D.py:145-169): only reachable from ``train_shape_reconstruction_with_ctp.py``,
+    which passes keyword arguments the reference classes do not accept -- outside the accelerated path."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("Enc3DCtp is outside the MI355X path (SURVEY.md 2.1 row 2: not used by the two named scripts)")
 
 
 class Dec3D(CaeBase):
@@ -222,8 +318,13 @@ class Cae3D(FlatParamsMixin, nn.Module):
         self.enc.freeze(freeze)
         self.dec.freeze(freeze)
 
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._adopt()
+
     def __getstate__(self):
         state = self.__dict__.copy()
-        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt"):
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt",
+                  "grad_sync", "grad_bucket_ready", "_bucket_hi", "_grads_synced", "_n_out"):
             state.pop(k, None)
         return state

@@ -47,8 +47,10 @@ class _UnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, images, *params):
         engine = model._engine(images)
+        model._begin_step()
         seg = engine.forward(images, model._param_dict(), model._buffer_dict(), model.training)
         ctx.model, ctx.engine = model, engine
+        ctx.generation, ctx.training = engine.generation, model.training
         ctx.save_for_backward(seg)
         return seg
 
@@ -56,34 +58,50 @@ class _UnetFn(torch.autograd.Function):
     def backward(ctx, dseg):
         model, engine = ctx.model, ctx.engine
         (seg,) = ctx.saved_tensors
+        # the activations and BatchNorm statistics of a pass live in the engine (one set per input shape): a later
+        # forward of the same shape has overwritten them
+        if ctx.generation != engine.generation:
+            raise RuntimeError("Unet3D.backward: another forward pass of the same input shape ran on this model after the "
+                               "one being differentiated (its activations are gone); run backward before the next "
+                               "forward -- gradient accumulation over micro-batches needs one backward per forward")
+        if not ctx.training:
+            raise RuntimeError("Unet3D.backward after an eval-mode forward is not supported: the fused backward uses the "
+                               "batch-statistics BatchNorm formula; call model.train() for passes that need gradients")
         names, views, inplace = model._grad_targets()
-        engine.backward(dseg, seg, model._param_dict(), dict(zip(names, views)))
+        engine.backward(dseg, seg, model._param_dict(), dict(zip(names, views)), ready=model._grads_ready_from)
         model._after_backward()
         return (None, None) + tuple(None if inplace else v for v in views)
 
 
 class Unet3D(FlatParamsMixin, nn.Module):
     FLAT_NBT = True      # every BatchNorm runs exactly once per forward: their step counters advance together
+    N_SCALES = 3
 
     def __init__(self, channels=[2, 32, 64, 128, 64, 32, 32, 2], channel_dim=1, channels_crop=[2, 3, 4],
                  dtype="bf16"):
         super().__init__()
-        n_ch_in, ch_b1, ch_b2, ch_b3, ch_b4, ch_b5, ch_bC, n_classes = channels
+        S = self.N_SCALES
+        assert len(channels) == 2 * S + 2, "%s takes %d channel counts (input, %d blocks, head, classes)" % (
+            type(self).__name__, 2 * S + 2, 2 * S - 1)
         self.channels = list(channels)
         self.channel_dim = channel_dim
         self.channels_crop = channels_crop
         self.compute_dtype = dtype           # "bf16" (fast) | "f32" (split-bf16 x3 MFMA, parity mode)
-
-        self.block1 = Block3x3x3(n_ch_in, ch_b1)
-        self.block2 = Block3x3x3(ch_b1, ch_b2)
-        self.block3 = Block3x3x3(ch_b2, ch_b3)
-        self.block4 = Block3x3x3(ch_b3 + ch_b2, ch_b4)
-        self.block5 = Block3x3x3(ch_b4 + ch_b1, ch_b5)
+        n_in, widths, ch_bC, n_classes = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
+        for i in range(1, S + 1):            # down path: block_i(b_{i-1} -> b_i)
+            setattr(self, "block%d" % i, Block3x3x3(n_in if i == 1 else widths[i - 2], widths[i - 1]))
+        for u in range(S + 1, 2 * S):        # up path: block_u(b_{u-1} + b_{2S-u} -> b_u)
+            setattr(self, "block%d" % u, Block3x3x3(widths[u - 2] + widths[2 * S - u - 1], widths[u - 1]))
         self.classify = nn.ModuleDict({
-            "0": nn.Conv3d(ch_b5, ch_bC, 1, stride=1, padding=0),
+            "0": nn.Conv3d(widths[-1], ch_bC, 1, stride=1, padding=0),
             "2": nn.Conv3d(ch_bC, n_classes, 1, stride=1, padding=0),
         })
         self._engines = {}
+
+    def output_size(self, size):
+        """spatial size of the segmentation for an input of spatial ``size`` (valid convolutions: 128^3 -> 88^3)"""
+        from stroke_prediction_amd.runtime.unet_engine import unet_out_dims
+        return unet_out_dims(tuple(size), self.N_SCALES)
 
     # ------------------------------------------------------------------ engine cache
     def _engine(self, images):
@@ -120,9 +138,41 @@ class Unet3D(FlatParamsMixin, nn.Module):
         for param in self.parameters():
             param.requires_grad = requires_grad
 
+    def __setstate__(self, state):
+        """Unpickling (``torch.load`` of a whole-module ``.model`` file, Learner.py:93, Tester.py:17).  A file written by the
+        REFERENCE's classes resolves to this class by its import path but carries the reference's attribute set: what this
+        implementation keeps beside the parameters (channel list, precision mode, engine cache) is rebuilt from the
+        parameter shapes -- the state_dict keys are the same, so the weights are used as they are."""
+        super().__setstate__(state)
+        d = self.__dict__
+        if "channels" not in d:
+            nb = len([k for k in self._modules if k.startswith("block")])
+            S = (nb + 1) // 2
+            conv = lambda i: dict(self._modules["block%d" % i].named_parameters())["bn_conv_relu_2x.1.weight"]
+            widths = [conv(i).shape[0] for i in range(1, nb + 1)]
+            head = dict(self._modules["classify"].named_parameters())
+            d["channels"] = [conv(1).shape[1]] + widths + [head["0.weight"].shape[0], head["2.weight"].shape[0]]
+            assert S == self.N_SCALES, "pickled network has %d scales, %s has %d" % (S, type(self).__name__, self.N_SCALES)
+        d.setdefault("channel_dim", 1)
+        d.setdefault("channels_crop", [2, 3, 4])
+        d.setdefault("compute_dtype", "bf16")
+        d["_engines"] = {}
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_engines"] = {}          # engines hold device buffers and ctypes handles: rebuilt on demand
-        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt"):
+        for k in ("_flat_param", "_flat_grad", "_flat_views", "_flat_pviews", "_flat_names", "_flat_device", "_flat_nbt",
+                  "grad_sync", "grad_bucket_ready", "_bucket_hi", "_grads_synced"):
             state.pop(k, None)
         return state
+
+
+class LargeUnet3D(Unet3D):
+    """The 4-scale network of the reference (``LargeUnet3D`` Unet3D.py:87-146: blocks 1-4 down, 5-7 up, same classify head;
+    state_dict keys ``block{1..7}.bn_conv_relu_2x.*``, ``classify.{0,2}.*``).  The reference class itself cannot be
+    constructed (it calls ``super(Unet3D, self).__init__()``, Unet3D.py:89); this is its topology on the same engine.
+    256^3 -> 164^3."""
+    N_SCALES = 4
+
+    def __init__(self, channels=[2, 32, 64, 128, 256, 128, 64, 32, 32, 2], channel_dim=1, channels_crop=[2, 3, 4], dtype="bf16"):
+        super().__init__(channels, channel_dim, channels_crop, dtype)

@@ -1392,6 +1392,33 @@ extern "C" int sp_adam_step_flat_dev(float* p, const float* g, float* m, float* 
   return SP_OK;
 }
 
+// hyper-parameters in device memory as well ({lr, beta1, beta2, eps, weight_decay}): a captured step keeps following
+// Learner.adapt_lr / adapt_betas (Learner.py:156-161, CaeReconstructionLearner.py:28-40) -- the host rewrites the five
+// floats between replays instead of re-capturing.
+__global__ void adam_hyp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                int64_t n, const float* __restrict__ hyper, const int32_t* __restrict__ step_ptr, float grad_scale) {
+  const float lr = hyper[0], beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3], wd = hyper[4];
+  const float step = (float)(*step_ptr);
+  const float bc1 = 1.f - powf(beta1, step), bc2 = 1.f - powf(beta2, step);
+  const float lr_over_bc1 = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float pi = p[i];
+    const float gi = g[i] * grad_scale + wd * pi;
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = pi - lr_over_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+  }
+}
+extern "C" int sp_adam_step_flat_hyp(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,
+                                     const int32_t* step_dev, float grad_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(p && g && m && v && n > 0 && step_dev && hyper_dev, "sp_adam_step_flat_hyp: bad arguments");
+  const unsigned grid = (unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  hipLaunchKernelGGL(adam_hyp_kernel, dim3(grid), dim3(256), 0, ST(stream), p, g, m, v, n, hyper_dev, step_dev, grad_scale);
+  SP_CHECK_LAUNCH("sp_adam_step_flat_hyp");
+  return SP_OK;
+}
+
 extern "C" int sp_adam_step_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                  float beta2, float eps, float weight_decay, int32_t step, float grad_scale,
                                  sp_stream_t stream) {

@@ -18,9 +18,9 @@ class CaeReconstructionLearner(Learner, CaeInference):
     N_EPOCHS_ADAPT_BETA1 = 4
 
     def __init__(self, dataloader_training, dataloader_validation, cae_model, optimizer, scheduler, n_epochs,
-                 path_previous_base, path_outputs_base, criterion, normalization_hours_penumbra=10, verbose=True):
+                 path_previous_base, path_outputs_base, criterion, normalization_hours_penumbra=10, verbose=True, **learner_kw):
         Learner.__init__(self, dataloader_training, dataloader_validation, cae_model, optimizer, scheduler, n_epochs,
-                         path_previous_base, path_outputs_base)
+                         path_previous_base, path_outputs_base, **learner_kw)
         CaeInference.__init__(self, cae_model, normalization_hours_penumbra)
         self._criterion = criterion
         self._verbose = verbose
@@ -42,6 +42,9 @@ class CaeReconstructionLearner(Learner, CaeInference):
     def get_start_min_loss(self):
         losses = [dto.loss for dto in self._metric_dtos['validate']]
         return min(losses) if losses else float('inf')
+
+    def graph_key(self, epoch):
+        return min(0.04 * max(0, epoch - 25), 1)       # the latent-loss ramp is a Python constant of the captured step
 
     def loss_step(self, dto: CaeDto, epoch):
         factor = min(0.04 * max(0, epoch - 25), 1)

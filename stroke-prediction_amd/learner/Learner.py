@@ -19,28 +19,47 @@ from common.dto.MetricMeasuresDto import MetricMeasuresDto, BinaryMeasuresDto
 from common.inference.Inference import Inference
 
 
+# The reference writes the metric history with jsonpickle 0.9.6 (Learner.py:103,110; requirements.txt:9): objects become
+# {"py/object": "<module>.<Class>", <attributes>}, non-finite floats the JSON extensions Infinity / NaN.  jsonpickle is
+# not a dependency here; the two functions below write and read that layout for the three DTO classes involved, so a
+# training interrupted under the reference resumes here and vice versa.
+_DTO_PATH = "common.dto.MetricMeasuresDto."
+
+
 def _encode_metrics(history):
     def enc(v):
         if isinstance(v, Dto):
-            d = {k: enc(x) for k, x in v}
-            d["__dto__"] = type(v).__name__
+            d = {"py/object": _DTO_PATH + type(v).__name__ if isinstance(v, (MetricMeasuresDto, BinaryMeasuresDto))
+                 else "common.dto.Dto.Dto"}
+            d.update({k: enc(x) for k, x in v})
             return d
-        if isinstance(v, float) and math.isinf(v):
-            return "inf"
+        if torch.is_tensor(v):
+            return float(v)
         return v
     return json.dumps({phase: [enc(m) for m in ms] for phase, ms in history.items()})
 
 
 def _decode_metrics(text):
+    seen = []
+
     def dec(v):
-        if isinstance(v, dict) and "__dto__" in v:
-            kind = v.pop("__dto__")
-            vals = {k: dec(x) for k, x in v.items()}
+        if isinstance(v, dict) and "py/id" in v:            # jsonpickle back-reference to the n-th object of the document
+            return seen[v["py/id"] - 1]
+        if isinstance(v, dict) and ("py/object" in v or "__dto__" in v):      # (__dto__: this package's round-1 files)
+            kind = (v.get("py/object") or v.get("__dto__")).rsplit(".", 1)[-1]
+            slot = len(seen)
+            seen.append(None)
+            vals = {k: dec(x) for k, x in v.items() if k not in ("py/object", "__dto__")}
             if kind == "BinaryMeasuresDto":
-                return BinaryMeasuresDto(**vals)
-            if kind == "MetricMeasuresDto":
-                return MetricMeasuresDto(**vals)
-            return Dto(**vals)
+                obj = BinaryMeasuresDto(*(vals.get(k) for k in ("dc", "hd", "assd", "precision", "sensitivity", "specificity")))
+            elif kind == "MetricMeasuresDto":
+                obj = MetricMeasuresDto(*(vals.get(k) for k in ("loss", "core", "penu", "lesion")))
+            else:
+                obj = Dto(**vals)
+            seen[slot] = obj
+            return obj
+        if isinstance(v, list):
+            return [dec(x) for x in v]
         return float("inf") if v == "inf" else v
     return {phase: [dec(m) for m in ms] for phase, ms in json.loads(text).items()}
 
@@ -57,9 +76,23 @@ class Learner(Inference):
     EXT_TRAIN = '.json'
     EXT_IMAGE = '.png'
 
+    GRAPH_WARMUP = 3      # eager steps before a (batch shape, graph_key) is captured: allocations and caches settle
+
     def __init__(self, dataloader_training, dataloader_validation, model, optimizer, scheduler, n_epochs: int,
-                 path_previous_base: str = None, path_outputs_base: str = '/tmp/stroke-prediction'):
+                 path_previous_base: str = None, path_outputs_base: str = '/tmp/stroke-prediction',
+                 graph: bool = False, batch_metrics: bool = True, sync_loss: bool = True):
+        """graph / batch_metrics / sync_loss are additions to the reference signature (Learner.py:33-35), all
+        defaulting to its behaviour.  graph=True: ``train_batch`` replays forward + loss + zero_grad + backward + step as
+        ONE hipGraph per (batch shapes, ``graph_key(epoch)``) -- the batch is copied into static device buffers, the
+        optimiser's lr / betas are read from device scalars (``FusedAdam(capturable=True)``), so ``adapt_lr`` /
+        ``adapt_betas`` keep working under replay.  batch_metrics=False skips ``batch_metrics_step`` (the reference's
+        per-batch medpy metrics, Learner.py:124,136; reported as zeros).  sync_loss=False keeps the batch loss on the device
+        (no host round trip per step); the epoch mean is converted once."""
         Inference.__init__(self, model)
+        self._graph_enabled = bool(graph)
+        self._batch_metrics = bool(batch_metrics)
+        self._sync_loss = bool(sync_loss)
+        self._graphs = {}
         assert dataloader_training.batch_size > 1, 'For normalization layers batch_size > 1 is required.'
         self._dataloader_training = dataloader_training
         self._dataloader_validation = dataloader_validation
@@ -127,35 +160,88 @@ class Learner(Inference):
         with open(path_training, 'r') as fp:
             self._metric_dtos = _decode_metrics(fp.read())
 
+    @staticmethod
+    def _is_rank0():
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
     def save_training(self):
+        if not self._is_rank0():             # data-parallel replicas are identical: one writer
+            return
         torch.save(self._optimizer.state_dict(), self.path('save', self.FNB_OPTIM))
         with open(self.path('save', self.FNB_TRAIN), 'w') as fp:
             fp.write(_encode_metrics(self._metric_dtos))
 
     def save_model(self, suffix=''):
+        if not self._is_rank0():
+            return
         was_cuda = self.is_cuda
+        dev = next(self._model.parameters()).device
         torch.save(self._model.cpu(), self.path('save', self.FNB_MODEL, suffix))
         if was_cuda:
-            self._model.cuda()
+            self._model.to(dev)
+        self._graphs.clear()                 # the parameters moved: captured steps point at the old storages
 
     # ------------------------------------------------------------------ the hot three lines
-    def train_batch(self, batch: dict, epoch) -> MetricMeasuresDto:
+    def _optimise(self, batch: dict, epoch):
+        """Learner.py:117-122: forward, loss, zero_grad / backward / step."""
         dto = self.inference_step(batch)
         loss = self.loss_step(dto, epoch)
 
         self._optimizer.zero_grad()
         loss.backward()
         self._optimizer.step()
+        return dto, loss
 
-        batch_metrics = self.batch_metrics_step(dto, epoch)
-        batch_metrics.loss = float(loss.detach())
+    def graph_key(self, epoch):
+        """whatever ``loss_step`` bakes into the captured step besides tensors (an epoch-dependent Python constant):
+        a new value means a new capture"""
+        return None
+
+    def _optimise_graph(self, batch: dict, epoch):
+        if not getattr(self._optimizer, "capturable", False):
+            raise RuntimeError("Learner(graph=True) needs an optimiser whose step can be captured and whose hyper-parameters "
+                               "live on the device: stroke_prediction_amd.optim.FusedAdam(..., capturable=True)")
+        dev = next(self._model.parameters()).device
+        tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        key = (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())), self.graph_key(epoch))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            g = self._graphs[key] = dict(static={k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in tensors.items()},
+                                         warm=0, graph=None, dto=None, loss=None)
+        for k, v in tensors.items():
+            g["static"][k].copy_(v, non_blocking=True)
+        sbatch = dict(batch)
+        sbatch.update(g["static"])
+        if g["graph"] is None:
+            if g["warm"] < self.GRAPH_WARMUP:
+                g["warm"] += 1
+                return self._optimise(sbatch, epoch)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: an RCCL watchdog thread may query events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                g["dto"], g["loss"] = self._optimise(sbatch, epoch)
+            g["graph"] = graph
+        if hasattr(self._optimizer, "push_hyper"):
+            self._optimizer.push_hyper()          # lr / betas as the schedulers left them
+        g["graph"].replay()
+        return g["dto"], g["loss"]
+
+    def train_batch(self, batch: dict, epoch) -> MetricMeasuresDto:
+        dto, loss = self._optimise_graph(batch, epoch) if self._graph_enabled else self._optimise(batch, epoch)
+
+        batch_metrics = self.batch_metrics_step(dto, epoch) if self._batch_metrics else MetricMeasuresDtoInit.init_dto(*([0.0] * 13))
+        batch_metrics.loss = float(loss.detach()) if self._sync_loss else loss.detach().clone()
         return batch_metrics
 
     def validate_batch(self, batch: dict, epoch) -> MetricMeasuresDto:
         with torch.no_grad():
             dto = self.inference_step(batch)
             loss = self.loss_step(dto, epoch)
-        batch_metrics = self.batch_metrics_step(dto, epoch)
+        batch_metrics = self.batch_metrics_step(dto, epoch) if self._batch_metrics else MetricMeasuresDtoInit.init_dto(*([0.0] * 13))
         batch_metrics.loss = float(loss.detach())
         return batch_metrics
 
@@ -164,6 +250,8 @@ class Learner(Inference):
         for batch in loader:
             acc.add(step_fn(batch, epoch))
         acc.div(len(loader))
+        if torch.is_tensor(acc.loss):        # sync_loss=False: one host round trip per epoch
+            acc.loss = float(acc.loss)
         return acc
 
     def run_training(self):

@@ -13,9 +13,9 @@ class UnetSegmentationLearner(Learner, UnetInference):
 
     def __init__(self, dataloader_training, dataloader_validation, unet_model, optimizer, scheduler, n_epochs,
                  criterion, path_previous_base=None, path_outputs_base='/tmp/unet-segmentation',
-                 surface_metrics=True):
+                 surface_metrics=True, **learner_kw):
         Learner.__init__(self, dataloader_training, dataloader_validation, unet_model, optimizer, scheduler,
-                         n_epochs, path_previous_base, path_outputs_base)
+                         n_epochs, path_previous_base, path_outputs_base, **learner_kw)
         UnetInference.__init__(self, unet_model)
         self._criterion = criterion
         self._surface_metrics = surface_metrics

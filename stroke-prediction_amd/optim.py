@@ -54,8 +54,14 @@ class FusedAdam(Optimizer):
             # flat aliases of the parameter / gradient storage (torch owns the memory)
             pf = torch.as_strided(ps[0].data, (n,), (1,))
             gf = torch.as_strided(ps[0].grad, (n,), (1,))
+            # step count: carried over from the flat group this one replaces (re-flatten after .cpu()/.cuda(): the
+            # device counter is the truth in capturable mode), else from the per-parameter state
+            step0 = int(self.state[ps[0]].get("step", 0))
+            if st is not None and self.capturable:
+                step0 = max(step0, int(st["step_dev"].item()))
             st = dict(key=key, p=pf, g=gf, m=m, v=v,
-                      step_dev=torch.full((1,), int(self.state[ps[0]].get("step", 0)), dtype=torch.int32, device=dev))
+                      step_dev=torch.full((1,), step0, dtype=torch.int32, device=dev),
+                      lr_dev=torch.zeros(8, dtype=torch.float32, device=dev), hyper=None)
             self._flat[gi] = st
         return st
 
@@ -71,10 +77,13 @@ class FusedAdam(Optimizer):
             st = self._flat_group(gi, group)
             if st is not None and self.capturable:
                 from stroke_prediction_amd.runtime import lib as L
+                # hyper-parameters live in device memory: while a hipGraph is being captured nothing is copied (a
+                # captured copy would freeze today's values); ``push_hyper`` refreshes them before each replay
+                if not torch.cuda.is_current_stream_capturing():
+                    self._push_hyper(st, group)
                 st["step_dev"].add_(1)
-                L.call("sp_adam_step_flat_dev", O.ptr(st["p"]), O.ptr(st["g"]), O.ptr(st["m"]), O.ptr(st["v"]),
-                       st["p"].numel(), group["lr"], b1, b2, group["eps"], group["weight_decay"], O.ptr(st["step_dev"]),
-                       self.grad_scale, O.stream())
+                L.call("sp_adam_step_flat_hyp", O.ptr(st["p"]), O.ptr(st["g"]), O.ptr(st["m"]), O.ptr(st["v"]),
+                       st["p"].numel(), O.ptr(st["lr_dev"]), O.ptr(st["step_dev"]), self.grad_scale, O.stream())
                 continue
             if st is not None:
                 step = int(self.state[group["params"][0]]["step"]) + 1
@@ -97,6 +106,40 @@ class FusedAdam(Optimizer):
                 O.adam_step_flat(p.data, p.grad.contiguous(), s["exp_avg"], s["exp_avg_sq"], group["lr"], b1, b2,
                                  group["eps"], group["weight_decay"], s["step"], self.grad_scale)
         return loss
+
+    @staticmethod
+    def _push_hyper(st, group):
+        hyp = (float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+               float(group["weight_decay"]))
+        if st["hyper"] != hyp:
+            st["lr_dev"].copy_(torch.tensor(hyp + (0.0,) * (st["lr_dev"].numel() - 5), dtype=torch.float32), non_blocking=False)
+            st["hyper"] = hyp
+
+    def push_hyper(self):
+        """capturable mode: copy lr / betas / eps / weight_decay of every flat group to the device if they changed
+        (schedulers and ``adapt_betas`` edit ``param_groups`` on the host).  Call before replaying a captured step."""
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi)
+            if st is not None:
+                self._push_hyper(st, group)
+
+    def state_dict(self):
+        """torch.optim.Adam layout; the step count of capturable mode lives on the device and is read back first."""
+        if self.capturable:
+            self.sync_step_from_device()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """The loaded exp_avg / exp_avg_sq / step replace the flat moments: drop the flat groups so that the next
+        step re-adopts them from ``self.state`` (the cache key alone -- parameter addresses -- would not change)."""
+        out = super().load_state_dict(state_dict)
+        self._flat = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                s = self.state.get(p)
+                if s is not None and "step" in s and torch.is_tensor(s["step"]):
+                    s["step"] = int(s["step"].item())
+        return out
 
     def sync_step_from_device(self):
         """capturable mode: copy the device step counters into the per-parameter state (before state_dict())."""

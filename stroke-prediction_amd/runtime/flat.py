@@ -8,6 +8,11 @@ kernel (``sp_adam_step_flat``) and of the single RCCL all-reduce in data-paralle
 import torch
 
 
+def _bump_epoch():
+    from . import ops
+    ops.bump_param_epoch()
+
+
 class FlatParamsMixin:
     _flat_param = None
     _flat_grad = None
@@ -21,6 +26,12 @@ class FlatParamsMixin:
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._flat_param = None       # .cuda()/.cpu()/.float() re-created the storages: re-flatten lazily
+        _bump_epoch()                 # packed weight fragments keyed on the old storages are stale
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        _bump_epoch()                 # (copy_ under no_grad bumps the version counters too; belt and braces)
         return out
 
     def _flat_root(self):
@@ -69,8 +80,11 @@ class FlatParamsMixin:
                     mod._flat_nbt = nbt
 
     def _param_dict(self):
+        """name -> tensor sharing the Parameter's storage AND its version counter (``p.detach()``; ``p.data`` always
+        reports ``_version == 0``): the conv runners key their packed-weight caches on (data_ptr, _version), so
+        ``load_state_dict``, ``torch.optim`` steps and in-place edits of a parameter all invalidate them."""
         self._ensure_flat()
-        return {n: p.data for n, p in self.named_parameters()}
+        return {n: p.detach() for n, p in self.named_parameters()}
 
     def _buffer_dict(self):
         self._ensure_flat()
@@ -101,9 +115,48 @@ class FlatParamsMixin:
             self._flat_grad.zero_()
         return self._flat_names, self._flat_views, inplace
 
+    # ---- data-parallel gradient exchange, bucketed in reverse layer order (parallel.DataParallelSync) --------------
+    # Backward fills the flat gradient buffer from its END (the last layers' parameters) towards its start.  The engine
+    # reports "everything from the first parameter named <prefix>* to the end of what is still pending is final"
+    # (_grads_ready_from); the installed ``grad_bucket_ready(flat_grad, lo, hi)`` starts an asynchronous all-reduce of
+    # that slice on the communication stream while the remaining data / weight gradients are computed, and
+    # ``grad_sync(flat_grad, lo, hi)`` (end of backward) reduces the rest and waits for the buckets.
+    grad_bucket_ready = None
+    _bucket_hi = None
+    _grads_synced = False
+
+    def _flat_offset_of(self, prefix):
+        off = 0
+        for n, p in self.named_parameters():
+            if n.startswith(prefix):
+                return off
+            off += p.numel()
+        raise KeyError(prefix)
+
+    def _grads_ready_from(self, prefix):
+        root = self._flat_root()
+        if root.grad_bucket_ready is None or root.grad_sync is None:
+            return
+        total = root._flat_grad.numel()
+        hi = total if root._bucket_hi is None else root._bucket_hi
+        lo = root._flat_offset_of(prefix)
+        if lo < hi:
+            root.grad_bucket_ready(root._flat_grad, lo, hi)
+            root._bucket_hi = lo
+
     def _after_backward(self):
-        if self.grad_sync is not None:
-            self.grad_sync(self._flat_grad)
+        root = self._flat_root()
+        if root.grad_sync is not None and not root._grads_synced:
+            hi = root._flat_grad.numel() if root._bucket_hi is None else root._bucket_hi
+            root.grad_sync(root._flat_grad, 0, hi)
+            root._bucket_hi = None
+            root._grads_synced = True
+
+    def _begin_step(self):
+        """a grad-enabled forward starts a new exchange round"""
+        root = self._flat_root()
+        root._grads_synced = False
+        root._bucket_hi = None
 
     def flat_buffers(self):
         self._ensure_flat()

@@ -85,6 +85,7 @@ _SIGS = {
     "sp_lerp_batch": ([vp, vp, vp, vp, i32, i32, i64, vp], i32),
     "sp_adam_step_flat": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp], i32),
     "sp_adam_step_flat_dev": ([vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, f32, vp], i32),
+    "sp_adam_step_flat_hyp": ([vp, vp, vp, vp, i64, vp, vp, f32, vp], i32),
 }
 EXPORTS = sorted(list(_SIGS) + ["sp_last_error"])
 

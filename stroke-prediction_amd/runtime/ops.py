@@ -272,9 +272,18 @@ class ConvRunner:
                 a.persist, a.ktab, a.ITH_zs = 3, ptr(s["ktab_zs"]), t["ITH_zs"]     # z-marching ring variant
                 if s.get("ktab_zr") is not None and not x_planar:
                     a.persist, a.ktab, a.wfrag_hi = 4, ptr(s["ktab_zr"]), ptr(s["hi_zr"])   # ... with row reuse
-            with _Timed("conv_igemm", 2 * batch * int(np.prod(sub.out_dims)) * len(sub.taps) * op.cin * op.cout,
+            # algorithmic FLOPs (plan.ConvOp.algo_macs), shared among the sub-convolutions by the work each issues
+            share = int(np.prod(sub.out_dims)) * len(sub.taps) / max(1, op.issued_macs())
+            with _Timed("conv_igemm", op.flops(batch) * share,
                         "%d->%d @%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_igemm", C.byref(a), st)
+
+
+def wgrad_dma_ok(cpi, cpo, dtype):
+    """channel-tile limits of the DMA weight-gradient kernel (64-wide outputs: the register-staged kernel measured faster)"""
+    return bool(USE_DMA and dtype == L.SP_BF16 and cpi % 16 == 0 and cpo % 16 == 0
+                and -(-cpo // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "4"))
+                and -(-cpi // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))
 
 
 class WgradRunner:
@@ -407,9 +416,16 @@ def prep_batch(pairs):
             todo.append((r, w, key))
     if not todo:
         return
-    tkey = tuple((id(r._st), w.data_ptr()) for r, w, _ in todo)
+    # the cached device table holds raw addresses only: key it on every address it contains, so an entry can only be
+    # replayed for runners that own exactly those buffers (ids / addresses recycled after an engine was freed)
+    tkey = tuple((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, r.op.nttot) +
+                 tuple((sub["kmap"].data_ptr(), sub["nsteps"], sub["hi"].data_ptr(), 0 if sub["lo"] is None else sub["lo"].data_ptr(),
+                        0 if sub.get("ktab_zr") is None else sub["hi_zr"].data_ptr()) for sub in r.subs)
+                 for r, w, _ in todo)
     tab = _prep_tables.get(tkey)
     if tab is None:
+        if len(_prep_tables) > 64:
+            _prep_tables.clear()
         items = []
         for r, w, _ in todo:
             assert w.dtype == torch.float32 and w.is_contiguous()

@@ -72,12 +72,16 @@ class ConvOp:
     dtype: int = 0
     nt: int = 1
     nttot: int = 1
+    algo_macs: int = 0           # ALGORITHMIC multiply-accumulates per sample and (cin, cout) pair: voxels x taps of the
+                                 # convolution this op belongs to (a data gradient counts the forward's output voxels, not
+                                 # the zero-padded taps its dense sub-convolutions run over)
 
     def flops(self, batch):
-        n = 0
-        for s in self.subs:
-            n += 2 * batch * int(np.prod(s.out_dims)) * len(s.taps) * self.cin * self.cout
-        return n
+        """algorithmic FLOPs of one launch set (2 x 27 x Cin x Cout per output voxel of the convolution)"""
+        return 2 * batch * self.algo_macs * self.cin * self.cout
+
+    def issued_macs(self):
+        return sum(int(np.prod(s.out_dims)) * len(s.taps) for s in self.subs)
 
 
 def _triple(v):
@@ -92,7 +96,7 @@ def conv_fwd_op(cin, cout, k, stride, pad, in_dims, cpi, cpo, dtype=0):
     taps = [(a, b, c, (a * k[1] + b) * k[2] + c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])]
     kk = k[0] * k[1] * k[2]
     sub = SubConv(taps, tuple(-x for x in p), out)
-    return _finish(ConvOp(cin, cout, cpi, cpo, tuple(in_dims), out, s, cin * kk, kk, [sub], dtype))
+    return _finish(ConvOp(cin, cout, cpi, cpo, tuple(in_dims), out, s, cin * kk, kk, [sub], dtype, algo_macs=int(np.prod(out)) * kk))
 
 
 def _transposed_subs(k, s, p, in_dims, y_dims):
@@ -136,7 +140,8 @@ def conv_dgrad_op(cin, cout, k, stride, pad, in_dims, cp_dz, cp_g, dtype=0, cin_
     kk = k[0] * k[1] * k[2]
     subs = _transposed_subs(k, s, p, out, tuple(in_dims))
     # roles swap: "cout" of this op is the conv's cin.  element (co'=ci, ci'=co, tap) = w[co, ci, tap]
-    return _finish(ConvOp(cout, cin, cp_dz, cp_g, out, tuple(in_dims), (1, 1, 1), kk, (cin_total or cin) * kk, subs, dtype))
+    return _finish(ConvOp(cout, cin, cp_dz, cp_g, out, tuple(in_dims), (1, 1, 1), kk, (cin_total or cin) * kk, subs, dtype,
+                          algo_macs=int(np.prod(out)) * kk))
 
 
 def convT_fwd_op(cin, cout, k, stride, pad, in_dims, cpi, cpo, dtype=0):
@@ -145,7 +150,8 @@ def convT_fwd_op(cin, cout, k, stride, pad, in_dims, cpi, cpo, dtype=0):
     y = tuple((in_dims[a] - 1) * s[a] - 2 * p[a] + k[a] for a in range(3))
     kk = k[0] * k[1] * k[2]
     subs = _transposed_subs(k, s, p, tuple(in_dims), y)
-    return _finish(ConvOp(cin, cout, cpi, cpo, tuple(in_dims), y, (1, 1, 1), kk, cout * kk, subs, dtype))
+    return _finish(ConvOp(cin, cout, cpi, cpo, tuple(in_dims), y, (1, 1, 1), kk, cout * kk, subs, dtype,
+                          algo_macs=min(int(np.prod(in_dims)) * kk, sum(int(np.prod(sb.out_dims)) * len(sb.taps) for sb in subs))))
 
 
 def convT_dgrad_op(cin, cout, k, stride, pad, in_dims, cp_dz, cp_g, dtype=0):
@@ -157,7 +163,8 @@ def convT_dgrad_op(cin, cout, k, stride, pad, in_dims, cp_dz, cp_g, dtype=0):
     taps = [(a, b, c, (a * k[1] + b) * k[2] + c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])]
     sub = SubConv(taps, tuple(-x for x in p), tuple(in_dims))
     # op "cout" = convT cin ; element (co'=ci, ci'=co, tap) = w[ci, co, tap]
-    return _finish(ConvOp(cout, cin, cp_dz, cp_g, y, tuple(in_dims), s, cout * kk, kk, [sub], dtype))
+    return _finish(ConvOp(cout, cin, cp_dz, cp_g, y, tuple(in_dims), s, cout * kk, kk, [sub], dtype,
+                          algo_macs=min(int(np.prod(in_dims)) * kk, int(np.prod(y)) * kk)))
 
 
 # ------------------------------------------------------------------------------------------------ tiling

@@ -1,10 +1,11 @@
-"""Forward / backward of the 3-scale 3-D U-Net (``Unet3D.forward`` Unet3D.py:56-79) on HIP kernels.
+"""Forward / backward of the 3-D U-Net (``Unet3D.forward`` Unet3D.py:56-79; 4-scale topology Unet3D.py:95-146) on HIP kernels.
 
 Data flow (channels-last tensors, BatchNorm folded into the consuming convolution's load):
 
   x0 -b1c1-> y11 -b1c2-> y12 -pool-> p1 -b2c1-> y21 -b2c2-> y22 -pool-> p2 -b3c1-> y31 -b3c2-> y32
   cat4 = [up(y32) | crop(y22)] -b4c1-> y41 -b4c2-> y42 ; cat5 = [up(y42) | crop(y12)] -b5c1-> y51 -b5c2-> y52
   y52 -1x1,lrelu-> h -1x1,sigmoid-> seg
+(three scales; the engine is written for S scales: blocks 1..S down, S+1..2S-1 up -- S = 4 is the LargeUnet3D topology)
 
 Batch statistics of every BatchNorm input are produced by the kernel that writes that tensor
 (conv / pool / upsample / crop epilogues); only the network input needs a stand-alone pass.
@@ -20,28 +21,47 @@ from .layers import ConvLayer, FirstConvLayer, Scratch
 LEAKY = 0.01
 
 
-def unet_out_dims(dims):
+def unet_out_dims(dims, scales=3):
+    """Appendix B of SURVEY.md: per axis, every block loses 4 voxels (two valid 3x3x3 convolutions), pooling halves
+    (floor), upsampling doubles.  scales = 3: 128 -> 88; scales = 4: 256 -> 164.  Raises for inputs too small."""
     out = []
     for n in dims:
-        b3 = ((n - 4) // 2 - 4) // 2 - 4
-        out.append(4 * b3 - 12)
+        m = n
+        for _ in range(scales - 1):
+            m = (m - 4) // 2
+        m -= 4
+        if m < 1:
+            raise ValueError("Unet3D: spatial size %s is too small for %d scales of valid 3x3x3 convolutions" % (tuple(dims), scales))
+        for _ in range(scales - 1):
+            m = 2 * m - 4
+        if m < 1:
+            raise ValueError("Unet3D: spatial size %s is too small for %d scales of valid 3x3x3 convolutions" % (tuple(dims), scales))
+        out.append(m)
     return tuple(out)
 
 
 class UnetEngine:
-    """Bound to one (batch, spatial size, dtype); the model keeps a small cache of engines."""
+    """Bound to one (batch, spatial size, dtype); the model keeps a small cache of engines.
+
+    channels = [n_in, b_1 .. b_{2S-1}, b_C, n_classes] for S scales: S = 3 is ``Unet3D`` (Unet3D.py:30-84, 8 numbers),
+    S = 4 the topology of ``LargeUnet3D`` (Unet3D.py:87-146, 10 numbers).  Blocks 1..S go down (pool between them),
+    blocks S+1..2S-1 go up; up block u concatenates the upsampled output of block u-1 with the centre crop of down
+    block 2S-u."""
 
     def __init__(self, channels, batch, dims, dtype, device):
         O.require_gpu()
         L.load()
-        n_in, b1, b2, b3, b4, b5, bc, ncls = channels
+        assert len(channels) >= 8 and len(channels) % 2 == 0, "channels: n_in, 2S-1 block widths, head width, classes"
+        S = self.scales = (len(channels) - 2) // 2
+        n_in, bch, bc, ncls = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
         assert ncls <= 8, "the classify head supports up to 8 classes"
         self.channels, self.batch, self.dims, self.dtype, self.device = list(channels), batch, tuple(dims), dtype, device
-        for n in dims:
-            b3d = ((n - 4) // 2 - 4) // 2 - 4
-            if b3d < 1 or 4 * b3d - 12 < 1:
-                raise ValueError("Unet3D: spatial size %s is too small for three scales of valid 3x3x3 "
-                                 "convolutions (minimum 44 per axis)" % (tuple(dims),))
+        try:
+            unet_out_dims(dims, S)
+        except ValueError:
+            raise ValueError("Unet3D: spatial size %s is too small for %s scales of valid 3x3x3 "
+                             "convolutions (minimum %d per axis)" % (tuple(dims), {3: "three", 4: "four"}.get(S, S),
+                                                                    {3: 44, 4: 92}.get(S, 0)))
         self.scratch = sc = Scratch(device)
         mk = lambda name, ci, co, d, bn=True, k=3, act=L.ACT_LEAKY, ap=LEAKY, out_dtype=None, blk=None, idx=None, \
             need_g=True, cpi=None, split=None: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc,
@@ -52,115 +72,128 @@ class UnetEngine:
         sub = lambda d, k: tuple(x - k for x in d)
         half = lambda d: tuple(x // 2 for x in d)
         dbl = lambda d: tuple(2 * x for x in d)
-        d0 = self.dims
+        # conv[i] = (first, second) convolution of block i (1-based); dims_in[i] = input dims of block i
+        self.conv, self.dims_in = {}, {}
+        d = self.dims
+        b1 = bch[0]
         # the network input gets a 16-channel pitch (not 8): every 3x3x3 layer then meets the 16-channel plane
         # granularity of the DMA weight-gradient kernel
         self.first_packed = FirstConvLayer.supported(n_in, b1, 3, 1, 0, dtype, True) and not os.environ.get("SP_GENERIC_FIRST")
-        if self.first_packed:   # two-channel input: packed-K kernels reading the NCDHW fp32 input directly
-            self.c11 = FirstConvLayer("b1c1", "conv", n_in, b1, 3, 1, 0, d0, batch, dtype, device, sc,
-                                      bn_prefix="block1.bn_conv_relu_2x.0", conv_prefix="block1.bn_conv_relu_2x.1",
-                                      act=L.ACT_LEAKY, act_param=LEAKY, need_input_grad=False, cpi=O.cpad(n_in, 16))
-        else:
-            self.c11 = mk("b1c1", n_in, b1, d0, blk="block1", idx=0, need_g=False, cpi=O.cpad(n_in, 16))
-        self.c12 = mk("b1c2", b1, b1, sub(d0, 2), blk="block1", idx=3)
-        d12 = sub(d0, 4)
-        dp1 = half(d12)
-        self.c21 = mk("b2c1", b1, b2, dp1, blk="block2", idx=0)
-        self.c22 = mk("b2c2", b2, b2, sub(dp1, 2), blk="block2", idx=3)
-        d22 = sub(dp1, 4)
-        dp2 = half(d22)
-        self.c31 = mk("b3c1", b2, b3, dp2, blk="block3", idx=0)
-        self.c32 = mk("b3c2", b3, b3, sub(dp2, 2), blk="block3", idx=3)
-        d32 = sub(dp2, 4)
-        dc4 = dbl(d32)
-        assert b3 % 8 == 0 and b4 % 8 == 0, "up-path channel counts must be multiples of 8"
+        for i in range(1, S + 1):                       # ---- down path
+            ci = n_in if i == 1 else bch[i - 2]
+            co = bch[i - 1]
+            self.dims_in[i] = d
+            if i == 1 and self.first_packed:   # two-channel input: packed-K kernels reading the NCDHW fp32 input directly
+                c1 = FirstConvLayer("b1c1", "conv", n_in, b1, 3, 1, 0, d, batch, dtype, device, sc,
+                                    bn_prefix="block1.bn_conv_relu_2x.0", conv_prefix="block1.bn_conv_relu_2x.1",
+                                    act=L.ACT_LEAKY, act_param=LEAKY, need_input_grad=False, cpi=O.cpad(n_in, 16))
+            else:
+                c1 = mk("b%dc1" % i, ci, co, d, blk="block%d" % i, idx=0, need_g=(i > 1), cpi=O.cpad(ci, 16) if i == 1 else None)
+            c2 = mk("b%dc2" % i, co, co, sub(d, 2), blk="block%d" % i, idx=3)
+            self.conv[i] = (c1, c2)
+            d = sub(d, 4)
+            if i < S:
+                d = half(d)
         split_ok = lambda cu, cs: cu if (256 % (cu // 8) == 0 and cu % 16 == 0 and cs % 16 == 0 and os.environ.get("SP_SPLIT_G")) else None   # measured: two data-gradient launches cost more (+45 us) than the dense reads save -> opt-in
-        self.c41 = mk("b4c1", b3 + b2, b4, dc4, blk="block4", idx=0, split=split_ok(b3, O.cpad(b2)))
-        self.c42 = mk("b4c2", b4, b4, sub(dc4, 2), blk="block4", idx=3)
-        d42 = sub(dc4, 4)
-        dc5 = dbl(d42)
-        self.c51 = mk("b5c1", b4 + b1, b5, dc5, blk="block5", idx=0, split=split_ok(b4, O.cpad(b1)))
-        self.c52 = mk("b5c2", b5, b5, sub(dc5, 2), blk="block5", idx=3)
-        d52 = sub(dc5, 4)
-        self.h0 = mk("classify.0", b5, bc, d52, bn=False, k=1)
-        self.h2 = mk("classify.2", bc, ncls, d52, bn=False, k=1, act=L.ACT_SIGMOID, ap=0.0, out_dtype=L.SP_F32)
-        self.out_dims = d52
+        for u in range(S + 1, 2 * S):                   # ---- up path: d = output dims of block u-1
+            cu, cs, co = bch[u - 2], bch[2 * S - u - 1], bch[u - 1]
+            assert cu % 8 == 0, "up-path channel counts must be multiples of 8"
+            d = dbl(d)
+            self.dims_in[u] = d
+            c1 = mk("b%dc1" % u, cu + cs, co, d, blk="block%d" % u, idx=0, split=split_ok(cu, O.cpad(cs)))
+            c2 = mk("b%dc2" % u, co, co, sub(d, 2), blk="block%d" % u, idx=3)
+            self.conv[u] = (c1, c2)
+            d = sub(d, 4)
+        self.out_dims = d
+        blast = bch[-1]
+        self.h0 = mk("classify.0", blast, bc, d, bn=False, k=1)
+        self.h2 = mk("classify.2", bc, ncls, d, bn=False, k=1, act=L.ACT_SIGMOID, ap=0.0, out_dtype=L.SP_F32)
         # fused pointwise head where a kernel exists for (C, CH, NC); the two generic 1x1 layers otherwise
-        self.fused_head = bool(L.load().sp_head_supported(b5, bc, ncls)) and b5 % 8 == 0 and not os.environ.get("SP_GENERIC_HEAD")
-        self.d12, self.dp1, self.d22, self.dp2, self.d32, self.dc4, self.d42, self.dc5 = d12, dp1, d22, dp2, d32, dc4, d42, dc5
-        self.layers = [self.c11, self.c12, self.c21, self.c22, self.c31, self.c32, self.c41, self.c42, self.c51,
-                       self.c52, self.h0, self.h2]
+        self.fused_head = bool(L.load().sp_head_supported(blast, bc, ncls)) and blast % 8 == 0 and not os.environ.get("SP_GENERIC_HEAD")
+        self.layers = [c for i in range(1, 2 * S) for c in self.conv[i]] + [self.h0, self.h2]
         for l in self.layers:
             l.reserve_bwd_scratch()
         sc.finalize()
         dt = dtype
-        self.x0 = None if self.first_packed else O.alloc_cl(batch, d0, self.c11.cpi, dt, device)
-        self.p1 = O.alloc_cl(batch, dp1, O.cpad(b1), dt, device)
-        self.p2 = O.alloc_cl(batch, dp2, O.cpad(b2), dt, device)
-        self.cat4 = O.alloc_cl(batch, dc4, b3 + O.cpad(b2), dt, device)
-        self.cat5 = O.alloc_cl(batch, dc5, b4 + O.cpad(b1), dt, device)
-        assert self.cat4.shape[-1] == self.c41.cpi and self.cat5.shape[-1] == self.c51.cpi
+        c11 = self.conv[1][0]
+        self.x0 = None if self.first_packed else O.alloc_cl(batch, self.dims, c11.cpi, dt, device)
+        self.pooled = {i: O.alloc_cl(batch, self.dims_in[i + 1], O.cpad(bch[i - 1]), dt, device) for i in range(1, S)}
+        self.cat = {u: O.alloc_cl(batch, self.dims_in[u], bch[u - 2] + O.cpad(bch[2 * S - u - 1]), dt, device) for u in range(S + 1, 2 * S)}
+        for u in range(S + 1, 2 * S):
+            assert self.cat[u].shape[-1] == self.conv[u][0].cpi
         self.ncls = ncls
-        # plane-major concat buffers when both consumers of each are the DMA kernels (bf16, folded BatchNorm)
-        self.cat_planar = bool(O.CAT_PLANAR and O.BN_SUMS_FROM_WGRAD and O.USE_DMA and dtype == L.SP_BF16 and self.c41.fold and self.c51.fold
-                               and self.cat4.shape[-1] % 16 == 0 and self.cat5.shape[-1] % 16 == 0)
-        self.c41.x_planar = self.c51.x_planar = self.cat_planar
+        # plane-major concat buffers where both consumers of one are the DMA kernels (bf16, folded BatchNorm, channel
+        # counts within the DMA weight-gradient kernel's tile limits): decided per up block
+        self.cat_planar = {}
+        for u in range(S + 1, 2 * S):
+            c = self.conv[u][0]
+            self.cat_planar[u] = bool(O.CAT_PLANAR and O.BN_SUMS_FROM_WGRAD and O.USE_DMA and dtype == L.SP_BF16 and c.fold
+                                      and self.cat[u].shape[-1] % 16 == 0 and O.wgrad_dma_ok(c.cpi, c.cpo, dtype)
+                                      and all(sb.tile["opp"] == 2 for sb in c.fwd_op.subs))
+            c.x_planar = self.cat_planar[u]
+        self.generation = 0         # bumped by every forward: a backward checks that its pass is still the resident one
+
+    # legacy names of the 3-scale engine (tools/)
+    def __getattr__(self, name):
+        if len(name) == 3 and name[0] == "c" and name[1:].isdigit() and "conv" in self.__dict__:
+            i, j = int(name[1]), int(name[2])
+            if i in self.conv and j in (1, 2):
+                return self.conv[i][j - 1]
+        raise AttributeError(name)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, images, params, bufs, training):
         """images: (B, n_in, D, H, W) fp32 on the device.  Returns seg (B, n_classes, D', H', W') fp32."""
-        B, dt = self.batch, self.dtype
+        B, dt, S = self.batch, self.dtype, self.scales
         assert tuple(images.shape) == (B, self.channels[0]) + self.dims and images.dtype == torch.float32
         images = images.contiguous()
+        self.generation += 1
         self.scratch.zero()
         if training and "__nbt_flat__" in bufs:
             bufs["__nbt_flat__"].add_(1)
         st = (lambda l: l.in_sums) if training else (lambda l: None)
+        c11 = self.conv[1][0]
         if self.first_packed:
             self.x0 = images                  # the packed first-layer kernels read the NCDHW fp32 input itself
             if training:
-                self.c11.input_stats(images)
+                c11.input_stats(images)
         else:
             O.ncdhw_to_cl(images, self.x0, dt)
             if training:
-                O.bn_stats(self.x0, dt, self.c11.in_sums)
-        y11 = self.c11.forward(self.x0, params, bufs, training, st(self.c12))
-        y12 = self.c12.forward(y11, params, bufs, training)
-        O.maxpool2_fwd(y12, self.p1, dt, st(self.c21))
-        y21 = self.c21.forward(self.p1, params, bufs, training, st(self.c22))
-        y22 = self.c22.forward(y21, params, bufs, training)
-        O.maxpool2_fwd(y22, self.p2, dt, st(self.c31))
-        y31 = self.c31.forward(self.p2, params, bufs, training, st(self.c32))
-        y32 = self.c32.forward(y31, params, bufs, training)
-        c3 = self.channels[3]
-        s4 = st(self.c41)
-        O.upsample2_crop_cat_fwd(y32, y22, self.cat4, dt, s4, planar=self.cat_planar)
-        y41 = self.c41.forward(self.cat4, params, bufs, training, st(self.c42))
-        y42 = self.c42.forward(y41, params, bufs, training)
-        c4 = self.channels[4]
-        s5 = st(self.c51)
-        O.upsample2_crop_cat_fwd(y42, y12, self.cat5, dt, s5, planar=self.cat_planar)
-        y51 = self.c51.forward(self.cat5, params, bufs, training, st(self.c52))
-        y52 = self.c52.forward(y51, params, bufs, training)
+                O.bn_stats(self.x0, dt, c11.in_sums)
+        x = self.x0
+        for i in range(1, S + 1):
+            c1, c2 = self.conv[i]
+            y1 = c1.forward(x, params, bufs, training, st(c2))
+            y2 = c2.forward(y1, params, bufs, training)
+            if i < S:
+                O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]))
+                x = self.pooled[i]
+        low = y2
+        for u in range(S + 1, 2 * S):
+            c1, c2 = self.conv[u]
+            O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u])
+            y1 = c1.forward(self.cat[u], params, bufs, training, st(c2))
+            low = c2.forward(y1, params, bufs, training)
         seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
-            L.call("sp_head_fwd", O.ptr(y52), dt, nv, B, y52.shape[-1], self.channels[5], O.ptr(params["classify.0.weight"]),
-                   O.ptr(params["classify.0.bias"]), self.channels[6], O.ptr(params["classify.2.weight"]),
+            L.call("sp_head_fwd", O.ptr(low), dt, nv, B, low.shape[-1], self.channels[-3], O.ptr(params["classify.0.weight"]),
+                   O.ptr(params["classify.0.bias"]), self.channels[-2], O.ptr(params["classify.2.weight"]),
                    O.ptr(params["classify.2.bias"]), self.ncls, LEAKY, O.ptr(seg), O.stream())
             return seg
-        h = self.h0.forward(y52, params, bufs, training)
+        h = self.h0.forward(low, params, bufs, training)
         o = self.h2.forward(h, params, bufs, training)
         O.cl_to_ncdhw(o, seg, L.SP_F32)
         return seg
 
-    def _up_bwd(self, low, cat, g, coef):
+    def _up_bwd(self, low, cat, g, coef, planar):
         """gradient of the upsampled half of a concat input -> dz of the low-resolution producer `low`"""
         dt = self.dtype
         if isinstance(g, tuple):      # dense per-part gradient tensors (ConvLayer split_g)
             O.upsample2_act_bwd(low.y, None, g[0], coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums, coef_stride=cat.shape[-1])
         else:
-            O.upsample2_act_bwd(low.y, None if self.cat_planar else cat, g, coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums)
+            O.upsample2_act_bwd(low.y, None if planar else cat, g, coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums)
 
     def _skip_bwd(self, prod, gp, coefp, cat, g, coef, c_up):
         """pool gradient + skip half of the concat gradient -> dz of the block output `prod`"""
@@ -172,15 +205,17 @@ class UnetEngine:
             O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums)
 
     # ------------------------------------------------------------------------------------------ backward
-    def backward(self, dseg, seg, params, grads):
+    def backward(self, dseg, seg, params, grads, ready=None):
         """dseg: dL/dseg (NCDHW fp32).  Accumulates into ``grads[name]`` (fp32 tensors, parameter layout).
-        Must follow a training-mode forward on the same engine (activations are kept in the layers)."""
-        dt = self.dtype
+        Must follow a training-mode forward on the same engine (activations are kept in the layers).
+        ready(prefix): called when every gradient from the first parameter named ``prefix*`` to the end of the flat
+        buffer is final (data-parallel buckets, runtime/flat.py)."""
+        dt, S = self.dtype, self.scales
         for l in self.layers:
             if not (self.fused_head and l in (self.h0, self.h2)):
                 l._init_bwd()
-        c = self
         dseg = dseg.contiguous()
+        last = self.conv[2 * S - 1][1]
         # all data-gradient weight re-packs depend on the parameters only: side stream, beside the head's backward
         pre = O.fork()
         with pre:      # ... and ONE launch for all of them
@@ -188,45 +223,48 @@ class UnetEngine:
                           if getattr(l, "dgrad", None) is not None and l.need_input_grad])
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
-            b5, bc, ncls = self.channels[5], self.channels[6], self.ncls
+            b5, bc, ncls = self.channels[-3], self.channels[-2], self.ncls
             lib = L.load()
             rows = lib.sp_head_bwd_rows(self.batch * nv)
             if getattr(self, "_hpart", None) is None:
                 self._hpart = torch.empty(rows * lib.sp_head_row_floats(b5, bc, ncls), dtype=torch.float32, device=self.device)
-            L.call("sp_head_bwd", O.ptr(c.c52.y), dt, nv, self.batch, c.c52.y.shape[-1], b5,
+            L.call("sp_head_bwd", O.ptr(last.y), dt, nv, self.batch, last.y.shape[-1], b5,
                    O.ptr(params["classify.0.weight"]), O.ptr(params["classify.0.bias"]), bc,
                    O.ptr(params["classify.2.weight"]), ncls, LEAKY, O.ptr(seg), O.ptr(dseg), L.ACT_LEAKY, LEAKY,
-                   O.ptr(c.c52.dz), O.ptr(self._hpart), O.stream())
+                   O.ptr(last.dz), O.ptr(self._hpart), O.stream())
             L.call("sp_head_grad_finish", O.ptr(self._hpart), rows, b5, bc, ncls, O.ptr(grads["classify.0.weight"]),
                    O.ptr(grads["classify.0.bias"]), O.ptr(grads["classify.2.weight"]), O.ptr(grads["classify.2.bias"]),
-                   O.ptr(c.c52.dbias_sums), O.stream())
+                   O.ptr(last.dbias_sums), O.stream())
         else:
             # output side: dz of the last 1x1 conv = dseg * sigmoid'(seg)
-            O.out_grad_to_cl(dseg, seg, dt, L.ACT_SIGMOID, 0.0, c.h2.dz, c.h2.dbias_sums)
-            g, _ = c.h2.backward(c.h0.y, params, grads)
-            O.bn_act_bwd(g, c.h0.y, None, dt, L.ACT_LEAKY, LEAKY, c.h0.dz, c.h0.dbias_sums)
-            g, _ = c.h0.backward(c.c52.y, params, grads)
-            O.bn_act_bwd(g, c.c52.y, None, dt, L.ACT_LEAKY, LEAKY, c.c52.dz, c.c52.dbias_sums)
+            O.out_grad_to_cl(dseg, seg, dt, L.ACT_SIGMOID, 0.0, self.h2.dz, self.h2.dbias_sums)
+            g, _ = self.h2.backward(self.h0.y, params, grads)
+            O.bn_act_bwd(g, self.h0.y, None, dt, L.ACT_LEAKY, LEAKY, self.h0.dz, self.h0.dbias_sums)
+            g, _ = self.h0.backward(last.y, params, grads)
+            O.bn_act_bwd(g, last.y, None, dt, L.ACT_LEAKY, LEAKY, last.dz, last.dbias_sums)
         pre.join()
-        g, coef = c.c52.backward(c.c51.y, params, grads)
-        O.bn_act_bwd(g, c.c51.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c51.dz, c.c51.dbias_sums)
-        g5, coef5 = c.c51.backward(c.cat5, params, grads)
-        self._up_bwd(c.c42, c.cat5, g5, coef5)
-        g, coef = c.c42.backward(c.c41.y, params, grads)
-        O.bn_act_bwd(g, c.c41.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c41.dz, c.c41.dbias_sums)
-        g4, coef4 = c.c41.backward(c.cat4, params, grads)
-        self._up_bwd(c.c32, c.cat4, g4, coef4)
-        g, coef = c.c32.backward(c.c31.y, params, grads)
-        O.bn_act_bwd(g, c.c31.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c31.dz, c.c31.dbias_sums)
-        gp2, coefp2 = c.c31.backward(c.p2, params, grads)
-        self._skip_bwd(c.c22, gp2, coefp2, c.cat4, g4, coef4, self.channels[3])
-        g, coef = c.c22.backward(c.c21.y, params, grads)
-        O.bn_act_bwd(g, c.c21.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c21.dz, c.c21.dbias_sums)
-        gp1, coefp1 = c.c21.backward(c.p1, params, grads)
-        self._skip_bwd(c.c12, gp1, coefp1, c.cat5, g5, coef5, self.channels[4])
-        g, coef = c.c12.backward(c.c11.y, params, grads)
-        if self.first_packed and coef is not None and c.c11.cpo == 16:
-            c.c11.backward(c.x0, params, grads, g=g, coef=coef)     # dz formed inside the weight-gradient kernel
-        else:
-            O.bn_act_bwd(g, c.c11.y, coef, dt, L.ACT_LEAKY, LEAKY, c.c11.dz, c.c11.dbias_sums)
-            c.c11.backward(c.x0, params, grads)       # only the first BatchNorm's gamma/beta need this dgrad
+        skip = {}                     # down block index -> (concat buffer, its gradient, coefficients, channels of the upsampled part)
+        for u in range(2 * S - 1, S, -1):
+            c1, c2 = self.conv[u]
+            g, coef = c2.backward(c1.y, params, grads)
+            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)
+            gu, coefu = c1.backward(self.cat[u], params, grads)
+            if ready is not None and u == S + 1:     # every up block and the head are final: their all-reduce bucket may start
+                ready("block%d." % (S + 1))
+            self._up_bwd(self.conv[u - 1][1], self.cat[u], gu, coefu, self.cat_planar[u])
+            skip[2 * S - u] = (self.cat[u], gu, coefu, self.channels[u - 1])
+        for i in range(S, 0, -1):
+            c1, c2 = self.conv[i]
+            g, coef = c2.backward(c1.y, params, grads)
+            if i > 1:
+                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)
+                gp, coefp = c1.backward(self.pooled[i - 1], params, grads)
+                if ready is not None and i == 2:
+                    ready("block2.")
+                cat, gu, coefu, c_up = skip[i - 1]
+                self._skip_bwd(self.conv[i - 1][1], gp, coefp, cat, gu, coefu, c_up)
+            elif self.first_packed and coef is not None and c1.cpo == 16:
+                c1.backward(self.x0, params, grads, g=g, coef=coef)     # dz formed inside the weight-gradient kernel
+            else:
+                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)
+                c1.backward(self.x0, params, grads)       # only the first BatchNorm's gamma/beta need this dgrad

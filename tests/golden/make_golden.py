@@ -59,16 +59,32 @@ def grads_summary(named):
     return out
 
 
-def gen_unet(size, seed, fname):
+def reference_large_unet(channels):
+    """The reference's OWN ``LargeUnet3D`` (common/model/Unet3D.py:87-146), unmodified.  Its constructor opens with
+    ``super(Unet3D, self).__init__()`` (Unet3D.py:89), which raises for an object that is not a ``Unet3D``; the name
+    ``Unet3D`` in that module's namespace is bound to ``LargeUnet3D`` for the duration of the call, so the line reads
+    ``super(LargeUnet3D, self).__init__()`` -- evidently what was meant -- and the class's own layer construction and
+    ``forward`` run as written.  No reference file is touched."""
+    import common.model.Unet3D as ref
+    keep = ref.Unet3D
+    ref.Unet3D = ref.LargeUnet3D
+    try:
+        return ref.LargeUnet3D(channels)
+    finally:
+        ref.Unet3D = keep
+
+
+def gen_unet(size, seed, fname, ch=(2, 16, 32, 64, 32, 16, 32, 2)):
     from oracle import weights as W
     from common.model.Unet3D import Unet3D
     import common.dto.UnetDto as UnetDtoUtil
     from common.metrics import BatchDiceLoss
 
-    ch = [2, 16, 32, 64, 32, 16, 32, 2]
-    model = Unet3D(ch)
+    ch = list(ch)
+    scales = (len(ch) - 2) // 2
+    model = Unet3D(ch) if scales == 3 else reference_large_unet(ch)
     model.load_state_dict(W.make_state_dict(W.unet_spec(ch), seed))
-    x, y = W.unet_inputs(2, size, seed)
+    x, y = W.unet_inputs(2, size, seed, scales=scales)
     crit = BatchDiceLoss([1.0])
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3,
                            weight_decay=1e-5, betas=(0.99, 0.999))   # train_unet_segmentation.py:13-14,32
@@ -179,14 +195,74 @@ def gen_cae(ch, seed, fname, d=28, hw=128):
     print("\nwrote", fname, {k: float(v) for k, v in fx.items() if k.startswith("loss_epoch")})
 
 
+def gen_checkpoints():
+    """whole-module pickles exactly as ``Learner.save_model`` writes them (``torch.save(self._model.cpu(),
+    path)``, learner/Learner.py:112-114) from the REFERENCE classes -- class paths ``common.model.Unet3D.Unet3D`` /
+    ``common.model.Cae3D.Cae3D`` + tensors -- with the eval-mode outputs they produce, and the ``.optim`` / ``.json``
+    companions of ``save_training`` (Learner.py:105-110).  Small channel counts keep the files small."""
+    from oracle import weights as W
+    from common.model.Unet3D import Unet3D
+    from common.model.Cae3D import Cae3D, Enc3D, Dec3D
+    import common.dto.UnetDto as UnetDtoUtil
+    import common.dto.CaeDto as CaeDtoUtil
+    ch = [2, 8, 8, 16, 8, 8, 8, 2]
+    model = Unet3D(ch)
+    model.load_state_dict(W.make_state_dict(W.unet_spec(ch), 41))
+    x, _ = W.unet_inputs(1, 44, 41)
+    model.eval()
+    with torch.no_grad():
+        dto = model(UnetDtoUtil.init_dto(x))
+    torch.save(model.cpu(), os.path.join(HERE, "ref_unet.model"))
+    fx = {"channels": np.array(ch), "seed": np.array(41), "size": np.array(44),
+          "seg": torch.cat((dto.outputs.core, dto.outputs.penu), 1).numpy().copy()}
+    # the optimiser state torch.optim.Adam saves after one step (Learner.py:108)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    x2, y2 = W.unet_inputs(2, 44, 42)
+    from common.metrics import BatchDiceLoss
+    crit = BatchDiceLoss([1.0])
+    dto = model(UnetDtoUtil.init_dto(x2, y2[:, 0:1], y2[:, 1:2]))
+    loss = (crit(dto.outputs.core, dto.given_variables.core) + crit(dto.outputs.penu, dto.given_variables.penu)) / 2
+    opt.zero_grad(); loss.backward(); opt.step()
+    torch.save(opt.state_dict(), os.path.join(HERE, "ref_unet.optim"))
+    fx["optim_step"] = np.array(1)
+    fx["exp_avg_head"] = opt.state_dict()["state"][1]["exp_avg"].reshape(-1)[:8].numpy().copy()
+    cch = [1, 8, 8, 8, 8, 16, 1]
+    enc = Enc3D(size_input_xy=64, size_input_z=28, channels=cch, n_ch_global=5, alpha=1.0)
+    dec = Dec3D(size_input_xy=64, size_input_z=28, channels=cch, n_ch_global=5, alpha=1.0)
+    cae = Cae3D(enc, dec)
+    cae.load_state_dict(W.make_state_dict(W.cae_spec(cch), 43))
+    labels, clinical = W.cae_inputs(1, 28, 64, 43)
+    cae.eval()
+    with torch.no_grad():
+        cdto = CaeDtoUtil.init_dto(clinical.float(), torch.tensor([[[[[0.25]]]]]), None, None, None, None, None, None, None)
+        cdto.given_variables.gtruth.core, cdto.given_variables.gtruth.penu, cdto.given_variables.gtruth.lesion = \
+            labels[:, 0:1], labels[:, 1:2], labels[:, 2:3]
+        cdto = cae(cdto)
+    torch.save(cae.cpu(), os.path.join(HERE, "ref_cae.model"))
+    fx["cae_channels"] = np.array(cch)
+    fx["cae_seed"] = np.array(43)
+    for k in ("core", "penu", "lesion", "interpolation"):
+        fx["cae_rec/" + k] = getattr(cdto.reconstructions.gtruth, k).numpy().copy()[:, :, 10:18, 24:40, 24:40]
+        fx["cae_lat/" + k] = getattr(cdto.latents.gtruth, k).numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "ref_checkpoints.npz"), **fx)
+    print("wrote ref_unet.model ref_unet.optim ref_cae.model ref_checkpoints.npz")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ["unet", "unet128", "cae"]
+    which = sys.argv[1:] or ["unet", "unet128", "cae", "unet4", "ckpt"]
     if "unet" in which:
         gen_unet(44, 11, "unet_44.npz")
         gen_unet(48, 12, "unet_48.npz")
         gen_unet((44, 48, 52), 13, "unet_44x48x52.npz")
+    if "ckpt" in which:
+        gen_checkpoints()
+    if "unet4" in which:      # BASELINE configs[4] topology (SURVEY 8d row #5: ch_bC = 32), smallest closed sizes
+        ch4 = (2, 32, 64, 128, 256, 128, 64, 32, 32, 2)
+        gen_unet(92, 31, "unet4_92.npz", ch4)
+        gen_unet((92, 100, 96), 32, "unet4_92x100x96.npz", ch4)
     if "unet128" in which:
         gen_unet_eval128(14, "unet_eval128.npz")
     if "cae" in which:

@@ -247,17 +247,20 @@ def test_graph_captured_step_with_stream_overlap_matches_eager():
 
 
 def test_metrics_on_device_match_numpy():
-    """N2: confusion counts from the HIP reduction equal the numpy restatement of medpy's measures."""
+    """N2: the device measures equal the oracle's restatement of medpy (oracle/measures.py)."""
     from stroke_prediction_amd.common import metrics as M
+    from oracle import measures as OM
     g = torch.Generator().manual_seed(5)
     res = torch.rand(2, 1, 20, 24, 28, generator=g)
     tgt = (torch.rand(2, 1, 20, 24, 28, generator=g) > 0.6).float()
-    ref = M.binary_measures_numpy(res.numpy(), tgt.numpy(), distances=True)
+    ref = OM.binary_measures(res.numpy(), tgt.numpy())
     got = M.binary_measures_torch(res.to(DEV), tgt.to(DEV), True, distances=True)
     fast = M.binary_measures_torch(res.to(DEV), tgt.to(DEV), True, distances=False)
-    for k in ("dc", "precision", "sensitivity", "specificity", "hd", "assd"):
-        assert abs(getattr(ref, k) - getattr(got, k)) < 1e-12, k
-    assert fast.dc == ref.dc and fast.hd == np.inf
+    for k in ("dc", "precision", "sensitivity", "specificity"):
+        assert abs(ref[k] - getattr(got, k)) < 1e-12, k
+    for k in ("hd", "assd"):
+        assert abs(ref[k] - getattr(got, k)) <= 1e-5 * max(1.0, ref[k]), k
+    assert fast.dc == ref["dc"] and fast.hd == np.inf
 
 
 def test_full_size_directional_derivative():
@@ -292,8 +295,7 @@ def test_full_size_directional_derivative():
             for p, d in zip(params, dirs):
                 p.add_(sgn * eps * d)
             model._ensure_flat()
-            from stroke_prediction_amd.runtime import ops as O
-            O.bump_param_epoch()                       # weights changed behind the re-pack cache's back
+            # (no manual cache invalidation: in-place edits bump the parameters' version counters, runtime/flat.py)
             vals.append(float(loss_of(model)[0].detach()))
             for p, d in zip(params, dirs):
                 p.add_(-sgn * eps * d)

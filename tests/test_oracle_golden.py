@@ -21,13 +21,16 @@ def _leafify(sd):
     return sd
 
 
-@pytest.mark.parametrize("fname", ["unet_44.npz", "unet_48.npz", "unet_44x48x52.npz"])
+@pytest.mark.parametrize("fname", ["unet_44.npz", "unet_48.npz", "unet_44x48x52.npz", "unet4_92.npz"])
 def test_unet_train_steps_match_reference(golden_dir, fname):
+    """three-scale ``Unet3D`` fixtures and the four-scale ``LargeUnet3D`` one (the reference class, constructed as
+    tests/golden/make_golden.py:reference_large_unet explains)"""
     fx = _load(golden_dir, fname)
     seed, size = int(fx["seed"]), tuple(int(s) for s in np.atleast_1d(fx["size"]))
     size = size * 3 if len(size) == 1 else size
-    sd = _leafify(W.make_state_dict(W.unet_spec(UNET_CH), seed))
-    x, y = W.unet_inputs(2, size, seed)
+    ch = [int(c) for c in fx["channels"]]
+    sd = _leafify(W.make_state_dict(W.unet_spec(ch), seed))
+    x, y = W.unet_inputs(2, size, seed, scales=(len(ch) - 2) // 2)
     names = nets.trainable(sd)
     m = [torch.zeros_like(sd[k]) for k in names]
     v = [torch.zeros_like(sd[k]) for k in names]

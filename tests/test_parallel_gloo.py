@@ -49,3 +49,75 @@ def test_flat_gradient_allreduce_world2():
     for rank, same_params, ok_sum, views_alias, scale, n in res:
         assert same_params and ok_sum and views_alias
         assert scale == 0.5 and n == 355014
+
+
+def _worker_buckets(rank, world, port, q):
+    """bucketed (reverse layer order, asynchronous) == one all-reduce, bit for bit, on random gradients."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stroke_prediction_amd  # noqa: F401
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    from stroke_prediction_amd.optim import attach_flat_grads
+    from stroke_prediction_amd.parallel import DataParallelSync
+    torch.manual_seed(7)
+    out = {}
+    for bucketed in (True, False):
+        model = Unet3D([2, 16, 32, 64, 32, 16, 32, 2])
+        sync = DataParallelSync(model, bucketed=bucketed)
+        _, flat_g = model.flat_buffers()
+        attach_flat_grads(model)
+        g = torch.Generator().manual_seed(1000 + rank)
+        flat_g.copy_(torch.randn(flat_g.numel(), generator=g))
+        model._begin_step()
+        # what UnetEngine.backward reports while it walks the layers back to front
+        model._grads_ready_from("block4.")
+        pending_after_first = model._bucket_hi
+        model._grads_ready_from("block2.")
+        model._after_backward()
+        out[bucketed] = (flat_g.clone(), sync.nbuckets_last, pending_after_first)
+        model._after_backward()          # idempotent: a second call in the same step must not reduce again
+        assert torch.equal(out[bucketed][0], flat_g)
+        sync.close()
+    off4 = sum(p.numel() for n, p in Unet3D([2, 16, 32, 64, 32, 16, 32, 2]).named_parameters()
+               if n.startswith(("block1.", "block2.", "block3.")))
+    q.put((rank, bool(torch.equal(out[True][0], out[False][0])), out[True][1], out[False][1], out[True][2], off4))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_single_world2():
+    world, port = 2, 29741
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_buckets, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, equal, nb_bucketed, nb_single, pending, off4 in res:
+        assert equal, "bucketed and single all-reduce differ"
+        assert nb_bucketed == 3 and nb_single == 1
+        assert pending == off4         # after the first report exactly blocks 1-3 are still pending
+
+
+def test_bench_self_launches_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE must spawn its own ranks before touching the GPU (the driver's
+    multi-GPU contract).  Here (no GPU) the children cannot run the workload: SP_BENCH_DRYRUN makes every rank join the
+    gloo group, all-reduce one value and rank 0 print the JSON skeleton -- the launcher, env plumbing and exit code are
+    what is tested."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(SP_BENCH_DRYRUN="1", SP_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["dryrun"] is True and res["ranks_seen"] == 2
