@@ -51,6 +51,32 @@ def _cpu_model():
     return platform.processor() or "unknown"
 
 
+def _usable_cpus():
+    """host cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a GPU box hands one
+    job a share of a large host: timing 256 threads on a 16-core share measures oversubscription, not the CPU)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                q = int(parts[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def _timed_cpu_steps(step, threads, steps):
     torch.set_num_threads(threads)
     times = []
@@ -62,12 +88,13 @@ def _timed_cpu_steps(step, threads, steps):
 
 
 def _cpu_report(vox, make_step, desc, steps):
-    ncpu = os.cpu_count() or 1
+    ncpu = _usable_cpus()
     prev = torch.get_num_threads()
     t_all = _timed_cpu_steps(make_step(), ncpu, steps)
     res = {"value": vox / t_all, "unit": "voxels/s", "cores": ncpu, "kind": "port",
-           "os_cpu_count": ncpu, "cpu_model": _cpu_model(), "s_per_step": t_all,
-           "sample": "%s, 1 warm-up + %d timed steps, median; all %d host threads" % (desc, steps, ncpu)}
+           "os_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(), "s_per_step": t_all,
+           "sample": "%s, 1 warm-up + %d timed steps, median; all %d usable host cores (affinity / cgroup quota; the host "
+                     "reports %s)" % (desc, steps, ncpu, os.cpu_count())}
     if ncpu != 8:
         t8 = _timed_cpu_steps(make_step(), 8, steps)
         res["threads_8"] = {"value": vox / t8, "s_per_step": t8, "cores": 8}
@@ -84,7 +111,7 @@ def cpu_baseline_unet(size, steps=3, batch=2, channels=CHANNELS):
         names = nets.trainable(sd)
         for k in names:
             sd[k].requires_grad_(True)
-        x, y = W.unet_inputs(batch, size, 1234)
+        x, y = W.unet_inputs(batch, size, 1234, scales=(len(channels) - 2) // 2)
         m = [torch.zeros_like(sd[k]) for k in names]
         v = [torch.zeros_like(sd[k]) for k in names]
 
@@ -371,8 +398,10 @@ def bench_unet(args, world, rank, dev, four_scale=False):
     if rank == 0 and world == 1 and not args.no_parity and not four_scale and args.dtype == "bf16":
         res["parity"] = parity_vs_f32(model, images)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # bounded CPU sample (about 10-30 s): the headline size for the 3-scale net; for the 4-scale net one 2x128^3 volume
+        # (a 256^3 oracle step is minutes) -- same network, same per-voxel work up to the valid-convolution border share
         res["cpu_baseline"] = cpu_baseline_unet(size, channels=channels) if not four_scale else \
-            cpu_baseline_unet(size, steps=1, channels=channels)
+            cpu_baseline_unet((128, 128, 128), steps=1, batch=1, channels=channels)
     if rank == 0 and world == 1 and args.torch_gpu_baseline and not four_scale:
         try:
             res["torch_gpu_baseline"] = torch_gpu_baseline(size, args.batch, bf16=(args.dtype == "bf16"))

@@ -107,6 +107,19 @@ typedef struct sp_conv_args {
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
 
+/* The same operation (nn.Conv3d(3, stride 1, padding 0) forward, Unet3D.py:19,22, or its data gradient) on the
+ * output-stationary z-marching kernel (csrc/sp_conv_zm.hip): a workgroup marches through the INPUT planes of a column of
+ * NW*MT x 16 output voxels, each plane staged once by LDS-DMA and fed to the three output planes it contributes to.
+ * Uses of sp_conv_args: x, y, bias, stats / stats_nrep (stats_mode 0), geometry, o0*, act (LEAKY / NONE), x_plane, Cout,
+ * CPi = 16 P, NT = NTtot = Cout / 16, MT (rows per wave) as sp_conv3d_zm_config(P, NT) reports; ktab and wfrag_hi in the
+ * kernel's own K order (runtime/plan.py:zm_plan): ktab[s*4+g] = byte offset of the octet inside a ring slot, fragments
+ * [(dz*KS + s)*NT + n] from sp_conv_prep_weights / sp_conv_prep_folded with the matching kmap.  in_scale must be NULL (the
+ * BatchNorm is folded into the weights).  zeros: >= 16 readable zero bytes on the device (source of padding chunks). */
+int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
+/* (input planes P = Cin/16, output tiles NT = Cout/16) -> rows per wave, ring slots and waves per workgroup of the kernel that
+ * exists for the pair (a workgroup covers NW*MT x 16 output voxels per plane); returns SP_EINVAL when there is none */
+int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
+
 /* Re-pack fp32 weights into MFMA A-fragments in the plan's K order.
  * kmap[step*4+g] = (src_tap_index << 16) | cin_octet, or -1 for a padding octet.
  * element (co, ci, tap) is read from w[co*sCo + ci*sCi + tap]. */

@@ -52,6 +52,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword holding two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Converting element by element
+// and packing by hand costs a conversion, a shift and an or per element (found in the ISA of every bf16 epilogue).
+typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sp_pack_bf16x2(float lo, float hi) {
+  const f32x2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sp_bf16x2));
+}
+
 // storage-type traits: T = bf16_t (fast path) or float (parity path)
 template <typename T> struct Store;
 template <> struct Store<bf16_t> {
@@ -70,12 +78,12 @@ template <> struct Store<bf16_t> {
   static __device__ __forceinline__ void st8(bf16_t* p, const float* v) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[2 * i]) | ((uint32_t)f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = sp_pack_bf16x2(v[2 * i], v[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
   static __device__ __forceinline__ void st4(bf16_t* p, const float* v) {
-    uint32_t w0 = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-    uint32_t w1 = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+    uint32_t w0 = sp_pack_bf16x2(v[0], v[1]);
+    uint32_t w1 = sp_pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = make_uint2(w0, w1);
   }
   static __device__ __forceinline__ void ld4(const bf16_t* p, float* v) {
@@ -178,6 +186,14 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 // loop, where it drains the prefetch of the NEXT tile and serialises DMA and compute (found in the ISA of the
 // double-buffered weight-gradient kernel).  The kernels order DMA and reads themselves: s_waitcnt vmcnt(0) + barrier
 // before a buffer is read.  m0 is not otherwise used by these kernels (no other LDS-DMA / GWS / movrel).
+// Same, WITHOUT the "memory" clobber: for DMAs placed inside an MFMA loop.  The clobber makes the statement a barrier for the
+// compiler's own LDS reads and stores, which could then no longer be prefetched / interleaved across it.  Only for DMAs whose
+// destination no instruction between the surrounding barriers touches (the kernel's own waits + s_barrier order it).
+__device__ __forceinline__ void sp_dma16_nc(const void* src, const void* lds_dst) {
+  typedef __attribute__((address_space(3))) void sp_lds_void;
+  const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(sp_lds_void*)lds_dst);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base));
+}
 __device__ __forceinline__ void sp_dma16(const void* src, const void* lds_dst) {
   typedef __attribute__((address_space(3))) void sp_lds_void;
   const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(sp_lds_void*)lds_dst);

@@ -1,0 +1,494 @@
+// Output-stationary z-marching convolution for the stride-1 3x3x3 layers of the U-Net (bf16, LDS-DMA staging).
+//
+// Replaces nn.Conv3d(3, padding 0) forward and its data gradient (Unet3D.py:19,22) on the layers whose weight
+// fragments fit the register file: Cin = 16 P, Cout = 16 NT with 3 * ceil(18 P / 4) * NT <= ~56 fragments.
+//
+// What the tiled kernel (sp_conv_dma.hip, conv_igemm_dma_kernel) and the ring kernel (conv_igemm_zs_kernel) leave on the
+// table, by their own phase stamps: stage -> K loop -> store run one after the other inside a workgroup, every input
+// plane is staged 2-3 times (z halo), and with Cout = 16 every activation fragment read from LDS feeds ONE MFMA.
+// Here a workgroup owns a COLUMN of TH x 16 output voxels and marches through the INPUT planes of that column:
+//
+//   * an input plane zi contributes to the three output planes zi, zi-1, zi-2 (taps dz = 0, 1, 2).  The wave keeps the
+//     accumulators of all three in registers, so a plane is staged ONCE, lives in LDS for exactly one step, and every
+//     activation fragment read from LDS feeds 3 x NT MFMAs (in-plane taps (dy, dx) x channels are the K loop: 18 P
+//     octets = ceil(18 P / 4) steps of 32);
+//   * the LDS ring therefore holds only planes in flight (2 or 3 slots): the DMA of plane zi+1 (zi+2) is issued at the
+//     top of step zi and has a whole step of MFMAs to land; one barrier per step;
+//   * all weight fragments (3 dz x KS x NT) are resident in registers -- one workgroup per CU, 512 registers per lane;
+//   * the epilogue of a finished plane (bias, activation, bf16 pack, BatchNorm statistics, stores) is carried into the
+//     NEXT step's instruction stream, where its VALU work issues between that step's MFMAs; stores are issued a whole
+//     step before the wait that has to cover them (vmcnt counts stores too on gfx9);
+//   * padding (data gradients: "full" correlation) costs nothing extra: out-of-volume 16-byte chunks are DMA'd from a
+//     zero page, so every wave issues the same number of DMA instructions per plane and the waits can be counted.
+//
+// K table (host, runtime/plan.py): ktab[s * 4 + g] = byte offset inside a slot of the octet lane group g reads in step s
+// ((plane p * ITH + dy) * 18 + dx) * 32 + octet * 16; weight fragments: [(dz * KS + s) * NT + n] * 64 lanes, packed by
+// sp_conv_prep_weights / sp_conv_prep_folded from the matching kmap (the BatchNorm of the un-padded forward convolution is
+// folded into weights and bias there, as for every DMA kernel).
+#include "sp_common.h"
+#include <string.h>
+
+struct ConvZmDev {
+  sp_conv_args a;
+  const void* zeros;      // >= 16 readable zero bytes
+  int32_t nty, ntx;
+  uint32_t ncols;
+  FastDiv d_tx, d_ty;
+};
+
+// ---- diagnostic build (-DSP_ZM_STAMPS, tools/stamp_zm.py): cycles per step segment, summed per wave -----------------
+#ifdef SP_ZM_STAMPS
+__device__ unsigned long long sp_zm_stamp_buf[1024][8][8];
+#define ZM_T(var)                                                                       \
+  unsigned long long var;                                                               \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");        \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#define ZM_ACC(k, t1, t0) zm_sum[k] += (t1) - (t0)
+extern "C" int sp_debug_zm_stamps(void* out, int nbytes) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(sp_zm_stamp_buf), nbytes) == hipSuccess ? 0 : -2;
+}
+#else
+#define ZM_T(var)
+#define ZM_ACC(k, t1, t0)
+#endif
+
+typedef unsigned int zm_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int zm_u32x4 __attribute__((ext_vector_type(4)));
+
+// four consecutive output channels of one voxel through a buffer descriptor: an out-of-range byte offset DROPS the store in
+// hardware, so rows / columns / planes outside the output need no branch (branches would cut the epilogue out of the
+// basic block whose MFMAs it is meant to issue between)
+template <typename T> struct ZmStore;
+typedef __bf16 zm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float zm_f32x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32; element-wise casts packed by hand
+// cost a conversion, a shift and an or per element
+__device__ __forceinline__ uint32_t zm_pack2(float lo, float hi) {
+  const zm_f32x2 f = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, zm_bf16x2));
+}
+template <> struct ZmStore<bf16_t> {
+  static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, uint32_t off, const float* v) {
+    zm_u32x2 d = {zm_pack2(v[0], v[1]), zm_pack2(v[2], v[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 0);
+  }
+};
+template <> struct ZmStore<float> {
+  static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, uint32_t off, const float* v) {
+    zm_u32x4 d = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 0);
+  }
+};
+
+// wait for the wave's own DMA (all but the N youngest vector-memory operations), then the workgroup barrier: a raw
+// s_barrier, NOT __syncthreads() -- its fence would wait for vmcnt(0) and drain the prefetch (and the stores) every step
+#define ZM_SYNC(N)                                                   \
+  do {                                                               \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");         \
+    __builtin_amdgcn_s_barrier();                                    \
+    asm volatile("" ::: "memory");                                   \
+  } while (0)
+
+// WLDS = false: all 3 x KS x NT weight fragments resident in registers (fits for one input plane and one output tile);
+// WLDS = true: they are copied to LDS once per workgroup (behind the ring) and every K step reads its 3 x NT fragments
+// from there, double-buffered against the MFMAs -- (MT + 3 NT) LDS reads feed 3 NT MT MFMAs, < 0.6 reads per MFMA.
+// STATS: per-channel sum / sum of squares of the output for the next BatchNorm (forward layers; data gradients skip the work).
+// NW: waves per workgroup (4, or 8 = two per SIMD: one wave's epilogue / DMA / LDS instructions issue under its partner's MFMAs).
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, typename TOUT>
+__global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
+  constexpr int WPS = NW / 4;
+  constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
+  constexpr int ITH = NW * MT + 2, ITW = 18;
+  constexpr int PCH = ITH * ITW * 2;              // 16-byte chunks of one 16-channel plane
+  constexpr int NCH = P * PCH;
+  constexpr int NJ = (NCH + 64 * NW - 1) / (64 * NW);   // DMA instructions per wave and input plane
+  constexpr int S = NJ * NW * 1024;               // slot stride in bytes
+  constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
+  constexpr int D = NSLOT - 1;                    // prefetch distance in planes
+  constexpr int NS = MT * NT;                     // store instructions of one epilogue
+  static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NS) <= 63, "counted vmcnt does not fit its 6-bit field");
+  constexpr int NWF = 3 * KS * NT;                // weight fragments (1 KiB each)
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const sp_conv_args& a = Q.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lv = lane & 15, lg = lane >> 4;
+  unsigned char* ring = lds;
+
+  int kv[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) kv[s] = a.ktab[s * 4 + lg];
+  const int vbase0 = (wave * MT * ITW + lv) * 32;      // this lane's voxel of the wave's first row inside a plane
+  const bf16x8* __restrict__ wf = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
+  bf16x8 w[WLDS ? 1 : 3][WLDS ? 1 : KS][WLDS ? 1 : NT];
+  const unsigned char* wl = lds + WOFF + lane * 16;           // this lane's 16 bytes of fragment 0
+  if (WLDS) {
+    for (int f = wave; f < NWF; f += NW) sp_dma16(reinterpret_cast<const unsigned char*>(wf) + (size_t)f * 1024 + lane * 16, lds + WOFF + f * 1024);
+  } else {
+#pragma unroll
+    for (int dz = 0; dz < (WLDS ? 0 : 3); ++dz)
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w[dz][s][n] = wf[((size_t)(dz * KS + s) * NT + n) * 64 + lane];
+  }
+
+  // per-lane DMA plan of one input plane set: chunk c = (wave + 4 j) * 64 + lane -> (plane p, row vy, voxel vx, half)
+  const int xpitch = a.x_plane ? 16 : a.CPi;      // elements per voxel of one plane's row
+  uint32_t rel[NJ];
+  int crd[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (wave + NW * j) * 64 + lane;
+    const bool ok = c < NCH;
+    const int cc = ok ? c : 0;
+    const int p = cc / PCH, r = cc - p * PCH;
+    const int half = r & 1, vox = r >> 1;
+    const int vy = vox / ITW, vx = vox - vy * ITW;
+    const uint32_t pl = a.x_plane ? (uint32_t)p * (uint32_t)a.x_plane : (uint32_t)p * 16u;
+    rel[j] = (pl + (uint32_t)((vy * a.Wi + vx) * xpitch + half * 8)) * 2u;
+    crd[j] = vy | (vx << 8) | (ok ? 0 : (1 << 30));
+  }
+  float bj[NT][4], s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bj[n][j] = a.bias ? a.bias[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
+  const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;      // host: act is LEAKY or NONE
+  const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(Q.zeros);
+#ifdef SP_ZM_STAMPS
+  unsigned long long zm_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 0 sync, 1 DMA issue, 2 K loop + epilogue, 3 steps, 4 total
+  ZM_T(t_begin);
+  const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+
+  // Work = (column, output plane) pairs cut into gridDim.x equal pieces of the flattened sequence; a piece that starts
+  // inside a column pays the two-plane prologue again.  XCD-aware piece id (neighbouring columns share halo in one L2).
+  const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
+  const uint64_t T = (uint64_t)Q.ncols * a.Do;
+  uint64_t pos = T * vb / gridDim.x;
+  const uint64_t pend_pos = T * (vb + 1) / gridDim.x;
+  while (pos < pend_pos) {
+    const uint32_t col = (uint32_t)(pos / (uint32_t)a.Do);
+    const int z0 = (int)(pos - (uint64_t)col * a.Do);
+    const int z1 = (int)min((uint64_t)a.Do, (uint64_t)z0 + (pend_pos - pos));
+    pos += (uint64_t)(z1 - z0);
+    const int nz = z1 - z0, nin = nz + 2;                     // output planes of this piece, input planes they need
+    uint32_t t = col;
+    uint32_t q = fdiv(t, Q.d_tx); const int tx = t - q * Q.ntx; t = q;
+    q = fdiv(t, Q.d_ty); const int ty = t - q * Q.nty; const int b = q;
+    const int oy0 = ty * (NW * MT), ox0 = tx * 16;
+    const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
+    const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * xpitch * 2;
+    int vmask = 0;                                            // in-plane validity of this lane's chunks
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int vy = crd[j] & 0xff, vx = (crd[j] >> 8) & 0xff;
+      if (!(crd[j] >> 30) && (unsigned)(iy0 + vy) < (unsigned)a.Hi && (unsigned)(ix0 + vx) < (unsigned)a.Wi) vmask |= 1 << j;
+    }
+    // one DMA instruction (1 KiB) of input plane i -> ring slot; inloop: issued between the MFMAs of a K step
+    const unsigned char* pl_src0 = nullptr;
+    unsigned char* pl_dst0 = nullptr;
+    int pl_mask = 0;
+    bool pl_fill = false;                                     // filler DMAs (zero page -> dump area) beyond the last plane
+    auto plane_begin = [&](int i, int slot) {
+      const int iz = z0 + a.o0D + i;
+      pl_mask = ((unsigned)iz < (unsigned)a.Di) ? vmask : 0;
+      pl_src0 = xin + (((int64_t)iz * a.Hi + iy0) * a.Wi + ix0) * (int64_t)(xpitch * 2);
+      pl_dst0 = ring + slot * S + wave * 1024;
+    };
+    auto plane_dma = [&](int j, bool inloop) {
+      const unsigned char* src = ((pl_mask >> j) & 1) ? pl_src0 + rel[j] : zsrc;      // padding / overhang: the zero page
+      unsigned char* dst = pl_dst0 + (pl_fill ? 0 : j * (NW * 1024));
+      if (inloop) sp_dma16_nc(src, dst); else sp_dma16(src, dst);
+    };
+    auto load_plane = [&](int i, int slot) {                  // whole plane at once (prologue)
+      plane_begin(i, slot);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) plane_dma(j, false);
+    };
+    TOUT* yout = reinterpret_cast<TOUT*>(a.y) + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)yout, 0, (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)sizeof(TOUT)), 0x00020000);
+    const int ox = ox0 + lv;
+    const bool colok = ox < a.Wo;
+    // byte offset of (row m, this lane's voxel and channel quad) inside an output plane, or "outside"
+    uint32_t rowoff[MT];
+    uint32_t rowok[MT];       // all-ones / zero bit mask (a float 0/1 factor would turn the garbage of a row outside the output into NaN)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int oy = oy0 + wave * MT + m;
+      const bool ok = colok && oy < a.Ho;
+      rowoff[m] = ok ? (uint32_t)((((oy * a.osH + a.ooH) * a.YW + (ox * a.osW + a.ooW)) * a.CPo + lg * 4) * (int)sizeof(TOUT)) : 0x80000000u;
+      rowok[m] = ok ? 0xffffffffu : 0u;
+    }
+    const uint32_t zstride = (uint32_t)(a.osD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
+    const uint32_t zbase = (uint32_t)(a.ooD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
+
+    // FOUR accumulator sets, one per output plane j mod 4: during step i (input plane i) the sets of planes i, i-1, i-2
+    // receive the taps dz = 0, 1, 2 while the set of plane i-3 -- finished at the end of step i-1 -- is read by the epilogue
+    // that is carried in this step's instruction stream.  No copy into a staging set, and no zeroing either: the first MFMA
+    // of a plane (dz = 0, K step 0) takes a zero C operand.
+    f32x4 acc[4][NT][MT];
+
+    ZM_SYNC(0);                                               // the previous piece has been consumed
+#pragma unroll
+    for (int k = 0; k < NSLOT - 1; ++k)
+      if (k < nin) load_plane(k, k);
+
+    // epilogue of the plane held by accumulator set R: straight-line code (no branch); fz < 0 (no finished plane) turns
+    // every store into an out-of-range one and every statistics term into 0 -- the instruction count never changes
+#define ZM_EPILOGUE(R_, fz_)                                                                                      \
+  {                                                                                                               \
+    const bool pv = (fz_) >= 0;                                                                                   \
+    const uint32_t zoff = pv ? zbase + (uint32_t)(fz_) * zstride : 0x80000000u;                                   \
+    const uint32_t pm = pv ? 0xffffffffu : 0u;                                                                    \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
+      const uint32_t off = (zoff | rowoff[m]) & 0x80000000u ? 0x80000000u : zoff + rowoff[m];                     \
+      const uint32_t msk = pm & rowok[m];                                                                         \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
+        float v[4];                                                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); } \
+        ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                                 \
+        if (STATS) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const float u = __uint_as_float(__float_as_uint(v[j]) & msk);                                         \
+            s1[n][j] += u; s2[n][j] = fmaf(u, u, s2[n][j]);                                                       \
+          }                                                                                                       \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  }
+
+    // the activation fragment of row m: one address per K step (slot + this lane's voxel + the step's octet) and the row as
+    // an immediate offset of the ds_read
+#define ZM_LDX(dst, s_)                                                                                           \
+  {                                                                                                               \
+    const unsigned char* xa_ = sb + vbase0 + kv[s_];                                                              \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(xa_ + m * (ITW * 32)); \
+  }
+#define ZM_LDW(dst, s_)                                                                                           \
+  if (WLDS) {                                                                                                     \
+    _Pragma("unroll") for (int dz = 0; dz < 3; ++dz)                                                              \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                            \
+            dst[dz][n] = *reinterpret_cast<const bf16x8*>(wl + ((dz * KS + (s_)) * NT + n) * 1024);               \
+  }
+#define ZM_DMA(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KS; j < (((s_) + 1) * NJ) / KS; ++j) plane_dma(j, true);
+#define ZM_W(DZ_, s_, n_, wv) (WLDS ? wv[DZ_][n_] : w[WLDS ? 0 : DZ_][WLDS ? 0 : s_][WLDS ? 0 : n_])
+#define ZM_MMA(R_, DZ_, s_, xv, wv)                                                                               \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                  \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
+          acc[R_][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ZM_W(DZ_, s_, n, wv), xv[m], acc[R_][n][m], 0, 0, 0);
+    // first contribution to a new output plane: C = 0
+#define ZM_MMA0(R_, DZ_, s_, xv, wv)                                                                              \
+  _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                  \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
+          acc[R_][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ZM_W(DZ_, s_, n, wv), xv[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#define ZM_MMA_D0(R_, s_, xv, wv) if ((s_) == 0) { ZM_MMA0(R_, 0, s_, xv, wv) } else { ZM_MMA(R_, 0, s_, xv, wv) }
+    // One step = one input plane i (phase PH = i mod 4, compile time): taps dz = 0 / 1 / 2 add into the sets PH, PH+3, PH+2
+    // (mod 4) of the output planes i, i-1, i-2; set PH+1 holds plane i-3, whose epilogue is issued between this step's MFMAs.
+#define ZM_STEP(PH)                                                                                               \
+  {                                                                                                               \
+    /* plane i has landed (issued NSLOT-1 steps ago).  Every step issues exactly NJ DMA instructions (of a later plane) and */ \
+    /* MT*NT stores (out-of-range ones are dropped by the buffer unit but counted), interleaved with its MFMAs in an order */ \
+    /* the compiler picks: everything issued in the last D-1 steps may stay in flight.  The barrier makes "landed" true for */ \
+    /* every wave, and everyone is done with the slot that is refilled during this step. */                         \
+    /* younger than plane i's DMA: the DMAs of planes i+1 .. i+D-1 and the stores of the last min(i, D-1) steps */   \
+    ZM_T(ts0);                                                                                                    \
+    if (i >= D - 1) ZM_SYNC((D - 1) * (NJ + NS));                                                                 \
+    else if (i == 0) ZM_SYNC((D - 1) * NJ);                                                                       \
+    else if (i == 1) ZM_SYNC((D - 1) * NJ + (D > 2 ? 1 : 0) * NS);                                                \
+    else if (i == 2) ZM_SYNC((D - 1) * NJ + (D > 3 ? 2 : 0) * NS);                                                \
+    else ZM_SYNC((D - 1) * NJ + (D > 4 ? 3 : 0) * NS);                                                            \
+    ZM_T(ts1);                                                                                                    \
+    /* the DMA of plane i+D goes out piecewise between the MFMAs below (ZM_DMA); beyond the piece's last plane the same */ \
+    /* number of instructions copies the zero page into a dump area, so that the counted waits stay valid */          \
+    pl_fill = false;                                                                                              \
+    if (i + D < nin) plane_begin(i + D, (islot + D) % NSLOT);                                                     \
+    else { pl_mask = 0; pl_fill = true; pl_dst0 = ring + NSLOT * S + wave * 1024; }                               \
+    ZM_T(ts2);                                                                                                    \
+    const unsigned char* sb = ring + islot * S;                                                                   \
+    const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
+    const int fz = (i >= 3 && i - 3 < nz) ? z0 + i - 3 : -1;       /* the plane whose epilogue rides in this step */ \
+    bf16x8 x0[MT], x1[MT];                                                                                        \
+    bf16x8 wa[WLDS ? 3 : 1][WLDS ? NT : 1], wb[WLDS ? 3 : 1][WLDS ? NT : 1];                                      \
+    if (v0 && v1 && v2) {                                                                                         \
+      ZM_EPILOGUE((PH + 1) % 4, fz)                                                                               \
+      ZM_LDX(x0, 0)                                                                                               \
+      ZM_LDW(wa, 0)                                                                                               \
+      _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
+        if (s + 1 < KS) { if ((s & 1) == 0) { ZM_LDX(x1, s + 1) ZM_LDW(wb, s + 1) } else { ZM_LDX(x0, s + 1) ZM_LDW(wa, s + 1) } } \
+        if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, wa) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x0, wa) ZM_MMA_D0(PH, s, x0, wa) }  \
+        else { ZM_MMA((PH + 2) % 4, 2, s, x1, wb) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x1, wb) ZM_MMA_D0(PH, s, x1, wb) } \
+      }                                                                                                           \
+    } else {   /* first / last planes of a piece: guarded groups; the epilogue AFTER the loop on purpose -- placed first in */ \
+               /* both branches the compiler hoists it out of them, away from the MFMAs it should hide behind */    \
+      _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
+        ZM_LDX(x0, s)                                                                                             \
+        ZM_LDW(wa, s)                                                                                             \
+        ZM_DMA(s)                                                                                                 \
+        if (v2) { ZM_MMA((PH + 2) % 4, 2, s, x0, wa) }                                                            \
+        if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, wa) }                                                            \
+        if (v0) { ZM_MMA_D0(PH, s, x0, wa) }                                                                      \
+      }                                                                                                           \
+      ZM_EPILOGUE((PH + 1) % 4, fz)                                                                               \
+    }                                                                                                             \
+    ZM_T(ts3);                                                                                                    \
+    ZM_ACC(0, ts1, ts0); ZM_ACC(1, ts2, ts1); ZM_ACC(2, ts3, ts2); ZM_ACC(3, 1, 0);                               \
+    if (v0 && v1 && v2) { ZM_ACC(5, ts3, ts2); ZM_ACC(6, 1, 0); }                                                 \
+    ++i;                                                                                                          \
+    islot = islot + 1 == NSLOT ? 0 : islot + 1;                                                                   \
+  }
+
+    // steps 0 .. nin: the last one (no input plane left: all groups off) only carries the epilogue of the last output plane
+    int i = 0, islot = 0;
+    while (true) {
+      ZM_STEP(0)
+      if (i > nin) break;
+      ZM_STEP(1)
+      if (i > nin) break;
+      ZM_STEP(2)
+      if (i > nin) break;
+      ZM_STEP(3)
+      if (i > nin) break;
+    }
+#undef ZM_STEP
+#undef ZM_MMA_D0
+#undef ZM_MMA0
+#undef ZM_MMA
+#undef ZM_W
+#undef ZM_DMA
+#undef ZM_LDW
+#undef ZM_LDX
+#undef ZM_EPILOGUE
+    // (accumulator sets of planes beyond nz hold partial sums that belong to the next piece: never stored)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may still be landing when the statistics reuse LDS
+#ifdef SP_ZM_STAMPS
+  {
+    ZM_T(t_end);
+    const unsigned long long rt_end = __builtin_amdgcn_s_memrealtime();
+    zm_sum[4] = t_end - t_begin;
+    zm_sum[7] = rt_end - rt_begin;       // 100 MHz ticks
+    if (lane == 0 && blockIdx.x < 1024)
+      for (int k = 0; k < 8; ++k) sp_zm_stamp_buf[blockIdx.x][wave][k] = zm_sum[k];
+  }
+#endif
+  if (STATS && a.stats != nullptr) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);
+    for (int k = tid; k < NT * 32; k += 64 * NW) red[k] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
+        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+      }
+    __syncthreads();
+    for (int k = tid; k < NT * 32; k += 64 * NW) {
+      const int c = k >> 1;
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)red[k]);
+    }
+  }
+}
+
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS>
+static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
+  constexpr int KS = (18 * P + 3) / 4;
+  constexpr int NCH = P * (NW * MT + 2) * 18 * 2;
+  constexpr int NJ = (NCH + 64 * NW - 1) / (64 * NW);
+  constexpr int S = NJ * NW * 1024;
+  // ring (+ 1 KiB per wave where the counted-wait filler DMAs land) (+ the weight fragments)
+  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? 3 * KS * NT * 1024 : 0);
+  static_assert(lds_bytes <= 160 * 1024, "ring + weights do not fit LDS");
+  ConvZmDev Q;
+  Q.a = *a;
+  Q.zeros = zeros;
+  Q.ntx = (a->Wo + 15) / 16;
+  Q.nty = (a->Ho + NW * MT - 1) / (NW * MT);
+  Q.ncols = (uint32_t)(a->B * Q.nty * Q.ntx);
+  Q.d_tx = make_fastdiv(Q.ntx);
+  Q.d_ty = make_fastdiv(Q.nty);
+  const uint64_t planes = (uint64_t)Q.ncols * a->Do;
+  static const int slots_env_ = getenv("SP_ZM_SLOTS") ? atoi(getenv("SP_ZM_SLOTS")) : 0;
+  const int slots = slots_env_ > 0 ? slots_env_ : 256;               // resident workgroups: one per CU
+  const unsigned grid = planes / 4 < (uint64_t)slots ? (unsigned)(planes / 4 > 0 ? planes / 4 : 1) : (unsigned)slots;
+  if (a->dtype_out == SP_F32) {
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, float>;
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+  } else {
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, bf16_t>;
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+  }
+  SP_CHECK_LAUNCH("sp_conv3d_zm");
+  return SP_OK;
+}
+
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW>
+static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
+  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true>(a, zeros, st);
+  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false>(a, zeros, st);
+}
+
+// (P, NT) -> rows per wave, ring slots, waves per workgroup; SP_EINVAL = no kernel.  runtime/plan.py (ZM_CONFIGS) must agree:
+// tests/test_cabi.py checks it.  SP_ZM_NW=4 forces the one-wave-per-SIMD set everywhere (A/B runs; read on both sides).
+static bool zm_nw4() { static const bool v = getenv("SP_ZM_NW") && atoi(getenv("SP_ZM_NW")) == 4; return v; }
+extern "C" int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW) {
+  int mt = 0, ns = 3, nw = 8;
+  // eight waves (two per SIMD): one wave's epilogue / DMA / LDS instructions issue under its partner's MFMAs -- measured 12-25 %
+  // faster than four waves with twice the rows each, except for three input planes, where the smaller per-wave tile makes the
+  // LDS weight reads (3 per 6 MFMAs) the limit and the register budget of two waves per SIMD spills
+  if (P == 1 && NT == 1) mt = 4;
+  else if (P == 1 && NT == 2) mt = 2;
+  else if (P == 1 && NT == 3) mt = 2;
+  else if (P == 2 && NT == 1) mt = 4;
+  else if (P == 2 && NT == 2) mt = 2;
+  else if (P == 3 && NT == 1) { mt = 4; nw = 4; }
+  if (zm_nw4() && mt && nw == 8) { mt *= 2; nw = 4; }
+  if (MT) *MT = mt;
+  if (NSLOT) *NSLOT = ns;
+  if (NW) *NW = nw;
+  return mt ? SP_OK : SP_EINVAL;
+}
+
+extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream) {
+  SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && zeros, "sp_conv3d_zm: null pointer");
+  SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr && a->stats_mode == 0, "sp_conv3d_zm: bf16 input, no affine on load, plain statistics");
+  SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
+  SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE, "sp_conv3d_zm: LeakyReLU or identity epilogue");
+  SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
+  SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_zm: stats_nrep must be a power of two");
+  SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_zm: empty output");
+  const int P = a->CPi / 16;
+  // every byte offset the kernel forms must fit 32 bits (per-sample base is 64-bit)
+  const uint64_t span = a->x_plane ? (uint64_t)P * (uint64_t)a->x_plane * 2 : (uint64_t)a->Di * a->Hi * a->Wi * a->CPi * 2;
+  SP_CHECK_ARG(span < (1ull << 31), "sp_conv3d_zm: input too large for 32-bit offsets");
+  SP_CHECK_ARG((uint64_t)a->YD * a->YH * a->YW * a->CPo * 4 < (1ull << 31), "sp_conv3d_zm: output sample too large for a buffer descriptor");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int32_t mt = 0, ns = 0, nw = 0;
+  SP_CHECK_ARG(sp_conv3d_zm_config(P, a->NT, &mt, &ns, &nw) == SP_OK && mt == a->MT, "sp_conv3d_zm: no kernel for P=%d NT=%d MT=%d", P, a->NT, a->MT);
+  // SP_ZM_VARIANT=<digit per (P,NT) class in the order 11 12 13 21 22 31>: tuning knob (tools/bench_conv.py)
+  static const char* var_ = getenv("SP_ZM_VARIANT");
+  auto v = [&](int k) { return (var_ && (int)strlen(var_) > k) ? var_[k] - '0' : 0; };
+  if (nw == 4) {
+    if (P == 1 && a->NT == 1) return launch_zm<1, 1, 8, 3, false, 4>(a, zeros, st);
+    if (P == 1 && a->NT == 2) return launch_zm<1, 2, 4, 3, true, 4>(a, zeros, st);
+    if (P == 1 && a->NT == 3) return launch_zm<1, 3, 4, 3, true, 4>(a, zeros, st);
+    if (P == 2 && a->NT == 1) return launch_zm<2, 1, 8, 3, true, 4>(a, zeros, st);
+    if (P == 2 && a->NT == 2) return launch_zm<2, 2, 4, 3, true, 4>(a, zeros, st);
+    if (P == 3 && a->NT == 1) return launch_zm<3, 1, 4, 3, true, 4>(a, zeros, st);
+    return SP_EINVAL;
+  }
+  if (P == 1 && a->NT == 1) return v(0) == 1 ? launch_zm<1, 1, 4, 3, true, 8>(a, zeros, st) : launch_zm<1, 1, 4, 3, false, 8>(a, zeros, st);
+  if (P == 1 && a->NT == 2) return launch_zm<1, 2, 2, 3, true, 8>(a, zeros, st);
+  if (P == 1 && a->NT == 3) return launch_zm<1, 3, 2, 3, true, 8>(a, zeros, st);
+  if (P == 2 && a->NT == 1) return launch_zm<2, 1, 4, 3, true, 8>(a, zeros, st);
+  if (P == 2 && a->NT == 2) return launch_zm<2, 2, 2, 3, true, 8>(a, zeros, st);
+  return SP_EINVAL;
+}

@@ -73,12 +73,15 @@ class ConvLayer:
         self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
         self.out_dims = tuple(self.fwd_op.y_dims)
         self.bank = bank            # optional dict shared by the layers of all contexts of one stack (packed weights)
-        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if bank is None else bank.setdefault((name, "fwd"), {}))
         self.count = float(batch * in_dims[0] * in_dims[1] * in_dims[2])
         # un-padded bf16 convolutions fold the BatchNorm into weights/bias so the tile can be staged by DMA
         pads = pad if isinstance(pad, (tuple, list)) else (pad,) * 3
         self.fold = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and max(pads) == 0
                          and all(s.tile["dma"] for s in self.fwd_op.subs))
+        # folded layers run without affine-on-load and with plain statistics: candidates for the z-marching kernel
+        zm_ok = self.fold and act in (L.ACT_NONE, L.ACT_LEAKY) and bank is None
+        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if bank is None else bank.setdefault((name, "fwd"), {}),
+                                zm_batch=batch if zm_ok else None)
         self.scratch = scratch
         # Padded bf16 convolutions behind a BatchNorm (the CAE): zero padding applies AFTER the normalisation, so the
         # BatchNorm cannot be folded into the weights, and a DMA cannot normalise on load.  The normalised input is
@@ -183,7 +186,9 @@ class ConvLayer:
                 self.g_parts.append(O.alloc_cl(self.batch, self.in_dims, O.cpad(cn), dt, dev))
             self.g = tuple(self.g_parts)
         elif self.need_input_grad or (self.bn_prefix is not None and not self.bn_from_wgrad):
-            self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}))
+            # (BatchNorm sums from the weight gradient: the data gradient is a plain convolution -> z-marching candidate)
+            self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}),
+                                      zm_batch=self.batch if (self.bn_from_wgrad and self.bank is None) else None)
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
         if self.bn_prefix is not None:
             self.coef = torch.zeros(3, self.cpi, device=dev)

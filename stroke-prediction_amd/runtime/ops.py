@@ -33,6 +33,19 @@ WGRAD_ZS = int(os.environ.get("SP_WGRAD_ZS", "1"))   # z-marching ring variant o
 CAT_PLANAR = bool(int(os.environ.get("SP_CAT_PLANAR", "1")))   # plane-major concat buffers (dense 16-channel planes for the DMA consumers)
 USE_ZS = bool(int(os.environ.get("SP_CONV_ZS", "1")))     # z-marching ring conv variant for the 16->16-channel stride-1 layers (-20 %)
 USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kernels)
+# output-stationary z-marching kernel (csrc/sp_conv_zm.hip) for the stride-1 3x3x3 layers between whole 16-channel tiles whose
+# volume gives every CU a few planes to march through; SP_CONV_ZM=0 falls back to the tiled / ring kernels
+USE_ZM = os.environ.get("SP_CONV_ZM", "1") != "0"
+ZM_MIN_PLANES = int(os.environ.get("SP_CONV_ZM_MIN_PLANES", "1024"))     # (column, plane) pairs per launch below which the march is all prologue
+_ZEROS = {}
+
+
+def zero_page(device):
+    """a few readable zero bytes on the device: source of every out-of-volume DMA chunk of the z-marching kernel"""
+    key = str(device)
+    if key not in _ZEROS:
+        _ZEROS[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return _ZEROS[key]
 
 # optional live kernel timing (bench.py): list of (tag, algorithmic_flops, start_event, end_event)
 PROFILE = None
@@ -140,9 +153,15 @@ def _dev_i32(a, device):
 class ConvRunner:
     """One planned convolution-like op (see ``plan.ConvOp``) bound to device tables and weight fragments."""
 
-    def __init__(self, op: P.ConvOp, device, share=None):
+    def _run_zm(self, a, x_planar, batch, with_stats, st):
+        return _run_zm_impl(self, a, x_planar, batch, with_stats, st)
+
+    def __init__(self, op: P.ConvOp, device, share=None, zm_batch=None):
         """share: a dict owned by the caller; runners built for the SAME op geometry that pass the same dict use
-        one set of packed weights / tables (the 3 encoder and 4 decoder passes of a CAE step)."""
+        one set of packed weights / tables (the 3 encoder and 4 decoder passes of a CAE step).
+        zm_batch: the caller promises to run this op with that batch size, without affine-on-load, with plain (or no)
+        statistics and a LeakyReLU / identity epilogue: the z-marching kernel is used where a plan exists and the volume
+        gives it enough planes, and the weights are packed in ITS K order only."""
         self.op = op
         self.device = device
         st = share if share is not None else {}
@@ -163,12 +182,34 @@ class ConvRunner:
                              hi_zr=torch.empty(15 * op.nttot * 64 * 8, dtype=torch.bfloat16, device=device))
                 subs.append(d)
             st["subs"] = subs
-            st["bias"] = torch.zeros(op.nttot * 16, dtype=torch.float32, device=device)
+            zm = P.zm_plan(op) if (USE_ZM and USE_DMA and zm_batch) else None
+            if zm is not None:
+                cols = -(-op.subs[0].out_dims[1] // zm["TH"]) * -(-op.subs[0].out_dims[2] // 16)
+                if zm_batch * cols * op.subs[0].out_dims[0] < ZM_MIN_PLANES:
+                    zm = None       # too few (column, plane) pairs: the march would be all prologue
+            if zm is not None:      # its own K order -> its own weight fragments (they replace the tiled kernel's: one re-pack per step)
+                zm = dict(zm, ktab_d=_dev_i32(zm["ktab"], device), kmap_d=_dev_i32(zm["kmap"], device),
+                          hi=torch.empty(zm["nsteps"] * zm["NT"] * 64 * 8, dtype=torch.bfloat16, device=device))
+            st["zm"] = zm
+            st["bias"] = torch.zeros(max(op.nttot, 0 if zm is None else zm["NT"]) * 16, dtype=torch.float32, device=device)
             st["has_bias"] = False
             st["prep_key"] = None
         self._st = st
         self.subs = st["subs"]
         self.bias = st["bias"]
+        self.zm = st.get("zm")
+        self.zm_batch = zm_batch if self.zm is not None else None
+
+    def uses_zm(self):
+        """the z-marching kernel runs this op (and its weight fragments are the only ones packed)"""
+        return self.zm is not None
+
+    def _pack(self):
+        """(kmap, nsteps, hi, NTtot) of the fragments the kernel that will run this op reads"""
+        if self.uses_zm():
+            z = self.zm
+            return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"])]
+        return [(s["kmap"], s["nsteps"], s["hi"], s["lo"], self.op.nttot) for s in self.subs]
 
     @property
     def has_bias(self):
@@ -194,19 +235,22 @@ class ConvRunner:
             self._st["prep_key"] = key
         else:
             self._st["prep_key"] = None
-        if fold_scale is not None and fold_shift is not None and len(self.subs) == 1:
-            s0 = self.subs[0]
+        packs = self._pack()
+        if fold_scale is not None and fold_shift is not None and len(packs) == 1:
+            kmap, nsteps, hi, lo, nttot = packs[0]
             ntaps = w.numel() // (op.cin * op.cout)
-            L.call("sp_conv_prep_folded", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s0["kmap"]), s0["nsteps"], op.nttot,
-                   ptr(s0["hi"]), ptr(s0["lo"]), ptr(fold_scale), ntaps, ptr(b), ptr(fold_shift), ptr(self.bias), op.nttot * 16,
+            L.call("sp_conv_prep_folded", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(kmap), nsteps, nttot,
+                   ptr(hi), ptr(lo), ptr(fold_scale), ntaps, ptr(b), ptr(fold_shift), ptr(self.bias), nttot * 16,
                    stream())
             self.has_bias = True
-            self._prep_zr(w, fold_scale)
+            if not self.uses_zm():
+                self._prep_zr(w, fold_scale)
             return
-        for s in self.subs:
-            L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(s["kmap"]), s["nsteps"],
-                   op.nttot, ptr(s["hi"]), ptr(s["lo"]), ptr(fold_scale), stream())
-        self._prep_zr(w, fold_scale)
+        for kmap, nsteps, hi, lo, nttot in packs:
+            L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(kmap), nsteps,
+                   nttot, ptr(hi), ptr(lo), ptr(fold_scale), stream())
+        if not self.uses_zm():
+            self._prep_zr(w, fold_scale)
         if fold_shift is not None:
             ntaps = w.numel() // (op.cin * op.cout)
             L.call("sp_conv_fold_bias", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ntaps, ptr(b), ptr(fold_shift),
@@ -250,6 +294,11 @@ class ConvRunner:
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
         st = stream()
+        if self.uses_zm():
+            assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY), \
+                "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
+                "affine-on-load, statistics mode and activation must be what was promised"
+            return self._run_zm(a, x_planar, batch, stats is not None, st)
         for s in self.subs:
             sub = s["sub"]
             t = sub.tile
@@ -284,6 +333,23 @@ def wgrad_dma_ok(cpi, cpo, dtype):
     return bool(USE_DMA and dtype == L.SP_BF16 and cpi % 16 == 0 and cpo % 16 == 0
                 and -(-cpo // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "4"))
                 and -(-cpi // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))
+
+
+def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
+    op, z = runner.op, runner.zm
+    sub = op.subs[0]
+    a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"]), None, ptr(z["ktab_d"])
+    a.Do, a.Ho, a.Wo = sub.out_dims
+    a.osD, a.osH, a.osW = 1, 1, 1
+    a.ooD, a.ooH, a.ooW = 0, 0, 0
+    a.o0D, a.o0H, a.o0W = sub.o0
+    a.MT, a.NT, a.NTtot = z["MT"], z["NT"], z["NT"]
+    a.dma, a.persist, a.zfill = 1, 5, 0
+    a.octs_per_group, a.ngroups, a.opp, a.vsb = 2 * z["P"], 1, 2, 32
+    a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
+    with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s zm%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)),
+                                                                    " +stats" if with_stats else "")):
+        L.call("sp_conv3d_zm", C.byref(a), ptr(zero_page(runner.device)), st)
 
 
 class WgradRunner:
@@ -419,8 +485,8 @@ def prep_batch(pairs):
     # the cached device table holds raw addresses only: key it on every address it contains, so an entry can only be
     # replayed for runners that own exactly those buffers (ids / addresses recycled after an engine was freed)
     tkey = tuple((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, r.op.nttot) +
-                 tuple((sub["kmap"].data_ptr(), sub["nsteps"], sub["hi"].data_ptr(), 0 if sub["lo"] is None else sub["lo"].data_ptr(),
-                        0 if sub.get("ktab_zr") is None else sub["hi_zr"].data_ptr()) for sub in r.subs)
+                 tuple((k.data_ptr(), n, h.data_ptr(), 0 if lo_ is None else lo_.data_ptr(), nt_) for k, n, h, lo_, nt_ in r._pack()) +
+                 tuple((0 if sub.get("ktab_zr") is None else sub["hi_zr"].data_ptr()) for sub in r.subs)
                  for r, w, _ in todo)
     tab = _prep_tables.get(tkey)
     if tab is None:
@@ -429,9 +495,10 @@ def prep_batch(pairs):
         items = []
         for r, w, _ in todo:
             assert w.dtype == torch.float32 and w.is_contiguous()
-            for sub in r.subs:
-                items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, sub["kmap"].data_ptr(), sub["nsteps"],
-                              r.op.nttot, sub["hi"].data_ptr(), 0 if sub["lo"] is None else sub["lo"].data_ptr(), 0))
+            for kmap, nsteps, hi, lo, nttot in r._pack():
+                items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, kmap.data_ptr(), nsteps,
+                              nttot, hi.data_ptr(), 0 if lo is None else lo.data_ptr(), 0))
+            for sub in ([] if r.uses_zm() else r.subs):
                 if sub.get("ktab_zr") is not None:
                     items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, sub["kmap_zr"].data_ptr(), 15,
                                   r.op.nttot, sub["hi_zr"].data_ptr(), 0, 0))

@@ -349,3 +349,50 @@ def _finish(op: ConvOp):
 def wgrad_taps(k, transposed_roles=False):
     k = _triple(k)
     return [(a, b, c, (a * k[1] + b) * k[2] + c) for a in range(k[0]) for b in range(k[1]) for c in range(k[2])]
+
+
+# ------------------------------------------------------------------------------------------------ z-marching plan
+# Output-stationary z-marching kernel (csrc/sp_conv_zm.hip): (P input planes of 16 channels, NT output tiles of 16) ->
+# (MT rows per wave, ring slots, NW waves per workgroup).  Mirrors sp_conv3d_zm_config (tests/test_cabi.py checks that the
+# two agree).  Default: eight waves (two per SIMD -- one wave's epilogue / DMA / LDS instructions issue under its partner's
+# MFMAs), four for three input planes; SP_ZM_NW=4: four waves with twice the rows each everywhere (read on both sides; A/B runs).
+ZM_CONFIGS_NW4 = {(1, 1): (8, 3, 4), (1, 2): (4, 3, 4), (1, 3): (4, 3, 4), (2, 1): (8, 3, 4), (2, 2): (4, 3, 4), (3, 1): (4, 3, 4)}
+ZM_CONFIGS_DEFAULT = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (1, 3): (2, 3, 8), (2, 1): (4, 3, 8), (2, 2): (2, 3, 8), (3, 1): (4, 3, 4)}
+ZM_CONFIGS = ZM_CONFIGS_NW4 if os.environ.get("SP_ZM_NW") == "4" else ZM_CONFIGS_DEFAULT
+ZM_ITW = 18
+
+
+def zm_plan(op: ConvOp):
+    """K tables of the z-marching kernel for a stride-1 3x3x3 op between whole 16-channel tiles, or None.
+
+    One input plane feeds the three output planes above it (taps dz = 0, 1, 2); the K loop of a step runs over the 18 P
+    in-plane octets (dy, dx, plane p, octet o) in that order, four per step:
+      ktab[s*4 + g]            byte offset of the octet inside a ring slot: ((p*ITH + dy)*18 + dx)*32 + o*16
+      kmap[(dz*KS + s)*4 + g]  (source tap << 16) | input octet for sp_conv_prep_weights, -1 for the padding octets
+    """
+    if op.dtype != 0 or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
+        return None
+    sub = op.subs[0]
+    if len(sub.taps) != 27 or tuple(sub.ext) != (3, 3, 3) or tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0):
+        return None
+    if op.cpi % 16 or op.cout % 16 or op.cin != op.cpi or op.cpo < op.cout:
+        return None
+    P_, NT = op.cpi // 16, op.cout // 16
+    if (P_, NT) not in ZM_CONFIGS:
+        return None
+    MT, nslot, nw = ZM_CONFIGS[(P_, NT)]
+    ith = nw * MT + 2
+    ks = (18 * P_ + 3) // 4
+    src = {(t[0], t[1], t[2]): t[3] for t in sub.taps}
+    ktab = np.zeros(ks * 4, dtype=np.int32)
+    kmap = np.full(3 * ks * 4, -1, dtype=np.int32)
+    for e in range(18 * P_):
+        t2d, rest = divmod(e, 2 * P_)
+        p, o = divmod(rest, 2)
+        dy, dx = divmod(t2d, 3)
+        ktab[e] = ((p * ith + dy) * ZM_ITW + dx) * 32 + o * 16
+        for dz in range(3):
+            kmap[dz * ks * 4 + e] = (src[(dz, dy, dx)] << 16) | (p * 2 + o)
+    for e in range(18 * P_, ks * 4):
+        ktab[e] = ktab[e - 2]                # zero-weight padding octets: any valid, conflict-free address
+    return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=nw * MT, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)

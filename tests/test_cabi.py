@@ -31,3 +31,18 @@ def test_version_and_error_text():
     rc = lib.sp_bn_stats(None, 0, 10, 8, None, None)
     assert rc == -1
     assert "sp_bn_stats" in L.last_error()
+
+
+def test_zm_config_matches_the_planner():
+    """sp_conv3d_zm_config (C side) and plan.ZM_CONFIGS (planner) describe the same kernels (no GPU needed: pure host code)"""
+    import ctypes as C
+    from stroke_prediction_amd.runtime import plan as P
+    lib = L.load()
+    for p in range(1, 8):
+        for nt in range(1, 8):
+            mt, ns, nw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            rc = lib.sp_conv3d_zm_config(p, nt, C.byref(mt), C.byref(ns), C.byref(nw))
+            if (p, nt) in P.ZM_CONFIGS:
+                assert rc == 0 and (mt.value, ns.value, nw.value) == P.ZM_CONFIGS[(p, nt)], (p, nt)
+            else:
+                assert rc != 0, (p, nt)

@@ -132,3 +132,65 @@ def test_tiles_fit_lds_for_all_reference_layers():
             assert op.subs[0].tile["read_cycles"] <= 4.5   # bank-conflict model: near conflict-free
             dop = P.conv_dgrad_op(ci, co, 3, 1, 0, (d, d, d), co, cpi, dtype=dt)
             assert dop.subs[0].tile["lds_bytes"] <= 160 * 1024
+
+
+def emulate_zm(op, zm, x_cl, w_flat):
+    """the z-marching kernel's view of its tables (csrc/sp_conv_zm.hip): input plane zi adds, for dz = 0..2, the in-plane
+    octets of every K step into output plane zi - dz; ktab gives the octet's position inside a ring slot, kmap the weight"""
+    sub = op.subs[0]
+    qd, qh, qw = sub.out_dims
+    Di, Hi, Wi = op.in_dims
+    ith, ks = zm["ITH"], zm["KS"]
+    y = torch.zeros((1, qd, qh, qw, op.cpo), dtype=torch.float64)
+    qy, qx = torch.meshgrid(torch.arange(qh), torch.arange(qw), indexing="ij")
+    for zi in range(sub.o0[0], sub.o0[0] + qd + 2):            # input planes the march visits
+        for dz in range(3):
+            zo = zi - sub.o0[0] - dz
+            if not (0 <= zo < qd) or not (0 <= zi < Di):
+                continue                                        # (out-of-volume planes arrive as zeros)
+            for e in range(ks * 4):
+                km = int(zm["kmap"][dz * ks * 4 + e])
+                if km < 0:
+                    continue
+                src, octet = km >> 16, km & 0xffff
+                off = int(zm["ktab"][e])
+                p, rem = divmod(off, ith * P.ZM_ITW * 32)
+                vox, r2 = divmod(rem, 32)
+                dy, dx = divmod(vox, P.ZM_ITW)
+                assert r2 % 16 == 0 and octet == p * 2 + r2 // 16, "kmap / ktab disagree on the channel octet"
+                assert dy < 3 and dx < 3
+                iy, ix = qy + sub.o0[1] + dy, qx + sub.o0[2] + dx
+                ok = (iy >= 0) & (iy < Hi) & (ix >= 0) & (ix < Wi)
+                xv = x_cl[0, zi][iy.clamp(0, Hi - 1), ix.clamp(0, Wi - 1)][..., octet * 8:octet * 8 + 8] * ok[..., None]
+                for j in range(8):
+                    ci = octet * 8 + j
+                    wv = torch.tensor([w_flat[co * op.w_sco + ci * op.w_sci + src] for co in range(op.cout)], dtype=torch.float64)
+                    y[0, zo, :, :, :op.cout] += xv[..., j:j + 1] * wv
+    return y
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (16, 48), (32, 16), (32, 32), (48, 16)])
+def test_z_marching_tables(cin, cout):
+    """forward and data gradient of a valid 3x3x3 convolution through the z-marching plan's tables"""
+    torch.manual_seed(cin + cout)
+    dims = (5, 6, 19)
+    x = torch.randn(1, cin, *dims, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(cout, cin, 3, 3, 3, dtype=torch.float64)
+    ref = F.conv3d(x, w)
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout)
+    zm = P.zm_plan(op)
+    assert zm is not None and (zm["P"], zm["NT"]) == (cin // 16, cout // 16) and zm["nsteps"] == 3 * zm["KS"]
+    y = emulate_zm(op, zm, to_cl(x.detach(), cin), w.reshape(-1).tolist())
+    torch.testing.assert_close(from_cl(y, cout), ref.detach(), rtol=1e-10, atol=1e-10)
+    dz = torch.randn_like(ref)
+    (gref,) = torch.autograd.grad(ref, x, dz)
+    dop = P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin)
+    zmd = P.zm_plan(dop)
+    assert zmd is not None and (zmd["P"], zmd["NT"]) == (cout // 16, cin // 16)
+    g = emulate_zm(dop, zmd, to_cl(dz, cout), w.reshape(-1).tolist())
+    torch.testing.assert_close(from_cl(g, cin), gref, rtol=1e-10, atol=1e-10)
+    # ring-slot geometry: every table offset lies inside the staged plane set
+    for z in (zm, zmd):
+        assert int(z["ktab"].max()) + 16 <= z["P"] * z["ITH"] * P.ZM_ITW * 32
+    assert P.zm_plan(P.conv_fwd_op(96, 32, 3, 1, 0, dims, 96, 32)) is None         # weight set too large: tiled kernel
+    assert P.zm_plan(P.conv_fwd_op(16, 24, 3, 2, 1, dims, 16, 24)) is None         # strided

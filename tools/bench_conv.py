@@ -38,7 +38,7 @@ for name, ci, co, d in LAYERS:
     line = "%-5s %3d->%-3d @%3d  %6.1f GF |" % (name, ci, co, d, gf)
     y = O.alloc_cl(B, op.y_dims, cpo, dt, DEV)
     if "fwd" in which:
-        r = O.ConvRunner(op, DEV)
+        r = O.ConvRunner(op, DEV, zm_batch=B if os.environ.get("ZM", "1") == "1" else None)
         st = torch.zeros(64, cpo, 2, dtype=torch.float64, device=DEV)
         if dt == L.SP_BF16 and os.environ.get("FOLD", "1") == "1":
             r.prep(w, torch.zeros(co, device=DEV), sc, sh)
@@ -46,15 +46,15 @@ for name, ci, co, d in LAYERS:
         else:
             r.prep(w, torch.zeros(co, device=DEV))
             t = timeit(lambda: r.run(x, y, B, sc, sh, L.ACT_LEAKY, 0.01, st, stats_nrep=64))
-        line += " fwd %7.1f us %6.1f TF/s (MT%d NT%d g%d lds%dK) |" % (t, gf / t * 1e3, op.subs[0].tile["MT"], op.nt, op.subs[0].tile["ngroups"], op.subs[0].tile["lds_bytes"] // 1024)
+        line += " fwd%s %7.1f us %6.1f TF/s (MT%d NT%d g%d lds%dK) |" % ("[zm]" if r.uses_zm() else "    ", t, gf / t * 1e3, op.subs[0].tile["MT"], op.nt, op.subs[0].tile["ngroups"], op.subs[0].tile["lds_bytes"] // 1024)
         tot["fwd"] = tot.get("fwd", 0) + t
     dz = torch.randn_like(y)
     if "dgrad" in which:
         dop = P.conv_dgrad_op(ci, co, 3, 1, 0, dims, cpo, cpi, dt)
-        dr = O.ConvRunner(dop, DEV); dr.prep(w)
+        dr = O.ConvRunner(dop, DEV, zm_batch=B if os.environ.get("ZM", "1") == "1" else None); dr.prep(w)
         g = O.alloc_cl(B, dims, cpi, dt, DEV)
         t = timeit(lambda: dr.run(dz, g, B))
-        line += " dgrad %7.1f us %6.1f TF/s |" % (t, gf / t * 1e3)
+        line += " dgrad%s %7.1f us %6.1f TF/s |" % ("[zm]" if dr.uses_zm() else "    ", t, gf / t * 1e3)
         tot["dgrad"] = tot.get("dgrad", 0) + t
     if "wgrad" in which:
         wg = O.WgradRunner(ci, co, 3, 1, 0, dims, op.y_dims, cpi, cpo, ci * 27, 27, dt, DEV)
