@@ -539,7 +539,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 4; unet4: 1)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 4; unet4: 2 -- BatchNorm training needs more than one sample, as Learner asserts)")
     ap.add_argument("--size", type=int, default=None, help="cubic input size (default 128; unet4: 256)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
     ap.add_argument("--workload", default="unet", choices=["unet", "cae", "unet-infer", "unet4"],
@@ -559,7 +559,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     args = ap.parse_args()
     if args.batch is None:
-        args.batch = 1 if args.workload == "unet4" else 4
+        args.batch = 2 if args.workload == "unet4" else 4
     if args.size is None:
         args.size = 256 if args.workload == "unet4" else 128
 

@@ -97,7 +97,8 @@ template <> struct ZmStore<float> {
 // from there, double-buffered against the MFMAs -- (MT + 3 NT) LDS reads feed 3 NT MT MFMAs, < 0.6 reads per MFMA.
 // STATS: per-channel sum / sum of squares of the output for the next BatchNorm (forward layers; data gradients skip the work).
 // NW: waves per workgroup (4, or 8 = two per SIMD: one wave's epilogue / DMA / LDS instructions issue under its partner's MFMAs).
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, typename TOUT>
+// ACTB: bias + LeakyReLU in the epilogue (forward layers); false: the accumulator is stored as it is (data gradients).
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, bool ACTB, typename TOUT>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -250,7 +251,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       const uint32_t msk = pm & rowok[m];                                                                         \
       _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
         float v[4];                                                                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); } \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
+          if (ACTB) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); }               \
+          else v[j] = acc[R_][n][m][j];                                                                           \
+        }                                                                                                         \
         ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                                 \
         if (STATS) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
@@ -396,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, bool ACTB>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
   constexpr int NCH = P * (NW * MT + 2) * 18 * 2;
@@ -418,11 +422,11 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   const int slots = slots_env_ > 0 ? slots_env_ : 256;               // resident workgroups: one per CU
   const unsigned grid = planes / 4 < (uint64_t)slots ? (unsigned)(planes / 4 > 0 ? planes / 4 : 1) : (unsigned)slots;
   if (a->dtype_out == SP_F32) {
-    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, float>;
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACTB, float>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
   } else {
-    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, bf16_t>;
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACTB, bf16_t>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
   }
@@ -432,8 +436,10 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
 
 template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW>
 static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
-  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true>(a, zeros, st);
-  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false>(a, zeros, st);
+  const bool plain = a->act == SP_ACT_NONE && a->bias == nullptr;      // data gradients: nothing to do but round and store
+  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true, true>(a, zeros, st);
+  if (plain) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, false>(a, zeros, st);
+  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, true>(a, zeros, st);
 }
 
 // (P, NT) -> rows per wave, ring slots, waves per workgroup; SP_EINVAL = no kernel.  runtime/plan.py (ZM_CONFIGS) must agree:

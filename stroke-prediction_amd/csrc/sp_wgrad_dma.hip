@@ -460,6 +460,8 @@ static int launch_wgrad_zs(const sp_wgrad_args* a, int COB, hipStream_t st) {
   return 1;
 }
 
+int sp_wgrad_zr_try(const sp_wgrad_args* a, hipStream_t st);   // sp_wgrad_zr.hip
+
 int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype == SP_BF16 && !a->in_scale && !a->dz_scale, "sp_conv3d_wgrad(dma): bf16, no affine on load");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->o0D <= 0 && a->o0H <= 0 && a->o0W <= 0 && a->o0D >= -2 && a->o0H >= -2 && a->o0W >= -2,
@@ -467,6 +469,11 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->ntap > 21 && a->ntap <= 28, "sp_conv3d_wgrad(dma): expects 22..28 taps (7 per wave)");
   SP_CHECK_ARG(a->Di - 2 * a->o0D == a->Do + a->kD - 1 && a->Hi - 2 * a->o0H == a->Ho + a->kH - 1 && a->Wi - 2 * a->o0W == a->Wo + a->kW - 1,
                "sp_conv3d_wgrad(dma): input / output extents do not match a stride-1 convolution with this padding");
+  // row-sliding z-marching variant (sp_wgrad_zr.hip): un-padded layers with per-workgroup partial blocks
+  {
+    const int rc = sp_wgrad_zr_try(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc <= 0) return rc;
+  }
   WgradDmaDev P;
   P.a = *a;
   int COB = a->CoT >= 4 ? 4 : (a->CoT >= 2 ? 2 : 1);
