@@ -150,20 +150,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
     }
     // issue(k): input plane z0 + k and dz plane z0 + k into slot k % NS.  Past the piece's last plane the previous
     // plane is fetched again (never read): every step issues the same NJ DMAs, which keeps the waits countable.
+    // one DMA of issue(k) at a time (j < NJX: input plane, else dz plane), so that the main loop can spread them between
+    // the MFMA groups of a step: a DMA costs 60-180 issue cycles that a burst of NJ of them would expose after the barrier
+    auto issue1 = [&](int j, int k, int slot) {
+      if (j < NJX) {
+        sp_dma16_nc(srcx[j < NJX ? j : 0], xring + slot * C::XSB + wave * 1024 + j * 4096);
+        srcx[j < NJX ? j : 0] += (k + 1 < nsteps) ? strx[j < NJX ? j : 0] : 0u;
+      } else {
+        const int jd = j < NJX ? 0 : j - NJX;
+        sp_dma16_nc(srcd[jd], dring + slot * C::DSB + wave * 1024 + jd * 4096);
+        srcd[jd] += (k + 1 < np) ? strd[jd] : 0u;
+      }
+    };
     auto issue = [&](int k, int slot) {
-      unsigned char* xd = xring + slot * C::XSB + wave * 1024;
-      unsigned char* dd = dring + slot * C::DSB + wave * 1024;
-      const bool advx = k + 1 < nsteps, advd = k + 1 < np;
 #pragma unroll
-      for (int j = 0; j < NJX; ++j) {
-        sp_dma16_nc(srcx[j], xd + j * 4096);
-        srcx[j] += advx ? strx[j] : 0u;
-      }
-#pragma unroll
-      for (int j = 0; j < NJD; ++j) {
-        sp_dma16_nc(srcd[j], dd + j * 4096);
-        srcd[j] += advd ? strd[j] : 0u;
-      }
+      for (int j = 0; j < NJ; ++j) issue1(j, k, slot);
     };
     bf16x8 A[3][RW];
 #pragma unroll
@@ -174,7 +175,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
     for (int s = 0; s < nsteps; ++s) {
       ZR_SYNC((D - 1) * NJ);                                 // step s landed (every wave's share); slot of step s - 1 is free
       const int sn = sl == 0 ? NS - 1 : sl - 1;              // (s + D) % NS == (s - 1) % NS
-      issue(s + D, sn);
       const unsigned char* ap = dring + sl * C::DSB + aoff;
       const unsigned char* bp = xring + sl * C::XSB + boff;
       if (s < np) {
@@ -184,12 +184,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
 #pragma unroll
         for (int r = 0; r < RW; ++r) A[0][r] = zfrag;
       }
+      constexpr int NG = RW + 2;                             // MFMA groups (input rows) of a step
+      // B fragments are double-buffered by hand: the reads of row yi + 1 are issued BEFORE the MFMAs of row yi (left
+      // alone, the scheduler re-uses one register set and waits for LDS at the head of every group)
+      bf16x8 bq[NG][3];
 #pragma unroll
-      for (int yi = 0; yi < RW + 2; ++yi) {
-        const unsigned char* brow = bp + yi * ZR_XW * ZR_VSB;
-        bf16x8 bf[3];
+      for (int dx = 0; dx < 3; ++dx) bq[0][dx] = zr_tr_read2(bp + dx * ZR_VSB + off0, bp + dx * ZR_VSB + off1);
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) bf[dx] = zr_tr_read2(brow + dx * ZR_VSB + off0, brow + dx * ZR_VSB + off1);
+      for (int yi = 0; yi < NG; ++yi) {
+        if (yi + 1 < NG) {
+          const unsigned char* brow = bp + (yi + 1) * ZR_XW * ZR_VSB;
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) bq[yi + 1][dx] = zr_tr_read2(brow + dx * ZR_VSB + off0, brow + dx * ZR_VSB + off1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this group's share of the step's DMAs (the slot they fill was released by the barrier above)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          if (j * NG / NJ == yi) issue1(j, s + D, sn);
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
           const int yl = yi - dy;
@@ -198,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
             for (int dzz = 0; dzz < 3; ++dzz)
 #pragma unroll
               for (int dx = 0; dx < 3; ++dx)
-                acc[dzz][dy][dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[dzz][yl], bf[dx], acc[dzz][dy][dx], 0, 0, 0);
+                acc[dzz][dy][dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[dzz][yl], bq[yi][dx], acc[dzz][dy][dx], 0, 0, 0);
           }
         }
       }
