@@ -578,14 +578,33 @@ __device__ __forceinline__ void raw_get2(const RawOct<float>& r, f2_t* v) {
 __device__ __forceinline__ void st8_f2(bf16_t* p, const f2_t* v) {
   uint32_t w[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(v[i].x) | ((uint32_t)f2bf(v[i].y) << 16);
+  for (int i = 0; i < 4; ++i) w[i] = sp_pack_bf16x2(v[i].x, v[i].y);
   *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ __forceinline__ void st8_f2(float* p, const f2_t* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
 }
-__device__ __forceinline__ f2_t round_like(const bf16_t*, f2_t v) { f2_t r = {bf2f(f2bf(v.x)), bf2f(f2bf(v.y))}; return r; }
+__device__ __forceinline__ f2_t round_like(const bf16_t*, f2_t v) {      // one packed conversion, two bit operations
+  const uint32_t u = sp_pack_bf16x2(v.x, v.y);
+  f2_t r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  return r;
+}
+// store eight values and return them as stored (what the statistics must see): bf16 converts each pair ONCE
+__device__ __forceinline__ void st8_f2_rounded(bf16_t* p, f2_t* v) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i] = sp_pack_bf16x2(v[i].x, v[i].y);
+    f2_t r = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+    v[i] = r;
+  }
+  *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ void st8_f2_rounded(float* p, f2_t* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+}
 __device__ __forceinline__ f2_t round_like(const float*, f2_t v) { return v; }
 
 // Upsample + crop + concat in ONE pass (Unet3D.py:67-72): every voxel row of the concat buffer (all CPd channels) is
@@ -690,6 +709,105 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
   }
   if (stats) block_channel_reduce<2>(part, oc, active, CPd, stats, red);
 }
+// ---- plane-major output, row-ordered variant.  The block-per-thread kernel above writes 16-byte pieces 64 bytes apart
+// (a lane's eight voxels are its own 2x2x2 block; neighbouring lanes are other channel octets = other planes): 140 us for
+// the 424 MB of the last concat, 3 TB/s.  Here blockIdx.y is the 16-channel plane and consecutive lanes are consecutive
+// (output x, channel half) pairs, so every store instruction of a wave writes 1 KB of one output row; a thread produces
+// the four outputs (2 z x 2 y) above its output x from 3 x 3 x 2 source octets (neighbouring lanes share them in L1).
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
+                                                          Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane,
+                                                          double* __restrict__ stats) {
+  __shared__ float red[32];
+  const int p = blockIdx.y, nup = CPu >> 4;
+  const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
+  const int oz = (ds.D - Do) / 2, oy = (ds.H - Ho) / 2, ox = (ds.W - Wo) / 2;
+  const int64_t total = (int64_t)dl.B * dl.D * dl.H * Wo * 2;
+  const int64_t chunk = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+  const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(total, i0 + chunk);
+  const int half = threadIdx.x & 1;                   // chunk and stride are even: a thread keeps its channel half
+  const FastDiv d_w2 = make_fastdiv(Wo * 2), d_h = make_fastdiv(dl.H), d_d = make_fastdiv(dl.D);
+  f2_t s1[4], s2[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s1[j] = s2[j] = f2_splat(0.f);
+  T* const cp = cat + (int64_t)p * cat_plane + half * 8;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    uint32_t r = fdiv((uint32_t)i, d_w2);
+    const int xo = ((uint32_t)i - r * (Wo * 2)) >> 1;
+    uint32_t q = fdiv(r, d_h); const int yl = r - q * dl.H;
+    r = fdiv(q, d_d); const int zl = q - r * dl.D; const int b = r;
+    f2_t out[4][4];                                     // [zo*2 + yo][channel pair]
+    if (p < nup) {
+      const int xi = xo >> 1, odd = xo & 1;
+      const int xa = max(odd ? xi : xi - 1, 0), xb = min(odd ? xi + 1 : xi, dl.W - 1);
+      const f2_t wa = f2_splat(odd ? 0.75f : 0.25f), wb = f2_splat(odd ? 0.25f : 0.75f);
+      const int ys[3] = {max(yl - 1, 0), yl, min(yl + 1, dl.H - 1)};
+      const int zs[3] = {max(zl - 1, 0), zl, min(zl + 1, dl.D - 1)};
+      const T* base = low + p * 16 + half * 8;
+      f2_t ye[3][4], yo[3][4];                          // per source plane: even / odd output row
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) {
+        f2_t v[3][4];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+          const T* row = base + (((int64_t)b * dl.D + zs[dz]) * dl.H + ys[dy]) * dl.W * CPu;
+          RawOct<T> ra, rb;
+          ra.load(row + (int64_t)xa * CPu); rb.load(row + (int64_t)xb * CPu);
+          f2_t a[4], c[4];
+          raw_get2(ra, a); raw_get2(rb, c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[dy][j] = f2_fma(wa, a[j], wb * c[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f2_t m = v[1][j] * 0.75f;
+          ye[dz][j] = f2_fma(f2_splat(0.25f), v[0][j], m);
+          yo[dz][j] = f2_fma(f2_splat(0.25f), v[2][j], m);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f2_t me = ye[1][j] * 0.75f, mo = yo[1][j] * 0.75f;
+        out[0][j] = f2_fma(f2_splat(0.25f), ye[0][j], me); out[1][j] = f2_fma(f2_splat(0.25f), yo[0][j], mo);
+        out[2][j] = f2_fma(f2_splat(0.25f), ye[2][j], me); out[3][j] = f2_fma(f2_splat(0.25f), yo[2][j], mo);
+      }
+    } else {
+      const T* base = skip + (p - nup) * 16 + half * 8;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        RawOct<T> rr;
+        rr.load(base + ((((int64_t)b * ds.D + 2 * zl + (k >> 1) + oz) * ds.H + 2 * yl + (k & 1) + oy) * ds.W + xo + ox) * CPs);
+        raw_get2(rr, out[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t vo = (((int64_t)b * Do + 2 * zl + (k >> 1)) * Ho + 2 * yl + (k & 1)) * Wo + xo;
+      st8_f2_rounded(cp + vo * 16, out[k]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += out[k][j]; s2[j] = f2_fma(out[k][j], out[k][j], s2[j]); }
+    }
+  }
+  if (stats) {       // channel c = p*16 + half*8 + 2j + {0,1}: lanes of one parity hold the same eight channels
+    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v4[4] = {s1[j].x, s2[j].x, s1[j].y, s2[j].y};         // (sum, sum^2) of channel 2j, then of channel 2j + 1
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float v = v4[k];
+#pragma unroll
+        for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) < 2) atomicAdd(&red[(half * 8 + 2 * j + (k >> 1)) * 2 + (k & 1)], v);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32)
+      atomicAdd(&stats[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CPd * 2 + (size_t)p * 32 + threadIdx.x], (double)red[threadIdx.x]);
+  }
+}
+
 extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                                          int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
                                          int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream) {
@@ -700,6 +818,16 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
   SP_CHECK_ARG(cat_plane == 0 || CPd % 16 == 0, "sp_upsample2_crop_cat_fwd: plane-major output needs whole 16-channel planes");
   OctMap om = make_octmap(CPd);
   Dims dl{B, D, H, W}, ds{B, Ds, Hs, Ws};
+  if (cat_plane && CPu % 16 == 0 && CPs % 16 == 0 && (int64_t)B * D * H * W * 4 < (1ll << 31) && !getenv("SP_UPCAT_BLOCKS")) {
+    const int64_t total = (int64_t)B * D * H * W * 4;     // (output x, channel half) pairs over the source rows
+    const int64_t want = (total + 1023) / 1024, cap = 2048 / (CPd / 16) + 1;
+    const unsigned gx = (unsigned)(want < cap ? want : cap);
+    dim3 grid(gx, CPd / 16);
+    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats);
+    else hipLaunchKernelGGL(upcat_rows_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, stats);
+    SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd(rows)");
+    return SP_OK;
+  }
   const int64_t nblk = (int64_t)B * D * H * W;          // one thread-slot per 2x2x2 output block
   const unsigned grid = grid_for(nblk, om.vpb);
   const size_t sh = (size_t)CPd * 2 * sizeof(float);
@@ -1072,6 +1200,222 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
   if (dbias) block_channel_reduce<1>(part, oc, true, CP, dbias, red);
 }
 
+// ---- ring variant of the tiled kernel (bf16, 16 / 32 / 64 channels).  The tiled kernel above stages a plane pair with
+// ordinary loads and waits for them at a barrier before every reduction: 1.8 TB/s (135 us for the 32-channel part of the
+// last concat gradient, 75 us for the 64-channel one).  Here the planes stream through a RING of four LDS slots filled by
+// LDS-DMA three planes ahead (counted s_waitcnt, one barrier per plane, border chunks by clamped addresses exactly as
+// above), the y patch through two slots of its own, and the work -- (column, input plane) pairs -- is cut into gridDim.x
+// equal pieces like the weight-gradient kernels do, so one workgroup per CU (the ring fills most of the LDS) still ends
+// the launch together.  Arithmetic and summation order are those of the tiled kernel.
+template <int OCT, int ACT>
+__global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ g,
+                                                                      const float* __restrict__ coef, int CPcat, int cstride,
+                                                                      Dims di, int nby, int nbx, int act, float ap,
+                                                                      bf16_t* __restrict__ dz, double* __restrict__ dbias) {
+  constexpr int CP = OCT * 8, TX = 16, TY = 256 / (16 * OCT), RY = 2 * TY + 2, RX = 2 * TX + 2;
+  constexpr int NCH = RY * RX * OCT, NJ = (NCH + 255) / 256, PSB = NJ * 4096;          // plane slot
+  constexpr int NYC = (TY + 2) * (TX + 2) * OCT, NJY = (NYC + 255) / 256, YSB = NJY * 4096;
+  constexpr int NS = 4, DP = 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* pring = smem;
+  unsigned char* yring = smem + NS * PSB;
+  float* red = nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pos = tid / OCT, oc = tid - pos * OCT;
+  const int ty = pos / TX, tx = pos - ty * TX;
+  const int D = di.D, H = di.H, W = di.W, Do = 2 * D, Ho = 2 * H, Wo = 2 * W;
+  float c0[8], c1[8], c2[8], part[1][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = oc * 8 + j;
+    c0[j] = coef[c]; c1[j] = coef[cstride + c]; c2[j] = 8.f * coef[2 * cstride + c];
+    part[0][j] = 0.f;
+  }
+  const int64_t gplane_b = (int64_t)Ho * Wo * CPcat * 2, yplane_b = (int64_t)H * W * CP * 2;
+  const uint32_t ncols = (uint32_t)di.B * nby * nbx;
+  const uint64_t T = (uint64_t)ncols * D;
+  uint64_t wpos = T * blockIdx.x / gridDim.x;
+  const uint64_t wend = T * (blockIdx.x + 1) / gridDim.x;
+  while (wpos < wend) {
+    const uint32_t col = (uint32_t)(wpos / (uint32_t)D);
+    const int z0 = (int)(wpos - (uint64_t)col * D);
+    const int z1 = (int)min((uint64_t)D, (uint64_t)z0 + (wend - wpos));
+    wpos += (uint64_t)(z1 - z0);
+    const int bx = col % nbx, by = (col / nbx) % nby, b = col / (nbx * nby);
+    const int y0 = by * TY, x0 = bx * TX;
+    const int yy = y0 + ty, xx = x0 + tx;
+    const bool valid = yy < H && xx < W;
+    const int yc_ = min(yy, H - 1), xc_ = min(xx, W - 1);
+    int oy[4], ox[4]; float wy[4], wx[4];
+    upT_axis(yc_, H, oy, wy); upT_axis(xc_, W, ox, wx);
+    const float myc = upM_diag(yc_, H), mxc = upM_diag(xc_, W);
+    const float my[3] = {yc_ >= 1 ? 0.375f : 0.f, myc, yc_ < H - 1 ? 0.375f : 0.f};
+    const float mx[3] = {xc_ >= 1 ? 0.375f : 0.f, mxc, xc_ < W - 1 ? 0.375f : 0.f};
+    // per-lane DMA plans of this column: byte offsets inside a plane (clamped coordinates carry zero weight)
+    uint32_t relp[NJ], rely[NJY];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      int c = (wave + 4 * j) * 64 + lane;
+      c = c < NCH ? c : NCH - 1;
+      const int vi = c / OCT, o_ = c - vi * OCT, vy = vi / RX, vx = vi - vy * RX;
+      const int gy = min(max(2 * y0 - 1 + vy, 0), Ho - 1), gx = min(max(2 * x0 - 1 + vx, 0), Wo - 1);
+      relp[j] = (uint32_t)(((gy * Wo + gx) * CPcat + o_ * 8) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < NJY; ++j) {
+      int c = (wave + 4 * j) * 64 + lane;
+      c = c < NYC ? c : NYC - 1;
+      const int vi = c / OCT, o_ = c - vi * OCT, vy = vi / (TX + 2), vx = vi - vy * (TX + 2);
+      const int sy = min(max(y0 - 1 + vy, 0), H - 1), sx = min(max(x0 - 1 + vx, 0), W - 1);
+      rely[j] = (uint32_t)(((sy * W + sx) * CP + o_ * 8) * 2);
+    }
+    const unsigned char* gb_ = reinterpret_cast<const unsigned char*>(g) + (int64_t)b * Do * gplane_b;
+    const unsigned char* yb_ = reinterpret_cast<const unsigned char*>(y) + (int64_t)b * D * yplane_b;
+    // steps s = 0 .. S-1 handle m = z0 - 2 + s; planes j = 0 .. 2(S-1)-1 belong to step 1 + j/2 (output planes 2m+1, 2m+2);
+    // the y plane of step s (input plane m + 1) travels with plane j = 2s - 1, the one of step 0 alone in the prologue
+    const int S = z1 - z0 + 2;
+    auto issue_plane = [&](int j) {                       // plane j of the sequence into slot j & 3 (+ a y plane when j is odd)
+      const int m = z0 - 1 + (j >> 1);
+      const int zo = min(max(2 * m + 1 + (j & 1), 0), Do - 1);
+      const unsigned char* src = gb_ + (int64_t)zo * gplane_b;
+      unsigned char* dst = pring + (j & (NS - 1)) * PSB + wave * 1024;
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) sp_dma16_nc(src + relp[k], dst + k * 4096);
+      if (j & 1) {
+        const int s = (j + 1) >> 1;
+        const int zy = min(max(z0 - 2 + s + 1, 0), D - 1);
+        const unsigned char* ys = yb_ + (int64_t)zy * yplane_b;
+        unsigned char* yd = yring + (s & 1) * YSB + wave * 1024;
+#pragma unroll
+        for (int k = 0; k < NJY; ++k) sp_dma16_nc(ys + rely[k], yd + k * 4096);
+      }
+    };
+    float Acur[8], Anext[8], qprev[8], qcur[8], qnext[8], ycur[8], ynext[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Acur[j] = Anext[j] = qprev[j] = qcur[j] = qnext[j] = ycur[j] = ynext[j] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                        // the previous piece's slots are consumed
+    {
+      const int zy = min(max(z0 - 1, 0), D - 1);            // y plane of step 0
+      const unsigned char* ys = yb_ + (int64_t)zy * yplane_b;
+#pragma unroll
+      for (int k = 0; k < NJY; ++k) sp_dma16_nc(ys + rely[k], yring + wave * 1024 + k * 4096);
+    }
+    issue_plane(0); issue_plane(1); issue_plane(2);
+    for (int s = 0; s < S; ++s) {
+      const int m = z0 - 2 + s;
+      const bool yplane = m + 1 >= 0 && m + 1 < D;
+      float P1[8], P2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) P1[j] = P2[j] = 0.f;
+      if (s == 0) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ + NJY) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = 2 * (s - 1) + h;
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ + NJY) : "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          issue_plane(j + DP);
+          const bf16_t* gb = reinterpret_cast<const bf16_t*>(pring + (j & (NS - 1)) * PSB);
+#pragma unroll 1
+          for (int bb = 0; bb < 4; ++bb) {
+            const float wyb = bb == 0 ? wy[0] : (bb == 1 ? wy[1] : (bb == 2 ? wy[2] : wy[3]));
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+              const float w = wyb * wx[cc];
+              float a8[8];
+              Store<bf16_t>::ld8(gb + ((2 * ty + bb) * RX + 2 * tx + cc) * CP + oc * 8, a8);
+              if (h == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) P1[q] = fmaf(w, a8[q], P1[q]);
+              } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) P2[q] = fmaf(w, a8[q], P2[q]);
+              }
+            }
+          }
+        }
+        int oz[4]; float wz[4], wn[4];
+        upT_axis(max(m, 0), D, oz, wz);
+        upT_axis(min(m + 1, D - 1), D, oz, wn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          Acur[j] += wz[2] * P1[j] + wz[3] * P2[j];
+          Anext[j] = wn[0] * P1[j] + wn[1] * P2[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qnext[j] = ynext[j] = 0.f;
+      if (yplane) {
+        const bf16_t* yb = reinterpret_cast<const bf16_t*>(yring + (s & 1) * YSB);
+#pragma unroll 1
+        for (int dy = 0; dy < 3; ++dy) {
+          const float myd = dy == 0 ? my[0] : (dy == 1 ? my[1] : my[2]);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const float w = myd * mx[dx];
+            float v8[8];
+            Store<bf16_t>::ld8(yb + ((ty + dy) * (TX + 2) + tx + dx) * CP + oc * 8, v8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qnext[j] = fmaf(w, v8[j], qnext[j]);
+            if (dy == 1 && dx == 1) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) ynext[j] = v8[j];
+            }
+          }
+        }
+      }
+      if (m >= z0) {
+        const float mzc = upM_diag(m, D);
+        const float mzl = m >= 1 ? 0.375f : 0.f, mzr = m < D - 1 ? 0.375f : 0.f;
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float my_ = mzl * qprev[j] + mzc * qcur[j] + mzr * qnext[j];
+          o8[j] = (c0[j] * Acur[j] + c1[j] * my_ + c2[j]) * act_bwd_t<ACT>(act, ap, ycur[j]);
+        }
+        if (valid) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) part[0][j] += o8[j];
+          Store<bf16_t>::st8(dz + ((((size_t)b * D + m) * H + yy) * W + xx) * CP + oc * 8, o8);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Acur[j] = Anext[j]; qprev[j] = qcur[j]; qcur[j] = qnext[j]; ycur[j] = ynext[j];
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (dbias) block_channel_reduce<1>(part, oc, true, CP, dbias, red);
+}
+
+template <int OCT>
+static int launch_up_bwd_ring(const void* y, const void* g, const float* coef, int CPcat, int cstride, Dims di, int act, float ap,
+                              void* dz, double* dbias, hipStream_t st) {
+  constexpr int TY = 256 / (16 * OCT), NJ = ((2 * TY + 2) * 34 * OCT + 255) / 256, NJY = ((TY + 2) * 18 * OCT + 255) / 256;
+  const int lds = 4 * NJ * 4096 + 2 * NJY * 4096;
+  const int nby = (di.H + TY - 1) / TY, nbx = (di.W + 15) / 16;
+  const int64_t T = (int64_t)di.B * nby * nbx * di.D;
+  const unsigned grid = (unsigned)(T < 256 ? T : 256);
+#define SP_L(A_)                                                                                                       \
+  {                                                                                                                    \
+    auto kern = upsample2_act_bwd_ring_kernel<OCT, A_>;                                                                \
+    SP_ENSURE_LDS(kern, lds, "sp_upsample2_act_bwd");                                                                  \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, cstride, di, nby, nbx, \
+                       act, ap, (bf16_t*)dz, dbias);                                                                   \
+  }
+  SP_ACT_DISPATCH(act, SP_L)
+#undef SP_L
+  SP_CHECK_LAUNCH("sp_upsample2_act_bwd(ring)");
+  return SP_OK;
+}
+
 extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
                                     int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
@@ -1080,6 +1424,12 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
   SP_CHECK_VOX((int64_t)B * D * H * W * 8, "sp_upsample2_act_bwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
+  if (dtype == SP_BF16 && (CP == 16 || CP == 32 || CP == 64) && D >= 2 && H >= 2 && W >= 2 && (int64_t)4 * H * W * CPcat * 2 < (1ll << 31) &&
+      !getenv("SP_UPSAMPLE_BWD_TILED") && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
+    if (CP == 16) return launch_up_bwd_ring<2>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, ST(stream));
+    if (CP == 32) return launch_up_bwd_ring<4>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, ST(stream));
+    return launch_up_bwd_ring<8>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, ST(stream));
+  }
   if (256 % om.OC == 0 && D >= 2 && H >= 2 && W >= 2 && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
     // tiled path: TY x TX input columns per workgroup, z split into chunks so that ~3 workgroups per CU exist
     UpTile ut;

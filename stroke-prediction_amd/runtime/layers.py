@@ -330,7 +330,7 @@ class FirstConvLayer(ConvLayer):
             return
         self.dz = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.dtype, self.device)
         vox = self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
-        self.nparts = max(8, min(int(os.environ.get("SP_FIRST_WGRAD_BLOCKS", "1024")), vox // 8192))
+        self.nparts = max(8, min(int(os.environ.get("SP_FIRST_WGRAD_BLOCKS", "1024")), vox // int(os.environ.get("SP_FIRST_WGRAD_MINVOX", "8192"))))
         self.partials = torch.empty(self.nparts * 27 * 16 * 2, dtype=torch.float32, device=self.device)
         self.tapsrc = torch.arange(27, dtype=torch.int32, device=self.device)
         self.coef = torch.zeros(3, self.cpi, device=self.device)

@@ -270,6 +270,37 @@ def test_row_sliding_weight_gradient_matches_autograd(cin, cout, dims, B, planar
     torch.testing.assert_close(got["1"], got["0"], rtol=1e-4, atol=1e-4 * scale)
 
 
+@pytest.mark.parametrize("C0,C1,ldims,B", [(32, 16, (5, 7, 9), 2), (64, 32, (3, 4, 6), 1), (16, 16, (2, 2, 2), 3)])
+def test_row_ordered_upsample_crop_concat(C0, C1, ldims, B):
+    """sp_upsample2_crop_cat_fwd with a plane-major output (upcat_rows_kernel: one 16-channel plane per blockIdx.y, lanes
+    along the output row) against F.interpolate + crop + cat (Unet3D.py:67-72), with the statistics of every channel."""
+    g = torch.Generator().manual_seed(C0 + C1)
+    low = bf(torch.randn(B, C0, *ldims, generator=g))
+    sdims = tuple(2 * d + 4 + 2 * (i % 2) for i, d in enumerate(ldims))
+    skip = bf(torch.randn(B, C1, *sdims, generator=g))
+    cdims = tuple(2 * d for d in ldims)
+    off = [(sdims[a] - cdims[a]) // 2 for a in range(3)]
+    ref = torch.cat((F.interpolate(low, scale_factor=2, mode="trilinear", align_corners=False),
+                     skip[:, :, off[0]:off[0] + cdims[0], off[1]:off[1] + cdims[1], off[2]:off[2] + cdims[2]]), 1)
+    lows, skips = _to_cl(low, C0), _to_cl(skip, C1)
+    cat = O.alloc_cl(B, cdims, C0 + C1, L.SP_BF16, DEV)
+    cat.fill_(3.0)
+    st = O.reduce_rows(C0 + C1, 2, DEV)
+    O.upsample2_crop_cat_fwd(lows, skips, cat, L.SP_BF16, st, planar=True)
+    np_ = (C0 + C1) // 16
+    got_cl = cat.view(np_, B, *cdims, 16).permute(1, 2, 3, 4, 0, 5).reshape(B, *cdims, C0 + C1).contiguous()
+    got = _from_cl(got_cl, C0 + C1)
+    torch.testing.assert_close(got, ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(got[:, C0:], ref[:, C0:], rtol=0, atol=0)           # the crop is a copy
+    st = st.sum(0).cpu()
+    torch.testing.assert_close(st[:, 0], got.double().sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(st[:, 1], (got.double() ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-3)
+    # the channels-last (block-per-thread) kernel computes the same tensor up to the last bf16 bit
+    cat2 = O.alloc_cl(B, cdims, C0 + C1, L.SP_BF16, DEV)
+    O.upsample2_crop_cat_fwd(lows, skips, cat2, L.SP_BF16, None, planar=False)
+    torch.testing.assert_close(_from_cl(cat2, C0 + C1), got, rtol=8e-3, atol=1e-3)
+
+
 # ------------------------------------------------------------------------------------------------ multi-step fixtures
 def _build(ch, seed, dtype, cls=Unet3D):
     model = cls(ch, dtype=dtype)
