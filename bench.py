@@ -213,8 +213,8 @@ def dryrun(args, world, rank):
         dist.all_reduce(seen)
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "train-step voxels/sec, 3D U-Net Bx2x128^3", "value": 0.0, "unit": "voxels/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "dryrun": True, "ranks_seen": int(seen.item())}))
+        emit_line({"metric": "train-step voxels/sec, 3D U-Net Bx2x128^3", "value": 0.0, "unit": "voxels/s", "n_gpus": world,
+                   "steps": args.steps, "warmup": args.warmup, "dryrun": True, "ranks_seen": int(seen.item())})
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -318,11 +318,24 @@ def init_dist(world, dev):
             dist.init_process_group("nccl", device_id=dev)
 
 
+_STDOUT_FD = None
+
+
+def emit_line(res):
+    """the ONE JSON line, on the real stdout (main() parks file descriptor 1 on stderr for everything else)"""
+    sys.stdout.flush()
+    if _STDOUT_FD is not None:
+        os.dup2(_STDOUT_FD, 1)
+    print(json.dumps(res))
+    sys.stdout.flush()
+    if _STDOUT_FD is not None:
+        os.dup2(2, 1)                           # communicator teardown may print as well
+
+
 def finish(res, rank):
     import torch.distributed as dist
     if rank == 0:
-        print(json.dumps(res))
-        sys.stdout.flush()
+        emit_line(res)
     if dist.is_initialized():
         dist.destroy_process_group()
     return 0
@@ -574,6 +587,12 @@ def main():
                          "bench.py start them)" % (args.gpus, world))
     if rank != 0:
         sys.stdout = open(os.devnull, "w")
+    # stdout carries the JSON line only: libraries that write to file descriptor 1 themselves (RCCL prints a banner --
+    # "ROCm version / Hostname / Librccl path" -- when a communicator is created) go to stderr until finish() prints
+    global _STDOUT_FD
+    sys.stdout.flush()
+    _STDOUT_FD = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("SP_BENCH_DRYRUN"):
         return dryrun(args, world, rank)
     # SP_BENCH_DEVICE / SP_BENCH_BACKEND: rehearsal of the multi-rank code path on a one-GPU box (all ranks on one
