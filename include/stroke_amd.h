@@ -120,6 +120,41 @@ int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
  * exists for the pair (a workgroup covers NW*MT x 16 output voxels per plane); returns SP_EINVAL when there is none */
 int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
 
+/* ------------------------------------------------------------------ self-sufficient entry points for the hot convolution
+ * nn.Conv3d(Cin, Cout, 3, stride 1, padding 0) of Block3x3x3 (Unet3D.py:19,22) and its data gradient on the z-marching
+ * kernel, for callers that have this header and nothing else (no runtime/plan.py): describe the layer, ask for the plan
+ * (workspace size, output extents), allocate `workspace_bytes` of device memory, init once, set weights whenever they
+ * change, run.  Tensors are bf16 channels-last [B][D][H][W][C] with C a multiple of 16 (zero-padded channels).
+ *   grad = 0: x = [B][D][H][W][Cin]          -> y = [B][D-2][H-2][W-2][Cout]   y = act(conv(x, w) + bias)
+ *   grad = 1: x = dz [B][D-2][H-2][W-2][Cout] -> y = [B][D][H][W][Cin]          y = conv_transpose(dz, w)
+ * (D, H, W are always the extents of the convolution's INPUT).  Pairs (Cin/16, Cout/16) of the op without a kernel
+ * (sp_conv3d_zm_config) are refused by sp_conv3d_plan: those layers need sp_conv3d_igemm and a host-built tile plan. */
+typedef struct sp_conv3d_desc {
+  int32_t B, Cin, Cout, D, H, W;
+  int32_t grad;
+} sp_conv3d_desc;
+typedef struct sp_conv3d_plan_t {
+  int32_t cin_op, cout_op;             /* channels the op reads / writes (swapped for the data gradient) */
+  int32_t P, NT, MT, NW, NSLOT, KS, nsteps, ITH;
+  int32_t Di, Hi, Wi, Do, Ho, Wo, o0;  /* extents of x and y, input coordinate of (output 0, tap 0) */
+  int64_t x_elems, y_elems;            /* bf16 elements of x and y */
+  int64_t workspace_bytes;
+  int64_t off_zero, off_ktab, off_kmap, off_bias, off_wfrag;   /* layout of the workspace */
+} sp_conv3d_plan_t;
+int sp_conv3d_plan(const sp_conv3d_desc* d, sp_conv3d_plan_t* plan);                 /* host only */
+/* host only: the kernel's K tables, ktab[4*KS] and kmap[12*KS] (what sp_conv3d_init uploads; runtime/plan.py:zm_plan) */
+int sp_conv3d_tables(const sp_conv3d_desc* d, const sp_conv3d_plan_t* plan, int32_t* ktab, int32_t* kmap);
+int sp_conv3d_init(const sp_conv3d_desc* d, const sp_conv3d_plan_t* plan, void* workspace, sp_stream_t stream);
+/* w: fp32 [Cout][Cin][3][3][3] on the device (nn.Conv3d layout); bias [Cout] or NULL; bn_scale / bn_shift [Cin] or NULL:
+ * a BatchNorm in front of the convolution folded into weights and bias (exact: no padding).  grad = 1: w only. */
+int sp_conv3d_set_weights(const sp_conv3d_desc* d, const sp_conv3d_plan_t* plan, void* workspace, const float* w,
+                          const float* bias, const float* bn_scale, const float* bn_shift, sp_stream_t stream);
+/* act: SP_ACT_NONE or SP_ACT_LEAKY; stats: NULL or [stats_nrep][Cout][2] fp64 (sum, sum of squares) accumulators;
+ * x_plane: 0 for channels-last x, else elements per 16-channel plane of a plane-major x */
+int sp_conv3d_run(const sp_conv3d_desc* d, const sp_conv3d_plan_t* plan, const void* workspace, const void* x, void* y,
+                  int32_t with_bias, int32_t act, float act_param, double* stats, int32_t stats_nrep, int64_t x_plane,
+                  sp_stream_t stream);
+
 /* Re-pack fp32 weights into MFMA A-fragments in the plan's K order.
  * kmap[step*4+g] = (src_tap_index << 16) | cin_octet, or -1 for a padding octet.
  * element (co, ci, tap) is read from w[co*sCo + ci*sCi + tap]. */

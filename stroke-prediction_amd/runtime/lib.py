@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_wgrad_zr.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_wgrad_zr.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1
@@ -36,7 +36,22 @@ class WgradArgs(C.Structure):
                                    "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64), ("zs", i32)]
 
 
+class Conv3dDesc(C.Structure):       # sp_conv3d_desc
+    _fields_ = [(n, i32) for n in ("B", "Cin", "Cout", "D", "H", "W", "grad")]
+
+
+class Conv3dPlan(C.Structure):       # sp_conv3d_plan_t
+    _fields_ = [(n, i32) for n in ("cin_op", "cout_op", "P", "NT", "MT", "NW", "NSLOT", "KS", "nsteps", "ITH",
+                                   "Di", "Hi", "Wi", "Do", "Ho", "Wo", "o0")] + \
+               [(n, i64) for n in ("x_elems", "y_elems", "workspace_bytes", "off_zero", "off_ktab", "off_kmap", "off_bias", "off_wfrag")]
+
+
 _SIGS = {
+    "sp_conv3d_plan": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan)], i32),
+    "sp_conv3d_tables": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp], i32),
+    "sp_conv3d_init": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp], i32),
+    "sp_conv3d_set_weights": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp, vp, vp, vp, vp], i32),
+    "sp_conv3d_run": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp, vp, i32, i32, f32, vp, i32, i64, vp], i32),
     "sp_version": ([], i32),
     "sp_surface_distances": ([vp, vp, f32, i32, vp, vp, vp, vp], i32),
     "sp_gaussian_filter3d": ([vp, vp, vp, i32, i32, i32, f32, f32, vp], i32),

@@ -46,3 +46,38 @@ def test_zm_config_matches_the_planner():
                 assert rc == 0 and (mt.value, ns.value, nw.value) == P.ZM_CONFIGS[(p, nt)], (p, nt)
             else:
                 assert rc != 0, (p, nt)
+
+
+def test_conv3d_plan_tables_match_the_planner():
+    """sp_conv3d_plan / sp_conv3d_tables (the header-only caller's route to the z-marching kernel) build the same K tables
+    as runtime/plan.py:zm_plan does for the Python host side, forward and data gradient (pure host code: no GPU)"""
+    import ctypes as C
+    import numpy as np
+    from stroke_prediction_amd.runtime import plan as P
+    lib = L.load()
+    for cin, cout in ((16, 16), (16, 32), (32, 16), (32, 32), (48, 16), (16, 48)):
+        for grad in (0, 1):
+            dims = (20, 22, 40)
+            d = L.Conv3dDesc(2, cin, cout, *dims, grad)
+            pl = L.Conv3dPlan()
+            op = (P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin, 0) if grad else
+                  P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, 0))
+            z = P.zm_plan(op)
+            rc = lib.sp_conv3d_plan(C.byref(d), C.byref(pl))
+            if z is None:
+                assert rc != 0, (cin, cout, grad)
+                continue
+            assert rc == 0, L.last_error()
+            assert (pl.P, pl.NT, pl.MT, pl.NW, pl.KS, pl.nsteps, pl.ITH) == (z["P"], z["NT"], z["MT"], z["NW"], z["KS"], z["nsteps"], z["ITH"])
+            assert (pl.Do, pl.Ho, pl.Wo) == tuple(op.subs[0].out_dims) and (pl.o0,) * 3 == tuple(op.subs[0].o0)
+            assert (pl.Di, pl.Hi, pl.Wi) == tuple(op.in_dims)
+            ktab = np.zeros(4 * pl.KS, np.int32); kmap = np.zeros(12 * pl.KS, np.int32)
+            assert lib.sp_conv3d_tables(C.byref(d), C.byref(pl), ktab.ctypes.data, kmap.ctypes.data) == 0
+            np.testing.assert_array_equal(ktab, z["ktab"])
+            np.testing.assert_array_equal(kmap, z["kmap"])
+            assert pl.workspace_bytes >= pl.off_wfrag + pl.nsteps * pl.NT * 1024 and pl.off_ktab >= 256
+    # channel counts without a kernel, and malformed descriptors, are refused with a message
+    bad = L.Conv3dDesc(1, 64, 64, 20, 20, 20, 0)
+    assert lib.sp_conv3d_plan(C.byref(bad), C.byref(L.Conv3dPlan())) == -1 and "sp_conv3d_plan" in L.last_error()
+    bad = L.Conv3dDesc(1, 8, 16, 20, 20, 20, 0)
+    assert lib.sp_conv3d_plan(C.byref(bad), C.byref(L.Conv3dPlan())) == -1

@@ -301,6 +301,54 @@ def test_row_ordered_upsample_crop_concat(C0, C1, ldims, B):
     torch.testing.assert_close(_from_cl(cat2, C0 + C1), got, rtol=8e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("cin,cout,grad,fold", [(16, 16, 0, True), (32, 32, 0, False), (48, 16, 0, True), (16, 32, 1, False),
+                                                (32, 16, 1, False)])
+def test_header_only_conv3d_entry_points(cin, cout, grad, fold):
+    """include/stroke_amd.h alone (sp_conv3d_plan / _init / _set_weights / _run: no runtime/plan.py, no ConvRunner): a valid
+    3x3x3 convolution with a folded BatchNorm, bias and LeakyReLU, and the data gradient, against torch on bf16 operands"""
+    import ctypes as C
+    lib = L.load()
+    B, dims = 2, (9, 21, 37)
+    g = torch.Generator().manual_seed(cin + 3 * cout + grad)
+    d = L.Conv3dDesc(B, cin, cout, *dims, grad)
+    pl = L.Conv3dPlan()
+    assert lib.sp_conv3d_plan(C.byref(d), C.byref(pl)) == 0, L.last_error()
+    ws = torch.empty(pl.workspace_bytes, dtype=torch.uint8, device=DEV)
+    st = O.stream()
+    assert lib.sp_conv3d_init(C.byref(d), C.byref(pl), ws.data_ptr(), st) == 0, L.last_error()
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    scale, shift = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    wd, bd, scd, shd = w.to(DEV), b.to(DEV), scale.to(DEV), shift.to(DEV)
+    if grad:
+        dz = bf(torch.randn(B, cout, *(x - 2 for x in dims), generator=g))
+        xin = _to_cl(dz, cout)
+        assert lib.sp_conv3d_set_weights(C.byref(d), C.byref(pl), ws.data_ptr(), wd.data_ptr(), None, None, None, st) == 0, L.last_error()
+        ref = F.conv_transpose3d(dz, bf(w))
+    else:
+        x = bf(torch.randn(B, cin, *dims, generator=g))
+        xin = _to_cl(x, cin)
+        assert lib.sp_conv3d_set_weights(C.byref(d), C.byref(pl), ws.data_ptr(), wd.data_ptr(), bd.data_ptr(),
+                                         scd.data_ptr() if fold else None, shd.data_ptr() if fold else None, st) == 0, L.last_error()
+        if fold:
+            ref = F.conv3d(x, bf(w * scale.view(1, -1, 1, 1, 1))) + (b + (w * shift.view(1, -1, 1, 1, 1)).sum((1, 2, 3, 4))).view(1, -1, 1, 1, 1)
+        else:
+            ref = F.conv3d(x, bf(w), b)
+        ref = F.leaky_relu(ref, LEAKY)
+    assert xin.numel() == pl.x_elems
+    y = torch.full((B, pl.Do, pl.Ho, pl.Wo, pl.cout_op), 7.0, dtype=torch.bfloat16, device=DEV)
+    assert y.numel() == pl.y_elems
+    nrep = 4
+    stats = torch.zeros(nrep, pl.cout_op, 2, dtype=torch.float64, device=DEV)
+    rc = lib.sp_conv3d_run(C.byref(d), C.byref(pl), ws.data_ptr(), xin.data_ptr(), y.data_ptr(), 0 if grad else 1,
+                           L.ACT_NONE if grad else L.ACT_LEAKY, LEAKY, None if grad else stats.data_ptr(), nrep, 0, st)
+    assert rc == 0, L.last_error()
+    got = _from_cl(y, pl.cout_op)
+    torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
+    if not grad:
+        torch.testing.assert_close(stats.sum(0)[:, 0].cpu(), got.double().sum((0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(got.numel() / cout))
+
+
 # ------------------------------------------------------------------------------------------------ multi-step fixtures
 def _build(ch, seed, dtype, cls=Unet3D):
     model = cls(ch, dtype=dtype)
