@@ -155,6 +155,35 @@ int sp_conv3d_run(const sp_conv3d_desc* d, const sp_conv3d_plan_t* plan, const v
                   int32_t with_bias, int32_t act, float act_param, double* stats, int32_t stats_nrep, int64_t x_plane,
                   sp_stream_t stream);
 
+/* ------------------------------------------------------------------ FC-like layers: split-K convolution without LDS
+ * The 800 <-> 100 channel layers around the CAE's latent (Cae3D.py:72-76, 178-180): a few hundred output voxels per sample,
+ * K = taps x Cin in the tens of thousands.  One workgroup per (64 output voxels, 8 output tiles, TAP); a second kernel sums the
+ * per-tap fp32 partials and applies bias / activation / statistics.  Single dense correlation only (out_stride 1):
+ *   y[b,o,co] = act(bias[co] + sum_{tap,ci} w[co,ci,src(tap)] * xin[b, o*s + o0 + taps[tap], ci])
+ * wfrag: sp_conv_prep_weights with kmap[(tap*spt + q)*4 + g] = (src_tap << 16) | (4q + g)  (spt = ceil(CPi/32) rounded up to a multiple of 4; -1 past the
+ * last octet), NTtot = ceil(Cout/16).  partial: sp_conv_fc_workspace floats.  stats as in sp_conv_args (stats_mode 1: aux is
+ * a bf16 tensor shaped like y). */
+typedef struct sp_conv_fc_args {
+  const void* x;           /* bf16 [B][Di][Hi][Wi][CPi] */
+  void* y;                 /* [B][Do][Ho][Wo][CPo], dtype_out */
+  const void* wfrag;
+  const float* in_scale;   /* [CPi] BatchNorm on load (inside the volume only), or NULL */
+  const float* in_shift;
+  const float* bias;       /* [>= Cout] or NULL */
+  double* stats;           /* [stats_nrep][CPo][2] or NULL */
+  const void* aux;
+  float* partial;
+  const int32_t* taps;     /* [ntap][3] */
+  int32_t B, Di, Hi, Wi, CPi, Do, Ho, Wo, CPo, Cout;
+  int32_t sD, sH, sW, o0D, o0H, o0W;
+  int32_t ntap;
+  int32_t act;
+  float act_param;
+  int32_t stats_mode, stats_nrep, dtype_out;
+} sp_conv_fc_args;
+int sp_conv_fc_workspace(int32_t B, int32_t Do, int32_t Ho, int32_t Wo, int32_t Cout, int32_t ntap, int64_t* floats);
+int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream);
+
 /* Re-pack fp32 weights into MFMA A-fragments in the plan's K order.
  * kmap[step*4+g] = (src_tap_index << 16) | cin_octet, or -1 for a padding octet.
  * element (co, ci, tap) is read from w[co*sCo + ci*sCi + tap]. */

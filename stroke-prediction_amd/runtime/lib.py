@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_wgrad_zr.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1
@@ -36,6 +36,12 @@ class WgradArgs(C.Structure):
                                    "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64), ("zs", i32)]
 
 
+class ConvFcArgs(C.Structure):       # sp_conv_fc_args
+    _fields_ = [(n, vp) for n in ("x", "y", "wfrag", "in_scale", "in_shift", "bias", "stats", "aux", "partial", "taps")] + \
+               [(n, i32) for n in ("B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
+                                   "ntap", "act")] + [("act_param", f32), ("stats_mode", i32), ("stats_nrep", i32), ("dtype_out", i32)]
+
+
 class Conv3dDesc(C.Structure):       # sp_conv3d_desc
     _fields_ = [(n, i32) for n in ("B", "Cin", "Cout", "D", "H", "W", "grad")]
 
@@ -47,6 +53,8 @@ class Conv3dPlan(C.Structure):       # sp_conv3d_plan_t
 
 
 _SIGS = {
+    "sp_conv_fc_workspace": ([i32, i32, i32, i32, i32, i32, C.POINTER(i64)], i32),
+    "sp_conv_fc": ([C.POINTER(ConvFcArgs), vp], i32),
     "sp_conv3d_plan": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan)], i32),
     "sp_conv3d_tables": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp], i32),
     "sp_conv3d_init": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp], i32),

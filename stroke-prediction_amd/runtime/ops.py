@@ -28,6 +28,7 @@ WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient part
 # 157 -> 157 us at 126^3) but those layers sit at the HBM ridge (216 FLOP per byte of activations in + out), and the
 # second set of weight fragments costs what the forward gains: 4.00 vs 4.00 ms per step.
 USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
+USE_FC = bool(int(os.environ.get("SP_CONV_FC", "1")))      # split-K kernel for FC-like layers (deep K, tiny output volume)
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 WGRAD_ZS = int(os.environ.get("SP_WGRAD_ZS", "1"))   # z-marching ring variant of the DMA weight gradient (0 off, 1 where it pays, 2 wherever it applies)
 CAT_PLANAR = bool(int(os.environ.get("SP_CAT_PLANAR", "1")))   # plane-major concat buffers (dense 16-channel planes for the DMA consumers)
@@ -191,7 +192,13 @@ class ConvRunner:
                 zm = dict(zm, ktab_d=_dev_i32(zm["ktab"], device), kmap_d=_dev_i32(zm["kmap"], device),
                           hi=torch.empty(zm["nsteps"] * zm["NT"] * 64 * 8, dtype=torch.bfloat16, device=device))
             st["zm"] = zm
-            st["bias"] = torch.zeros(max(op.nttot, 0 if zm is None else zm["NT"]) * 16, dtype=torch.float32, device=device)
+            fc = P.fc_plan(op) if (USE_FC and zm is None) else None
+            if fc is not None:      # split-K kernel for FC-like layers: its own (tap-major) K order and fragments
+                fc = dict(fc, kmap_d=_dev_i32(fc["kmap"], device), taps_d=_dev_i32(fc["taps"], device),
+                          hi=torch.empty(fc["nsteps"] * fc["NT"] * 64 * 8, dtype=torch.bfloat16, device=device), partial=None)
+            st["fc"] = fc
+            st["bias"] = torch.zeros(max(op.nttot, 0 if zm is None else zm["NT"], 0 if fc is None else fc["NT"]) * 16,
+                                     dtype=torch.float32, device=device)
             st["has_bias"] = False
             st["prep_key"] = None
         self._st = st
@@ -199,6 +206,7 @@ class ConvRunner:
         self.bias = st["bias"]
         self.zm = st.get("zm")
         self.zm_batch = zm_batch if self.zm is not None else None
+        self.fc = st.get("fc")
 
     def uses_zm(self):
         """the z-marching kernel runs this op (and its weight fragments are the only ones packed)"""
@@ -209,6 +217,9 @@ class ConvRunner:
         if self.uses_zm():
             z = self.zm
             return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"])]
+        if self.fc is not None:
+            f = self.fc
+            return [(f["kmap_d"], f["nsteps"], f["hi"], None, f["NT"])]
         return [(s["kmap"], s["nsteps"], s["hi"], s["lo"], self.op.nttot) for s in self.subs]
 
     @property
@@ -243,13 +254,13 @@ class ConvRunner:
                    ptr(hi), ptr(lo), ptr(fold_scale), ntaps, ptr(b), ptr(fold_shift), ptr(self.bias), nttot * 16,
                    stream())
             self.has_bias = True
-            if not self.uses_zm():
+            if not self.uses_zm() and self.fc is None:
                 self._prep_zr(w, fold_scale)
             return
         for kmap, nsteps, hi, lo, nttot in packs:
             L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(kmap), nsteps,
                    nttot, ptr(hi), ptr(lo), ptr(fold_scale), stream())
-        if not self.uses_zm():
+        if not self.uses_zm() and self.fc is None:
             self._prep_zr(w, fold_scale)
         if fold_shift is not None:
             ntaps = w.numel() // (op.cin * op.cout)
@@ -299,6 +310,9 @@ class ConvRunner:
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"
             return self._run_zm(a, x_planar, batch, stats is not None, st)
+        if self.fc is not None and not x_planar:
+            return _run_fc(self, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep,
+                           stats_mode, aux, st)
         for s in self.subs:
             sub = s["sub"]
             t = sub.tile
@@ -350,6 +364,35 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
     with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s zm%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)),
                                                                     " +stats" if with_stats else "")):
         L.call("sp_conv3d_zm", C.byref(a), ptr(zero_page(runner.device)), st)
+
+
+def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep, stats_mode, aux, st):
+    """split-K kernel for FC-like layers (csrc/sp_conv_fc.hip)"""
+    op, f = runner.op, runner.fc
+    sub = op.subs[0]
+    M = batch * int(np.prod(sub.out_dims))
+    need = f["ntap"] * M * f["NT"] * 16
+    if f["partial"] is None or f["partial"].numel() < need:
+        f["partial"] = torch.empty(need, dtype=torch.float32, device=runner.device)
+    a = L.ConvFcArgs()
+    a.x, a.y, a.wfrag = ptr(x), ptr(y), ptr(f["hi"])
+    a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
+    a.bias = ptr(runner.bias) if (runner.has_bias and use_bias) else None
+    a.stats, a.aux, a.partial, a.taps = ptr(stats), ptr(aux), ptr(f["partial"]), ptr(f["taps_d"])
+    a.B = batch
+    a.Di, a.Hi, a.Wi = op.in_dims
+    a.CPi = op.cpi
+    a.Do, a.Ho, a.Wo = sub.out_dims
+    a.CPo, a.Cout = y.shape[4], op.cout
+    a.sD, a.sH, a.sW = op.stride
+    a.o0D, a.o0H, a.o0W = sub.o0
+    a.ntap = f["ntap"]
+    a.act, a.act_param = act, act_param
+    a.stats_mode, a.stats_nrep = stats_mode, stats_nrep
+    a.dtype_out = op.dtype if dtype_out is None else dtype_out
+    with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s fc%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)),
+                                                                    " +stats" if stats is not None else "")):
+        L.call("sp_conv_fc", C.byref(a), st)
 
 
 class WgradRunner:

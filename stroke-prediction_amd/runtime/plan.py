@@ -396,3 +396,30 @@ def zm_plan(op: ConvOp):
     for e in range(18 * P_, ks * 4):
         ktab[e] = ktab[e - 2]                # zero-weight padding octets: any valid, conflict-free address
     return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=nw * MT, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)
+
+
+# ------------------------------------------------------------------------------------------------ FC-like layers
+FC_MIN_CPI = 256          # input channel pitch from which the split-K kernel is considered
+FC_MAX_VOX = 4096         # output voxels per sample up to which it is
+
+
+def fc_plan(op: ConvOp):
+    """Tables of the split-K kernel (csrc/sp_conv_fc.hip) for a single dense bf16 correlation with a deep K and a tiny
+    output volume -- the 800 -> 100 transposed convolution and the data gradient of the 100 -> 800 convolution around
+    the CAE's latent (Cae3D.py:72-76, 178-180) -- or None.  K order: tap-major, then the input octets four per step."""
+    if op.dtype != 0 or len(op.subs) != 1:
+        return None
+    sub = op.subs[0]
+    if tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0) or tuple(sub.out_dims) != tuple(op.y_dims):
+        return None
+    if op.cpi < FC_MIN_CPI or int(np.prod(sub.out_dims)) > FC_MAX_VOX:
+        return None
+    octs = op.cpi // 8
+    spt = -(-(-(-octs // 4)) // 4) * 4       # K steps per tap, padded to the kernel's prefetch depth (zero-weight octets)
+    ntap = len(sub.taps)
+    kmap = np.full(ntap * spt * 4, -1, dtype=np.int32)
+    for ti, t in enumerate(sub.taps):
+        for o in range(octs):
+            kmap[ti * spt * 4 + o] = (t[3] << 16) | o
+    taps = np.array([[t[0], t[1], t[2]] for t in sub.taps], dtype=np.int32)
+    return dict(ntap=ntap, spt=spt, nsteps=ntap * spt, NT=-(-op.cout // 16), kmap=kmap, taps=taps)
