@@ -55,6 +55,47 @@ __device__ __forceinline__ void first_stage_x(const FirstDev& P, int b, int oz0,
     }
   }
 }
+// The same in two halves, so that the loads of the NEXT tile are in flight while the MFMAs of the current one run (the
+// kernels are persistent loops over tiles; staged synchronously every tile waited out an HBM round trip of scattered
+// 4-byte loads with nothing else to do): first_load_x issues the loads into registers, first_store_x converts and
+// writes the LDS tile after the barrier that retires the previous tile.
+__device__ __forceinline__ void raw8_to_f32(const uint4& r, float (&f)[8]) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+}
+constexpr int FT_XIT = (FT_ROWS * FT_XP + 255) / 256;      // elements per thread
+__device__ __forceinline__ void first_load_x(const FirstDev& P, int b, int oz0, int oy0, int ox0, float (&r)[FT_XIT][2]) {
+  const size_t plane = (size_t)P.D * P.H * P.W;
+  const float* x0 = P.x + (size_t)b * 2 * plane;
+#pragma unroll
+  for (int it = 0; it < FT_XIT; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < FT_ROWS * FT_XP) {
+      const int row = fdiv(i, P.d_xp), xo = i - row * FT_XP;
+      const int zz = fdiv(row, P.d_xy), yy = row - zz * FT_XY;
+      const int gz = min(oz0 + zz, P.D - 1), gy = min(oy0 + yy, P.H - 1), gx = min(ox0 + xo, P.W - 1);
+      const size_t o = ((size_t)gz * P.H + gy) * P.W + gx;
+      r[it][0] = x0[o]; r[it][1] = x0[plane + o];
+    }
+  }
+}
+template <bool INTERLEAVED>
+__device__ __forceinline__ void first_store_x(const float (&r)[FT_XIT][2], uint32_t* xt) {
+#pragma unroll
+  for (int it = 0; it < FT_XIT; ++it) {
+    const int i = threadIdx.x + it * 256;
+    if (i < FT_ROWS * FT_XP) {
+      if (INTERLEAVED) {
+        xt[i] = sp_pack_bf16x2(r[it][0], r[it][1]);
+      } else {
+        bf16_t* pl = reinterpret_cast<bf16_t*>(xt);
+        pl[i] = f2bf(r[it][0]);
+        pl[FT_ROWS * FT_XP + i] = f2bf(r[it][1]);
+      }
+    }
+  }
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ input statistics
@@ -174,12 +215,23 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
   const float slope = act == SP_ACT_LEAKY ? ap : 1.f;
   const bool lin = act == SP_ACT_LEAKY || act == SP_ACT_NONE;
 
+  float xr[FT_XIT][2];
+  if (blockIdx.x < P.ntiles) {
+    int b, oz0, oy0, ox0;
+    first_decode(P, blockIdx.x, b, oz0, oy0, ox0);
+    first_load_x(P, b, oz0, oy0, ox0, xr);
+  }
   for (uint32_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
     int b, oz0, oy0, ox0;
     first_decode(P, tile, b, oz0, oy0, ox0);
     __syncthreads();                                        // the previous tile has been consumed
-    first_stage_x<true>(P, b, oz0, oy0, ox0, xt);
+    first_store_x<true>(xr, xt);
     __syncthreads();
+    if (tile + gridDim.x < P.ntiles) {                      // next tile's input: in flight during this tile's MFMAs and stores
+      int b2, oz2, oy2, ox2;
+      first_decode(P, tile + gridDim.x, b2, oz2, oy2, ox2);
+      first_load_x(P, b2, oz2, oy2, ox2, xr);
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wave + rr, zz = row >> 2, yy = row & 3;
@@ -289,22 +341,47 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
     }
   }
 
+  // operands of a tile are fetched into registers one tile ahead (see first_load_x): x, and g / y (or dz)
+  constexpr int DZIT = FT_TZ * FT_TY * FT_TX * 2 / 256;
+  float xr[FT_XIT][2];
+  uint4 gq[DZIT], yq[DZIT];
+  auto load_dz = [&](int b, int oz0, int oy0, int ox0) {
+#pragma unroll
+    for (int it = 0; it < DZIT; ++it) {
+      const int i = tid + it * 256;
+      const int half = i & 1, vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
+      const int oz = oz0 + (row >> 2), oy = oy0 + (row & 3), ox = ox0 + vx;
+      gq[it] = yq[it] = make_uint4(0, 0, 0, 0);
+      if (oz < P.Do && oy < P.Ho && ox < P.Wo) {
+        const size_t o = ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * 16 + half * 8;
+        if (FUSED) { gq[it] = *reinterpret_cast<const uint4*>(gg + o); yq[it] = *reinterpret_cast<const uint4*>(yg + o); }
+        else gq[it] = *reinterpret_cast<const uint4*>(dzg + o);
+      }
+    }
+  };
+  if (blockIdx.x < P.ntiles) {
+    int b, oz0, oy0, ox0;
+    first_decode(P, blockIdx.x, b, oz0, oy0, ox0);
+    first_load_x(P, b, oz0, oy0, ox0, xr);
+    load_dz(b, oz0, oy0, ox0);
+  }
   for (uint32_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
     int b, oz0, oy0, ox0;
     first_decode(P, tile, b, oz0, oy0, ox0);
     __syncthreads();
-    first_stage_x<false>(P, b, oz0, oy0, ox0, xt);
+    first_store_x<false>(xr, xt);
     // dz tile: [row = zz*TY + yy][x][16 ch], zero where the output voxel does not exist
-    for (int i = tid; i < FT_TZ * FT_TY * FT_TX * 2; i += 256) {
-      const int half = i & 1, vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
+#pragma unroll
+    for (int it = 0; it < DZIT; ++it) {
+      const int i = tid + it * 256;
+      const int vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
       const int oz = oz0 + (row >> 2), oy = oy0 + (row & 3), ox = ox0 + vx;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (oz < P.Do && oy < P.Ho && ox < P.Wo) {
-        const size_t o = ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * 16 + half * 8;
         if (FUSED) {
           float g8[8], y8[8], d8[8];
-          Store<bf16_t>::ld8(gg + o, g8);
-          Store<bf16_t>::ld8(yg + o, y8);
+          raw8_to_f32(gq[it], g8);
+          raw8_to_f32(yq[it], y8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             d8[j] = (k0[j] * g8[j] + k1[j] * y8[j] + k2[j]) * act_bwd_from_y(ACT >= 0 ? ACT : act, ap, y8[j]);
@@ -312,15 +389,21 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
           }
           uint32_t w4[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) w4[j] = (uint32_t)f2bf(d8[2 * j]) | ((uint32_t)f2bf(d8[2 * j + 1]) << 16);
+          for (int j = 0; j < 4; ++j) w4[j] = sp_pack_bf16x2(d8[2 * j], d8[2 * j + 1]);
           v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
         } else {
-          v = *reinterpret_cast<const uint4*>(dzg + o);
+          v = gq[it];
         }
       }
       *reinterpret_cast<uint4*>(dzt + (size_t)i * 16) = v;
     }
     __syncthreads();
+    if (tile + gridDim.x < P.ntiles) {
+      int b2, oz2, oy2, ox2;
+      first_decode(P, tile + gridDim.x, b2, oz2, oy2, ox2);
+      first_load_x(P, b2, oz2, oy2, ox2, xr);
+      load_dz(b2, oz2, oy2, ox2);
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       const int row = 2 * wave + rr, zz = row >> 2, yy = row & 3;
