@@ -590,9 +590,13 @@ def test_fusedadam_state_dict_round_trip_and_reflatten(tmp_path):
         b.load_state_dict(sd_model)
         ob.load_state_dict(torch.load(path, weights_only=False))
         lb = run(b, ob, 1)
-        assert abs(la - lb) < 1e-6, (capturable, la, lb)
+        # two runs of the same step differ by ~1e-7 in the gradients (order of the fp64 statistics atomics); Adam turns that
+        # into up to ~1e-4 * lr-sized differences on elements whose gradient is of the order of eps (tools/dbg_steps.py).
+        # A lost moment buffer or a restarted bias correction shows as O(lr) = 1e-3 on EVERY element.
+        assert abs(la - lb) < 1e-5, (capturable, la, lb)
         for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
-            assert float((p - q).abs().max()) <= 2e-6, (capturable, n)
+            d = (p - q).abs()
+            assert float(d.max()) <= 2e-4 and float(d.mean()) <= 2e-6, (capturable, n, float(d.max()), float(d.mean()))
         # the save_model round trip re-flattens: bias correction must not restart
         a.cpu()
         a.to(DEV)
