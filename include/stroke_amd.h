@@ -106,6 +106,10 @@ typedef struct sp_conv_args {
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
+/* n (<= 8) sub-convolutions of one op -- the parity classes of a stride-2 transposed convolution (Cae3D.py:178-204) or of a
+ * strided convolution's data gradient -- in ONE launch when they share register blocking, data types and the register-staged
+ * kernel (dma = 0); otherwise the classes are launched one after the other.  Same result either way. */
+int sp_conv3d_igemm_multi(const sp_conv_args* args, int32_t n, sp_stream_t stream);
 
 /* The same operation (nn.Conv3d(3, stride 1, padding 0) forward, Unet3D.py:19,22, or its data gradient) on the
  * output-stationary z-marching kernel (csrc/sp_conv_zm.hip): a workgroup marches through the INPUT planes of a column of

@@ -67,7 +67,7 @@ struct ConvDev {
 };
 
 template <int NT, int MT, int NP, typename TIN, typename TOUT>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
+__device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -334,7 +334,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
   STAMP(5);
 }
 
+template <int NT, int MT, int NP, typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvDev P) {
+  conv_igemm_body<NT, MT, NP, TIN, TOUT>(P);
+}
+
+// Several sub-convolutions of ONE op in one launch (the parity classes of a stride-2 transposed convolution, Cae3D.py:
+// 178-204: eight launches of 10-22 us, most of them a fraction of a wave of workgroups): blockIdx.z selects the class; the
+// classes differ in taps, offsets and extents only, so one template instance serves them all.
+#define SP_CONV_MULTI_MAX 8
+struct ConvDevMulti { ConvDev p[SP_CONV_MULTI_MAX]; };
+template <int NT, int MT, int NP, typename TIN, typename TOUT>
+__global__ __launch_bounds__(256) void conv_igemm_multi_kernel(const ConvDevMulti M) {
+  const ConvDev& P = M.p[blockIdx.z];
+  if (blockIdx.x >= P.nblk) return;
+  conv_igemm_body<NT, MT, NP, TIN, TOUT>(P);
+}
+
 // ------------------------------------------------------------------------------------------------
+template <int NT, int MT, int NP, typename TIN, typename TOUT>
+static int launch_conv_multi(const ConvDevMulti& M, int lds_bytes, dim3 grid, hipStream_t st) {
+  auto kern = conv_igemm_multi_kernel<NT, MT, NP, TIN, TOUT>;
+  SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_igemm_multi");
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, M);
+  SP_CHECK_LAUNCH("sp_conv3d_igemm_multi");
+  return SP_OK;
+}
+template <int NT, int MT>
+static int dispatch_dtype_multi(const ConvDevMulti& M, int lds_bytes, dim3 grid, hipStream_t st) {
+  const int di = M.p[0].a.dtype_in, dout = M.p[0].a.dtype_out;
+  if (di == SP_BF16 && dout == SP_BF16) return launch_conv_multi<NT, MT, 1, bf16_t, bf16_t>(M, lds_bytes, grid, st);
+  if (di == SP_F32 && dout == SP_F32) return launch_conv_multi<NT, MT, 2, float, float>(M, lds_bytes, grid, st);
+  if (di == SP_BF16 && dout == SP_F32) return launch_conv_multi<NT, MT, 1, bf16_t, float>(M, lds_bytes, grid, st);
+  sp_set_error("sp_conv3d_igemm_multi: unsupported dtype pair in=%d out=%d", di, dout);
+  return SP_EINVAL;
+}
+
 template <int NT, int MT, int NP, typename TIN, typename TOUT>
 static int launch_conv(const ConvDev& P, dim3 grid, hipStream_t st) {
   auto kern = conv_igemm_kernel<NT, MT, NP, TIN, TOUT>;
@@ -356,7 +391,47 @@ static int dispatch_dtype(const ConvDev& P, dim3 grid, hipStream_t st) {
 
 int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream);   // sp_conv_dma.hip
 
-extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
+static int conv_check_build(const sp_conv_args* a, ConvDev& P);
+
+// n sub-convolutions (n <= 8) that share weights layout, register blocking and data types -- the parity classes of a
+// transposed / strided-gradient op -- in ONE launch of the register-staged kernel; anything else (DMA-staged classes,
+// differing blockings) falls back to one sp_conv3d_igemm per class.
+extern "C" int sp_conv3d_igemm_multi(const sp_conv_args* args, int32_t n, sp_stream_t stream) {
+  SP_CHECK_ARG(args && n >= 1, "sp_conv3d_igemm_multi: bad arguments");
+  bool same = n >= 2 && n <= SP_CONV_MULTI_MAX;
+  for (int i = 0; i < n && same; ++i)
+    same = !args[i].dma && args[i].NT == args[0].NT && args[i].MT == args[0].MT && args[i].NTtot == args[0].NTtot &&
+           args[i].dtype_in == args[0].dtype_in && args[i].dtype_out == args[0].dtype_out;
+  if (!same) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = sp_conv3d_igemm(&args[i], stream);
+      if (rc != SP_OK) return rc;
+    }
+    return SP_OK;
+  }
+  ConvDevMulti M;
+  int lds = 0;
+  uint32_t gx = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = conv_check_build(&args[i], M.p[i]);
+    if (rc != SP_OK) return rc;
+    lds = args[i].lds_bytes > lds ? args[i].lds_bytes : lds;
+    gx = M.p[i].nblk > gx ? M.p[i].nblk : gx;
+  }
+  for (int i = n; i < SP_CONV_MULTI_MAX; ++i) M.p[i] = M.p[0];
+  dim3 grid(gx, args[0].NTtot / args[0].NT, n);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const sp_conv_args* a = &args[0];
+#define SP_CASE(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return dispatch_dtype_multi<NT_, MT_>(M, lds, grid, st)
+  SP_CASE(1, 8); SP_CASE(2, 8); SP_CASE(3, 8); SP_CASE(4, 8);
+  SP_CASE(1, 4); SP_CASE(2, 4); SP_CASE(3, 4); SP_CASE(4, 4);
+  SP_CASE(1, 2); SP_CASE(2, 2); SP_CASE(3, 2); SP_CASE(4, 2);
+#undef SP_CASE
+  sp_set_error("sp_conv3d_igemm_multi: no kernel for NT=%d MT=%d", a->NT, a->MT);
+  return SP_EINVAL;
+}
+
+static int conv_check_build(const sp_conv_args* a, ConvDev& P) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab, "sp_conv3d_igemm: null pointer");
   SP_CHECK_ARG(a->CPi % 8 == 0 && a->CPo % 8 == 0, "sp_conv3d_igemm: channel pitch must be a multiple of 8 (CPi=%d CPo=%d)", a->CPi, a->CPo);
   SP_CHECK_ARG(a->TD * a->TH == 4 * a->MT, "sp_conv3d_igemm: TD*TH (%d*%d) must equal 4*MT (%d)", a->TD, a->TH, 4 * a->MT);
@@ -376,8 +451,6 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
     SP_CHECK_ARG(a->lds_bytes >= a->NT * 16 * 2 * 4, "sp_conv3d_igemm: LDS too small for the reduction");
   }
   SP_CHECK_ARG(a->stats_mode == 0 || (a->dma && a->aux), "sp_conv3d_igemm: stats_mode 1 needs the DMA kernel and aux");
-  if (a->dma) return sp_conv3d_igemm_dma(a, stream);
-  ConvDev P;
   P.a = *a;
   P.d_octs = make_fastdiv(a->octs_per_group);
   P.d_itw = make_fastdiv(a->ITW);
@@ -391,6 +464,14 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
   const uint64_t nblk = (uint64_t)P.ntx * P.nty * P.ntz * a->B;
   SP_CHECK_ARG(nblk < (1ull << 31), "sp_conv3d_igemm: grid too large");
   P.nblk = (uint32_t)nblk;
+  return SP_OK;
+}
+
+extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
+  ConvDev P;
+  const int rc = conv_check_build(a, P);
+  if (rc != SP_OK) return rc;
+  if (a->dma) return sp_conv3d_igemm_dma(a, stream);
   dim3 grid(P.nblk, a->NTtot / a->NT);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define SP_CASE(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return dispatch_dtype<NT_, MT_>(P, grid, st)

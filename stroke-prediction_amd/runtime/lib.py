@@ -66,6 +66,7 @@ _SIGS = {
     "sp_map_coordinates_linear": ([vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, i32, i32, vp], i32),
     "sp_conv_prep_weights_batch": ([vp, i32, i32, vp], i32),
     "sp_conv3d_igemm": ([C.POINTER(ConvArgs), vp], i32),
+    "sp_conv3d_igemm_multi": ([C.POINTER(ConvArgs), i32, vp], i32),
     "sp_conv3d_zm": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),

@@ -28,6 +28,7 @@ WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient part
 # 157 -> 157 us at 126^3) but those layers sit at the HBM ridge (216 FLOP per byte of activations in + out), and the
 # second set of weight fragments costs what the forward gains: 4.00 vs 4.00 ms per step.
 USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
+USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
 USE_FC = bool(int(os.environ.get("SP_CONV_FC", "1")))      # split-K kernel for FC-like layers (deep K, tiny output volume)
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
 WGRAD_ZS = int(os.environ.get("SP_WGRAD_ZS", "1"))   # z-marching ring variant of the DMA weight gradient (0 off, 1 where it pays, 2 wherever it applies)
@@ -313,7 +314,8 @@ class ConvRunner:
         if self.fc is not None and not x_planar:
             return _run_fc(self, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep,
                            stats_mode, aux, st)
-        for s in self.subs:
+        multi = (L.ConvArgs * len(self.subs))() if (USE_MULTI and 2 <= len(self.subs) <= 8 and not x_planar) else None
+        for si, s in enumerate(self.subs):
             sub = s["sub"]
             t = sub.tile
             a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(s["hi"]), ptr(s["lo"]), ptr(s["ktab"])
@@ -335,11 +337,19 @@ class ConvRunner:
                 a.persist, a.ktab, a.ITH_zs = 3, ptr(s["ktab_zs"]), t["ITH_zs"]     # z-marching ring variant
                 if s.get("ktab_zr") is not None and not x_planar:
                     a.persist, a.ktab, a.wfrag_hi = 4, ptr(s["ktab_zr"]), ptr(s["hi_zr"])   # ... with row reuse
+            if multi is not None:       # the parity classes of one op go out in ONE launch (sp_conv3d_igemm_multi)
+                C.memmove(C.byref(multi, si * C.sizeof(L.ConvArgs)), C.byref(a), C.sizeof(L.ConvArgs))
+                continue
             # algorithmic FLOPs (plan.ConvOp.algo_macs), shared among the sub-convolutions by the work each issues
             share = int(np.prod(sub.out_dims)) * len(sub.taps) / max(1, op.issued_macs())
             with _Timed("conv_igemm", op.flops(batch) * share,
                         "%d->%d @%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_igemm", C.byref(a), st)
+        if multi is not None:
+            with _Timed("conv_igemm", op.flops(batch),
+                        "%d->%d @%s x%d classes%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), len(self.subs),
+                                                      " +stats" if stats is not None else "")):
+                L.call("sp_conv3d_igemm_multi", multi, len(self.subs), st)
 
 
 def wgrad_dma_ok(cpi, cpo, dtype):
