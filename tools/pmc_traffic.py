@@ -27,7 +27,7 @@ for k in sorted(f, key=lambda k: -f[k][0])[:24]:
     n = f[k][1]; wv = w.get(k, [0.0, 1])
     lines.append("| `%s` | %d | %.1f | %.1f |" % (k[:70], n, 2 * f[k][0] / n / 1024, wv[0] / max(1, wv[1]) / 1024))
 open(os.path.join(ROOT, "profiles", "%s_pmc_traffic.md" % tag), "w").write("\n".join(lines) + "\n")
-fam = {"conv_igemm": ("conv_igemm", "conv_zm3_kernel", "first_fwd_kernel"),
+fam = {"conv_igemm": ("conv_igemm", "conv_zm3_kernel", "conv_fc_", "first_fwd_kernel"),
        "conv_wgrad": ("wgrad_dma_kernel", "wgrad_zs_kernel", "wgrad_zr_kernel", "wgrad_kernel", "first_wgrad_kernel")}
 tj = os.path.join(ROOT, "profiles", "traffic.json")
 out = json.load(open(tj)) if (prefix and os.path.exists(tj)) else {}
