@@ -1,4 +1,5 @@
-// Weight gradient of the un-padded, stride-1 3x3x3 convolutions (every Block3x3x3 conv of the U-Net, Unet3D.py:19,22),
+// Weight gradient of the stride-1 3x3x3 convolutions, padding 0..2 (every Block3x3x3 conv of the U-Net, Unet3D.py:19,22; the
+// padded layers of the CAE, Cae3D.py:41-70,186-218, on their materialised BatchNorm output),
 // bf16, "row-sliding" z-marching variant.  Same GEMM view as sp_wgrad_dma.hip (dw[tap][co][ci] = sum over output voxels
 // of dz[v][co] * x[v + tap][ci], K = 32 voxels along x per MFMA, both operands through LDS and ds_read_b64_tr_b16), but
 // organised around the INPUT row instead of the tap, which is what the LDS bandwidth asks for:
@@ -128,8 +129,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
     uint32_t q = fdiv(t, P.d_tx); const int tx = t - q * P.ntx; t = q;
     q = fdiv(t, P.d_ty); const int ty = t - q * P.nty; const int b = q;
     const int oy0 = ty * C::TY, ox0 = tx * 32;
+    // padded layers (o0 = -padding <= 0): the input window starts o0 voxels before the output tile; planes, rows and columns
+    // outside the input come from the zero page.  xcol may point in front of the tensor: it is only dereferenced for
+    // chunks inside it.
+    const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W, izs = z0 + a.o0D;
     const unsigned char* xcol = reinterpret_cast<const unsigned char*>(a.x) +
-        ((((int64_t)b * a.Di + z0) * a.Hi + oy0) * a.Wi + ox0) * xpitch * 2;
+        ((((int64_t)b * a.Di + izs) * a.Hi + iy0) * a.Wi + ix0) * xpitch * 2;
     const unsigned char* dcol = reinterpret_cast<const unsigned char*>(a.dz) +
         ((((int64_t)b * a.Do + z0) * a.Ho + oy0) * a.Wo + ox0) * a.CPo * 2;
     const unsigned char* srcx[NJX]; uint32_t strx[NJX];
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
 #pragma unroll
     for (int j = 0; j < NJX; ++j) {
       const int vy = crdx[j] & 0xff, vx = (crdx[j] >> 8) & 0xff;
-      const bool ok = crdx[j] >= 0 && oy0 + vy < a.Hi && ox0 + vx < a.Wi;
+      const bool ok = crdx[j] >= 0 && (unsigned)(iy0 + vy) < (unsigned)a.Hi && (unsigned)(ix0 + vx) < (unsigned)a.Wi;
       srcx[j] = ok ? xcol + relx[j] : zeros;
       strx[j] = ok ? xplane_b : 0u;
     }
@@ -154,7 +159,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
     // the MFMA groups of a step: a DMA costs 60-180 issue cycles that a burst of NJ of them would expose after the barrier
     auto issue1 = [&](int j, int k, int slot) {
       if (j < NJX) {
-        sp_dma16_nc(srcx[j < NJX ? j : 0], xring + slot * C::XSB + wave * 1024 + j * 4096);
+        const bool zin = (unsigned)(izs + min(k, nsteps - 1)) < (unsigned)a.Di;          // wave-uniform: plane inside the input
+        sp_dma16_nc(zin ? srcx[j < NJX ? j : 0] : zeros, xring + slot * C::XSB + wave * 1024 + j * 4096);
         srcx[j < NJX ? j : 0] += (k + 1 < nsteps) ? strx[j < NJX ? j : 0] : 0u;
       } else {
         const int jd = j < NJX ? 0 : j - NJX;
@@ -263,8 +269,9 @@ int sp_wgrad_zr_try(const sp_wgrad_args* a, hipStream_t st) {
   const char* knob = getenv("SP_WGRAD_ZR");          // read per launch: the parity tests compare both kernel families
   if ((knob && atoi(knob) == 0) || !a->parts || a->dtype != SP_BF16 || a->in_scale || a->dz_scale) return 1;
   if (a->kD != 3 || a->kH != 3 || a->kW != 3 || a->ntap != 27) return 1;
-  if (a->sD != 1 || a->sH != 1 || a->sW != 1 || a->o0D || a->o0H || a->o0W) return 1;
-  if (a->Di != a->Do + 2 || a->Hi != a->Ho + 2 || a->Wi != a->Wo + 2) return 1;
+  if (a->sD != 1 || a->sH != 1 || a->sW != 1) return 1;
+  if (a->o0D > 0 || a->o0H > 0 || a->o0W > 0 || a->o0D < -2 || a->o0H < -2 || a->o0W < -2) return 1;      // padding 0..2
+  if (a->Di - 2 * a->o0D != a->Do + 2 || a->Hi - 2 * a->o0H != a->Ho + 2 || a->Wi - 2 * a->o0W != a->Wo + 2) return 1;
   if (a->CPi % 16 || a->CPo % 16 || a->Ho > 255 * 8 || (int64_t)a->Hi * a->Wi * a->CPi * 2 >= (1ll << 31)) return 1;
   if (a->x_plane && (int64_t)a->x_plane * 2 * a->CiT >= (1ll << 32)) return 1;
   const int COB = (a->CoT % 2 == 0) ? 2 : 1, CIB = (a->CiT % 2 == 0) ? 2 : 1;

@@ -239,19 +239,23 @@ ZR_CASES = [   # cin, cout, input dims, batch, plane-major input, workgroups (No
     (16, 32, (7, 15, 36), 2, False, 8), (32, 32, (8, 12, 37), 2, False, None), (48, 16, (6, 19, 37), 1, True, 16),
     (96, 32, (5, 11, 35), 2, True, None), (64, 64, (7, 9, 11), 2, False, None), (32, 64, (9, 9, 9), 3, False, 40),
 ]
+ZR_CASES = [c + ((0, 0, 0),) for c in ZR_CASES] + [      # the CAE's padded layers (Cae3D.py:41-70, 186-218)
+    (16, 16, (9, 20, 37), 2, False, None, (1, 0, 0)), (32, 32, (7, 12, 35), 1, False, 16, (1, 2, 2)),
+    (16, 32, (6, 14, 33), 2, False, None, (1, 1, 1)), (32, 16, (3, 9, 31), 2, False, 24, (2, 2, 2)),
+]
 
 
-@pytest.mark.parametrize("cin,cout,dims,B,planar,nblocks", ZR_CASES)
-def test_row_sliding_weight_gradient_matches_autograd(cin, cout, dims, B, planar, nblocks, monkeypatch):
+@pytest.mark.parametrize("cin,cout,dims,B,planar,nblocks,pad", ZR_CASES)
+def test_row_sliding_weight_gradient_matches_autograd(cin, cout, dims, B, planar, nblocks, pad, monkeypatch):
     """csrc/sp_wgrad_zr.hip alone (every (cout tile, cin tile) blocking, ragged rows and widths, pieces that start in the
     middle of a column, more workgroups than planes, plane-major concat input) against F.conv3d autograd on the same
     bf16-rounded operands, and against the tap-major kernels it replaces (same operands: fp32 summation order only)."""
     g = torch.Generator().manual_seed(cin * 11 + cout)
-    od = tuple(d - 2 for d in dims)
+    od = tuple(d - 2 + 2 * q for d, q in zip(dims, pad))
     x = bf(torch.randn(B, cin, *dims, generator=g))
     dz = bf(torch.randn(B, cout, *od, generator=g))
     wr = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
-    F.conv3d(x, wr).backward(dz)
+    F.conv3d(x, wr, padding=pad).backward(dz)
     xs, dzs = _to_cl(x, cin), _to_cl(dz, cout)
     if planar:
         xs = xs.view(B, *dims, cin // 16, 16).permute(4, 0, 1, 2, 3, 5).contiguous().view(B, *dims, cin)
@@ -260,7 +264,7 @@ def test_row_sliding_weight_gradient_matches_autograd(cin, cout, dims, B, planar
         monkeypatch.setenv("SP_WGRAD_ZR", zr)        # read per launch (sp_wgrad_zr.hip)
         if nblocks is not None:
             monkeypatch.setenv("SP_WGRAD_BLOCKS", str(nblocks))
-        wg = O.WgradRunner(cin, cout, 3, 1, 0, dims, od, cin, cout, cin * 27, 27, L.SP_BF16, DEV)
+        wg = O.WgradRunner(cin, cout, 3, 1, pad, dims, od, cin, cout, cin * 27, 27, L.SP_BF16, DEV)
         assert wg.dma
         dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
         wg.run(xs, dzs, B, dw, x_planar=planar)
