@@ -97,8 +97,9 @@ template <> struct ZmStore<float> {
 // from there, double-buffered against the MFMAs -- (MT + 3 NT) LDS reads feed 3 NT MT MFMAs, < 0.6 reads per MFMA.
 // STATS: per-channel sum / sum of squares of the output for the next BatchNorm (forward layers; data gradients skip the work).
 // NW: waves per workgroup (4, or 8 = two per SIMD: one wave's epilogue / DMA / LDS instructions issue under its partner's MFMAs).
-// ACTB: bias + LeakyReLU in the epilogue (forward layers); false: the accumulator is stored as it is (data gradients).
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, bool ACTB, typename TOUT>
+// ACT: 1 = bias + LeakyReLU / identity in the epilogue (forward layers), 2 = bias + ELU (the CAE's layers, Cae3D.py:41-70), 0 = the
+// accumulator is stored as it is (data gradients).
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, typename TOUT>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bj[n][j] = a.bias ? a.bias[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
-  const float slope = a.act == SP_ACT_LEAKY ? a.act_param : 1.f;      // host: act is LEAKY or NONE
+  const float slope = a.act == SP_ACT_NONE ? 1.f : a.act_param;       // LeakyReLU slope (identity: 1) or the ELU's alpha
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(Q.zeros);
 #ifdef SP_ZM_STAMPS
   unsigned long long zm_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 0 sync, 1 DMA issue, 2 K loop + epilogue, 3 steps, 4 total
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
         float v[4];                                                                                               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
-          if (ACTB) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); }               \
+          if (ACT == 1) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); }           \
+          else if (ACT == 2) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = zz > 0.f ? zz : slope * (__expf(zz) - 1.f); } \
           else v[j] = acc[R_][n][m][j];                                                                           \
         }                                                                                                         \
         ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                                 \
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, bool ACTB>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
   constexpr int NCH = P * (NW * MT + 2) * 18 * 2;
@@ -422,11 +424,16 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   const int slots = slots_env_ > 0 ? slots_env_ : 256;               // resident workgroups: one per CU
   const unsigned grid = planes / 4 < (uint64_t)slots ? (unsigned)(planes / 4 > 0 ? planes / 4 : 1) : (unsigned)slots;
   if (a->dtype_out == SP_F32) {
-    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACTB, float>;
-    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+    if constexpr (ACT == 2) {
+      sp_set_error("sp_conv3d_zm: the ELU epilogue is built for bf16 outputs");
+      return SP_EINVAL;
+    } else {
+      auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, float>;
+      SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+    }
   } else {
-    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACTB, bf16_t>;
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
   }
@@ -437,9 +444,18 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
 template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW>
 static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   const bool plain = a->act == SP_ACT_NONE && a->bias == nullptr;      // data gradients: nothing to do but round and store
-  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true, true>(a, zeros, st);
-  if (plain) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, false>(a, zeros, st);
-  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, true>(a, zeros, st);
+  if (a->act == SP_ACT_ELU) {
+    if constexpr (NW == 8 && P <= 2) {      // the CAE's 16 / 24 / 32-channel layers
+      if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true, 2>(a, zeros, st);
+      return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, 2>(a, zeros, st);
+    } else {
+      sp_set_error("sp_conv3d_zm: no ELU instance for P=%d NW=%d", P, NW);
+      return SP_EINVAL;
+    }
+  }
+  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true, 1>(a, zeros, st);
+  if (plain) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, 0>(a, zeros, st);
+  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, 1>(a, zeros, st);
 }
 
 // (P, NT) -> rows per wave, ring slots, waves per workgroup; SP_EINVAL = no kernel.  runtime/plan.py (ZM_CONFIGS) must agree:
@@ -467,7 +483,7 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && zeros, "sp_conv3d_zm: null pointer");
   SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr && a->stats_mode == 0, "sp_conv3d_zm: bf16 input, no affine on load, plain statistics");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
-  SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE, "sp_conv3d_zm: LeakyReLU or identity epilogue");
+  SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE || a->act == SP_ACT_ELU, "sp_conv3d_zm: LeakyReLU, ELU or identity epilogue");
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_zm: stats_nrep must be a power of two");
   SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_zm: empty output");

@@ -78,10 +78,6 @@ class ConvLayer:
         pads = pad if isinstance(pad, (tuple, list)) else (pad,) * 3
         self.fold = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and max(pads) == 0
                          and all(s.tile["dma"] for s in self.fwd_op.subs))
-        # folded layers run without affine-on-load and with plain statistics: candidates for the z-marching kernel
-        zm_ok = self.fold and act in (L.ACT_NONE, L.ACT_LEAKY) and bank is None
-        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if bank is None else bank.setdefault((name, "fwd"), {}),
-                                zm_batch=batch if zm_ok else None)
         self.scratch = scratch
         # Padded bf16 convolutions behind a BatchNorm (the CAE): zero padding applies AFTER the normalisation, so the
         # BatchNorm cannot be folded into the weights, and a DMA cannot normalise on load.  The normalised input is
@@ -92,6 +88,12 @@ class ConvLayer:
                                 and max(pads) > 0 and max(pads) <= 2 and max(strides) == 1 and k == 3 and self.cpi % 16 == 0
                                 and self.cpo % 16 == 0 and all(s.tile["dma"] for s in self.fwd_op.subs) and O.MATERIALIZE_BN)
         self.xhat = None
+        # folded layers run without affine-on-load and with plain statistics: candidates for the z-marching kernel; so do the
+        # materialised ones (the kernel pads from its zero page and has an ELU epilogue)
+        zm_ok = (self.fold and act in (L.ACT_NONE, L.ACT_LEAKY) and bank is None) or \
+                (self.materialize and act == L.ACT_ELU and O.ZM_CAE and self.out_dtype == dtype)
+        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if bank is None else bank.setdefault((name, "fwd"), {}),
+                                zm_batch=batch if zm_ok else None)
         if bn_prefix is not None:
             self.apply_coef = torch.zeros(3, self.cpi, device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift
             self.scale = self.apply_coef[0]

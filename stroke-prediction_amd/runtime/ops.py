@@ -28,6 +28,7 @@ WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient part
 # 157 -> 157 us at 126^3) but those layers sit at the HBM ridge (216 FLOP per byte of activations in + out), and the
 # second set of weight fragments costs what the forward gains: 4.00 vs 4.00 ms per step.
 USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
+ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
 USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
 USE_FC = bool(int(os.environ.get("SP_CONV_FC", "1")))      # split-K kernel for FC-like layers (deep K, tiny output volume)
 USE_PERSIST = bool(int(os.environ.get("SP_CONV_PERSIST", "0")))     # persistent double-buffered conv variant: measured slower than 3 workgroups/CU (272 vs 238 us on 16->16 @126^3), opt-in
@@ -307,7 +308,7 @@ class ConvRunner:
         a.act, a.act_param = act, act_param
         st = stream()
         if self.uses_zm():
-            assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY), \
+            assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"
             return self._run_zm(a, x_planar, batch, stats is not None, st)
@@ -368,6 +369,7 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
     a.ooD, a.ooH, a.ooW = 0, 0, 0
     a.o0D, a.o0H, a.o0W = sub.o0
     a.MT, a.NT, a.NTtot = z["MT"], z["NT"], z["NT"]
+    a.Cout = z["NT"] * 16            # whole tiles: channels past op.cout have zero weights and bias
     a.dma, a.persist, a.zfill = 1, 5, 0
     a.octs_per_group, a.ngroups, a.opp, a.vsb = 2 * z["P"], 1, 2, 32
     a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0

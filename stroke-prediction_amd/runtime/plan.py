@@ -375,9 +375,10 @@ def zm_plan(op: ConvOp):
     sub = op.subs[0]
     if len(sub.taps) != 27 or tuple(sub.ext) != (3, 3, 3) or tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0):
         return None
-    if op.cpi % 16 or op.cout % 16 or op.cin != op.cpi or op.cpo < op.cout:
+    # whole 16-channel planes / tiles in memory; channels past cin / cout (24 -> 32 in the CAE) carry zero weights and bias
+    P_, NT = op.cpi // 16, -(-op.cout // 16)
+    if op.cpi % 16 or op.cpo % 16 or op.cin > op.cpi or op.cpo < NT * 16:
         return None
-    P_, NT = op.cpi // 16, op.cout // 16
     if (P_, NT) not in ZM_CONFIGS:
         return None
     MT, nslot, nw = ZM_CONFIGS[(P_, NT)]

@@ -353,6 +353,40 @@ def test_header_only_conv3d_entry_points(cin, cout, grad, fold):
         torch.testing.assert_close(stats.sum(0)[:, 0].cpu(), got.double().sum((0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(got.numel() / cout))
 
 
+@pytest.mark.parametrize("cin,cout,dims,B,pad", [(16, 16, (9, 36, 40), 2, (1, 0, 0)), (24, 24, (6, 34, 36), 1, (1, 2, 2)),
+                                                 (16, 24, (5, 33, 20), 2, (1, 1, 1)), (32, 16, (4, 40, 17), 2, (0, 0, 0))])
+def test_z_marching_kernel_padded_elu(cin, cout, dims, B, pad):
+    """the CAE's stride-1 3x3x3 layers on the z-marching kernel: zero padding from the zero page, ELU epilogue, channel
+    counts that are not multiples of 16 (24 -> pitch 32, zero weights and bias on the pad channels), statistics"""
+    from stroke_prediction_amd.runtime import plan as P
+    O.ZM_MIN_PLANES = 0
+    g = torch.Generator().manual_seed(cin * 5 + cout)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    x = bf(torch.randn(B, cin, *dims, generator=g))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    op = P.conv_fwd_op(cin, cout, 3, 1, pad, dims, cpi, cpo, L.SP_BF16)
+    run = O.ConvRunner(op, DEV, zm_batch=B)
+    assert run.uses_zm()
+    run.prep(w.to(DEV), b.to(DEV))
+    xs = _to_cl(x, cpi)
+    y = O.alloc_cl(B, op.y_dims, cpo, L.SP_BF16, DEV)
+    y.fill_(7.0)
+    nrep = 4
+    stats = torch.zeros(nrep * cpo * 2, dtype=torch.float64, device=DEV)
+    run.run(xs, y, B, None, None, L.ACT_ELU, 1.0, stats, stats_nrep=nrep)
+    ref = F.elu(F.conv3d(x, bf(w), b, padding=pad), 1.0)
+    got = _from_cl(y, cout)
+    torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
+    if cpo > cout:
+        assert float(y[..., cout:].float().abs().max()) == 0.0
+    st = stats.view(nrep, cpo, 2).sum(0).cpu()
+    nvox = got.numel() / cout
+    torch.testing.assert_close(st[:cout, 0], got.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(nvox))
+    torch.testing.assert_close(st[:cout, 1], (got.double() ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(nvox))
+    assert float(st[cout:].abs().max()) == 0.0 if cpo > cout else True
+
+
 # ------------------------------------------------------------------------------------------------ multi-step fixtures
 def _build(ch, seed, dtype, cls=Unet3D):
     model = cls(ch, dtype=dtype)
