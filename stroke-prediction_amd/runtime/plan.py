@@ -195,7 +195,7 @@ def _pick_rows(out_dims, fits):
     raise AssertionError("no tile configuration fits LDS")
 
 
-def _plan_sub(op: ConvOp, sub: SubConv):
+def _plan_sub(op: ConvOp, sub: SubConv, force_rows=None):
     s = op.stride
     ext = sub.ext
     octs = op.cpi // 8
@@ -210,7 +210,7 @@ def _plan_sub(op: ConvOp, sub: SubConv):
         d = tile_dims(c)
         return d[0] * d[1] * d[2] * (opp + 1) * 16 * np_planes + 4096 <= (budget if limit == "budget" else 156 * 1024)
 
-    mt, td, th = _pick_rows(sub.out_dims, fits)
+    mt, td, th = _pick_rows(sub.out_dims, fits) if force_rows is None else force_rows
     # Layers with two or more output tiles and at most four 16-channel input planes: 4x4x16-voxel tiles (MT = 4) instead of
     # 4x8x16.  The staged halo tile shrinks from 70 KB to ~41 KB for two planes, three or four workgroups fit a CU, and
     # their stage / MFMA / store phases overlap (tools/stamp_conv.py: each phase leaves the matrix pipe idle for its own
@@ -218,7 +218,7 @@ def _plan_sub(op: ConvOp, sub: SubConv):
     # (96->32) the larger halo re-read costs more than the overlap gains (100 -> 114 us).  SP_PLAN_ROWS_WIDE=MT,TD,TH
     # overrides, SP_PLAN_ROWS_WIDE=0 restores the large tile.
     _force = os.environ.get("SP_PLAN_ROWS_WIDE", "4,4,4")
-    if _force not in ("", "0") and -(-op.cout // 16) >= 2 and op.dtype == 0 and op.cpi <= 64 and s == (1, 1, 1):
+    if force_rows is None and _force not in ("", "0") and -(-op.cout // 16) >= 2 and op.dtype == 0 and op.cpi <= 64 and s == (1, 1, 1):
         c = tuple(int(v) for v in _force.split(","))
         if fits(c, "hard") and sub.out_dims[0] >= c[1] and sub.out_dims[1] >= c[2]:
             mt, td, th = c
@@ -343,6 +343,17 @@ def _finish(op: ConvOp):
         op.nt, op.nttot = 1, -(-op.cout // 16)
     for sub in op.subs:
         _plan_sub(op, sub)
+    # The parity classes of a transposed / strided-gradient op go out in ONE launch when they share the register blocking
+    # (sp_conv3d_igemm_multi): classes whose extents differ by a voxel may pick different row tiles -- settle on the smallest
+    # that every class can stage.
+    if len(op.subs) > 1 and len({(sb.tile["MT"], sb.tile["TD"], sb.tile["TH"]) for sb in op.subs}) > 1:
+        for cand in sorted({(sb.tile["MT"], sb.tile["TD"], sb.tile["TH"]) for sb in op.subs}):
+            try:
+                for sub in op.subs:
+                    _plan_sub(op, sub, force_rows=cand)
+                break
+            except AssertionError:
+                continue
     return op
 
 

@@ -194,3 +194,43 @@ def test_z_marching_tables(cin, cout):
         assert int(z["ktab"].max()) + 16 <= z["P"] * z["ITH"] * P.ZM_ITW * 32
     assert P.zm_plan(P.conv_fwd_op(96, 32, 3, 1, 0, dims, 96, 32)) is None         # weight set too large: tiled kernel
     assert P.zm_plan(P.conv_fwd_op(16, 24, 3, 2, 1, dims, 16, 24)) is None         # strided
+
+
+def test_fc_plan_tables():
+    """runtime/plan.py:fc_plan (split-K kernel for the FC-like layers): tap-major K order, steps per tap padded to the kernel's
+    prefetch depth, every (tap, octet) exactly once, padding entries -1"""
+    from stroke_prediction_amd.runtime import plan as P
+    op = P.convT_fwd_op(800, 100, 3, 1, 0, (1, 10, 10), 800, 112, 0)
+    f = P.fc_plan(op)
+    assert f is not None and f["ntap"] == 27 and f["NT"] == 7
+    assert f["spt"] % 4 == 0 and f["spt"] * 4 >= 100 and f["nsteps"] == 27 * f["spt"]
+    km = f["kmap"].reshape(27, f["spt"] * 4)
+    for t in range(27):
+        real = km[t][km[t] >= 0]
+        assert len(real) == 100 and set(int(v) & 0xffff for v in real) == set(range(100))
+        assert len({int(v) >> 16 for v in real}) == 1
+    assert len({int(km[t][0]) >> 16 for t in range(27)}) == 27          # every source tap once
+    assert f["taps"].shape == (27, 3)
+    # shallow K or big volumes stay on the tiled kernels
+    assert P.fc_plan(P.conv_fwd_op(100, 800, 3, 1, 0, (3, 12, 12), 112, 800, 0)) is None
+    assert P.fc_plan(P.conv_fwd_op(256, 16, 3, 1, 0, (40, 40, 40), 256, 16, 0)) is None
+
+
+def test_zm_plan_accepts_padded_channel_counts_and_padding():
+    """the CAE's 24-channel layers (pitch 32) and padded convolutions get z-marching plans; the tables only depend on (P, NT)"""
+    from stroke_prediction_amd.runtime import plan as P
+    a = P.zm_plan(P.conv_fwd_op(24, 24, 3, 1, (1, 2, 2), (8, 40, 40), 32, 32, 0))
+    b = P.zm_plan(P.conv_fwd_op(32, 32, 3, 1, 0, (8, 40, 40), 32, 32, 0))
+    assert a is not None and (a["P"], a["NT"]) == (2, 2)
+    np.testing.assert_array_equal(a["ktab"], b["ktab"])
+    np.testing.assert_array_equal(a["kmap"], b["kmap"])
+    assert P.zm_plan(P.conv_fwd_op(24, 24, 3, 1, 0, (8, 40, 40), 24, 24, 0)) is None       # pitch not a multiple of 16
+
+
+def test_parity_classes_share_one_row_tile():
+    """sp_conv3d_igemm_multi needs one register blocking for all classes of an op"""
+    from stroke_prediction_amd.runtime import plan as P
+    for op in (P.convT_fwd_op(100, 32, 3, 2, 0, (3, 12, 12), 112, 32, 0), P.convT_fwd_op(16, 16, 2, 2, 0, (14, 62, 62), 16, 16, 0),
+               P.conv_dgrad_op(16, 24, 3, 2, 1, (28, 124, 124), 32, 16, 0)):
+        assert len(op.subs) == 8
+        assert len({(sb.tile["MT"], sb.tile["TD"], sb.tile["TH"]) for sb in op.subs}) == 1
