@@ -342,9 +342,13 @@ def finish(res, rank):
 
 
 def use_graph_for(args, world):
-    # N = 1: the step is replayed as one hipGraph (Learner(graph=True)).  N > 1: eager launches by default -- the RCCL
-    # collectives inside a capture are the one thing that cannot be rehearsed on a 1-GPU box; SP_DIST_GRAPH=1 captures too.
-    return not args.no_graph and (world == 1 or bool(os.environ.get("SP_DIST_GRAPH")))
+    # N = 1: the step is replayed as one hipGraph (Learner(graph=True)).  N > 1, fast mode: forward + loss + backward are one
+    # graph, the gradient all-reduce and the fused Adam launch follow eagerly (no collective inside a capture -- the one thing
+    # that cannot be rehearsed with several ranks on a 1-GPU box; SP_DIST_GRAPH=1 captures it too).  Exact mode (collectives
+    # inside forward and backward): eager.  SP_DIST_EAGER=1: eager launches for N > 1 as in round 1.
+    if args.no_graph:
+        return False
+    return world == 1 or (args.dp_mode == "fast" and not os.environ.get("SP_DIST_EAGER"))
 
 
 # ------------------------------------------------------------------------------------------------ workloads
@@ -386,7 +390,8 @@ def bench_unet(args, world, rank, dev, four_scale=False):
     dt, last = timed_steps(step, args, world, dev)
     ms = 1e3 * dt / args.steps
     vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
-    launch_mode = "hipGraph (Learner(graph=True))" if use_graph else "eager"
+    launch_mode = ("hipGraph (Learner(graph=True))" if world == 1 or os.environ.get("SP_DIST_GRAPH") else
+                   "hipGraph of forward + loss + backward, then all-reduce and Adam (Learner(graph=True))") if use_graph else "eager"
     name = ("4-scale 3D U-Net --channels %s" % " ".join(map(str, CHANNELS4))) if four_scale else \
         "3D U-Net --channels 2 16 32 64 32 16 32 2"
     res = {
@@ -397,7 +402,9 @@ def bench_unet(args, world, rank, dev, four_scale=False):
                                % (name, args.batch, args.size, out[0], "configs[4] topology" if four_scale else "configs[1]"),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(last.loss),
                    "launch": launch_mode, "dp_mode": args.dp_mode if world > 1 else None,
-                   "grad_exchange": (("%d buckets, reverse layer order, async on the RCCL stream" % sync.nbuckets_last)
+                   "grad_exchange": (("one all-reduce of the flat gradient buffer between the backward graph and Adam"
+                                      if (use_graph and not os.environ.get("SP_DIST_GRAPH")) else
+                                      "%d buckets, reverse layer order, async on the RCCL stream" % sync.nbuckets_last)
                                      if not args.no_buckets else "one blocking all-reduce") if world > 1 else None},
     }
     if not args.no_kernel_timing:

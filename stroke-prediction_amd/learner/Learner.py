@@ -11,6 +11,8 @@ passes one (any ``torch.optim`` optimizer still works).  torch-0.3 idioms of the
 import json
 import math
 
+import os
+
 import torch
 
 import common.dto.MetricMeasuresDto as MetricMeasuresDtoInit
@@ -215,19 +217,48 @@ class Learner(Inference):
             g["static"][k].copy_(v, non_blocking=True)
         sbatch = dict(batch)
         sbatch.update(g["static"])
+        # Data-parallel replicas (parallel.DataParallelSync installed model.grad_sync): the gradient all-reduce stays OUTSIDE
+        # the capture -- forward + loss + backward are one graph, then the exchange of the flat gradient buffer (one RCCL
+        # call, 1.4 MB: latency-bound either way) and the fused Adam launch run eagerly.  SP_DIST_GRAPH=1 captures the
+        # collectives too (works with a one-rank communicator; not rehearsable with several ranks on a one-GPU box).
+        sync_fn = getattr(self._model, "grad_sync", None)
+        split = sync_fn is not None and not os.environ.get("SP_DIST_GRAPH")
+        if sync_fn is not None:
+            from stroke_prediction_amd.runtime import layers as _layers
+            if _layers.SYNC["on"]:                # exact mode exchanges BatchNorm sums inside forward and backward: no capture
+                return self._optimise(batch, epoch)
         if g["graph"] is None:
             if g["warm"] < self.GRAPH_WARMUP:
                 g["warm"] += 1
                 return self._optimise(sbatch, epoch)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            # thread_local: an RCCL watchdog thread may query events while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                g["dto"], g["loss"] = self._optimise(sbatch, epoch)
-            g["graph"] = graph
+            if split:
+                bucket_fn = self._model.grad_bucket_ready
+                self._model.grad_sync = self._model.grad_bucket_ready = None
+            try:
+                # thread_local: an RCCL watchdog thread may query events while this thread captures
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    if split:
+                        g["dto"] = self.inference_step(sbatch)
+                        g["loss"] = self.loss_step(g["dto"], epoch)
+                        self._optimizer.zero_grad()
+                        g["loss"].backward()
+                    else:
+                        g["dto"], g["loss"] = self._optimise(sbatch, epoch)
+            finally:
+                if split:
+                    self._model.grad_sync, self._model.grad_bucket_ready = sync_fn, bucket_fn
+            g["graph"], g["split"] = graph, split
         if hasattr(self._optimizer, "push_hyper"):
             self._optimizer.push_hyper()          # lr / betas as the schedulers left them
         g["graph"].replay()
+        if g.get("split"):
+            _, flat_grad = self._model.flat_buffers()
+            sync_fn(flat_grad, 0, flat_grad.numel())
+            root = self._model._flat_root() if hasattr(self._model, "_flat_root") else self._model
+            root._grads_synced = True             # an optimiser pre-hook (DataParallelSync(optimizer=...)) must not exchange again
+            self._optimizer.step()
         return g["dto"], g["loss"]
 
     def train_batch(self, batch: dict, epoch) -> MetricMeasuresDto:
