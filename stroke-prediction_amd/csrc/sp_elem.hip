@@ -1306,8 +1306,9 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
       const int m = z0 - 2 + s;
       const bool yplane = m + 1 >= 0 && m + 1 < D;
       float P1[8], P2[8];
+      f2_t Pp1[4], Pp2[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) P1[j] = P2[j] = 0.f;
+      for (int j = 0; j < 4; ++j) Pp1[j] = Pp2[j] = f2_splat(0.f);
       if (s == 0) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NJ + NJY) : "memory");
         __builtin_amdgcn_s_barrier();
@@ -1326,19 +1327,23 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
             const float wyb = bb == 0 ? wy[0] : (bb == 1 ? wy[1] : (bb == 2 ? wy[2] : wy[3]));
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-              const float w = wyb * wx[cc];
-              float a8[8];
-              Store<bf16_t>::ld8(gb + ((2 * ty + bb) * RX + 2 * tx + cc) * CP + oc * 8, a8);
+              const f2_t w2 = f2_splat(wyb * wx[cc]);
+              RawOct<bf16_t> ro;
+              ro.load(gb + ((2 * ty + bb) * RX + 2 * tx + cc) * CP + oc * 8);
+              f2_t a2[4];
+              raw_get2(ro, a2);                      // packed pairs: v_pk_fma_f32 halves the multiply-adds of this VALU-bound loop
               if (h == 0) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) P1[q] = fmaf(w, a8[q], P1[q]);
+                for (int q = 0; q < 4; ++q) Pp1[q] = f2_fma(w2, a2[q], Pp1[q]);
               } else {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) P2[q] = fmaf(w, a8[q], P2[q]);
+                for (int q = 0; q < 4; ++q) Pp2[q] = f2_fma(w2, a2[q], Pp2[q]);
               }
             }
           }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { P1[2 * j] = Pp1[j].x; P1[2 * j + 1] = Pp1[j].y; P2[2 * j] = Pp2[j].x; P2[2 * j + 1] = Pp2[j].y; }
         int oz[4]; float wz[4], wn[4];
         upT_axis(max(m, 0), D, oz, wz);
         upT_axis(min(m + 1, D - 1), D, oz, wn);
