@@ -305,6 +305,38 @@ def roofline_from(agg, per_layer, nsteps, ms_per_step, dtype, layers_to=None, tr
     return roof, kernels
 
 
+def conv_roofline_unet(size, channels, batch, peak_tflops, kernels):
+    """the tighter per-layer bound  sum over the 3x3x3 layers and the three passes (forward, data gradient --
+    none for the first layer --, weight gradient) of  max(FLOP / MFMA peak, ideal bytes / HBM peak)  with every operand read
+    once and every result written once in bf16 (the weight-gradient output is negligible), against the measured time of the
+    same kernels (conv_igemm + conv_wgrad families).  3-scale topology of Unet3D.py:31-79."""
+    c = channels
+    d = size
+    layers = []
+    skips = []
+    for blk in range(3):                                   # block1..3 (valid convolutions, pool between)
+        cin, cout = c[blk], c[blk + 1]
+        layers += [(cin, cout, d), (cout, cout, d - 2)]
+        d -= 4
+        if blk < 2:
+            skips.append((cout, d))
+            d //= 2
+    for up, (cs, _) in zip((4, 5), reversed(skips)):       # block4, block5: upsample x2, concat with the cropped skip
+        d *= 2
+        cin, cout = c[up - 1] + cs, c[up]
+        layers += [(cin, cout, d), (cout, cout, d - 2)]
+        d -= 4
+    ideal = 0.0
+    for i, (cin, cout, din) in enumerate(layers):
+        vin, vout = batch * din ** 3, batch * (din - 2) ** 3
+        t = max(2.0 * 27 * cin * cout * vout / (peak_tflops * 1e12), (vin * cin + vout * cout) * 2 / (HBM_PEAK_GBS * 1e9))
+        ideal += t * (2 if i == 0 else 3)
+    measured = sum(kernels[k]["time_s_per_step"] for k in ("conv_igemm", "conv_wgrad") if k in kernels)
+    return {"ideal_ms": 1e3 * ideal, "measured_ms": 1e3 * measured, "frac": ideal / measured if measured else None,
+            "definition": "sum over the ten 3x3x3 layers x (fwd, dgrad, wgrad) of max(FLOP / %.0f TFLOP/s, bf16 operand bytes / %.0f GB/s)"
+                          % (peak_tflops, HBM_PEAK_GBS)}
+
+
 def init_dist(world, dev):
     import torch.distributed as dist
     if world > 1 or os.environ.get("SP_FORCE_SYNC"):      # SP_FORCE_SYNC: 1-rank RCCL group, rehearses capture on one GPU
@@ -413,6 +445,8 @@ def bench_unet(args, world, rank, dev, four_scale=False):
         roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None)
         if roof:
             res["roofline"], res["kernels"] = roof, kernels
+            if not four_scale and args.dtype == "bf16":
+                roof["conv_roofline"] = conv_roofline_unet(args.size, channels, args.batch, PEAK_TFLOPS[args.dtype], kernels)
         if args.size == 128 and not four_scale:
             res["train_step_tflops"] = TRAIN_GFLOP_PER_SAMPLE_128 * 1e9 * world * args.batch * args.steps / dt / 1e12
     if rank == 0 and world == 1 and not args.no_parity and not four_scale and args.dtype == "bf16":
