@@ -842,7 +842,7 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
 // One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
 // (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
+__global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
     const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, int ccs0, int cstride, Dims di, int CP, Dims dc,
     OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias) {
@@ -854,16 +854,16 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
   const int Dp = di.D / 2, Hp = di.H / 2, Wp = di.W / 2;                        // pooled dims (floor)
   const int cz = (di.D - dc.D) / 2, cy = (di.H - dc.H) / 2, cx = (di.W - dc.W) / 2;
   const int64_t nwin = (int64_t)di.B * Dw * Hw * Ww;
-  for (int i = threadIdx.x; i < 3 * CP; i += 256) cpl[i] = gp ? coefp[i] : 0.f;
+  float* csl = red + 4 * CP;                          // skip-side coefficients [3][CP]: LDS too (24 VGPRs less: 150 -> <= 128, one more wave per SIMD)
+  for (int i = threadIdx.x; i < 3 * CP; i += 256) {
+    cpl[i] = gp ? coefp[i] : 0.f;
+    const int r = i / CP, c = i - r * CP;
+    csl[i] = gs ? coefs[r * cstride + ccs0 + c] : 0.f;
+  }
   __syncthreads();
   float part[1][8];
-  float s0[8], s1[8], s2[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    part[0][j] = 0.f;
-    const int c = oc * 8 + j;
-    s0[j] = (gs && active) ? coefs[ccs0 + c] : 0.f; s1[j] = (gs && active) ? coefs[cstride + ccs0 + c] : 0.f; s2[j] = (gs && active) ? coefs[2 * cstride + ccs0 + c] : 0.f;
-  }
+  for (int j = 0; j < 8; ++j) part[0][j] = 0.f;
   const Unflat uf_(Dw, Hw, Ww);
   if (active) {
     // each workgroup walks ONE contiguous voxel range (neighbouring rows stay in its L1 / the XCD's L2)
@@ -920,7 +920,10 @@ __global__ __launch_bounds__(256) void pool_skip_act_bwd_kernel(
             Store<T>::ld8(gs + o, g8);
             // the skip half of the concat buffer is a verbatim crop of y: its value is the y just loaded
 #pragma unroll
-            for (int j = 0; j < 8; ++j) d[j] += s0[j] * g8[j] + s1[j] * yv[j] + s2[j];
+            for (int j = 0; j < 8; ++j) {
+              const int c = oc * 8 + j;
+              d[j] += csl[c] * g8[j] + csl[CP + c] * yv[j] + csl[2 * CP + c];
+            }
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_t<ACT>(act, ap, yv[j]); part[0][j] += d[j]; }
@@ -945,7 +948,7 @@ extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* 
   Dims di{B, D, H, W}, dc{B, Dc, Hc, Wc};
   const int64_t nwin = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
   const unsigned grid = grid_for(nwin, om.vpb);
-  const size_t sh = (size_t)CP * 4 * sizeof(float);
+  const size_t sh = (size_t)CP * 7 * sizeof(float);
 #define SP_L(A_)                                                                                                                          \
   if (dtype == SP_BF16) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
                                            (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0,   \
