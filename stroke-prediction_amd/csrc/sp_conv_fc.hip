@@ -37,7 +37,10 @@ __global__ __launch_bounds__(256) void conv_fc_partial_kernel(const ConvFcDev P)
   const int32_t* tp = a.taps + tap * 3;
   const int iz = oz * a.sD + a.o0D + tp[0], iy = oy * a.sH + a.o0H + tp[1], ix = ox * a.sW + a.o0W + tp[2];
   const bool inside = m < P.M && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
-  const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.x) + ((((int64_t)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix) * a.CPi;
+  // channels-last: 16 bytes of octet o at voxel*CPi + 8 o; plane-major ([CPi/16][B][D][H][W][16], a.x_plane elements per plane):
+  // at (o >> 1) * x_plane + voxel*16 + 8 (o & 1)
+  const int64_t vox = (((int64_t)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix;
+  const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.x) + vox * (a.x_plane ? 16 : a.CPi);
   const uint4* wf = reinterpret_cast<const uint4*>(a.wfrag) + ((size_t)tap * P.spt * P.NTtot + nt0) * 64 + lane;
   f32x4 acc[FC_NTB];
 #pragma unroll
@@ -49,7 +52,8 @@ __global__ __launch_bounds__(256) void conv_fc_partial_kernel(const ConvFcDev P)
     auto fetch = [&](int s, int u) {
       const int oct = s * 4 + g;
       bq[u] = make_uint4(0, 0, 0, 0);
-      if (inside && oct < P.octs) bq[u] = *reinterpret_cast<const uint4*>(xp + oct * 8);
+      if (inside && oct < P.octs)
+        bq[u] = *reinterpret_cast<const uint4*>(a.x_plane ? xp + (int64_t)(oct >> 1) * a.x_plane + (oct & 1) * 8 : xp + oct * 8);
       const uint4* ws = wf + (size_t)s * P.NTtot * 64;
 #pragma unroll
       for (int n = 0; n < FC_NTB; ++n) aq[u][n] = ws[(n < nn ? n : nn - 1) * 64];      // tiles past the last one: a valid fragment, result dropped
@@ -178,6 +182,7 @@ extern "C" int sp_conv_fc_workspace(int32_t B, int32_t Do, int32_t Ho, int32_t W
 
 extern "C" int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag && a->partial && a->taps, "sp_conv_fc: null pointer");
+  SP_CHECK_ARG(a->x_plane == 0 || a->CPi % 16 == 0, "sp_conv_fc: plane-major input needs whole 16-channel planes");
   SP_CHECK_ARG(a->CPi % 8 == 0 && a->CPo % 8 == 0 && a->CPo <= 2048 && a->Cout <= a->CPo && a->Cout >= 1, "sp_conv_fc: channel pitches");
   SP_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "sp_conv_fc: scale and shift come together");
   SP_CHECK_ARG(a->ntap >= 1 && a->ntap <= 65535, "sp_conv_fc: taps");

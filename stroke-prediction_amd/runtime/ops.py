@@ -312,9 +312,9 @@ class ConvRunner:
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"
             return self._run_zm(a, x_planar, batch, stats is not None, st)
-        if self.fc is not None and not x_planar:
+        if self.fc is not None:     # (its fragments are the only ones packed: every call of this runner goes there)
             return _run_fc(self, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep,
-                           stats_mode, aux, st)
+                           stats_mode, aux, st, x_planar)
         multi = (L.ConvArgs * len(self.subs))() if (USE_MULTI and 2 <= len(self.subs) <= 8 and not x_planar) else None
         for si, s in enumerate(self.subs):
             sub = s["sub"]
@@ -354,10 +354,10 @@ class ConvRunner:
 
 
 def wgrad_dma_ok(cpi, cpo, dtype):
-    """channel-tile limits of the DMA weight-gradient kernel (64-wide outputs: the register-staged kernel measured faster)"""
+    """the DMA weight-gradient kernels apply (whole 16-channel tiles; the tile-count limits are knobs only)"""
     return bool(USE_DMA and dtype == L.SP_BF16 and cpi % 16 == 0 and cpo % 16 == 0
-                and -(-cpo // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "4"))
-                and -(-cpi // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))
+                and -(-cpo // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "64"))
+                and -(-cpi // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))
 
 
 def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
@@ -378,7 +378,8 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
         L.call("sp_conv3d_zm", C.byref(a), ptr(zero_page(runner.device)), st)
 
 
-def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep, stats_mode, aux, st):
+def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep, stats_mode, aux, st,
+            x_planar=False):
     """split-K kernel for FC-like layers (csrc/sp_conv_fc.hip)"""
     op, f = runner.op, runner.fc
     sub = op.subs[0]
@@ -402,6 +403,7 @@ def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtyp
     a.act, a.act_param = act, act_param
     a.stats_mode, a.stats_nrep = stats_mode, stats_nrep
     a.dtype_out = op.dtype if dtype_out is None else dtype_out
+    a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
     with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s fc%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)),
                                                                     " +stats" if stats is not None else "")):
         L.call("sp_conv_fc", C.byref(a), st)
@@ -437,7 +439,7 @@ class WgradRunner:
         # bf16 fast path: un-padded stride-1 3x3x3 convolution -> DMA double-buffered kernel, BatchNorm folded into finish
         self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and max(p) <= 2
                         and tuple(in_dims) == tuple(d + 2 - 2 * q for d, q in zip(out_dims, p)) and cpi % 16 == 0 and cpo % 16 == 0
-                        and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "4")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "8")))   # 64-wide outputs: register-staged kernel measured faster
+                        and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "64")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))   # (limits are knobs: the row-sliding kernel takes any tile counts -- 192->64 @88^3 2155 -> 706 us against the register-staged kernel)
         a.dma = int(self.dma)
         if self.dma:
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", "512"))

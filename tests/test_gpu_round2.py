@@ -740,3 +740,29 @@ def test_learner_split_graph_keeps_the_gradient_exchange_outside_the_capture(tmp
         out[tag] = model.flat_buffers()[0].clone()
     # same trajectory up to the run-to-run noise of four Adam steps (see the three-step fixture test)
     assert float((out["graph"] - out["eager"]).abs().max()) < 8e-3 and float((out["graph"] - out["eager"]).abs().mean()) < 2e-4
+
+
+@pytest.mark.parametrize("cin,cout,d,B", [(256, 64, 8, 2), (384, 128, 8, 1), (272, 48, 6, 3), (192, 64, 8, 2)])
+def test_many_plane_concat_input_small_volume(cin, cout, d, B):
+    """plane-major (concat-buffer) input with 12-24 planes at the tiny volumes of the 4-scale net's deepest up block: the
+    split-K kernel (Cin >= 256, few output voxels) has to read the plane-major layout too -- its fragments are the only
+    ones such a runner packs"""
+    from stroke_prediction_amd.runtime import plan as P
+    dims = (d, d, d)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = bf(torch.randn(B, cin, *dims, generator=g))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
+    run = O.ConvRunner(op, DEV)
+    assert (run.fc is not None) == (cin >= 256)
+    run.prep(w.to(DEV), torch.zeros(cout, device=DEV))
+    xs = _to_cl(x, cin)
+    xp = xs.view(B, *dims, cin // 16, 16).permute(4, 0, 1, 2, 3, 5).contiguous().view(B, *dims, cin)
+    ref = F.conv3d(x, bf(w))
+    outs = []
+    for planar, xin in ((False, xs), (True, xp)):
+        y = O.alloc_cl(B, op.y_dims, cout, L.SP_BF16, DEV)
+        run.run(xin, y, B, None, None, L.ACT_NONE, 0.0, None, x_planar=planar)
+        outs.append(_from_cl(y, cout))
+        torch.testing.assert_close(outs[-1], ref, rtol=3e-2, atol=3e-2)
+    assert torch.equal(outs[0], outs[1])
