@@ -28,6 +28,8 @@ WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient part
 # 157 -> 157 us at 126^3) but those layers sit at the HBM ridge (216 FLOP per byte of activations in + out), and the
 # second set of weight fragments costs what the forward gains: 4.00 vs 4.00 ms per step.
 USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
+USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with too many output tiles for one z-marching launch: a launch per 32-channel slice
+ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "8000"))  # ... when the volume is large enough (measured: 32->96 @48^3 gains nothing, @166^3 40 %)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
 USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
 USE_FC = bool(int(os.environ.get("SP_CONV_FC", "1")))      # split-K kernel for FC-like layers (deep K, tiny output volume)
@@ -194,7 +196,19 @@ class ConvRunner:
                 zm = dict(zm, ktab_d=_dev_i32(zm["ktab"], device), kmap_d=_dev_i32(zm["kmap"], device),
                           hi=torch.empty(zm["nsteps"] * zm["NT"] * 64 * 8, dtype=torch.bfloat16, device=device))
             st["zm"] = zm
-            fc = P.fc_plan(op) if (USE_FC and zm is None) else None
+            # more output tiles than a z-marching kernel holds: one launch per slice of output channels (plan.zm_slices)
+            zms = None
+            if zm is None and USE_ZM and USE_DMA and zm_batch and USE_ZM_SLICES:
+                sl = P.zm_slices(op)
+                cols = -(-op.subs[0].out_dims[1] // 16) * -(-op.subs[0].out_dims[2] // 16) if sl else 0
+                if sl and zm_batch * cols * op.subs[0].out_dims[0] >= ZM_SLICE_MIN_PLANES:
+                    zms = []
+                    for c0, cn, sub_op in sl:
+                        z = P.zm_plan(sub_op)
+                        zms.append(dict(z, c0=c0, cn=cn, ktab_d=_dev_i32(z["ktab"], device), kmap_d=_dev_i32(z["kmap"], device),
+                                        hi=torch.empty(z["nsteps"] * z["NT"] * 64 * 8, dtype=torch.bfloat16, device=device)))
+            st["zms"] = zms
+            fc = P.fc_plan(op) if (USE_FC and zm is None and zms is None) else None
             if fc is not None:      # split-K kernel for FC-like layers: its own (tap-major) K order and fragments
                 fc = dict(fc, kmap_d=_dev_i32(fc["kmap"], device), taps_d=_dev_i32(fc["taps"], device),
                           hi=torch.empty(fc["nsteps"] * fc["NT"] * 64 * 8, dtype=torch.bfloat16, device=device), partial=None)
@@ -207,22 +221,27 @@ class ConvRunner:
         self.subs = st["subs"]
         self.bias = st["bias"]
         self.zm = st.get("zm")
-        self.zm_batch = zm_batch if self.zm is not None else None
+        self.zms = st.get("zms")
+        self.zm_batch = zm_batch if (self.zm is not None or self.zms is not None) else None
         self.fc = st.get("fc")
 
     def uses_zm(self):
         """the z-marching kernel runs this op (and its weight fragments are the only ones packed)"""
-        return self.zm is not None
+        return self.zm is not None or self.zms is not None
 
     def _pack(self):
-        """(kmap, nsteps, hi, NTtot) of the fragments the kernel that will run this op reads"""
+        """(kmap, nsteps, hi, lo, NTtot, first output channel, output channels) of every set of fragments the kernel(s) that
+        will run this op read; all but the output-channel slices of the z-marching kernel cover the whole op"""
+        cout = self.op.cout
+        if self.zms is not None:
+            return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"], z["c0"], z["cn"]) for z in self.zms]
         if self.uses_zm():
             z = self.zm
-            return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"])]
+            return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"], 0, cout)]
         if self.fc is not None:
             f = self.fc
-            return [(f["kmap_d"], f["nsteps"], f["hi"], None, f["NT"])]
-        return [(s["kmap"], s["nsteps"], s["hi"], s["lo"], self.op.nttot) for s in self.subs]
+            return [(f["kmap_d"], f["nsteps"], f["hi"], None, f["NT"], 0, cout)]
+        return [(s["kmap"], s["nsteps"], s["hi"], s["lo"], self.op.nttot, 0, cout) for s in self.subs]
 
     @property
     def has_bias(self):
@@ -250,7 +269,7 @@ class ConvRunner:
             self._st["prep_key"] = None
         packs = self._pack()
         if fold_scale is not None and fold_shift is not None and len(packs) == 1:
-            kmap, nsteps, hi, lo, nttot = packs[0]
+            kmap, nsteps, hi, lo, nttot, _, _ = packs[0]
             ntaps = w.numel() // (op.cin * op.cout)
             L.call("sp_conv_prep_folded", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(kmap), nsteps, nttot,
                    ptr(hi), ptr(lo), ptr(fold_scale), ntaps, ptr(b), ptr(fold_shift), ptr(self.bias), nttot * 16,
@@ -259,8 +278,8 @@ class ConvRunner:
             if not self.uses_zm() and self.fc is None:
                 self._prep_zr(w, fold_scale)
             return
-        for kmap, nsteps, hi, lo, nttot in packs:
-            L.call("sp_conv_prep_weights", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(kmap), nsteps,
+        for kmap, nsteps, hi, lo, nttot, c0, cn in packs:      # (a slice: element (co', ci', tap) of it is w[(c0 + co') sCo + ci' sCi + tap])
+            L.call("sp_conv_prep_weights", w.data_ptr() + 4 * c0 * op.w_sco, op.w_sco, op.w_sci, cn, op.cin, ptr(kmap), nsteps,
                    nttot, ptr(hi), ptr(lo), ptr(fold_scale), stream())
         if not self.uses_zm() and self.fc is None:
             self._prep_zr(w, fold_scale)
@@ -311,6 +330,10 @@ class ConvRunner:
             assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"
+            if self.zms is not None:
+                for z in self.zms:
+                    _run_zm_impl(self, a, x_planar, batch, stats is not None, st, z=z, y=y, stats=stats, use_bias=use_bias)
+                return
             return self._run_zm(a, x_planar, batch, stats is not None, st)
         if self.fc is not None:     # (its fragments are the only ones packed: every call of this runner goes there)
             return _run_fc(self, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep,
@@ -360,9 +383,16 @@ def wgrad_dma_ok(cpi, cpo, dtype):
                 and -(-cpi // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))
 
 
-def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
-    op, z = runner.op, runner.zm
+def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, stats=None, use_bias=True):
+    op = runner.op
+    sliced = z is not None
+    z = runner.zm if z is None else z
     sub = op.subs[0]
+    if sliced:      # output channels [c0, c0 + cn) of y (full pitch), of the bias and of the statistics rows
+        esz = y.element_size()
+        a.y = y.data_ptr() + z["c0"] * esz
+        a.bias = (runner.bias.data_ptr() + 4 * z["c0"]) if (runner.has_bias and use_bias) else None
+        a.stats = None if stats is None else stats.data_ptr() + 16 * z["c0"]
     a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"]), None, ptr(z["ktab_d"])
     a.Do, a.Ho, a.Wo = sub.out_dims
     a.osD, a.osH, a.osW = 1, 1, 1
@@ -373,8 +403,9 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st):
     a.dma, a.persist, a.zfill = 1, 5, 0
     a.octs_per_group, a.ngroups, a.opp, a.vsb = 2 * z["P"], 1, 2, 32
     a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
-    with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s zm%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)),
-                                                                    " +stats" if with_stats else "")):
+    with _Timed("conv_igemm", op.flops(batch) * (z["cn"] / op.cout if sliced else 1.0),
+                "%d->%d @%s zm%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " slices" if sliced else "",
+                                       " +stats" if with_stats else "")):
         L.call("sp_conv3d_zm", C.byref(a), ptr(zero_page(runner.device)), st)
 
 
@@ -542,7 +573,7 @@ def prep_batch(pairs):
     # the cached device table holds raw addresses only: key it on every address it contains, so an entry can only be
     # replayed for runners that own exactly those buffers (ids / addresses recycled after an engine was freed)
     tkey = tuple((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, r.op.nttot) +
-                 tuple((k.data_ptr(), n, h.data_ptr(), 0 if lo_ is None else lo_.data_ptr(), nt_) for k, n, h, lo_, nt_ in r._pack()) +
+                 tuple((k.data_ptr(), n, h.data_ptr(), 0 if lo_ is None else lo_.data_ptr(), nt_, c0_, cn_) for k, n, h, lo_, nt_, c0_, cn_ in r._pack()) +
                  tuple((0 if sub.get("ktab_zr") is None else sub["hi_zr"].data_ptr()) for sub in r.subs)
                  for r, w, _ in todo)
     tab = _prep_tables.get(tkey)
@@ -552,8 +583,8 @@ def prep_batch(pairs):
         items = []
         for r, w, _ in todo:
             assert w.dtype == torch.float32 and w.is_contiguous()
-            for kmap, nsteps, hi, lo, nttot in r._pack():
-                items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, kmap.data_ptr(), nsteps,
+            for kmap, nsteps, hi, lo, nttot, c0, cn in r._pack():
+                items.append((w.data_ptr() + 4 * c0 * r.op.w_sco, r.op.w_sco, r.op.w_sci, cn, r.op.cin, kmap.data_ptr(), nsteps,
                               nttot, hi.data_ptr(), 0 if lo is None else lo.data_ptr(), 0))
             for sub in ([] if r.uses_zm() else r.subs):
                 if sub.get("ktab_zr") is not None:

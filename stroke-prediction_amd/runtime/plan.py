@@ -435,3 +435,27 @@ def fc_plan(op: ConvOp):
             kmap[ti * spt * 4 + o] = (t[3] << 16) | o
     taps = np.array([[t[0], t[1], t[2]] for t in sub.taps], dtype=np.int32)
     return dict(ntap=ntap, spt=spt, nsteps=ntap * spt, NT=-(-op.cout // 16), kmap=kmap, taps=taps)
+
+
+def zm_slices(op: ConvOp):
+    """Output-channel slices [(c0, cn)] that put an op with MORE output tiles than any z-marching kernel holds onto that
+    kernel anyway: one launch per slice of 32 (or 16) output channels, every launch reading the (narrow) input again --
+    32 -> 64 forward, 32 -> 96 data gradient of the 4-scale net (tiled kernel 610-690 TFLOP/s, z-marching 1100+).  None when
+    the op is not a candidate."""
+    if op.dtype != 0 or op.cout % 16 or op.cpi % 16 or op.cpi // 16 > 2 or zm_plan(op) is not None:
+        return None
+    import dataclasses
+    P_, nt = op.cpi // 16, op.cout // 16
+    step = 2 if (P_, 2) in ZM_CONFIGS else 1
+    if (P_, step) not in ZM_CONFIGS or nt <= step:
+        return None
+    out = []
+    c0 = 0
+    while c0 < op.cout:
+        cn = min(step * 16, op.cout - c0)
+        sub_op = dataclasses.replace(op, cout=cn)
+        if zm_plan(sub_op) is None:
+            return None
+        out.append((c0, cn, sub_op))
+        c0 += cn
+    return out

@@ -766,3 +766,49 @@ def test_many_plane_concat_input_small_volume(cin, cout, d, B):
         outs.append(_from_cl(y, cout))
         torch.testing.assert_close(outs[-1], ref, rtol=3e-2, atol=3e-2)
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("kind,cin,cout,dims,B", [("fwd", 32, 64, (6, 20, 40), 2), ("fwd", 16, 80, (5, 19, 33), 1),
+                                                  ("dgrad", 96, 32, (7, 18, 37), 2), ("dgrad", 64, 16, (6, 21, 20), 1)])
+def test_z_marching_output_slices(kind, cin, cout, dims, B, monkeypatch):
+    """ops with more output tiles than a z-marching kernel holds run as one launch per 32-channel slice of the output
+    (runtime/plan.py:zm_slices): forward 32 -> 64 with bias / LeakyReLU / statistics, and the data gradient of a 96 -> 32
+    convolution (32 -> 96), against torch and against the tiled kernel"""
+    from stroke_prediction_amd.runtime import plan as P
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    monkeypatch.setattr(O, "ZM_SLICE_MIN_PLANES", 0)
+    g = torch.Generator().manual_seed(cin * 3 + cout)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    outs = {}
+    for sliced in (True, False):
+        monkeypatch.setattr(O, "USE_ZM_SLICES", sliced)
+        if kind == "fwd":
+            x = bf(torch.randn(B, cin, *dims, generator=torch.Generator().manual_seed(1)))
+            op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
+            run = O.ConvRunner(op, DEV, zm_batch=B)
+            assert (run.zms is not None) == sliced and run.zm is None
+            run.prep(w.to(DEV), b.to(DEV))
+            y = O.alloc_cl(B, op.y_dims, cout, L.SP_BF16, DEV)
+            y.fill_(5.0)
+            nrep = 4
+            stats = torch.zeros(nrep * cout * 2, dtype=torch.float64, device=DEV)
+            run.run(_to_cl(x, cin), y, B, None, None, L.ACT_LEAKY, LEAKY, stats, stats_nrep=nrep)
+            got = _from_cl(y, cout)
+            torch.testing.assert_close(got, F.leaky_relu(F.conv3d(x, bf(w), b), LEAKY), rtol=3e-2, atol=3e-2)
+            st = stats.view(nrep, cout, 2).sum(0).cpu()
+            torch.testing.assert_close(st[:, 0], got.double().sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(got.numel() / cout))
+        else:
+            od = tuple(v - 2 for v in dims)
+            dz = bf(torch.randn(B, cout, *od, generator=torch.Generator().manual_seed(2)))
+            dop = P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin, L.SP_BF16)
+            run = O.ConvRunner(dop, DEV, zm_batch=B)
+            assert (run.zms is not None) == sliced and run.zm is None
+            run.prep(w.to(DEV))
+            y = O.alloc_cl(B, dims, cin, L.SP_BF16, DEV)
+            y.fill_(5.0)
+            run.run(_to_cl(dz, cout), y, B)
+            got = _from_cl(y, cin)
+            torch.testing.assert_close(got, F.conv_transpose3d(dz, bf(w)), rtol=3e-2, atol=3e-2)
+        outs[sliced] = got
+    torch.testing.assert_close(outs[True], outs[False], rtol=2e-2, atol=2e-2)
