@@ -174,6 +174,138 @@ __global__ __launch_bounds__(256) void conv_fc_finish_kernel(const ConvFcDev P) 
   }
 }
 
+// ---- pointwise (1x1x1) convolutions with few input channels (the CAE's tail, Cae3D.py:214-218: 16 -> 16 and 16 -> 1 at
+// 28 x 128 x 128, and their data gradients): the same operand-from-global MFMA formulation with ONE K step and no K split
+// -- weights resident in registers, a wave walks 16-voxel tiles, bias / activation / statistics / store in the same kernel.
+// Through the tiled implicit-GEMM kernels such a layer cost 41-72 us for 117 MB of traffic.
+#define PW_SPT 2            // K steps (32 channels each) at most: Cin <= 64
+template <int SPT, int NTB, typename TOUT>      // compile-time K steps and output tiles per workgroup: no guard around an MFMA, no idle MFMA
+__global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
+  const sp_conv_fc_args& a = P.a;
+  __shared__ float red[NTB * 16 * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int vl = lane & 15, g = lane >> 4;
+  const int nt0 = blockIdx.y * NTB;
+  const int nn = min(NTB, P.NTtot - nt0);
+  const int32_t* tp = a.taps;
+  const uint4* wf = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)nt0 * 64 + lane;
+  uint4 aq[SPT][NTB];
+  float sc[SPT][8], sh[SPT][8];
+#pragma unroll
+  for (int s = 0; s < SPT; ++s) {
+#pragma unroll
+    for (int n = 0; n < NTB; ++n) aq[s][n] = wf[((size_t)s * P.NTtot + (n < nn ? n : nn - 1)) * 64];
+    const int oct = s * 4 + g;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = a.in_scale && oct < P.octs;
+      sc[s][j] = ok ? a.in_scale[oct * 8 + j] : 1.f;
+      sh[s][j] = ok ? a.in_shift[oct * 8 + j] : 0.f;
+    }
+  }
+  float bj[NTB][4], s1[NTB][4], s2[NTB][4];
+#pragma unroll
+  for (int n = 0; n < NTB; ++n)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = (nt0 + n) * 16 + g * 4 + j;
+      bj[n][j] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
+      s1[n][j] = s2[n][j] = 0.f;
+    }
+  const int ntile = (P.M + 15) / 16;
+  constexpr int TPW = 4;             // tiles in flight per wave: the loads of four tiles are issued before the first is used (eight: no change)
+  for (int base = (blockIdx.x * 4 + wave) * TPW; base < ntile; base += gridDim.x * 4 * TPW) {
+    uint4 raw[TPW][SPT];
+    int mm[TPW];
+    bool ins[TPW];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int m = (base + u) * 16 + vl;
+      mm[u] = m;
+      uint32_t t = (uint32_t)(m < P.M ? m : P.M - 1);
+      uint32_t q = fdiv(t, P.d_w); const int ox = t - q * a.Wo; t = q;
+      q = fdiv(t, P.d_h); const int oy = t - q * a.Ho; t = q;
+      q = fdiv(t, P.d_d); const int oz = t - q * a.Do; const int b = q;
+      const int iz = oz * a.sD + a.o0D + tp[0], iy = oy * a.sH + a.o0H + tp[1], ix = ox * a.sW + a.o0W + tp[2];
+      ins[u] = m < P.M && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+      const int64_t vox = (((int64_t)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix;
+      const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.x) + vox * (a.x_plane ? 16 : a.CPi);
+#pragma unroll
+      for (int s = 0; s < SPT; ++s) {
+        const int oct = s * 4 + g;
+        raw[u][s] = make_uint4(0, 0, 0, 0);
+        if (ins[u] && oct < P.octs)
+          raw[u][s] = *reinterpret_cast<const uint4*>(a.x_plane ? xp + (int64_t)(oct >> 1) * a.x_plane + (oct & 1) * 8 : xp + oct * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int m = mm[u];
+      f32x4 acc[NTB];
+#pragma unroll
+      for (int n = 0; n < NTB; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < SPT; ++s) {
+        const int oct = s * 4 + g;
+        uint4 r4 = raw[u][s];
+        if (a.in_scale && ins[u] && oct < P.octs) {
+          const uint32_t w[4] = {r4.x, r4.y, r4.z, r4.w};
+          uint32_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+            o[j] = sp_pack_bf16x2(fmaf(lo, sc[s][2 * j], sh[s][2 * j]), fmaf(hi, sc[s][2 * j + 1], sh[s][2 * j + 1]));
+          }
+          r4 = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        const bf16x8 bfr = __builtin_bit_cast(bf16x8, r4);
+#pragma unroll
+        for (int n = 0; n < NTB; ++n)
+          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[s][n]), bfr, acc[n], 0, 0, 0);
+      }
+      // D[cout = 4 g + j][voxel = vl]
+      if (m < P.M) {
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) {
+          if (n < nn) {
+            const int c0 = (nt0 + n) * 16 + g * 4;
+            float v[4], x4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              v[j] = (c0 + j < a.Cout) ? act_fwd(a.act, a.act_param, acc[n][j] + bj[n][j]) : 0.f;
+              if (sizeof(TOUT) == 2) v[j] = bf2f(f2bf(v[j]));        // statistics of what is stored, like the tiled kernels
+            }
+            if (c0 < a.CPo) {
+              if (a.stats) {
+                if (a.stats_mode == 1) Store<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(a.aux) + (size_t)m * a.CPo + c0, x4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] += a.stats_mode == 1 ? v[j] * x4[j] : v[j] * v[j]; }
+              }
+              Store<TOUT>::st4(reinterpret_cast<TOUT*>(a.y) + (size_t)m * a.CPo + c0, v);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {
+    for (int i = threadIdx.x; i < NTB * 32; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NTB; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1 = row16_sum(s1[n][j]), x2 = row16_sum(s2[n][j]);
+        if (vl == 0 && n < nn) { atomicAdd(&red[(n * 16 + g * 4 + j) * 2], x1); atomicAdd(&red[(n * 16 + g * 4 + j) * 2 + 1], x2); }
+      }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nn * 32; i += 256) {
+      const int c = nt0 * 16 + (i >> 1);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+    }
+  }
+}
+
 extern "C" int sp_conv_fc_workspace(int32_t B, int32_t Do, int32_t Ho, int32_t Wo, int32_t Cout, int32_t ntap, int64_t* floats) {
   SP_CHECK_ARG(floats && B >= 1 && Do >= 1 && Ho >= 1 && Wo >= 1 && Cout >= 1 && ntap >= 1, "sp_conv_fc_workspace: bad arguments");
   *floats = (int64_t)ntap * B * Do * Ho * Wo * ((Cout + 15) / 16 * 16);
@@ -181,7 +313,8 @@ extern "C" int sp_conv_fc_workspace(int32_t B, int32_t Do, int32_t Ho, int32_t W
 }
 
 extern "C" int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream) {
-  SP_CHECK_ARG(a && a->x && a->y && a->wfrag && a->partial && a->taps, "sp_conv_fc: null pointer");
+  SP_CHECK_ARG(a && a->x && a->y && a->wfrag && a->taps, "sp_conv_fc: null pointer");
+  SP_CHECK_ARG(a->partial || (a->ntap == 1 && a->CPi <= PW_SPT * 32), "sp_conv_fc: a partial buffer, or one tap and <= 64 input channels (pointwise mode)");
   SP_CHECK_ARG(a->x_plane == 0 || a->CPi % 16 == 0, "sp_conv_fc: plane-major input needs whole 16-channel planes");
   SP_CHECK_ARG(a->CPi % 8 == 0 && a->CPo % 8 == 0 && a->CPo <= 2048 && a->Cout <= a->CPo && a->Cout >= 1, "sp_conv_fc: channel pitches");
   SP_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "sp_conv_fc: scale and shift come together");
@@ -190,11 +323,32 @@ extern "C" int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv_fc: stats_nrep must be a power of two");
   SP_CHECK_ARG(!a->stats || a->stats_mode == 0 || (a->stats_mode == 1 && a->aux && a->dtype_out == SP_BF16), "sp_conv_fc: statistics mode");
   const int64_t M = (int64_t)a->B * a->Do * a->Ho * a->Wo;
-  SP_CHECK_ARG(M >= 1 && M < (1ll << 24), "sp_conv_fc: output volume (this kernel is for small ones)");
+  SP_CHECK_ARG(M >= 1 && M < (a->partial ? (1ll << 24) : (1ll << 31) - 16), "sp_conv_fc: output volume");
   ConvFcDev P;
   P.a = *a;
   P.M = (int32_t)M;
   P.octs = a->CPi / 8;
+  if (!a->partial) {      // pointwise mode: one tap, K steps not padded (plan.py:fc_plan), everything in one kernel
+    P.spt = (P.octs + 3) / 4;
+    P.NTtot = (a->Cout + 15) / 16;
+    P.d_w = make_fastdiv(a->Wo); P.d_h = make_fastdiv(a->Ho); P.d_d = make_fastdiv(a->Do);
+    const int64_t tiles = (M + 15) / 16;
+    unsigned gx = (unsigned)((tiles + 15) / 16 < 2048 ? (tiles + 15) / 16 : 2048);
+    const int ntb = P.NTtot >= 4 ? 4 : (P.NTtot >= 2 ? 2 : 1);
+    dim3 grid(gx, (unsigned)((P.NTtot + ntb - 1) / ntb));
+    hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
+#define PW_CASE(S_, N_)                                                                                              \
+  if (P.spt == S_ && ntb == N_) {                                                                                    \
+    if (a->dtype_out == SP_BF16) hipLaunchKernelGGL((conv_pw_kernel<S_, N_, bf16_t>), grid, dim3(256), 0, st0, P);   \
+    else hipLaunchKernelGGL((conv_pw_kernel<S_, N_, float>), grid, dim3(256), 0, st0, P);                            \
+    SP_CHECK_LAUNCH("sp_conv_fc(pointwise)");                                                                        \
+    return SP_OK;                                                                                                    \
+  }
+    PW_CASE(1, 1) PW_CASE(1, 2) PW_CASE(1, 4) PW_CASE(2, 1) PW_CASE(2, 2) PW_CASE(2, 4)
+#undef PW_CASE
+    sp_set_error("sp_conv_fc(pointwise): no kernel for %d K steps", P.spt);
+    return SP_EINVAL;
+  }
   P.spt = ((P.octs + 3) / 4 + FC_PD - 1) / FC_PD * FC_PD;          // runtime/plan.py:fc_plan pads the same way
   P.NTtot = (a->Cout + 15) / 16;
   P.d_w = make_fastdiv(a->Wo); P.d_h = make_fastdiv(a->Ho); P.d_d = make_fastdiv(a->Do);

@@ -415,14 +415,14 @@ def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtyp
     op, f = runner.op, runner.fc
     sub = op.subs[0]
     M = batch * int(np.prod(sub.out_dims))
-    need = f["ntap"] * M * f["NT"] * 16
-    if f["partial"] is None or f["partial"].numel() < need:
+    need = 0 if f["pointwise"] else f["ntap"] * M * f["NT"] * 16
+    if need and (f["partial"] is None or f["partial"].numel() < need):
         f["partial"] = torch.empty(need, dtype=torch.float32, device=runner.device)
     a = L.ConvFcArgs()
     a.x, a.y, a.wfrag = ptr(x), ptr(y), ptr(f["hi"])
     a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
     a.bias = ptr(runner.bias) if (runner.has_bias and use_bias) else None
-    a.stats, a.aux, a.partial, a.taps = ptr(stats), ptr(aux), ptr(f["partial"]), ptr(f["taps_d"])
+    a.stats, a.aux, a.partial, a.taps = ptr(stats), ptr(aux), (ptr(f["partial"]) if need else None), ptr(f["taps_d"])
     a.B = batch
     a.Di, a.Hi, a.Wi = op.in_dims
     a.CPi = op.cpi
@@ -435,7 +435,7 @@ def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtyp
     a.stats_mode, a.stats_nrep = stats_mode, stats_nrep
     a.dtype_out = op.dtype if dtype_out is None else dtype_out
     a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
-    with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s fc%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)),
+    with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s %s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), "pw" if f["pointwise"] else "fc",
                                                                     " +stats" if stats is not None else "")):
         L.call("sp_conv_fc", C.byref(a), st)
 

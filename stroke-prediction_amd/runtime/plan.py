@@ -424,9 +424,18 @@ def fc_plan(op: ConvOp):
     sub = op.subs[0]
     if tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0) or tuple(sub.out_dims) != tuple(op.y_dims):
         return None
+    octs = op.cpi // 8
+    if len(sub.taps) == 1 and op.cpi <= 64:
+        # pointwise mode of the same kernel file (conv_pw_kernel): one tap, one or two K steps, no K split, any volume --
+        # the 1x1x1 layers at the CAE's tail (Cae3D.py:214-218) and generic classify heads
+        spt = -(-octs // 4)
+        kmap = np.full(spt * 4, -1, dtype=np.int32)
+        t = sub.taps[0]
+        kmap[:octs] = (t[3] << 16) | np.arange(octs)
+        return dict(ntap=1, spt=spt, nsteps=spt, NT=-(-op.cout // 16), kmap=kmap, taps=np.array([[t[0], t[1], t[2]]], dtype=np.int32),
+                    pointwise=True)
     if op.cpi < FC_MIN_CPI or int(np.prod(sub.out_dims)) > FC_MAX_VOX:
         return None
-    octs = op.cpi // 8
     spt = -(-(-(-octs // 4)) // 4) * 4       # K steps per tap, padded to the kernel's prefetch depth (zero-weight octets)
     ntap = len(sub.taps)
     kmap = np.full(ntap * spt * 4, -1, dtype=np.int32)
@@ -434,7 +443,7 @@ def fc_plan(op: ConvOp):
         for o in range(octs):
             kmap[ti * spt * 4 + o] = (t[3] << 16) | o
     taps = np.array([[t[0], t[1], t[2]] for t in sub.taps], dtype=np.int32)
-    return dict(ntap=ntap, spt=spt, nsteps=ntap * spt, NT=-(-op.cout // 16), kmap=kmap, taps=taps)
+    return dict(ntap=ntap, spt=spt, nsteps=ntap * spt, NT=-(-op.cout // 16), kmap=kmap, taps=taps, pointwise=False)
 
 
 def zm_slices(op: ConvOp):
