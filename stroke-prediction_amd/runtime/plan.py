@@ -215,10 +215,12 @@ def _plan_sub(op: ConvOp, sub: SubConv, force_rows=None):
     # 4x8x16.  The staged halo tile shrinks from 70 KB to ~41 KB for two planes, three or four workgroups fit a CU, and
     # their stage / MFMA / store phases overlap (tools/stamp_conv.py: each phase leaves the matrix pipe idle for its own
     # workgroup): 32->32 @58^3 85 -> 79 us, 32->96 @48^3 158 -> 138 us, 64->64 @25^3 56 -> 41 us; with six input planes
-    # (96->32) the larger halo re-read costs more than the overlap gains (100 -> 114 us).  SP_PLAN_ROWS_WIDE=MT,TD,TH
+    # (96->32) the larger halo re-read costs more than the overlap gains (100 -> 114 us; 1848 -> 2312 us at 168^3), while from
+    # eight planes on the input is staged in several channel groups anyway and the small tile wins again (4-scale net:
+    # 192->64 @88^3 1167 -> 932 us, 384->128 @48^3 739 -> 557 us, 128->128 @59^3 552 -> 417 us).  SP_PLAN_ROWS_WIDE=MT,TD,TH
     # overrides, SP_PLAN_ROWS_WIDE=0 restores the large tile.
     _force = os.environ.get("SP_PLAN_ROWS_WIDE", "4,4,4")
-    if force_rows is None and _force not in ("", "0") and -(-op.cout // 16) >= 2 and op.dtype == 0 and op.cpi <= 64 and s == (1, 1, 1):
+    if force_rows is None and _force not in ("", "0") and -(-op.cout // 16) >= 2 and op.dtype == 0 and (op.cpi <= 64 or op.cpi >= 128) and s == (1, 1, 1):
         c = tuple(int(v) for v in _force.split(","))
         if fits(c, "hard") and sub.out_dims[0] >= c[1] and sub.out_dims[1] >= c[2]:
             mt, td, th = c
