@@ -227,6 +227,7 @@ static int wgrad_dispatch(const WgradDev& P, int COB, int CIB, dim3 grid, int ld
 }
 
 int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream);   // sp_wgrad_dma.hip
+int sp_wgrad_pw_try(const sp_wgrad_args* a, hipStream_t st);            // sp_wgrad_pw.hip
 
 extern "C" int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->dz && a->dw_acc && a->taps, "sp_conv3d_wgrad: null pointer");
@@ -234,6 +235,10 @@ extern "C" int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->ntap >= 1 && a->ntap <= 4 * WG_TAPS_PER_WAVE, "sp_conv3d_wgrad: ntap=%d out of range", a->ntap);
   SP_CHECK_ARG(a->CoT * 16 >= a->CPo && a->CiT * 16 >= a->CPi, "sp_conv3d_wgrad: tile counts too small");
   SP_CHECK_ARG(a->nblocks >= 1, "sp_conv3d_wgrad: nblocks");
+  {     // pointwise layers with per-workgroup partial blocks: the streaming kernel of sp_wgrad_pw.hip
+    const int rc = sp_wgrad_pw_try(a, reinterpret_cast<hipStream_t>(stream));
+    if (rc <= 0) return rc;
+  }
   if (a->dma) return sp_conv3d_wgrad_dma(a, stream);
   WgradDev P;
   P.a = *a;

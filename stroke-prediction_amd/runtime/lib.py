@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1

@@ -30,6 +30,7 @@ WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient part
 USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
 USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with too many output tiles for one z-marching launch: a launch per 32-channel slice
 ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "8000"))  # ... when the volume is large enough (measured: 32->96 @48^3 gains nothing, @166^3 40 %)
+USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
 USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
 USE_FC = bool(int(os.environ.get("SP_CONV_FC", "1")))      # split-K kernel for FC-like layers (deep K, tiny output volume)
@@ -471,6 +472,9 @@ class WgradRunner:
         self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and max(p) <= 2
                         and tuple(in_dims) == tuple(d + 2 - 2 * q for d, q in zip(out_dims, p)) and cpi % 16 == 0 and cpo % 16 == 0
                         and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "64")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))   # (limits are knobs: the row-sliding kernel takes any tile counts -- 192->64 @88^3 2155 -> 706 us against the register-staged kernel)
+        # pointwise layers (1x1x1, stride 1): streaming kernel of csrc/sp_wgrad_pw.hip, BatchNorm folded into the finish as well
+        self.pw = bool(USE_PW_WGRAD and WGRAD_PARTS and dtype == L.SP_BF16 and k == (1, 1, 1) and s == (1, 1, 1) and max(p) == 0
+                       and cpi % 16 == 0 and cpo % 16 == 0 and tuple(in_dims) == tuple(out_dims))
         a.dma = int(self.dma)
         if self.dma:
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", "512"))
@@ -483,7 +487,7 @@ class WgradRunner:
 
     def folds(self, in_scale):
         """BatchNorm folded into the finish step (raw x in the kernel): exact only without padding"""
-        return bool(self.dma and in_scale is not None and self.unpadded)
+        return bool((self.dma or self.pw) and in_scale is not None and self.unpadded)
 
     def _alloc_acc(self, batch):
         """Accumulator block(s).  WGRAD_PARTS: one block per persistent workgroup, written with plain stores and summed
@@ -534,7 +538,7 @@ class WgradRunner:
             assert a.dma and a.cib == 1, "plane-major input: DMA weight-gradient kernel, one plane per workgroup"
             a.x_plane = batch * a.Di * a.Hi * a.Wi * 16
         with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout,
-                    "%d->%d @%dx%dx%d %s" % (self.cin, self.cout, a.Di, a.Hi, a.Wi, "dma" if a.dma else "reg")):
+                    "%d->%d @%dx%dx%d %s" % (self.cin, self.cout, a.Di, a.Hi, a.Wi, "dma" if a.dma else ("pw" if (self.pw and not a.in_scale) else "reg"))):
             L.call("sp_conv3d_wgrad", C.byref(a), stream())
         finish = lambda: self._finish(fold, dw, in_scale, in_shift, dbias_sums, dbias_grad, nbias, bn_w, bn_sums, bn_nrep)
         if defer_finish:

@@ -812,3 +812,37 @@ def test_z_marching_output_slices(kind, cin, cout, dims, B, monkeypatch):
             torch.testing.assert_close(got, F.conv_transpose3d(dz, bf(w)), rtol=3e-2, atol=3e-2)
         outs[sliced] = got
     torch.testing.assert_close(outs[True], outs[False], rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("cin,cout,dims,B,fold", [(16, 16, (5, 21, 33), 2, True), (16, 1, (7, 18, 20), 2, True), (32, 32, (6, 11, 19), 1, False),
+                                                  (32, 2, (4, 9, 35), 3, True), (48, 16, (3, 10, 11), 2, False)])
+def test_pointwise_weight_gradient(cin, cout, dims, B, fold, monkeypatch):
+    """csrc/sp_wgrad_pw.hip (1x1x1 convolutions: the CAE's tail, generic classify heads) against autograd, with the BatchNorm
+    in front of the layer folded into the finish step, and against the generic kernel it replaces"""
+    g = torch.Generator().manual_seed(cin * 13 + cout)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    x = bf(torch.randn(B, cin, *dims, generator=g))
+    dz = bf(torch.randn(B, cout, *dims, generator=g))
+    scale, shift = torch.rand(cpi, generator=g) + 0.5, torch.randn(cpi, generator=g) * 0.1
+    xn = x * scale[:cin].view(1, -1, 1, 1, 1) + shift[:cin].view(1, -1, 1, 1, 1) if fold else x
+    wr = torch.zeros(cout, cin, 1, 1, 1, requires_grad=True)
+    F.conv3d(xn, wr).backward(dz)
+    xs, dzs = _to_cl(x, cpi), _to_cl(dz, cpo)
+    dbs = torch.zeros(cpo, dtype=torch.float64, device=DEV)
+    dbs[:cout] = dz.double().sum((0, 2, 3, 4)).to(DEV)
+    got = {}
+    for pw in (True, False):
+        monkeypatch.setattr(O, "USE_PW_WGRAD", pw)
+        wg = O.WgradRunner(cin, cout, 1, 1, 0, dims, dims, cpi, cpo, cin, 1, L.SP_BF16, DEV)
+        assert wg.pw == pw
+        dw = torch.zeros(cout, cin, 1, 1, 1, device=DEV)
+        db = torch.zeros(cout, device=DEV)
+        if fold:
+            wg.run(xs, dzs, B, dw, scale.to(DEV), shift.to(DEV), dbias_sums=dbs, dbias_grad=db, nbias=cout)
+        else:
+            wg.run(xs, dzs, B, dw, dbias_sums=dbs, dbias_grad=db, nbias=cout)
+        got[pw] = dw.cpu()
+        torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    sc = float(wr.grad.abs().max())
+    torch.testing.assert_close(got[True], wr.grad, rtol=2e-3, atol=4e-3 * sc)
+    torch.testing.assert_close(got[True], got[False], rtol=5e-3, atol=6e-3 * sc)
