@@ -53,12 +53,12 @@ __global__ __launch_bounds__(256) void wgrad_pw_kernel(const WgradPwDev P) {
     unsigned char* dst = mybuf + buf * (NPL * 1024);
 #pragma unroll
     for (int c = 0; c < COT; ++c) {
-      const bool okc = ok && co_t0 + c < a.CoT;
+      const bool okc = ok && (co_t0 + c) * 16 + dh * 8 < a.CPo;       // (a pitch of 8: the upper half of the tile reads zeros)
       sp_dma16_nc(okc ? dg + (v * a.CPo + (co_t0 + c) * 16 + dh * 8) * 2 : zeros, dst + c * 1024);
     }
 #pragma unroll
     for (int i = 0; i < CIT; ++i) {
-      const bool oki = ok && ci_t0 + i < a.CiT;
+      const bool oki = ok && (ci_t0 + i) * 16 + dh * 8 < a.CPi;
       sp_dma16_nc(oki ? xg + (v * a.CPi + (ci_t0 + i) * 16 + dh * 8) * 2 : zeros, dst + (COT + i) * 1024);
     }
   };
@@ -115,7 +115,7 @@ int sp_wgrad_pw_try(const sp_wgrad_args* a, hipStream_t st) {
   if ((knob && atoi(knob) == 0) || !a->parts || a->dtype != SP_BF16 || a->in_scale || a->dz_scale) return 1;
   if (a->ntap != 1 || a->kD != 1 || a->kH != 1 || a->kW != 1 || a->sD != 1 || a->sH != 1 || a->sW != 1) return 1;
   if (a->o0D || a->o0H || a->o0W || a->Di != a->Do || a->Hi != a->Ho || a->Wi != a->Wo || a->x_plane) return 1;
-  if (a->CPi % 16 || a->CPo % 16 || a->CPi != a->CiT * 16 || a->CPo != a->CoT * 16) return 1;
+  if (a->CPi % 8 || a->CPo % 8 || a->CiT != (a->CPi + 15) / 16 || a->CoT != (a->CPo + 15) / 16) return 1;
   WgradPwDev P;
   P.a = *a;
   P.M = (int64_t)a->B * a->Do * a->Ho * a->Wo;

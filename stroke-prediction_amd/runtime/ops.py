@@ -474,7 +474,7 @@ class WgradRunner:
                         and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "64")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))   # (limits are knobs: the row-sliding kernel takes any tile counts -- 192->64 @88^3 2155 -> 706 us against the register-staged kernel)
         # pointwise layers (1x1x1, stride 1): streaming kernel of csrc/sp_wgrad_pw.hip, BatchNorm folded into the finish as well
         self.pw = bool(USE_PW_WGRAD and WGRAD_PARTS and dtype == L.SP_BF16 and k == (1, 1, 1) and s == (1, 1, 1) and max(p) == 0
-                       and cpi % 16 == 0 and cpo % 16 == 0 and tuple(in_dims) == tuple(out_dims))
+                       and cpi % 8 == 0 and cpo % 8 == 0 and tuple(in_dims) == tuple(out_dims))
         a.dma = int(self.dma)
         if self.dma:
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", "512"))
