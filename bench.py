@@ -33,7 +33,8 @@ CHANNELS = [2, 16, 32, 64, 32, 16, 32, 2]
 CHANNELS4 = [2, 32, 64, 128, 256, 128, 64, 32, 32, 2]       # configs[4] with ch_bC = 32
 CAE_CHANNELS = [1, 16, 24, 32, 100, 800, 1]
 # dense MFMA peaks (MI355X_MICROARCH.md): bf16 2.5 PFLOP/s; f32 mode = 3 bf16 MFMAs per product; fp8 (MX-scaled) 5 PFLOP/s
-PEAK_TFLOPS = {"bf16": 2500.0, "f32": 2500.0 / 3.0, "fp8": 5000.0}
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 2500.0 / 3.0, "fp8": 5000.0}
+DTYPES = ["bf16", "f32"]      # precision modes the models accept (f16 / fp8 are appended below when the library has them)
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_SAMPLE_128 = 345.7                        # SURVEY.md 8d (fwd + dgrad + wgrad)
 CAE_TRAIN_GFLOP_PER_SAMPLE = {28: 305.5, 124: 1431.0}     # SURVEY.md 8d (3 enc + 4 dec passes)
@@ -454,14 +455,14 @@ def bench_unet(args, world, rank, dev, four_scale=False):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # bounded CPU sample (about 10-30 s): the headline size for the 3-scale net; for the 4-scale net one 2x128^3 volume
         # (a 256^3 oracle step is minutes) -- same network, same per-voxel work up to the valid-convolution border share
-        res["cpu_baseline"] = cpu_baseline_unet(size, channels=channels) if not four_scale else \
+        res["cpu_baseline"] = cpu_baseline_unet(size, channels=channels, steps=getattr(args, "cpu_steps", 3)) if not four_scale else \
             cpu_baseline_unet((128, 128, 128), steps=1, batch=1, channels=channels)
     if rank == 0 and world == 1 and args.torch_gpu_baseline and not four_scale:
         try:
             res["torch_gpu_baseline"] = torch_gpu_baseline(size, args.batch, bf16=(args.dtype == "bf16"))
         except Exception as e:
             res["torch_gpu_baseline"] = {"error": str(e).splitlines()[0][:200]}
-    return finish(res, rank)
+    return res
 
 
 def parity_vs_f32(model, images):
@@ -530,7 +531,7 @@ def bench_unet_infer(args, world, rank, dev):
            "config": {"workload": "3D U-Net --channels 2 16 32 64 32 16 32 2, batch %d/GPU, 2x%d^3 -> 2x%d^3, eval forward "
                                   "(SURVEY 8 row N1)" % (args.batch, args.size, out[0]),
                       "launch": "hipGraph" if graph is not None else "eager"}}
-    return finish(res, rank)
+    return res
 
 
 def bench_cae(args, world, rank, dev):
@@ -584,8 +585,8 @@ def bench_cae(args, world, rank, dev):
         if d in CAE_TRAIN_GFLOP_PER_SAMPLE:
             res["train_step_tflops"] = CAE_TRAIN_GFLOP_PER_SAMPLE[d] * 1e9 * world * args.batch * args.steps / dt / 1e12
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_cae(d, hw, steps=3 if d <= 28 else 1)
-    return finish(res, rank)
+        res["cpu_baseline"] = cpu_baseline_cae(d, hw, steps=min(getattr(args, "cpu_steps", 3), 3 if d <= 28 else 1))
+    return res
 
 
 def main():
@@ -595,7 +596,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 4; unet4: 2 -- BatchNorm training needs more than one sample, as Learner asserts)")
     ap.add_argument("--size", type=int, default=None, help="cubic input size (default 128; unet4: 256)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"])
+    ap.add_argument("--dtype", default="bf16", choices=DTYPES)
+    ap.add_argument("--no-secondary", action="store_true", help="default run only: skip the compact results of the other workloads")
     ap.add_argument("--workload", default="unet", choices=["unet", "cae", "unet-infer", "unet4"],
                     help="unet = BASELINE configs[1] (headline); cae = configs[2]: CAE 1 16 24 32 100 800 1, 3 enc + 4 dec passes; "
                          "unet4 = configs[4] topology (4-scale U-Net 2 32 64 128 256 128 64 32 [32] 2, default 256^3); "
@@ -644,11 +646,66 @@ def main():
     dev = torch.device("cuda", local_rank)
     init_dist(world, dev)
     import stroke_prediction_amd  # noqa: F401  (puts the drop-in packages on sys.path)
+    res = run_workload(args, world, rank, dev)
+    if args.workload == "unet" and world == 1 and rank == 0 and not args.no_secondary and args.dtype == "bf16" and args.size == 128:
+        res["secondary"] = secondary_workloads(args, dev)
+    return finish(res, rank)
+
+
+def run_workload(args, world, rank, dev):
     if args.workload == "cae":
         return bench_cae(args, world, rank, dev)
     if args.workload == "unet-infer":
         return bench_unet_infer(args, world, rank, dev)
     return bench_unet(args, world, rank, dev, four_scale=(args.workload == "unet4"))
+
+
+def secondary_workloads(args, dev):
+    """The other workloads of BASELINE.json / SURVEY 8 under the same clock as the headline line (the driver runs only the
+    default command): each with its own model, warm-up and timed region, AFTER the headline's timed region has closed;
+    compact results (the full line of each is what `bench.py --workload ... ` prints).  Bounded: 10 timed steps each, one
+    timed CPU-oracle step where a CPU leg is given."""
+    import copy
+    import gc
+    out = {}
+    t_all = time.perf_counter()
+    plan = [("cae_d28", dict(workload="cae", cae_depth=28, dtype="bf16"), True),
+            ("cae_d124", dict(workload="cae", cae_depth=124, dtype="bf16"), False),
+            ("unet4_bf16", dict(workload="unet4", dtype="bf16", batch=2, size=256), True),
+            ("unet4_fp8", dict(workload="unet4", dtype="fp8", batch=2, size=256), False),
+            ("unet_f16", dict(workload="unet", dtype="f16"), False),
+            ("unet_f32", dict(workload="unet", dtype="f32"), False),
+            ("unet_infer", dict(workload="unet-infer", dtype="bf16"), False)]
+    for name, over, cpu in plan:
+        if over["dtype"] not in DTYPES:
+            continue
+        a = copy.copy(args)
+        a.steps, a.warmup, a.layers, a.no_parity, a.torch_gpu_baseline = 10, 3, False, True, False
+        a.no_cpu_baseline = not cpu or args.no_cpu_baseline
+        a.cpu_steps = 1
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = run_workload(a, 1, 0, dev)
+            c = {"metric": r["metric"], "workload": r["config"]["workload"], "dtype": r["dtype"], "ms_per_step": r["ms_per_step"],
+                 "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"]}
+            if r.get("roofline"):
+                c["roofline"] = {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}
+            if r.get("train_step_tflops") is not None:
+                c["train_step_tflops"] = r["train_step_tflops"]
+            if r.get("parity"):
+                c["parity"] = r["parity"]
+            if r.get("cpu_baseline"):
+                c["cpu_baseline"] = {k: r["cpu_baseline"][k] for k in ("value", "unit", "cores", "kind", "s_per_step", "sample")}
+            out[name] = c
+        except Exception as e:      # a secondary leg must never take the headline line down
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e).splitlines()[0][:300] if str(e) else "")}
+        out[name]["wall_s"] = time.perf_counter() - t0
+        gc.collect()
+        torch.cuda.empty_cache()
+    out["wall_s"] = time.perf_counter() - t_all
+    return out
 
 
 if __name__ == "__main__":

@@ -412,6 +412,8 @@ def set_np_seed(workerid):
 def _loader(dataset, items, batch_size, num_workers, pin_memory, seeded):
     from torch.utils.data import DataLoader
     from torch.utils.data.sampler import SubsetRandomSampler
+    if getattr(getattr(dataset, "transform", None), "device", None) is not None:
+        num_workers = 0      # the transform chain uploads and runs HIP kernels: a forked worker cannot re-initialise the GPU
     return DataLoader(dataset, batch_size=batch_size, sampler=SubsetRandomSampler(items), num_workers=num_workers,
                       pin_memory=pin_memory, worker_init_fn=set_np_seed if seeded else None)
 

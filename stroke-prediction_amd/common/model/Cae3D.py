@@ -35,17 +35,22 @@ class _Lease:
     """A StackContext on loan from the pool to one autograd node: returned by backward, or -- when the graph is dropped
     without a backward (a grad-enabled forward whose loss is never differentiated) -- when the node is collected."""
 
-    def __init__(self, pool, key, sc):
-        self.pool, self.key, self.sc = pool, key, sc
+    def __init__(self, pool, key, sc, module=None):
+        self.pool, self.key, self.sc, self.module = pool, key, sc, module
 
-    def release(self):
+    def release(self, dropped=False):
         if self.sc is not None:
             self.pool.release(self.key, self.sc)
             self.sc = None
+            if dropped and self.module is not None:
+                # the pass will never be differentiated: it no longer counts as "backward still to come", or the stack's
+                # gradients would never be declared final again (and the in-backward gradient exchange stay off)
+                self.module._n_out = max(0, getattr(self.module, "_n_out", 1) - 1)
+        self.module = None
 
     def __del__(self):
         try:
-            self.release()
+            self.release(dropped=True)
         except Exception:
             pass
 
@@ -58,7 +63,7 @@ class _StackFn(torch.autograd.Function):
         key, sc = module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device)
         out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training)
         ctx.module, ctx.sc = module, sc
-        ctx.lease = _Lease(module._pool(), key, sc)
+        ctx.lease = _Lease(module._pool(), key, sc, module)
         module._begin_step()
         module._n_out = getattr(module, "_n_out", 0) + 1       # passes of this stack whose backward is still to come
         ctx.training = module.training

@@ -52,6 +52,8 @@ def _decode_metrics(text):
             slot = len(seen)
             seen.append(None)
             vals = {k: dec(x) for k, x in v.items() if k not in ("py/object", "__dto__")}
+            if any(isinstance(x, dict) and "py/id" in x and seen[x["py/id"] - 1] is None for x in v.values()):
+                raise ValueError("metric history: back-reference to an object that is still being decoded")
             if kind == "BinaryMeasuresDto":
                 obj = BinaryMeasuresDto(*(vals.get(k) for k in ("dc", "hd", "assd", "precision", "sensitivity", "specificity")))
             elif kind == "MetricMeasuresDto":
@@ -61,9 +63,12 @@ def _decode_metrics(text):
             seen[slot] = obj
             return obj
         if isinstance(v, list):
-            return [dec(x) for x in v]
+            out = []
+            seen.append(out)            # jsonpickle 0.9.6 numbers lists too (its _mkref counts every container)
+            out.extend(dec(x) for x in v)
+            return out
         return float("inf") if v == "inf" else v
-    return {phase: [dec(m) for m in ms] for phase, ms in json.loads(text).items()}
+    return {phase: dec(ms) for phase, ms in json.loads(text).items()}
 
 
 class Learner(Inference):
@@ -175,14 +180,14 @@ class Learner(Inference):
             fp.write(_encode_metrics(self._metric_dtos))
 
     def save_model(self, suffix=''):
+        """Learner.py:112-114 writes ``model.cpu()`` and moves the model back.  Here the LIVE model is never moved: a CPU
+        copy is pickled.  Moving it would re-create the parameter storages, invalidate the captured step (hipGraph) on rank 0
+        only, and rank 0 would then re-warm with eager steps whose bucketed gradient exchange issues other collectives than
+        the graph replays of the other ranks (a hang in any multi-rank run_training, which saves after epoch 0)."""
         if not self._is_rank0():
             return
-        was_cuda = self.is_cuda
-        dev = next(self._model.parameters()).device
-        torch.save(self._model.cpu(), self.path('save', self.FNB_MODEL, suffix))
-        if was_cuda:
-            self._model.to(dev)
-        self._graphs.clear()                 # the parameters moved: captured steps point at the old storages
+        import copy
+        torch.save(copy.deepcopy(self._model).cpu(), self.path('save', self.FNB_MODEL, suffix))
 
     # ------------------------------------------------------------------ the hot three lines
     def _optimise(self, batch: dict, epoch):

@@ -15,6 +15,8 @@ SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1
+# precision modes of the models (``Unet3D(dtype=...)``, ``Enc3D(dtype=...)``) -> storage type of the engine's tensors
+DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32}
 SP_REDUCE_ROWS = 8    # replica rows of the accumulators the elementwise kernels reduce into (include/stroke_amd.h)
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 

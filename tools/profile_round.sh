@@ -5,19 +5,19 @@
 set -o pipefail
 TAG=${1:-r02}; WL=${2:-unet}
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_$TAG_$WL; mkdir -p $OUT
+OUT="gpurun_out/prof_${TAG}_${WL}"; mkdir -p "$OUT"
 db() { find $1 -name "*.db" | head -1; }
 csvf() { find $1 -name "*counter_collection.csv" | head -1; }
 if [ "$WL" = unet ]; then
-  rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --steps 10 --warmup 3 --no-parity --no-cpu-baseline > $OUT/g.log 2>&1 && \
+  rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_bench_kernel_stats.csv > gpurun_out/${TAG}_bench_kernel_stats.txt
-  SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/s -o s -- python bench.py --steps 10 --warmup 3 --no-parity --no-cpu-baseline > $OUT/s.log 2>&1 && \
+  SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/s -o s -- python bench.py --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary > $OUT/s.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/s) gpurun_out/${TAG}_bench_kernel_stats_serial.csv > gpurun_out/${TAG}_bench_kernel_stats_serial.txt
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-kernel-timing > $OUT/f.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-kernel-timing > $OUT/w.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/f.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/w.log 2>&1
   python tools/pmc_traffic.py $(csvf $OUT/f) $(csvf $OUT/w) $TAG > gpurun_out/${TAG}_pmc_traffic.txt
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $OUT/q1 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-kernel-timing > $OUT/q1.log 2>&1
-  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/q2 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-kernel-timing > $OUT/q2.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $OUT/q1 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q1.log 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/q2 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q2.log 2>&1
   python tools/pmc_sq.py $(csvf $OUT/q1) $(csvf $OUT/q2) > gpurun_out/${TAG}_mfma_busy.txt
 else
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload cae --steps 5 --warmup 2 --no-cpu-baseline > $OUT/g.log 2>&1 && \
@@ -26,5 +26,5 @@ else
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python bench.py --workload cae --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing > $OUT/w.log 2>&1
   python tools/pmc_traffic.py $(csvf $OUT/f) $(csvf $OUT/w) ${TAG}_cae cae_ "bench.py --workload cae --steps 1 --warmup 1 --no-graph, CAE B=4 1x28x128x128 bf16" > gpurun_out/${TAG}_cae_pmc_traffic.txt
 fi
-rm -rf $OUT
+rm -rf "$OUT"
 ls -la gpurun_out | grep ${TAG}_ | tail -12
