@@ -103,6 +103,13 @@ typedef struct sp_conv_args {
   int32_t ITH_zs;              /* persist == 3 only */
   int64_t x_plane;             /* dma kernel: != 0 -> x is plane-major [CPi/16][B][D][H][W][16] with this many elements per
                                   plane (concat buffers written by sp_upsample2_crop_cat_fwd); 0 -> channels-last */
+  /* ---- fp8 kernel (sp_conv3d_zm8) only; zero elsewhere */
+  void* y8;                    /* optional second output: e4m3 plane-major copy of y, [Cout/16][B][YD][YH][YW][16 bytes] */
+  int64_t y8_plane;            /* bytes per 16-channel plane of y8 (>= B*YD*YH*YW*16) */
+  const float* f8_wscale;      /* [NT*16] epilogue multiplier per output channel (sp_conv_prep_f8: 2^-k of the weight row,
+                                  times the reciprocal operand scale of a data gradient) */
+  float y8_scale;              /* y8 = e4m3(y8_scale * y) */
+  int32_t f8_bin;              /* B operand (x) format: 0 = e4m3 (forward), 1 = e5m2 (data gradient: x = quantised dz) */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -123,6 +130,29 @@ int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
 /* (input planes P = Cin/16, output tiles NT = Cout/16) -> rows per wave, ring slots and waves per workgroup of the kernel that
  * exists for the pair (a workgroup covers NW*MT x 16 output voxels per plane); returns SP_EINVAL when there is none */
 int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
+
+/* ------------------------------------------------------------------ fp8 (BASELINE.json configs[4]: "4-scale U-Net ... fp8 MFMA")
+ * The same z-marching operation on v_mfma_f32_16x16x128_f8f6f4 (csrc/sp_conv_zm8.hip): x is an fp8 PLANE-MAJOR tensor
+ * [CPi/16][B][Di][Hi][Wi][16 bytes] (x_plane = bytes per plane), e4m3 for a forward convolution, e5m2 (f8_bin = 1) for a data
+ * gradient; weights are e4m3 fragments from sp_conv_prep_f8 with one power-of-two scale per output channel, undone by the
+ * epilogue (f8_wscale); accumulation, bias, LeakyReLU and the BatchNorm statistics are fp32; y is bf16 channels-last as for
+ * sp_conv3d_zm, y8 (optional) its e4m3 plane-major copy for the next fp8 convolution.  ktab[(s*4+g)*2+h] = byte offset of
+ * chunk h of lane group g in K step s inside a ring slot (runtime/plan.py:zm8_plan).  Replaces nn.Conv3d(3, padding 0)
+ * (Unet3D.py:19,22 inside the 4-scale topology Unet3D.py:95-146) for 32 <= Cin <= 96. */
+int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
+int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
+/* fp32 weights -> e4m3 A fragments in the plan's K order.  kmap[(step*4+g)*2+h] = (src_tap << 16) | input 16-channel plane, or
+ * -1 (zero chunk); element (co, ci, tap) = w[co*sCo + ci*sCi + tap] * fold_scale[ci] (fold_scale may be NULL).  Per output
+ * channel: 2^k = largest power of two with |row| * 2^k <= 224; winv[co] = out_scale / 2^k; bias_out[co] (may be NULL) =
+ * bias[co] + sum_{ci,tap} w * fold_shift[ci] in fp32 (BatchNorm folded into an un-padded convolution, exact). */
+int sp_conv_prep_f8(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,
+                    int32_t nsteps, int32_t NT, void* wfrag, const float* fold_scale, const float* fold_shift,
+                    int32_t ntaps, const float* bias, float* bias_out, float* winv, float out_scale, sp_stream_t stream);
+/* dst = fp8(scale * src): src bf16 channels-last [nvox][CP] (src_plane = 0) or plane-major [CP/16][..][16] (src_plane =
+ * elements per plane); dst plane-major [CP/16][nvox][16 bytes] with dst_plane bytes per plane; fmt 0 = e4m3 (saturating at
+ * 448), 1 = e5m2 (57344).  The operand of sp_conv3d_zm8 where no producer wrote it (pooled / concatenated tensors, dz). */
+int sp_quantize_f8(const void* src, int32_t CP, int64_t src_plane, void* dst, int64_t dst_plane, int64_t nvox, int32_t fmt,
+                   float scale, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ self-sufficient entry points for the hot convolution
  * nn.Conv3d(Cin, Cout, 3, stride 1, padding 0) of Block3x3x3 (Unet3D.py:19,22) and its data gradient on the z-marching

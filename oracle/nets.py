@@ -37,6 +37,52 @@ def _ident(t):
     return t
 
 
+# ---- fp8 emulation of the "fp8" precision mode of the HIP path (stroke-prediction_amd/runtime/f8.py, csrc/sp_conv_zm8.hip):
+# the MFMA operands of the forward and data-gradient convolution are OCP e4m3 / e5m2, everything else as in the bf16 mode.
+def round_e4m3(t):
+    """round to nearest even, saturating at +-448 (what v_cvt_pk_fp8_f32 behind a clamp does)"""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(t.dtype)
+
+
+def round_e5m2(t):
+    return t.clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(t.dtype)
+
+
+def quant_weights_e4m3(wf):
+    """e4m3 weights with one power-of-two scale per output channel: 2^k = largest power of two with max|row| * 2^k <= 224
+    (sp_conv_prep_f8); returns the de-quantised weights"""
+    amax = wf.detach().abs().flatten(1).max(dim=1).values.clamp_min(1e-30)
+    sc = torch.exp2(torch.floor(torch.log2(224.0 / amax))).view(-1, 1, 1, 1, 1)
+    return round_e4m3(wf * sc) / sc
+
+
+class _F8Conv(torch.autograd.Function):
+    """y = conv(e4m3(x), e4m3(w)) + b;  dx = conv^T(e5m2(S dy) / S, e4m3(w));  dw from the un-quantised x and dy (the weight
+    gradient of the fp8 mode is computed from the bf16 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, wf, bf, grad_scale):
+        wq = quant_weights_e4m3(wf)
+        ctx.save_for_backward(x, wf)
+        ctx.S = grad_scale
+        return F.conv3d(round_e4m3(x), wq, bf)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wf = ctx.saved_tensors
+        gq = round_e5m2(g * ctx.S) / ctx.S
+        # the data gradient packs the weights with one scale per INPUT channel of the convolution (its output channels)
+        wq = quant_weights_e4m3(wf.transpose(0, 1).contiguous()).transpose(0, 1).contiguous()
+        gx = torch.nn.grad.conv3d_input(x.shape, wq, gq)
+        gw = torch.nn.grad.conv3d_weight(x, wq.shape, g)
+        return gx, gw, g.sum(dim=(0, 2, 3, 4)), None
+
+
+def f8_grad_scale(n_out_voxels):
+    """runtime/f8.py:grad_scale_for"""
+    return float(2.0 ** math.ceil(math.log2(64.0 * max(1, n_out_voxels))))
+
+
 def _bn(sd, prefix, x, training):
     """``nn.BatchNorm3d`` call sites; training mode normalises with biased batch
     variance and updates running stats with the unbiased one."""
@@ -54,7 +100,7 @@ def center_crop(t, like, dims=(2, 3, 4)):
     return t
 
 
-def _bn_folded_conv(sd, bn_p, cv_p, x, training, q):
+def _bn_folded_conv(sd, bn_p, cv_p, x, training, q, f8=None):
     """The HIP bf16 path folds the BatchNorm of an un-padded convolution into weights and bias
     (conv(s*x+t) = conv_{W*s}(x) + sum W*t) so the raw bf16 input can be staged by LDS-DMA: the weights are
     rounded AFTER the fold, the input is not re-rounded.  Same function as BN -> conv, emulated here so that the
@@ -73,19 +119,21 @@ def _bn_folded_conv(sd, bn_p, cv_p, x, training, q):
         mean, var = sd[bn_p + ".running_mean"], sd[bn_p + ".running_var"]
     scale = gamma / torch.sqrt(var + BN_EPS)
     shift = beta - mean * scale
-    wf = q(w * scale.view(1, -1, 1, 1, 1))
     bf = b + (w * shift.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
+    if f8 is not None and cv_p in f8["layers"]:
+        return _F8Conv.apply(x, w * scale.view(1, -1, 1, 1, 1), bf, f8["grad_scale"])
+    wf = q(w * scale.view(1, -1, 1, 1, 1))
     return F.conv3d(x, wf, bf)
 
 
-def unet_block(sd, p, x, training, q=_ident):
+def unet_block(sd, p, x, training, q=_ident, f8=None):
     """``Block3x3x3`` Unet3D.py:14-27: BN-conv(3,p0)-lrelu twice.
     ``q`` models the storage rounding of the HIP bf16 path (identity for the reference semantics):
     it is applied where that path rounds -- the normalised conv operand, the weights, the stored output."""
     for bn_i, cv_i in ((0, 1), (3, 4)):
         bn_p, cv_p = "%s.bn_conv_relu_2x.%d" % (p, bn_i), "%s.bn_conv_relu_2x.%d" % (p, cv_i)
         if q is not _ident:
-            x = _bn_folded_conv(sd, bn_p, cv_p, x, training, q)
+            x = _bn_folded_conv(sd, bn_p, cv_p, x, training, q, f8)
         else:
             x = F.conv3d(_bn(sd, bn_p, x, training), sd[cv_p + ".weight"], sd[cv_p + ".bias"])
         x = q(F.leaky_relu(x, LEAKY))
@@ -98,22 +146,23 @@ def upsample2(x, align_corners=False):
     return F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=align_corners)
 
 
-def unet_forward(sd, x, training=True, return_all=False, q=_ident):
+def unet_forward(sd, x, training=True, return_all=False, q=_ident, f8=None):
     """``Unet3D.forward`` Unet3D.py:56-79 (three scales) and ``LargeUnet3D.forward`` Unet3D.py:118-146 (four): the number
     of scales S follows from the block count of the state dict (2S - 1 blocks).  Returns sigmoid probs (B,2,...).
-    ``q=round_bf16`` emulates the bf16 storage points of the HIP fast path (see ``unet_block``)."""
+    ``q=round_bf16`` emulates the bf16 storage points of the HIP fast path (see ``unet_block``); ``f8=dict(layers={conv
+    prefixes}, grad_scale=S)`` additionally runs those convolutions with fp8 operands (``_F8Conv``; needs q=round_bf16)."""
     nblocks = len({k.split(".")[0] for k in sd if k.startswith("block")})
     S = (nblocks + 1) // 2
     outs = {}
     h = q(x)
     for i in range(1, S + 1):                              # down: block, pool (Unet3D.py:57-63 / :119-128)
-        outs[i] = unet_block(sd, "block%d" % i, h, training, q)
+        outs[i] = unet_block(sd, "block%d" % i, h, training, q, f8)
         if i < S:
             h = F.max_pool3d(outs[i], 2, 2)
     low = outs[S]
     for u in range(S + 1, 2 * S):                          # up: upsample, crop + cat, block (Unet3D.py:64-73 / :129-141)
         up = q(upsample2(low))
-        outs[u] = low = unet_block(sd, "block%d" % u, torch.cat((up, center_crop(outs[2 * S - u], up)), dim=1), training, q)
+        outs[u] = low = unet_block(sd, "block%d" % u, torch.cat((up, center_crop(outs[2 * S - u], up)), dim=1), training, q, f8)
     # (the HIP path fuses the classify head: weights enter as hi + lo bf16 pairs = fp32 accuracy; the hidden layer is
     # never stored but is rounded to bf16 as the operand of the second matrix product)
     h = q(F.leaky_relu(F.conv3d(low, sd["classify.0.weight"], sd["classify.0.bias"]), LEAKY))

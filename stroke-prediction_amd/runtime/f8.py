@@ -1,0 +1,142 @@
+"""fp8 (OCP e4m3 / e5m2) execution of the stride-1 3x3x3 convolutions: drivers of ``sp_conv3d_zm8`` / ``sp_conv_prep_f8`` /
+``sp_quantize_f8`` (csrc/sp_conv_zm8.hip; BASELINE.json configs[4]).
+
+Precision recipe (``Unet3D(dtype="fp8")``): the MFMA operands of the forward and the data-gradient convolution of every
+3x3x3 layer with 32..96 input channels are fp8 -- activations e4m3 (plane-major copies written by the producing
+convolution's epilogue, or by one quantisation pass for pooled / concatenated tensors), weights e4m3 with a power-of-two scale
+per output channel, output gradients e5m2 scaled by a power of two -- with fp32 accumulation; BatchNorm statistics, bias,
+activations, Dice and Adam stay fp32, the stored activations every other kernel reads stay bf16, and the weight gradients
+(a reduction over millions of voxels) are computed from the bf16 tensors.  The first layer (2 input channels), the
+classify head and the layers with more than 96 input channels run on the bf16 kernels.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import lib as L
+from . import ops as O
+from . import plan as P
+
+F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "1024"))     # (column, plane) pairs below which the march is all prologue
+E4M3, E5M2 = 0, 1
+
+
+def alloc_f8(batch, dims, cp, device):
+    """plane-major fp8 tensor [cp/16][B][D][H][W][16 bytes]"""
+    assert cp % 16 == 0
+    return torch.empty((cp // 16, batch) + tuple(dims) + (16,), dtype=torch.uint8, device=device)
+
+
+def quantize(src, dst, fmt=E4M3, scale=1.0, src_planar=False):
+    """dst (plane-major fp8, see alloc_f8) = fp8(scale * src); src bf16 channels-last (B, D, H, W, CP) or the same shape stored
+    plane-major (the concat buffers)."""
+    B, D, H, W, CP = src.shape
+    nvox = B * D * H * W
+    assert src.dtype == torch.bfloat16 and dst.dtype == torch.uint8 and tuple(dst.shape) == (CP // 16, B, D, H, W, 16), \
+        (tuple(src.shape), tuple(dst.shape))
+    with O._Timed("quantize_f8", 0.0, "%s %dx%dx%d x%d" % ("e5m2" if fmt else "e4m3", D, H, W, CP)):
+        L.call("sp_quantize_f8", O.ptr(src), CP, nvox * 16 if src_planar else 0, O.ptr(dst), nvox * 16, nvox, fmt, float(scale),
+               O.stream())
+
+
+class ConvRunnerF8:
+    """One stride-1 3x3x3 op (``plan.ConvOp``: a forward convolution or a data gradient) on the fp8 z-marching kernel, one
+    launch per slice of <= 32 output channels."""
+
+    @staticmethod
+    def applicable(op, batch):
+        sl = P.zm8_slices(op)
+        if sl is None or op.cin > op.cpi:
+            return False
+        z = P.zm8_plan(sl[0][2])
+        sub = op.subs[0]
+        cols = -(-sub.out_dims[1] // z["TH"]) * -(-sub.out_dims[2] // 16)
+        return batch * cols * sub.out_dims[0] >= F8_MIN_PLANES
+
+    def __init__(self, op, device, batch, bin_fmt=E4M3):
+        assert ConvRunnerF8.applicable(op, batch)
+        self.op, self.device, self.batch, self.bin = op, device, batch, bin_fmt
+        self.slices = []
+        for c0, cn, sub_op in P.zm8_slices(op):
+            z = P.zm8_plan(sub_op)
+            self.slices.append(dict(z, c0=c0, cn=cn, ktab_d=O._dev_i32(z["ktab"], device), kmap_d=O._dev_i32(z["kmap"], device),
+                                    wfrag=torch.empty(z["nsteps"] * z["NT"] * 2048, dtype=torch.uint8, device=device)))
+        cpad = -(-op.cout // 16) * 16
+        self.bias = torch.zeros(cpad, dtype=torch.float32, device=device)
+        self.winv = torch.ones(cpad, dtype=torch.float32, device=device)
+        self.has_bias = False
+        self._key = None
+
+    def prep(self, w, b=None, fold_scale=None, fold_shift=None, out_scale=1.0):
+        """e4m3 fragments of w (x fold_scale per input channel), folded bias, per-channel dequantisation multipliers
+        (x out_scale: the reciprocal of the scale the B operand was quantised with)."""
+        op = self.op
+        assert w.dtype == torch.float32 and w.is_contiguous()
+        if fold_scale is None:      # depends on the weights only: keyed like ConvRunner.prep
+            key = (w.data_ptr(), w._version, O.PARAM_EPOCH[0], float(out_scale))
+            if self._key == key:
+                return
+            self._key = key
+        else:
+            self._key = None
+        ntaps = w.numel() // (op.cin * op.cout)
+        want_bias = b is not None or fold_shift is not None
+        for s in self.slices:
+            c0 = s["c0"]
+            L.call("sp_conv_prep_f8", w.data_ptr() + 4 * c0 * op.w_sco, op.w_sco, op.w_sci, s["cn"], op.cin, O.ptr(s["kmap_d"]),
+                   s["nsteps"], s["NT"], O.ptr(s["wfrag"]), O.ptr(fold_scale), O.ptr(fold_shift), ntaps,
+                   None if b is None else b.data_ptr() + 4 * c0, (self.bias.data_ptr() + 4 * c0) if want_bias else None,
+                   self.winv.data_ptr() + 4 * c0, float(out_scale), O.stream())
+        self.has_bias = want_bias
+
+    def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
+        op, batch = self.op, self.batch
+        sub = op.subs[0]
+        assert x8.dtype == torch.uint8 and tuple(x8.shape) == (op.cpi // 16, batch) + tuple(op.in_dims) + (16,), \
+            (tuple(x8.shape), op.cpi, op.in_dims)
+        assert y.dtype == torch.bfloat16 and tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
+        if y8 is not None:
+            assert self.bin == E4M3 and y8.dtype == torch.uint8 and tuple(y8.shape) == (y.shape[4] // 16, batch) + tuple(op.y_dims) + (16,)
+        a = L.ConvArgs()
+        a.x = O.ptr(x8)
+        a.dtype_in, a.dtype_out = L.SP_BF16, L.SP_BF16
+        a.B = batch
+        a.Di, a.Hi, a.Wi = op.in_dims
+        a.CPi = op.cpi
+        a.x_plane = batch * int(np.prod(op.in_dims)) * 16
+        a.YD, a.YH, a.YW = op.y_dims
+        a.CPo = y.shape[4]
+        a.Do, a.Ho, a.Wo = sub.out_dims
+        a.osD = a.osH = a.osW = 1
+        a.sD = a.sH = a.sW = 1
+        a.o0D, a.o0H, a.o0W = sub.o0
+        a.act, a.act_param = act, act_param
+        a.stats_nrep = stats_nrep
+        a.f8_bin = self.bin
+        a.y8_scale = float(y8_scale)
+        plane8 = batch * int(np.prod(op.y_dims)) * 16
+        a.y8_plane = plane8
+        st = O.stream()
+        for s in self.slices:
+            c0 = s["c0"]
+            a.y = y.data_ptr() + 2 * c0
+            a.bias = (self.bias.data_ptr() + 4 * c0) if self.has_bias else None
+            a.f8_wscale = self.winv.data_ptr() + 4 * c0
+            a.stats = None if stats is None else stats.data_ptr() + 16 * c0
+            a.y8 = None if y8 is None else y8.data_ptr() + (c0 // 16) * plane8
+            a.wfrag_hi, a.ktab = O.ptr(s["wfrag"]), O.ptr(s["ktab_d"])
+            a.MT, a.NT, a.NTtot = s["MT"], s["NT"], s["NT"]
+            a.Cout = s["NT"] * 16
+            with O._Timed("conv_igemm", op.flops(batch) * s["cn"] / op.cout,
+                          "%d->%d @%s zm8 %s%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), "e5m2" if self.bin else "e4m3",
+                                                     " slices" if len(self.slices) > 1 else "", " +stats" if stats is not None else "")):
+                L.call("sp_conv3d_zm8", C.byref(a), O.ptr(O.zero_page(self.device)), st)
+
+
+def grad_scale_for(n_out_voxels):
+    """power of two the output gradients are multiplied with before they are rounded to e5m2: a mean-type loss over
+    n_out_voxels has per-voxel gradients ~ 1/n; 64 n puts them in the middle of e5m2's 30 binades."""
+    return float(2.0 ** math.ceil(math.log2(64.0 * max(1, n_out_voxels))))

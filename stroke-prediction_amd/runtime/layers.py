@@ -106,6 +106,30 @@ class ConvLayer:
         # backward side is created lazily (inference never pays for it)
         self._bwd_ready = False
         self.y = None
+        # fp8 execution (runtime/f8.py; enabled per layer by the engine in the "fp8" precision mode)
+        self.f8_fwd = self.f8_dgrad = None
+        self.f8_on = False
+        self.x8 = self.y8 = self.dz8 = None
+        self.want_y8 = False
+        self.f8_grad_scale = 1.0
+
+    def enable_f8(self, grad_scale):
+        """fp8 MFMA operands for this layer's forward and data-gradient convolution where the fp8 z-marching kernel has an
+        instance for its shape (folded BatchNorm, stride 1, 3x3x3, 32..96 input channels); returns whether the forward runs
+        in fp8.  The engine then provides ``self.x8`` (e4m3 plane-major copy of the input) before every forward."""
+        from . import f8 as F8
+        self.f8_on = True
+        self.f8_grad_scale = float(grad_scale)
+        if (self.fold and self.kind == "conv" and self.dtype == L.SP_BF16 and self.out_dtype == L.SP_BF16 and self.bank is None
+                and self.act in (L.ACT_NONE, L.ACT_LEAKY) and F8.ConvRunnerF8.applicable(self.fwd_op, self.batch)):
+            self.f8_fwd = F8.ConvRunnerF8(self.fwd_op, self.device, self.batch, F8.E4M3)
+        return self.f8_fwd is not None
+
+    def alloc_y8(self):
+        from . import f8 as F8
+        if self.y8 is None:
+            self.y8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, self.device)
+        return self.y8
 
     # ---------------------------------------------------------------- forward
     @property
@@ -144,7 +168,10 @@ class ConvLayer:
             self.fwd.run(self.xhat, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
                          stats_nrep=STATS_NREP)
             return y
-        if self.fold:
+        if self.f8_fwd is not None:       # fp8 operands: x8 = e4m3 copy of x (engine), BatchNorm folded into the e4m3 weights
+            self.f8_fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
+            self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=self.alloc_y8() if self.want_y8 else None)
+        elif self.fold:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
                          stats_nrep=STATS_NREP, x_planar=self.x_planar)
@@ -192,6 +219,11 @@ class ConvLayer:
             self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}),
                                       zm_batch=self.batch if (self.bn_from_wgrad and self.bank is None) else None)
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
+            if self.f8_on and self.bn_from_wgrad and self.need_input_grad and self.kind == "conv":
+                from . import f8 as F8      # plain data gradient (no statistics epilogue): fp8 candidate, dz as e5m2
+                if F8.ConvRunnerF8.applicable(dop, self.batch):
+                    self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.E5M2)
+                    self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
         if self.bn_prefix is not None:
             self.coef = torch.zeros(3, self.cpi, device=dev)
         self._bwd_ready = True
@@ -273,6 +305,13 @@ class ConvLayer:
         return self.g, self.coef
 
     def _run_dgrad(self, w):
+        if self.f8_dgrad is not None:
+            from . import f8 as F8
+            S = self.f8_grad_scale
+            F8.quantize(self.dz, self.dz8, F8.E5M2, S)
+            self.f8_dgrad.prep(w, out_scale=1.0 / S)
+            self.f8_dgrad.run(self.dz8, self.g)
+            return
         if getattr(self, "dgrad_parts", None):
             for (runner, woff), g in zip(self.dgrad_parts, self.g_parts):
                 runner.prep(w.view(-1)[woff:])

@@ -11,12 +11,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1
 # precision modes of the models (``Unet3D(dtype=...)``, ``Enc3D(dtype=...)``) -> storage type of the engine's tensors
-DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32}
+DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16}    # fp8: bf16 storage + fp8 MFMA operands (runtime/f8.py)
 SP_REDUCE_ROWS = 8    # replica rows of the accumulators the elementwise kernels reduce into (include/stroke_amd.h)
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -29,7 +29,8 @@ class ConvArgs(C.Structure):
                    "dtype_in", "dtype_out", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "YD", "YH", "YW", "CPo",
                    "osD", "osH", "osW", "ooD", "ooH", "ooW", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
                    "TD", "TH", "ITD", "ITH", "ITW", "MT", "NT", "NTtot", "ngroups", "octs_per_group", "opp", "vsb",
-                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32), ("x_plane", i64)]
+                   "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32), ("x_plane", i64),
+                                                                           ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32)]
 
 
 class WgradArgs(C.Structure):
@@ -71,6 +72,10 @@ _SIGS = {
     "sp_conv3d_igemm_multi": ([C.POINTER(ConvArgs), i32, vp], i32),
     "sp_conv3d_zm": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    "sp_conv3d_zm8": ([C.POINTER(ConvArgs), vp, vp], i32),
+    "sp_conv3d_zm8_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    "sp_conv_prep_f8": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, f32, vp], i32),
+    "sp_quantize_f8": ([vp, i32, i64, vp, i64, i64, i32, f32, vp], i32),
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv_prep_folded": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp], i32),

@@ -412,6 +412,64 @@ def zm_plan(op: ConvOp):
     return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=nw * MT, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)
 
 
+# ------------------------------------------------------------------------------------------------ fp8 z-marching plan
+# csrc/sp_conv_zm8.hip: (P planes of 16 fp8 input channels, NT output tiles) -> (MT rows per wave, ring slots, waves).
+# Mirrors sp_conv3d_zm8_config (tests/test_cabi.py).
+ZM8_CONFIGS = {(2, 2): (2, 3, 8), (2, 1): (4, 3, 8), (4, 2): (2, 3, 8), (4, 1): (4, 3, 8), (6, 2): (2, 2, 8)}
+
+
+def zm8_plan(op: ConvOp):
+    """K tables of the fp8 z-marching kernel for a stride-1 3x3x3 op between whole 16-channel planes / tiles, or None.
+
+    One MFMA step takes K = 128 = 8 chunks of 16 fp8 channels; chunk e = (in-plane tap (dy, dx), plane p), tap-major, so that
+    the two chunks of a lane group are two planes of one tap (P even):
+      ktab[(s*4 + g)*2 + h]             byte offset of the chunk inside a ring slot: ((p*ITH + dy)*18 + dx)*16
+      kmap[((dz*KS + s)*4 + g)*2 + h]   (source tap << 16) | input plane for sp_conv_prep_f8, -1 for padding chunks"""
+    if op.dtype != 0 or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
+        return None
+    sub = op.subs[0]
+    if len(sub.taps) != 27 or tuple(sub.ext) != (3, 3, 3) or tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0):
+        return None
+    P_, NT = op.cpi // 16, -(-op.cout // 16)
+    if op.cpi % 16 or op.cpo % 16 or op.cin > op.cpi or op.cpo < NT * 16 or (P_, NT) not in ZM8_CONFIGS:
+        return None
+    MT, nslot, nw = ZM8_CONFIGS[(P_, NT)]
+    ith = nw * MT + 2
+    ks = (9 * P_ + 7) // 8
+    src = {(t[0], t[1], t[2]): t[3] for t in sub.taps}
+    ktab = np.zeros(ks * 8, dtype=np.int32)
+    kmap = np.full(3 * ks * 8, -1, dtype=np.int32)
+    for e in range(9 * P_):
+        t2d, p = divmod(e, P_)
+        dy, dx = divmod(t2d, 3)
+        ktab[e] = ((p * ith + dy) * ZM_ITW + dx) * 16
+        for dz in range(3):
+            kmap[dz * ks * 8 + e] = (src[(dz, dy, dx)] << 16) | p
+    for e in range(9 * P_, ks * 8):
+        ktab[e] = ktab[e - 2]                # zero-weight padding chunks: any valid address
+    return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=nw * MT, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)
+
+
+def zm8_slices(op: ConvOp):
+    """[(first output channel, channels, sub-op)]: the op as one fp8 launch (a single slice) or one launch per 32 output
+    channels when it has more output tiles than a kernel instance holds (each launch reads the whole narrow input); None when
+    no instance applies."""
+    import dataclasses
+    if zm8_plan(op) is not None:
+        return [(0, op.cout, op)]
+    if op.dtype != 0 or op.cout % 16 or op.cpi % 16 or (op.cpi // 16, 2) not in ZM8_CONFIGS:
+        return None
+    out, c0 = [], 0
+    while c0 < op.cout:
+        cn = min(32, op.cout - c0)
+        sub_op = dataclasses.replace(op, cout=cn)
+        if zm8_plan(sub_op) is None:
+            return None
+        out.append((c0, cn, sub_op))
+        c0 += cn
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ FC-like layers
 FC_MIN_CPI = 256          # input channel pitch from which the split-K kernel is considered
 FC_MAX_VOX = 4096         # output voxels per sample up to which it is

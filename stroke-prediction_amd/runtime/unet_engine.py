@@ -48,9 +48,12 @@ class UnetEngine:
     blocks S+1..2S-1 go up; up block u concatenates the upsampled output of block u-1 with the centre crop of down
     block 2S-u."""
 
-    def __init__(self, channels, batch, dims, dtype, device):
+    def __init__(self, channels, batch, dims, dtype, device, f8=False):
+        """f8: the "fp8" precision mode -- storage stays bf16 (dtype), the 3x3x3 layers the fp8 kernel has an instance for
+        run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py)."""
         O.require_gpu()
         L.load()
+        assert not f8 or dtype == L.SP_BF16
         assert len(channels) >= 8 and len(channels) % 2 == 0, "channels: n_in, 2S-1 block widths, head width, classes"
         S = self.scales = (len(channels) - 2) // 2
         n_in, bch, bc, ncls = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
@@ -132,6 +135,27 @@ class UnetEngine:
                                       and all(sb.tile["opp"] == 2 for sb in c.fwd_op.subs))
             c.x_planar = self.cat_planar[u]
         self.generation = 0         # bumped by every forward: a backward checks that its pass is still the resident one
+        # ---- fp8 mode: which layers run on the fp8 kernel, and where each one's e4m3 input comes from
+        self.f8 = bool(f8)
+        self.f8_src = {}            # layer -> ("y8", producer layer) | ("quant", bf16 source getter, plane-major?)
+        if self.f8:
+            from . import f8 as F8
+            gs = F8.grad_scale_for(batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2])
+            for i in range(1, 2 * S):
+                c1, c2 = self.conv[i]
+                for lay in (c1, c2):
+                    if not isinstance(lay, FirstConvLayer):
+                        lay.enable_f8(gs)
+                if c2.f8_fwd is not None:
+                    if c1.f8_fwd is not None:
+                        c1.want_y8 = True
+                        self.f8_src[c2] = ("y8", c1)
+                    else:
+                        c2.x8 = F8.alloc_f8(batch, c2.in_dims, c2.cpi, device)
+                        self.f8_src[c2] = ("quant", c1, False)
+                if c1.f8_fwd is not None:
+                    c1.x8 = F8.alloc_f8(batch, c1.in_dims, c1.cpi, device)
+                    self.f8_src[c1] = ("quant", None, bool(self.cat_planar.get(i, False)))
 
     # legacy names of the 3-scale engine (tools/)
     def __getattr__(self, name):
@@ -164,7 +188,9 @@ class UnetEngine:
         x = self.x0
         for i in range(1, S + 1):
             c1, c2 = self.conv[i]
+            self._f8_input(c1, x)
             y1 = c1.forward(x, params, bufs, training, st(c2))
+            self._f8_input(c2, y1)
             y2 = c2.forward(y1, params, bufs, training)
             if i < S:
                 O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]))
@@ -173,7 +199,9 @@ class UnetEngine:
         for u in range(S + 1, 2 * S):
             c1, c2 = self.conv[u]
             O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u])
+            self._f8_input(c1, self.cat[u])
             y1 = c1.forward(self.cat[u], params, bufs, training, st(c2))
+            self._f8_input(c2, y1)
             low = c2.forward(y1, params, bufs, training)
         seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)
         if self.fused_head:
@@ -186,6 +214,18 @@ class UnetEngine:
         o = self.h2.forward(h, params, bufs, training)
         O.cl_to_ncdhw(o, seg, L.SP_F32)
         return seg
+
+    def _f8_input(self, lay, x):
+        """fp8 mode: make ``lay.x8`` the e4m3 plane-major copy of its input x -- written by the producing fp8 convolution's
+        epilogue, else by one quantisation pass over the bf16 tensor"""
+        src = self.f8_src.get(lay)
+        if src is None:
+            return
+        if src[0] == "y8":
+            lay.x8 = src[1].alloc_y8()
+        else:
+            from . import f8 as F8
+            F8.quantize(x, lay.x8, F8.E4M3, 1.0, src_planar=src[2])
 
     def _up_bwd(self, low, cat, g, coef, planar):
         """gradient of the upsampled half of a concat input -> dz of the low-resolution producer `low`"""
@@ -220,7 +260,7 @@ class UnetEngine:
         pre = O.fork()
         with pre:      # ... and ONE launch for all of them
             O.prep_batch([(l.dgrad, params[l.conv_prefix + ".weight"]) for l in self.layers
-                          if getattr(l, "dgrad", None) is not None and l.need_input_grad])
+                          if getattr(l, "dgrad", None) is not None and l.need_input_grad and l.f8_dgrad is None])
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
             b5, bc, ncls = self.channels[-3], self.channels[-2], self.ncls

@@ -1,0 +1,261 @@
+"""fp8 path (BASELINE.json configs[4]: "4-scale U-Net ... fp8 MFMA"): the e4m3 / e5m2 z-marching convolution, its weight
+packing and the quantisation kernel against torch on the SAME quantised operands (tight tolerances: what differs is the order
+of the fp32 sums), then the 4-scale network in the "fp8" precision mode against the fp8-emulating oracle (oracle/nets.py
+``_F8Conv``) and against the fixtures recorded from the reference (stated fp8 tolerances)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, weights as W
+from stroke_prediction_amd.common.model.Unet3D import Unet3D, LargeUnet3D
+import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+from stroke_prediction_amd.runtime import lib as L
+from stroke_prediction_amd.runtime import ops as O
+from stroke_prediction_amd.runtime import plan as P
+from stroke_prediction_amd.runtime import f8 as F8
+
+DEV = "cuda:0"
+CH4 = [2, 32, 64, 128, 256, 128, 64, 32, 32, 2]
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+LEAKY = 0.01
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def _to_cl(x, cp):
+    """(B, C, D, H, W) fp32 -> bf16 channels-last (B, D, H, W, cp) on the device"""
+    B, Cc = x.shape[:2]
+    out = torch.zeros((B,) + tuple(x.shape[2:]) + (cp,), dtype=torch.bfloat16)
+    out[..., :Cc] = x.permute(0, 2, 3, 4, 1).bfloat16()
+    return out.to(DEV)
+
+
+def _from_planar8(t8, dtype):
+    """plane-major fp8 bytes (P, B, D, H, W, 16) -> (B, 16 P, D, H, W) fp32"""
+    Pn, B, D, H, W, _ = t8.shape
+    v = t8.cpu().view(dtype).float()
+    return v.permute(1, 0, 5, 2, 3, 4).reshape(B, Pn * 16, D, H, W)
+
+
+@pytest.mark.parametrize("fmt,scale", [(F8.E4M3, 1.0), (F8.E4M3, 8.0), (F8.E5M2, 2.0 ** 20)])
+@pytest.mark.parametrize("planar", [False, True])
+def test_quantize_matches_torch_fp8(fmt, scale, planar):
+    """sp_quantize_f8 == clamp + round-to-nearest-even cast of torch (OCP formats: e4m3fn, e5m2), bit for bit"""
+    g = torch.Generator().manual_seed(5)
+    B, Cc, dims = 2, 48, (5, 7, 19)
+    x = bf(torch.randn(B, Cc, *dims, generator=g) * torch.logspace(-3, 2.9, Cc).view(1, -1, 1, 1, 1))
+    if fmt == F8.E5M2:
+        x = x * 1e-6
+    x[0, 0, 0, 0, :4] = torch.tensor([1e9, -1e9, 0.0, -0.0]) / scale
+    xs = _to_cl(x, Cc)
+    src = xs.view(B, *dims, Cc // 16, 16).permute(4, 0, 1, 2, 3, 5).contiguous().view(B, *dims, Cc) if planar else xs
+    dst = F8.alloc_f8(B, dims, Cc, DEV)
+    F8.quantize(src, dst, fmt, scale, src_planar=planar)
+    got = _from_planar8(dst, torch.float8_e5m2 if fmt else torch.float8_e4m3fn)
+    ref = (nets.round_e5m2 if fmt else nets.round_e4m3)(bf(x) * scale)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+def _ref_conv(x, w, b, fold_scale, fold_shift, slope):
+    wf = w * fold_scale.view(1, -1, 1, 1, 1)
+    bfold = b + (w * fold_shift.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
+    z = F.conv3d(nets.round_e4m3(x).double(), nets.quant_weights_e4m3(wf).double(), bfold.double())
+    return F.leaky_relu(z, slope).float()
+
+
+# (cin, cout, input dims, batch): the kernel instances (P, NT) = (2,2) (4,2) (6,2), the sliced ops (NT 4 and 6), ragged
+# rows / columns (extents that are not multiples of the 16 x 16 tile) and a piece boundary inside a column
+@pytest.mark.parametrize("cin,cout,dims,B", [
+    (32, 32, (12, 37, 40), 2), (64, 32, (9, 36, 35), 2), (96, 32, (8, 34, 50), 1), (32, 64, (10, 40, 36), 2),
+    (64, 64, (11, 33, 34), 1), (32, 96, (9, 35, 38), 1), (32, 32, (30, 20, 19), 3),
+])
+def test_fp8_conv_forward_matches_torch_on_quantised_operands(cin, cout, dims, B):
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = bf(torch.randn(B, cin, *dims, generator=g) * 1.5)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    fs = torch.rand(cin, generator=g) + 0.5
+    fsh = torch.randn(cin, generator=g) * 0.2
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
+    keep = F8.F8_MIN_PLANES
+    F8.F8_MIN_PLANES = 1
+    try:
+        run = F8.ConvRunnerF8(op, DEV, B, F8.E4M3)
+    finally:
+        F8.F8_MIN_PLANES = keep
+    x8 = F8.alloc_f8(B, dims, cin, DEV)
+    F8.quantize(_to_cl(x, cin), x8, F8.E4M3, 1.0)
+    run.prep(w.to(DEV), b.to(DEV), fs.to(DEV), fsh.to(DEV))
+    y = torch.full((B,) + tuple(op.y_dims) + (cout,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y8 = F8.alloc_f8(B, op.y_dims, cout, DEV)
+    nrep = 8
+    stats = torch.zeros(nrep, cout, 2, dtype=torch.float64, device=DEV)
+    run.run(x8, y, L.ACT_LEAKY, LEAKY, stats, nrep, y8=y8)
+    ref = _ref_conv(x, w, b, fs, fsh, LEAKY)
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    # same operands, fp32 accumulation in another order, bf16 rounding of the result (2^-9 relative)
+    err = (got - ref).abs() / (ref.abs() + 0.05)
+    assert float(err.max()) < 1.2e-2 and float(err.mean()) < 2e-3, (float(err.max()), float(err.mean()))
+    # the e4m3 copy is the rounding of the fp32 result: against the rounding of the (bf16-rounded) stored one a value next to
+    # a rounding boundary may fall on the other side
+    got8 = _from_planar8(y8, torch.float8_e4m3fn)
+    ref8 = nets.round_e4m3(got)
+    ulp = (got8 - ref8).abs() / (ref8.abs() * 0.125 + 2.0 ** -9)
+    assert float(ulp.max()) <= 1.001 and float((ulp > 0).float().mean()) < 0.08
+    s = stats.sum(0).cpu()
+    n = ref.numel() / cout
+    np.testing.assert_allclose(s[:, 0].numpy() / n, ref.double().mean(dim=(0, 2, 3, 4)).numpy(), rtol=0, atol=2e-3)
+    np.testing.assert_allclose(s[:, 1].numpy() / n, (ref.double() ** 2).mean(dim=(0, 2, 3, 4)).numpy(), rtol=5e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("cin,cout,dims,B", [(32, 32, (12, 37, 40), 2), (32, 64, (9, 36, 35), 1), (96, 32, (8, 34, 34), 1), (64, 64, (9, 33, 34), 1)])
+def test_fp8_data_gradient_matches_torch_on_quantised_operands(cin, cout, dims, B):
+    """g = conv_transpose(e5m2(S dz) / S, e4m3(w)) of nn.Conv3d(cin, cout, 3): the e5m2 form of the kernel on the "full"
+    correlation (padding chunks from the zero page), one launch per 32 input channels"""
+    g_ = torch.Generator().manual_seed(cin + 3 * cout)
+    od = tuple(d - 2 for d in dims)
+    S = 2.0 ** 22
+    dz = bf(torch.randn(B, cout, *od, generator=g_) * 3e-7 * torch.logspace(-1, 1, cout).view(1, -1, 1, 1, 1))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g_) / math.sqrt(27 * cin)
+    dop = P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin, L.SP_BF16)
+    keep = F8.F8_MIN_PLANES
+    F8.F8_MIN_PLANES = 1
+    try:
+        run = F8.ConvRunnerF8(dop, DEV, B, F8.E5M2)
+    finally:
+        F8.F8_MIN_PLANES = keep
+    dz8 = F8.alloc_f8(B, od, cout, DEV)
+    F8.quantize(_to_cl(dz, cout), dz8, F8.E5M2, S)
+    run.prep(w.to(DEV), out_scale=1.0 / S)
+    gout = torch.full((B,) + tuple(dims) + (cin,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    run.run(dz8, gout)
+    # the op's "output channels" are the convolution's input channels: one weight scale per INPUT channel of the conv
+    wq = nets.quant_weights_e4m3(w.permute(1, 0, 2, 3, 4).contiguous()).permute(1, 0, 2, 3, 4)
+    ref = F.conv_transpose3d((nets.round_e5m2(dz * S) / S).double(), wq.double()).float()
+    got = gout.float().cpu().permute(0, 4, 1, 2, 3)
+    scale = float(ref.abs().mean())
+    err = (got - ref).abs() / (ref.abs() + 0.5 * scale)
+    assert float(err.max()) < 1.2e-2, float(err.max())
+
+
+def _f8_layer_names(model, x):
+    eng = model._engine(x)
+    return {l.conv_prefix for l in eng.layers if l.f8_fwd is not None}, eng
+
+
+def test_unet4_fp8_mode_matches_the_fp8_emulating_oracle():
+    """4-scale network, "fp8" precision mode, 2 x 2 x 100 x 92 x 96: forward / loss against the oracle run with the same fp8
+    operand roundings (tolerance: bf16-storage noise on top, as in the bf16 test of this network), and the layers that are
+    expected to run on the fp8 kernel do."""
+    seed = 3
+    size = (100, 92, 96)
+    x, y = W.unet_inputs(2, size, seed, scales=4)
+    model = LargeUnet3D(CH4, dtype="fp8")
+    model.load_state_dict(W.make_state_dict(W.unet_spec(CH4), seed))
+    model = model.to(DEV).train()
+    keep = F8.F8_MIN_PLANES
+    F8.F8_MIN_PLANES = 64           # small volume: let the layers the bench runs in fp8 run in fp8 here too
+    try:
+        names, eng = _f8_layer_names(model, x.to(DEV))
+        assert {"block1.bn_conv_relu_2x.4", "block2.bn_conv_relu_2x.1", "block2.bn_conv_relu_2x.4", "block7.bn_conv_relu_2x.1",
+                "block7.bn_conv_relu_2x.4"} <= names, names
+        dto = model(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
+        seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+        loss = nets.unet_loss(seg, y.to(DEV))
+        loss.backward()
+    finally:
+        F8.F8_MIN_PLANES = keep
+    n_out = int(np.prod(seg.shape)) // 2
+    f8 = dict(layers=names, grad_scale=nets.f8_grad_scale(n_out))
+    sd = W.make_state_dict(W.unet_spec(CH4), seed)
+    tr = nets.trainable(sd)
+    for k in tr:
+        sd[k].requires_grad_(True)
+    seg_ref = nets.unet_forward(sd, x, training=True, q=nets.round_bf16, f8=f8)
+    loss_ref = nets.unet_loss(seg_ref, y)
+    g_ref = dict(zip(tr, torch.autograd.grad(loss_ref, [sd[k] for k in tr])))
+    sd32 = W.make_state_dict(W.unet_spec(CH4), seed)
+    seg32 = nets.unet_forward(sd32, x, training=True)
+    d_emul = float((seg.detach().cpu() - seg_ref.detach()).abs().max())
+    d_f32 = float((seg.detach().cpu() - seg32).abs().max())
+    print("fp8 mode: max |seg - fp8-emulating oracle| %.3e, max |seg - fp32 oracle| %.3e, loss %.5f / %.5f" % (d_emul, d_f32, float(loss), float(loss_ref)))
+    assert d_emul < 1.5e-2 and d_f32 < 4e-2
+    assert abs(float(loss) - float(loss_ref)) < 5e-3
+    # gradients: at 4 x 4 x 4 outputs the deep layers see a few hundred voxels; norms within a factor (as the bf16 test of this
+    # network), direction checked on the large tensors of the layers that ran in fp8
+    for k, p in model.named_parameters():
+        a, b = p.grad.detach().cpu().double(), g_ref[k].double()
+        if b.numel() >= 4096 and k.rsplit(".", 1)[0] in names:
+            cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+            assert cos > 0.8, (k, cos)
+        assert 0.3 < float(a.norm() / (b.norm() + 1e-30)) < 3.0, (k, float(a.norm()), float(b.norm()))
+
+
+@pytest.mark.parametrize("fname", ["unet4_92.npz", "unet4_92x100x96.npz"])
+def test_unet4_fp8_mode_against_the_reference_fixture(fname):
+    """the reference's own LargeUnet3D outputs (tests/golden/make_golden.py) vs the fp8 mode; tolerance stated for fp8
+    operands: probabilities 4e-2 abs (bf16 mode of this test: 2e-2), loss 1e-2"""
+    fx = np.load(os.path.join(GOLDEN, fname))
+    seed = int(fx["seed"])
+    size = tuple(int(v) for v in np.atleast_1d(fx["size"]))
+    size = size * 3 if len(size) == 1 else size
+    x, y = W.unet_inputs(2, size, seed, scales=4)
+    model = LargeUnet3D(CH4, dtype="fp8")
+    model.load_state_dict(W.make_state_dict(W.unet_spec(CH4), seed))
+    model = model.to(DEV).train()
+    keep = F8.F8_MIN_PLANES
+    F8.F8_MIN_PLANES = 64
+    try:
+        dto = model(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
+    finally:
+        F8.F8_MIN_PLANES = keep
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1).detach().cpu()
+    assert float((seg - torch.from_numpy(fx["seg"])).abs().max()) < 4e-2
+    assert abs(float(nets.unet_loss(seg, y)) - float(fx["loss/0"])) < 1e-2
+
+
+def test_unet4_fp8_directional_derivative_at_a_large_volume():
+    """configs[4] was "untested at its own size": a size-independent property at 2 x 2 x 188^3 (the largest the CPU-free test
+    budget allows; the kernels' piece / column logic is volume-agnostic).  The loss change along the NEGATIVE gradient
+    direction must be the first-order prediction: L(p - eps g/|g|) - L(p) = -eps |g| (1 + O(eps)), checked in the fp8
+    mode with the gradient from the fp8 backward and the losses from fp8 forwards (eval-free: same batch statistics)."""
+    seed = 5
+    size = (188, 188, 188)
+    torch.manual_seed(seed)
+    x = torch.randn((2, 2) + size, device=DEV)
+    model = LargeUnet3D(CH4, dtype="fp8")
+    model.load_state_dict(W.make_state_dict(W.unet_spec(CH4), seed))
+    model = model.to(DEV).train()
+    out = model.output_size(size)
+    y = (torch.rand((2, 2) + tuple(out), device=DEV) > 0.7).float()
+
+    def loss_of():
+        dto = model(UnetDtoUtil.init_dto(x, y[:, 0:1], y[:, 1:2]))
+        return nets.unet_loss(torch.cat((dto.outputs.core, dto.outputs.penu), 1), y)
+
+    l0 = loss_of()
+    l0.backward()
+    flat_p, flat_g = model.flat_buffers()
+    g = flat_g.clone()
+    gn = float(g.double().norm())
+    assert math.isfinite(gn) and gn > 0
+    eps = 2e-2 / gn * 0.05          # predicted loss change 1e-3: well above the fp8 / bf16 forward noise of a mean over 2 x 96^3 voxels
+    steps = []
+    with torch.no_grad():
+        for k in (1.0, 2.0):
+            flat_p.add_(g, alpha=-eps * k)
+            O.bump_param_epoch()
+            steps.append(float(loss_of()) - float(l0))
+            flat_p.add_(g, alpha=eps * k)
+    pred = -eps * gn * gn
+    print("directional derivative: predicted %.4e per step, measured %.4e, %.4e" % (pred, steps[0], steps[1] / 2))
+    assert steps[0] < 0 and steps[1] < steps[0]
+    assert 0.6 < steps[0] / pred < 1.4, (steps, pred)
