@@ -349,9 +349,11 @@ static int launch_zm8_3(const sp_conv_args* a, const void* zeros, hipStream_t st
 
 template <int P, int NT, int MT, int NSLOT, int NW>
 static int launch_zm8(const sp_conv_args* a, const void* zeros, hipStream_t st) {
-  if (a->f8_bin) {      // data gradient: e5m2 operand, plain epilogue, bf16 result only
-    return launch_zm8_3<P, NT, MT, NSLOT, NW, false, 0, true, false>(a, zeros, st);
+  if (a->act == SP_ACT_NONE && a->bias == nullptr && a->stats == nullptr && a->y8 == nullptr) {      // data gradients: plain epilogue, bf16 result only
+    return a->f8_bin ? launch_zm8_3<P, NT, MT, NSLOT, NW, false, 0, true, false>(a, zeros, st)
+                     : launch_zm8_3<P, NT, MT, NSLOT, NW, false, 0, false, false>(a, zeros, st);
   }
+  if (a->f8_bin) { sp_set_error("sp_conv3d_zm8: the e5m2 operand form has the plain epilogue only"); return SP_EINVAL; }
   const bool q8 = a->y8 != nullptr;
   if (a->stats) return q8 ? launch_zm8_3<P, NT, MT, NSLOT, NW, true, 1, false, true>(a, zeros, st)
                           : launch_zm8_3<P, NT, MT, NSLOT, NW, true, 1, false, false>(a, zeros, st);

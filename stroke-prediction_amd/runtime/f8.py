@@ -22,6 +22,8 @@ from . import plan as P
 
 F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "1024"))     # (column, plane) pairs below which the march is all prologue
 E4M3, E5M2 = 0, 1
+DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient convolutions on the fp8 kernel too (0: forward only)
+DZ_FMT = E5M2 if os.environ.get("SP_F8_DZ", "e5m2") == "e5m2" else E4M3      # storage format of the quantised output gradients
 
 
 def alloc_f8(batch, dims, cp, device):

@@ -221,8 +221,8 @@ class ConvLayer:
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
             if self.f8_on and self.bn_from_wgrad and self.need_input_grad and self.kind == "conv":
                 from . import f8 as F8      # plain data gradient (no statistics epilogue): fp8 candidate, dz as e5m2
-                if F8.ConvRunnerF8.applicable(dop, self.batch):
-                    self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.E5M2)
+                if F8.DGRAD and F8.ConvRunnerF8.applicable(dop, self.batch):
+                    self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.DZ_FMT)
                     self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
         if self.bn_prefix is not None:
             self.coef = torch.zeros(3, self.cpi, device=dev)
@@ -308,7 +308,7 @@ class ConvLayer:
         if self.f8_dgrad is not None:
             from . import f8 as F8
             S = self.f8_grad_scale
-            F8.quantize(self.dz, self.dz8, F8.E5M2, S)
+            F8.quantize(self.dz, self.dz8, F8.DZ_FMT, S)
             self.f8_dgrad.prep(w, out_scale=1.0 / S)
             self.f8_dgrad.run(self.dz8, self.g)
             return
