@@ -395,6 +395,27 @@ int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const fl
                          int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                          float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
 
+/* ------------------------------------------------------------------ the same kernels with an fp8 shadow output
+ * ("fp8" precision mode): besides the bf16 tensor the kernel writes q8 = fp8(q8_scale * stored value) PLANE-MAJOR,
+ * [CP/16][voxels][16 bytes] with q8_plane bytes per plane -- the operand of the next sp_conv3d_zm8 (q8_fmt 0 = e4m3: the
+ * input of a forward convolution; 1 = e5m2: the output gradient read by a data gradient) -- instead of a separate
+ * sp_quantize_f8 pass over HBM.  bf16 tensors with CP % 16 == 0 only; every other argument as in the plain entry point.
+ * sp_upsample2_crop_cat_fwd_q8 needs the plane-major concat (cat_plane != 0, CPu and CPs multiples of 16). */
+int sp_bn_act_bwd_q8(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP, int32_t act,
+                     float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale,
+                     sp_stream_t stream);
+int sp_maxpool2_fwd_q8(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
+                       double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream);
+int sp_upsample2_crop_cat_fwd_q8(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
+                                 int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs, int32_t Ws,
+                                 int64_t cat_plane, double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale,
+                                 sp_stream_t stream);
+int sp_pool_skip_act_bwd_q8(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
+                            const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                            int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc,
+                            int32_t Wc, int32_t act, float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane,
+                            int32_t q8_fmt, float q8_scale, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ network output side + Dice (Unet3D.py:53,75-77;
  * metrics.py:16-28).  dz[b,v,c] = dout[b,c,v]*act'(out[b,c,v]) : NCDHW fp32 -> channels-last */
 int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C, int64_t DHW, int32_t CP,

@@ -112,6 +112,35 @@ template <> struct Store<float> {
   }
 };
 
+// ---- optional fp8 shadow output of an elementwise kernel (the "fp8" precision mode, csrc/sp_conv_zm8.hip): besides its bf16
+// tensor the kernel writes q8 = fp8(scale * bf16(value)) into a PLANE-MAJOR tensor [CP/16][nvox][16 bytes] -- the operand of
+// the next fp8 convolution -- instead of leaving that to a separate pass over HBM (sp_quantize_f8).  p == nullptr: off.
+struct SpQ8 {
+  unsigned char* p;
+  int64_t plane;      // bytes per 16-channel plane
+  float scale;
+  int32_t fmt;        // 0 = e4m3 (saturating at 448), 1 = e5m2 (57344)
+};
+__device__ __forceinline__ uint32_t sp_q8_pack4(const float* v, float s, int fmt) {
+  float a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[j])) << 16) * s;   // the stored (bf16) value
+  int r;
+  if (fmt) {
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(a[0], -57344.f, 57344.f), __builtin_amdgcn_fmed3f(a[1], -57344.f, 57344.f), 0, false);
+    r = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(a[2], -57344.f, 57344.f), __builtin_amdgcn_fmed3f(a[3], -57344.f, 57344.f), r, true);
+  } else {
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(a[1], -448.f, 448.f), 0, false);
+    r = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a[2], -448.f, 448.f), __builtin_amdgcn_fmed3f(a[3], -448.f, 448.f), r, true);
+  }
+  return (uint32_t)r;
+}
+// channels [8 oc, 8 oc + 8) of voxel v
+__device__ __forceinline__ void sp_q8_store8(const SpQ8& q, int64_t v, int oc, const float* vals) {
+  *reinterpret_cast<uint2*>(q.p + (int64_t)(oc >> 1) * q.plane + v * 16 + (oc & 1) * 8) =
+      make_uint2(sp_q8_pack4(vals, q.scale, q.fmt), sp_q8_pack4(vals + 4, q.scale, q.fmt));
+}
+
 // ---- activations (fwd value; derivative as a function of the OUTPUT y) ------------------------
 __device__ __forceinline__ float act_fwd(int act, float p, float z) {
   switch (act) {

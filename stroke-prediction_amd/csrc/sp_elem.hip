@@ -308,7 +308,7 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                           const float* __restrict__ coef, int64_t nvox, int CP,
                                                           OctMap om, int act, float ap, T* __restrict__ dz,
-                                                          double* __restrict__ dbias) {
+                                                          double* __restrict__ dbias, const SpQ8 q8) {
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
@@ -335,25 +335,38 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
         part[0][j] += o[j];
       }
       Store<T>::st8(dz + v * CP + oc * 8, o);
+      if (q8.p) sp_q8_store8(q8, v, oc, o);
     }
   }
   if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
 }
-extern "C" int sp_bn_act_bwd(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
-                             int32_t act, float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+static int bn_act_bwd_impl(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
+                           int32_t act, float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream) {
   SP_CHECK_ARG(g && y && dz && CP % 8 == 0 && CP <= 2048, "sp_bn_act_bwd: bad arguments");
+  SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= nvox * 16 && q8.scale > 0.f), "sp_bn_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   OctMap om = make_octmap(CP);
   const unsigned grid = grid_for(nvox, om.vpb * 4);
   const size_t sh = (size_t)CP * sizeof(float);
 #define SP_L(A_)                                                                                                                   \
   if (dtype == SP_BF16) hipLaunchKernelGGL((bn_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)g, \
-                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);           \
+                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums, q8);       \
   else hipLaunchKernelGGL((bn_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)g, (const float*)y,   \
-                          coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums)
+                          coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums, q8)
   SP_ACT_DISPATCH(act, SP_L)
 #undef SP_L
   SP_CHECK_LAUNCH("sp_bn_act_bwd");
   return SP_OK;
+}
+extern "C" int sp_bn_act_bwd(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
+                             int32_t act, float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+  return bn_act_bwd_impl(g, y, coef, dtype, nvox, CP, act, act_param, dz, dbias_sums, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_bn_act_bwd_q8(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
+                                int32_t act, float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane,
+                                int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_bn_act_bwd_q8: bad fp8 output");
+  return bn_act_bwd_impl(g, y, coef, dtype, nvox, CP, act, act_param, dz, dbias_sums,
+                         SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ pool / upsample / crop fwd
@@ -377,7 +390,7 @@ struct Unflat {
 // MaxPool3d(2,2), floor mode (Unet3D.py:39,41)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims di, int CP,
-                                                            OctMap om, double* __restrict__ stats) {
+                                                            OctMap om, double* __restrict__ stats, const SpQ8 q8) {
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
@@ -406,25 +419,37 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
         for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], a[j]);
       }
       Store<T>::st8(y + v * CP + oc * 8, m);
+      if (q8.p) sp_q8_store8(q8, v, oc, m);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { part[0][j] += m[j]; part[1][j] += m[j] * m[j]; }
     }
   }
   if (stats) block_channel_reduce<2>(part, oc, active, CP, stats, red);
 }
-extern "C" int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
-                               int32_t CP, double* stats, sp_stream_t stream) {
+static int maxpool2_fwd_impl(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
+                             int32_t CP, double* stats, SpQ8 q8, sp_stream_t stream) {
   SP_CHECK_ARG(x && y && CP % 8 == 0 && D >= 2 && H >= 2 && W >= 2, "sp_maxpool2_fwd: bad arguments");
+  SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= (int64_t)B * (D / 2) * (H / 2) * (W / 2) * 16 && q8.scale > 0.f),
+               "sp_maxpool2_fwd_q8: bf16 tensors of whole 16-channel planes");
   SP_CHECK_VOX((int64_t)B * D * H * W, "sp_maxpool2_fwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
   const int64_t nout = (int64_t)B * (D / 2) * (H / 2) * (W / 2);
   const unsigned grid = grid_for(nout, om.vpb * 2);
   const size_t sh = (size_t)CP * 2 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats);
-  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats, q8);
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats, q8);
   SP_CHECK_LAUNCH("sp_maxpool2_fwd");
   return SP_OK;
+}
+extern "C" int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
+                               int32_t CP, double* stats, sp_stream_t stream) {
+  return maxpool2_fwd_impl(x, y, dtype, B, D, H, W, CP, stats, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_maxpool2_fwd_q8(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
+                                  double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_maxpool2_fwd_q8: bad fp8 output");
+  return maxpool2_fwd_impl(x, y, dtype, B, D, H, W, CP, stats, SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
 
 // nn.Upsample(scale_factor=2, mode='trilinear'), align_corners=False (Unet3D.py:44,46):
@@ -717,7 +742,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
                                                           Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane,
-                                                          double* __restrict__ stats) {
+                                                          double* __restrict__ stats, const SpQ8 q8) {
   __shared__ float red[32];
   const int p = blockIdx.y, nup = CPu >> 4;
   const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
@@ -784,6 +809,12 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
     for (int k = 0; k < 4; ++k) {
       const int64_t vo = (((int64_t)b * Do + 2 * zl + (k >> 1)) * Ho + 2 * yl + (k & 1)) * Wo + xo;
       st8_f2_rounded(cp + vo * 16, out[k]);
+      if (q8.p) {
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o8[2 * j] = out[k][j].x; o8[2 * j + 1] = out[k][j].y; }
+        sp_q8_store8(q8, vo, 2 * p + half, o8);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) { s1[j] += out[k][j]; s2[j] = f2_fma(out[k][j], out[k][j], s2[j]); }
     }
@@ -808,9 +839,9 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
   }
 }
 
-extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
-                                         int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
-                                         int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream) {
+static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
+                      int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
+                      int32_t Ws, int64_t cat_plane, double* stats, SpQ8 q8, sp_stream_t stream) {
   SP_CHECK_ARG(low && skip && cat && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
   SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_upsample2_crop_cat_fwd");
   SP_CHECK_ARG(2 * D <= Ds && 2 * H <= Hs && 2 * W <= Ws, "sp_upsample2_crop_cat_fwd: skip smaller than the upsampled grid");
@@ -823,11 +854,13 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
     const int64_t want = (total + 1023) / 1024, cap = 2048 / (CPd / 16) + 1;
     const unsigned gx = (unsigned)(want < cap ? want : cap);
     dim3 grid(gx, CPd / 16);
-    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats);
-    else hipLaunchKernelGGL(upcat_rows_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, stats);
+    SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && q8.plane >= (int64_t)B * D * H * W * 8 * 16 && q8.scale > 0.f), "sp_upsample2_crop_cat_fwd_q8: bf16 tensors only");
+    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats, q8);
+    else hipLaunchKernelGGL(upcat_rows_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, stats, q8);
     SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd(rows)");
     return SP_OK;
   }
+  SP_CHECK_ARG(!q8.p, "sp_upsample2_crop_cat_fwd_q8: the fp8 copy is written by the plane-major (row-ordered) kernel only: cat_plane != 0, channel counts multiples of 16");
   const int64_t nblk = (int64_t)B * D * H * W;          // one thread-slot per 2x2x2 output block
   const unsigned grid = grid_for(nblk, om.vpb);
   const size_t sh = (size_t)CPd * 2 * sizeof(float);
@@ -835,6 +868,19 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
   else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, om, stats);
   SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd");
   return SP_OK;
+}
+extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
+                                         int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
+                                         int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream) {
+  return upcat_impl(low, CPu, skip, CPs, cat, CPd, dtype, B, D, H, W, Ds, Hs, Ws, cat_plane, stats, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_upsample2_crop_cat_fwd_q8(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
+                                            int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
+                                            int32_t Ws, int64_t cat_plane, double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt,
+                                            float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_upsample2_crop_cat_fwd_q8: bad fp8 output");
+  return upcat_impl(low, CPu, skip, CPs, cat, CPd, dtype, B, D, H, W, Ds, Hs, Ws, cat_plane, stats,
+                    SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ fused backward pieces
@@ -845,7 +891,7 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
     const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, int ccs0, int cstride, Dims di, int CP, Dims dc,
-    OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias) {
+    OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8) {
   extern __shared__ float red[];
   float* cpl = red + CP;                              // pool-side coefficients [3][CP]: used once per window -> LDS, not VGPRs
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
@@ -927,19 +973,23 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_t<ACT>(act, ap, yv[j]); part[0][j] += d[j]; }
-          Store<T>::st8(dz + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, d);
+          const int64_t vo_ = (((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix;
+          Store<T>::st8(dz + vo_ * CP + oc * 8, d);
+          if (q8.p) sp_q8_store8(q8, vo_, oc, d);
         }
       }
     }
   }
   if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
 }
-extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
-                                    const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
-                                    int32_t dtype, int32_t B, int32_t D,
-                                    int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
-                                    float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+static int pool_skip_impl(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
+                          const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                          int32_t dtype, int32_t B, int32_t D,
+                          int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
+                          float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream) {
   SP_CHECK_ARG(y && dz && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
+  SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= (int64_t)B * D * H * W * 16 && q8.scale > 0.f),
+               "sp_pool_skip_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   SP_CHECK_VOX((int64_t)B * D * H * W, "sp_pool_skip_act_bwd");
   SP_CHECK_ARG(!gp || coefp, "sp_pool_skip_act_bwd: pool gradient without coefficients");
   SP_CHECK_ARG(!gs || (coefs && cs0 % 8 == 0 && cs0 + CP <= CPcat && Dc <= D && Hc <= H && Wc <= W), "sp_pool_skip_act_bwd: bad skip arguments");
@@ -952,14 +1002,31 @@ extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* 
 #define SP_L(A_)                                                                                                                          \
   if (dtype == SP_BF16) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
                                            (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0,   \
-                                           coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums);                          \
+                                           coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums, q8);                      \
   else hipLaunchKernelGGL((pool_skip_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, \
                           coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act,       \
-                          act_param, (float*)dz, dbias_sums)
+                          act_param, (float*)dz, dbias_sums, q8)
   SP_ACT_DISPATCH(act, SP_L)
 #undef SP_L
   SP_CHECK_LAUNCH("sp_pool_skip_act_bwd");
   return SP_OK;
+}
+extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
+                                    const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                                    int32_t dtype, int32_t B, int32_t D,
+                                    int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
+                                    float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+  return pool_skip_impl(y, gp, coefp, cat, gs, coefs, cs0, CPcat, coef_c0, coef_stride, dtype, B, D, H, W, CP, Dc, Hc, Wc, act,
+                        act_param, dz, dbias_sums, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_pool_skip_act_bwd_q8(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
+                                       const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                                       int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t Dc,
+                                       int32_t Hc, int32_t Wc, int32_t act, float act_param, void* dz, double* dbias_sums,
+                                       void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_pool_skip_act_bwd_q8: bad fp8 output");
+  return pool_skip_impl(y, gp, coefp, cat, gs, coefs, cs0, CPcat, coef_c0, coef_stride, dtype, B, D, H, W, CP, Dc, Hc, Wc, act,
+                        act_param, dz, dbias_sums, SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
 
 // transposed trilinear x2: per axis, input i receives from outputs 2i-1 (w .25), 2i (.75, or 1 at i=0),

@@ -110,6 +110,7 @@ class ConvLayer:
         self.f8_fwd = self.f8_dgrad = None
         self.f8_on = False
         self.x8 = self.y8 = self.dz8 = None
+        self.dz8_ready = False      # set by the kernel that formed dz when it also wrote the fp8 copy (dz8_out)
         self.want_y8 = False
         self.f8_grad_scale = 1.0
 
@@ -124,6 +125,17 @@ class ConvLayer:
                 and self.act in (L.ACT_NONE, L.ACT_LEAKY) and F8.ConvRunnerF8.applicable(self.fwd_op, self.batch)):
             self.f8_fwd = F8.ConvRunnerF8(self.fwd_op, self.device, self.batch, F8.E4M3)
         return self.f8_fwd is not None
+
+    def dz8_out(self):
+        """(tensor, format, scale) for the fp8 shadow output of the kernel that forms this layer's dz, or None: the data
+        gradient then needs no quantisation pass.  Call after _init_bwd."""
+        if self.f8_dgrad is None or not self.FUSE_Q8:
+            return None
+        from . import f8 as F8
+        self.dz8_ready = True
+        return (self.dz8, F8.DZ_FMT, self.f8_grad_scale)
+
+    FUSE_Q8 = not os.environ.get("SP_F8_NO_FUSE")      # (A/B knob: every fp8 operand by a separate sp_quantize_f8 pass)
 
     def alloc_y8(self):
         from . import f8 as F8
@@ -308,7 +320,9 @@ class ConvLayer:
         if self.f8_dgrad is not None:
             from . import f8 as F8
             S = self.f8_grad_scale
-            F8.quantize(self.dz, self.dz8, F8.DZ_FMT, S)
+            if not self.dz8_ready:
+                F8.quantize(self.dz, self.dz8, F8.DZ_FMT, S)
+            self.dz8_ready = False
             self.f8_dgrad.prep(w, out_scale=1.0 / S)
             self.f8_dgrad.run(self.dz8, self.g)
             return

@@ -652,14 +652,28 @@ def bn_bwd_finalize(sums, count, gamma, mean, invstd, c, cp, dgamma, dbeta, coef
            ptr(dbeta), ptr(coef), pscale, stream())
 
 
-def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias):
+def _q8_args(q8, nvox):
+    """q8 = (plane-major fp8 tensor, format, scale): the fp8 shadow output of an elementwise kernel (runtime/f8.py)"""
+    t, fmt, scale = q8
+    assert t.dtype == torch.uint8 and t.numel() == t.shape[0] * nvox * 16, (tuple(t.shape), nvox)
+    return ptr(t), nvox * 16, int(fmt), float(scale)
+
+
+def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None):
     nvox = y.numel() // y.shape[-1]
+    if q8 is not None:
+        L.call("sp_bn_act_bwd_q8", ptr(g), ptr(y), ptr(coef), dtype, nvox, y.shape[-1], act, act_param, ptr(dz),
+               ptr(dbias), *_q8_args(q8, nvox), stream())
+        return
     L.call("sp_bn_act_bwd", ptr(g), ptr(y), ptr(coef), dtype, nvox, y.shape[-1], act, act_param, ptr(dz),
            ptr(dbias), stream())
 
 
-def maxpool2_fwd(x, y, dtype, stats=None):
+def maxpool2_fwd(x, y, dtype, stats=None, q8=None):
     B, D, H, W, CP = x.shape
+    if q8 is not None:
+        L.call("sp_maxpool2_fwd_q8", ptr(x), ptr(y), dtype, B, D, H, W, CP, ptr(stats), *_q8_args(q8, y.numel() // CP), stream())
+        return
     L.call("sp_maxpool2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, ptr(stats), stream())
 
 
@@ -668,12 +682,17 @@ def upsample2_fwd(x, y, dtype, stats=None):
     L.call("sp_upsample2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, y.shape[-1], ptr(stats), stream())
 
 
-def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False):
+def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False, q8=None):
     """cat = concat(upsample2(low), centre_crop(skip)) in one pass (+ per-channel (sum, sum^2) of cat into stats).
     planar: cat (same shape) is written plane-major [C/16][B][D][H][W][16] for the DMA consumers (x_planar=True)."""
     B, D, H, W, CPu = low.shape
     _, Ds, Hs, Ws, CPs = skip.shape
     assert tuple(cat.shape) == (B, 2 * D, 2 * H, 2 * W, CPu + CPs), (tuple(cat.shape), tuple(low.shape), tuple(skip.shape))
+    if q8 is not None:
+        assert planar and CPu % 16 == 0 and CPs % 16 == 0
+        L.call("sp_upsample2_crop_cat_fwd_q8", ptr(low), CPu, ptr(skip), CPs, ptr(cat), CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
+               B * 8 * D * H * W * 16, ptr(stats), *_q8_args(q8, B * 8 * D * H * W), stream())
+        return
     L.call("sp_upsample2_crop_cat_fwd", ptr(low), CPu, ptr(skip), CPs, ptr(cat), CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
            (B * 8 * D * H * W * 16) if planar else 0, ptr(stats), stream())
 
@@ -684,7 +703,7 @@ def crop_copy(src, dst, c0, dtype, stats=None):
     L.call("sp_crop_copy", ptr(src), ptr(dst), dtype, B, Ds, Hs, Ws, CPs, Dd, Hd, Wd, CPd, c0, ptr(stats), stream())
 
 
-def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias, coef_c0=0, coef_stride=0):
+def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias, coef_c0=0, coef_stride=0, q8=None):
     """gs: gradient tensor holding the skip part in channels [cs0, cs0+CP) (pitch gs.shape[-1]); coefs indexed with
     (coef_c0, coef_stride) when the gradient is a dense tensor of the skip part only (else like the gradient)."""
     B, D, H, W, CP = y.shape
@@ -692,6 +711,10 @@ def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, 
         _, Dc, Hc, Wc, CPcat = gs.shape
     else:
         Dc = Hc = Wc = CPcat = 0
+    if q8 is not None:
+        L.call("sp_pool_skip_act_bwd_q8", ptr(y), ptr(gp), ptr(coefp), ptr(cat), ptr(gs), ptr(coefs), cs0, CPcat, coef_c0, coef_stride,
+               dtype, B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), *_q8_args(q8, B * D * H * W), stream())
+        return
     L.call("sp_pool_skip_act_bwd", ptr(y), ptr(gp), ptr(coefp), ptr(cat), ptr(gs), ptr(coefs), cs0, CPcat, coef_c0, coef_stride,
            dtype, B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), stream())
 

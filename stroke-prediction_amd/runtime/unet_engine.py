@@ -137,6 +137,7 @@ class UnetEngine:
         self.generation = 0         # bumped by every forward: a backward checks that its pass is still the resident one
         # ---- fp8 mode: which layers run on the fp8 kernel, and where each one's e4m3 input comes from
         self.f8 = bool(f8)
+        self._f8_fused = set()
         self.f8_src = {}            # layer -> ("y8", producer layer) | ("quant", bf16 source getter, plane-major?)
         if self.f8:
             from . import f8 as F8
@@ -193,12 +194,13 @@ class UnetEngine:
             self._f8_input(c2, y1)
             y2 = c2.forward(y1, params, bufs, training)
             if i < S:
-                O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]))
+                O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]), q8=self._f8_fused_input(self.conv[i + 1][0]))
                 x = self.pooled[i]
         low = y2
         for u in range(S + 1, 2 * S):
             c1, c2 = self.conv[u]
-            O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u])
+            O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u],
+                                     q8=self._f8_fused_input(c1) if self.cat_planar[u] and low.shape[-1] % 16 == 0 else None)
             self._f8_input(c1, self.cat[u])
             y1 = c1.forward(self.cat[u], params, bufs, training, st(c2))
             self._f8_input(c2, y1)
@@ -215,11 +217,23 @@ class UnetEngine:
         O.cl_to_ncdhw(o, seg, L.SP_F32)
         return seg
 
+    def _f8_fused_input(self, lay):
+        """fp8 mode: (lay.x8, e4m3, 1.0) when the pooling / concatenation kernel that writes lay's input should write its e4m3
+        copy as well (the separate quantisation pass is then skipped once), else None"""
+        if self.f8_src.get(lay) is None or self.f8_src[lay][0] != "quant" or not ConvLayer.FUSE_Q8:
+            return None
+        from . import f8 as F8
+        self._f8_fused.add(lay)
+        return (lay.x8, F8.E4M3, 1.0)
+
     def _f8_input(self, lay, x):
         """fp8 mode: make ``lay.x8`` the e4m3 plane-major copy of its input x -- written by the producing fp8 convolution's
-        epilogue, else by one quantisation pass over the bf16 tensor"""
+        epilogue or by the pooling / concatenation kernel, else by one quantisation pass over the bf16 tensor"""
         src = self.f8_src.get(lay)
         if src is None:
+            return
+        if lay in self._f8_fused:
+            self._f8_fused.discard(lay)
             return
         if src[0] == "y8":
             lay.x8 = src[1].alloc_y8()
@@ -240,9 +254,10 @@ class UnetEngine:
         dt = self.dtype
         if isinstance(g, tuple):
             O.pool_skip_act_bwd(prod.y, gp, coefp, None, g[1], coef, 0, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums,
-                                coef_c0=c_up, coef_stride=cat.shape[-1])
+                                coef_c0=c_up, coef_stride=cat.shape[-1], q8=prod.dz8_out())
         else:
-            O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums)
+            O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums,
+                                q8=prod.dz8_out())
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dseg, seg, params, grads, ready=None):
@@ -281,13 +296,13 @@ class UnetEngine:
             g, _ = self.h2.backward(self.h0.y, params, grads)
             O.bn_act_bwd(g, self.h0.y, None, dt, L.ACT_LEAKY, LEAKY, self.h0.dz, self.h0.dbias_sums)
             g, _ = self.h0.backward(last.y, params, grads)
-            O.bn_act_bwd(g, last.y, None, dt, L.ACT_LEAKY, LEAKY, last.dz, last.dbias_sums)
+            O.bn_act_bwd(g, last.y, None, dt, L.ACT_LEAKY, LEAKY, last.dz, last.dbias_sums, q8=last.dz8_out())
         pre.join()
         skip = {}                     # down block index -> (concat buffer, its gradient, coefficients, channels of the upsampled part)
         for u in range(2 * S - 1, S, -1):
             c1, c2 = self.conv[u]
             g, coef = c2.backward(c1.y, params, grads)
-            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)
+            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums, q8=c1.dz8_out())
             gu, coefu = c1.backward(self.cat[u], params, grads)
             if ready is not None and u == S + 1:     # every up block and the head are final: their all-reduce bucket may start
                 ready("block%d." % (S + 1))
@@ -297,7 +312,7 @@ class UnetEngine:
             c1, c2 = self.conv[i]
             g, coef = c2.backward(c1.y, params, grads)
             if i > 1:
-                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)
+                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums, q8=c1.dz8_out())
                 gp, coefp = c1.backward(self.pooled[i - 1], params, grads)
                 if ready is not None and i == 2:
                     ready("block2.")

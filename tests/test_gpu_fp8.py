@@ -316,3 +316,48 @@ def test_unet4_fp8_mode_trains_like_the_bf16_mode():
     assert abs(b[0] - f[0]) < 5e-3
     assert f[-1] < 0.6 * f[0], f                         # it learns ...
     assert abs(f[-1] - b[-1]) < 0.25 * (b[0] - b[-1]), (b[-1], f[-1])      # ... as far as the bf16 mode does, give or take a quarter of the way
+
+
+def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
+    """the four elementwise kernels that can write the fp8 operand of the next convolution themselves (sp_*_q8) produce
+    exactly what sp_quantize_f8 makes of the bf16 tensor they store"""
+    g_ = torch.Generator().manual_seed(17)
+    B, CP, dims = 2, 32, (10, 12, 22)
+    S = 2.0 ** 18
+
+    def cl(shape_dims, cp, scale=1.0):
+        return (torch.randn((B,) + tuple(shape_dims) + (cp,), generator=g_) * scale).bfloat16().to(DEV)
+
+    # BatchNorm / activation backward -> dz (+ e5m2 copy)
+    g, y = cl(dims, CP, 1e-5), cl(dims, CP)
+    coef = (torch.randn(3, CP, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+    dz, dz8, ref8 = torch.empty_like(g), F8.alloc_f8(B, dims, CP, DEV), F8.alloc_f8(B, dims, CP, DEV)
+    O.bn_act_bwd(g, y, coef, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz, None, q8=(dz8, F8.E5M2, S))
+    F8.quantize(dz, ref8, F8.E5M2, S)
+    assert torch.equal(dz8, ref8) and float(dz.float().abs().max()) > 0
+    # MaxPool3d -> pooled (+ e4m3 copy)
+    x = cl(dims, CP)
+    pd = tuple(d // 2 for d in dims)
+    p, p8, r8 = O.alloc_cl(B, pd, CP, L.SP_BF16, DEV), F8.alloc_f8(B, pd, CP, DEV), F8.alloc_f8(B, pd, CP, DEV)
+    O.maxpool2_fwd(x, p, L.SP_BF16, None, q8=(p8, F8.E4M3, 1.0))
+    F8.quantize(p, r8, F8.E4M3, 1.0)
+    assert torch.equal(p8, r8)
+    # pool + skip backward -> dz of a block output (+ e5m2 copy)
+    gp = cl(pd, CP, 1e-5)
+    cd = tuple(d - 4 for d in dims)
+    gs = cl(cd, 64, 1e-5)
+    coefp = (torch.randn(3, CP, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+    coefs = (torch.randn(3, 64, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+    dz2, dz28, ref28 = torch.empty_like(x), F8.alloc_f8(B, dims, CP, DEV), F8.alloc_f8(B, dims, CP, DEV)
+    O.pool_skip_act_bwd(x, gp, coefp, None, gs, coefs, 32, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz2, None, q8=(dz28, F8.E5M2, S))
+    F8.quantize(dz2, ref28, F8.E5M2, S)
+    assert torch.equal(dz28, ref28) and float(dz2.float().abs().max()) > 0
+    # upsample + crop + concat, plane-major -> cat (+ e4m3 copy)
+    ld = (4, 5, 9)
+    low, skip = cl(ld, 32), cl(tuple(2 * d + 4 for d in ld), 16)
+    od = tuple(2 * d for d in ld)
+    cat = torch.empty((B,) + od + (48,), dtype=torch.bfloat16, device=DEV)
+    cat8, rc8 = F8.alloc_f8(B, od, 48, DEV), F8.alloc_f8(B, od, 48, DEV)
+    O.upsample2_crop_cat_fwd(low, skip, cat, L.SP_BF16, None, planar=True, q8=(cat8, F8.E4M3, 1.0))
+    F8.quantize(cat, rc8, F8.E4M3, 1.0, src_planar=True)
+    assert torch.equal(cat8, rc8)
