@@ -9,6 +9,7 @@ strided and transposed convolutions through the same table-driven implicit-GEMM 
 interpolation (Cae3D.py:78-89) stays a three-operand torch expression on B x 800 x 1 x 10 x 10 values.
 ``Enc3DStep`` / ``Enc3DCtp`` (learned step, CTP-conditioned encoder) are outside the accelerated path.
 """
+import os
 import weakref
 
 import torch
@@ -55,13 +56,44 @@ class _Lease:
             pass
 
 
+# The 3 encoder / 4 decoder passes of a step (Cae3D.py:105-107,230-233) are independent but for the BatchNorm running statistics
+# and the shared parameter gradients.  SP_CAE_STREAMS (default 1): while a hipGraph is being captured every pass of a call runs
+# on its own stream -- parallel branches of the graph: the step is ~980 launches, 765 of them under 20 us, which then overlap
+# 3-4 deep -- with per-layer events keeping the running-statistics updates in pass order and per-pass gradient buffers added up
+# on one stream.  2: in eager launches too.  0: one stream.
+CAE_STREAMS = int(os.environ.get("SP_CAE_STREAMS", "1"))
+_LANE_STREAMS = {}
+_REDUCE_STREAMS = {}
+
+
+def _concurrent_passes():
+    return CAE_STREAMS == 2 or (CAE_STREAMS == 1 and torch.cuda.is_current_stream_capturing())
+
+
+def _lane_stream(device, lane):
+    key = (device.index, lane)
+    if key not in _LANE_STREAMS:
+        _LANE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _LANE_STREAMS[key]
+
+
+def _reduce_stream(device):
+    if device.index not in _REDUCE_STREAMS:
+        _REDUCE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return _REDUCE_STREAMS[device.index]
+
+
 class _StackFn(torch.autograd.Function):
-    """One encoder or decoder call.  ``x`` needs a gradient only for the decoder (the latent)."""
+    """One encoder or decoder call.  ``x`` needs a gradient only for the decoder (the latent).
+    opts: None, or dict(lane, nlanes, order, bump_nbt) of a pass that runs concurrently with its siblings."""
 
     @staticmethod
-    def forward(ctx, module, x, *params):
-        key, sc = module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device)
-        out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training)
+    def forward(ctx, module, opts, x, *params):
+        opts = opts or {}
+        key, sc = module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device, lane=opts.get("lane", 0))
+        out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training, bump_nbt=opts.get("bump_nbt", True),
+                         order=opts.get("order"))
+        ctx.concurrent = opts.get("nlanes", 1) > 1
         ctx.module, ctx.sc = module, sc
         ctx.lease = _Lease(module._pool(), key, sc, module)
         module._begin_step()
@@ -80,12 +112,27 @@ class _StackFn(torch.autograd.Function):
                                "batch-statistics BatchNorm formula; call model.train() for passes that need gradients"
                                % type(module).__name__)
         names, views, inplace = module._grad_targets()
-        dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
+        red = None
+        if ctx.concurrent and inplace:
+            # sibling passes run their backward on other streams at the same time: accumulate into this context's own buffer,
+            # then add it to the stack's segment of the flat gradient buffer on ONE stream (adds of all passes in issue order)
+            priv, grads = sc.private_grads(names, views)
+            dx = sc.backward(dout, out, module._param_dict(), grads, ctx.need_dx)
+            seg = module._flat_segment()
+            cur = torch.cuda.current_stream()
+            red = _reduce_stream(dout.device)
+            red.wait_stream(cur)
+            with torch.cuda.stream(red):
+                seg.add_(priv)              # (the segment's offset is not 16-byte aligned: a plain torch add, ~9 MB)
+        else:
+            dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
         ctx.lease.release()
         module._n_out = max(0, getattr(module, "_n_out", 1) - 1)
         if module._n_out == 0:
+            if red is not None:
+                torch.cuda.current_stream().wait_stream(red)      # every pass of this stack has queued its add by now
             module._stack_grads_final()
-        return (None, dx) + tuple(None if inplace else v for v in views)
+        return (None, None, dx) + tuple(None if inplace else v for v in views)
 
 
 class CaeBase(FlatParamsMixin, nn.Module):
@@ -123,7 +170,7 @@ class CaeBase(FlatParamsMixin, nn.Module):
             self._stack_pool = StackPool(self._TABLE, self._PREFIX, self.channels, self.alpha, self._LAST_SIGMOID)
         return self._stack_pool
 
-    def _run_stack(self, x):
+    def _run_stack(self, x, opts=None):
         if x is None:
             return None
         if not x.is_cuda or not next(self.parameters()).is_cuda:
@@ -134,11 +181,58 @@ class CaeBase(FlatParamsMixin, nn.Module):
             x = x.float()
         params = [p for _, p in self.named_parameters()]
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
-            return _StackFn.apply(self, x, *params)
-        key, sc = self._pool().acquire(x.shape[0], tuple(x.shape[2:]), self._dtype_code(), x.device)
-        out = sc.forward(x, self._param_dict(), self._buffer_dict(), self.training)
+            return _StackFn.apply(self, opts, x, *params)
+        opts = opts or {}
+        key, sc = self._pool().acquire(x.shape[0], tuple(x.shape[2:]), self._dtype_code(), x.device, lane=opts.get("lane", 0))
+        out = sc.forward(x, self._param_dict(), self._buffer_dict(), self.training, bump_nbt=opts.get("bump_nbt", True),
+                         order=opts.get("order"))
         self._pool().release(key, sc)
         return out
+
+    def _run_stack_many(self, xs):
+        """The passes of one encoder / decoder call (``None`` entries stay ``None``): one after the other on the current
+        stream, or -- see CAE_STREAMS -- each on its own stream with the outputs joined back before returning."""
+        idx = [i for i, x in enumerate(xs) if x is not None]
+        if len(idx) <= 1 or not xs[idx[0]].is_cuda or not _concurrent_passes():
+            return [self._run_stack(x) for x in xs]
+        self._ensure_flat()
+        dev = xs[idx[0]].device
+        main = torch.cuda.current_stream(dev)
+        n = len(idx)
+        training = self.training
+        if training:
+            nbt = self._buffer_dict().get("__nbt_flat__")
+            if nbt is not None:
+                nbt.add_(n)                       # one increment for the n passes (each BatchNorm runs once per pass)
+        nlayers = len(self._TABLE)
+        outs = list(xs)
+        prev = None
+        for lane, i in enumerate(idx):
+            s = main if lane == 0 else _lane_stream(dev, lane)
+            if lane:
+                s.wait_stream(main)
+            rec = [torch.cuda.Event() for _ in range(nlayers)] if (training and lane + 1 < n) else None
+            with torch.cuda.stream(s):
+                outs[i] = self._run_stack(xs[i], dict(lane=lane, nlanes=n, bump_nbt=nbt is None if training else True,
+                                                      order=(prev, rec) if training else None))
+            prev = rec
+        for lane, i in enumerate(idx):
+            if lane:
+                main.wait_stream(_lane_stream(dev, lane))
+                outs[i].record_stream(main)
+        return outs
+
+    def _flat_segment(self):
+        """this stack's slice of the (root's) flat gradient buffer"""
+        root = self._flat_root()
+        n = sum(p.numel() for p in self.parameters())
+        if root is self:
+            return root._flat_grad[:n]
+        for name, m in root.named_children():
+            if m is self:
+                lo = root._flat_offset_of(name + ".")
+                return root._flat_grad[lo:lo + n]
+        raise RuntimeError("stack is not a child of its flat root")
 
     def _stack_grads_final(self):
         """every pass of this stack recorded in the current step has run its backward: its parameter gradients are
@@ -224,15 +318,12 @@ class Enc3D(CaeBase):
         if dto.flag == CaeDtoUtil.FLAG_GTRUTH or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
             assert dto.latents.gtruth._is_empty()   # do not overwrite earlier results by mistake
             gt, lat = dto.given_variables.gtruth, dto.latents.gtruth
-            lat.core = self._forward_single(gt.core)
-            lat.penu = self._forward_single(gt.penu)
-            lat.lesion = self._forward_single(gt.lesion)
+            lat.core, lat.penu, lat.lesion = self._run_stack_many([gt.core, gt.penu, gt.lesion])
             lat.interpolation = self._interpolate(lat.core, lat.penu, step)
         if dto.flag == CaeDtoUtil.FLAG_INPUTS or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
             assert dto.latents.inputs._is_empty()
             inp, lat = dto.given_variables.inputs, dto.latents.inputs
-            lat.core = self._forward_single(inp.core)
-            lat.penu = self._forward_single(inp.penu)
+            lat.core, lat.penu = self._run_stack_many([inp.core, inp.penu])
             lat.interpolation = self._interpolate(lat.core, lat.penu, step)
         return dto
 
@@ -285,16 +376,11 @@ class Dec3D(CaeBase):
         if dto.flag == CaeDtoUtil.FLAG_GTRUTH or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
             assert dto.reconstructions.gtruth._is_empty()
             lat, rec = dto.latents.gtruth, dto.reconstructions.gtruth
-            rec.core = self._forward_single(lat.core)
-            rec.penu = self._forward_single(lat.penu)
-            rec.lesion = self._forward_single(lat.lesion)
-            rec.interpolation = self._forward_single(lat.interpolation)
+            rec.core, rec.penu, rec.lesion, rec.interpolation = self._run_stack_many([lat.core, lat.penu, lat.lesion, lat.interpolation])
         if dto.flag == CaeDtoUtil.FLAG_INPUTS or dto.flag == CaeDtoUtil.FLAG_DEFAULT:
             assert dto.reconstructions.inputs._is_empty()
             lat, rec = dto.latents.inputs, dto.reconstructions.inputs
-            rec.core = self._forward_single(lat.core)
-            rec.penu = self._forward_single(lat.penu)
-            rec.interpolation = self._forward_single(lat.interpolation)
+            rec.core, rec.penu, rec.interpolation = self._run_stack_many([lat.core, lat.penu, lat.interpolation])
         return dto
 
 

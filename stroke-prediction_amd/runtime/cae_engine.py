@@ -71,11 +71,15 @@ class StackContext:
         self.x0 = O.alloc_cl(batch, in_dims, self.layers[0].cpi, dtype, device)
         self.out_dtype = self.layers[-1].out_dtype
 
-    def forward(self, x, params, bufs, training):
-        """x: (B, cin, D, H, W) fp32 on the device -> (B, cout, D', H', W') fp32."""
+    def forward(self, x, params, bufs, training, bump_nbt=True, order=None):
+        """x: (B, cin, D, H, W) fp32 on the device -> (B, cout, D', H', W') fp32.
+        order = (wait, record): per-layer event lists of concurrently running passes of one stack (Cae3D._run_stack_many) --
+        layer i starts after the previous pass recorded wait[i], and records record[i] when its own work is enqueued, so the
+        BatchNorm running statistics are updated in pass order, as by the reference's sequential calls (Cae3D.py:105-107)."""
         assert tuple(x.shape) == (self.batch, self.cin) + self.in_dims, (tuple(x.shape), self.in_dims)
         self.scratch.zero()
-        if training and "__nbt_flat__" in bufs:
+        wait_ev, rec_ev = order if order is not None else (None, None)
+        if training and bump_nbt and "__nbt_flat__" in bufs:
             bufs["__nbt_flat__"].add_(1)
         O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)
         if training:
@@ -83,10 +87,27 @@ class StackContext:
         h = self.x0
         for i, lay in enumerate(self.layers):
             nxt = self.layers[i + 1].in_sums if (training and i + 1 < len(self.layers)) else None
+            if wait_ev is not None:
+                torch.cuda.current_stream().wait_event(wait_ev[i])
             h = lay.forward(h, params, bufs, training, nxt)
+            if rec_ev is not None:
+                rec_ev[i].record()
         out = torch.empty((self.batch, self.cout) + self.out_dims, dtype=torch.float32, device=self.device)
         O.cl_to_ncdhw(h, out, self.out_dtype)
         return out
+
+    def private_grads(self, names, views):
+        """a zeroed gradient buffer of this context shaped like the stack's segment of the flat gradient buffer (concurrent
+        passes accumulate privately; Cae3D._StackFn.backward adds the buffers up in stream order)"""
+        n = sum(v.numel() for v in views)
+        if getattr(self, "_gpriv", None) is None or self._gpriv.numel() != n:
+            self._gpriv = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._gpriv.zero_()
+        out, off = {}, 0
+        for k, v in zip(names, views):
+            out[k] = self._gpriv[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+        return self._gpriv, out
 
     def backward(self, dout, out, params, grads, need_input_grad):
         """dout = dL/dout (NCDHW fp32).  Accumulates parameter gradients; returns dL/dx (NCDHW fp32) or None."""
@@ -129,8 +150,11 @@ class StackPool:
         self.free = {}
         self.banks = {}
 
-    def acquire(self, batch, in_dims, dtype, device):
-        key = (batch, tuple(in_dims), dtype, str(device))
+    def acquire(self, batch, in_dims, dtype, device, lane=0):
+        """lane > 0: a pass that runs CONCURRENTLY with the lane-0 pass of the same call (its own stream): its contexts share
+        no packed weights / split-K workspace with the other lanes (the shared bank is written once per step by whoever
+        comes first -- a race between streams)."""
+        key = (batch, tuple(in_dims), dtype, str(device), lane)
         lst = self.free.setdefault(key, [])
         if lst:
             return key, lst.pop()

@@ -115,7 +115,7 @@ class fork:
         self.main = torch.cuda.current_stream()
         self.on = overlap_level() > 0
         if self.on:
-            key = self.main.device.index
+            key = (self.main.device.index, self.main.cuda_stream)      # one side stream per launching stream (concurrent CAE passes)
             if key not in _SIDE:
                 _SIDE[key] = torch.cuda.Stream(device=self.main.device)
             self.side = _SIDE[key]

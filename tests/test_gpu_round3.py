@@ -95,3 +95,77 @@ def test_save_model_between_captured_steps_keeps_the_graph_valid(tmp_path):
     # atomics separates the two trajectories (see test_learner_graph_mode_matches_eager_and_follows_schedulers)
     assert np.allclose(out["plain"][0], out["saved"][0], atol=2e-3), (out["plain"][0], out["saved"][0])
     assert float((out["plain"][1] - out["saved"][1]).abs().max()) < 8e-3
+
+
+# ------------------------------------------------------------------------------------------------ CAE: concurrent passes
+def _cae_step(ch, seed, d, hw, dtype, streams, graph=False, steps=1):
+    """one (or a few) CaeReconstructionLearner.train_batch steps; returns reconstructions, loss, the flat gradient after the
+    first backward and every buffer -- with the 3 + 4 passes on one stream (streams = 0) or one stream each (2)"""
+    from stroke_prediction_amd.common.model import Cae3D as M
+    from stroke_prediction_amd.common.model.Cae3D import Cae3D, Enc3D, Dec3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.CaeReconstructionLearner import CaeReconstructionLearner
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    keep = M.CAE_STREAMS
+    M.CAE_STREAMS = streams
+    try:
+        cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype=dtype), Dec3D(hw, d, ch, 5, 1.0, dtype=dtype))
+        cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+        cae = cae.to(DEV).train()
+        opt = FusedAdam([p for p in cae.parameters()], lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999), capturable=True)
+        attach_flat_grads(cae)
+
+        class Loader(list):
+            batch_size = 2
+        learner = CaeReconstructionLearner(Loader(), None, cae, opt, None, 1, None, "/tmp/_cae_r3", BatchDiceLoss([1.0]),
+                                           verbose=False, graph=graph, batch_metrics=False)
+        learner.GRAPH_WARMUP = 1
+        labels, clinical = W.cae_inputs(2, d, hw, seed)
+        batch = {"case_id": [0, 1], "images": None, "labels": labels.to(DEV), "clinical": clinical.to(DEV)}
+        dto = learner.inference_step(batch)
+        loss = learner.loss_step(dto, 30)
+        opt.zero_grad()
+        loss.backward()
+        torch.cuda.synchronize()
+        rec = {k: getattr(dto.reconstructions.gtruth, k).detach().clone() for k in ("core", "penu", "lesion", "interpolation")}
+        grad = cae.flat_buffers()[1].clone()
+        bufs = {k: v.detach().clone() for k, v in cae.named_buffers()}
+        losses = []
+        for _ in range(steps):
+            losses.append(float(learner.train_batch(batch, 30).loss))
+        torch.cuda.synchronize()
+        return rec, float(loss.detach()), grad, bufs, losses, cae.flat_buffers()[0].clone()
+    finally:
+        M.CAE_STREAMS = keep
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_cae_concurrent_passes_equal_sequential_passes(dtype):
+    """VERDICT r2 item 2 (structure of the CAE step): the 3 encoder / 4 decoder passes of a call on one stream each
+    (SP_CAE_STREAMS) -- same reconstructions, loss and BatchNorm buffers (the running statistics are updated in pass order
+    through per-layer events), gradients equal up to the order of the seven partial sums (each pass accumulates into its own
+    buffer, added in issue order)."""
+    ch = [1, 16, 24, 32, 100, 200, 1]
+    a = _cae_step(ch, 23, 28, 64, dtype, 0)
+    b = _cae_step(ch, 23, 28, 64, dtype, 2)
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k                 # forward: the same kernels on the same data
+    assert a[1] == b[1]
+    for k in a[3]:
+        if k.endswith("num_batches_tracked"):
+            assert int(a[3][k]) == int(b[3][k]) == (3 if k.startswith("enc.") else 4), k
+        else:
+            assert torch.equal(a[3][k], b[3][k]), k             # running statistics: pass order kept
+    rel = float((a[2] - b[2]).double().norm() / a[2].double().norm())
+    assert rel < 2e-6, rel
+
+
+def test_cae_graph_mode_with_concurrent_passes_follows_the_eager_trajectory():
+    """Learner(graph=True) captures the step with the passes as parallel graph branches: four replayed steps stay on the
+    trajectory of the sequential eager steps (bf16 run-to-run noise of the fp64 statistics atomics only)."""
+    ch = [1, 16, 24, 32, 100, 200, 1]
+    a = _cae_step(ch, 23, 28, 64, "f32", 0, graph=False, steps=4)
+    b = _cae_step(ch, 23, 28, 64, "f32", 1, graph=True, steps=4)
+    np.testing.assert_allclose(a[4], b[4], rtol=0, atol=3e-4)
+    assert b[4][-1] < b[4][0]
+    assert float((a[5] - b[5]).abs().max()) < 8e-3
