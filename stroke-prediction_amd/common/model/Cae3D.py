@@ -9,6 +9,7 @@ strided and transposed convolutions through the same table-driven implicit-GEMM 
 interpolation (Cae3D.py:78-89) stays a three-operand torch expression on B x 800 x 1 x 10 x 10 values.
 ``Enc3DStep`` / ``Enc3DCtp`` (learned step, CTP-conditioned encoder) are outside the accelerated path.
 """
+import contextlib
 import os
 import weakref
 
@@ -19,6 +20,7 @@ import common.dto.CaeDto as CaeDtoUtil
 from common.dto.CaeDto import CaeDto
 from stroke_prediction_amd.runtime import lib as _L
 from stroke_prediction_amd.runtime.flat import FlatParamsMixin
+from stroke_prediction_amd.runtime import ops as _O
 
 
 def _containers(table, cm):
@@ -62,6 +64,7 @@ class _Lease:
 # 3-4 deep -- with per-layer events keeping the running-statistics updates in pass order and per-pass gradient buffers added up
 # on one stream.  2: in eager launches too.  0: one stream.
 CAE_STREAMS = int(os.environ.get("SP_CAE_STREAMS", "1"))
+_DBG = set(os.environ.get("SP_CAE_DBG", "").split(","))
 _LANE_STREAMS = {}
 _REDUCE_STREAMS = {}
 
@@ -90,10 +93,12 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, opts, x, *params):
         opts = opts or {}
-        key, sc = module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device, lane=opts.get("lane", 0))
-        out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training, bump_nbt=opts.get("bump_nbt", True),
-                         order=opts.get("order"))
-        ctx.concurrent = opts.get("nlanes", 1) > 1
+        key, sc = opts.get("sc") or module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device, lane=opts.get("lane", 0))
+        ctx.concurrent = bool(opts.get("concurrent"))
+        with (_O.no_fork() if ctx.concurrent else contextlib.nullcontext()):
+            out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training, bump_nbt=opts.get("bump_nbt", True),
+                             order=opts.get("order"))
+        ctx.home = opts.get("home")              # the stream the call came from (concurrent passes: joined again after backward)
         ctx.module, ctx.sc = module, sc
         ctx.lease = _Lease(module._pool(), key, sc, module)
         module._begin_step()
@@ -113,11 +118,12 @@ class _StackFn(torch.autograd.Function):
                                % type(module).__name__)
         names, views, inplace = module._grad_targets()
         red = None
-        if ctx.concurrent and inplace:
+        if ctx.concurrent and inplace and "nored" not in _DBG:
             # sibling passes run their backward on other streams at the same time: accumulate into this context's own buffer,
             # then add it to the stack's segment of the flat gradient buffer on ONE stream (adds of all passes in issue order)
             priv, grads = sc.private_grads(names, views)
-            dx = sc.backward(dout, out, module._param_dict(), grads, ctx.need_dx)
+            with _O.no_fork():
+                dx = sc.backward(dout, out, module._param_dict(), grads, ctx.need_dx)
             seg = module._flat_segment()
             cur = torch.cuda.current_stream()
             red = _reduce_stream(dout.device)
@@ -125,13 +131,19 @@ class _StackFn(torch.autograd.Function):
             with torch.cuda.stream(red):
                 seg.add_(priv)              # (the segment's offset is not 16-byte aligned: a plain torch add, ~9 MB)
         else:
-            dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
+            with (_O.no_fork() if ctx.concurrent else contextlib.nullcontext()):
+                dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
         ctx.lease.release()
         module._n_out = max(0, getattr(module, "_n_out", 1) - 1)
         if module._n_out == 0:
             if red is not None:
                 torch.cuda.current_stream().wait_stream(red)      # every pass of this stack has queued its add by now
             module._stack_grads_final()
+        if ctx.concurrent and ctx.home is not None and ctx.home != torch.cuda.current_stream() and "nojoin" not in _DBG:
+            # autograd joins a node's stream with its consumers' and with the streams of AccumulateGrad nodes; a pass that
+            # returns no gradient tensor (parameters accumulate in place, the encoder input needs none) would otherwise stay
+            # un-joined: the optimiser on the home stream would not wait for it, and a stream capture could not end
+            ctx.home.wait_stream(torch.cuda.current_stream())
         return (None, None, dx) + tuple(None if inplace else v for v in views)
 
 
@@ -183,7 +195,7 @@ class CaeBase(FlatParamsMixin, nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _StackFn.apply(self, opts, x, *params)
         opts = opts or {}
-        key, sc = self._pool().acquire(x.shape[0], tuple(x.shape[2:]), self._dtype_code(), x.device, lane=opts.get("lane", 0))
+        key, sc = opts.get("sc") or self._pool().acquire(x.shape[0], tuple(x.shape[2:]), self._dtype_code(), x.device, lane=opts.get("lane", 0))
         out = sc.forward(x, self._param_dict(), self._buffer_dict(), self.training, bump_nbt=opts.get("bump_nbt", True),
                          order=opts.get("order"))
         self._pool().release(key, sc)
@@ -193,33 +205,47 @@ class CaeBase(FlatParamsMixin, nn.Module):
         """The passes of one encoder / decoder call (``None`` entries stay ``None``): one after the other on the current
         stream, or -- see CAE_STREAMS -- each on its own stream with the outputs joined back before returning."""
         idx = [i for i, x in enumerate(xs) if x is not None]
-        if len(idx) <= 1 or not xs[idx[0]].is_cuda or not _concurrent_passes():
+        if len(idx) <= 1 or not xs[idx[0]].is_cuda or CAE_STREAMS == 0:
             return [self._run_stack(x) for x in xs]
+        # Pass k always runs in the contexts of lane k (their own packed weights and workspaces), whether or not the lanes run
+        # concurrently right now: the eager warm-up steps of Learner(graph=True) thereby create, on one stream, exactly the
+        # contexts the captured step uses (building one uploads tables, which a capturing stream may not do).
+        conc = _concurrent_passes()
         self._ensure_flat()
         dev = xs[idx[0]].device
         main = torch.cuda.current_stream(dev)
         n = len(idx)
         training = self.training
-        if training:
-            nbt = self._buffer_dict().get("__nbt_flat__")
-            if nbt is not None:
-                nbt.add_(n)                       # one increment for the n passes (each BatchNorm runs once per pass)
+        nbt = self._buffer_dict().get("__nbt_flat__") if training else None
+        if nbt is not None:
+            nbt.add_(n)                           # one increment for the n passes (each BatchNorm runs once per pass)
         nlayers = len(self._TABLE)
         outs = list(xs)
         prev = None
+        x0 = xs[idx[0]]
+        scs = [self._pool().acquire(x0.shape[0], tuple(x0.shape[2:]), self._dtype_code(), dev, lane=lane) for lane in range(n)]
+        fork_ev = None
+        if conc:
+            # weights that depend on the parameters only are packed once, here, before the lanes fork (shared bank)
+            with_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            scs[0][1].prepare(self._param_dict(), with_bwd)
+            fork_ev = torch.cuda.Event()
+            fork_ev.record(main)          # every lane starts HERE (not behind lane 0's work, which goes to the home stream)
         for lane, i in enumerate(idx):
-            s = main if lane == 0 else _lane_stream(dev, lane)
-            if lane:
-                s.wait_stream(main)
-            rec = [torch.cuda.Event() for _ in range(nlayers)] if (training and lane + 1 < n) else None
+            s = main if (lane == 0 or not conc) else _lane_stream(dev, lane)
+            if s is not main:
+                s.wait_event(fork_ev)
+            rec = [torch.cuda.Event() for _ in range(nlayers)] if (conc and training and lane + 1 < n and "noorder" not in _DBG) else None
             with torch.cuda.stream(s):
-                outs[i] = self._run_stack(xs[i], dict(lane=lane, nlanes=n, bump_nbt=nbt is None if training else True,
-                                                      order=(prev, rec) if training else None))
+                outs[i] = self._run_stack(xs[i], dict(lane=lane, sc=scs[lane], concurrent=conc, home=main, bump_nbt=nbt is None,
+                                                      order=(prev, rec) if (conc and training) else None))
             prev = rec
-        for lane, i in enumerate(idx):
-            if lane:
-                main.wait_stream(_lane_stream(dev, lane))
-                outs[i].record_stream(main)
+        if conc:
+            for lane, i in enumerate(idx):
+                if lane:
+                    main.wait_stream(_lane_stream(dev, lane))
+                    if "norecord" not in _DBG:
+                        outs[i].record_stream(main)
         return outs
 
     def _flat_segment(self):

@@ -96,6 +96,19 @@ class StackContext:
         O.cl_to_ncdhw(h, out, self.out_dtype)
         return out
 
+    def prepare(self, params, with_bwd):
+        """Pack every weight that depends on the parameters only (forward fragments of the un-folded layers, data-gradient
+        fragments) NOW, on the current stream: passes that then run concurrently on other streams find the shared bank
+        current and launch no re-pack of their own."""
+        for lay in self.layers:
+            c = lay.conv_prefix
+            if not lay.fold:
+                lay.fwd.prep(params[c + ".weight"], params[c + ".bias"])
+            if with_bwd:
+                lay._init_bwd()
+                if getattr(lay, "dgrad", None) is not None and lay.f8_dgrad is None:
+                    lay.dgrad.prep(params[c + ".weight"])
+
     def private_grads(self, names, views):
         """a zeroed gradient buffer of this context shaped like the stack's segment of the flat gradient buffer (concurrent
         passes accumulate privately; Cae3D._StackFn.backward adds the buffers up in stream order)"""
@@ -151,15 +164,16 @@ class StackPool:
         self.banks = {}
 
     def acquire(self, batch, in_dims, dtype, device, lane=0):
-        """lane > 0: a pass that runs CONCURRENTLY with the lane-0 pass of the same call (its own stream): its contexts share
-        no packed weights / split-K workspace with the other lanes (the shared bank is written once per step by whoever
-        comes first -- a race between streams)."""
+        """lane: index of the pass inside one encoder / decoder call (Cae3D._run_stack_many): pass k always gets the contexts of
+        lane k, so the eager warm-up steps build exactly the contexts a captured step replays.  All lanes share the bank of
+        packed weights (un-folded fragments depend on the parameters only; ``StackContext.prepare`` fills it once per step
+        before concurrent passes fork)."""
         key = (batch, tuple(in_dims), dtype, str(device), lane)
         lst = self.free.setdefault(key, [])
         if lst:
             return key, lst.pop()
         return key, StackContext(self.table, self.prefix, self.channels, self.alpha, batch, in_dims, dtype, device,
-                                 self.last_sigmoid, bank=self.banks.setdefault(key, {}))
+                                 self.last_sigmoid, bank=self.banks.setdefault(key[:-1], {}))
 
     def release(self, key, ctx):
         lst = self.free.setdefault(key, [])

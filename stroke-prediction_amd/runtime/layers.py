@@ -92,7 +92,8 @@ class ConvLayer:
         # materialised ones (the kernel pads from its zero page and has an ELU epilogue)
         zm_ok = (self.fold and act in (L.ACT_NONE, L.ACT_LEAKY) and bank is None) or \
                 (self.materialize and act == L.ACT_ELU and O.ZM_CAE and self.out_dtype == dtype)
-        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if bank is None else bank.setdefault((name, "fwd"), {}),
+        # (folded fragments depend on the BatchNorm statistics of the pass: never shared between the contexts of a bank)
+        self.fwd = O.ConvRunner(self.fwd_op, device, share=None if (bank is None or self.fold) else bank.setdefault((name, "fwd"), {}),
                                 zm_batch=batch if zm_ok else None)
         if bn_prefix is not None:
             self.apply_coef = torch.zeros(3, self.cpi, device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift

@@ -99,8 +99,25 @@ _OV = os.environ.get("SP_OVERLAP", "2")
 _OV_EAGER = bool(os.environ.get("SP_OVERLAP_EAGER"))
 
 
+import threading
+_tls = threading.local()
+
+
+class no_fork:
+    """with no_fork(): the second stream is not used by what runs inside (this thread).  The concurrent passes of the CAE
+    (common/model/Cae3D.py) are parallel branches already; forking a side stream per branch inside a stream capture ends in a
+    segmentation fault of hipStreamEndCapture (ROCm 7.2; tools/dbg_cae_capture.py)."""
+
+    def __enter__(self):
+        _tls.suppress = getattr(_tls, "suppress", 0) + 1
+
+    def __exit__(self, *exc):
+        _tls.suppress -= 1
+        return False
+
+
 def overlap_level():
-    if _OV in ("0", ""):
+    if _OV in ("0", "") or getattr(_tls, "suppress", 0):
         return 0
     if not _OV_EAGER and not torch.cuda.is_current_stream_capturing():
         return 0
@@ -417,13 +434,14 @@ def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtyp
     sub = op.subs[0]
     M = batch * int(np.prod(sub.out_dims))
     need = 0 if f["pointwise"] else f["ntap"] * M * f["NT"] * 16
-    if need and (f["partial"] is None or f["partial"].numel() < need):
-        f["partial"] = torch.empty(need, dtype=torch.float32, device=runner.device)
+    part = getattr(runner, "_fc_partial", None)       # per runner (not in the shared bank): concurrent passes each need their own
+    if need and (part is None or part.numel() < need):
+        part = runner._fc_partial = torch.empty(need, dtype=torch.float32, device=runner.device)
     a = L.ConvFcArgs()
     a.x, a.y, a.wfrag = ptr(x), ptr(y), ptr(f["hi"])
     a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
     a.bias = ptr(runner.bias) if (runner.has_bias and use_bias) else None
-    a.stats, a.aux, a.partial, a.taps = ptr(stats), ptr(aux), (ptr(f["partial"]) if need else None), ptr(f["taps_d"])
+    a.stats, a.aux, a.partial, a.taps = ptr(stats), ptr(aux), (ptr(part) if need else None), ptr(f["taps_d"])
     a.B = batch
     a.Di, a.Hi, a.Wi = op.in_dims
     a.CPi = op.cpi
