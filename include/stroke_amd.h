@@ -484,6 +484,23 @@ int sp_adam_step_flat_dev(float* p, const float* g, float* m, float* v, int64_t 
 int sp_adam_step_flat_hyp(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper_dev,
                           const int32_t* step_dev, float grad_scale, sp_stream_t stream);
 
+/* ------------------------------------------------------------------ data-parallel gradient exchange (RCCL over xGMI)
+ * The reference has no distributed code; the path shards by batch and needs ONE collective per step, the sum of the flat
+ * fp32 gradient buffer over the replicas (learner/Learner.py:120-122 per replica).  comm is an ncclComm_t of
+ * the process's librccl (resolved at run time: these entry points fail with SP_EHIP where RCCL is absent, the rest of the
+ * library does not depend on it).  Host side: rank 0 calls sp_comm_unique_id, ships the 128 bytes to the other ranks (any
+ * side channel: torch.distributed's store, MPI, a file), every rank calls sp_comm_init_rank with its device current.
+ * Every collective is enqueued on the caller's stream and returns. */
+int sp_comm_available(void);                                   /* 1 when librccl and its symbols were found */
+int sp_comm_unique_id(void* id128);                            /* ncclGetUniqueId -> 128 bytes */
+int sp_comm_init_rank(void** comm, int32_t nranks, const void* id128, int32_t rank);
+int sp_comm_destroy(void* comm);
+int sp_allreduce_flat(void* comm, float* buf, int64_t n, sp_stream_t stream);        /* buf = sum over ranks, in place */
+/* two-shot form for the xGMI full mesh: buf holds nranks chunks of `chunk` floats; after the reduce-scatter chunk `rank` of
+ * this rank's buf is the sum; the all-gather then fills the other chunks */
+int sp_reduce_scatter_flat(void* comm, float* buf, int64_t chunk, int32_t rank, sp_stream_t stream);
+int sp_allgather_flat(void* comm, float* buf, int64_t chunk, int32_t rank, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ input pipeline (SURVEY.md 8 "next" row N4)
  * ElasticDeform.elastic_transform (common/data.py:326-339) on the device.  Volumes are C-ordered (n0, n1, n2) fp32
  * arrays, the reference's (x, y, z) numpy layout.

@@ -18,8 +18,59 @@ import torch
 import torch.distributed as dist
 
 
+class DirectComm:
+    """An RCCL communicator of this process created through the C ABI (``sp_comm_*`` / ``sp_allreduce_flat``,
+    include/stroke_amd.h) instead of torch.distributed's: the 128-byte unique id travels over the existing process group
+    (any backend), the collectives run on a stream of ours -- forked from the launching stream and joined before the
+    optimiser -- so they can sit inside a captured step as a parallel graph branch.  ``two_shot``: reduce-scatter +
+    all-gather over a padded copy-free view (every xGMI link carries 1/world of the buffer at once) instead of one
+    all-reduce.  UNMEASURED on more than one GPU (this build's boxes have one): opt-in, ``DataParallelSync(direct=True)`` or
+    SP_DIST_DIRECT=1."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from stroke_prediction_amd.runtime import lib as L
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.call("sp_comm_unique_id", uid)
+        if self.world > 1:
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = C.create_string_buffer(box[0], 128)
+        self._comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.call("sp_comm_init_rank", C.byref(self._comm), self.world, uid, self.rank)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self._L = L
+
+    def all_reduce_async(self, t, two_shot=False):
+        """sum of the fp32 tensor t over the ranks, in place, on the communicator's stream (ordered after everything enqueued
+        on the current stream so far); ``wait`` makes the current stream wait for it"""
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        n = t.numel()
+        if two_shot and self.world > 1 and n % self.world == 0:
+            chunk = n // self.world
+            self._L.call("sp_reduce_scatter_flat", self._comm, t.data_ptr(), chunk, self.rank, self.stream.cuda_stream)
+            self._L.call("sp_allgather_flat", self._comm, t.data_ptr(), chunk, self.rank, self.stream.cuda_stream)
+        else:
+            self._L.call("sp_allreduce_flat", self._comm, t.data_ptr(), n, self.stream.cuda_stream)
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def close(self):
+        if self._comm:
+            torch.cuda.synchronize(self.device)
+            self._L.call("sp_comm_destroy", self._comm)
+            self._comm = None
+
+
 class DataParallelSync:
-    def __init__(self, model, process_group=None, mode="fast", optimizer=None, bucketed=True):
+    def __init__(self, model, process_group=None, mode="fast", optimizer=None, bucketed=True, direct=None):
         """optimizer: optional -- a ``step`` pre-hook is registered that exchanges whatever part of the gradient has not
         been exchanged yet (models whose backward is several autograd nodes, the CAE, finish their exchange there at
         the latest).  bucketed=False: ONE blocking all-reduce at the end of backward (round-1 behaviour)."""
@@ -31,6 +82,11 @@ class DataParallelSync:
         self._works = []
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.nbuckets_last = 0
+        if direct is None:
+            direct = bool(os.environ.get("SP_DIST_DIRECT"))
+        # direct: the gradient exchange goes through sp_allreduce_flat on a communicator of our own (DirectComm)
+        self.direct = DirectComm(process_group) if (direct and dist.is_initialized() and torch.cuda.is_available()
+                                                    and dist.get_backend(process_group) != "gloo") else None
         # SP_FORCE_SYNC: install the exchange even on a 1-rank group (rehearses RCCL + hipGraph capture on one GPU)
         if self.world > 1 or (dist.is_initialized() and os.environ.get("SP_FORCE_SYNC")):
             model.grad_sync = self._sync
@@ -43,6 +99,9 @@ class DataParallelSync:
                 optimizer.register_step_pre_hook(lambda *a, **k: self.sync())
 
     def close(self):
+        if self.direct is not None:
+            self.direct.close()
+            self.direct = None
         from stroke_prediction_amd.runtime import layers
         layers.SYNC.update(group=None, world=1, on=False)
         self.model.grad_sync = None
@@ -69,11 +128,21 @@ class DataParallelSync:
     # behind an event of the current stream, so a bucket's ring runs over xGMI while the compute stream goes on with
     # the remaining data / weight gradients; ``Work.wait()`` makes the compute stream (Adam) wait for it.
     def _bucket(self, flat_grad, lo, hi):
+        if self.direct is not None:
+            self.direct.all_reduce_async(flat_grad[lo:hi])
+            self._works.append(None)
+            return
         self._works.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _sync(self, flat_grad, lo=0, hi=None):
         hi = flat_grad.numel() if hi is None else hi
         self.nbuckets_last = len(self._works) + (1 if hi > lo else 0)
+        if self.direct is not None:
+            if hi > lo:
+                self.direct.all_reduce_async(flat_grad[lo:hi])
+            self.direct.wait()
+            self._works = []
+            return
         if hi > lo:
             dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         for w in self._works:

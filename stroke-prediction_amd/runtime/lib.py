@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_plan.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_plan.hip", "sp_comm.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1
@@ -64,6 +64,13 @@ _SIGS = {
     "sp_conv3d_set_weights": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp, vp, vp, vp, vp], i32),
     "sp_conv3d_run": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp, vp, i32, i32, f32, vp, i32, i64, vp], i32),
     "sp_version": ([], i32),
+    "sp_comm_available": ([], i32),
+    "sp_comm_unique_id": ([vp], i32),
+    "sp_comm_init_rank": ([C.POINTER(vp), i32, vp, i32], i32),
+    "sp_comm_destroy": ([vp], i32),
+    "sp_allreduce_flat": ([vp, vp, i64, vp], i32),
+    "sp_reduce_scatter_flat": ([vp, vp, i64, i32, vp], i32),
+    "sp_allgather_flat": ([vp, vp, i64, i32, vp], i32),
     "sp_surface_distances": ([vp, vp, f32, i32, vp, vp, vp, vp], i32),
     "sp_gaussian_filter3d": ([vp, vp, vp, i32, i32, i32, f32, f32, vp], i32),
     "sp_map_coordinates_linear": ([vp, vp, vp, vp, f32, f32, f32, f32, vp, i32, i32, i32, vp], i32),
@@ -198,7 +205,7 @@ def build(verbose=False):
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs, check=True)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"], check=True)
     global _lib
     _lib = None
     return LIB_PATH
