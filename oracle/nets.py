@@ -33,6 +33,22 @@ def round_bf16(t):
     return _RoundBf16.apply(t)
 
 
+class _RoundF16(torch.autograd.Function):
+    """Round to IEEE-half storage precision in the forward, identity in the backward (the "f16" mode of the HIP path)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.half().to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def round_f16(t):
+    return _RoundF16.apply(t)
+
+
 def _ident(t):
     return t
 

@@ -48,7 +48,8 @@ class _UnetFn(torch.autograd.Function):
     def forward(ctx, model, images, *params):
         engine = model._engine(images)
         model._begin_step()
-        seg = engine.forward(images, model._param_dict(), model._buffer_dict(), model.training)
+        with _L.use(engine.variant):
+            seg = engine.forward(images, model._param_dict(), model._buffer_dict(), model.training)
         ctx.model, ctx.engine = model, engine
         ctx.generation, ctx.training = engine.generation, model.training
         ctx.save_for_backward(seg)
@@ -68,7 +69,8 @@ class _UnetFn(torch.autograd.Function):
             raise RuntimeError("Unet3D.backward after an eval-mode forward is not supported: the fused backward uses the "
                                "batch-statistics BatchNorm formula; call model.train() for passes that need gradients")
         names, views, inplace = model._grad_targets()
-        engine.backward(dseg, seg, model._param_dict(), dict(zip(names, views)), ready=model._grads_ready_from)
+        with _L.use(engine.variant):
+            engine.backward(dseg, seg, model._param_dict(), dict(zip(names, views)), ready=model._grads_ready_from)
         model._after_backward()
         return (None, None) + tuple(None if inplace else v for v in views)
 
@@ -87,7 +89,8 @@ class Unet3D(FlatParamsMixin, nn.Module):
         self.channel_dim = channel_dim
         self.channels_crop = channels_crop
         self.compute_dtype = dtype           # "bf16" (fast) | "f32" (split-bf16 x3 MFMA, parity mode) | "fp8" (bf16 storage,
-                                             # e4m3 / e5m2 MFMA operands where the fp8 kernel applies: runtime/f8.py)
+                                             # e4m3 / e5m2 MFMA operands where the fp8 kernel applies: runtime/f8.py) | "f16"
+                                             # (IEEE-half storage: libstroke_amd_f16.so, 3 more mantissa bits at the bf16 speed)
         n_in, widths, ch_bC, n_classes = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
         for i in range(1, S + 1):            # down path: block_i(b_{i-1} -> b_i)
             setattr(self, "block%d" % i, Block3x3x3(n_in if i == 1 else widths[i - 2], widths[i - 1]))
@@ -119,8 +122,10 @@ class Unet3D(FlatParamsMixin, nn.Module):
         if eng is None:
             if len(self._engines) >= 4:
                 self._engines.clear()
-            eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device,
-                             f8=(self.compute_dtype == "fp8"))
+            variant = _L.VARIANT_OF[self.compute_dtype]
+            with _L.use(variant):
+                eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device,
+                                 f8=(self.compute_dtype == "fp8"), variant=variant)
             self._engines[key] = eng
         return eng
 
@@ -132,7 +137,9 @@ class Unet3D(FlatParamsMixin, nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             segmentation = _UnetFn.apply(self, images, *params)
         else:
-            segmentation = self._engine(images).forward(images, self._param_dict(), self._buffer_dict(), self.training)
+            eng = self._engine(images)
+            with _L.use(eng.variant):
+                segmentation = eng.forward(images, self._param_dict(), self._buffer_dict(), self.training)
         dto.outputs.core = segmentation[:, 0, :, :, :].unsqueeze(1)
         dto.outputs.penu = segmentation[:, 1, :, :, :].unsqueeze(1)
         return dto

@@ -43,18 +43,65 @@ void sp_set_error(const char* fmt, ...);
     }                                                                                                              \
   } while (0)
 
-// ---- bf16 conversion ------------------------------------------------------------------------
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// ---- the 16-bit storage type ------------------------------------------------------------------
+// bf16 (8 exponent / 7 mantissa bits) in libstroke_amd.so.  The SAME sources built with -DSP_HALF_F16 give
+// libstroke_amd_f16.so, the "f16" precision mode: IEEE half (5 / 10 bits) -- three more mantissa bits at the same MFMA rate
+// (v_mfma_f32_16x16x32_f16) and the same bytes; the range is what BatchNorm-ed activations need, and the engine scales the
+// output gradients by a power of two (runtime/unet_engine.py) because 1e-7-sized gradients are below half's subnormals.
+// Everything that depends on the format is in this block; the kernels keep the name bf16_t for "16-bit storage word".
+#ifdef SP_HALF_F16
+typedef _Float16 sp_h16;
+#else
+typedef __bf16 sp_h16;
+#endif
+typedef sp_h16 sp_h16x8 __attribute__((ext_vector_type(8)));
+typedef sp_h16 sp_h16x4 __attribute__((ext_vector_type(4)));
+typedef sp_h16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+// D = A B + C on 16-bit operands (any 16-byte / 8-byte vector types holding the storage words); the three modifier arguments
+// of the builtin are always 0 here
+template <typename A, typename B>
+__device__ __forceinline__ f32x4 SP_MFMA16(A a, B b, f32x4 c, int = 0, int = 0, int = 0) {
+#ifdef SP_HALF_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sp_h16x8, a), __builtin_bit_cast(sp_h16x8, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sp_h16x8, a), __builtin_bit_cast(sp_h16x8, b), c, 0, 0, 0);
+#endif
+}
+template <typename A, typename B>
+__device__ __forceinline__ f32x4 SP_MFMA16_K16(A a, B b, f32x4 c, int = 0, int = 0, int = 0) {
+#ifdef SP_HALF_F16
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(sp_h16x4, a), __builtin_bit_cast(sp_h16x4, b), c, 0, 0, 0);
+#else
+  typedef short sp_s16x4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(sp_s16x4, a), __builtin_bit_cast(sp_s16x4, b), c, 0, 0, 0);
+#endif
+}
 
-// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)__builtin_bit_cast(sp_h16, h); }
+// the low / high half of a dword holding two storage words
+__device__ __forceinline__ float sp_h2f_lo(uint32_t w) {
+#ifdef SP_HALF_F16
+  return bf2f((bf16_t)(w & 0xffffu));
+#else
+  return __uint_as_float(w << 16);
+#endif
+}
+__device__ __forceinline__ float sp_h2f_hi(uint32_t w) {
+#ifdef SP_HALF_F16
+  return bf2f((bf16_t)(w >> 16));
+#else
+  return __uint_as_float(w & 0xffff0000u);
+#endif
+}
+
+// round-to-nearest-even; NaN stays NaN (plain cast lowers to v_cvt_pk_bf16_f32 / v_cvt_f16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f2bf(float f) {
-  __bf16 b = (__bf16)f;
+  sp_h16 b = (sp_h16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
 
-// two floats -> one dword holding two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32.  Converting element by element
-// and packing by hand costs a conversion, a shift and an or per element (found in the ISA of every bf16 epilogue).
-typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
+// two floats -> one dword holding two storage words (round to nearest even): ONE v_cvt_pk_bf16_f32.  Converting element by
+// element and packing by hand costs a conversion, a shift and an or per element (found in the ISA of every bf16 epilogue).
 __device__ __forceinline__ uint32_t sp_pack_bf16x2(float lo, float hi) {
   const f32x2 f = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, sp_bf16x2));
@@ -71,8 +118,8 @@ template <> struct Store<bf16_t> {
     uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      v[2 * i] = __uint_as_float(w[i] << 16);
-      v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+      v[2 * i] = sp_h2f_lo(w[i]);
+      v[2 * i + 1] = sp_h2f_hi(w[i]);
     }
   }
   static __device__ __forceinline__ void st8(bf16_t* p, const float* v) {
@@ -88,8 +135,8 @@ template <> struct Store<bf16_t> {
   }
   static __device__ __forceinline__ void ld4(const bf16_t* p, float* v) {
     uint2 r = *reinterpret_cast<const uint2*>(p);
-    v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
-    v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    v[0] = sp_h2f_lo(r.x); v[1] = sp_h2f_hi(r.x);
+    v[2] = sp_h2f_lo(r.y); v[3] = sp_h2f_hi(r.y);
   }
 };
 template <> struct Store<float> {
@@ -124,7 +171,7 @@ struct SpQ8 {
 __device__ __forceinline__ uint32_t sp_q8_pack4(const float* v, float s, int fmt) {
   float a[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) a[j] = __uint_as_float(((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)v[j])) << 16) * s;   // the stored (bf16) value
+  for (int j = 0; j < 4; ++j) a[j] = bf2f(f2bf(v[j])) * s;   // the stored (16-bit) value
   int r;
   if (fmt) {
     r = __builtin_amdgcn_cvt_pk_bf8_f32(__builtin_amdgcn_fmed3f(a[0], -57344.f, 57344.f), __builtin_amdgcn_fmed3f(a[1], -57344.f, 57344.f), 0, false);

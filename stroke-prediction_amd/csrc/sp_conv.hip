@@ -27,7 +27,7 @@ template <> struct RawChunk<bf16_t> {
   __device__ __forceinline__ void unpack(float* v) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { v[2 * i] = sp_h2f_lo(w[i]); v[2 * i + 1] = sp_h2f_hi(w[i]); }
   }
 };
 template <> struct RawChunk<float> {
@@ -181,8 +181,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
             uint32_t wl[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float r0 = v[2 * j] - __uint_as_float(w[j] << 16);
-              const float r1 = v[2 * j + 1] - __uint_as_float(w[j] & 0xffff0000u);
+              const float r0 = v[2 * j] - sp_h2f_lo(w[j]);
+              const float r1 = v[2 * j + 1] - sp_h2f_hi(w[j]);
               wl[j] = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
             }
             *reinterpret_cast<uint4*>(dst + a.lo_offset) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
@@ -220,7 +220,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
     bf16x8 xb[MT];                                                                                    \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) xb[m] = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + koff); \
     _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                    \
-        _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[n], xb[m], acc[n][m], 0, 0, 0); }
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = SP_MFMA16(wv[n], xb[m], acc[n][m], 0, 0, 0); }
       SP_LDW(w1, 1)
       SP_LDW(w2, 2)
       for (int s = 0; s < nst; s += 4) {
@@ -257,10 +257,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
       for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n], xb[m], acc[n][m], 0, 0, 0);
+          acc[n][m] = SP_MFMA16(wa[n], xb[m], acc[n][m], 0, 0, 0);
           if (NP == 2) {
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[n], xl[m], acc[n][m], 0, 0, 0);
-            acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[n], xb[m], acc[n][m], 0, 0, 0);
+            acc[n][m] = SP_MFMA16(wa[n], xl[m], acc[n][m], 0, 0, 0);
+            acc[n][m] = SP_MFMA16(wl[n], xb[m], acc[n][m], 0, 0, 0);
           }
         }
       }

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
   _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + (koff_));
 #define SP_MMA(wv, xv)                                                                                \
   _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                      \
-      _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[n], xv[m], acc[n][m], 0, 0, 0);
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = SP_MFMA16(wv[n], xv[m], acc[n][m], 0, 0, 0);
     {
       const int k0 = ktab_l[lg];
       SP_LDX(x0, k0)
@@ -464,10 +464,10 @@ __global__ __launch_bounds__(256) void conv_igemm_persist_kernel(const ConvDmaDe
       }
       if ((s & 1) == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x0[m], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[m] = SP_MFMA16(wreg[s], x0[m], acc[m], 0, 0, 0);
       } else {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], x1[m], acc[m], 0, 0, 0);
+        for (int m = 0; m < MT; ++m) acc[m] = SP_MFMA16(wreg[s], x1[m], acc[m], 0, 0, 0);
       }
     }
     // ---- epilogue ------------------------------------------------------------------------------------------------
@@ -665,12 +665,12 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void conv_igemm_zs_kernel(c
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s][n], x0[m], acc[n][m], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n][m] = SP_MFMA16(wreg[s][n], x0[m], acc[n][m], 0, 0, 0);
         } else {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < NT; ++n) acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s][n], x1[m], acc[n][m], 0, 0, 0);
+            for (int n = 0; n < NT; ++n) acc[n][m] = SP_MFMA16(wreg[s][n], x1[m], acc[n][m], 0, 0, 0);
         }
       }
 #undef ZS_OFF
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zr_kernel(const ConvZsDev P
 #pragma unroll
           for (int dy = 0; dy < 3; ++dy) {
             const int m = r - dy;                             // output row served through tap row dy
-            if (m >= 0 && m < MT) acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[dy * NTY + t][0], xr[r & 1][t], acc[0][m], 0, 0, 0);
+            if (m >= 0 && m < MT) acc[0][m] = SP_MFMA16(wreg[dy * NTY + t][0], xr[r & 1][t], acc[0][m], 0, 0, 0);
           }
         }
       }

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_fc_partial_kernel(const ConvFcDev P)
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+              const float lo = sp_h2f_lo(w[j]), hi = sp_h2f_hi(w[j]);
               o[j] = sp_pack_bf16x2(fmaf(lo, sc[2 * j], sh[2 * j]), fmaf(hi, sc[2 * j + 1], sh[2 * j + 1]));
             }
             raw = make_uint4(o[0], o[1], o[2], o[3]);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_fc_partial_kernel(const ConvFcDev P)
           const bf16x8 bfr = __builtin_bit_cast(bf16x8, raw);
 #pragma unroll
           for (int n = 0; n < FC_NTB; ++n)
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[u][n]), bfr, acc[n], 0, 0, 0);
+            acc[n] = SP_MFMA16(__builtin_bit_cast(bf16x8, aq[u][n]), bfr, acc[n], 0, 0, 0);
           fetch(min(s + FC_PD, P.spt - 1), u);
         }
       }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
           uint32_t o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xffff0000u);
+            const float lo = sp_h2f_lo(w[j]), hi = sp_h2f_hi(w[j]);
             o[j] = sp_pack_bf16x2(fmaf(lo, sc[s][2 * j], sh[s][2 * j]), fmaf(hi, sc[s][2 * j + 1], sh[s][2 * j + 1]));
           }
           r4 = make_uint4(o[0], o[1], o[2], o[3]);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
         const bf16x8 bfr = __builtin_bit_cast(bf16x8, r4);
 #pragma unroll
         for (int n = 0; n < NTB; ++n)
-          acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, aq[s][n]), bfr, acc[n], 0, 0, 0);
+          acc[n] = SP_MFMA16(__builtin_bit_cast(bf16x8, aq[s][n]), bfr, acc[n], 0, 0, 0);
       }
       // D[cout = 4 g + j][voxel = vl]
       if (m < P.M) {

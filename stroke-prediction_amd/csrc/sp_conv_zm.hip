@@ -62,7 +62,7 @@ typedef unsigned int zm_u32x4 __attribute__((ext_vector_type(4)));
 // hardware, so rows / columns / planes outside the output need no branch (branches would cut the epilogue out of the
 // basic block whose MFMAs it is meant to issue between)
 template <typename T> struct ZmStore;
-typedef __bf16 zm_bf16x2 __attribute__((ext_vector_type(2)));
+typedef sp_h16 zm_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float zm_f32x2 __attribute__((ext_vector_type(2)));
 // two floats -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32; element-wise casts packed by hand
 // cost a conversion, a shift and an or per element
@@ -286,12 +286,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #define ZM_MMA(R_, DZ_, s_, xv, wv)                                                                               \
   _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                  \
       _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
-          acc[R_][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ZM_W(DZ_, s_, n, wv), xv[m], acc[R_][n][m], 0, 0, 0);
+          acc[R_][n][m] = SP_MFMA16(ZM_W(DZ_, s_, n, wv), xv[m], acc[R_][n][m], 0, 0, 0);
     // first contribution to a new output plane: C = 0
 #define ZM_MMA0(R_, DZ_, s_, xv, wv)                                                                              \
   _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                  \
       _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
-          acc[R_][n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ZM_W(DZ_, s_, n, wv), xv[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc[R_][n][m] = SP_MFMA16(ZM_W(DZ_, s_, n, wv), xv[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #define ZM_MMA_D0(R_, s_, xv, wv) if ((s_) == 0) { ZM_MMA0(R_, 0, s_, xv, wv) } else { ZM_MMA(R_, 0, s_, xv, wv) }
     // One step = one input plane i (phase PH = i mod 4, compile time): taps dz = 0 / 1 / 2 add into the sets PH, PH+3, PH+2
     // (mod 4) of the output planes i, i-1, i-2; set PH+1 holds plane i-3, whose epilogue is issued between this step's MFMAs.

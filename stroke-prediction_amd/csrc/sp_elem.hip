@@ -573,7 +573,7 @@ template <> struct RawOct<bf16_t> {
   __device__ __forceinline__ void get(float* v) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(w[i] << 16); v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u); }
+    for (int i = 0; i < 4; ++i) { v[2 * i] = sp_h2f_lo(w[i]); v[2 * i + 1] = sp_h2f_hi(w[i]); }
   }
 };
 template <> struct RawOct<float> {
@@ -594,7 +594,7 @@ __device__ __forceinline__ f2_t f2_splat(float v) { f2_t r = {v, v}; return r; }
 __device__ __forceinline__ void raw_get2(const RawOct<bf16_t>& r, f2_t* v) {
   const uint32_t w[4] = {r.r.x, r.r.y, r.r.z, r.r.w};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { f2_t t = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)}; v[i] = t; }
+  for (int i = 0; i < 4; ++i) { f2_t t = {sp_h2f_lo(w[i]), sp_h2f_hi(w[i])}; v[i] = t; }
 }
 __device__ __forceinline__ void raw_get2(const RawOct<float>& r, f2_t* v) {
 #pragma unroll
@@ -612,7 +612,7 @@ __device__ __forceinline__ void st8_f2(float* p, const f2_t* v) {
 }
 __device__ __forceinline__ f2_t round_like(const bf16_t*, f2_t v) {      // one packed conversion, two bit operations
   const uint32_t u = sp_pack_bf16x2(v.x, v.y);
-  f2_t r = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+  f2_t r = {sp_h2f_lo(u), sp_h2f_hi(u)};
   return r;
 }
 // store eight values and return them as stored (what the statistics must see): bf16 converts each pair ONCE
@@ -621,7 +621,7 @@ __device__ __forceinline__ void st8_f2_rounded(bf16_t* p, f2_t* v) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     w[i] = sp_pack_bf16x2(v[i].x, v[i].y);
-    f2_t r = {__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)};
+    f2_t r = {sp_h2f_lo(w[i]), sp_h2f_hi(w[i])};
     v[i] = r;
   }
   *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);

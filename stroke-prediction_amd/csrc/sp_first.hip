@@ -62,7 +62,7 @@ __device__ __forceinline__ void first_stage_x(const FirstDev& P, int b, int oz0,
 __device__ __forceinline__ void raw8_to_f32(const uint4& r, float (&f)[8]) {
   const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(w[j] << 16); f[2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u); }
+  for (int j = 0; j < 4; ++j) { f[2 * j] = sp_h2f_lo(w[j]); f[2 * j + 1] = sp_h2f_hi(w[j]); }
 }
 constexpr int FT_XIT = (FT_ROWS * FT_XP + 255) / 256;      // elements per thread
 __device__ __forceinline__ void first_load_x(const FirstDev& P, int b, int oz0, int oy0, int ox0, float (&r)[FT_XIT][2]) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
           const uint32_t* p = xt + goff[s] + rbase + t * 16;
           union { uint32_t u[4]; bf16x8 v; } bq;
           bq.u[0] = p[0]; bq.u[1] = p[1]; bq.u[2] = p[2]; bq.u[3] = p[3];
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s], bq.v, acc, 0, 0, 0);
+          acc = SP_MFMA16(af[s], bq.v, acc, 0, 0, 0);
         }
         const int ox = ox0 + t * 16 + n;
         float v[4];
@@ -423,9 +423,9 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
           b1.u[0] = __builtin_amdgcn_alignbit(q.y, q.x, 16); b1.u[1] = __builtin_amdgcn_alignbit(q.z, q.y, 16);
           b1.u[2] = __builtin_amdgcn_alignbit(q.w, q.z, 16); b1.u[3] = __builtin_amdgcn_alignbit(q4, q.w, 16);
           b2.u[0] = q.y; b2.u[1] = q.z; b2.u[2] = q.w; b2.u[3] = q4;
-          acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b0.v, acc[0][c], 0, 0, 0);
-          acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b1.v, acc[1][c], 0, 0, 0);
-          acc[2][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, b2.v, acc[2][c], 0, 0, 0);
+          acc[0][c] = SP_MFMA16(af, b0.v, acc[0][c], 0, 0, 0);
+          acc[1][c] = SP_MFMA16(af, b1.v, acc[1][c], 0, 0, 0);
+          acc[2][c] = SP_MFMA16(af, b2.v, acc[2][c], 0, 0, 0);
         }
       }
     }

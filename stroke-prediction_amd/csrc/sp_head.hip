@@ -187,12 +187,12 @@ template <int NP> struct HeadK;      // second-stage operand: 8 (CH = 32) or 4 (
 template <> struct HeadK<2> {
   typedef bf16x8 vec;
   static __device__ __forceinline__ int k_of(int lg, int e) { return e < 4 ? 4 * lg + e : 16 + 4 * lg + (e - 4); }
-  static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) { return SP_MFMA16(a, b, c, 0, 0, 0); }
 };
 template <> struct HeadK<1> {
   typedef hd_bf16x4 vec;
   static __device__ __forceinline__ int k_of(int lg, int e) { return 4 * lg + e; }
-  static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ f32x4 mma(vec a, vec b, f32x4 c) { return SP_MFMA16_K16(a, b, c, 0, 0, 0); }
 };
 __device__ __forceinline__ void hd_split(float w, short& hi, short& lo) {
   const bf16_t h = f2bf(w);
@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const bf16_t* __rest
 #pragma unroll
       for (int t = 0; t < NP; ++t) {
         f32x4 hp = {b1k[t][0], b1k[t][1], b1k[t][2], b1k[t][3]};
-        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1h[t], xb, hp, 0, 0, 0);
-        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1l[t], xb, hp, 0, 0, 0);
+        hp = SP_MFMA16_K16(a1h[t], xb, hp, 0, 0, 0);
+        hp = SP_MFMA16_K16(a1l[t], xb, hp, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) hb[4 * t + j] = (short)f2bf(fmaxf(hp[j], slope * hp[j]));
       }
@@ -343,8 +343,8 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
       for (int t = 0; t < NP; ++t) {
         f32x4 hp = {b1k[t][0], b1k[t][1], b1k[t][2], b1k[t][3]};
-        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1h[t], xb, hp, 0, 0, 0);
-        hp = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a1l[t], xb, hp, 0, 0, 0);
+        hp = SP_MFMA16_K16(a1h[t], xb, hp, 0, 0, 0);
+        hp = SP_MFMA16_K16(a1l[t], xb, hp, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float dh = 0.f;
@@ -408,9 +408,9 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
       for (int p = 0; p < NP; ++p) {
         const bf16x8 fd = hd_tr_read2(tD + p * PLANE + ko + off0, tD + p * PLANE + ko + off1);
         const bf16x8 fh = hd_tr_read2(tH + p * PLANE + ko + off0, tH + p * PLANE + ko + off1);
-        accW1[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd, fx, accW1[p], 0, 0, 0);
-        accW2[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fh, accW2[p], 0, 0, 0);
-        accB1[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fd, accB1[p], 0, 0, 0);
+        accW1[p] = SP_MFMA16(fd, fx, accW1[p], 0, 0, 0);
+        accW2[p] = SP_MFMA16(fa, fh, accW2[p], 0, 0, 0);
+        accB1[p] = SP_MFMA16(fa, fd, accB1[p], 0, 0, 0);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -43,8 +43,8 @@ __device__ __forceinline__ void put_chunk(unsigned char* dst, int lo_off, const 
     uint32_t wl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float r0 = v[2 * j] - __uint_as_float(w[j] << 16);
-      const float r1 = v[2 * j + 1] - __uint_as_float(w[j] & 0xffff0000u);
+      const float r0 = v[2 * j] - sp_h2f_lo(w[j]);
+      const float r1 = v[2 * j + 1] - sp_h2f_hi(w[j]);
       wl[j] = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
     }
     *reinterpret_cast<uint4*>(dst + lo_off) = make_uint4(wl[0], wl[1], wl[2], wl[3]);
@@ -174,10 +174,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradDev P) {
             if (NP == 2) bfl = tr_read2(base + P.lo_off + b_off0, base + P.lo_off + b_off1);
 #pragma unroll
             for (int c = 0; c < COB; ++c) {
-              acc[tt][c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[tt][c][i], 0, 0, 0);
+              acc[tt][c][i] = SP_MFMA16(af[c], bf, acc[tt][c][i], 0, 0, 0);
               if (NP == 2) {
-                acc[tt][c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bfl, acc[tt][c][i], 0, 0, 0);
-                acc[tt][c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afl[c], bf, acc[tt][c][i], 0, 0, 0);
+                acc[tt][c][i] = SP_MFMA16(af[c], bfl, acc[tt][c][i], 0, 0, 0);
+                acc[tt][c][i] = SP_MFMA16(afl[c], bf, acc[tt][c][i], 0, 0, 0);
               }
             }
           }

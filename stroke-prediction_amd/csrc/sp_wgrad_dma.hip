@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
           const bf16x8 bf = wd_tr_read2(bp + off0, bp + off1);
 #pragma unroll
           for (int c = 0; c < COB; ++c)
-            acc[tt][c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[tt][c][i], 0, 0, 0);
+            acc[tt][c][i] = SP_MFMA16(af[c], bf, acc[tt][c][i], 0, 0, 0);
         }
       }
     }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_zs_kernel(const WgradZsDev P) {
           const unsigned char* bp = brow + tb[tt];
           const bf16x8 bf = wd_tr_read2(bp + off0, bp + off1);
 #pragma unroll
-          for (int c = 0; c < COB; ++c) acc[tt][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf, acc[tt][c], 0, 0, 0);
+          for (int c = 0; c < COB; ++c) acc[tt][c] = SP_MFMA16(af[c], bf, acc[tt][c], 0, 0, 0);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void wgrad_pw_kernel(const WgradPwDev P) {
 #pragma unroll
     for (int c = 0; c < COT; ++c)
 #pragma unroll
-      for (int i = 0; i < CIT; ++i) acc[c][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[c], bf[i], acc[c][i], 0, 0, 0);
+      for (int i = 0; i < CIT; ++i) acc[c][i] = SP_MFMA16(af[c], bf[i], acc[c][i], 0, 0, 0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the reads of this buffer are done before it is refilled
     buf ^= 1;
   }

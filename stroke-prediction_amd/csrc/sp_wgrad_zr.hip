@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
             for (int dzz = 0; dzz < 3; ++dzz)
 #pragma unroll
               for (int dx = 0; dx < 3; ++dx)
-                acc[dzz][dy][dx] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[dzz][yl], bq[yi][dx], acc[dzz][dy][dx], 0, 0, 0);
+                acc[dzz][dy][dx] = SP_MFMA16(A[dzz][yl], bq[yi][dx], acc[dzz][dy][dx], 0, 0, 0);
           }
         }
       }

@@ -16,7 +16,12 @@ SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip"
 
 SP_BF16, SP_F32 = 0, 1
 # precision modes of the models (``Unet3D(dtype=...)``, ``Enc3D(dtype=...)``) -> storage type of the engine's tensors
-DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16}    # fp8: bf16 storage + fp8 MFMA operands (runtime/f8.py)
+DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16, "f16": SP_BF16}
+#   fp8: bf16 storage + fp8 MFMA operands (runtime/f8.py); f16: IEEE-half storage -- the SAME sources built with
+#   -DSP_HALF_F16 into libstroke_amd_f16.so (csrc/sp_common.h), selected per engine with ``use("f16")``; the kernels'
+#   dtype code stays SP_BF16 = "the 16-bit storage type of this library"
+VARIANTS = {"": ("libstroke_amd.so", []), "f16": ("libstroke_amd_f16.so", ["-DSP_HALF_F16"])}
+VARIANT_OF = {"bf16": "", "f32": "", "fp8": "", "f16": "f16"}
 SP_REDUCE_ROWS = 8    # replica rows of the accumulators the elementwise kernels reduce into (include/stroke_amd.h)
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -135,11 +140,59 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["sp_last_error"])
 
 _lib = None
+_libs = {}
+import threading as _threading
+_tls = _threading.local()
 
 
-def load():
-    """Load the shared library once; raises if it has not been built."""
+def current_variant():
+    return getattr(_tls, "variant", "")
+
+
+class use:
+    """``with use("f16"):`` -- calls made by this thread inside the block go to that build of the library (an engine is bound
+    to one build: its tensors hold that build's 16-bit format)."""
+
+    def __init__(self, variant):
+        self.variant = variant or ""
+
+    def __enter__(self):
+        self.prev = current_variant()
+        _tls.variant = self.variant
+        return self
+
+    def __exit__(self, *exc):
+        _tls.variant = self.prev
+        return False
+
+
+def lib_path(variant=""):
+    if variant == "":
+        return LIB_PATH
+    return os.path.join(os.path.dirname(LIB_PATH), VARIANTS[variant][0])
+
+
+def load(variant=None):
+    """Load the shared library (of the calling thread's current build, or the named one) once; raises if it has not been built."""
     global _lib
+    variant = current_variant() if variant is None else variant
+    if variant:
+        if variant in _libs:
+            return _libs[variant]
+        path = lib_path(variant)
+        import torch  # noqa: F401
+        if not os.path.exists(path):
+            raise RuntimeError("stroke_prediction_amd: %s is missing -- build it with `python -c \"import __graft_entry__ as g; "
+                               "g.build()\"`. There is no CPU/PyTorch fallback." % path)
+        lib = C.CDLL(path)
+        for name, (argtypes, restype) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = restype
+        lib.sp_last_error.argtypes = [C.c_char_p, C.c_size_t]
+        lib.sp_last_error.restype = None
+        _libs[variant] = lib
+        return lib
     if _lib is not None:
         return _lib
     # torch bundles its own HIP runtime (libamdhip64): import it FIRST so that this library binds to the
@@ -180,32 +233,37 @@ def call(name, *args):
 
 
 def build(verbose=False):
-    """Compile the HIP sources for gfx950 into ``lib/libstroke_amd.so`` (cross-compiles without a GPU)."""
+    """Compile the HIP sources for gfx950 into ``lib/libstroke_amd.so`` and its precision variants (cross-compiles without a
+    GPU).  One object per source and build (rebuilt only when stale, all compiled concurrently), then one link per build."""
     import subprocess
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     srcs = [os.path.join(CSRC_DIR, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC_DIR, "sp_common.h"),
-                   os.path.join(os.path.dirname(PKG_DIR), "include", "stroke_amd.h")]
-    if os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    hdrs = [os.path.join(CSRC_DIR, "sp_common.h"), os.path.join(os.path.dirname(PKG_DIR), "include", "stroke_amd.h")]
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # one object per source (rebuilt only when stale, compiled concurrently), then one link
-    objdir = os.path.join(os.path.dirname(LIB_PATH), "obj")
-    os.makedirs(objdir, exist_ok=True)
-    hdrs = deps[len(srcs):]
-    jobs, objs = [], []
-    for src in srcs:
-        obj = os.path.join(objdir, os.path.basename(src) + ".o")
-        objs.append(obj)
-        if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            jobs.append((cmd, subprocess.Popen(cmd)))
+    jobs, links = [], []
+    for variant, (fname, flags) in VARIANTS.items():
+        out = lib_path(variant)
+        if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in srcs + hdrs):
+            continue
+        objdir = os.path.join(os.path.dirname(LIB_PATH), "obj" + ("_" + variant if variant else ""))
+        os.makedirs(objdir, exist_ok=True)
+        objs = []
+        for src in srcs:
+            obj = os.path.join(objdir, os.path.basename(src) + ".o")
+            objs.append(obj)
+            if not (os.path.exists(obj) and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in [src] + hdrs)):
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + flags + ["-c", src, "-o", obj]
+                if verbose:
+                    print(" ".join(cmd))
+                jobs.append((cmd, subprocess.Popen(cmd)))
+        links.append([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"])
     for cmd, pr in jobs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"], check=True)
+    for cmd in links:
+        subprocess.run(cmd, check=True)
     global _lib
-    _lib = None
+    if links:
+        _lib = None
+        _libs.clear()
     return LIB_PATH

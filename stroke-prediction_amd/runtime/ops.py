@@ -9,7 +9,17 @@ import torch
 from . import lib as L
 from . import plan as P
 
-TORCH_DT = {L.SP_BF16: torch.bfloat16, L.SP_F32: torch.float32}
+class _TorchDt:
+    """storage code -> torch dtype of the tensors this thread's current library build works on (lib.use): the 16-bit code is
+    bfloat16 in libstroke_amd.so and float16 in the "f16" build"""
+
+    def __getitem__(self, code):
+        if code == L.SP_F32:
+            return torch.float32
+        return torch.float16 if L.current_variant() == "f16" else torch.bfloat16
+
+
+TORCH_DT = _TorchDt()
 
 
 # bumped whenever parameters may have changed behind torch's back (FusedAdam's kernel writes raw pointers)

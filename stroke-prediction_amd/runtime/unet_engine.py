@@ -10,6 +10,7 @@ Data flow (channels-last tensors, BatchNorm folded into the consuming convolutio
 Batch statistics of every BatchNorm input are produced by the kernel that writes that tensor
 (conv / pool / upsample / crop epilogues); only the network input needs a stand-alone pass.
 """
+import math
 import os
 
 import torch
@@ -48,12 +49,14 @@ class UnetEngine:
     blocks S+1..2S-1 go up; up block u concatenates the upsampled output of block u-1 with the centre crop of down
     block 2S-u."""
 
-    def __init__(self, channels, batch, dims, dtype, device, f8=False):
+    def __init__(self, channels, batch, dims, dtype, device, f8=False, variant=""):
         """f8: the "fp8" precision mode -- storage stays bf16 (dtype), the 3x3x3 layers the fp8 kernel has an instance for
         run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py)."""
         O.require_gpu()
         L.load()
         assert not f8 or dtype == L.SP_BF16
+        self.variant = variant       # build of the library this engine's tensors belong to (lib.use): "" = bf16, "f16" = IEEE half
+        assert L.current_variant() == variant, "construct and run an engine inside lib.use(engine.variant)"
         assert len(channels) >= 8 and len(channels) % 2 == 0, "channels: n_in, 2S-1 block widths, head width, classes"
         S = self.scales = (len(channels) - 2) // 2
         n_in, bch, bc, ncls = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
@@ -135,6 +138,12 @@ class UnetEngine:
                                       and all(sb.tile["opp"] == 2 for sb in c.fwd_op.subs))
             c.x_planar = self.cat_planar[u]
         self.generation = 0         # bumped by every forward: a backward checks that its pass is still the resident one
+        # IEEE-half storage: output gradients of a mean-type loss over n voxels are ~1/n, below half's subnormals for the volumes
+        # this network sees -- the backward runs on S * gradients (S a power of two ~ n; everything in it is linear) into a
+        # private buffer, which is added to the parameter gradients as 1/S of itself
+        nvox_out = batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
+        self.loss_scale = float(2.0 ** math.ceil(math.log2(max(2, nvox_out)))) if variant == "f16" else 1.0
+        self._gpriv = None
         # ---- fp8 mode: which layers run on the fp8 kernel, and where each one's e4m3 input comes from
         self.f8 = bool(f8)
         self._f8_fused = set()
@@ -261,6 +270,31 @@ class UnetEngine:
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dseg, seg, params, grads, ready=None):
+        if self.loss_scale == 1.0:
+            return self._backward(dseg, seg, params, grads, ready)
+        S = self.loss_scale
+        names = list(grads)
+        n = sum(grads[k].numel() for k in names)
+        if self._gpriv is None or self._gpriv.numel() != n:
+            self._gpriv = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._gpriv.zero_()
+        priv, off = {}, 0
+        for k in names:
+            priv[k] = self._gpriv[off:off + grads[k].numel()].view(grads[k].shape)
+            off += grads[k].numel()
+        self._backward(dseg * S, seg, params, priv, None)
+        first = grads[names[0]]
+        flat_ok = all(grads[k].is_contiguous() for k in names) and \
+            all(grads[b].data_ptr() == grads[a].data_ptr() + 4 * grads[a].numel() for a, b in zip(names, names[1:]))
+        if flat_ok:      # the views of one flat buffer (runtime/flat.py): one add
+            torch.as_strided(first, (n,), (1,)).add_(self._gpriv, alpha=1.0 / S)
+        else:
+            for k in names:
+                grads[k].add_(priv[k], alpha=1.0 / S)
+        if ready is not None:
+            ready("block1.")         # every gradient is final only now: one exchange
+
+    def _backward(self, dseg, seg, params, grads, ready=None):
         """dseg: dL/dseg (NCDHW fp32).  Accumulates into ``grads[name]`` (fp32 tensors, parameter layout).
         Must follow a training-mode forward on the same engine (activations are kept in the layers).
         ready(prefix): called when every gradient from the first parameter named ``prefix*`` to the end of the flat
