@@ -153,7 +153,9 @@ def test_cae_concurrent_passes_equal_sequential_passes(dtype):
     # The same kernels on the same data.  Two SEQUENTIAL runs already differ by the run-to-run noise of the fp64 statistics
     # atomics (1e-7 relative in a BatchNorm scale; in bf16 that flips the rounding of isolated activations and spreads over the
     # 22 layers): the concurrent run must stay within three times that distance of the sequential one (floors: f32 / bf16).
-    fl = dict(f32=(2e-5, 2e-6, 2e-4), bf16=(5e-2, 3e-4, 5e-3))[dtype]      # (bf16: the maximum over 230 k voxels is a heavy tail)
+    # (bf16: two runs are sometimes bit-identical and sometimes 1e-3 apart on average -- a flipped rounding in the 200-value
+    # BatchNorm of the latent moves everything behind it; the floors are that spread, a race would show as garbage)
+    fl = dict(f32=(2e-5, 2e-6, 2e-4), bf16=(5e-2, 3e-3, 8e-2))[dtype]
     for k in a[0]:
         d, d0 = (a[0][k] - b[0][k]).abs(), (a[0][k] - a2[0][k]).abs()
         assert float(d.max()) <= 3 * float(d0.max()) + fl[0] and float(d.mean()) <= 3 * float(d0.mean()) + fl[1], \
