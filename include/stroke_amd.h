@@ -110,6 +110,9 @@ typedef struct sp_conv_args {
                                   times the reciprocal operand scale of a data gradient) */
   float y8_scale;              /* y8 = e4m3(y8_scale * y) */
   int32_t f8_bin;              /* B operand (x) format: 0 = e4m3 (forward), 1 = e5m2 (data gradient: x = quantised dz) */
+  /* ---- batched passes (sp_conv3d_igemm / _multi only; 0 elsewhere) */
+  int32_t group_batch;         /* > 0: samples [g*group_batch, (g+1)*group_batch) are BatchNorm group g: in_scale / in_shift of
+                                  the group at + g*CPi, its statistics rows at stats + g*stats_nrep*CPo*2 */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -357,6 +360,21 @@ int sp_bn_bwd_finalize(const double* sums /* [nrep][CP][2] */, int32_t nrep, dou
  * dbias_sums[c] += sum_voxels dz (fp64, may be NULL) */
 int sp_bn_act_bwd(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
                   int32_t act, float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
+
+/* The same three for G BatchNorm GROUPS in one launch -- the batched passes of the CAE (Cae3D.py:105-107 three encoder calls,
+ * :230-233 four decoder calls): the passes are stacked along the batch axis (samples [g*Bg, (g+1)*Bg) = pass g), every pass
+ * keeps its OWN batch statistics, and the running statistics take the G momentum updates in pass order.  sums
+ * [G][nrep][CP][2]; scale / shift of group g at scale + g*coef_stride (rows 0 / 2 of a [G][3][CP] table: coef_stride = 3*CP);
+ * mean / invstd [G][CP]; coef [G][3][CP].  sp_bn_act_bwd_groups: voxels [g*group_vox, (g+1)*group_vox) use coef + g*3*CP. */
+int sp_bn_finalize_groups(const double* sums, int32_t nrep, double count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps, int32_t training, int32_t C,
+                          int32_t CP, int32_t G, int32_t coef_stride, float* scale, float* shift, float* mean, float* invstd,
+                          sp_stream_t stream);
+int sp_bn_bwd_finalize_groups(const double* sums, int32_t nrep, double count, const float* gamma, const float* mean,
+                              const float* invstd, int32_t C, int32_t CP, int32_t G, float* dgamma, float* dbeta, float* coef,
+                              float param_grad_scale, sp_stream_t stream);
+int sp_bn_act_bwd_groups(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP, int32_t act,
+                         float act_param, void* dz, double* dbias_sums, int64_t group_vox, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ pooling / upsampling / skip (Unet3D.py:59-72)
  * MaxPool3d(2,2) floor mode; optional output statistics [CP][2] */

@@ -147,6 +147,51 @@ class _StackFn(torch.autograd.Function):
         return (None, None, dx) + tuple(None if inplace else v for v in views)
 
 
+# SP_CAE_BATCHED (default 1): the passes of one encoder / decoder call are stacked along the batch axis and run as ONE pass
+# through a grouped StackContext -- one launch per layer for the convolution, the weight gradient and the data gradient of all
+# passes, per-pass BatchNorm statistics, running statistics updated in pass order (runtime/layers.py, ConvLayer(groups=G)).
+# 0: every pass on its own (sequentially, or as parallel graph branches: SP_CAE_STREAMS).
+CAE_BATCHED = int(os.environ.get("SP_CAE_BATCHED", "1"))
+
+
+class _StackManyFn(torch.autograd.Function):
+    """All passes of one encoder / decoder call as one autograd node: forward(module, n, x_0 .. x_{n-1}, *params) -> n outputs."""
+
+    @staticmethod
+    def forward(ctx, module, n, *args):
+        xs, B = args[:n], args[0].shape[0]
+        key, sc = module._pool().acquire(n * B, tuple(xs[0].shape[2:]), module._dtype_code(), xs[0].device, groups=n)
+        x = torch.cat([t.float() for t in xs], 0)
+        out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training)
+        ctx.module, ctx.sc, ctx.n, ctx.B = module, sc, n, B
+        ctx.lease = _Lease(module._pool(), key, sc, module)
+        module._begin_step()
+        module._n_out = getattr(module, "_n_out", 0) + 1
+        ctx.training = module.training
+        ctx.need_dx = any(t.requires_grad for t in xs)
+        ctx.save_for_backward(out)
+        outs = tuple(out[i * B:(i + 1) * B] for i in range(n))
+        return outs
+
+    @staticmethod
+    def backward(ctx, *douts):
+        module, sc, n, B = ctx.module, ctx.sc, ctx.n, ctx.B
+        (out,) = ctx.saved_tensors
+        if not ctx.training:
+            raise RuntimeError("%s.backward after an eval-mode forward is not supported: the fused backward uses the "
+                               "batch-statistics BatchNorm formula; call model.train() for passes that need gradients"
+                               % type(module).__name__)
+        dout = torch.cat([torch.zeros_like(out[:B]) if d is None else d for d in douts], 0)
+        names, views, inplace = module._grad_targets()
+        dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
+        ctx.lease.release()
+        module._n_out = max(0, getattr(module, "_n_out", 1) - 1)
+        if module._n_out == 0:
+            module._stack_grads_final()
+        dxs = tuple(None for _ in range(n)) if dx is None else tuple(dx[i * B:(i + 1) * B] for i in range(n))
+        return (None, None) + dxs + tuple(None if inplace else v for v in views)
+
+
 class CaeBase(FlatParamsMixin, nn.Module):
     FLAT_NBT = True      # every BatchNorm of a stack runs once per stack call: their step counters advance together
 
@@ -205,6 +250,9 @@ class CaeBase(FlatParamsMixin, nn.Module):
         """The passes of one encoder / decoder call (``None`` entries stay ``None``): one after the other on the current
         stream, or -- see CAE_STREAMS -- each on its own stream with the outputs joined back before returning."""
         idx = [i for i, x in enumerate(xs) if x is not None]
+        if CAE_BATCHED and len(idx) > 1 and xs[idx[0]].is_cuda and next(self.parameters()).is_cuda and \
+                all(xs[i].shape == xs[idx[0]].shape and xs[i].device == xs[idx[0]].device for i in idx):
+            return self._run_stack_batched(xs, idx)
         if len(idx) <= 1 or not xs[idx[0]].is_cuda or CAE_STREAMS == 0:
             return [self._run_stack(x) for x in xs]
         # Pass k always runs in the contexts of lane k (their own packed weights and workspaces), whether or not the lanes run
@@ -246,6 +294,25 @@ class CaeBase(FlatParamsMixin, nn.Module):
                     main.wait_stream(_lane_stream(dev, lane))
                     if "norecord" not in _DBG:
                         outs[i].record_stream(main)
+        return outs
+
+    def _run_stack_batched(self, xs, idx):
+        """all passes of the call in ONE grouped context (CAE_BATCHED)"""
+        self._ensure_flat()
+        n = len(idx)
+        ins = [xs[i] for i in idx]
+        params = [p for _, p in self.named_parameters()]
+        outs = list(xs)
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in ins) or any(p.requires_grad for p in params)):
+            res = _StackManyFn.apply(self, n, *ins, *params)
+        else:
+            B = ins[0].shape[0]
+            key, sc = self._pool().acquire(n * B, tuple(ins[0].shape[2:]), self._dtype_code(), ins[0].device, groups=n)
+            out = sc.forward(torch.cat([t.float() for t in ins], 0), self._param_dict(), self._buffer_dict(), self.training)
+            self._pool().release(key, sc)
+            res = tuple(out[i * B:(i + 1) * B] for i in range(n))
+        for i, r in zip(idx, res):
+            outs[i] = r
         return outs
 
     def _flat_segment(self):

@@ -81,6 +81,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
   q = fdiv(t, P.d_tz); const int tz = t - q * P.ntz; const int b = q;
   const int oz0 = tz * a.TD, oy0 = ty * a.TH, ox0 = tx * 16;
   const int nt0 = blockIdx.y * NT;
+  // batched passes (group_batch > 0): samples [g*group_batch, (g+1)*group_batch) are one BatchNorm group -- its own affine
+  // table on the operand load and its own rows of the statistics accumulator (a tile belongs to one sample)
+  const int bgrp = a.group_batch > 0 ? b / a.group_batch : 0;
+  const float* const g_in_scale = a.in_scale ? a.in_scale + (size_t)bgrp * a.CPi : nullptr;
+  const float* const g_in_shift = a.in_shift ? a.in_shift + (size_t)bgrp * a.CPi : nullptr;
+  double* const g_stats = a.stats ? a.stats + (size_t)bgrp * a.stats_nrep * a.CPo * 2 : nullptr;
   // input coordinate of LDS tile voxel (0,0,0)
   const int iz0 = oz0 * a.sD + a.o0D, iy0 = oy0 * a.sH + a.o0H, ix0 = ox0 * a.sW + a.o0W;
 
@@ -122,10 +128,10 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
     // load is latency-bound otherwise (one 1 KiB wave-load in flight per wave).
     const int oct0 = grp * a.octs_per_group;
     float fsc[8], fsh[8];
-    if (a.in_scale && fixed_oc) {
+    if (g_in_scale && fixed_oc) {
       const int c = (oct0 + my_oc) * 8;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { fsc[j] = a.in_scale[c + j]; fsh[j] = a.in_shift[c + j]; }
+      for (int j = 0; j < 8; ++j) { fsc[j] = g_in_scale[c + j]; fsh[j] = g_in_shift[c + j]; }
     }
     for (int base = 0; base < nchunks; base += 256 * SB) {
       RawChunk<TIN> raw[SB];
@@ -159,13 +165,13 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
           float v[8];
           if (inb & (1u << u)) {
             raw[u].unpack(v);
-            if (a.in_scale) {
+            if (g_in_scale) {
               if (fixed_oc) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], fsc[j], fsh[j]);
               } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a.in_scale[cch[u] + j], a.in_shift[cch[u] + j]);
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], g_in_scale[cch[u] + j], g_in_shift[cch[u] + j]);
               }
             }
           } else {
@@ -328,7 +334,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
     __syncthreads();
     for (int i = tid; i < NT * 16 * 2; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&g_stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
     }
   }
   STAMP(5);
@@ -471,6 +477,7 @@ extern "C" int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream) {
   ConvDev P;
   const int rc = conv_check_build(a, P);
   if (rc != SP_OK) return rc;
+  SP_CHECK_ARG(a->group_batch == 0 || (a->group_batch > 0 && a->B % a->group_batch == 0), "sp_conv3d_igemm: group_batch %d does not divide the batch %d", a->group_batch, a->B);
   if (a->dma) return sp_conv3d_igemm_dma(a, stream);
   dim3 grid(P.nblk, a->NTtot / a->NT);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);

@@ -301,9 +301,11 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
       }
     __syncthreads();
     // spread the global accumulators over 8 replicas (by workgroup) to keep same-address atomics apart
+    // batched passes (group_batch > 0): the tile's sample decides the BatchNorm group whose rows receive the sums
+    double* const g_stats = a.stats + (size_t)(a.group_batch > 0 ? b / a.group_batch : 0) * a.stats_nrep * a.CPo * 2;
     for (int i = tid; i < NT * 16 * 2; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&g_stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
     }
   }
   STAMP(5);
@@ -1036,6 +1038,8 @@ static int dispatch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
 
 int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 input and no affine on load");
+  SP_CHECK_ARG(a->group_batch == 0 || (a->persist == 0 && a->group_batch > 0 && a->B % a->group_batch == 0),
+               "sp_conv3d_igemm(dma): BatchNorm groups (group_batch %d, B %d) need the tiled kernel (persist 0) and whole groups", a->group_batch, a->B);
   if (a->persist == 3 || a->persist == 4) return launch_zs(a, reinterpret_cast<hipStream_t>(stream));      // z-marching plans (ktab in their format)
   SP_CHECK_ARG(a->x_plane == 0 || (a->opp == 2 && !a->persist && a->x_plane < (1ll << 31)), "sp_conv3d_igemm(dma): plane-major input needs 16-channel planes");
   SP_CHECK_ARG(a->opp == 1 || a->opp == 2, "sp_conv3d_igemm(dma): octets per plane must be 1 or 2");

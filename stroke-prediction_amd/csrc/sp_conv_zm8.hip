@@ -380,6 +380,7 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && a->f8_wscale && zeros && a->in_scale == nullptr, "sp_conv3d_zm8: null pointer (or affine-on-load requested)");
   SP_CHECK_ARG(a->dtype_out == SP_BF16 && a->stats_mode == 0 && a->x_plane > 0, "sp_conv3d_zm8: bf16 output, plain statistics, plane-major fp8 input");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm8: stride 1 only");
+  SP_CHECK_ARG(a->group_batch == 0, "sp_conv3d_zm8: no BatchNorm groups (run one launch per group)");
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE, "sp_conv3d_zm8: LeakyReLU or identity epilogue");
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout && a->CPo % 4 == 0,
                "sp_conv3d_zm8: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);

@@ -275,6 +275,99 @@ extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, co
   return SP_OK;
 }
 
+// The same for G BatchNorm groups of one launch (batched passes of the CAE: samples [g*Bg, (g+1)*Bg) of the batch are pass g,
+// Cae3D.py:105-107,230-233): sums [G][nrep][CP][2]; scale / shift at scale + g*coef_stride (the rows of a [G][3][CP] table),
+// mean / invstd [G][CP]; the running statistics take the G momentum updates IN GROUP ORDER (one thread per channel), exactly
+// as the reference's G sequential module calls do.
+__global__ void bn_finalize_groups_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
+                                          const float* __restrict__ beta, float* running_mean, float* running_var,
+                                          float momentum, float eps, int training, int C, int CP, int G, int coef_stride,
+                                          float* scale, float* shift, float* mean_out, float* invstd_out) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float rm = 0.f, rv = 1.f;
+  if (c < C && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+  for (int g = 0; g < G; ++g) {
+    float* sc_o = scale + (size_t)g * coef_stride;
+    float* sh_o = shift + (size_t)g * coef_stride;
+    if (c >= C) {
+      if (lane == 0) { sc_o[c] = 0.f; sh_o[c] = 0.f; if (mean_out) { mean_out[(size_t)g * CP + c] = 0.f; invstd_out[(size_t)g * CP + c] = 0.f; } }
+      continue;
+    }
+    float mean, invstd;
+    if (training) {
+      const double* sg = sums + (size_t)g * nrep * CP * 2;
+      double s1 = 0, s2 = 0;
+      for (int r = lane; r < nrep; r += 64) { s1 += sg[((size_t)r * CP + c) * 2]; s2 += sg[((size_t)r * CP + c) * 2 + 1]; }
+      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+      const double m = s1 / count;
+      double var = s2 / count - m * m;
+      if (var < 0) var = 0;
+      mean = (float)m;
+      invstd = (float)(1.0 / sqrt(var + (double)eps));
+      const double unb = count > 1 ? var * count / (count - 1) : var;
+      rm = (1.f - momentum) * rm + momentum * (float)m;
+      rv = (1.f - momentum) * rv + momentum * (float)unb;
+    } else {
+      mean = rm;
+      invstd = 1.f / sqrtf(rv + eps);
+    }
+    if (lane == 0) {
+      const float sc = gamma[c] * invstd;
+      sc_o[c] = sc;
+      sh_o[c] = beta[c] - mean * sc;
+      if (mean_out) { mean_out[(size_t)g * CP + c] = mean; invstd_out[(size_t)g * CP + c] = invstd; }
+    }
+  }
+  if (training && running_mean && c < C && lane == 0) { running_mean[c] = rm; running_var[c] = rv; }
+}
+extern "C" int sp_bn_finalize_groups(const double* sums, int32_t nrep, double count, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps, int32_t training,
+                                     int32_t C, int32_t CP, int32_t G, int32_t coef_stride, float* scale, float* shift,
+                                     float* mean, float* invstd, sp_stream_t stream) {
+  SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP && G >= 1 && coef_stride >= CP, "sp_bn_finalize_groups: bad arguments");
+  SP_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "sp_bn_finalize_groups: missing statistics");
+  SP_CHECK_ARG(nrep >= 1, "sp_bn_finalize_groups: nrep");
+  hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, C, CP, G, coef_stride, scale, shift, mean, invstd);
+  SP_CHECK_LAUNCH("sp_bn_finalize_groups");
+  return SP_OK;
+}
+
+// backward: sums [G][nrep][CP][2], mean / invstd [G][CP], coef [G][3][CP]; dgamma / dbeta accumulate the G groups
+__global__ void bn_bwd_finalize_groups_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
+                                              const float* __restrict__ mean, const float* __restrict__ invstd, int C, int CP, int G,
+                                              float* dgamma, float* dbeta, float* coef, float pscale) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  float dg_acc = 0.f, db_acc = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float* cf = coef + (size_t)g * 3 * CP;
+    if (c >= C) { if (lane == 0) { cf[c] = 0.f; cf[CP + c] = 0.f; cf[2 * CP + c] = 0.f; } continue; }
+    const double* sg = sums + (size_t)g * nrep * CP * 2;
+    double s1 = 0, s2 = 0;
+    for (int r = lane; r < nrep; r += 64) { s1 += sg[((size_t)r * CP + c) * 2]; s2 += sg[((size_t)r * CP + c) * 2 + 1]; }
+    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+    const double mu = mean[(size_t)g * CP + c], is = invstd[(size_t)g * CP + c], ga = gamma[c];
+    const double dg = (s2 - mu * s1) * is, db = s1;
+    dg_acc += pscale * (float)dg; db_acc += pscale * (float)db;
+    const double c0 = ga * is, c1 = -ga * is * is * dg / count;
+    if (lane == 0) {
+      cf[c] = (float)c0;
+      cf[CP + c] = (float)c1;
+      cf[2 * CP + c] = (float)(-c0 * db / count - c1 * mu);
+    }
+  }
+  if (c < C && lane == 0 && dgamma) { dgamma[c] += dg_acc; dbeta[c] += db_acc; }
+}
+extern "C" int sp_bn_bwd_finalize_groups(const double* sums, int32_t nrep, double count, const float* gamma, const float* mean,
+                                         const float* invstd, int32_t C, int32_t CP, int32_t G, float* dgamma, float* dbeta,
+                                         float* coef, float param_grad_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(sums && gamma && mean && invstd && coef && count > 0 && G >= 1, "sp_bn_bwd_finalize_groups: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep < 1 ? 1 : nrep, count, gamma, mean,
+                     invstd, C, CP, G, dgamma, dbeta, coef, param_grad_scale);
+  SP_CHECK_LAUNCH("sp_bn_bwd_finalize_groups");
+  return SP_OK;
+}
+
 // dgamma = (S2 - mean*S1)*invstd ; dbeta = S1 ; dx = coef0*g + coef1*x + coef2 with
 // coef0 = gamma*invstd, coef1 = -gamma*invstd^2*dgamma/N, coef2 = -coef0*dbeta/N - coef1*mean
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
@@ -308,12 +401,14 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                           const float* __restrict__ coef, int64_t nvox, int CP,
                                                           OctMap om, int act, float ap, T* __restrict__ dz,
-                                                          double* __restrict__ dbias, const SpQ8 q8) {
+                                                          double* __restrict__ dbias, const SpQ8 q8, int64_t gvox) {
+  // gvox > 0: voxels [g*gvox, (g+1)*gvox) use the coefficient table coef + g*3*CP (the batched passes of the CAE)
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
   float part[1][8];
   float c0[8], c1[8], c2[8];
+  int64_t gend = gvox > 0 ? 0 : nvox;      // first voxel of the NEXT group: the coefficients in registers hold below it
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     part[0][j] = 0.f;
@@ -326,6 +421,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
     const int64_t chunk_ = ((nvox + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
     const int64_t vend_ = min((int64_t)nvox, ((int64_t)blockIdx.x + 1) * chunk_);
     for (int64_t v = (int64_t)blockIdx.x * chunk_ + slot; v < vend_; v += om.vpb) {
+      if (v >= gend) {       // (only with gvox > 0) entering another group: its coefficient table
+        const int64_t gi = v / gvox;
+        gend = (gi + 1) * gvox;
+        const float* cg = coef + (size_t)gi * 3 * CP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { c0[j] = cg[oc * 8 + j]; c1[j] = cg[CP + oc * 8 + j]; c2[j] = cg[2 * CP + oc * 8 + j]; }
+      }
       float a[8], b[8], o[8];
       Store<T>::ld8(g + v * CP + oc * 8, a);
       Store<T>::ld8(y + v * CP + oc * 8, b);
@@ -341,17 +443,18 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
   if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
 }
 static int bn_act_bwd_impl(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
-                           int32_t act, float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream) {
+                           int32_t act, float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream, int64_t gvox = 0) {
   SP_CHECK_ARG(g && y && dz && CP % 8 == 0 && CP <= 2048, "sp_bn_act_bwd: bad arguments");
+  SP_CHECK_ARG(gvox == 0 || (coef && gvox > 0 && nvox % gvox == 0), "sp_bn_act_bwd_groups: the groups must tile the tensor");
   SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= nvox * 16 && q8.scale > 0.f), "sp_bn_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   OctMap om = make_octmap(CP);
   const unsigned grid = grid_for(nvox, om.vpb * 4);
   const size_t sh = (size_t)CP * sizeof(float);
 #define SP_L(A_)                                                                                                                   \
   if (dtype == SP_BF16) hipLaunchKernelGGL((bn_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)g, \
-                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums, q8);       \
+                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums, q8, gvox); \
   else hipLaunchKernelGGL((bn_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)g, (const float*)y,   \
-                          coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums, q8)
+                          coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums, q8, gvox)
   SP_ACT_DISPATCH(act, SP_L)
 #undef SP_L
   SP_CHECK_LAUNCH("sp_bn_act_bwd");
@@ -360,6 +463,11 @@ static int bn_act_bwd_impl(const void* g, const void* y, const float* coef, int3
 extern "C" int sp_bn_act_bwd(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
                              int32_t act, float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
   return bn_act_bwd_impl(g, y, coef, dtype, nvox, CP, act, act_param, dz, dbias_sums, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_bn_act_bwd_groups(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
+                                    int32_t act, float act_param, void* dz, double* dbias_sums, int64_t group_vox, sp_stream_t stream) {
+  SP_CHECK_ARG(group_vox > 0, "sp_bn_act_bwd_groups: group_vox");
+  return bn_act_bwd_impl(g, y, coef, dtype, nvox, CP, act, act_param, dz, dbias_sums, SpQ8{nullptr, 0, 1.f, 0}, stream, group_vox);
 }
 extern "C" int sp_bn_act_bwd_q8(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
                                 int32_t act, float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane,

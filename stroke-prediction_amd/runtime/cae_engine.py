@@ -45,11 +45,16 @@ def channel_map(channels):
 class StackContext:
     """One call of an encoder / decoder stack: layers (with their activations), scratch, I/O staging."""
 
-    def __init__(self, table, prefix, channels, alpha, batch, in_dims, dtype, device, last_sigmoid, bank=None):
+    def __init__(self, table, prefix, channels, alpha, batch, in_dims, dtype, device, last_sigmoid, bank=None, groups=1):
+        """groups > 1: ``batch`` = groups x (samples of one pass): the passes of one encoder / decoder call stacked along the
+        batch axis -- ONE launch per layer for the convolution, its weight gradient and its data gradient, per-pass
+        BatchNorm statistics (layers.ConvLayer(groups=...))."""
         O.require_gpu()
         L.load()
         cm = channel_map(channels)
         self.batch, self.dtype, self.device = batch, dtype, device
+        self.G = groups
+        self.gb = batch // groups
         self.scratch = sc = Scratch(device)
         self.layers = []
         dims = tuple(in_dims)
@@ -60,7 +65,7 @@ class StackContext:
                             bn_prefix="%s.%d" % (prefix, 3 * i), conv_prefix="%s.%d" % (prefix, 3 * i + 1),
                             act=L.ACT_SIGMOID if last else L.ACT_ELU, act_param=0.0 if last else alpha,
                             out_dtype=L.SP_F32 if last else None, need_input_grad=True, bank=bank,
-                            pitch=16 if (dtype == L.SP_BF16 and PITCH16) else 8)
+                            pitch=16 if (dtype == L.SP_BF16 and PITCH16) else 8, groups=groups)
             self.layers.append(lay)
             dims = lay.out_dims
         self.in_dims, self.out_dims = tuple(in_dims), dims
@@ -80,10 +85,13 @@ class StackContext:
         self.scratch.zero()
         wait_ev, rec_ev = order if order is not None else (None, None)
         if training and bump_nbt and "__nbt_flat__" in bufs:
-            bufs["__nbt_flat__"].add_(1)
+            bufs["__nbt_flat__"].add_(self.G)         # every BatchNorm sees G calls
         O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)
         if training:
-            O.bn_stats(self.x0, self.dtype, self.layers[0].in_sums)
+            s0 = self.layers[0].in_sums
+            per = s0.numel() // self.G
+            for gi in range(self.G):                  # statistics of the stack input, per pass
+                O.bn_stats(self.x0[gi * self.gb:(gi + 1) * self.gb], self.dtype, s0[gi * per:(gi + 1) * per])
         h = self.x0
         for i, lay in enumerate(self.layers):
             nxt = self.layers[i + 1].in_sums if (training and i + 1 < len(self.layers)) else None
@@ -137,17 +145,18 @@ class StackContext:
                 self._dy = O.alloc_cl(self.batch, self.out_dims, last.cpo, dt, self.device)
             O.ncdhw_to_cl(dout, self._dy, dt)
             O.bn_act_bwd(self._dy, last.y, None, dt, last.act, last.act_param, last.dz, last.dbias_sums)
+        gv = (lambda t: (t.numel() // t.shape[-1] // self.G) if self.G > 1 else 0)      # voxels per BatchNorm group of a tensor
         for i in range(len(self.layers) - 1, -1, -1):
             lay = self.layers[i]
             x = self.layers[i - 1].y if i > 0 else self.x0
             g, coef = lay.backward(x, params, grads)
             if i > 0:
                 prev = self.layers[i - 1]
-                O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums)
+                O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y) if coef is not None else 0)
             elif need_input_grad:
                 if not hasattr(self, "_dx"):
                     self._dx = O.alloc_cl(self.batch, self.in_dims, lay.cpi, dt, self.device)
-                O.bn_act_bwd(g, self.x0, coef, dt, L.ACT_NONE, 0.0, self._dx, None)
+                O.bn_act_bwd(g, self.x0, coef, dt, L.ACT_NONE, 0.0, self._dx, None, group_vox=gv(self.x0) if coef is not None else 0)
                 dx = torch.empty((self.batch, self.cin) + self.in_dims, dtype=torch.float32, device=self.device)
                 O.cl_to_ncdhw(self._dx, dx, dt)
                 return dx
@@ -163,17 +172,17 @@ class StackPool:
         self.free = {}
         self.banks = {}
 
-    def acquire(self, batch, in_dims, dtype, device, lane=0):
+    def acquire(self, batch, in_dims, dtype, device, lane=0, groups=1):
         """lane: index of the pass inside one encoder / decoder call (Cae3D._run_stack_many): pass k always gets the contexts of
         lane k, so the eager warm-up steps build exactly the contexts a captured step replays.  All lanes share the bank of
         packed weights (un-folded fragments depend on the parameters only; ``StackContext.prepare`` fills it once per step
         before concurrent passes fork)."""
-        key = (batch, tuple(in_dims), dtype, str(device), lane)
+        key = (batch, tuple(in_dims), dtype, str(device), lane) + ((groups,) if groups > 1 else ())
         lst = self.free.setdefault(key, [])
         if lst:
             return key, lst.pop()
         return key, StackContext(self.table, self.prefix, self.channels, self.alpha, batch, in_dims, dtype, device,
-                                 self.last_sigmoid, bank=self.banks.setdefault(key[:-1], {}))
+                                 self.last_sigmoid, bank=self.banks.setdefault((key[:4], groups), {}), groups=groups)
 
     def release(self, key, ctx):
         lst = self.free.setdefault(key, [])

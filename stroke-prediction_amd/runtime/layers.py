@@ -57,7 +57,15 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8):
+                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8, groups=1):
+        """groups > 1 (the batched passes of the CAE, runtime/cae_engine.py): the batch holds `groups` passes of batch // groups
+        samples each; every pass is its own BatchNorm group (own batch statistics, own scale / shift / backward coefficients),
+        the convolution, its weight gradient and its data gradient run ONCE over the whole batch.  The normalised input is
+        always written out per group (``xhat``), so no kernel needs an affine on its operand load and the weights never
+        depend on a pass."""
+        self.G = int(groups)
+        assert batch % self.G == 0
+        self.gb = batch // self.G
         self.name, self.kind = name, kind
         self.cin, self.cout, self.k, self.stride, self.pad = cin, cout, k, stride, pad
         self.in_dims, self.batch, self.dtype, self.device = tuple(in_dims), batch, dtype, device
@@ -73,11 +81,11 @@ class ConvLayer:
         self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
         self.out_dims = tuple(self.fwd_op.y_dims)
         self.bank = bank            # optional dict shared by the layers of all contexts of one stack (packed weights)
-        self.count = float(batch * in_dims[0] * in_dims[1] * in_dims[2])
+        self.count = float(self.gb * in_dims[0] * in_dims[1] * in_dims[2])       # voxels of ONE BatchNorm group
         # un-padded bf16 convolutions fold the BatchNorm into weights/bias so the tile can be staged by DMA
         pads = pad if isinstance(pad, (tuple, list)) else (pad,) * 3
         self.fold = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and max(pads) == 0
-                         and all(s.tile["dma"] for s in self.fwd_op.subs))
+                         and all(s.tile["dma"] for s in self.fwd_op.subs) and self.G == 1)
         self.scratch = scratch
         # Padded bf16 convolutions behind a BatchNorm (the CAE): zero padding applies AFTER the normalisation, so the
         # BatchNorm cannot be folded into the weights, and a DMA cannot normalise on load.  The normalised input is
@@ -87,21 +95,28 @@ class ConvLayer:
         self.materialize = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and not self.fold
                                 and max(pads) > 0 and max(pads) <= 2 and max(strides) == 1 and k == 3 and self.cpi % 16 == 0
                                 and self.cpo % 16 == 0 and all(s.tile["dma"] for s in self.fwd_op.subs) and O.MATERIALIZE_BN)
+        if self.G > 1:
+            self.materialize = bn_prefix is not None        # grouped: xhat = s_g x + t_g for EVERY layer behind a BatchNorm
         self.xhat = None
         # folded layers run without affine-on-load and with plain statistics: candidates for the z-marching kernel; so do the
         # materialised ones (the kernel pads from its zero page and has an ELU epilogue)
         zm_ok = (self.fold and act in (L.ACT_NONE, L.ACT_LEAKY) and bank is None) or \
                 (self.materialize and act == L.ACT_ELU and O.ZM_CAE and self.out_dtype == dtype)
         # (folded fragments depend on the BatchNorm statistics of the pass: never shared between the contexts of a bank)
+        if self.G > 1:
+            zm_ok = bool(self.materialize and kind == "conv" and dtype == L.SP_BF16 and act == L.ACT_ELU and O.ZM_CAE
+                         and self.out_dtype == dtype and max(pads) <= 2 and max(strides) == 1 and k == 3
+                         and self.cpi % 16 == 0 and self.cpo % 16 == 0)
         self.fwd = O.ConvRunner(self.fwd_op, device, share=None if (bank is None or self.fold) else bank.setdefault((name, "fwd"), {}),
-                                zm_batch=batch if zm_ok else None)
+                                zm_batch=self.gb if zm_ok else None)
         if bn_prefix is not None:
-            self.apply_coef = torch.zeros(3, self.cpi, device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift
-            self.scale = self.apply_coef[0]
-            self.shift = self.apply_coef[2]
-            self.mean = torch.zeros(self.cpi, device=device)
-            self.invstd = torch.zeros(self.cpi, device=device)
-            self.in_sums_id = scratch.reserve(self.cpi * 2 * STATS_NREP)
+            G = self.G
+            self.apply_coef = torch.zeros((G, 3, self.cpi) if G > 1 else (3, self.cpi), device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift
+            self.scale = self.apply_coef[..., 0, :] if G > 1 else self.apply_coef[0]
+            self.shift = self.apply_coef[..., 2, :] if G > 1 else self.apply_coef[2]
+            self.mean = torch.zeros((G, self.cpi) if G > 1 else (self.cpi,), device=device)
+            self.invstd = torch.zeros((G, self.cpi) if G > 1 else (self.cpi,), device=device)
+            self.in_sums_id = scratch.reserve(G * self.cpi * 2 * STATS_NREP)
         else:
             self.scale = self.shift = None
         # backward side is created lazily (inference never pays for it)
@@ -161,9 +176,16 @@ class ConvLayer:
         if training and SYNC["on"]:
             _allreduce(self.in_sums)
             world = SYNC["world"]
-        O.bn_finalize(self.in_sums if training else None, self.count * world, params[p + ".weight"], params[p + ".bias"],
-                      bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
-                      self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
+        if self.G > 1:
+            L.call("sp_bn_finalize_groups", O.ptr(self.in_sums if training else None), STATS_NREP, float(self.count * world),
+                   O.ptr(params[p + ".weight"]), O.ptr(params[p + ".bias"]), O.ptr(bufs[p + ".running_mean"]),
+                   O.ptr(bufs[p + ".running_var"]), BN_MOMENTUM, BN_EPS, int(training), self.cin, self.cpi, self.G, 3 * self.cpi,
+                   self.apply_coef.data_ptr(), self.apply_coef.data_ptr() + 8 * self.cpi, O.ptr(self.mean), O.ptr(self.invstd),
+                   O.stream())
+        else:
+            O.bn_finalize(self.in_sums if training else None, self.count * world, params[p + ".weight"], params[p + ".bias"],
+                          bufs[p + ".running_mean"], bufs[p + ".running_var"], BN_MOMENTUM, BN_EPS, training,
+                          self.cin, self.cpi, self.scale, self.shift, self.mean, self.invstd, nrep=STATS_NREP)
         if training and "__nbt_flat__" not in bufs:      # else: one increment for all BatchNorms (UnetEngine.forward)
             bufs[p + ".num_batches_tracked"].add_(1)
 
@@ -173,6 +195,18 @@ class ConvLayer:
             self._bn_fwd(params, bufs, training)
         c = self.conv_prefix
         y = self.alloc_out()
+        if self.G > 1:
+            src = x
+            if self.materialize:
+                if self.xhat is None:
+                    self.xhat = torch.empty_like(x)
+                O.bn_act_bwd(x, x, self.apply_coef, self.dtype, L.ACT_NONE, 0.0, self.xhat, None,
+                             group_vox=x.numel() // x.shape[-1] // self.G)      # xhat = scale_g * x + shift_g
+                src = self.xhat
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
+            self.fwd.run(src, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
+                         stats_nrep=STATS_NREP, group_batch=self.gb)
+            return y
         if self.materialize:
             if self.xhat is None:
                 self.xhat = torch.empty_like(x)
@@ -217,7 +251,7 @@ class ConvLayer:
         # the data-gradient convolution needs no statistics epilogue (no second read of x, no atomics) -- and is not
         # run at all for the first layer of a network, whose input gradient nobody wants.
         self.bn_from_wgrad = bool(self.bn_prefix is not None and self.kind == "conv" and self.wgrad.folds(self.scale)
-                                  and max(P._triple(p)) == 0 and O.BN_SUMS_FROM_WGRAD)
+                                  and max(P._triple(p)) == 0 and O.BN_SUMS_FROM_WGRAD and self.G == 1)
         if self.split_g and self.kind == "conv" and self.need_input_grad and self.bn_from_wgrad:
             # gradient of a channel-concatenated input as one dense tensor per part: both consumers (upsample backward,
             # pool/skip backward) then read whole lines instead of 64 / 32 bytes of every 96-byte row
@@ -238,13 +272,13 @@ class ConvLayer:
                     self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.DZ_FMT)
                     self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
         if self.bn_prefix is not None:
-            self.coef = torch.zeros(3, self.cpi, device=dev)
+            self.coef = torch.zeros((self.G, 3, self.cpi) if self.G > 1 else (3, self.cpi), device=dev)
         self._bwd_ready = True
 
     def reserve_bwd_scratch(self):
         self.dbias_sums_id = self.scratch.reserve(self.cpo * L.SP_REDUCE_ROWS)     # replica rows, see include/stroke_amd.h
         if self.bn_prefix is not None:
-            self.bsums_id = self.scratch.reserve(self.cpi * 2 * STATS_NREP)
+            self.bsums_id = self.scratch.reserve(self.G * self.cpi * 2 * STATS_NREP)
 
     @property
     def dbias_sums(self):
@@ -256,6 +290,8 @@ class ConvLayer:
         dx = coef0*g + coef1*x + coef2 (coef None: dx = g)."""
         c = self.conv_prefix
         w = params[c + ".weight"]
+        if self.G > 1:
+            return self._backward_grouped(x, w, params, grads)
         # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
         if self.bn_from_wgrad:
             bs = self.scratch.get(self.bsums_id)
@@ -295,6 +331,55 @@ class ConvLayer:
                 f.__exit__(None, None, None)
         try:
             return self._backward_input(x, w, params, grads)
+        finally:
+            if f is not None:
+                f.join()
+
+    def _backward_grouped(self, x, w, params, grads):
+        """groups > 1: one weight-gradient launch over all passes (operands: the materialised normalised input and dz -- the
+        sum over the batch IS the sum over the passes), one data-gradient launch whose epilogue (or one reduction per group)
+        yields the per-group BatchNorm-backward sums, one grouped finalize."""
+        c = self.conv_prefix
+        src = self.xhat if self.materialize else x
+        f = O.fork() if O.overlap_level() == 2 else None
+        if f is not None:
+            f.__enter__()
+        try:
+            if self.kind == "conv":
+                self.wgrad.run(src, self.dz, self.batch, grads[c + ".weight"], None, None,
+                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+            else:
+                self.wgrad.run(self.dz, src, self.batch, grads[c + ".weight"], None, None, None, None,
+                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
+        finally:
+            if f is not None:
+                f.__exit__(None, None, None)
+        try:
+            if not (self.need_input_grad or self.bn_prefix is not None):
+                return None, None
+            self.dgrad.prep(w)
+            if self.bn_prefix is None:
+                self.dgrad.run(self.dz, self.g, self.batch)
+                return self.g, None
+            bs = self.scratch.get(self.bsums_id)
+            fused = all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None
+            if fused:
+                self.dgrad.run(self.dz, self.g, self.batch, stats=bs, stats_nrep=STATS_NREP, stats_mode=1, aux=x, group_batch=self.gb)
+            else:
+                self.dgrad.run(self.dz, self.g, self.batch)
+                per = self.cpi * 2 * STATS_NREP
+                for gi in range(self.G):
+                    sl = slice(gi * self.gb, (gi + 1) * self.gb)
+                    O.bn_bwd_reduce(self.g[sl], x[sl], self.dtype, bs[gi * per:(gi + 1) * per])
+            p = self.bn_prefix
+            world = 1
+            if SYNC["on"]:
+                _allreduce(bs)
+                world = SYNC["world"]
+            L.call("sp_bn_bwd_finalize_groups", O.ptr(bs), STATS_NREP, float(self.count * world), O.ptr(params[p + ".weight"]),
+                   O.ptr(self.mean), O.ptr(self.invstd), self.cin, self.cpi, self.G, O.ptr(grads[p + ".weight"]),
+                   O.ptr(grads[p + ".bias"]), O.ptr(self.coef), 1.0 / world, O.stream())
+            return self.g, self.coef
         finally:
             if f is not None:
                 f.join()

@@ -35,7 +35,8 @@ class ConvArgs(C.Structure):
                    "osD", "osH", "osW", "ooD", "ooH", "ooW", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
                    "TD", "TH", "ITD", "ITH", "ITW", "MT", "NT", "NTtot", "ngroups", "octs_per_group", "opp", "vsb",
                    "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32), ("x_plane", i64),
-                                                                           ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32)]
+                                                                           ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32),
+                                                                           ("group_batch", i32)]
 
 
 class WgradArgs(C.Structure):
@@ -107,6 +108,9 @@ _SIGS = {
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),
     "sp_bn_finalize": ([vp, i32, f64, vp, vp, vp, vp, f32, f32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
     "sp_bn_bwd_reduce": ([vp, vp, i32, i64, i32, vp, vp], i32),
+    "sp_bn_finalize_groups": ([vp, i32, f64, vp, vp, vp, vp, f32, f32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp], i32),
+    "sp_bn_bwd_finalize_groups": ([vp, i32, f64, vp, vp, vp, i32, i32, i32, vp, vp, vp, f32, vp], i32),
+    "sp_bn_act_bwd_groups": ([vp, vp, vp, i32, i64, i32, i32, f32, vp, vp, i64, vp], i32),
     "sp_bn_bwd_finalize": ([vp, i32, f64, vp, vp, vp, i32, i32, vp, vp, vp, f32, vp], i32),
     "sp_bn_act_bwd": ([vp, vp, vp, i32, i64, i32, i32, f32, vp, vp, vp], i32),
     "sp_maxpool2_fwd": ([vp, vp, i32, i32, i32, i32, i32, i32, vp, vp], i32),

@@ -328,11 +328,27 @@ class ConvRunner:
                        ptr(s["hi_zr"]), None, ptr(fold_scale), stream())
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
-            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False):
+            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only."""
         op = self.op
         dtype_out = op.dtype if dtype_out is None else dtype_out
+        if group_batch and group_batch < batch and stats is not None and (self.uses_zm() or self.fc is not None):
+            # BatchNorm groups (statistics rows per group) on a kernel that is not group-aware: one launch per group on the
+            # contiguous slices of the batch (the z-marching and split-K kernels)
+            assert in_scale is None and batch % group_batch == 0
+            per = stats.numel() // (batch // group_batch)
+            for gi in range(batch // group_batch):
+                sl = slice(gi * group_batch, (gi + 1) * group_batch)
+                self.run(x[sl], y[sl], group_batch, None, None, act, act_param, stats[gi * per:(gi + 1) * per], dtype_out, use_bias,
+                         stats_nrep, stats_mode, None if aux is None else aux[sl], x_planar, 0)
+            return
+        if group_batch and (self.uses_zm()) and batch != self.zm_batch:
+            for gi in range(batch // group_batch):       # (no statistics: still one launch per group -- the runner is planned for one)
+                sl = slice(gi * group_batch, (gi + 1) * group_batch)
+                self.run(x[sl], y[sl], group_batch, None, None, act, act_param, None, dtype_out, use_bias, stats_nrep, stats_mode,
+                         None, x_planar, 0)
+            return
         assert x.dtype == TORCH_DT[op.dtype] and y.dtype == TORCH_DT[dtype_out]
         assert tuple(x.shape) == (batch,) + tuple(op.in_dims) + (op.cpi,), (tuple(x.shape), op.in_dims, op.cpi)
         assert tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
@@ -353,6 +369,7 @@ class ConvRunner:
         a.sD, a.sH, a.sW = op.stride
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
+        a.group_batch = group_batch if (group_batch and group_batch < batch and stats is not None) else 0
         st = stream()
         if self.uses_zm():
             assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
@@ -385,7 +402,7 @@ class ConvRunner:
                 assert a.dma and t["opp"] == 2, "plane-major input: DMA kernel with 16-channel planes only"
                 a.x_plane = batch * int(np.prod(op.in_dims)) * 16
                 a.persist = 0               # (the persistent variants address channels-last rows)
-            if USE_ZS and a.dma and s.get("ktab_zs") is not None and stats_mode == 0 and a.CPo >= 16:
+            if USE_ZS and a.dma and s.get("ktab_zs") is not None and stats_mode == 0 and a.CPo >= 16 and not a.group_batch:
                 a.persist, a.ktab, a.ITH_zs = 3, ptr(s["ktab_zs"]), t["ITH_zs"]     # z-marching ring variant
                 if s.get("ktab_zr") is not None and not x_planar:
                     a.persist, a.ktab, a.wfrag_hi = 4, ptr(s["ktab_zr"]), ptr(s["hi_zr"])   # ... with row reuse
@@ -687,8 +704,13 @@ def _q8_args(q8, nvox):
     return ptr(t), nvox * 16, int(fmt), float(scale)
 
 
-def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None):
+def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None, group_vox=0):
     nvox = y.numel() // y.shape[-1]
+    if group_vox:       # coef is a [G][3][CP] table, one per group of group_vox consecutive voxels (batched CAE passes)
+        assert q8 is None and coef is not None
+        L.call("sp_bn_act_bwd_groups", ptr(g), ptr(y), ptr(coef), dtype, nvox, y.shape[-1], act, act_param, ptr(dz), ptr(dbias),
+               group_vox, stream())
+        return
     if q8 is not None:
         L.call("sp_bn_act_bwd_q8", ptr(g), ptr(y), ptr(coef), dtype, nvox, y.shape[-1], act, act_param, ptr(dz),
                ptr(dbias), *_q8_args(q8, nvox), stream())

@@ -99,7 +99,7 @@ def test_save_model_between_captured_steps_keeps_the_graph_valid(tmp_path):
 
 
 # ------------------------------------------------------------------------------------------------ CAE: concurrent passes
-def _cae_step(ch, seed, d, hw, dtype, streams, graph=False, steps=1):
+def _cae_step(ch, seed, d, hw, dtype, streams, graph=False, steps=1, batched=0):
     """one (or a few) CaeReconstructionLearner.train_batch steps; returns reconstructions, loss, the flat gradient after the
     first backward and every buffer -- with the 3 + 4 passes on one stream (streams = 0) or one stream each (2)"""
     from stroke_prediction_amd.common.model import Cae3D as M
@@ -107,8 +107,8 @@ def _cae_step(ch, seed, d, hw, dtype, streams, graph=False, steps=1):
     from stroke_prediction_amd.common.metrics import BatchDiceLoss
     from stroke_prediction_amd.learner.CaeReconstructionLearner import CaeReconstructionLearner
     from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
-    keep = M.CAE_STREAMS
-    M.CAE_STREAMS = streams
+    keep = M.CAE_STREAMS, M.CAE_BATCHED
+    M.CAE_STREAMS, M.CAE_BATCHED = streams, batched
     try:
         cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype=dtype), Dec3D(hw, d, ch, 5, 1.0, dtype=dtype))
         cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
@@ -137,7 +137,7 @@ def _cae_step(ch, seed, d, hw, dtype, streams, graph=False, steps=1):
         torch.cuda.synchronize()
         return rec, float(loss.detach()), grad, bufs, losses, cae.flat_buffers()[0].clone()
     finally:
-        M.CAE_STREAMS = keep
+        M.CAE_STREAMS, M.CAE_BATCHED = keep
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -266,3 +266,32 @@ def test_f16_mode_train_step_matches_the_oracle_and_the_fixture():
         if rel > (0.5 if small else 0.12) or cos < (0.9 if small else 0.99):
             bad.append((k, rel, cos))
     assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------ CAE: batched passes
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_cae_batched_passes_equal_sequential_passes(dtype):
+    """the 3 encoder / 4 decoder passes of a call stacked along the batch axis (SP_CAE_BATCHED: one launch
+    per layer for the convolution, weight gradient and data gradient of all passes; per-pass BatchNorm statistics, scale /
+    shift tables and backward coefficients; running statistics updated in pass order by one grouped finalize kernel) against
+    the pass-by-pass execution: reconstructions, loss, every BatchNorm buffer incl. num_batches_tracked (+= 3 / 4), gradients.
+    f32: tight.  bf16: the batched path normalises every layer's input into a stored tensor where the sequential path folds
+    the BatchNorm into the weights of un-padded layers or applies it on the operand load -- same function, other rounding
+    points, so bf16 is held to the distance between two bf16 pipelines (as against the emulating oracle, test_gpu_cae.py)."""
+    ch = [1, 16, 24, 32, 100, 200, 1]
+    a = _cae_step(ch, 23, 28, 64, dtype, 0, batched=0)
+    b = _cae_step(ch, 23, 28, 64, dtype, 0, batched=1)
+    tol = dict(f32=(1e-4, 1e-5, 2e-5, 5e-4), bf16=(6e-2, 4e-3, 5e-3, 0.12))[dtype]
+    for k in a[0]:
+        d = (a[0][k] - b[0][k]).abs()
+        assert float(d.max()) <= tol[0] and float(d.mean()) <= tol[1], (k, float(d.max()), float(d.mean()))
+    assert abs(a[1] - b[1]) <= tol[2], (a[1], b[1])
+    for k in a[3]:
+        if k.endswith("num_batches_tracked"):
+            assert int(a[3][k]) == int(b[3][k]) == (3 if k.startswith("enc.") else 4), k
+        else:
+            d = float((a[3][k] - b[3][k]).abs().max())
+            assert d <= (2e-5 if dtype == "f32" else 5e-3) * float(a[3][k].abs().max() + 1e-2), (k, d)
+    rel = float((a[2] - b[2]).double().norm() / a[2].double().norm())
+    print("batched vs sequential: flat gradient rel-L2 %.2e (%s)" % (rel, dtype))
+    assert rel < tol[3], rel
