@@ -242,6 +242,9 @@ typedef struct sp_prep_item {
   void* wfrag_hi;
   void* wfrag_lo;            /* or NULL */
   const float* fold_scale;   /* or NULL */
+  const float* bias;         /* or NULL: bias_out (when given) is then zeroed */
+  float* bias_out;           /* or NULL; bias_pad floats: bias[0..bias_n) followed by zeros (what sp_conv_args.bias reads) */
+  int32_t bias_n, bias_pad;
 } sp_prep_item;
 int sp_conv_prep_weights_batch(const sp_prep_item* items_dev, int32_t n, int32_t max_blocks, sp_stream_t stream);
 /* BatchNorm folded into an un-padded convolution: bias_out[co] = bias[co] + sum_{ci,tap} w[co,ci,tap]*shift[ci]

@@ -531,6 +531,8 @@ __global__ void prep_wfrag_kernel(const float* __restrict__ w, int64_t sCo, int6
 // all re-packs that depend on the parameters only (the data-gradient weights of every layer) in ONE launch: grid.y = item
 __global__ void prep_wfrag_batch_kernel(const sp_prep_item* __restrict__ items) {
   const sp_prep_item it = items[blockIdx.y];
+  if (blockIdx.x == 0 && it.bias_out)      // the layer's bias, zero-padded to whole output tiles
+    for (int c = threadIdx.x; c < it.bias_pad; c += blockDim.x) it.bias_out[c] = (it.bias && c < it.bias_n) ? it.bias[c] : 0.f;
   prep_wfrag_one(it.w, it.sCo, it.sCi, it.Cout, it.Cin, it.kmap, it.nsteps, it.NTtot, reinterpret_cast<bf16_t*>(it.wfrag_hi),
                  reinterpret_cast<bf16_t*>(it.wfrag_lo), it.fold_scale, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }

@@ -86,6 +86,12 @@ class StackContext:
         wait_ev, rec_ev = order if order is not None else (None, None)
         if training and bump_nbt and "__nbt_flat__" in bufs:
             bufs["__nbt_flat__"].add_(self.G)         # every BatchNorm sees G calls
+        # every weight re-pack of the stack that depends on the parameters only (forward fragments of the un-folded layers with
+        # their biases, data-gradient fragments once the backward exists) in ONE launch -- 40-odd launches and as many bias
+        # copies per call otherwise
+        O.prep_batch([(l.fwd, params[l.conv_prefix + ".weight"], params[l.conv_prefix + ".bias"]) for l in self.layers if not l.fold] +
+                     [(l.dgrad, params[l.conv_prefix + ".weight"]) for l in self.layers
+                      if l._bwd_ready and getattr(l, "dgrad", None) is not None and l.f8_dgrad is None])
         O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)
         if training:
             s0 = self.layers[0].in_sums

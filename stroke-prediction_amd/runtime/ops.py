@@ -604,49 +604,60 @@ class WgradRunner:
 
 
 _PREP_ITEM = np.dtype([("w", "<u8"), ("sCo", "<i8"), ("sCi", "<i8"), ("Cout", "<i4"), ("Cin", "<i4"), ("kmap", "<u8"),
-                       ("nsteps", "<i4"), ("NTtot", "<i4"), ("hi", "<u8"), ("lo", "<u8"), ("fold", "<u8")])   # sp_prep_item
+                       ("nsteps", "<i4"), ("NTtot", "<i4"), ("hi", "<u8"), ("lo", "<u8"), ("fold", "<u8"),
+                       ("bias", "<u8"), ("bias_out", "<u8"), ("bias_n", "<i4"), ("bias_pad", "<i4")])   # sp_prep_item
 _prep_tables = {}
 
 
 def prep_batch(pairs):
     """Re-pack the (un-folded) weights of many ConvRunners in ONE launch (sp_conv_prep_weights_batch).
-    pairs: [(runner, w)]; runners whose fragments are current (same key as ConvRunner.prep) are skipped, and after
-    the call every runner's key is current, so a later runner.prep(w) is a no-op."""
+    pairs: [(runner, w)] or [(runner, w, b)] -- with b the layer's bias is copied (zero-padded) in the same launch; runners
+    whose fragments are current (same key as ConvRunner.prep(w, b)) are skipped, and after the call every runner's key is
+    current, so a later runner.prep(w, b) is a no-op."""
     todo = []
-    for r, w in pairs:
-        key = (w.data_ptr(), w._version, PARAM_EPOCH[0], None)
+    for item in pairs:
+        r, w = item[0], item[1]
+        b = item[2] if len(item) > 2 else None
+        key = (w.data_ptr(), w._version, PARAM_EPOCH[0], None if b is None else (b.data_ptr(), b._version))
         if r._st["prep_key"] != key:
-            todo.append((r, w, key))
+            todo.append((r, w, b, key))
     if not todo:
         return
     # the cached device table holds raw addresses only: key it on every address it contains, so an entry can only be
     # replayed for runners that own exactly those buffers (ids / addresses recycled after an engine was freed)
-    tkey = tuple((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, r.op.nttot) +
+    tkey = tuple((w.data_ptr(), 0 if b is None else b.data_ptr(), r.bias.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, r.op.nttot) +
                  tuple((k.data_ptr(), n, h.data_ptr(), 0 if lo_ is None else lo_.data_ptr(), nt_, c0_, cn_) for k, n, h, lo_, nt_, c0_, cn_ in r._pack()) +
                  tuple((0 if sub.get("ktab_zr") is None else sub["hi_zr"].data_ptr()) for sub in r.subs)
-                 for r, w, _ in todo)
+                 for r, w, b, _ in todo)
     tab = _prep_tables.get(tkey)
     if tab is None:
         if len(_prep_tables) > 64:
             _prep_tables.clear()
         items = []
-        for r, w, _ in todo:
+        for r, w, b, _ in todo:
             assert w.dtype == torch.float32 and w.is_contiguous()
+            first = True
             for kmap, nsteps, hi, lo, nttot, c0, cn in r._pack():
+                bias_fields = (0, 0, 0, 0)
+                if first and b is not None:        # once per runner: bias[0..cout) + zero padding into the runner's padded copy
+                    bias_fields = (b.data_ptr(), r.bias.data_ptr(), r.op.cout, r.bias.numel())
+                first = False
                 items.append((w.data_ptr() + 4 * c0 * r.op.w_sco, r.op.w_sco, r.op.w_sci, cn, r.op.cin, kmap.data_ptr(), nsteps,
-                              nttot, hi.data_ptr(), 0 if lo is None else lo.data_ptr(), 0))
+                              nttot, hi.data_ptr(), 0 if lo is None else lo.data_ptr(), 0) + bias_fields)
             for sub in ([] if r.uses_zm() else r.subs):
                 if sub.get("ktab_zr") is not None:
                     items.append((w.data_ptr(), r.op.w_sco, r.op.w_sci, r.op.cout, r.op.cin, sub["kmap_zr"].data_ptr(), 15,
-                                  r.op.nttot, sub["hi_zr"].data_ptr(), 0, 0))
+                                  r.op.nttot, sub["hi_zr"].data_ptr(), 0, 0, 0, 0, 0, 0))
         arr = np.array(items, dtype=_PREP_ITEM)
         dev = torch.from_numpy(arr.view(np.uint8).copy()).to(todo[0][1].device)
         maxb = max((int(it[6]) * int(it[7]) * 64 + 255) // 256 for it in items)
         tab = _prep_tables[tkey] = (dev, len(items), maxb)
     dev, n, maxb = tab
     L.call("sp_conv_prep_weights_batch", dev.data_ptr(), n, maxb, stream())
-    for r, _, key in todo:
+    for r, _, b, key in todo:
         r._st["prep_key"] = key
+        if b is not None:
+            r.has_bias = True
 
 
 def _dbias_stride(dbias_sums):

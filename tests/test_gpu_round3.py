@@ -281,7 +281,7 @@ def test_cae_batched_passes_equal_sequential_passes(dtype):
     ch = [1, 16, 24, 32, 100, 200, 1]
     a = _cae_step(ch, 23, 28, 64, dtype, 0, batched=0)
     b = _cae_step(ch, 23, 28, 64, dtype, 0, batched=1)
-    tol = dict(f32=(1e-4, 1e-5, 2e-5, 5e-4), bf16=(6e-2, 4e-3, 5e-3, 0.12))[dtype]
+    tol = dict(f32=(1e-4, 1e-5, 2e-5, 2e-3), bf16=(6e-2, 4e-3, 5e-3, 0.12))[dtype]
     for k in a[0]:
         d = (a[0][k] - b[0][k]).abs()
         assert float(d.max()) <= tol[0] and float(d.mean()) <= tol[1], (k, float(d.max()), float(d.mean()))
