@@ -41,6 +41,34 @@ def _batch_strided(x):
     return x, (x.stride(0) if x.shape[0] > 1 else inner)
 
 
+class _GlobalMeanFn(torch.autograd.Function):
+    """mean over the GLOBAL batch in the exact data-parallel mode: local sum, all-reduce, / (elements x world); the backward
+    hands every local element 1 / (elements x world) of the upstream gradient -- the local backward then yields this rank's
+    share of the gradient of the global mean, and the SUM of the flat gradient buffers is the whole-batch gradient."""
+
+    @staticmethod
+    def forward(ctx, t, world):
+        from stroke_prediction_amd.runtime.layers import _allreduce
+        s = t.sum(dtype=torch.float64).reshape(1)
+        _allreduce(s)
+        ctx.n, ctx.shape = t.numel() * world, t.shape
+        return (s[0] / ctx.n).to(t.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.n).expand(ctx.shape), None
+
+
+def batch_mean(t):
+    """``torch.mean`` of a per-sample tensor as the reference's single process sees it (the loss recipes of
+    CaeReconstructionLearner.py:58-67 average over the whole batch): the global mean when the exact data-parallel mode is on
+    (parallel.DataParallelSync(mode="exact")), the plain mean otherwise."""
+    from stroke_prediction_amd.runtime.layers import SYNC
+    if SYNC["on"] and SYNC["world"] > 1:
+        return _GlobalMeanFn.apply(t, SYNC["world"])
+    return torch.mean(t)
+
+
 class _DiceFn(torch.autograd.Function):
     """loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps); sums over batch and volume per channel.  Three HIP
     launches forward (sums, finalize) and one backward; the scalar algebra never leaves the device."""

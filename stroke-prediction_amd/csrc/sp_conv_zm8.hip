@@ -2,7 +2,7 @@
 // (BASELINE.json configs[4]: "4-scale U-Net ... fp8 MFMA"; topology Unet3D.py:87-146) on v_mfma_f32_16x16x128_f8f6f4.
 //
 // Replaces nn.Conv3d(3, padding 0) forward and its data gradient (Unet3D.py:19,22) for layers between whole 16-channel planes
-// with 32 <= Cin <= 96.  Same march as csrc/sp_conv_zm.hip (read that header first): a workgroup owns a column of NW*MT x 16
+// with 32 <= Cin <= 128.  Same march as csrc/sp_conv_zm.hip (read that header first): a workgroup owns a column of NW*MT x 16
 // output voxels and walks the INPUT planes; plane i is staged ONCE by LDS-DMA into a ring and feeds the three output planes
 // i, i-1, i-2 held in four rotating accumulator sets.  What changes with one-byte operands:
 //
@@ -370,6 +370,7 @@ extern "C" int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t*
   else if (P == 4 && NT == 2) { mt = 2; }
   else if (P == 4 && NT == 1) { mt = 4; }
   else if (P == 6 && NT == 2) { mt = 2; ns = 2; }
+  else if (P == 8 && NT == 1) { mt = 4; ns = 2; nw = 4; }      // 128 input channels: 9 full K steps, one output tile per launch (weights 54 KiB, two 48 KiB slots)
   if (MT) *MT = mt;
   if (NSLOT) *NSLOT = ns;
   if (NW) *NW = nw;
@@ -402,6 +403,7 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
   if (P == 4 && a->NT == 2) return launch_zm8<4, 2, 2, 3, 8>(a, zeros, st);
   if (P == 4 && a->NT == 1) return launch_zm8<4, 1, 4, 3, 8>(a, zeros, st);
   if (P == 6 && a->NT == 2) return launch_zm8<6, 2, 2, 2, 8>(a, zeros, st);
+  if (P == 8 && a->NT == 1) return launch_zm8<8, 1, 4, 2, 4>(a, zeros, st);
   return SP_EINVAL;
 }
 

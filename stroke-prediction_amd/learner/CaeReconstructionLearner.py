@@ -53,12 +53,12 @@ class CaeReconstructionLearner(Learner, CaeInference):
         rec, gt, lat = dto.reconstructions.gtruth, dto.given_variables.gtruth, dto.latents.gtruth
         diff_penu_fuct = rec.penu - rec.interpolation
         diff_penu_core = rec.penu - rec.core
-        loss = torch.mean(torch.abs(diff_penu_fuct) - diff_penu_fuct)
-        loss = loss + torch.mean(torch.abs(diff_penu_core) - diff_penu_core)
+        loss = metrics.batch_mean(torch.abs(diff_penu_fuct) - diff_penu_fuct)      # (= torch.mean outside the exact data-parallel mode)
+        loss = loss + metrics.batch_mean(torch.abs(diff_penu_core) - diff_penu_core)
         loss = loss + self._criterion(rec.core, gt.core)
         loss = loss + self._criterion(rec.penu, gt.penu)
         loss = loss + self._criterion(rec.lesion, gt.lesion)
-        loss = loss + factor * torch.mean(torch.abs(lat.interpolation - lat.lesion))
+        loss = loss + factor * metrics.batch_mean(torch.abs(lat.interpolation - lat.lesion))
         return loss / (5 + factor)
 
     def batch_metrics_step(self, dto: CaeDto, epoch):

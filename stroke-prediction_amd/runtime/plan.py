@@ -415,7 +415,7 @@ def zm_plan(op: ConvOp):
 # ------------------------------------------------------------------------------------------------ fp8 z-marching plan
 # csrc/sp_conv_zm8.hip: (P planes of 16 fp8 input channels, NT output tiles) -> (MT rows per wave, ring slots, waves).
 # Mirrors sp_conv3d_zm8_config (tests/test_cabi.py).
-ZM8_CONFIGS = {(2, 2): (2, 3, 8), (2, 1): (4, 3, 8), (4, 2): (2, 3, 8), (4, 1): (4, 3, 8), (6, 2): (2, 2, 8)}
+ZM8_CONFIGS = {(2, 2): (2, 3, 8), (2, 1): (4, 3, 8), (4, 2): (2, 3, 8), (4, 1): (4, 3, 8), (6, 2): (2, 2, 8), (8, 1): (4, 2, 4)}
 
 
 def zm8_plan(op: ConvOp):
@@ -457,11 +457,13 @@ def zm8_slices(op: ConvOp):
     import dataclasses
     if zm8_plan(op) is not None:
         return [(0, op.cout, op)]
-    if op.dtype != 0 or op.cout % 16 or op.cpi % 16 or (op.cpi // 16, 2) not in ZM8_CONFIGS:
+    P_ = op.cpi // 16
+    width = 32 if (P_, 2) in ZM8_CONFIGS else (16 if (P_, 1) in ZM8_CONFIGS else 0)      # output channels per launch
+    if op.dtype != 0 or op.cout % 16 or op.cpi % 16 or not width:
         return None
     out, c0 = [], 0
     while c0 < op.cout:
-        cn = min(32, op.cout - c0)
+        cn = min(width, op.cout - c0)
         sub_op = dataclasses.replace(op, cout=cn)
         if zm8_plan(sub_op) is None:
             return None

@@ -83,3 +83,80 @@ def test_exact_mode_two_ranks_equal_single_process():
     # gradient norm by 1/(number of output voxels).  52^3 inputs (12^3 outputs) keep that below 1e-2; typical 1e-4.
     assert res["grad"] < 3e-2, res
     assert res["rm"] < 1e-4 and res["rv"] < 1e-3, res
+
+
+def _run_cae(rank, world, port, q):
+    """the same for the CAE: per-pass BatchNorm sums of every encoder / decoder call (batched: [passes][replicas][C][2]) and
+    the Dice sums are all-reduced, so two ranks with two samples each reproduce the four-sample single-process step"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stroke_prediction_amd  # noqa: F401
+    from oracle import weights as W
+    from stroke_prediction_amd.common.model.Cae3D import Cae3D, Enc3D, Dec3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.CaeReconstructionLearner import CaeReconstructionLearner
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    from stroke_prediction_amd.parallel import DataParallelSync
+    dev = "cuda:0"
+    ch = [1, 16, 24, 32, 100, 200, 1]
+    d, hw, seed = 28, 64, 23
+    labels, clinical = W.cae_inputs(4, d, hw, seed)
+
+    class Loader(list):
+        batch_size = 2
+
+    def fresh():
+        cae = Cae3D(Enc3D(hw, d, ch, 5, 1.0, dtype="f32"), Dec3D(hw, d, ch, 5, 1.0, dtype="f32"))
+        cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+        return cae.to(dev).train()
+
+    def run(cae, lab, cli):
+        opt = FusedAdam(list(cae.parameters()), lr=1e-3)
+        attach_flat_grads(cae)
+        learner = CaeReconstructionLearner(Loader(), None, cae, opt, None, 1, None, "/tmp/_cae_exact", BatchDiceLoss([1.0]),
+                                           verbose=False, batch_metrics=False)
+        dto = learner.inference_step({"case_id": [0, 1], "images": None, "labels": lab.to(dev), "clinical": cli.to(dev)})
+        loss = learner.loss_step(dto, 30)
+        opt.zero_grad()
+        loss.backward()
+        rec = torch.cat([getattr(dto.reconstructions.gtruth, k).detach() for k in ("core", "penu", "lesion", "interpolation")], 1).cpu()
+        return rec, float(loss.detach()), cae.flat_buffers()[1].clone().cpu(), {n: b.detach().cpu().clone() for n, b in cae.named_buffers()}
+
+    ref = run(fresh(), labels, clinical) if rank == 0 else None
+    dist.barrier()
+    cae = fresh()
+    sync = DataParallelSync(cae, mode="exact")
+    lo, hi = rank * 2, rank * 2 + 2
+    rec, loss, grad, bufs = run(cae, labels[lo:hi], clinical[lo:hi])
+    cae._after_backward()
+    grad = cae.flat_buffers()[1].clone().cpu()
+    sync.close()
+    if rank == 0:
+        rrec, rloss, rgrad, rbufs = ref
+        q.put(dict(rec=float((rec - rrec[lo:hi]).abs().max()), loss=abs(loss - rloss), grad=float((grad - rgrad).norm() / rgrad.norm()),
+                   rm=max(float((bufs[n] - rbufs[n]).abs().max()) for n in bufs if n.endswith("running_mean")),
+                   rv=max(float((bufs[n] - rbufs[n]).abs().max() / (rbufs[n].abs().max() + 1e-6)) for n in bufs if n.endswith("running_var"))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exact_mode_cae_two_ranks_equal_single_process():
+    """the exact data-parallel mode of the CAE (per-pass BatchNorm sums of the batched encoder / decoder
+    calls, Dice sums) -- two gloo ranks on the one GPU against one process with the whole batch"""
+    world, port = 2, 29751
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_run_cae, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    print("exact-mode CAE, 2 ranks vs 1 process:", res)
+    assert res["rec"] < 2e-4 and res["loss"] < 2e-5, res
+    assert res["grad"] < 2e-2, res
+    assert res["rm"] < 1e-4 and res["rv"] < 1e-3, res
