@@ -287,14 +287,19 @@ def roofline_from(agg, per_layer, nsteps, ms_per_step, dtype, layers_to=None, tr
     dom = max(agg, key=lambda k: agg[k][0])
     t, fl, n = agg[dom]
     peak = PEAK_TFLOPS[dtype]
-    traffic = None
-    try:    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/*.md)
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f)[traffic_key or dom]["bytes_per_launch"]
-    except Exception:
-        pass
+    traffic, traffic_source = None, None
+    if traffic_key:     # HBM bytes per launch from the committed rocprofv3 --pmc passes of THIS workload (FETCH_SIZE x2 + WRITE_SIZE,
+        try:            # profiles/*_pmc_traffic.md; regenerated by tools/profile_round.sh) -- null for workloads without such a pass
+            tj = os.path.join(ROOT, "profiles", "traffic.json")
+            with open(tj) as f:
+                d = json.load(f)
+            traffic = d[traffic_key]["bytes_per_launch"]
+            traffic_source = {"file": "profiles/traffic.json", "mtime": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(tj))),
+                              "passes": d.get("_source" + ("_cae" if traffic_key.startswith("cae_") else ""), "")[:160]}
+        except Exception:
+            pass
     roof = {"bound": "mfma", "kernel": dom, "achieved": fl / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-            "frac": fl / t / 1e12 / peak, "traffic": traffic, "launches": n, "avg_launch_us": 1e6 * t / n,
+            "frac": fl / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_source, "launches": n, "avg_launch_us": 1e6 * t / n,
             "share_of_step": (t / nsteps) / (ms_per_step * 1e-3),
             "flops": "algorithmic: 2 x taps x Cin x Cout per output voxel of the convolution (data gradients: the forward's output voxels)",
             "timing": "HIP events on the launch stream around every launch, %d eager steps" % nsteps}
@@ -443,7 +448,8 @@ def bench_unet(args, world, rank, dev, four_scale=False):
     if not args.no_kernel_timing:
         nprof = min(args.steps, 3)
         agg, per_layer = kernel_profile(lambda: learner._optimise(batch, 0), nprof, world)
-        roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None)
+        tkey = "conv_igemm" if (not four_scale and args.dtype == "bf16" and args.size == 128 and args.batch == 4) else None
+        roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None, traffic_key=tkey)
         if roof:
             res["roofline"], res["kernels"] = roof, kernels
             if not four_scale and args.dtype == "bf16":
@@ -583,7 +589,8 @@ def bench_cae(args, world, rank, dev):
     if not args.no_kernel_timing:
         nprof = min(args.steps, 3)
         agg, per_layer = kernel_profile(lambda: learner._optimise(batch, epoch), nprof, world)
-        roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None, traffic_key="cae_conv_igemm")
+        roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None,
+                                      traffic_key="cae_conv_igemm" if (d == 28 and args.batch == 4 and args.dtype == "bf16") else None)
         if roof:
             res["roofline"], res["kernels"] = roof, kernels
         if d in CAE_TRAIN_GFLOP_PER_SAMPLE:
