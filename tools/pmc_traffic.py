@@ -40,4 +40,9 @@ for name, pats in fam.items():
     out[prefix + name] = {"launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "bytes_per_launch": (fb + wb) / n}
 out["_source" + ("_" + prefix.rstrip("_") if prefix else "")] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python %s`; FETCH_SIZE doubled per the gfx950 correction; see profiles/%s_pmc_traffic.md" % (workload, tag)
 json.dump(out, open(tj, "w"), indent=1)
+# the GPU box returns gpurun_out/ only: leave copies there (copy them into profiles/ after the call)
+go = os.path.join(ROOT, "gpurun_out")
+if os.path.isdir(go):
+    open(os.path.join(go, "%s_pmc_traffic.md" % tag), "w").write("\n".join(lines) + "\n")
+    json.dump(out, open(os.path.join(go, "traffic_%s.json" % tag), "w"), indent=1)
 print("\n".join(lines[:16])); print(json.dumps(out, indent=1))
