@@ -151,6 +151,24 @@ int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int
 int sp_conv_prep_f8(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,
                     int32_t nsteps, int32_t NT, void* wfrag, const float* fold_scale, const float* fold_shift,
                     int32_t ntaps, const float* bias, float* bias_out, float* winv, float out_scale, sp_stream_t stream);
+/* the same for n weight tensors / output-channel slices in ONE launch (a sliced op packs one item per slice; the data-gradient
+ * weights of a whole network depend on the parameters only).  items_dev: DEVICE array; max_rows = max over the items of NT*16. */
+typedef struct sp_f8_prep_item {
+  const float* w;
+  int64_t sCo, sCi;
+  int32_t Cout, Cin;
+  const int32_t* kmap;
+  int32_t nsteps, NT;
+  void* wfrag;
+  const float* fold_scale;   /* or NULL */
+  const float* fold_shift;   /* or NULL */
+  const float* bias;         /* or NULL */
+  float* bias_out;           /* or NULL */
+  float* winv;
+  int32_t ntaps;
+  float out_scale;
+} sp_f8_prep_item;
+int sp_conv_prep_f8_batch(const sp_f8_prep_item* items_dev, int32_t n, int32_t max_rows, sp_stream_t stream);
 /* dst = fp8(scale * src): src bf16 channels-last [nvox][CP] (src_plane = 0) or plane-major [CP/16][..][16] (src_plane =
  * elements per plane); dst plane-major [CP/16][nvox][16 bytes] with dst_plane bytes per plane; fmt 0 = e4m3 (saturating at
  * 448), 1 = e5m2 (57344).  The operand of sp_conv3d_zm8 where no producer wrote it (pooled / concatenated tensors, dz). */

@@ -410,14 +410,14 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
 // ---------------------------------------------------------------------------------------------------- weights
 // One workgroup per output channel: amax of the folded row -> power-of-two scale -> e4m3 fragments, the folded bias
 // (exact, from the fp32 weights) and the dequantisation multiplier.
-__global__ __launch_bounds__(256) void prep_f8_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
-                                                       const int32_t* __restrict__ kmap, int nsteps, int NT, unsigned char* __restrict__ wfrag,
-                                                       const float* __restrict__ fold, const float* __restrict__ shift, int ntaps,
-                                                       const float* __restrict__ bias, float* __restrict__ bias_out, float* __restrict__ winv,
-                                                       float out_scale) {
+__device__ __forceinline__ void prep_f8_row(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
+                                            const int32_t* __restrict__ kmap, int nsteps, int NT, unsigned char* __restrict__ wfrag,
+                                            const float* __restrict__ fold, const float* __restrict__ shift, int ntaps,
+                                            const float* __restrict__ bias, float* __restrict__ bias_out, float* __restrict__ winv,
+                                            float out_scale, int co) {
   __shared__ float red[8];
   __shared__ float sh_scale;
-  const int co = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   float amax = 0.f, bsum = 0.f;
   if (co < Cout)
     for (int i = tid; i < Cin * ntaps; i += 256) {
@@ -455,6 +455,26 @@ __global__ __launch_bounds__(256) void prep_f8_kernel(const float* __restrict__ 
     const size_t f = (size_t)step * NT + (co >> 4);
     wfrag[f * 2048 + h * 1024 + ((g << 4) | (co & 15)) * 16 + c] = (unsigned char)(r & 0xff);
   }
+}
+
+__global__ __launch_bounds__(256) void prep_f8_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
+                                                       const int32_t* __restrict__ kmap, int nsteps, int NT, unsigned char* __restrict__ wfrag,
+                                                       const float* __restrict__ fold, const float* __restrict__ shift, int ntaps,
+                                                       const float* __restrict__ bias, float* __restrict__ bias_out, float* __restrict__ winv,
+                                                       float out_scale) {
+  prep_f8_row(w, sCo, sCi, Cout, Cin, kmap, nsteps, NT, wfrag, fold, shift, ntaps, bias, bias_out, winv, out_scale, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void prep_f8_batch_kernel(const sp_f8_prep_item* __restrict__ items) {
+  const sp_f8_prep_item it = items[blockIdx.y];
+  if ((int)blockIdx.x >= it.NT * 16) return;
+  prep_f8_row(it.w, it.sCo, it.sCi, it.Cout, it.Cin, it.kmap, it.nsteps, it.NT, reinterpret_cast<unsigned char*>(it.wfrag), it.fold_scale,
+              it.fold_shift, it.ntaps, it.bias, it.bias_out, it.winv, it.out_scale, blockIdx.x);
+}
+extern "C" int sp_conv_prep_f8_batch(const sp_f8_prep_item* items_dev, int32_t n, int32_t max_rows, sp_stream_t stream) {
+  SP_CHECK_ARG(items_dev && n >= 1 && n <= 65535 && max_rows >= 16, "sp_conv_prep_f8_batch: bad arguments");
+  hipLaunchKernelGGL(prep_f8_batch_kernel, dim3((unsigned)max_rows, (unsigned)n), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), items_dev);
+  SP_CHECK_LAUNCH("sp_conv_prep_f8_batch");
+  return SP_OK;
 }
 
 extern "C" int sp_conv_prep_f8(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,

@@ -26,6 +26,49 @@ DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient conv
 DZ_FMT = E5M2 if os.environ.get("SP_F8_DZ", "e5m2") == "e5m2" else E4M3      # storage format of the quantised output gradients
 
 
+_F8_ITEM = np.dtype([("w", "<u8"), ("sCo", "<i8"), ("sCi", "<i8"), ("Cout", "<i4"), ("Cin", "<i4"), ("kmap", "<u8"), ("nsteps", "<i4"), ("NT", "<i4"),
+                     ("wfrag", "<u8"), ("fold_scale", "<u8"), ("fold_shift", "<u8"), ("bias", "<u8"), ("bias_out", "<u8"), ("winv", "<u8"),
+                     ("ntaps", "<i4"), ("out_scale", "<f4")])      # sp_f8_prep_item
+_tables = {}
+
+
+def prep_many(jobs):
+    """e4m3 weight fragments of several ConvRunnerF8 (all their output-channel slices) in ONE launch.
+    jobs: [(runner, w, b, fold_scale, fold_shift, out_scale)]; jobs whose fragments are current are skipped."""
+    todo = []
+    for r, w, b, fs, fsh, osc in jobs:
+        key = None if fs is not None else (w.data_ptr(), w._version, O.PARAM_EPOCH[0], float(osc))
+        if key is None or r._key != key:
+            todo.append((r, w, b, fs, fsh, osc, key))
+    if not todo:
+        return
+    tkey = tuple((w.data_ptr(), 0 if b is None else b.data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, float(osc), r.bias.data_ptr(), r.winv.data_ptr()) +
+                 tuple(s["wfrag"].data_ptr() for s in r.slices) for r, w, b, fs, fsh, osc, _ in todo)
+    tab = _tables.get(tkey)
+    if tab is None:
+        if len(_tables) > 256:
+            _tables.clear()
+        items = []
+        for r, w, b, fs, fsh, osc, _ in todo:
+            op = r.op
+            assert w.dtype == torch.float32 and w.is_contiguous()
+            ntaps = w.numel() // (op.cin * op.cout)
+            want_bias = b is not None or fsh is not None
+            for s in r.slices:
+                c0 = s["c0"]
+                items.append((w.data_ptr() + 4 * c0 * op.w_sco, op.w_sco, op.w_sci, s["cn"], op.cin, s["kmap_d"].data_ptr(), s["nsteps"], s["NT"],
+                              s["wfrag"].data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, 0 if b is None else b.data_ptr() + 4 * c0,
+                              (r.bias.data_ptr() + 4 * c0) if want_bias else 0, r.winv.data_ptr() + 4 * c0, ntaps, float(osc)))
+        arr = np.array(items, dtype=_F8_ITEM)
+        dev = torch.from_numpy(arr.view(np.uint8).copy()).to(todo[0][1].device)
+        tab = _tables[tkey] = (dev, len(items), max(int(it[7]) * 16 for it in items))
+    dev, n, rows = tab
+    L.call("sp_conv_prep_f8_batch", dev.data_ptr(), n, rows, O.stream())
+    for r, w, b, fs, fsh, osc, key in todo:
+        r._key = key
+        r.has_bias = b is not None or fsh is not None
+
+
 def alloc_f8(batch, dims, cp, device):
     """plane-major fp8 tensor [cp/16][B][D][H][W][16 bytes]"""
     assert cp % 16 == 0
@@ -75,24 +118,7 @@ class ConvRunnerF8:
     def prep(self, w, b=None, fold_scale=None, fold_shift=None, out_scale=1.0):
         """e4m3 fragments of w (x fold_scale per input channel), folded bias, per-channel dequantisation multipliers
         (x out_scale: the reciprocal of the scale the B operand was quantised with)."""
-        op = self.op
-        assert w.dtype == torch.float32 and w.is_contiguous()
-        if fold_scale is None:      # depends on the weights only: keyed like ConvRunner.prep
-            key = (w.data_ptr(), w._version, O.PARAM_EPOCH[0], float(out_scale))
-            if self._key == key:
-                return
-            self._key = key
-        else:
-            self._key = None
-        ntaps = w.numel() // (op.cin * op.cout)
-        want_bias = b is not None or fold_shift is not None
-        for s in self.slices:
-            c0 = s["c0"]
-            L.call("sp_conv_prep_f8", w.data_ptr() + 4 * c0 * op.w_sco, op.w_sco, op.w_sci, s["cn"], op.cin, O.ptr(s["kmap_d"]),
-                   s["nsteps"], s["NT"], O.ptr(s["wfrag"]), O.ptr(fold_scale), O.ptr(fold_shift), ntaps,
-                   None if b is None else b.data_ptr() + 4 * c0, (self.bias.data_ptr() + 4 * c0) if want_bias else None,
-                   self.winv.data_ptr() + 4 * c0, float(out_scale), O.stream())
-        self.has_bias = want_bias
+        prep_many([(self, w, b, fold_scale, fold_shift, out_scale)])      # one launch for all slices
 
     def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
         op, batch = self.op, self.batch

@@ -89,6 +89,7 @@ _SIGS = {
     "sp_conv3d_zm8_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
     "sp_conv_prep_f8": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, f32, vp], i32),
     "sp_quantize_f8": ([vp, i32, i64, vp, i64, i64, i32, f32, vp], i32),
+    "sp_conv_prep_f8_batch": ([vp, i32, i32, vp], i32),
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv_prep_folded": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp], i32),

@@ -310,6 +310,10 @@ class UnetEngine:
         with pre:      # ... and ONE launch for all of them
             O.prep_batch([(l.dgrad, params[l.conv_prefix + ".weight"]) for l in self.layers
                           if getattr(l, "dgrad", None) is not None and l.need_input_grad and l.f8_dgrad is None])
+            f8l = [l for l in self.layers if l.f8_dgrad is not None]
+            if f8l:      # ... and ONE for the e4m3 fragments of every fp8 data gradient
+                from . import f8 as F8
+                F8.prep_many([(l.f8_dgrad, params[l.conv_prefix + ".weight"], None, None, None, 1.0 / l.f8_grad_scale) for l in f8l])
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
             b5, bc, ncls = self.channels[-3], self.channels[-2], self.ncls

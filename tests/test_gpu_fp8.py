@@ -204,7 +204,8 @@ def test_unet4_fp8_mode_matches_the_fp8_emulating_oracle():
     # below, the consistency of forward and backward by the directional-derivative test.
     for k, p in model.named_parameters():
         a, b = p.grad.detach().cpu().double(), g_ref[k].double()
-        assert 0.3 < float(a.norm() / (b.norm() + 1e-30)) < 3.0, (k, float(a.norm()), float(b.norm()))
+        lim = 3.0 if a.numel() > 64 else 10.0      # (2..64-element BatchNorm / bias gradients: sums with total cancellation, see test_gpu_unet.py)
+        assert 1.0 / lim < float(a.norm() / (b.norm() + 1e-30)) < lim, (k, float(a.norm()), float(b.norm()))
 
 
 @pytest.mark.parametrize("fname", ["unet4_92.npz", "unet4_92x100x96.npz"])
