@@ -315,6 +315,26 @@ int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc,
                            int32_t bn_cp /* channel pitch of a bn_sums replica; <= 0: CiP */,
                            int32_t dbias_stride /* row pitch of the SP_REDUCE_ROWS replica rows of dbias_sums; <= 0: one row */,
                            sp_stream_t stream);
+/* the same with dw_acc multiplied by acc_scale first (sp_conv3d_wgrad_f8: the accumulators carry the scale of the quantised dz) */
+int sp_wgrad_finish_folded_scaled(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                                  int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale, const float* shift,
+                                  const double* dbias_sums, float* dw, float* dbias_grad, const float* w_for_bn, double* bn_sums,
+                                  int32_t bn_nrep, int32_t bn_cp, int32_t dbias_stride, float acc_scale, sp_stream_t stream);
+/* fp8 weight gradient of nn.Conv3d(3, stride 1, padding 0) (Unet3D.py:19,22; csrc/sp_wgrad_f8.hip): x = the conv's input as
+ * a plane-major e4m3 tensor [CiT][B][Di][Hi][Wi][16 bytes], dz = the output gradient as a plane-major e5m2 tensor
+ * [CoT][B][Do][Ho][Wo][16 bytes] (quantised with a power-of-two scale S); CoT, CiT even.  Each of the nblocks persistent
+ * workgroups WRITES one block [27][CoT*16][CiT*16] fp32 of dw_acc = S * partial sum; sp_wgrad_finish_folded_scaled(acc_scale =
+ * 1/S) adds them up (and yields the BatchNorm-backward sums as for the bf16 kernels). */
+typedef struct sp_wgrad_f8_args {
+  const void* x;
+  const void* dz;
+  float* dw_acc;
+  int32_t B, Di, Hi, Wi, Do, Ho, Wo;
+  int32_t CoT, CiT;          /* cout / cin tiles of 16 */
+  int32_t nblocks;           /* grid.x: persistent workgroups per 32 x 32 channel block */
+  int64_t x_plane, dz_plane; /* bytes per 16-channel plane */
+} sp_wgrad_f8_args;
+int sp_conv3d_wgrad_f8(const sp_wgrad_f8_args* a, sp_stream_t stream);
 /* bn_sums != NULL (first layer of a network: no input gradient wanted, so no data-gradient convolution is run):
  * also accumulate the BatchNorm-backward sums of the layer's input,  bn_sums[rep][ci][0] += sum_v g  and
  * bn_sums[rep][ci][1] += sum_v g*x  with g = conv_transpose(dz, w_for_bn), computed from the weight-gradient

@@ -554,7 +554,8 @@ __global__ __launch_bounds__(32 * RL) void wgrad_finish_folded_parts_kernel(cons
                                                                         const double* __restrict__ dbias,
                                                                         float* __restrict__ dw, float* __restrict__ dbias_grad,
                                                                         const float* __restrict__ wbn,
-                                                                        double* __restrict__ bn_sums, int bn_nrep, int bn_cp, int dbs) {
+                                                                        double* __restrict__ bn_sums, int bn_nrep, int bn_cp, int dbs,
+                                                                        float acc_scale) {
   __shared__ float red[RL][33];
   const int64_t total = (int64_t)ntap * CoP * CiP;
   const int64_t gid = (int64_t)blockIdx.x * (32 * RL) + threadIdx.x;
@@ -577,6 +578,7 @@ __global__ __launch_bounds__(32 * RL) void wgrad_finish_folded_parts_kernel(cons
   float v = 0.f;
 #pragma unroll
   for (int i = 0; i < RL; ++i) v += red[i][el];
+  v *= acc_scale;                  // (fp8 weight gradient: the accumulators carry the power-of-two scale of the quantised dz)
   const int ci = idx % CiP;
   const int co = (idx / CiP) % CoP;
   const int t = idx / ((int64_t)CiP * CoP);
@@ -594,7 +596,7 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                            const double* __restrict__ dbias, float* __restrict__ dw,
                                            float* __restrict__ dbias_grad, const float* __restrict__ wbn,
-                                           double* __restrict__ bn_sums, int bn_nrep, int bn_cp, int dbs) {
+                                           double* __restrict__ bn_sums, int bn_nrep, int bn_cp, int dbs, float acc_scale) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)ntap * CoP * CiP;
   if (dbias_grad && idx < Cout) dbias_grad[idx] += (float)sp_rows_sum(dbias, (int)idx, dbs);
@@ -602,7 +604,7 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
   const int ci = idx % CiP;
   const int co = (idx / CiP) % CoP;
   const int t = idx / ((int64_t)CiP * CoP);
-  const float v = acc[idx];
+  const float v = acc[idx] * acc_scale;
   acc[idx] = 0.f;
   if (co < Cout && ci < Cin) {
     const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
@@ -612,10 +614,11 @@ __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_
   }
 }
 
-extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
-                                      int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
-                                      const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
-                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, int32_t dbias_stride, sp_stream_t stream) {
+static int wgrad_finish_folded_impl(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                                    int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
+                                    const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
+                                    const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, int32_t dbias_stride,
+                                    float acc_scale, sp_stream_t stream) {
   SP_CHECK_ARG(dw_acc && tapsrc && dw && scale && shift && dbias_sums && Cout <= CoP && Cin <= CiP, "sp_wgrad_finish_folded: bad arguments");
   const int64_t total = (int64_t)ntap * CoP * CiP;
   SP_CHECK_ARG(nparts >= 1 && Cout <= (total + 31) / 32 * 256, "sp_wgrad_finish_folded: nparts");      // (dbias_grad: one thread per output channel)
@@ -625,17 +628,33 @@ extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32
     if (nparts >= 128)
       hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel<32>, dim3((unsigned)((total + 31) / 32)), dim3(1024), 0,
                          reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
-                         scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride);
+                         scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride, acc_scale);
     else
       hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0,
                          reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi,
-                         scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride);
+                         scale, shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride, acc_scale);
     SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
     return SP_OK;
   }
   hipLaunchKernelGGL(wgrad_finish_folded_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), dw_acc, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale,
-                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride);
+                     shift, dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride, acc_scale);
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
   return SP_OK;
+}
+extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                                      int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
+                                      const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
+                                      const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, int32_t dbias_stride, sp_stream_t stream) {
+  return wgrad_finish_folded_impl(dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale, shift, dbias_sums, dw, dbias_grad,
+                                  w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride, 1.f, stream);
+}
+extern "C" int sp_wgrad_finish_folded_scaled(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
+                                             int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
+                                             const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,
+                                             const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, int32_t dbias_stride,
+                                             float acc_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(acc_scale > 0.f, "sp_wgrad_finish_folded_scaled: acc_scale");
+  return wgrad_finish_folded_impl(dw_acc, nparts, tapsrc, ntap, CoP, CiP, Cout, Cin, sCo, sCi, scale, shift, dbias_sums, dw, dbias_grad,
+                                  w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride, acc_scale, stream);
 }

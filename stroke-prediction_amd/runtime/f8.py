@@ -23,6 +23,7 @@ from . import plan as P
 F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "1024"))     # (column, plane) pairs below which the march is all prologue
 E4M3, E5M2 = 0, 1
 DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient convolutions on the fp8 kernel too (0: forward only)
+WGRAD = bool(int(os.environ.get("SP_F8_WGRAD", "1")))       # weight gradients of the fp8 layers on fp8 operands as well (0: from the bf16 tensors)
 DZ_FMT = E5M2 if os.environ.get("SP_F8_DZ", "e5m2") == "e5m2" else E4M3      # storage format of the quantised output gradients
 
 
@@ -162,6 +163,62 @@ class ConvRunnerF8:
                           "%d->%d @%s zm8 %s%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), "e5m2" if self.bin else "e4m3",
                                                      " slices" if len(self.slices) > 1 else "", " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_zm8", C.byref(a), O.ptr(O.zero_page(self.device)), st)
+
+
+class WgradRunnerF8:
+    """Weight gradient of a stride-1 un-padded 3x3x3 convolution on the fp8 operands the forward (x8: e4m3 copy of the raw
+    input) and the data gradient (dz8: e5m2 copy of S * dz) already hold (``sp_conv3d_wgrad_f8``).  Rides on the layer's bf16
+    ``ops.WgradRunner`` for everything but the kernel: the finish step is the folded one (BatchNorm of the input applied to
+    the accumulator, BatchNorm-backward sums out of it), called with acc_scale = 1 / S."""
+
+    BLOCK_UNITS = int(os.environ.get("SP_F8_WGRAD_UNITS", "8"))      # (column, plane) pairs a persistent workgroup wants at least
+
+    @staticmethod
+    def applicable(wg):
+        return bool(WGRAD and DZ_FMT == E5M2 and wg.dma and wg.unpadded and wg.cot % 2 == 0 and wg.cit % 2 == 0)
+
+    def __init__(self, wg):
+        assert WgradRunnerF8.applicable(wg)
+        self.wg = wg
+        self.acc = None
+        self.acc_batch = None
+        self.args = L.WgradF8Args()
+
+    def _alloc(self, batch):
+        wg, a = self.wg, self.args
+        w = wg.args
+        yz = (wg.cot // 2) * (wg.cit // 2)
+        units = batch * -(-w.Ho // 4) * -(-w.Wo // 32) * w.Do
+        nb = max(8, min(512 // yz, units // self.BLOCK_UNITS)) // 8 * 8
+        a.nblocks = self.nparts = int(os.environ.get("SP_F8_WGRAD_BLOCKS", nb))
+        self.acc = torch.empty(self.nparts * wg.ntap * wg.cot * 16 * wg.cit * 16, dtype=torch.float32, device=wg.device)
+        self.acc_batch = batch
+
+    def run(self, x8, dz8, batch, grad_scale, dw, in_scale, in_shift, dbias_sums, dbias_grad, bn_w=None, bn_sums=None, bn_nrep=1):
+        """launches the kernel; returns the finish step (a callable, as ``WgradRunner.run(defer_finish=True)``)"""
+        wg, a = self.wg, self.args
+        w = wg.args
+        assert x8.dtype == torch.uint8 and tuple(x8.shape) == (wg.cit, batch, w.Di, w.Hi, w.Wi, 16), (tuple(x8.shape), wg.cit)
+        assert dz8.dtype == torch.uint8 and tuple(dz8.shape) == (wg.cot, batch, w.Do, w.Ho, w.Wo, 16), (tuple(dz8.shape), wg.cot)
+        assert in_scale is not None and dbias_sums is not None
+        if self.acc is None or self.acc_batch != batch:
+            self._alloc(batch)
+        a.x, a.dz, a.dw_acc = O.ptr(x8), O.ptr(dz8), O.ptr(self.acc)
+        a.B = batch
+        a.Di, a.Hi, a.Wi, a.Do, a.Ho, a.Wo = w.Di, w.Hi, w.Wi, w.Do, w.Ho, w.Wo
+        a.CoT, a.CiT = wg.cot, wg.cit
+        a.x_plane = batch * w.Di * w.Hi * w.Wi * 16
+        a.dz_plane = batch * w.Do * w.Ho * w.Wo * 16
+        with O._Timed("conv_wgrad", 2 * batch * w.Do * w.Ho * w.Wo * wg.ntap * wg.cin * wg.cout,
+                      "%d->%d @%dx%dx%d f8" % (wg.cin, wg.cout, w.Di, w.Hi, w.Wi)):
+            L.call("sp_conv3d_wgrad_f8", C.byref(a), O.stream())
+
+        def finish():
+            L.call("sp_wgrad_finish_folded_scaled", O.ptr(self.acc), self.nparts, O.ptr(wg.tapsrc), wg.ntap, wg.cot * 16, wg.cit * 16,
+                   wg.cout, wg.cin, wg.w_sco, wg.w_sci, O.ptr(in_scale), O.ptr(in_shift), O.ptr(dbias_sums), O.ptr(dw),
+                   O.ptr(dbias_grad), O.ptr(bn_w), O.ptr(bn_sums), bn_nrep, 0, O._dbias_stride(dbias_sums), 1.0 / float(grad_scale),
+                   O.stream())
+        return finish
 
 
 def grad_scale_for(n_out_voxels):

@@ -123,7 +123,7 @@ class ConvLayer:
         self._bwd_ready = False
         self.y = None
         # fp8 execution (runtime/f8.py; enabled per layer by the engine in the "fp8" precision mode)
-        self.f8_fwd = self.f8_dgrad = None
+        self.f8_fwd = self.f8_dgrad = self.f8_wgrad = None
         self.f8_on = False
         self.x8 = self.y8 = self.dz8 = None
         self.dz8_ready = False      # set by the kernel that formed dz when it also wrote the fp8 copy (dz8_out)
@@ -145,7 +145,7 @@ class ConvLayer:
     def dz8_out(self):
         """(tensor, format, scale) for the fp8 shadow output of the kernel that forms this layer's dz, or None: the data
         gradient then needs no quantisation pass.  Call after _init_bwd."""
-        if self.f8_dgrad is None or not self.FUSE_Q8:
+        if (self.f8_dgrad is None and self.f8_wgrad is None) or not self.FUSE_Q8:
             return None
         from . import f8 as F8
         self.dz8_ready = True
@@ -271,6 +271,12 @@ class ConvLayer:
                 if F8.DGRAD and F8.ConvRunnerF8.applicable(dop, self.batch):
                     self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.DZ_FMT)
                     self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
+        if self.f8_fwd is not None and self.bn_from_wgrad:
+            from . import f8 as F8      # weight gradient from the fp8 copies both other convolutions of the layer use
+            if F8.WgradRunnerF8.applicable(self.wgrad):
+                self.f8_wgrad = F8.WgradRunnerF8(self.wgrad)
+                if self.dz8 is None:
+                    self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
         if self.bn_prefix is not None:
             self.coef = torch.zeros((self.G, 3, self.cpi) if self.G > 1 else (3, self.cpi), device=dev)
         self._bwd_ready = True
@@ -295,9 +301,15 @@ class ConvLayer:
         # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
         if self.bn_from_wgrad:
             bs = self.scratch.get(self.bsums_id)
-            run_wgrad = lambda: self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
-                                               dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
-                                               bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True, x_planar=self.x_planar)
+            if self.f8_wgrad is not None:
+                self._ensure_dz8()
+                run_wgrad = lambda: self.f8_wgrad.run(self.x8, self.dz8, self.batch, self.f8_grad_scale, grads[c + ".weight"],
+                                                      self.scale, self.shift, self.dbias_sums, grads[c + ".bias"],
+                                                      bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP)
+            else:
+                run_wgrad = lambda: self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
+                                                   dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
+                                                   bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True, x_planar=self.x_planar)
             whole = O.overlap_level() == 2      # the weight-gradient kernel itself runs beside the data gradient
             finish = None if whole else run_wgrad()
             # finish + BatchNorm-backward finalize on the side stream, beside the data-gradient convolution
@@ -309,6 +321,7 @@ class ConvLayer:
                 self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
             if self.need_input_grad:
                 self._run_dgrad(w)
+            self.dz8_ready = False
             f.join()
             return (self.g, self.coef) if self.need_input_grad else (None, None)
         # every other layer: the weight gradient (kernel + finish) is independent of the data gradient as well -- second
@@ -402,13 +415,17 @@ class ConvLayer:
         self._bn_bwd_finalize(bs, params, grads, STATS_NREP)
         return self.g, self.coef
 
+    def _ensure_dz8(self):
+        """dz8 = fp8(S * dz) unless the kernel that formed dz wrote it (dz8_out)"""
+        if not self.dz8_ready:
+            from . import f8 as F8
+            F8.quantize(self.dz, self.dz8, F8.DZ_FMT, self.f8_grad_scale)
+            self.dz8_ready = True
+
     def _run_dgrad(self, w):
         if self.f8_dgrad is not None:
-            from . import f8 as F8
             S = self.f8_grad_scale
-            if not self.dz8_ready:
-                F8.quantize(self.dz, self.dz8, F8.DZ_FMT, S)
-            self.dz8_ready = False
+            self._ensure_dz8()
             self.f8_dgrad.prep(w, out_scale=1.0 / S)
             self.f8_dgrad.run(self.dz8, self.g)
             return

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_plan.hip", "sp_comm.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_wgrad_f8.hip", "sp_plan.hip", "sp_comm.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32 = 0, 1
@@ -43,6 +43,11 @@ class WgradArgs(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "dz", "in_scale", "in_shift", "dz_scale", "dz_shift", "dw_acc", "taps")] + \
                [(n, i32) for n in ("dtype", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "sD", "sH", "sW",
                                    "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64), ("zs", i32)]
+
+
+class WgradF8Args(C.Structure):      # sp_wgrad_f8_args
+    _fields_ = [(n, vp) for n in ("x", "dz", "dw_acc")] + \
+               [(n, i32) for n in ("B", "Di", "Hi", "Wi", "Do", "Ho", "Wo", "CoT", "CiT", "nblocks")] + [("x_plane", i64), ("dz_plane", i64)]
 
 
 class ConvFcArgs(C.Structure):       # sp_conv_fc_args
@@ -96,6 +101,8 @@ _SIGS = {
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
     "sp_wgrad_finish": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, i32, vp], i32),
     "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
+    "sp_wgrad_finish_folded_scaled": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),
+    "sp_conv3d_wgrad_f8": ([C.POINTER(WgradF8Args), vp], i32),
     "sp_upsample2_crop_cat_fwd": ([vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, vp], i32),
     "sp_confusion_counts": ([vp, vp, f32, i64, vp, vp], i32),
     "sp_first_supported": ([i32, i32, i32], i32),

@@ -146,6 +146,60 @@ def test_fp8_data_gradient_matches_torch_on_quantised_operands(cin, cout, dims, 
     err = (got - ref).abs() / (ref.abs() + 0.5 * scale)
     assert float(err.max()) < 1.2e-2, float(err.max())
 
+# (cin, cout, input dims, batch): 32 x 32 channel blocks 1x1 .. 2x4, extents that are not multiples of the 4-row x 32-voxel
+# column (ragged rows, ragged and multiple x tiles), piece boundaries inside a column (more workgroups than columns)
+@pytest.mark.parametrize("cin,cout,dims,B", [(32, 32, (7, 10, 34), 2), (64, 32, (9, 23, 45), 1), (32, 64, (6, 14, 70), 2), (64, 64, (12, 37, 40), 1),
+                                             (128, 64, (5, 9, 21), 1), (32, 32, (40, 6, 12), 1)])
+def test_fp8_weight_gradient_matches_torch_on_quantised_operands(cin, cout, dims, B):
+    """dW = sum_v (e5m2(S dz) / S)[v] * (scale * e4m3(x) + shift)[v + tap] of nn.Conv3d(cin, cout, 3) (Unet3D.py:19,22) by
+    sp_conv3d_wgrad_f8 + sp_wgrad_finish_folded_scaled, with the BatchNorm-backward sums (sum g, sum g x) of the raw input"""
+    g_ = torch.Generator().manual_seed(cin * 5 + cout)
+    od = tuple(d - 2 for d in dims)
+    S = 2.0 ** 22
+    x = bf(torch.randn(B, cin, *dims, generator=g_) * 1.5 + 0.3)
+    dz = bf(torch.randn(B, cout, *od, generator=g_) * 3e-7 * torch.logspace(-1, 1, cout).view(1, -1, 1, 1, 1))
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g_) / math.sqrt(27 * cin)).to(DEV)
+    fs = (torch.rand(cin, generator=g_) + 0.5).to(DEV)
+    fsh = (torch.randn(cin, generator=g_) * 0.2).to(DEV)
+    wg = O.WgradRunner(cin, cout, 3, 1, 0, dims, od, cin, cout, cin * 27, 27, L.SP_BF16, DEV)
+    assert F8.WgradRunnerF8.applicable(wg)
+    run = F8.WgradRunnerF8(wg)
+    x8 = F8.alloc_f8(B, dims, cin, DEV)
+    dz8 = F8.alloc_f8(B, od, cout, DEV)
+    F8.quantize(_to_cl(x, cin), x8, F8.E4M3, 1.0)
+    F8.quantize(_to_cl(dz, cout), dz8, F8.E5M2, S)
+    dzq = (nets.round_e5m2(dz * S) / S).double()
+    xq = nets.round_e4m3(x).double()
+    dbs = torch.zeros(L.SP_REDUCE_ROWS, cout, dtype=torch.float64, device=DEV)
+    dbs[0] = dzq.sum(dim=(0, 2, 3, 4)).to(DEV)
+    dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    nrep = 4
+    bn = torch.zeros(nrep, cin, 2, dtype=torch.float64, device=DEV)
+    for _ in range(2):      # the accumulator blocks are written, not added to: a second run gives the same sums once more
+        run.run(x8, dz8, B, S, dw, fs, fsh, dbs, db, bn_w=w, bn_sums=bn.view(-1), bn_nrep=nrep)()
+    torch.cuda.synchronize()
+    xn = xq * fs.cpu().double().view(1, -1, 1, 1, 1) + fsh.cpu().double().view(1, -1, 1, 1, 1)
+    ref = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64)
+    raw = torch.zeros_like(ref)
+    for a in range(3):
+        for b_ in range(3):
+            for c in range(3):
+                ref[:, :, a, b_, c] = torch.einsum("bovyx,bivyx->oi", dzq, xn[:, :, a:a + od[0], b_:b_ + od[1], c:c + od[2]])
+                raw[:, :, a, b_, c] = torch.einsum("bovyx,bivyx->oi", dzq, xq[:, :, a:a + od[0], b_:b_ + od[1], c:c + od[2]])
+    got = dw.cpu().double() / 2
+    scale = float(ref.abs().mean())
+    err = (got - ref).abs() / (ref.abs() + 0.5 * scale)
+    assert float(err.max()) < 2e-3, float(err.max())       # exact products, fp32 accumulation in another order
+    np.testing.assert_allclose(db.cpu().double().numpy() / 2, dbs[0].cpu().numpy(), rtol=1e-5)
+    # BatchNorm-backward sums of the conv's input gradient g = conv_transpose(dz, W):  sum g = sum_taps W * sum dz,
+    # sum g x = sum_taps W * (sum dz x)  (runtime/layers.py: bn_from_wgrad)
+    s = bn.sum(0).cpu() / 2
+    sum_g = torch.einsum("oiabc,o->i", w.cpu().double(), dbs[0].cpu())
+    sum_gx = torch.einsum("oiabc,oiabc->i", w.cpu().double(), raw)
+    np.testing.assert_allclose(s[:, 0].numpy(), sum_g.numpy(), rtol=1e-4, atol=1e-6 * float(sum_g.abs().max()))
+    np.testing.assert_allclose(s[:, 1].numpy(), sum_gx.numpy(), rtol=2e-3, atol=2e-3 * float(sum_gx.abs().max()))
+
 
 def _f8_layer_names(model, x):
     eng = model._engine(x)
