@@ -73,14 +73,16 @@ def quant_weights_e4m3(wf):
 
 
 class _F8Conv(torch.autograd.Function):
-    """y = conv(e4m3(x), e4m3(w)) + b;  dx = conv^T(e5m2(S dy) / S, e4m3(w));  dw from the un-quantised x and dy (the weight
-    gradient of the fp8 mode is computed from the bf16 tensors)."""
+    """y = conv(e4m3(x), e4m3(w)) + b;  dx = conv^T(e5m2(S dy) / S, e4m3(w));  dw from the un-quantised x and dy (the bf16
+    weight-gradient kernels) or, with wgrad8, from the same fp8 copies: dw = sum e5m2(S dy) / S * e4m3(x)
+    (csrc/sp_wgrad_f8.hip) -- through the folded weights this is also where the BatchNorm-backward sums of x come from."""
 
     @staticmethod
-    def forward(ctx, x, wf, bf, grad_scale):
+    def forward(ctx, x, wf, bf, grad_scale, wgrad8=False):
         wq = quant_weights_e4m3(wf)
         ctx.save_for_backward(x, wf)
         ctx.S = grad_scale
+        ctx.wgrad8 = bool(wgrad8)
         return F.conv3d(round_e4m3(x), wq, bf)
 
     @staticmethod
@@ -90,8 +92,11 @@ class _F8Conv(torch.autograd.Function):
         # the data gradient packs the weights with one scale per INPUT channel of the convolution (its output channels)
         wq = quant_weights_e4m3(wf.transpose(0, 1).contiguous()).transpose(0, 1).contiguous()
         gx = torch.nn.grad.conv3d_input(x.shape, wq, gq)
-        gw = torch.nn.grad.conv3d_weight(x, wq.shape, g)
-        return gx, gw, g.sum(dim=(0, 2, 3, 4)), None
+        if ctx.wgrad8:
+            gw = torch.nn.grad.conv3d_weight(round_e4m3(x), wq.shape, gq)
+        else:
+            gw = torch.nn.grad.conv3d_weight(x, wq.shape, g)
+        return gx, gw, g.sum(dim=(0, 2, 3, 4)), None, None
 
 
 def f8_grad_scale(n_out_voxels):
@@ -137,7 +142,7 @@ def _bn_folded_conv(sd, bn_p, cv_p, x, training, q, f8=None):
     shift = beta - mean * scale
     bf = b + (w * shift.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
     if f8 is not None and cv_p in f8["layers"]:
-        return _F8Conv.apply(x, w * scale.view(1, -1, 1, 1, 1), bf, f8["grad_scale"])
+        return _F8Conv.apply(x, w * scale.view(1, -1, 1, 1, 1), bf, f8["grad_scale"], cv_p in f8.get("wgrad", ()))
     wf = q(w * scale.view(1, -1, 1, 1, 1))
     return F.conv3d(x, wf, bf)
 

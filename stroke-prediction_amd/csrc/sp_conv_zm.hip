@@ -70,6 +70,14 @@ __device__ __forceinline__ uint32_t zm_pack2(float lo, float hi) {
   const zm_f32x2 f = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, zm_bf16x2));
 }
+// four floats -> four e4m3 bytes (round to nearest even, saturating at +-448)
+__device__ __forceinline__ uint32_t zm_pack4_e4m3(const float* v, float s) {
+  const float a = __builtin_amdgcn_fmed3f(v[0] * s, -448.f, 448.f), b = __builtin_amdgcn_fmed3f(v[1] * s, -448.f, 448.f);
+  const float c = __builtin_amdgcn_fmed3f(v[2] * s, -448.f, 448.f), d = __builtin_amdgcn_fmed3f(v[3] * s, -448.f, 448.f);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
 template <> struct ZmStore<bf16_t> {
   static __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t r, uint32_t off, const float* v) {
     zm_u32x2 d = {zm_pack2(v[0], v[1]), zm_pack2(v[2], v[3])};
@@ -99,7 +107,8 @@ template <> struct ZmStore<float> {
 // NW: waves per workgroup (4, or 8 = two per SIMD: one wave's epilogue / DMA / LDS instructions issue under its partner's MFMAs).
 // ACT: 1 = bias + LeakyReLU / identity in the epilogue (forward layers), 2 = bias + ELU (the CAE's layers, Cae3D.py:41-70), 0 = the
 // accumulator is stored as it is (data gradients).
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, typename TOUT>
+// Q8: the e4m3 plane-major copy of the output is written as well (a.y8: the fp8 forward of the NEXT layer reads it, csrc/sp_conv_zm8.hip).
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, typename TOUT, bool Q8 = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -110,7 +119,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int S = NJ * NW * 1024;               // slot stride in bytes
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
-  constexpr int NS = MT * NT;                     // store instructions of one epilogue
+  constexpr int NS = MT * NT * (Q8 ? 2 : 1);      // store instructions of one epilogue
   static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NS) <= 63, "counted vmcnt does not fit its 6-bit field");
   constexpr int NWF = 3 * KS * NT;                // weight fragments (1 KiB each)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -228,6 +237,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     }
     const uint32_t zstride = (uint32_t)(a.osD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
     const uint32_t zbase = (uint32_t)(a.ooD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
+    // the e4m3 copy (dense output only: no phase strides): plane n of sample b, 4 bytes per lane at voxel * 16 + lg * 4
+    __amdgpu_buffer_rsrc_t y8rs[Q8 ? NT : 1];
+    uint32_t rowoff8[Q8 ? MT : 1];
+    const uint32_t zstride8 = (uint32_t)(a.YH * a.YW * 16);
+    const float q8s = a.y8_scale;
+    if constexpr (Q8) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        y8rs[n] = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<unsigned char*>(a.y8) + (size_t)n * a.y8_plane + (size_t)b * a.YD * a.YH * a.YW * 16), 0,
+            (int)((uint32_t)a.YD * a.YH * a.YW * 16u), 0x00020000);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = oy0 + wave * MT + m;
+        rowoff8[m] = (colok && oy < a.Ho) ? (uint32_t)((oy * a.YW + ox) * 16 + lg * 4) : 0x80000000u;
+      }
+    }
 
     // FOUR accumulator sets, one per output plane j mod 4: during step i (input plane i) the sets of planes i, i-1, i-2
     // receive the taps dz = 0, 1, 2 while the set of plane i-3 -- finished at the end of step i-1 -- is read by the epilogue
@@ -249,6 +275,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     const uint32_t pm = pv ? 0xffffffffu : 0u;                                                                    \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
       const uint32_t off = (zoff | rowoff[m]) & 0x80000000u ? 0x80000000u : zoff + rowoff[m];                     \
+      const uint32_t off8 = !Q8 || ((zoff | rowoff[m]) & 0x80000000u) ? 0x80000000u : (uint32_t)(fz_) * zstride8 + rowoff8[Q8 ? m : 0]; \
       const uint32_t msk = pm & rowok[m];                                                                         \
       _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
         float v[4];                                                                                               \
@@ -258,6 +285,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           else v[j] = acc[R_][n][m][j];                                                                           \
         }                                                                                                         \
         ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                                 \
+        if constexpr (Q8) {      /* of the STORED 16-bit values: the copy equals sp_quantize_f8 of y bit for bit */     \
+          const uint32_t w0_ = zm_pack2(v[0], v[1]), w1_ = zm_pack2(v[2], v[3]);                                  \
+          const float r_[4] = {sp_h2f_lo(w0_), sp_h2f_hi(w0_), sp_h2f_lo(w1_), sp_h2f_hi(w1_)};                   \
+          __builtin_amdgcn_raw_buffer_store_b32(zm_pack4_e4m3(r_, q8s), y8rs[n], off8, 0, 0);                     \
+        }                                                                                                         \
         if (STATS) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
             const float u = __uint_as_float(__float_as_uint(v[j]) & msk);                                         \
@@ -432,6 +464,15 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
       SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
     }
+  } else if (a->y8) {
+    if constexpr (ACT == 1 && P == 1 && NT == 2) {      // the first layer of an fp8-mode network (2 -> 32 channels)
+      auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, true>;
+      SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+    } else {
+      sp_set_error("sp_conv3d_zm: the e4m3 copy (y8) is built for the P=1 NT=2 forward instance (bias + LeakyReLU / identity epilogue)");
+      return SP_EINVAL;
+    }
   } else {
     auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
@@ -488,6 +529,10 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_zm: stats_nrep must be a power of two");
   SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_zm: empty output");
+  SP_CHECK_ARG(!a->y8 || (a->dtype_out == SP_BF16 && a->osD == 1 && a->osH == 1 && a->osW == 1 && a->ooD == 0 && a->ooH == 0 && a->ooW == 0 &&
+                          a->YD == a->Do && a->YH == a->Ho && a->YW == a->Wo && a->y8_scale > 0.f &&
+                          (uint64_t)a->y8_plane >= (uint64_t)a->B * a->YD * a->YH * a->YW * 16),
+               "sp_conv3d_zm: y8 needs a dense bf16 output, a positive y8_scale and y8_plane >= one plane of the output");
   const int P = a->CPi / 16;
   // every byte offset the kernel forms must fit 32 bits (per-sample base is 64-bit)
   const uint64_t span = a->x_plane ? (uint64_t)P * (uint64_t)a->x_plane * 2 : (uint64_t)a->Di * a->Hi * a->Wi * a->CPi * 2;

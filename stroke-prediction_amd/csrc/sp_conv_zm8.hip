@@ -204,7 +204,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
         typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));                                          \
         const u32x2_ d_ = {sp_pack_bf16x2(v[0], v[1]), sp_pack_bf16x2(v[2], v[3])};                               \
         __builtin_amdgcn_raw_buffer_store_b64(d_, yrs, off + (uint32_t)(n * 32), 0, 0);                           \
-        if (Q8) __builtin_amdgcn_raw_buffer_store_b32(zm8_pack4_e4m3(v, q8s), y8rs[n], off8, 0, 0);               \
+        if (Q8) {      /* of the STORED 16-bit values: the copy equals sp_quantize_f8 of y bit for bit */                \
+          const float r_[4] = {sp_h2f_lo(d_.x), sp_h2f_hi(d_.x), sp_h2f_lo(d_.y), sp_h2f_hi(d_.y)};               \
+          __builtin_amdgcn_raw_buffer_store_b32(zm8_pack4_e4m3(r_, q8s), y8rs[n], off8, 0, 0);                    \
+        }                                                                                                         \
         if (STATS) {                                                                                              \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
             const float u = __uint_as_float(__float_as_uint(v[j]) & msk);                                         \

@@ -153,6 +153,13 @@ class ConvLayer:
 
     FUSE_Q8 = not os.environ.get("SP_F8_NO_FUSE")      # (A/B knob: every fp8 operand by a separate sp_quantize_f8 pass)
 
+    def y8_capable(self):
+        """this layer's forward kernel can write the e4m3 plane-major copy of its output next to the bf16 one"""
+        if self.f8_fwd is not None:
+            return True
+        return bool(self.FUSE_Q8 and self.kind == "conv" and self.G == 1 and not self.materialize and self.out_dtype == L.SP_BF16
+                    and self.act in (L.ACT_NONE, L.ACT_LEAKY) and self.fwd.zm_y8_ok())
+
     def alloc_y8(self):
         from . import f8 as F8
         if self.y8 is None:
@@ -221,11 +228,11 @@ class ConvLayer:
         elif self.fold:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
-                         stats_nrep=STATS_NREP, x_planar=self.x_planar)
+                         stats_nrep=STATS_NREP, x_planar=self.x_planar, y8=self.alloc_y8() if self.want_y8 else None)
         else:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
             self.fwd.run(x, y, self.batch, self.scale, self.shift, self.act, self.act_param, out_stats,
-                         dtype_out=self.out_dtype, stats_nrep=STATS_NREP)
+                         dtype_out=self.out_dtype, stats_nrep=STATS_NREP, y8=self.alloc_y8() if self.want_y8 else None)
         return y
 
     # ---------------------------------------------------------------- backward

@@ -186,6 +186,10 @@ def _dev_i32(a, device):
 class ConvRunner:
     """One planned convolution-like op (see ``plan.ConvOp``) bound to device tables and weight fragments."""
 
+    def zm_y8_ok(self):
+        """the z-marching instance of this runner can also write the e4m3 plane-major copy of its output (run(y8=...))"""
+        return bool(self.uses_zm() and self.zms is None and self.zm["P"] == 1 and self.zm["NT"] == 2)
+
     def _run_zm(self, a, x_planar, batch, with_stats, st):
         return _run_zm_impl(self, a, x_planar, batch, with_stats, st)
 
@@ -328,10 +332,12 @@ class ConvRunner:
                        ptr(s["hi_zr"]), None, ptr(fold_scale), stream())
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
-            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0):
+            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
-        buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only."""
+        buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
+        y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners)."""
         op = self.op
+        assert y8 is None or (self.zm_y8_ok() and not group_batch and use_bias and act in (L.ACT_NONE, L.ACT_LEAKY))
         dtype_out = op.dtype if dtype_out is None else dtype_out
         if group_batch and group_batch < batch and stats is not None and (self.uses_zm() or self.fc is not None):
             # BatchNorm groups (statistics rows per group) on a kernel that is not group-aware: one launch per group on the
@@ -370,6 +376,10 @@ class ConvRunner:
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
         a.group_batch = group_batch if (group_batch and group_batch < batch and stats is not None) else 0
+        if y8 is not None:
+            assert (self.has_bias or act != L.ACT_NONE), "y8: the bias / activation epilogue instance only"
+            assert y8.dtype == torch.uint8 and tuple(y8.shape) == (y.shape[4] // 16, batch) + tuple(op.y_dims) + (16,)
+            a.y8, a.y8_plane, a.y8_scale = ptr(y8), batch * int(np.prod(op.y_dims)) * 16, 1.0
         st = stream()
         if self.uses_zm():
             assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \

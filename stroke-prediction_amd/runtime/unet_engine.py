@@ -157,7 +157,7 @@ class UnetEngine:
                     if not isinstance(lay, FirstConvLayer):
                         lay.enable_f8(gs)
                 if c2.f8_fwd is not None:
-                    if c1.f8_fwd is not None:
+                    if c1.y8_capable():      # (an fp8 layer, or the bf16 z-marching first layer: its epilogue writes the copy)
                         c1.want_y8 = True
                         self.f8_src[c2] = ("y8", c1)
                     else:

@@ -104,12 +104,9 @@ def test_fp8_conv_forward_matches_torch_on_quantised_operands(cin, cout, dims, B
     # same operands, fp32 accumulation in another order, bf16 rounding of the result (2^-9 relative)
     err = (got - ref).abs() / (ref.abs() + 0.05)
     assert float(err.max()) < 1.2e-2 and float(err.mean()) < 2e-3, (float(err.max()), float(err.mean()))
-    # the e4m3 copy is the rounding of the fp32 result: against the rounding of the (bf16-rounded) stored one a value next to
-    # a rounding boundary may fall on the other side
+    # the e4m3 copy is the rounding of the STORED bf16 value
     got8 = _from_planar8(y8, torch.float8_e4m3fn)
-    ref8 = nets.round_e4m3(got)
-    ulp = (got8 - ref8).abs() / (ref8.abs() * 0.125 + 2.0 ** -9)
-    assert float(ulp.max()) <= 1.001 and float((ulp > 0).float().mean()) < 0.08
+    assert torch.equal(got8, nets.round_e4m3(got))
     s = stats.sum(0).cpu()
     n = ref.numel() / cout
     np.testing.assert_allclose(s[:, 0].numpy() / n, ref.double().mean(dim=(0, 2, 3, 4)).numpy(), rtol=0, atol=2e-3)
@@ -229,7 +226,9 @@ def test_unet4_fp8_mode_matches_the_fp8_emulating_oracle():
     finally:
         F8.F8_MIN_PLANES = keep
     n_out = int(np.prod(seg.shape)) // 2
-    f8 = dict(layers=names, grad_scale=nets.f8_grad_scale(n_out))
+    wg8 = {l.conv_prefix for l in eng.layers if l.f8_wgrad is not None}
+    assert F8.WGRAD == (len(wg8) > 0), wg8
+    f8 = dict(layers=names, grad_scale=nets.f8_grad_scale(n_out), wgrad=wg8)
     sd = W.make_state_dict(W.unet_spec(CH4), seed)
     tr = nets.trainable(sd)
     for k in tr:
@@ -256,10 +255,11 @@ def test_unet4_fp8_mode_matches_the_fp8_emulating_oracle():
     # for the first, identical with the data gradients in bf16 -- it is the e4m3 forward, not the e5m2 backward).  What is held
     # here: the norms (as for the bf16 mode of this network); what the noise does to training is held by the trajectory test
     # below, the consistency of forward and backward by the directional-derivative test.
+    ratios = {k: float(p.grad.detach().cpu().double().norm() / (g_ref[k].double().norm() + 1e-30)) for k, p in model.named_parameters()}
+    print("gradient norm ratios furthest from 1:", sorted(((round(max(r, 1 / r), 2), k) for k, r in ratios.items()), reverse=True)[:6])
     for k, p in model.named_parameters():
-        a, b = p.grad.detach().cpu().double(), g_ref[k].double()
-        lim = 3.0 if a.numel() > 64 else 10.0      # (2..64-element BatchNorm / bias gradients: sums with total cancellation, see test_gpu_unet.py)
-        assert 1.0 / lim < float(a.norm() / (b.norm() + 1e-30)) < lim, (k, float(a.norm()), float(b.norm()))
+        lim = 3.0 if p.numel() > 64 else 10.0      # (2..64-element BatchNorm / bias gradients: sums with total cancellation, see test_gpu_unet.py)
+        assert 1.0 / lim < ratios[k] < lim, (k, ratios[k])
 
 
 @pytest.mark.parametrize("fname", ["unet4_92.npz", "unet4_92x100x96.npz"])
@@ -419,3 +419,42 @@ def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
     O.upsample2_crop_cat_fwd(low, skip, cat, L.SP_BF16, None, planar=True, q8=(cat8, F8.E4M3, 1.0))
     F8.quantize(cat, rc8, F8.E4M3, 1.0, src_planar=True)
     assert torch.equal(cat8, rc8)
+
+
+@pytest.mark.parametrize("with_stats", [True, False])
+def test_first_layer_convolution_writes_the_e4m3_copy_of_its_output(with_stats):
+    """the bf16 z-marching kernel of the network's first layer (nn.Conv3d(2, 32, 3), Unet3D.py:19) writes the e4m3 operand of
+    the fp8 layer behind it: bit for bit sp_quantize_f8 of the stored bf16 output, which is what it is without the copy"""
+    g_ = torch.Generator().manual_seed(23)
+    B, cin, cout, dims = 2, 2, 32, (12, 37, 40)
+    x = bf(torch.randn(B, cin, *dims, generator=g_))
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g_) / math.sqrt(27 * cin)).to(DEV)
+    b = (torch.randn(cout, generator=g_) * 0.1).to(DEV)
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, 16, cout, L.SP_BF16)
+    keep = O.ZM_MIN_PLANES
+    O.ZM_MIN_PLANES = 1          # (small volume: the z-marching kernel all the same)
+    try:
+        run = O.ConvRunner(op, DEV, zm_batch=B)
+    finally:
+        O.ZM_MIN_PLANES = keep
+    assert run.zm_y8_ok()
+    run.prep(w, b)
+    xs = _to_cl(x, 16)
+    nrep = 8
+    outs = []
+    for want in (True, False):
+        y = torch.full((B,) + tuple(op.y_dims) + (cout,), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y8 = F8.alloc_f8(B, op.y_dims, cout, DEV) if want else None
+        stats = torch.zeros(nrep, cout, 2, dtype=torch.float64, device=DEV) if with_stats else None
+        run.run(xs, y, B, None, None, L.ACT_LEAKY, LEAKY, stats, stats_nrep=nrep, y8=y8)
+        outs.append((y, y8, stats))
+    (y, y8, st), (y0, _, st0) = outs
+    assert torch.equal(y, y0)
+    ref = F.leaky_relu(F.conv3d(x.double(), bf(w.cpu()).double(), b.cpu().double()), LEAKY).float()
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    assert float(((got - ref).abs() / (ref.abs() + 0.05)).max()) < 1.2e-2
+    if with_stats:
+        torch.testing.assert_close(st.sum(0), st0.sum(0), rtol=1e-6, atol=1e-6)      # (fp32 partial sums, another schedule)
+    ref8 = F8.alloc_f8(B, op.y_dims, cout, DEV)
+    F8.quantize(y, ref8, F8.E4M3, 1.0)
+    assert torch.equal(y8, ref8)

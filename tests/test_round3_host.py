@@ -76,3 +76,33 @@ def test_bench_offers_only_precision_modes_that_exist():
     for dt in bench.DTYPES:
         assert dt in L.DTYPE_CODES, dt
         assert dt in bench.PEAK_TFLOPS
+
+
+def test_oracle_fp8_roundings_are_the_ocp_formats_and_the_fp8_conv_has_the_documented_gradients():
+    """oracle/nets.py: round_e4m3 / round_e5m2 are torch's float8_e4m3fn / float8_e5m2 casts (saturating), and _F8Conv's
+    backward is what csrc/sp_conv_zm8.hip / sp_wgrad_f8.hip compute: dx from e5m2(S dy) and e4m3 weights, dw from the bf16
+    tensors or (wgrad8) from the fp8 copies"""
+    import torch.nn.functional as F
+    from oracle import nets
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn(4000, generator=g) * torch.logspace(-9, 3, 4000)
+    v[:4] = torch.tensor([1e9, -1e9, 0.0, 449.0])
+    ref4 = v.clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    ref5 = v.clamp(-57344, 57344).to(torch.float8_e5m2).float()
+    assert torch.equal(nets.round_e4m3(v), ref4) and torch.equal(nets.round_e5m2(v), ref5)
+    x = torch.randn(1, 4, 6, 7, 8, generator=g).requires_grad_(True)
+    w = (torch.randn(3, 4, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b = torch.zeros(3, requires_grad=True)
+    S = 2.0 ** 10
+    dy = torch.randn(1, 3, 4, 5, 6, generator=g) * 1e-2
+    for wg8 in (False, True):
+        y = nets._F8Conv.apply(x, w, b, S, wg8)
+        gx, gw, gb = torch.autograd.grad(y, (x, w, b), dy)
+        dyq = nets.round_e5m2(dy * S) / S
+        wq_t = nets.quant_weights_e4m3(w.detach().transpose(0, 1).contiguous()).transpose(0, 1)
+        torch.testing.assert_close(gx, F.conv_transpose3d(dyq, wq_t), rtol=1e-5, atol=1e-7)
+        xs, ds = (nets.round_e4m3(x.detach()), dyq) if wg8 else (x.detach(), dy)
+        ref_w = torch.stack([torch.stack([torch.stack([torch.einsum("bozyx,bizyx->oi", ds, xs[:, :, a:a + 4, c:c + 5, d:d + 6])
+                                                        for d in range(3)], -1) for c in range(3)], -2) for a in range(3)], -3)
+        torch.testing.assert_close(gw, ref_w, rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(gb, dy.sum(dim=(0, 2, 3, 4)))
