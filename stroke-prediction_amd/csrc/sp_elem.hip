@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
         o[j] = (c0[j] * a[j] + c1[j] * b[j] + c2[j]) * act_bwd_t<ACT>(act, ap, b[j]);
         part[0][j] += o[j];
       }
-      Store<T>::st8(dz + v * CP + oc * 8, o);
+      if (dz) Store<T>::st8(dz + v * CP + oc * 8, o);      // (NULL: both readers take the fp8 copy)
       if (q8.p) sp_q8_store8(q8, v, oc, o);
     }
   }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
 }
 static int bn_act_bwd_impl(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
                            int32_t act, float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream, int64_t gvox = 0) {
-  SP_CHECK_ARG(g && y && dz && CP % 8 == 0 && CP <= 2048, "sp_bn_act_bwd: bad arguments");
+  SP_CHECK_ARG(g && y && (dz || q8.p) && CP % 8 == 0 && CP <= 2048, "sp_bn_act_bwd: bad arguments");
   SP_CHECK_ARG(gvox == 0 || (coef && gvox > 0 && nvox % gvox == 0), "sp_bn_act_bwd_groups: the groups must tile the tensor");
   SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= nvox * 16 && q8.scale > 0.f), "sp_bn_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   OctMap om = make_octmap(CP);
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
 #pragma unroll
           for (int j = 0; j < 8; ++j) { d[j] *= act_bwd_t<ACT>(act, ap, yv[j]); part[0][j] += d[j]; }
           const int64_t vo_ = (((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix;
-          Store<T>::st8(dz + vo_ * CP + oc * 8, d);
+          if (dz) Store<T>::st8(dz + vo_ * CP + oc * 8, d);
           if (q8.p) sp_q8_store8(q8, vo_, oc, d);
         }
       }
@@ -1095,7 +1095,7 @@ static int pool_skip_impl(const void* y, const void* gp, const float* coefp, con
                           int32_t dtype, int32_t B, int32_t D,
                           int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
                           float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream) {
-  SP_CHECK_ARG(y && dz && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
+  SP_CHECK_ARG(y && (dz || q8.p) && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
   SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= (int64_t)B * D * H * W * 16 && q8.scale > 0.f),
                "sp_pool_skip_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   SP_CHECK_VOX((int64_t)B * D * H * W, "sp_pool_skip_act_bwd");

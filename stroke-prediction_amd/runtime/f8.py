@@ -24,6 +24,7 @@ F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "1024"))     # (column, p
 E4M3, E5M2 = 0, 1
 DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient convolutions on the fp8 kernel too (0: forward only)
 WGRAD = bool(int(os.environ.get("SP_F8_WGRAD", "1")))       # weight gradients of the fp8 layers on fp8 operands as well (0: from the bf16 tensors)
+WGRAD_ONLY = bool(int(os.environ.get("SP_F8_WGRAD_ONLY", "1")))  # ... and those of the layers whose forward has no fp8 instance (their x8 is made for it)
 DZ_FMT = E5M2 if os.environ.get("SP_F8_DZ", "e5m2") == "e5m2" else E4M3      # storage format of the quantised output gradients
 
 

@@ -124,7 +124,7 @@ class ConvLayer:
         self.y = None
         # fp8 execution (runtime/f8.py; enabled per layer by the engine in the "fp8" precision mode)
         self.f8_fwd = self.f8_dgrad = self.f8_wgrad = None
-        self.f8_on = False
+        self.f8_on = self.f8_wgrad_only = False
         self.x8 = self.y8 = self.dz8 = None
         self.dz8_ready = False      # set by the kernel that formed dz when it also wrote the fp8 copy (dz8_out)
         self.want_y8 = False
@@ -140,6 +140,12 @@ class ConvLayer:
         if (self.fold and self.kind == "conv" and self.dtype == L.SP_BF16 and self.out_dtype == L.SP_BF16 and self.bank is None
                 and self.act in (L.ACT_NONE, L.ACT_LEAKY) and F8.ConvRunnerF8.applicable(self.fwd_op, self.batch)):
             self.f8_fwd = F8.ConvRunnerF8(self.fwd_op, self.device, self.batch, F8.E4M3)
+        # no fp8 forward instance (more input planes than the ring holds, too few columns): the weight gradient can still
+        # run on fp8 copies of the two tensors -- the engine then fills x8 in training steps only
+        self.f8_wgrad_only = bool(self.f8_fwd is None and F8.WGRAD and F8.WGRAD_ONLY and F8.DZ_FMT == F8.E5M2 and self.fold
+                                  and self.kind == "conv" and self.dtype == L.SP_BF16 and self.bank is None and self.G == 1
+                                  and self.k == 3 and max(P._triple(self.stride)) == 1 and max(P._triple(self.pad)) == 0
+                                  and self.cpi % 32 == 0 and self.cpo % 32 == 0 and self.cin == self.cpi and self.cout == self.cpo)
         return self.f8_fwd is not None
 
     def dz8_out(self):
@@ -151,6 +157,15 @@ class ConvLayer:
         self.dz8_ready = True
         return (self.dz8, F8.DZ_FMT, self.f8_grad_scale)
 
+    def dz_target(self):
+        """where the kernel that forms this layer's dz stores the 16-bit tensor: ``self.dz``, or None when it also writes the fp8
+        copy (dz8_out) and both convolutions of this layer's backward read that one.  Call after _init_bwd."""
+        if (self.SKIP_DZ and self.FUSE_Q8 and self.f8_wgrad is not None
+                and (self.f8_dgrad is not None or not self.need_input_grad)):
+            return None
+        return self.dz
+
+    SKIP_DZ = not os.environ.get("SP_F8_KEEP_DZ")      # (A/B knob: the 16-bit dz is always stored)
     FUSE_Q8 = not os.environ.get("SP_F8_NO_FUSE")      # (A/B knob: every fp8 operand by a separate sp_quantize_f8 pass)
 
     def y8_capable(self):
@@ -278,7 +293,7 @@ class ConvLayer:
                 if F8.DGRAD and F8.ConvRunnerF8.applicable(dop, self.batch):
                     self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.DZ_FMT)
                     self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
-        if self.f8_fwd is not None and self.bn_from_wgrad:
+        if (self.f8_fwd is not None or self.f8_wgrad_only) and self.x8 is not None and self.bn_from_wgrad:
             from . import f8 as F8      # weight gradient from the fp8 copies both other convolutions of the layer use
             if F8.WgradRunnerF8.applicable(self.wgrad):
                 self.f8_wgrad = F8.WgradRunnerF8(self.wgrad)

@@ -147,6 +147,8 @@ class UnetEngine:
         # ---- fp8 mode: which layers run on the fp8 kernel, and where each one's e4m3 input comes from
         self.f8 = bool(f8)
         self._f8_fused = set()
+        self._f8_train_only = set()
+        self._training = True
         self.f8_src = {}            # layer -> ("y8", producer layer) | ("quant", bf16 source getter, plane-major?)
         if self.f8:
             from . import f8 as F8
@@ -163,9 +165,19 @@ class UnetEngine:
                     else:
                         c2.x8 = F8.alloc_f8(batch, c2.in_dims, c2.cpi, device)
                         self.f8_src[c2] = ("quant", c1, False)
-                if c1.f8_fwd is not None:
+                elif c2.f8_wgrad_only:      # x8 only feeds the weight gradient: made in training steps only
+                    if c1.y8_capable():
+                        c1.want_y8 = True
+                        self.f8_src[c2] = ("y8", c1)
+                    else:
+                        c2.x8 = F8.alloc_f8(batch, c2.in_dims, c2.cpi, device)
+                        self.f8_src[c2] = ("quant", c1, False)
+                        self._f8_train_only.add(c2)
+                if c1.f8_fwd is not None or c1.f8_wgrad_only:
                     c1.x8 = F8.alloc_f8(batch, c1.in_dims, c1.cpi, device)
                     self.f8_src[c1] = ("quant", None, bool(self.cat_planar.get(i, False)))
+                    if c1.f8_fwd is None:
+                        self._f8_train_only.add(c1)
 
     # legacy names of the 3-scale engine (tools/)
     def __getattr__(self, name):
@@ -182,6 +194,7 @@ class UnetEngine:
         assert tuple(images.shape) == (B, self.channels[0]) + self.dims and images.dtype == torch.float32
         images = images.contiguous()
         self.generation += 1
+        self._training = bool(training)
         self.scratch.zero()
         if training and "__nbt_flat__" in bufs:
             bufs["__nbt_flat__"].add_(1)
@@ -231,6 +244,8 @@ class UnetEngine:
         copy as well (the separate quantisation pass is then skipped once), else None"""
         if self.f8_src.get(lay) is None or self.f8_src[lay][0] != "quant" or not ConvLayer.FUSE_Q8:
             return None
+        if lay in self._f8_train_only and not self._training:
+            return None
         from . import f8 as F8
         self._f8_fused.add(lay)
         return (lay.x8, F8.E4M3, 1.0)
@@ -239,7 +254,7 @@ class UnetEngine:
         """fp8 mode: make ``lay.x8`` the e4m3 plane-major copy of its input x -- written by the producing fp8 convolution's
         epilogue or by the pooling / concatenation kernel, else by one quantisation pass over the bf16 tensor"""
         src = self.f8_src.get(lay)
-        if src is None:
+        if src is None or (lay in self._f8_train_only and not self._training):
             return
         if lay in self._f8_fused:
             self._f8_fused.discard(lay)
@@ -262,10 +277,10 @@ class UnetEngine:
         """pool gradient + skip half of the concat gradient -> dz of the block output `prod`"""
         dt = self.dtype
         if isinstance(g, tuple):
-            O.pool_skip_act_bwd(prod.y, gp, coefp, None, g[1], coef, 0, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums,
+            O.pool_skip_act_bwd(prod.y, gp, coefp, None, g[1], coef, 0, dt, L.ACT_LEAKY, LEAKY, prod.dz_target(), prod.dbias_sums,
                                 coef_c0=c_up, coef_stride=cat.shape[-1], q8=prod.dz8_out())
         else:
-            O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz, prod.dbias_sums,
+            O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz_target(), prod.dbias_sums,
                                 q8=prod.dz8_out())
 
     # ------------------------------------------------------------------------------------------ backward
@@ -334,13 +349,13 @@ class UnetEngine:
             g, _ = self.h2.backward(self.h0.y, params, grads)
             O.bn_act_bwd(g, self.h0.y, None, dt, L.ACT_LEAKY, LEAKY, self.h0.dz, self.h0.dbias_sums)
             g, _ = self.h0.backward(last.y, params, grads)
-            O.bn_act_bwd(g, last.y, None, dt, L.ACT_LEAKY, LEAKY, last.dz, last.dbias_sums, q8=last.dz8_out())
+            O.bn_act_bwd(g, last.y, None, dt, L.ACT_LEAKY, LEAKY, last.dz_target(), last.dbias_sums, q8=last.dz8_out())
         pre.join()
         skip = {}                     # down block index -> (concat buffer, its gradient, coefficients, channels of the upsampled part)
         for u in range(2 * S - 1, S, -1):
             c1, c2 = self.conv[u]
             g, coef = c2.backward(c1.y, params, grads)
-            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums, q8=c1.dz8_out())
+            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out())
             gu, coefu = c1.backward(self.cat[u], params, grads)
             if ready is not None and u == S + 1:     # every up block and the head are final: their all-reduce bucket may start
                 ready("block%d." % (S + 1))
@@ -350,7 +365,7 @@ class UnetEngine:
             c1, c2 = self.conv[i]
             g, coef = c2.backward(c1.y, params, grads)
             if i > 1:
-                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums, q8=c1.dz8_out())
+                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out())
                 gp, coefp = c1.backward(self.pooled[i - 1], params, grads)
                 if ready is not None and i == 2:
                     ready("block2.")

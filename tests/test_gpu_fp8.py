@@ -393,6 +393,13 @@ def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
     O.bn_act_bwd(g, y, coef, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz, None, q8=(dz8, F8.E5M2, S))
     F8.quantize(dz, ref8, F8.E5M2, S)
     assert torch.equal(dz8, ref8) and float(dz.float().abs().max()) > 0
+    # ... and without the 16-bit tensor (both readers of dz take the fp8 copy): same copy, same bias-gradient sums
+    dz8b = F8.alloc_f8(B, dims, CP, DEV)
+    sa, sb = (torch.zeros(L.SP_REDUCE_ROWS, CP, dtype=torch.float64, device=DEV) for _ in range(2))
+    O.bn_act_bwd(g, y, coef, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz, sa, q8=(dz8, F8.E5M2, S))
+    O.bn_act_bwd(g, y, coef, L.SP_BF16, L.ACT_LEAKY, LEAKY, None, sb, q8=(dz8b, F8.E5M2, S))
+    assert torch.equal(dz8b, ref8)
+    torch.testing.assert_close(sa.sum(0), sb.sum(0), rtol=1e-6, atol=1e-12)
     # MaxPool3d -> pooled (+ e4m3 copy)
     x = cl(dims, CP)
     pd = tuple(d // 2 for d in dims)
@@ -410,6 +417,9 @@ def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
     O.pool_skip_act_bwd(x, gp, coefp, None, gs, coefs, 32, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz2, None, q8=(dz28, F8.E5M2, S))
     F8.quantize(dz2, ref28, F8.E5M2, S)
     assert torch.equal(dz28, ref28) and float(dz2.float().abs().max()) > 0
+    dz28b = F8.alloc_f8(B, dims, CP, DEV)
+    O.pool_skip_act_bwd(x, gp, coefp, None, gs, coefs, 32, L.SP_BF16, L.ACT_LEAKY, LEAKY, None, None, q8=(dz28b, F8.E5M2, S))
+    assert torch.equal(dz28b, ref28)
     # upsample + crop + concat, plane-major -> cat (+ e4m3 copy)
     ld = (4, 5, 9)
     low, skip = cl(ld, 32), cl(tuple(2 * d + 4 for d in ld), 16)
