@@ -863,7 +863,7 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
   f2_t s1[4], s2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) s1[j] = s2[j] = f2_splat(0.f);
-  T* const cp = cat + (int64_t)p * cat_plane + half * 8;
+  T* const cp = cat ? cat + (int64_t)p * cat_plane + half * 8 : nullptr;      // (NULL: fp8 copy and statistics only)
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
     uint32_t r = fdiv((uint32_t)i, d_w2);
     const int xo = ((uint32_t)i - r * (Wo * 2)) >> 1;
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t vo = (((int64_t)b * Do + 2 * zl + (k >> 1)) * Ho + 2 * yl + (k & 1)) * Wo + xo;
-      st8_f2_rounded(cp + vo * 16, out[k]);
+      if (cp) st8_f2_rounded(cp + vo * 16, out[k]);
       if (q8.p) {
         float o8[8];
 #pragma unroll
@@ -950,7 +950,10 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
 static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                       int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
                       int32_t Ws, int64_t cat_plane, double* stats, SpQ8 q8, sp_stream_t stream) {
-  SP_CHECK_ARG(low && skip && cat && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
+  // cat == NULL: only the fp8 copy (and the statistics) are wanted -- rows kernel only
+  SP_CHECK_ARG(low && skip && (cat || q8.p) && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
+  SP_CHECK_ARG(cat || (cat_plane && CPu % 16 == 0 && CPs % 16 == 0 && (int64_t)B * D * H * W * 4 < (1ll << 31) && !getenv("SP_UPCAT_BLOCKS")),
+               "sp_upsample2_crop_cat_fwd_q8: without the 16-bit output the plane-major form is required");
   SP_CHECK_VOX((int64_t)B * Ds * Hs * Ws, "sp_upsample2_crop_cat_fwd");
   SP_CHECK_ARG(2 * D <= Ds && 2 * H <= Hs && 2 * W <= Ws, "sp_upsample2_crop_cat_fwd: skip smaller than the upsampled grid");
   SP_CHECK_ARG(CPd <= 2048, "sp_upsample2_crop_cat_fwd: too many channels");

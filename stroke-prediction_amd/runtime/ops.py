@@ -753,17 +753,19 @@ def upsample2_fwd(x, y, dtype, stats=None):
     L.call("sp_upsample2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, y.shape[-1], ptr(stats), stream())
 
 
-def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False, q8=None):
+def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False, q8=None, store=True):
     """cat = concat(upsample2(low), centre_crop(skip)) in one pass (+ per-channel (sum, sum^2) of cat into stats).
-    planar: cat (same shape) is written plane-major [C/16][B][D][H][W][16] for the DMA consumers (x_planar=True)."""
+    planar: cat (same shape) is written plane-major [C/16][B][D][H][W][16] for the DMA consumers (x_planar=True).
+    store=False (with q8): the 16-bit tensor is not written -- every reader takes the fp8 copy."""
     B, D, H, W, CPu = low.shape
     _, Ds, Hs, Ws, CPs = skip.shape
     assert tuple(cat.shape) == (B, 2 * D, 2 * H, 2 * W, CPu + CPs), (tuple(cat.shape), tuple(low.shape), tuple(skip.shape))
     if q8 is not None:
         assert planar and CPu % 16 == 0 and CPs % 16 == 0
-        L.call("sp_upsample2_crop_cat_fwd_q8", ptr(low), CPu, ptr(skip), CPs, ptr(cat), CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
+        L.call("sp_upsample2_crop_cat_fwd_q8", ptr(low), CPu, ptr(skip), CPs, ptr(cat) if store else None, CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
                B * 8 * D * H * W * 16, ptr(stats), *_q8_args(q8, B * 8 * D * H * W), stream())
         return
+    assert store
     L.call("sp_upsample2_crop_cat_fwd", ptr(low), CPu, ptr(skip), CPs, ptr(cat), CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
            (B * 8 * D * H * W * 16) if planar else 0, ptr(stats), stream())
 

@@ -221,8 +221,15 @@ class UnetEngine:
         low = y2
         for u in range(S + 1, 2 * S):
             c1, c2 = self.conv[u]
-            O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u],
-                                     q8=self._f8_fused_input(c1) if self.cat_planar[u] and low.shape[-1] % 16 == 0 else None)
+            q8 = self._f8_fused_input(c1) if self.cat_planar[u] and low.shape[-1] % 16 == 0 else None
+            # fp8 forward AND fp8 weight gradient: nobody reads the 16-bit concat buffer (the backward kernels of its two
+            # producers recompute their half from y) -- it is not written
+            keep = True
+            if q8 is not None and c1.f8_fwd is not None and ConvLayer.SKIP_DZ:
+                if training:
+                    c1._init_bwd()
+                keep = training and c1.f8_wgrad is None
+            O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u], q8=q8, store=keep)
             self._f8_input(c1, self.cat[u])
             y1 = c1.forward(self.cat[u], params, bufs, training, st(c2))
             self._f8_input(c2, y1)
