@@ -113,6 +113,10 @@ typedef struct sp_conv_args {
   /* ---- batched passes (sp_conv3d_igemm / _multi only; 0 elsewhere) */
   int32_t group_batch;         /* > 0: samples [g*group_batch, (g+1)*group_batch) are BatchNorm group g: in_scale / in_shift of
                                   the group at + g*CPi, its statistics rows at stats + g*stats_nrep*CPo*2 */
+  /* ---- fp8 kernel: several output-channel slices of an op in one launch (0 / 1: one slice) */
+  int32_t nslices;             /* > 1: slice s computes output channels [s*Cout, (s+1)*Cout) -- y, bias, f8_wscale, stats are the
+                                  pointers of slice 0 (the others follow at + s*Cout channels), y8 at + s*NT planes */
+  int64_t slice_wfrag_stride;  /* bytes between the weight fragments (wfrag_hi) of consecutive slices */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);

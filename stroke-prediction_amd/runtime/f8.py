@@ -24,6 +24,8 @@ F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "1024"))     # (column, p
 E4M3, E5M2 = 0, 1
 DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient convolutions on the fp8 kernel too (0: forward only)
 WGRAD = bool(int(os.environ.get("SP_F8_WGRAD", "1")))       # weight gradients of the fp8 layers on fp8 operands as well (0: from the bf16 tensors)
+FUSE_SLICES = bool(int(os.environ.get("SP_F8_FUSE_SLICES", "1")))  # the output-channel slices of an op in one launch (0: one launch each)
+FUSE_SLICES_MIN = 4      # ... when every workgroup of that launch gets at least this many (column, plane) pairs
 WGRAD_ONLY = bool(int(os.environ.get("SP_F8_WGRAD_ONLY", "1")))  # ... and those of the layers whose forward has no fp8 instance (their x8 is made for it)
 DZ_FMT = E5M2 if os.environ.get("SP_F8_DZ", "e5m2") == "e5m2" else E4M3      # storage format of the quantised output gradients
 
@@ -107,10 +109,21 @@ class ConvRunnerF8:
         assert ConvRunnerF8.applicable(op, batch)
         self.op, self.device, self.batch, self.bin = op, device, batch, bin_fmt
         self.slices = []
-        for c0, cn, sub_op in P.zm8_slices(op):
-            z = P.zm8_plan(sub_op)
-            self.slices.append(dict(z, c0=c0, cn=cn, ktab_d=O._dev_i32(z["ktab"], device), kmap_d=O._dev_i32(z["kmap"], device),
-                                    wfrag=torch.empty(z["nsteps"] * z["NT"] * 2048, dtype=torch.uint8, device=device)))
+        sl = [(c0, cn, P.zm8_plan(sub_op)) for c0, cn, sub_op in P.zm8_slices(op)]
+        # equal slices (same tile count, consecutive channel ranges): their fragments share one buffer and ONE launch runs them
+        # all (sp_conv_args.nslices: the slices' pieces of an output row then leave the L2 as whole lines)
+        nt0, n0 = sl[0][2]["NT"], sl[0][2]["nsteps"]
+        self.fused = bool(FUSE_SLICES and 2 <= len(sl) <= 16 and all(z["NT"] == nt0 and z["nsteps"] == n0 and c0 == i * nt0 * 16 for i, (c0, _, z) in enumerate(sl)))
+        self.wstride = n0 * nt0 * 2048
+        pool = torch.empty(len(sl) * self.wstride, dtype=torch.uint8, device=device) if self.fused else None
+        for i, (c0, cn, z) in enumerate(sl):
+            wf = pool[i * self.wstride:(i + 1) * self.wstride] if self.fused else torch.empty(z["nsteps"] * z["NT"] * 2048, dtype=torch.uint8, device=device)
+            self.slices.append(dict(z, c0=c0, cn=cn, ktab_d=O._dev_i32(z["ktab"], device), kmap_d=O._dev_i32(z["kmap"], device), wfrag=wf))
+        if self.fused:      # enough (column, plane) pairs for every team of the one launch
+            z = self.slices[0]
+            sub = op.subs[0]
+            pairs = batch * -(-sub.out_dims[1] // z["TH"]) * -(-sub.out_dims[2] // 16) * sub.out_dims[0]
+            self.fused = pairs >= FUSE_SLICES_MIN * 8 * (32 // len(sl))
         cpad = -(-op.cout // 16) * 16
         self.bias = torch.zeros(cpad, dtype=torch.float32, device=device)
         self.winv = torch.ones(cpad, dtype=torch.float32, device=device)
@@ -150,7 +163,8 @@ class ConvRunnerF8:
         plane8 = batch * int(np.prod(op.y_dims)) * 16
         a.y8_plane = plane8
         st = O.stream()
-        for s in self.slices:
+        a.nslices, a.slice_wfrag_stride = (len(self.slices), self.wstride) if self.fused else (0, 0)
+        for s in (self.slices[:1] if self.fused else self.slices):
             c0 = s["c0"]
             a.y = y.data_ptr() + 2 * c0
             a.bias = (self.bias.data_ptr() + 4 * c0) if self.has_bias else None
@@ -160,9 +174,10 @@ class ConvRunnerF8:
             a.wfrag_hi, a.ktab = O.ptr(s["wfrag"]), O.ptr(s["ktab_d"])
             a.MT, a.NT, a.NTtot = s["MT"], s["NT"], s["NT"]
             a.Cout = s["NT"] * 16
-            with O._Timed("conv_igemm", op.flops(batch) * s["cn"] / op.cout,
+            with O._Timed("conv_igemm", op.flops(batch) * (1.0 if self.fused else s["cn"] / op.cout),
                           "%d->%d @%s zm8 %s%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), "e5m2" if self.bin else "e4m3",
-                                                     " slices" if len(self.slices) > 1 else "", " +stats" if stats is not None else "")):
+                                                     (" %d slices in one" % len(self.slices)) if self.fused else (" slices" if len(self.slices) > 1 else ""),
+                                                     " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_zm8", C.byref(a), O.ptr(O.zero_page(self.device)), st)
 
 

@@ -36,7 +36,8 @@ class ConvArgs(C.Structure):
                    "TD", "TH", "ITD", "ITH", "ITW", "MT", "NT", "NTtot", "ngroups", "octs_per_group", "opp", "vsb",
                    "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32), ("x_plane", i64),
                                                                            ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32),
-                                                                           ("group_batch", i32)]
+                                                                           ("group_batch", i32), ("nslices", i32),
+                                                                          ("slice_wfrag_stride", i64)]
 
 
 class WgradArgs(C.Structure):

@@ -468,3 +468,47 @@ def test_first_layer_convolution_writes_the_e4m3_copy_of_its_output(with_stats):
     ref8 = F8.alloc_f8(B, op.y_dims, cout, DEV)
     F8.quantize(y, ref8, F8.E4M3, 1.0)
     assert torch.equal(y8, ref8)
+
+
+@pytest.mark.parametrize("cin,cout,dims,B,dgrad", [(32, 64, (10, 40, 36), 2, False), (32, 96, (12, 37, 40), 1, False), (64, 64, (18, 33, 34), 2, False),
+                                                   (96, 32, (9, 34, 34), 1, True), (64, 128, (8, 34, 34), 1, True), (192, 64, (8, 36, 34), 1, True)])
+def test_fp8_slices_in_one_launch_equal_one_launch_per_slice(cin, cout, dims, B, dgrad):
+    """sp_conv_args.nslices: the 32-channel output slices of an op as teams of workgroups of ONE launch (forward with bias,
+    LeakyReLU, statistics and the e4m3 copy; data gradient with the e5m2 operand) -- bit for bit the per-slice launches"""
+    g_ = torch.Generator().manual_seed(cin + cout)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g_) / math.sqrt(27 * cin)).to(DEV)
+    if dgrad:
+        op = P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin, L.SP_BF16)
+        idims, ich, och = tuple(d - 2 for d in dims), cout, cin
+    else:
+        op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
+        idims, ich, och = dims, cin, cout
+    x = bf(torch.randn(B, ich, *idims, generator=g_))
+    x8 = F8.alloc_f8(B, idims, ich, DEV)
+    F8.quantize(_to_cl(x, ich), x8, F8.E5M2 if dgrad else F8.E4M3, 1.0)
+    b = (torch.randn(cout, generator=g_) * 0.1).to(DEV)
+    keep = (F8.F8_MIN_PLANES, F8.FUSE_SLICES, F8.FUSE_SLICES_MIN)
+    outs = []
+    try:
+        F8.F8_MIN_PLANES, F8.FUSE_SLICES_MIN = 1, 1
+        for fuse in (True, False):
+            F8.FUSE_SLICES = fuse
+            run = F8.ConvRunnerF8(op, DEV, B, F8.E5M2 if dgrad else F8.E4M3)
+            assert len(run.slices) > 1 and run.fused == fuse
+            y = torch.full((B,) + tuple(op.y_dims) + (och,), float("nan"), dtype=torch.bfloat16, device=DEV)
+            if dgrad:
+                run.prep(w, out_scale=0.5)
+                run.run(x8, y)
+                outs.append((y,))
+            else:
+                run.prep(w, b)
+                y8 = F8.alloc_f8(B, op.y_dims, och, DEV)
+                stats = torch.zeros(8, och, 2, dtype=torch.float64, device=DEV)
+                run.run(x8, y, L.ACT_LEAKY, LEAKY, stats, 8, y8=y8)
+                outs.append((y, y8, stats.sum(0)))
+    finally:
+        F8.F8_MIN_PLANES, F8.FUSE_SLICES, F8.FUSE_SLICES_MIN = keep
+    assert torch.equal(outs[0][0], outs[1][0]) and not bool(torch.isnan(outs[0][0].float()).any())
+    if not dgrad:
+        assert torch.equal(outs[0][1], outs[1][1])
+        torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-6, atol=1e-6)
