@@ -374,6 +374,20 @@ int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t
 int sp_first_wgrad_fused(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
                          int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks, double* dbias_sums,
                          sp_stream_t stream);
+/* The same four for Cout = 16 or 32 output channels (Conv3d(2, 32, 3): the first layer of the 4-scale network, BASELINE.json
+ * configs[4]): every "16" above reads Cout -- wfrag (Cout/16)*3*64*8 bf16, bias_f / y rows / coef rows / dbias rows of Cout,
+ * partials [nblocks][27][Cout][2].  sp_first_conv_fwd_n can also write y8, the e4m3 plane-major copy of y
+ * ([Cout/16][B][D-2][H-2][W-2][16 bytes], y8_plane bytes per plane; NULL: none) for an fp8 second layer. */
+int sp_first_prep_n(const float* w, const float* b, const float* scale, const float* shift, void* wfrag, float* bias_f,
+                    int32_t Cout, sp_stream_t stream);
+int sp_first_conv_fwd_n(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag, const float* bias_f,
+                        int32_t act, float act_param, void* y, double* stats, int32_t nrep, int32_t Cout, void* y8,
+                        int64_t y8_plane, sp_stream_t stream);
+int sp_first_wgrad_n(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
+                     int32_t nblocks, int32_t Cout, sp_stream_t stream);
+int sp_first_wgrad_fused_n(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
+                           int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks, double* dbias_sums,
+                           int32_t Cout, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ layout
  * NCDHW fp32 (reference layout, README.md:13 / data.py:305) <-> channels-last-3d */

@@ -165,53 +165,66 @@ extern "C" int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t D
 // A fragment of MFMA step s (0..2), lane l: row co = l % 16, K slice j = l / 16 -> group g = 4s + j = (dz, dy),
 // elements e = 0..7 = (dx = e / 2, c = e % 2);  W' = W * scale[c],  b' = b + sum W * shift[c]
 __global__ void first_prep_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f) {
-  const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes
-  const int s = t >> 6, l = t & 63, co = l & 15, g = 4 * s + (l >> 4);
+                                  const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f, int Cout) {
+  const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes; blockIdx.x = output tile of 16 channels
+  const int s = t >> 6, l = t & 63, co = blockIdx.x * 16 + (l & 15), g = 4 * s + (l >> 4);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int dx = e >> 1, c = e & 1;
     float v = 0.f;
-    if (g < 9 && dx < 3) v = w[(co * 2 + c) * 27 + g * 3 + dx] * (scale ? scale[c] : 1.f);
-    wfrag[(size_t)t * 8 + e] = f2bf(v);
+    if (g < 9 && dx < 3 && co < Cout) v = w[(co * 2 + c) * 27 + g * 3 + dx] * (scale ? scale[c] : 1.f);
+    wfrag[((size_t)blockIdx.x * 192 + t) * 8 + e] = f2bf(v);
   }
   if (t < 16) {
-    float acc = b ? b[t] : 0.f;
-    if (shift)
+    const int cb = blockIdx.x * 16 + t;
+    float acc = (b && cb < Cout) ? b[cb] : 0.f;
+    if (shift && cb < Cout)
       for (int c = 0; c < 2; ++c)
-        for (int k = 0; k < 27; ++k) acc = fmaf(w[(t * 2 + c) * 27 + k], shift[c], acc);
-    bias_f[t] = acc;
+        for (int k = 0; k < 27; ++k) acc = fmaf(w[(cb * 2 + c) * 27 + k], shift[c], acc);
+    bias_f[cb] = acc;
   }
 }
 
-extern "C" int sp_first_supported(int32_t Cin, int32_t Cout, int32_t k) { return Cin == 2 && Cout == 16 && k == 3; }
+// Cout = 16 (the 3-scale network of BASELINE.json configs[1]) or 32 (the 4-scale one, configs[4]): one or two output tiles
+extern "C" int sp_first_supported(int32_t Cin, int32_t Cout, int32_t k) { return Cin == 2 && (Cout == 16 || Cout == 32) && k == 3; }
 
-extern "C" int sp_first_prep(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
-                             float* bias_f, sp_stream_t stream) {
-  SP_CHECK_ARG(w && wfrag && bias_f, "sp_first_prep: null pointer");
-  hipLaunchKernelGGL(first_prep_kernel, dim3(1), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f);
+extern "C" int sp_first_prep_n(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
+                               float* bias_f, int32_t Cout, sp_stream_t stream) {
+  SP_CHECK_ARG(w && wfrag && bias_f && (Cout == 16 || Cout == 32), "sp_first_prep: null pointer / 16 or 32 output channels");
+  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f, Cout);
   SP_CHECK_LAUNCH("sp_first_prep");
   return SP_OK;
 }
+extern "C" int sp_first_prep(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
+                             float* bias_f, sp_stream_t stream) {
+  return sp_first_prep_n(w, b, scale, shift, wfrag, bias_f, 16, stream);
+}
 
 // ------------------------------------------------------------------------------------------------ forward
+// NT output tiles of 16 channels (y rows of 16 NT channels); y8 != NULL: also the e4m3 plane-major copy of y
+// ([NT][B][Do][Ho][Wo][16 bytes], the operand of an fp8 second layer -- csrc/sp_conv_zm8.hip), rounded from the stored value.
+template <int NT>
 __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const bf16x8* __restrict__ wfrag,
                                                          const float* __restrict__ bias, int act, float ap,
-                                                         bf16_t* __restrict__ y, double* __restrict__ stats, int nrep) {
+                                                         bf16_t* __restrict__ y, double* __restrict__ stats, int nrep,
+                                                         unsigned char* __restrict__ y8, int64_t y8_plane) {
   __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];
-  __shared__ float red[32];
+  __shared__ float red[32 * NT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
-  bf16x8 af[3];
+  bf16x8 af[NT][3];
   int goff[3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
-    af[s] = wfrag[s * 64 + lane];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) af[nt][s] = wfrag[(nt * 3 + s) * 64 + lane];
     const int g = min(4 * s + lg, 8);                       // groups 9..11 carry zero weights: any finite data will do
     goff[s] = ((g / 3) * FT_XY + (g % 3)) * FT_XP;
   }
-  float bj[4], s1[4], s2[4];
+  float bj[NT][4], s1[NT][4], s2[NT][4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { bj[j] = bias[lg * 4 + j]; s1[j] = s2[j] = 0.f; }
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { bj[nt][j] = bias[nt * 16 + lg * 4 + j]; s1[nt][j] = s2[nt][j] = 0.f; }
   const float slope = act == SP_ACT_LEAKY ? ap : 1.f;
   const bool lin = act == SP_ACT_LEAKY || act == SP_ACT_NONE;
 
@@ -238,45 +251,58 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
       const int oz = oz0 + zz, oy = oy0 + yy;
       const bool rok = oz < P.Do && oy < P.Ho;
       const int rbase = (zz * FT_XY + yy) * FT_XP + n;
-      bf16_t* yrow = y + ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo) * 16 + lg * 4;
+      const size_t vrow = (((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo;      // first voxel of the output row
+      bf16_t* yrow = y + vrow * (16 * NT) + lg * 4;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        union { uint32_t u[4]; bf16x8 v; } bq[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           const uint32_t* p = xt + goff[s] + rbase + t * 16;
-          union { uint32_t u[4]; bf16x8 v; } bq;
-          bq.u[0] = p[0]; bq.u[1] = p[1]; bq.u[2] = p[2]; bq.u[3] = p[3];
-          acc = SP_MFMA16(af[s], bq.v, acc, 0, 0, 0);
+          bq[s].u[0] = p[0]; bq[s].u[1] = p[1]; bq[s].u[2] = p[2]; bq[s].u[3] = p[3];
         }
         const int ox = ox0 + t * 16 + n;
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float z = acc[j] + bj[j];
-          v[j] = lin ? fmaxf(z, slope * z) : act_fwd(act, ap, z);
-        }
-        if (rok && ox < P.Wo) {
-          Store<bf16_t>::st4(yrow + (size_t)ox * 16, v);
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 3; ++s) acc = SP_MFMA16(af[nt][s], bq[s].v, acc, 0, 0, 0);
+          float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float q = bf2f(f2bf(v[j]));               // statistics of what is stored
-            s1[j] += q; s2[j] = fmaf(q, q, s2[j]);
+            const float z = acc[j] + bj[nt][j];
+            v[j] = lin ? fmaxf(z, slope * z) : act_fwd(act, ap, z);
+          }
+          if (rok && ox < P.Wo) {
+            Store<bf16_t>::st4(yrow + (size_t)ox * (16 * NT) + nt * 16, v);
+            float q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              q[j] = bf2f(f2bf(v[j]));                      // statistics (and the e4m3 copy) of what is stored
+              s1[nt][j] += q[j]; s2[nt][j] = fmaf(q[j], q[j], s2[nt][j]);
+            }
+            if (y8) {
+              int r8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(q[1], -448.f, 448.f), 0, false);
+              r8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q[2], -448.f, 448.f), __builtin_amdgcn_fmed3f(q[3], -448.f, 448.f), r8, true);
+              *reinterpret_cast<int*>(y8 + (size_t)nt * y8_plane + (vrow + ox) * 16 + lg * 4) = r8;
+            }
           }
         }
       }
     }
   }
   if (stats) {
-    if (tid < 32) red[tid] = 0.f;
+    for (int k = tid; k < 32 * NT; k += 256) red[k] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float x1 = row16_sum(s1[j]), x2 = row16_sum(s2[j]);
-      if (n == 0) { atomicAdd(&red[(lg * 4 + j) * 2], x1); atomicAdd(&red[(lg * 4 + j) * 2 + 1], x2); }
-    }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1 = row16_sum(s1[nt][j]), x2 = row16_sum(s2[nt][j]);
+        if (n == 0) { atomicAdd(&red[(nt * 16 + lg * 4 + j) * 2], x1); atomicAdd(&red[(nt * 16 + lg * 4 + j) * 2 + 1], x2); }
+      }
     __syncthreads();
-    if (tid < 32) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * 32 + tid], (double)red[tid]);
+    if (tid < 32 * NT) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * (32 * NT) + tid], (double)red[tid]);
   }
 }
 
@@ -291,19 +317,29 @@ static int first_geometry(FirstDev& P, const float* x, int B, int D, int H, int 
   return 0;
 }
 
-extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag,
-                                 const float* bias_f, int32_t act, float act_param, void* y, double* stats, int32_t nrep,
-                                 sp_stream_t stream) {
-  SP_CHECK_ARG(x && wfrag && bias_f && y && B >= 1 && D >= 3 && H >= 3 && W >= 3, "sp_first_conv_fwd: bad arguments");
+extern "C" int sp_first_conv_fwd_n(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag,
+                                   const float* bias_f, int32_t act, float act_param, void* y, double* stats, int32_t nrep,
+                                   int32_t Cout, void* y8, int64_t y8_plane, sp_stream_t stream) {
+  SP_CHECK_ARG(x && wfrag && bias_f && y && B >= 1 && D >= 3 && H >= 3 && W >= 3 && (Cout == 16 || Cout == 32), "sp_first_conv_fwd: bad arguments");
   SP_CHECK_ARG(!stats || nrep >= 1, "sp_first_conv_fwd: stats replicas");
+  SP_CHECK_ARG(!y8 || y8_plane >= (int64_t)B * (D - 2) * (H - 2) * (W - 2) * 16, "sp_first_conv_fwd: y8_plane smaller than a plane of the output");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_conv_fwd: too many tiles");
   static const unsigned cap_ = getenv("SP_FIRST_BLOCKS") ? (unsigned)atoi(getenv("SP_FIRST_BLOCKS")) : 2048u;
   const unsigned grid = P.ntiles < cap_ ? P.ntiles : cap_;
-  hipLaunchKernelGGL(first_fwd_kernel, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
-                     (bf16_t*)y, stats, nrep);
+  if (Cout == 16)
+    hipLaunchKernelGGL(first_fwd_kernel<1>, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
+                       (bf16_t*)y, stats, nrep, (unsigned char*)y8, y8_plane);
+  else
+    hipLaunchKernelGGL(first_fwd_kernel<2>, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
+                       (bf16_t*)y, stats, nrep, (unsigned char*)y8, y8_plane);
   SP_CHECK_LAUNCH("sp_first_conv_fwd");
   return SP_OK;
+}
+extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag,
+                                 const float* bias_f, int32_t act, float act_param, void* y, double* stats, int32_t nrep,
+                                 sp_stream_t stream) {
+  return sp_first_conv_fwd_n(x, B, D, H, W, wfrag, bias_f, act, act_param, y, stats, nrep, 16, nullptr, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -314,46 +350,54 @@ extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H
 // FUSED: dz is not read but formed on the fly, dz = (c0*g + c1*y + c2) * act'(y) (BatchNorm backward of the NEXT layer
 // and the activation derivative, i.e. sp_bn_act_bwd), and its per-channel sum is accumulated for the bias gradient --
 // the 2 x 256 MB round trip of dz through HBM and one launch disappear (nobody else reads this layer's dz).
-template <bool FUSED, int ACT>      // ACT >= 0: activation fixed at compile time (no per-element branch chain)
+template <bool FUSED, int ACT, int NT>      // ACT >= 0: activation fixed at compile time (no per-element branch chain); NT output tiles
 __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, const bf16_t* __restrict__ dzg,
                                                            const bf16_t* __restrict__ gg, const bf16_t* __restrict__ yg,
                                                            const float* __restrict__ coef, int act, float ap,
                                                            double* __restrict__ dbias, float* __restrict__ part) {
+  constexpr int CO = 16 * NT;                                                  // output channels (row pitch of dz / g / y)
+  constexpr int DZP = FT_TZ * FT_TY * FT_TX * 32;                              // bytes of one 16-channel plane of the dz tile
   __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];        // planar: [c][row][x] bf16
-  __shared__ __attribute__((aligned(16))) unsigned char dzt[FT_TZ * FT_TY * FT_TX * 32];
+  __shared__ __attribute__((aligned(16))) unsigned char dzt[NT * DZP];         // [tile][row][x][16 ch]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
   const int lq = n >> 2, lp = n & 3;
   const int r = n < 9 ? n : 0;                             // idle columns read tap 0 (their results are never flushed)
   const int boff = ((r / 3) * FT_XY + (r % 3)) * FT_XP + 8 * lg;        // elements, per channel plane
   const int aoff0 = (8 * lg + lq) * 32 + lp * 8, aoff1 = aoff0 + 4 * 32;   // bytes inside a 32-voxel K block
-  f32x4 acc[3][2];
+  f32x4 acc[NT][3][2];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) acc[d][0] = acc[d][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) acc[t][d][0] = acc[t][d][1] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16_t* xpl = reinterpret_cast<const bf16_t*>(xt);
   typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-  // fused mode: this thread always stages the same channel half (i & 1 == tid & 1)
+  // a thread always stages the same channel octet q = tid % (2 NT) (i = tid + 256 it, 256 % (2 NT) == 0)
+  const int q8 = tid & (2 * NT - 1);
   float k0[8], k1[8], k2[8], dsum[8];
   if (FUSED) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = (tid & 1) * 8 + j;
-      k0[j] = coef[c]; k1[j] = coef[16 + c]; k2[j] = coef[32 + c]; dsum[j] = 0.f;
+      const int c = q8 * 8 + j;
+      k0[j] = coef[c]; k1[j] = coef[CO + c]; k2[j] = coef[2 * CO + c]; dsum[j] = 0.f;
     }
   }
 
   // operands of a tile are fetched into registers one tile ahead (see first_load_x): x, and g / y (or dz)
-  constexpr int DZIT = FT_TZ * FT_TY * FT_TX * 2 / 256;
+  constexpr int DZIT = FT_TZ * FT_TY * FT_TX * 2 * NT / 256;
   float xr[FT_XIT][2];
   uint4 gq[DZIT], yq[DZIT];
+  // chunk i = (row, x, octet): 16 bytes = 8 channels of one output voxel
+  auto chunk = [&](int i, int& row, int& vx) { const int v = i / (2 * NT); vx = v & (FT_TX - 1); row = v >> 6; };
+  static_assert(FT_TX == 64, "chunk decoding assumes 64-voxel tile rows");
   auto load_dz = [&](int b, int oz0, int oy0, int ox0) {
 #pragma unroll
     for (int it = 0; it < DZIT; ++it) {
-      const int i = tid + it * 256;
-      const int half = i & 1, vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
+      int row, vx;
+      chunk(tid + it * 256, row, vx);
       const int oz = oz0 + (row >> 2), oy = oy0 + (row & 3), ox = ox0 + vx;
       gq[it] = yq[it] = make_uint4(0, 0, 0, 0);
       if (oz < P.Do && oy < P.Ho && ox < P.Wo) {
-        const size_t o = ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * 16 + half * 8;
+        const size_t o = ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * CO + q8 * 8;
         if (FUSED) { gq[it] = *reinterpret_cast<const uint4*>(gg + o); yq[it] = *reinterpret_cast<const uint4*>(yg + o); }
         else gq[it] = *reinterpret_cast<const uint4*>(dzg + o);
       }
@@ -370,11 +414,11 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
     first_decode(P, tile, b, oz0, oy0, ox0);
     __syncthreads();
     first_store_x<false>(xr, xt);
-    // dz tile: [row = zz*TY + yy][x][16 ch], zero where the output voxel does not exist
+    // dz tile: per 16-channel tile a plane [row = zz*TY + yy][x][16 ch], zero where the output voxel does not exist
 #pragma unroll
     for (int it = 0; it < DZIT; ++it) {
-      const int i = tid + it * 256;
-      const int vx = (i >> 1) & (FT_TX - 1), row = i >> 7;
+      int row, vx;
+      chunk(tid + it * 256, row, vx);
       const int oz = oz0 + (row >> 2), oy = oy0 + (row & 3), ox = ox0 + vx;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (oz < P.Do && oy < P.Ho && ox < P.Wo) {
@@ -395,7 +439,7 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
           v = gq[it];
         }
       }
-      *reinterpret_cast<uint4*>(dzt + (size_t)i * 16) = v;
+      *reinterpret_cast<uint4*>(dzt + (q8 >> 1) * DZP + (size_t)((row * FT_TX + vx) * 2 + (q8 & 1)) * 16) = v;
     }
     __syncthreads();
     if (tile + gridDim.x < P.ntiles) {
@@ -409,10 +453,14 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
       const int row = 2 * wave + rr, zz = row >> 2, yy = row & 3;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const unsigned char* ab = dzt + (row * FT_TX + ks * 32) * 32;
-        const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + aoff0));
-        const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + aoff1));
-        const bf16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        bf16x8 af[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const unsigned char* ab = dzt + t * DZP + (row * FT_TX + ks * 32) * 32;
+          const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + aoff0));
+          const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ab + aoff1));
+          af[t] = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const bf16_t* bp = xpl + c * (FT_ROWS * FT_XP) + (zz * FT_XY + yy) * FT_XP + ks * 32 + boff;
@@ -423,9 +471,12 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
           b1.u[0] = __builtin_amdgcn_alignbit(q.y, q.x, 16); b1.u[1] = __builtin_amdgcn_alignbit(q.z, q.y, 16);
           b1.u[2] = __builtin_amdgcn_alignbit(q.w, q.z, 16); b1.u[3] = __builtin_amdgcn_alignbit(q4, q.w, 16);
           b2.u[0] = q.y; b2.u[1] = q.z; b2.u[2] = q.w; b2.u[3] = q4;
-          acc[0][c] = SP_MFMA16(af, b0.v, acc[0][c], 0, 0, 0);
-          acc[1][c] = SP_MFMA16(af, b1.v, acc[1][c], 0, 0, 0);
-          acc[2][c] = SP_MFMA16(af, b2.v, acc[2][c], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t][0][c] = SP_MFMA16(af[t], b0.v, acc[t][0][c], 0, 0, 0);
+            acc[t][1][c] = SP_MFMA16(af[t], b1.v, acc[t][1][c], 0, 0, 0);
+            acc[t][2][c] = SP_MFMA16(af[t], b2.v, acc[t][2][c], 0, 0, 0);
+          }
         }
       }
     }
@@ -434,60 +485,75 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
   // waves' tiles added through LDS
   __syncthreads();
   float* st = reinterpret_cast<float*>(dzt);
-  for (int i = tid; i < 27 * 16 * 2; i += 256) st[i] = 0.f;
+  for (int i = tid; i < 27 * CO * 2; i += 256) st[i] = 0.f;
   __syncthreads();
   if (n < 9) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
+      for (int d = 0; d < 3; ++d)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(&st[((n * 3 + d) * 16 + lg * 4 + j) * 2 + c], acc[d][c][j]);
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(&st[((n * 3 + d) * CO + t * 16 + lg * 4 + j) * 2 + c], acc[t][d][c][j]);
   }
   __syncthreads();
-  for (int i = tid; i < 27 * 16 * 2; i += 256) part[(size_t)blockIdx.x * (27 * 16 * 2) + i] = st[i];
-  if (FUSED && dbias) {       // sum of dz per output channel: threads with equal parity hold the same eight channels
+  for (int i = tid; i < 27 * CO * 2; i += 256) part[(size_t)blockIdx.x * (27 * CO * 2) + i] = st[i];
+  if (FUSED && dbias) {       // sum of dz per output channel: threads with equal tid % (2 NT) hold the same eight channels
     __syncthreads();
-    float* rd = st;           // 16 floats
-    if (tid < 16) rd[tid] = 0.f;
+    float* rd = st;           // CO floats
+    if (tid < CO) rd[tid] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = dsum[j];
-      // lanes of one parity: xor-reduce over the other 5 lane bits
+      // lanes of one octet: xor-reduce over the other lane bits
 #pragma unroll
-      for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane < 2) atomicAdd(&rd[(lane & 1) * 8 + j], v);
+      for (int o = 32; o >= 2 * NT; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane < 2 * NT) atomicAdd(&rd[lane * 8 + j], v);
     }
     __syncthreads();
-    if (tid < 16) atomicAdd(&dbias[(blockIdx.x % SP_REDUCE_ROWS) * 16 + tid], (double)rd[tid]);
+    if (tid < CO) atomicAdd(&dbias[(blockIdx.x % SP_REDUCE_ROWS) * CO + tid], (double)rd[tid]);
   }
 }
 
-extern "C" int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
-                              int32_t nblocks, sp_stream_t stream) {
-  SP_CHECK_ARG(x && dz && partials && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1, "sp_first_wgrad: bad arguments");
+extern "C" int sp_first_wgrad_n(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
+                                int32_t nblocks, int32_t Cout, sp_stream_t stream) {
+  SP_CHECK_ARG(x && dz && partials && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1 && (Cout == 16 || Cout == 32), "sp_first_wgrad: bad arguments");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad: too many tiles");
-  hipLaunchKernelGGL((first_wgrad_kernel<false, -1>), dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, nullptr, nullptr,
-                     nullptr, 0, 0.f, nullptr, partials);
+  if (Cout == 16)
+    hipLaunchKernelGGL((first_wgrad_kernel<false, -1, 1>), dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, nullptr, nullptr,
+                       nullptr, 0, 0.f, nullptr, partials);
+  else
+    hipLaunchKernelGGL((first_wgrad_kernel<false, -1, 2>), dim3(nblocks), dim3(256), 0, ST(stream), P, (const bf16_t*)dz, nullptr, nullptr,
+                       nullptr, 0, 0.f, nullptr, partials);
   SP_CHECK_LAUNCH("sp_first_wgrad");
   return SP_OK;
 }
+extern "C" int sp_first_wgrad(const float* x, const void* dz, int32_t B, int32_t D, int32_t H, int32_t W, float* partials,
+                              int32_t nblocks, sp_stream_t stream) {
+  return sp_first_wgrad_n(x, dz, B, D, H, W, partials, nblocks, 16, stream);
+}
 
-extern "C" int sp_first_wgrad_fused(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
-                                    int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks,
-                                    double* dbias_sums, sp_stream_t stream) {
-  SP_CHECK_ARG(x && g && y && coef && partials && dbias_sums && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1,
+extern "C" int sp_first_wgrad_fused_n(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
+                                      int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks,
+                                      double* dbias_sums, int32_t Cout, sp_stream_t stream) {
+  SP_CHECK_ARG(x && g && y && coef && partials && dbias_sums && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1 && (Cout == 16 || Cout == 32),
                "sp_first_wgrad_fused: bad arguments");
   FirstDev P;
   SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad_fused: too many tiles");
-  if (act == SP_ACT_LEAKY)
-    hipLaunchKernelGGL((first_wgrad_kernel<true, SP_ACT_LEAKY>), dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,
-                       (const bf16_t*)y, coef, act, act_param, dbias_sums, partials);
-  else
-    hipLaunchKernelGGL((first_wgrad_kernel<true, -1>), dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,
-                       (const bf16_t*)y, coef, act, act_param, dbias_sums, partials);
+#define SP_FW(A_, N_)                                                                                                             \
+  hipLaunchKernelGGL((first_wgrad_kernel<true, A_, N_>), dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g,    \
+                     (const bf16_t*)y, coef, act, act_param, dbias_sums, partials)
+  if (Cout == 16) { if (act == SP_ACT_LEAKY) SP_FW(SP_ACT_LEAKY, 1); else SP_FW(-1, 1); }
+  else { if (act == SP_ACT_LEAKY) SP_FW(SP_ACT_LEAKY, 2); else SP_FW(-1, 2); }
+#undef SP_FW
   SP_CHECK_LAUNCH("sp_first_wgrad_fused");
   return SP_OK;
+}
+extern "C" int sp_first_wgrad_fused(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
+                                    int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks,
+                                    double* dbias_sums, sp_stream_t stream) {
+  return sp_first_wgrad_fused_n(x, g, y, coef, act, act_param, B, D, H, W, partials, nblocks, dbias_sums, 16, stream);
 }

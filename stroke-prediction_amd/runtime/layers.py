@@ -470,7 +470,7 @@ class ConvLayer:
 
 
 class FirstConvLayer(ConvLayer):
-    """First layer of a network on the packed-K kernels of sp_first.hip: BatchNorm(2) -> Conv3d(2, 16, 3) -> act read
+    """First layer of a network on the packed-K kernels of sp_first.hip: BatchNorm(2) -> Conv3d(2, 16 or 32, 3) -> act read
     straight from the NCDHW fp32 input (no channels-last copy, no padded channels), and a backward that needs no
     data-gradient convolution (the BatchNorm-backward sums come out of the weight gradient).  bf16 storage only."""
 
@@ -481,8 +481,9 @@ class FirstConvLayer(ConvLayer):
     def __init__(self, *a, **kw):
         super().__init__(*a, **kw)
         assert FirstConvLayer.supported(self.cin, self.cout, self.k, self.stride, self.pad, self.dtype, self.bn_prefix)
-        self.wfrag = torch.zeros(3 * 64 * 8, dtype=torch.bfloat16, device=self.device)
-        self.bias_f = torch.zeros(16, device=self.device)
+        assert self.cpo == self.cout
+        self.wfrag = torch.zeros((self.cout // 16) * 3 * 64 * 8, dtype=torch.bfloat16, device=self.device)
+        self.bias_f = torch.zeros(self.cout, device=self.device)
         self.flops = 2.0 * self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2] * 27 * self.cin * self.cout
 
     def input_stats(self, images):
@@ -497,13 +498,18 @@ class FirstConvLayer(ConvLayer):
         c = self.conv_prefix
         y = self.alloc_out()
         st = O.stream()
-        L.call("sp_first_prep", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
-               O.ptr(self.wfrag), O.ptr(self.bias_f), st)
+        L.call("sp_first_prep_n", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
+               O.ptr(self.wfrag), O.ptr(self.bias_f), self.cout, st)
         D, H, W = self.in_dims
+        y8 = self.alloc_y8() if self.want_y8 else None      # (fp8 mode: the e4m3 operand of the second layer)
         with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
-            L.call("sp_first_conv_fwd", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.bias_f), self.act,
-                   self.act_param, O.ptr(y), O.ptr(out_stats), STATS_NREP, st)
+            L.call("sp_first_conv_fwd_n", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.bias_f), self.act,
+                   self.act_param, O.ptr(y), O.ptr(out_stats), STATS_NREP, self.cout, O.ptr(y8),
+                   0 if y8 is None else y8[0].numel(), st)
         return y
+
+    def y8_capable(self):
+        return bool(self.FUSE_Q8)
 
     def _init_bwd(self):
         if self._bwd_ready:
@@ -511,7 +517,7 @@ class FirstConvLayer(ConvLayer):
         self.dz = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.dtype, self.device)
         vox = self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
         self.nparts = max(8, min(int(os.environ.get("SP_FIRST_WGRAD_BLOCKS", "1024")), vox // int(os.environ.get("SP_FIRST_WGRAD_MINVOX", "8192"))))
-        self.partials = torch.empty(self.nparts * 27 * 16 * 2, dtype=torch.float32, device=self.device)
+        self.partials = torch.empty(self.nparts * 27 * self.cout * 2, dtype=torch.float32, device=self.device)
         self.tapsrc = torch.arange(27, dtype=torch.int32, device=self.device)
         self.coef = torch.zeros(3, self.cpi, device=self.device)
         self._bwd_ready = True
@@ -525,11 +531,12 @@ class FirstConvLayer(ConvLayer):
         bs = self.scratch.get(self.bsums_id)
         with O._Timed("conv_wgrad", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
             if g is not None:
-                L.call("sp_first_wgrad_fused", O.ptr(images), O.ptr(g), O.ptr(self.y), O.ptr(coef), self.act, self.act_param,
-                       self.batch, D, H, W, O.ptr(self.partials), self.nparts, O.ptr(self.dbias_sums), st)
+                L.call("sp_first_wgrad_fused_n", O.ptr(images), O.ptr(g), O.ptr(self.y), O.ptr(coef), self.act, self.act_param,
+                       self.batch, D, H, W, O.ptr(self.partials), self.nparts, O.ptr(self.dbias_sums), self.cout, st)
             else:
-                L.call("sp_first_wgrad", O.ptr(images), O.ptr(self.dz), self.batch, D, H, W, O.ptr(self.partials), self.nparts, st)
-        L.call("sp_wgrad_finish_folded", O.ptr(self.partials), self.nparts, O.ptr(self.tapsrc), 27, 16, 2, self.cout,
+                L.call("sp_first_wgrad_n", O.ptr(images), O.ptr(self.dz), self.batch, D, H, W, O.ptr(self.partials), self.nparts,
+                       self.cout, st)
+        L.call("sp_wgrad_finish_folded", O.ptr(self.partials), self.nparts, O.ptr(self.tapsrc), 27, self.cout, 2, self.cout,
                self.cin, self.cin * 27, 27, O.ptr(self.scale), O.ptr(self.shift), O.ptr(self.dbias_sums),
                O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(params[c + ".weight"]), O.ptr(bs), STATS_NREP,
                self.cpi, self.cpo, st)

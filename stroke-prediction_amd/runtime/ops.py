@@ -406,7 +406,7 @@ class ConvRunner:
                       "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "zfill"):
                 setattr(a, k, t[k])
             a.dma = int(t["dma"] and in_scale is None and USE_DMA)
-            a.persist = int(USE_PERSIST)
+            a.persist = 0 if a.group_batch else int(USE_PERSIST)      # (BatchNorm groups: the tiled kernel only)
             a.x_plane = 0
             if x_planar:
                 assert a.dma and t["opp"] == 2, "plane-major input: DMA kernel with 16-channel planes only"

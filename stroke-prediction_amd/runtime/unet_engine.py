@@ -378,7 +378,7 @@ class UnetEngine:
                     ready("block2.")
                 cat, gu, coefu, c_up = skip[i - 1]
                 self._skip_bwd(self.conv[i - 1][1], gp, coefp, cat, gu, coefu, c_up)
-            elif self.first_packed and coef is not None and c1.cpo == 16:
+            elif self.first_packed and coef is not None and c1.cpo in (16, 32):
                 c1.backward(self.x0, params, grads, g=g, coef=coef)     # dz formed inside the weight-gradient kernel
             else:
                 O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)

@@ -554,18 +554,20 @@ def test_upsample2_act_bwd_tiled(dtype, C0, ldims):
     torch.testing.assert_close(dbias.sum(0).cpu().float(), want.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=BIAS_ATOL[dtype])
 
 
-def test_first_layer_packed():
-    """sp_first.hip: BatchNorm-folded Conv3d(2,16,3)+LeakyReLU, its statistics, the input statistics and the weight
-    gradient (+ BatchNorm-backward sums) straight from the NCDHW input, against torch on bf16-rounded operands."""
+@pytest.mark.parametrize("CO", [16, 32])
+def test_first_layer_packed(CO):
+    """sp_first.hip: BatchNorm-folded Conv3d(2, 16 | 32, 3)+LeakyReLU, its statistics (and the e4m3 copy of the output), the
+    input statistics and the weight gradient (+ BatchNorm-backward sums) straight from the NCDHW input, against torch on
+    bf16-rounded operands."""
     torch.manual_seed(17)
     lib = L.load()
-    assert lib.sp_first_supported(2, 16, 3) == 1 and lib.sp_first_supported(3, 16, 3) == 0
+    assert lib.sp_first_supported(2, CO, 3) == 1 and lib.sp_first_supported(3, 16, 3) == 0 and lib.sp_first_supported(2, 48, 3) == 0
     B, dims = 2, (9, 11, 70)                      # ragged against the 2 x 4 x 64 tile, two x tiles
     od = tuple(d - 2 for d in dims)
     x = torch.randn(B, 2, *dims) * 1.5 + 0.3
     xq = x.bfloat16().float()
-    w = torch.randn(16, 2, 3, 3, 3) * 0.2
-    b = torch.randn(16) * 0.1
+    w = torch.randn(CO, 2, 3, 3, 3) * 0.2
+    b = torch.randn(CO) * 0.1
     scale, shift = torch.rand(16) + 0.5, torch.randn(16) * 0.1
     xd = x.to(DEV).contiguous()
     nrep = 64
@@ -576,35 +578,40 @@ def test_first_layer_packed():
     ref = torch.stack([xq.double().sum((0, 2, 3, 4)), (xq.double() ** 2).sum((0, 2, 3, 4))], 1)
     torch.testing.assert_close(got[:2], ref, rtol=1e-6, atol=1e-3)
     # forward
-    wfrag = torch.zeros(3 * 64 * 8, dtype=torch.bfloat16, device=DEV)
-    bias_f = torch.zeros(16, device=DEV)
+    wfrag = torch.zeros((CO // 16) * 3 * 64 * 8, dtype=torch.bfloat16, device=DEV)
+    bias_f = torch.zeros(CO, device=DEV)
     wd, bd, sc, sh = w.to(DEV), b.to(DEV), scale.to(DEV), shift.to(DEV)
-    L.call("sp_first_prep", O.ptr(wd), O.ptr(bd), O.ptr(sc), O.ptr(sh), O.ptr(wfrag), O.ptr(bias_f), O.stream())
-    y = O.alloc_cl(B, od, 16, L.SP_BF16, DEV)
-    st = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
-    L.call("sp_first_conv_fwd", O.ptr(xd), B, dims[0], dims[1], dims[2], O.ptr(wfrag), O.ptr(bias_f), L.ACT_LEAKY, 0.01,
-           O.ptr(y), O.ptr(st), nrep, O.stream())
+    L.call("sp_first_prep_n", O.ptr(wd), O.ptr(bd), O.ptr(sc), O.ptr(sh), O.ptr(wfrag), O.ptr(bias_f), CO, O.stream())
+    y = O.alloc_cl(B, od, CO, L.SP_BF16, DEV)
+    st = torch.zeros(nrep, CO, 2, dtype=torch.float64, device=DEV)
+    from stroke_prediction_amd.runtime import f8 as F8
+    y8 = F8.alloc_f8(B, od, CO, DEV)
+    L.call("sp_first_conv_fwd_n", O.ptr(xd), B, dims[0], dims[1], dims[2], O.ptr(wfrag), O.ptr(bias_f), L.ACT_LEAKY, 0.01,
+           O.ptr(y), O.ptr(st), nrep, CO, O.ptr(y8), y8[0].numel(), O.stream())
+    r8 = F8.alloc_f8(B, od, CO, DEV)
+    F8.quantize(y, r8, F8.E4M3, 1.0)
+    assert torch.equal(y8, r8)                     # the e4m3 copy == sp_quantize_f8 of the stored output
     wf = (w * scale[:2].view(1, 2, 1, 1, 1)).bfloat16().float()
     bf = b + (w * shift[:2].view(1, 2, 1, 1, 1)).sum((1, 2, 3, 4))
     y_ref = F.leaky_relu(F.conv3d(xq, wf, bf), 0.01)
-    yg = from_cl(y, 16, L.SP_BF16)
+    yg = from_cl(y, CO, L.SP_BF16)
     torch.testing.assert_close(yg, y_ref, rtol=1e-2, atol=1e-2)
     sg = st.sum(0).cpu()
     torch.testing.assert_close(sg[:, 0].float(), yg.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
     torch.testing.assert_close(sg[:, 1].float(), (yg ** 2).sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
     # weight gradient + BatchNorm-backward sums
-    dz = rnd(L.SP_BF16, torch.randn(B, 16, *od))
-    dz_cl = to_cl(dz, 16, L.SP_BF16)
+    dz = rnd(L.SP_BF16, torch.randn(B, CO, *od))
+    dz_cl = to_cl(dz, CO, L.SP_BF16)
     nparts = 24
-    part = torch.full((nparts * 27 * 16 * 2,), float("nan"), device=DEV)
-    L.call("sp_first_wgrad", O.ptr(xd), O.ptr(dz_cl), B, dims[0], dims[1], dims[2], O.ptr(part), nparts, O.stream())
-    dw = torch.zeros(16, 2, 3, 3, 3, device=DEV)
-    db = torch.zeros(16, device=DEV)
-    dbs = torch.zeros(16, dtype=torch.float64, device=DEV)
+    part = torch.full((nparts * 27 * CO * 2,), float("nan"), device=DEV)
+    L.call("sp_first_wgrad_n", O.ptr(xd), O.ptr(dz_cl), B, dims[0], dims[1], dims[2], O.ptr(part), nparts, CO, O.stream())
+    dw = torch.zeros(CO, 2, 3, 3, 3, device=DEV)
+    db = torch.zeros(CO, device=DEV)
+    dbs = torch.zeros(CO, dtype=torch.float64, device=DEV)
     dbs[:] = dz.double().sum((0, 2, 3, 4)).to(DEV)
     bs = torch.zeros(nrep, 16, 2, dtype=torch.float64, device=DEV)
     tapsrc = torch.arange(27, dtype=torch.int32, device=DEV)
-    L.call("sp_wgrad_finish_folded", O.ptr(part), nparts, O.ptr(tapsrc), 27, 16, 2, 16, 2, 54, 27, O.ptr(sc), O.ptr(sh),
+    L.call("sp_wgrad_finish_folded", O.ptr(part), nparts, O.ptr(tapsrc), 27, CO, 2, CO, 2, 54, 27, O.ptr(sc), O.ptr(sh),
            O.ptr(dbs), O.ptr(dw), O.ptr(db), O.ptr(wd), O.ptr(bs), nrep, 16, 0, O.stream())
     xn = xq * scale[:2].view(1, 2, 1, 1, 1) + shift[:2].view(1, 2, 1, 1, 1)
     wr = w.clone().requires_grad_(True)
@@ -617,18 +624,18 @@ def test_first_layer_packed():
     torch.testing.assert_close(got[:2], ref, rtol=1e-4, atol=1e-2)
     assert float(got[2:].abs().max()) == 0.0
     # fused variant: dz = (c0*g + c1*y + c2) * LeakyReLU'(y) formed inside the kernel == sp_bn_act_bwd followed by the above
-    gq = rnd(L.SP_BF16, torch.randn(B, 16, *od))
-    coef = torch.randn(3, 16) * 0.5
-    g_cl = to_cl(gq, 16, L.SP_BF16)
+    gq = rnd(L.SP_BF16, torch.randn(B, CO, *od))
+    coef = torch.randn(3, CO) * 0.5
+    g_cl = to_cl(gq, CO, L.SP_BF16)
     dz2 = torch.empty_like(dz_cl)
-    dbs2 = O.reduce_rows(16, 1, DEV)
+    dbs2 = O.reduce_rows(CO, 1, DEV)
     O.bn_act_bwd(g_cl, y, coef.to(DEV), L.SP_BF16, L.ACT_LEAKY, 0.01, dz2, dbs2)
-    p_ref = torch.empty(nparts * 27 * 16 * 2, device=DEV)
-    L.call("sp_first_wgrad", O.ptr(xd), O.ptr(dz2), B, dims[0], dims[1], dims[2], O.ptr(p_ref), nparts, O.stream())
+    p_ref = torch.empty(nparts * 27 * CO * 2, device=DEV)
+    L.call("sp_first_wgrad_n", O.ptr(xd), O.ptr(dz2), B, dims[0], dims[1], dims[2], O.ptr(p_ref), nparts, CO, O.stream())
     p_fus = torch.full_like(p_ref, float("nan"))
-    dbs3 = O.reduce_rows(16, 1, DEV)
+    dbs3 = O.reduce_rows(CO, 1, DEV)
     cd = coef.to(DEV)
-    L.call("sp_first_wgrad_fused", O.ptr(xd), O.ptr(g_cl), O.ptr(y), O.ptr(cd), L.ACT_LEAKY, 0.01, B, dims[0], dims[1], dims[2],
-           O.ptr(p_fus), nparts, O.ptr(dbs3), O.stream())
+    L.call("sp_first_wgrad_fused_n", O.ptr(xd), O.ptr(g_cl), O.ptr(y), O.ptr(cd), L.ACT_LEAKY, 0.01, B, dims[0], dims[1], dims[2],
+           O.ptr(p_fus), nparts, O.ptr(dbs3), CO, O.stream())
     torch.testing.assert_close(p_fus.view(nparts, -1).sum(0), p_ref.view(nparts, -1).sum(0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(dbs3.sum(0), dbs2.sum(0), rtol=1e-5, atol=1e-4)
