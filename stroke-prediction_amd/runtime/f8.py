@@ -2,12 +2,12 @@
 ``sp_quantize_f8`` (csrc/sp_conv_zm8.hip; BASELINE.json configs[4]).
 
 Precision recipe (``Unet3D(dtype="fp8")``): the MFMA operands of the forward and the data-gradient convolution of every
-3x3x3 layer with 32..96 input channels are fp8 -- activations e4m3 (plane-major copies written by the producing
-convolution's epilogue, or by one quantisation pass for pooled / concatenated tensors), weights e4m3 with a power-of-two scale
-per output channel, output gradients e5m2 scaled by a power of two -- with fp32 accumulation; BatchNorm statistics, bias,
-activations, Dice and Adam stay fp32, the stored activations every other kernel reads stay bf16, and the weight gradients
-(a reduction over millions of voxels) are computed from the bf16 tensors.  The first layer (2 input channels), the
-classify head and the layers with more than 96 input channels run on the bf16 kernels.
+3x3x3 layer with 32..128 input channels, and of the weight gradient of every 3x3x3 layer but the first, are fp8 -- activations
+e4m3 (plane-major copies written by the producing convolution's epilogue, or by the pooling / concatenation kernel, or by one
+quantisation pass), weights e4m3 with a power-of-two scale per output channel, output gradients e5m2 scaled by a power of two --
+with fp32 accumulation; BatchNorm statistics, bias, activations, Dice and Adam stay fp32, the stored activations every other
+kernel reads stay bf16.  The first layer (2 input channels), the classify head and the forward / data gradient of the layers with
+12 or 24 input planes run on the bf16 kernels.
 """
 import ctypes as C
 import math
