@@ -20,7 +20,7 @@ from . import lib as L
 from . import ops as O
 from . import plan as P
 
-F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "1024"))     # (column, plane) pairs below which the march is all prologue
+F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "128"))      # (column, plane) pairs below which the march is all prologue (measured: 128 -> 128 @46^3 169 -> 110 us, 128 -> 256 @28^3 117 -> 69 us against the bf16 tiled kernel)
 E4M3, E5M2 = 0, 1
 DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient convolutions on the fp8 kernel too (0: forward only)
 WGRAD = bool(int(os.environ.get("SP_F8_WGRAD", "1")))       # weight gradients of the fp8 layers on fp8 operands as well (0: from the bf16 tensors)
@@ -113,17 +113,27 @@ class ConvRunnerF8:
         # equal slices (same tile count, consecutive channel ranges): their fragments share one buffer and ONE launch runs them
         # all (sp_conv_args.nslices: the slices' pieces of an output row then leave the L2 as whole lines)
         nt0, n0 = sl[0][2]["NT"], sl[0][2]["nsteps"]
-        self.fused = bool(FUSE_SLICES and 2 <= len(sl) <= 16 and all(z["NT"] == nt0 and z["nsteps"] == n0 and c0 == i * nt0 * 16 for i, (c0, _, z) in enumerate(sl)))
+        uniform = bool(FUSE_SLICES and len(sl) >= 2 and all(z["NT"] == nt0 and z["nsteps"] == n0 and c0 == i * nt0 * 16 for i, (c0, _, z) in enumerate(sl)))
+        # slices per launch: a divisor m <= 16 of the slice count; the 32 workgroups of an XCD form floor(32 / m) teams of m -- the
+        # largest m that leaves at most 10 % of them idle (24 slices: three launches of 8), else the best filling one
+        self.fuse_m = 0
+        if uniform:
+            cands = [m for m in range(2, min(16, len(sl)) + 1) if len(sl) % m == 0]
+            good = [m for m in cands if (32 // m) * m >= 29]
+            if cands:
+                self.fuse_m = max(good) if good else max(cands, key=lambda m: ((32 // m) * m, m))
         self.wstride = n0 * nt0 * 2048
-        pool = torch.empty(len(sl) * self.wstride, dtype=torch.uint8, device=device) if self.fused else None
+        pool = torch.empty(len(sl) * self.wstride, dtype=torch.uint8, device=device) if self.fuse_m else None
         for i, (c0, cn, z) in enumerate(sl):
-            wf = pool[i * self.wstride:(i + 1) * self.wstride] if self.fused else torch.empty(z["nsteps"] * z["NT"] * 2048, dtype=torch.uint8, device=device)
+            wf = pool[i * self.wstride:(i + 1) * self.wstride] if self.fuse_m else torch.empty(z["nsteps"] * z["NT"] * 2048, dtype=torch.uint8, device=device)
             self.slices.append(dict(z, c0=c0, cn=cn, ktab_d=O._dev_i32(z["ktab"], device), kmap_d=O._dev_i32(z["kmap"], device), wfrag=wf))
-        if self.fused:      # enough (column, plane) pairs for every team of the one launch
+        if self.fuse_m:     # enough (column, plane) pairs for every team of a launch
             z = self.slices[0]
             sub = op.subs[0]
             pairs = batch * -(-sub.out_dims[1] // z["TH"]) * -(-sub.out_dims[2] // 16) * sub.out_dims[0]
-            self.fused = pairs >= FUSE_SLICES_MIN * 8 * (32 // len(sl))
+            if pairs < FUSE_SLICES_MIN * 8 * (32 // self.fuse_m):
+                self.fuse_m = 0
+        self.fused = self.fuse_m > 0
         cpad = -(-op.cout // 16) * 16
         self.bias = torch.zeros(cpad, dtype=torch.float32, device=device)
         self.winv = torch.ones(cpad, dtype=torch.float32, device=device)
@@ -163,8 +173,9 @@ class ConvRunnerF8:
         plane8 = batch * int(np.prod(op.y_dims)) * 16
         a.y8_plane = plane8
         st = O.stream()
-        a.nslices, a.slice_wfrag_stride = (len(self.slices), self.wstride) if self.fused else (0, 0)
-        for s in (self.slices[:1] if self.fused else self.slices):
+        a.nslices, a.slice_wfrag_stride = (self.fuse_m, self.wstride) if self.fused else (0, 0)
+        nl = len(self.slices) // self.fuse_m if self.fused else 0
+        for s in (self.slices[::self.fuse_m] if self.fused else self.slices):
             c0 = s["c0"]
             a.y = y.data_ptr() + 2 * c0
             a.bias = (self.bias.data_ptr() + 4 * c0) if self.has_bias else None
@@ -174,9 +185,9 @@ class ConvRunnerF8:
             a.wfrag_hi, a.ktab = O.ptr(s["wfrag"]), O.ptr(s["ktab_d"])
             a.MT, a.NT, a.NTtot = s["MT"], s["NT"], s["NT"]
             a.Cout = s["NT"] * 16
-            with O._Timed("conv_igemm", op.flops(batch) * (1.0 if self.fused else s["cn"] / op.cout),
+            with O._Timed("conv_igemm", op.flops(batch) * (1.0 / nl if self.fused else s["cn"] / op.cout),
                           "%d->%d @%s zm8 %s%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), "e5m2" if self.bin else "e4m3",
-                                                     (" %d slices in one" % len(self.slices)) if self.fused else (" slices" if len(self.slices) > 1 else ""),
+                                                     (" %d slices in one" % self.fuse_m) if self.fused else (" slices" if len(self.slices) > 1 else ""),
                                                      " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_zm8", C.byref(a), O.ptr(O.zero_page(self.device)), st)
 

@@ -471,7 +471,8 @@ def test_first_layer_convolution_writes_the_e4m3_copy_of_its_output(with_stats):
 
 
 @pytest.mark.parametrize("cin,cout,dims,B,dgrad", [(32, 64, (10, 40, 36), 2, False), (32, 96, (12, 37, 40), 1, False), (64, 64, (18, 33, 34), 2, False),
-                                                   (96, 32, (9, 34, 34), 1, True), (64, 128, (8, 34, 34), 1, True), (192, 64, (8, 36, 34), 1, True)])
+                                                   (96, 32, (9, 34, 34), 1, True), (64, 128, (8, 34, 34), 1, True), (192, 64, (8, 36, 34), 1, True),
+                                                   (384, 128, (8, 34, 34), 1, True)])      # (24 slices: three launches of eight)
 def test_fp8_slices_in_one_launch_equal_one_launch_per_slice(cin, cout, dims, B, dgrad):
     """sp_conv_args.nslices: the 32-channel output slices of an op as teams of workgroups of ONE launch (forward with bias,
     LeakyReLU, statistics and the e4m3 copy; data gradient with the e5m2 operand) -- bit for bit the per-slice launches"""
