@@ -147,6 +147,12 @@ int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int3
  * chunk h of lane group g in K step s inside a ring slot (runtime/plan.py:zm8_plan).  Replaces nn.Conv3d(3, padding 0)
  * (Unet3D.py:19,22 inside the 4-scale topology Unet3D.py:95-146) for 32 <= Cin <= 96. */
 int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
+/* Input-channel groups: a convolution with more input planes than an fp8 instance holds runs one sp_conv3d_zm8 per group of
+ * planes with dtype_out = SP_F32 (y = the group's fp32 partial sums [B*YD*YH*YW][CPo], no bias / activation / statistics), then
+ * y[m][c] (bf16) = act(sum_g partial[g][m][c] + sum_g bias[g*bias_stride + c]); stats[rep][CP][2] += (sum y, sum y^2). */
+int sp_conv_partial_finish(const float* partial, int32_t ngroups, int64_t nvox, int32_t CP, const float* bias /* or NULL */,
+                           int32_t bias_stride, int32_t act, float act_param, void* y, double* stats /* or NULL */,
+                           int32_t stats_nrep, sp_stream_t stream);
 int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
 /* fp32 weights -> e4m3 A fragments in the plan's K order.  kmap[(step*4+g)*2+h] = (src_tap << 16) | input 16-channel plane, or
  * -1 (zero chunk); element (co, ci, tap) = w[co*sCo + ci*sCi + tap] * fold_scale[ci] (fold_scale may be NULL).  Per output

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
     nvb = gridDim.x;
   }
   const int c0s = sl * NT * 16;                    // first output channel of this workgroup's slice
-  bf16_t* const y_sl = reinterpret_cast<bf16_t*>(a.y) + c0s;
+  constexpr int OB = ACT == 2 ? 4 : 2;             // bytes per output element (ACT == 2: fp32 partial sums of an input-channel group)
+  unsigned char* const y_sl = reinterpret_cast<unsigned char*>(a.y) + (size_t)c0s * OB;
   unsigned char* const y8_sl = Q8 ? reinterpret_cast<unsigned char*>(a.y8) + (size_t)sl * NT * a.y8_plane : nullptr;
   const float* const bias_sl = a.bias ? a.bias + c0s : nullptr;
   double* const stats_sl = a.stats ? a.stats + (size_t)c0s * 2 : nullptr;
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
 #pragma unroll
       for (int j = 0; j < NJ; ++j) plane_dma(j, false);
     };
-    bf16_t* yout = y_sl + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
+    unsigned char* yout = y_sl + (size_t)b * a.YD * a.YH * a.YW * a.CPo * OB;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)yout, 0, (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * 2u), 0x00020000);
+        (void*)yout, 0, (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)OB), 0x00020000);
     // the e4m3 copy: plane n of this launch, sample b -- one descriptor per output tile
     __amdgpu_buffer_rsrc_t y8rs[NT];
     if (Q8) {
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
       const bool inr = !((zoff | rowoff[m]) & 0x80000000u);                                                       \
       const uint32_t vx_ = zoff + rowoff[m];                                                                      \
-      const uint32_t off = inr ? vx_ * (uint32_t)(a.CPo * 2) + (uint32_t)(lg * 8) : 0x80000000u;                  \
+      const uint32_t off = inr ? vx_ * (uint32_t)(a.CPo * OB) + (uint32_t)(lg * 4 * OB) : 0x80000000u;            \
       const uint32_t off8 = inr ? vx_ * 16u + (uint32_t)(lg * 4) : 0x80000000u;                                   \
       const uint32_t msk = pm & rowok[m];                                                                         \
       _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
@@ -223,8 +224,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
           else v[j] = acc[R_][n][m][j] * wi[n][j];                                                                \
         }                                                                                                         \
         typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));                                          \
+        typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));                                          \
         const u32x2_ d_ = {sp_pack_bf16x2(v[0], v[1]), sp_pack_bf16x2(v[2], v[3])};                               \
-        __builtin_amdgcn_raw_buffer_store_b64(d_, yrs, off + (uint32_t)(n * 32), 0, 0);                           \
+        if (ACT == 2) {                                                                                           \
+          const u32x4_ f_ = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}; \
+          __builtin_amdgcn_raw_buffer_store_b128(f_, yrs, off + (uint32_t)(n * 64), 0, 0);                        \
+        } else {                                                                                                  \
+          __builtin_amdgcn_raw_buffer_store_b64(d_, yrs, off + (uint32_t)(n * 32), 0, 0);                         \
+        }                                                                                                         \
         if (Q8) {      /* of the STORED 16-bit values: the copy equals sp_quantize_f8 of y bit for bit */                \
           const float r_[4] = {sp_h2f_lo(d_.x), sp_h2f_hi(d_.x), sp_h2f_lo(d_.y), sp_h2f_hi(d_.y)};               \
           __builtin_amdgcn_raw_buffer_store_b32(zm8_pack4_e4m3(r_, q8s), y8rs[n], off8, 0, 0);                    \
@@ -377,6 +384,15 @@ static int launch_zm8_3(const sp_conv_args* a, const void* zeros, hipStream_t st
 
 template <int P, int NT, int MT, int NSLOT, int NW>
 static int launch_zm8(const sp_conv_args* a, const void* zeros, hipStream_t st) {
+  if (a->dtype_out == SP_F32) {      // fp32 partial sums of one input-channel group (sp_conv_partial_finish adds the groups up)
+    if constexpr ((P == 6 && NT == 2) || (P == 8 && NT == 1)) {
+      return a->f8_bin ? launch_zm8_3<P, NT, MT, NSLOT, NW, false, 2, true, false>(a, zeros, st)
+                       : launch_zm8_3<P, NT, MT, NSLOT, NW, false, 2, false, false>(a, zeros, st);
+    } else {
+      sp_set_error("sp_conv3d_zm8: the fp32 partial-sum form is built for the (6, 2) and (8, 1) instances");
+      return SP_EINVAL;
+    }
+  }
   if (a->act == SP_ACT_NONE && a->bias == nullptr && a->stats == nullptr && a->y8 == nullptr) {      // data gradients: plain epilogue, bf16 result only
     return a->f8_bin ? launch_zm8_3<P, NT, MT, NSLOT, NW, false, 0, true, false>(a, zeros, st)
                      : launch_zm8_3<P, NT, MT, NSLOT, NW, false, 0, false, false>(a, zeros, st);
@@ -407,7 +423,9 @@ extern "C" int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t*
 
 extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && a->f8_wscale && zeros && a->in_scale == nullptr, "sp_conv3d_zm8: null pointer (or affine-on-load requested)");
-  SP_CHECK_ARG(a->dtype_out == SP_BF16 && a->stats_mode == 0 && a->x_plane > 0, "sp_conv3d_zm8: bf16 output, plain statistics, plane-major fp8 input");
+  SP_CHECK_ARG((a->dtype_out == SP_BF16 || a->dtype_out == SP_F32) && a->stats_mode == 0 && a->x_plane > 0, "sp_conv3d_zm8: bf16 output (or fp32 partial sums), plain statistics, plane-major fp8 input");
+  SP_CHECK_ARG(a->dtype_out == SP_BF16 || (a->bias == nullptr && a->act == SP_ACT_NONE && a->stats == nullptr && a->y8 == nullptr),
+               "sp_conv3d_zm8: fp32 partial sums take no bias / activation / statistics / e4m3 copy (sp_conv_partial_finish applies them)");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm8: stride 1 only");
   SP_CHECK_ARG(a->group_batch == 0, "sp_conv3d_zm8: no BatchNorm groups (run one launch per group)");
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE, "sp_conv3d_zm8: LeakyReLU or identity epilogue");
@@ -422,7 +440,7 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
   const int P = a->CPi / 16;
   SP_CHECK_ARG((uint64_t)P * (uint64_t)a->x_plane < (1ull << 32) && (uint64_t)a->x_plane >= (uint64_t)a->B * a->Di * a->Hi * a->Wi * 16,
                "sp_conv3d_zm8: input planes too large for 32-bit offsets / x_plane smaller than a plane");
-  SP_CHECK_ARG((uint64_t)a->YD * a->YH * a->YW * a->CPo * 2 < (1ull << 31), "sp_conv3d_zm8: output sample too large for a buffer descriptor");
+  SP_CHECK_ARG((uint64_t)a->YD * a->YH * a->YW * a->CPo * (a->dtype_out == SP_F32 ? 4 : 2) < (1ull << 31), "sp_conv3d_zm8: output sample too large for a buffer descriptor");
   SP_CHECK_ARG(!a->y8 || ((uint64_t)a->y8_plane >= (uint64_t)a->B * a->YD * a->YH * a->YW * 16 && a->y8_scale > 0.f),
                "sp_conv3d_zm8: y8_plane smaller than a plane of the output / y8_scale not positive");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -435,6 +453,98 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
   if (P == 6 && a->NT == 2) return launch_zm8<6, 2, 2, 2, 8>(a, zeros, st);
   if (P == 8 && a->NT == 1) return launch_zm8<8, 1, 4, 2, 4>(a, zeros, st);
   return SP_EINVAL;
+}
+
+// ---------------------------------------------------------------------------------------------------- input-channel groups
+// y[m][c] = act(sum_g partial[g][m][c] + sum_g bias[g][c]) for a convolution whose input channels were split into G groups (more
+// input planes than a ring slot holds: the 192 -> 64 and 384 -> 128 layers behind the concatenations, the 256-channel bottleneck
+// of Unet3D.py:95-146): one thread = one voxel x 8 channels; statistics of the stored values for the next BatchNorm.
+__global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* __restrict__ partial, int G, int64_t M, int CP,
+                                                                   const float* __restrict__ bias, int bias_stride, int act, float ap,
+                                                                   bf16_t* __restrict__ y, double* __restrict__ stats, int nrep) {
+  extern __shared__ float red[];      // [CP][2]
+  const int OC = CP / 8;
+  const int pos = threadIdx.x / OC, oc = threadIdx.x - pos * OC, vpb = 256 / OC;
+  const bool active = pos < vpb;
+  float bj[8], s1[8], s2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float b = 0.f;
+    if (bias && active)
+      for (int g = 0; g < G; ++g) b += bias[(size_t)g * bias_stride + oc * 8 + j];
+    bj[j] = b; s1[j] = s2[j] = 0.f;
+  }
+  const float slope = act == SP_ACT_LEAKY ? ap : 1.f;
+  if (active) {
+    const int64_t chunk = ((M + gridDim.x - 1) / gridDim.x + vpb - 1) / vpb * vpb;
+    const int64_t mend = min(M, ((int64_t)blockIdx.x + 1) * chunk);
+    // two voxels per trip: 4 G independent 16-byte loads in flight per thread
+    for (int64_t m0 = (int64_t)blockIdx.x * chunk + pos; m0 < mend; m0 += 2 * vpb) {
+      float v[2][8];
+      const bool two = m0 + vpb < mend;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = bj[j];
+      const float* p = partial + m0 * CP + oc * 8;
+      const size_t ustep = two ? (size_t)vpb * CP : 0;      // (no second voxel: the first one again, not stored)
+#pragma unroll 2
+      for (int g = 0; g < G; ++g) {
+        float4 q[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          q[u][0] = *reinterpret_cast<const float4*>(p + (size_t)g * M * CP + u * ustep);
+          q[u][1] = *reinterpret_cast<const float4*>(p + (size_t)g * M * CP + u * ustep + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          v[u][0] += q[u][0].x; v[u][1] += q[u][0].y; v[u][2] += q[u][0].z; v[u][3] += q[u][0].w;
+          v[u][4] += q[u][1].x; v[u][5] += q[u][1].y; v[u][6] += q[u][1].z; v[u][7] += q[u][1].w;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !two) break;
+        uint32_t w4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z0 = fmaxf(v[u][2 * j], slope * v[u][2 * j]), z1 = fmaxf(v[u][2 * j + 1], slope * v[u][2 * j + 1]);
+          w4[j] = sp_pack_bf16x2(z0, z1);
+          if (stats) {
+            const float q0 = sp_h2f_lo(w4[j]), q1 = sp_h2f_hi(w4[j]);
+            s1[2 * j] += q0; s2[2 * j] = fmaf(q0, q0, s2[2 * j]);
+            s1[2 * j + 1] += q1; s2[2 * j + 1] = fmaf(q1, q1, s2[2 * j + 1]);
+          }
+        }
+        *reinterpret_cast<uint4*>(y + (m0 + (int64_t)u * vpb) * CP + oc * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+      }
+    }
+  }
+  if (stats) {
+    for (int k = threadIdx.x; k < CP * 2; k += 256) red[k] = 0.f;
+    __syncthreads();
+    if (active)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { atomicAdd(&red[(oc * 8 + j) * 2], s1[j]); atomicAdd(&red[(oc * 8 + j) * 2 + 1], s2[j]); }
+    __syncthreads();
+    for (int k = threadIdx.x; k < CP * 2; k += 256) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * CP * 2 + k], (double)red[k]);
+  }
+}
+
+extern "C" int sp_conv_partial_finish(const float* partial, int32_t ngroups, int64_t nvox, int32_t CP, const float* bias,
+                                      int32_t bias_stride, int32_t act, float act_param, void* y, double* stats, int32_t stats_nrep,
+                                      sp_stream_t stream) {
+  SP_CHECK_ARG(partial && y && ngroups >= 1 && nvox >= 1 && CP % 8 == 0 && CP >= 8 && CP <= 2048, "sp_conv_partial_finish: bad arguments");
+  SP_CHECK_ARG(act == SP_ACT_NONE || act == SP_ACT_LEAKY, "sp_conv_partial_finish: LeakyReLU or identity");
+  SP_CHECK_ARG(!bias || bias_stride >= CP, "sp_conv_partial_finish: bias_stride");
+  SP_CHECK_ARG(!stats || stats_nrep >= 1, "sp_conv_partial_finish: stats replicas");
+  const int vpb = 256 / (CP / 8);
+  int64_t want = (nvox + (int64_t)vpb * 8 - 1) / ((int64_t)vpb * 8);
+  const unsigned grid = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
+  hipLaunchKernelGGL(conv_partial_finish_kernel, dim3(grid), dim3(256), (size_t)CP * 2 * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+                     partial, ngroups, nvox, CP, bias, bias_stride, act, act_param, reinterpret_cast<bf16_t*>(y), stats, stats_nrep);
+  SP_CHECK_LAUNCH("sp_conv_partial_finish");
+  return SP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------- weights

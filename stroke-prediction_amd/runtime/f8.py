@@ -26,6 +26,7 @@ DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient conv
 WGRAD = bool(int(os.environ.get("SP_F8_WGRAD", "1")))       # weight gradients of the fp8 layers on fp8 operands as well (0: from the bf16 tensors)
 FUSE_SLICES = bool(int(os.environ.get("SP_F8_FUSE_SLICES", "1")))  # the output-channel slices of an op in one launch (0: one launch each)
 FUSE_SLICES_MIN = 4      # ... when every workgroup of that launch gets at least this many (column, plane) pairs
+SPLIT = bool(int(os.environ.get("SP_F8_SPLIT", "1")))       # ops with 12 / 16 / 24 input planes as groups of 6 / 8 planes + one finish pass
 WGRAD_ONLY = bool(int(os.environ.get("SP_F8_WGRAD_ONLY", "1")))  # ... and those of the layers whose forward has no fp8 instance (their x8 is made for it)
 DZ_FMT = E5M2 if os.environ.get("SP_F8_DZ", "e5m2") == "e5m2" else E4M3      # storage format of the quantised output gradients
 
@@ -40,13 +41,14 @@ def prep_many(jobs):
     """e4m3 weight fragments of several ConvRunnerF8 (all their output-channel slices) in ONE launch.
     jobs: [(runner, w, b, fold_scale, fold_shift, out_scale)]; jobs whose fragments are current are skipped."""
     todo = []
-    for r, w, b, fs, fsh, osc in jobs:
+    for job in jobs:
+        r, w, b, fs, fsh, osc = job[:6]
         key = None if fs is not None else (w.data_ptr(), w._version, O.PARAM_EPOCH[0], float(osc))
         if key is None or r._key != key:
             todo.append((r, w, b, fs, fsh, osc, key))
     if not todo:
         return
-    tkey = tuple((w.data_ptr(), 0 if b is None else b.data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, float(osc), r.bias.data_ptr(), r.winv.data_ptr()) +
+    tkey = tuple((w.data_ptr(), 0 if b is None else b.data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, float(osc), r.bias.data_ptr(), r.winv.data_ptr(), r.ci0) +
                  tuple(s["wfrag"].data_ptr() for s in r.slices) for r, w, b, fs, fsh, osc, _ in todo)
     tab = _tables.get(tkey)
     if tab is None:
@@ -56,12 +58,14 @@ def prep_many(jobs):
         for r, w, b, fs, fsh, osc, _ in todo:
             op = r.op
             assert w.dtype == torch.float32 and w.is_contiguous()
-            ntaps = w.numel() // (op.cin * op.cout)
+            ntaps = 27                    # (3 x 3 x 3 only)
             want_bias = b is not None or fsh is not None
+            ci0 = r.ci0                   # the runner covers input channels [ci0, ci0 + op.cin) of the weight and of the fold tables
             for s in r.slices:
                 c0 = s["c0"]
-                items.append((w.data_ptr() + 4 * c0 * op.w_sco, op.w_sco, op.w_sci, s["cn"], op.cin, s["kmap_d"].data_ptr(), s["nsteps"], s["NT"],
-                              s["wfrag"].data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, 0 if b is None else b.data_ptr() + 4 * c0,
+                items.append((w.data_ptr() + 4 * (c0 * op.w_sco + ci0 * op.w_sci), op.w_sco, op.w_sci, s["cn"], op.cin, s["kmap_d"].data_ptr(), s["nsteps"], s["NT"],
+                              s["wfrag"].data_ptr(), (O.ptr(fs) + 4 * ci0) if fs is not None else 0, (O.ptr(fsh) + 4 * ci0) if fsh is not None else 0,
+                              0 if b is None else b.data_ptr() + 4 * c0,
                               (r.bias.data_ptr() + 4 * c0) if want_bias else 0, r.winv.data_ptr() + 4 * c0, ntaps, float(osc)))
         arr = np.array(items, dtype=_F8_ITEM)
         dev = torch.from_numpy(arr.view(np.uint8).copy()).to(todo[0][1].device)
@@ -105,9 +109,10 @@ class ConvRunnerF8:
         cols = -(-sub.out_dims[1] // z["TH"]) * -(-sub.out_dims[2] // 16)
         return batch * cols * sub.out_dims[0] >= F8_MIN_PLANES
 
-    def __init__(self, op, device, batch, bin_fmt=E4M3):
+    def __init__(self, op, device, batch, bin_fmt=E4M3, ci0=0):
         assert ConvRunnerF8.applicable(op, batch)
         self.op, self.device, self.batch, self.bin = op, device, batch, bin_fmt
+        self.ci0 = ci0                # first input channel (of the weight tensor and the fold tables) this runner's op starts at
         self.slices = []
         sl = [(c0, cn, P.zm8_plan(sub_op)) for c0, cn, sub_op in P.zm8_slices(op)]
         # equal slices (same tile count, consecutive channel ranges): their fragments share one buffer and ONE launch runs them
@@ -140,22 +145,30 @@ class ConvRunnerF8:
         self.has_bias = False
         self._key = None
 
+    def prep_jobs(self, w, out_scale):
+        """prep_many jobs of an un-folded re-pack (data gradients: the engine batches those of all layers into one launch)"""
+        return [(self, w, None, None, None, out_scale)]
+
     def prep(self, w, b=None, fold_scale=None, fold_shift=None, out_scale=1.0):
         """e4m3 fragments of w (x fold_scale per input channel), folded bias, per-channel dequantisation multipliers
         (x out_scale: the reciprocal of the scale the B operand was quantised with)."""
         prep_many([(self, w, b, fold_scale, fold_shift, out_scale)])      # one launch for all slices
 
     def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
+        """y bf16: the finished output; y fp32: this op's partial sums (one input-channel group of a larger convolution --
+        no bias, activation, statistics; ConvRunnerF8Split adds the groups up)"""
         op, batch = self.op, self.batch
         sub = op.subs[0]
+        partial = y.dtype == torch.float32
         assert x8.dtype == torch.uint8 and tuple(x8.shape) == (op.cpi // 16, batch) + tuple(op.in_dims) + (16,), \
             (tuple(x8.shape), op.cpi, op.in_dims)
-        assert y.dtype == torch.bfloat16 and tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
+        assert (partial or y.dtype == torch.bfloat16) and tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
+        assert not partial or (act == L.ACT_NONE and stats is None and y8 is None)
         if y8 is not None:
             assert self.bin == E4M3 and y8.dtype == torch.uint8 and tuple(y8.shape) == (y.shape[4] // 16, batch) + tuple(op.y_dims) + (16,)
         a = L.ConvArgs()
         a.x = O.ptr(x8)
-        a.dtype_in, a.dtype_out = L.SP_BF16, L.SP_BF16
+        a.dtype_in, a.dtype_out = L.SP_BF16, (L.SP_F32 if partial else L.SP_BF16)
         a.B = batch
         a.Di, a.Hi, a.Wi = op.in_dims
         a.CPi = op.cpi
@@ -177,8 +190,8 @@ class ConvRunnerF8:
         nl = len(self.slices) // self.fuse_m if self.fused else 0
         for s in (self.slices[::self.fuse_m] if self.fused else self.slices):
             c0 = s["c0"]
-            a.y = y.data_ptr() + 2 * c0
-            a.bias = (self.bias.data_ptr() + 4 * c0) if self.has_bias else None
+            a.y = y.data_ptr() + y.element_size() * c0
+            a.bias = (self.bias.data_ptr() + 4 * c0) if (self.has_bias and not partial) else None
             a.f8_wscale = self.winv.data_ptr() + 4 * c0
             a.stats = None if stats is None else stats.data_ptr() + 16 * c0
             a.y8 = None if y8 is None else y8.data_ptr() + (c0 // 16) * plane8
@@ -190,6 +203,66 @@ class ConvRunnerF8:
                                                      (" %d slices in one" % self.fuse_m) if self.fused else (" slices" if len(self.slices) > 1 else ""),
                                                      " +stats" if stats is not None else "")):
                 L.call("sp_conv3d_zm8", C.byref(a), O.ptr(O.zero_page(self.device)), st)
+
+
+class ConvRunnerF8Split:
+    """A stride-1 3x3x3 op with more input planes than an fp8 instance holds (12, 16, 24: the layers behind the concatenations and
+    the 256-channel bottleneck of the 4-scale network): one ConvRunnerF8 per group of 6 or 8 input planes writes fp32 partial sums,
+    ``sp_conv_partial_finish`` adds the groups (and their folded biases), applies the activation and takes the statistics.
+    Same interface as ConvRunnerF8 (no e4m3 copy of the output)."""
+
+    @staticmethod
+    def groups(op):
+        P_ = op.cpi // 16
+        if op.cin != op.cpi or op.cpi % 16:
+            return None
+        for gp in (6, 8):
+            if P_ > 8 and P_ % gp == 0:
+                return gp, P_ // gp
+        return None
+
+    @staticmethod
+    def _sub_op(op, gp):
+        import dataclasses
+        return dataclasses.replace(op, cin=gp * 16, cpi=gp * 16)
+
+    @staticmethod
+    def applicable(op, batch):
+        g = ConvRunnerF8Split.groups(op)
+        return bool(SPLIT and g is not None and ConvRunnerF8.applicable(ConvRunnerF8Split._sub_op(op, g[0]), batch))
+
+    def __init__(self, op, device, batch, bin_fmt=E4M3):
+        assert ConvRunnerF8Split.applicable(op, batch)
+        self.op, self.device, self.batch, self.bin = op, device, batch, bin_fmt
+        self.gp, self.G = ConvRunnerF8Split.groups(op)
+        sub = ConvRunnerF8Split._sub_op(op, self.gp)
+        self.runners = [ConvRunnerF8(sub, device, batch, bin_fmt, ci0=g * self.gp * 16) for g in range(self.G)]
+        self.cpad = self.runners[0].bias.numel()
+        self.bias_all = torch.zeros(self.G, self.cpad, dtype=torch.float32, device=device)
+        for g, r in enumerate(self.runners):
+            r.bias = self.bias_all[g]
+        self.partial = None
+        self.has_bias = False
+
+    def prep(self, w, b=None, fold_scale=None, fold_shift=None, out_scale=1.0):
+        prep_many([(r, w, b if g == 0 else None, fold_scale, fold_shift, out_scale) for g, r in enumerate(self.runners)])
+        self.has_bias = b is not None or fold_shift is not None
+
+    def prep_jobs(self, w, out_scale):
+        return [(r, w, None, None, None, out_scale) for r in self.runners]
+
+    def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
+        op, batch = self.op, self.batch
+        assert y8 is None and y.dtype == torch.bfloat16 and y.shape[4] == self.cpad == op.cpo, (tuple(y.shape), self.cpad, op.cpo)
+        assert tuple(x8.shape) == (op.cpi // 16, batch) + tuple(op.in_dims) + (16,), (tuple(x8.shape), op.cpi)
+        nvox = batch * int(np.prod(op.y_dims))
+        if self.partial is None:
+            self.partial = torch.empty((self.G, batch) + tuple(op.y_dims) + (self.cpad,), dtype=torch.float32, device=self.device)
+        for g, r in enumerate(self.runners):
+            r.run(x8[g * self.gp:(g + 1) * self.gp], self.partial[g])
+        with O._Timed("conv_partial_finish", 0.0, "%d->%d @%s x%d groups" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), self.G)):
+            L.call("sp_conv_partial_finish", O.ptr(self.partial), self.G, nvox, self.cpad, O.ptr(self.bias_all) if self.has_bias else None,
+                   self.cpad, act, act_param, O.ptr(y), O.ptr(stats), stats_nrep, O.stream())
 
 
 class WgradRunnerF8:

@@ -138,8 +138,11 @@ class ConvLayer:
         self.f8_on = True
         self.f8_grad_scale = float(grad_scale)
         if (self.fold and self.kind == "conv" and self.dtype == L.SP_BF16 and self.out_dtype == L.SP_BF16 and self.bank is None
-                and self.act in (L.ACT_NONE, L.ACT_LEAKY) and F8.ConvRunnerF8.applicable(self.fwd_op, self.batch)):
-            self.f8_fwd = F8.ConvRunnerF8(self.fwd_op, self.device, self.batch, F8.E4M3)
+                and self.act in (L.ACT_NONE, L.ACT_LEAKY)):
+            if F8.ConvRunnerF8.applicable(self.fwd_op, self.batch):
+                self.f8_fwd = F8.ConvRunnerF8(self.fwd_op, self.device, self.batch, F8.E4M3)
+            elif F8.ConvRunnerF8Split.applicable(self.fwd_op, self.batch):      # 12 / 16 / 24 input planes: groups of planes
+                self.f8_fwd = F8.ConvRunnerF8Split(self.fwd_op, self.device, self.batch, F8.E4M3)
         # no fp8 forward instance (more input planes than the ring holds, too few columns): the weight gradient can still
         # run on fp8 copies of the two tensors -- the engine then fills x8 in training steps only
         self.f8_wgrad_only = bool(self.f8_fwd is None and F8.WGRAD and F8.WGRAD_ONLY and F8.DZ_FMT == F8.E5M2 and self.fold
@@ -171,7 +174,8 @@ class ConvLayer:
     def y8_capable(self):
         """this layer's forward kernel can write the e4m3 plane-major copy of its output next to the bf16 one"""
         if self.f8_fwd is not None:
-            return True
+            from . import f8 as F8
+            return isinstance(self.f8_fwd, F8.ConvRunnerF8)      # (the split form finishes in an elementwise pass: no copy)
         return bool(self.FUSE_Q8 and self.kind == "conv" and self.G == 1 and not self.materialize and self.out_dtype == L.SP_BF16
                     and self.act in (L.ACT_NONE, L.ACT_LEAKY) and self.fwd.zm_y8_ok())
 
@@ -292,6 +296,9 @@ class ConvLayer:
                 from . import f8 as F8      # plain data gradient (no statistics epilogue): fp8 candidate, dz as e5m2
                 if F8.DGRAD and F8.ConvRunnerF8.applicable(dop, self.batch):
                     self.f8_dgrad = F8.ConvRunnerF8(dop, dev, self.batch, F8.DZ_FMT)
+                elif F8.DGRAD and F8.ConvRunnerF8Split.applicable(dop, self.batch):
+                    self.f8_dgrad = F8.ConvRunnerF8Split(dop, dev, self.batch, F8.DZ_FMT)
+                if self.f8_dgrad is not None:
                     self.dz8 = F8.alloc_f8(self.batch, self.out_dims, self.cpo, dev)
         if (self.f8_fwd is not None or self.f8_wgrad_only) and self.x8 is not None and self.bn_from_wgrad:
             from . import f8 as F8      # weight gradient from the fp8 copies both other convolutions of the layer use

@@ -335,7 +335,7 @@ class UnetEngine:
             f8l = [l for l in self.layers if l.f8_dgrad is not None]
             if f8l:      # ... and ONE for the e4m3 fragments of every fp8 data gradient
                 from . import f8 as F8
-                F8.prep_many([(l.f8_dgrad, params[l.conv_prefix + ".weight"], None, None, None, 1.0 / l.f8_grad_scale) for l in f8l])
+                F8.prep_many([j for l in f8l for j in l.f8_dgrad.prep_jobs(params[l.conv_prefix + ".weight"], 1.0 / l.f8_grad_scale)])
         if self.fused_head:
             nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
             b5, bc, ncls = self.channels[-3], self.channels[-2], self.ncls

@@ -513,3 +513,66 @@ def test_fp8_slices_in_one_launch_equal_one_launch_per_slice(cin, cout, dims, B,
     if not dgrad:
         assert torch.equal(outs[0][1], outs[1][1])
         torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("cin,cout,dims,B,gp", [(192, 64, (9, 36, 35), 1, 96), (384, 128, (8, 34, 34), 1, 96), (256, 32, (8, 34, 36), 2, 128)])
+def test_fp8_conv_with_input_channel_groups_matches_torch_on_quantised_operands(cin, cout, dims, B, gp):
+    """more input planes than an fp8 instance holds (the layers behind the concatenations, the 256-channel bottleneck): groups of
+    6 / 8 planes write fp32 partial sums (sp_conv3d_zm8, dtype_out = f32), sp_conv_partial_finish adds them up with the folded
+    biases, LeakyReLU and the statistics.  The e4m3 weight scale is per (output channel, group)."""
+    g = torch.Generator().manual_seed(cin + cout)
+    x = bf(torch.randn(B, cin, *dims, generator=g) * 1.5)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    fs = torch.rand(cin, generator=g) + 0.5
+    fsh = torch.randn(cin, generator=g) * 0.2
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
+    keep = F8.F8_MIN_PLANES, F8.FUSE_SLICES_MIN
+    F8.F8_MIN_PLANES, F8.FUSE_SLICES_MIN = 1, 1
+    try:
+        assert not F8.ConvRunnerF8.applicable(op, B) and F8.ConvRunnerF8Split.applicable(op, B)
+        run = F8.ConvRunnerF8Split(op, DEV, B, F8.E4M3)
+    finally:
+        F8.F8_MIN_PLANES, F8.FUSE_SLICES_MIN = keep
+    assert run.G == cin // gp
+    x8 = F8.alloc_f8(B, dims, cin, DEV)
+    F8.quantize(_to_cl(x, cin), x8, F8.E4M3, 1.0)
+    run.prep(w.to(DEV), b.to(DEV), fs.to(DEV), fsh.to(DEV))
+    y = torch.full((B,) + tuple(op.y_dims) + (cout,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    nrep = 8
+    stats = torch.zeros(nrep, cout, 2, dtype=torch.float64, device=DEV)
+    run.run(x8, y, L.ACT_LEAKY, LEAKY, stats, nrep)
+    wf = w * fs.view(1, -1, 1, 1, 1)
+    wq = torch.cat([nets.quant_weights_e4m3(wf[:, c0:c0 + gp].contiguous()) for c0 in range(0, cin, gp)], 1)
+    bfold = b + (w * fsh.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
+    ref = F.leaky_relu(F.conv3d(nets.round_e4m3(x).double(), wq.double(), bfold.double()), LEAKY).float()
+    got = y.float().cpu().permute(0, 4, 1, 2, 3)
+    err = (got - ref).abs() / (ref.abs() + 0.05)
+    assert float(err.max()) < 1.2e-2 and float(err.mean()) < 2e-3, (float(err.max()), float(err.mean()))
+    s = stats.sum(0).cpu()
+    n = ref.numel() / cout
+    np.testing.assert_allclose(s[:, 0].numpy() / n, got.double().mean(dim=(0, 2, 3, 4)).numpy(), rtol=0, atol=1e-4)
+    np.testing.assert_allclose(s[:, 1].numpy() / n, (got.double() ** 2).mean(dim=(0, 2, 3, 4)).numpy(), rtol=1e-4, atol=1e-5)
+    # data gradient of a convolution with `cin` OUTPUT channels: the op's input planes are dz's
+    od = tuple(d - 2 for d in dims)
+    S = 2.0 ** 20
+    ci2 = 32
+    dz = bf(torch.randn(B, cin, *od, generator=g) * 1e-6)
+    w2 = torch.randn(cin, ci2, 3, 3, 3, generator=g) / math.sqrt(27 * ci2)
+    dop = P.conv_dgrad_op(ci2, cin, 3, 1, 0, dims, cin, ci2, L.SP_BF16)
+    F8.F8_MIN_PLANES, F8.FUSE_SLICES_MIN = 1, 1
+    try:
+        drun = F8.ConvRunnerF8Split(dop, DEV, B, F8.E5M2)
+    finally:
+        F8.F8_MIN_PLANES, F8.FUSE_SLICES_MIN = keep
+    dz8 = F8.alloc_f8(B, od, cin, DEV)
+    F8.quantize(_to_cl(dz, cin), dz8, F8.E5M2, S)
+    drun.prep(w2.to(DEV), out_scale=1.0 / S)
+    gout = torch.full((B,) + tuple(dims) + (ci2,), float("nan"), dtype=torch.bfloat16, device=DEV)
+    drun.run(dz8, gout)
+    # one e4m3 scale per (input channel of the conv, group of its output channels)
+    wq2 = torch.cat([nets.quant_weights_e4m3(w2[c0:c0 + gp].permute(1, 0, 2, 3, 4).contiguous()).permute(1, 0, 2, 3, 4) for c0 in range(0, cin, gp)], 0)
+    gref = F.conv_transpose3d((nets.round_e5m2(dz * S) / S).double(), wq2.double()).float()
+    gg = gout.float().cpu().permute(0, 4, 1, 2, 3)
+    sc = float(gref.abs().mean())
+    assert float(((gg - gref).abs() / (gref.abs() + 0.5 * sc)).max()) < 1.2e-2
