@@ -217,6 +217,15 @@ __device__ __forceinline__ double sp_rows_sum(const double* __restrict__ d, int 
   return t;
 }
 
+// ---- ordered (run-to-run reproducible) block reduction of per-wave column partials: wave w stores its value of column k at
+// red[w * ncol + k] (exactly one lane per wave and column), and after a barrier sp_cols_sum adds the waves up in wave order --
+// no LDS float atomics, whose arrival order (and with it the fp32 rounding) changes from run to run
+__device__ __forceinline__ float sp_cols_sum(const float* red, int ncol, int nwaves, int k) {
+  float t = 0.f;
+  for (int w = 0; w < nwaves; ++w) t += red[w * ncol + k];
+  return t;
+}
+
 // ---- exact unsigned division by a runtime constant (host computes mul/shift) --------------------
 struct FastDiv { uint32_t mul, shift; };
 __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv d) { return (__umulhi(n, d.mul) + n) >> d.shift; }

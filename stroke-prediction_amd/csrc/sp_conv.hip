@@ -318,23 +318,21 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
   STAMP(4);
   if (a.stats) {
     __syncthreads();                       // tile no longer needed: reuse LDS for the block reduction
-    float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < NT * 16 * 2; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [4 waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1 = row16_sum(s1[n][j]), x2 = row16_sum(s2[n][j]);
         if (lv == 0) {
-          atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1);
-          atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2);
+          red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1;
+          red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2;
         }
       }
     __syncthreads();
     for (int i = tid; i < NT * 16 * 2; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&g_stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&g_stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NT * 32, 4, i));
     }
   }
   STAMP(5);

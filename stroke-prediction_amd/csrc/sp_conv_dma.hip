@@ -286,17 +286,15 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
   STAMP(4);
   if (a.stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < NT * 16 * 2; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [4 waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1 = row16_sum(s1[n][j]), x2 = row16_sum(s2[n][j]);
         if (lv == 0) {
-          atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1);
-          atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2);
+          red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1;
+          red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2;
         }
       }
     __syncthreads();
@@ -305,7 +303,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
     double* const g_stats = a.stats + (size_t)(a.group_batch > 0 ? b / a.group_batch : 0) * a.stats_nrep * a.CPo * 2;
     for (int i = tid; i < NT * 16 * 2; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&g_stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&g_stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NT * 32, 4, i));
     }
   }
   STAMP(5);
@@ -517,18 +515,16 @@ __global__ __launch_bounds__(256) void conv_igemm_persist_kernel(const ConvDmaDe
   }
   if (want_stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < 32; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [4 waves][32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float x1s = row16_sum(s1[j]), x2s = row16_sum(s2[j]);
-      if (lv == 0) { atomicAdd(&red[(lg * 4 + j) * 2], x1s); atomicAdd(&red[(lg * 4 + j) * 2 + 1], x2s); }
+      if (lv == 0) { red[wave * 32 + (lg * 4 + j) * 2] = x1s; red[wave * 32 + (lg * 4 + j) * 2 + 1] = x2s; }
     }
     __syncthreads();
     for (int i = tid; i < 32; i += 256) {
       const int c = i >> 1;
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, 32, 4, i));
     }
   }
 }
@@ -718,20 +714,18 @@ __global__ __launch_bounds__(256, (NT == 1 ? 2 : 1)) void conv_igemm_zs_kernel(c
   }
   if (want_stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < NT * 32; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [4 waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
-        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+        if (lv == 0) { red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1s; red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2s; }
       }
     __syncthreads();
     for (int i = tid; i < NT * 32; i += 256) {
       const int c = i >> 1;
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NT * 32, 4, i));
     }
   }
 }
@@ -921,20 +915,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_zr_kernel(const ConvZsDev P
   }
   if (want_stats) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    for (int i = tid; i < NT * 32; i += 256) red[i] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [4 waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
-        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+        if (lv == 0) { red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1s; red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2s; }
       }
     __syncthreads();
     for (int i = tid; i < NT * 32; i += 256) {
       const int c = i >> 1;
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NT * 32, 4, i));
     }
   }
 }

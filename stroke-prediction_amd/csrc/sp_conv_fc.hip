@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_fc_finish_kernel(const ConvFcDev P) 
 template <int SPT, int NTB, typename TOUT>      // compile-time K steps and output tiles per workgroup: no guard around an MFMA, no idle MFMA
 __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
   const sp_conv_fc_args& a = P.a;
-  __shared__ float red[NTB * 16 * 2];
+  __shared__ float red[4 * NTB * 16 * 2];      // [wave][column]: added up in wave order (sp_cols_sum)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int vl = lane & 15, g = lane >> 4;
   const int nt0 = blockIdx.y * NTB;
@@ -289,19 +289,17 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
     }
   }
   if (a.stats) {
-    for (int i = threadIdx.x; i < NTB * 32; i += 256) red[i] = 0.f;
-    __syncthreads();
 #pragma unroll
     for (int n = 0; n < NTB; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1 = row16_sum(s1[n][j]), x2 = row16_sum(s2[n][j]);
-        if (vl == 0 && n < nn) { atomicAdd(&red[(n * 16 + g * 4 + j) * 2], x1); atomicAdd(&red[(n * 16 + g * 4 + j) * 2 + 1], x2); }
+        if (vl == 0 && n < nn) { red[wave * (NTB * 32) + (n * 16 + g * 4 + j) * 2] = x1; red[wave * (NTB * 32) + (n * 16 + g * 4 + j) * 2 + 1] = x2; }
       }
     __syncthreads();
     for (int i = threadIdx.x; i < nn * 32; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)red[i]);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NTB * 32, 4, i));
     }
   }
 }

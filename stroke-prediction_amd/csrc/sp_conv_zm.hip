@@ -416,20 +416,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #endif
   if (STATS && a.stats != nullptr) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    for (int k = tid; k < NT * 32; k += 64 * NW) red[k] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [NW waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
-        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+        if (lv == 0) { red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1s; red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2s; }
       }
     __syncthreads();
     for (int k = tid; k < NT * 32; k += 64 * NW) {
       const int c = k >> 1;
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)red[k]);
+      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
     }
   }
 }

@@ -335,20 +335,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (STATS && stats_sl != nullptr) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);
-    for (int k = tid; k < NT * 32; k += 64 * NW) red[k] = 0.f;
-    __syncthreads();
+    float* red = reinterpret_cast<float*>(lds);      // [NW waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
     for (int n = 0; n < NT; ++n)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
-        if (lv == 0) { atomicAdd(&red[(n * 16 + lg * 4 + j) * 2], x1s); atomicAdd(&red[(n * 16 + lg * 4 + j) * 2 + 1], x2s); }
+        if (lv == 0) { red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1s; red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2s; }
       }
     __syncthreads();
     for (int k = tid; k < NT * 32; k += 64 * NW) {
       const int c = k >> 1;
-      if (c0s + c < a.CPo) atomicAdd(&stats_sl[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)red[k]);
+      if (c0s + c < a.CPo) atomicAdd(&stats_sl[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
     }
   }
 }
@@ -462,7 +460,7 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
 __global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* __restrict__ partial, int G, int64_t M, int CP,
                                                                    const float* __restrict__ bias, int bias_stride, int act, float ap,
                                                                    bf16_t* __restrict__ y, double* __restrict__ stats, int nrep) {
-  extern __shared__ float red[];      // [CP][2]
+  __shared__ __attribute__((aligned(16))) float tr[256 * 16];
   const int OC = CP / 8;
   const int pos = threadIdx.x / OC, oc = threadIdx.x - pos * OC, vpb = 256 / OC;
   const bool active = pos < vpb;
@@ -520,14 +518,16 @@ __global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* _
       }
     }
   }
-  if (stats) {
-    for (int k = threadIdx.x; k < CP * 2; k += 256) red[k] = 0.f;
+  if (stats) {      // ordered: thread t's sixteen partials at tr[t][*]; column (channel, moment) = the sum over the voxel slots in order
+    float4* d = reinterpret_cast<float4*>(tr + threadIdx.x * 16);
+    d[0] = make_float4(s1[0], s2[0], s1[1], s2[1]); d[1] = make_float4(s1[2], s2[2], s1[3], s2[3]);
+    d[2] = make_float4(s1[4], s2[4], s1[5], s2[5]); d[3] = make_float4(s1[6], s2[6], s1[7], s2[7]);
     __syncthreads();
-    if (active)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { atomicAdd(&red[(oc * 8 + j) * 2], s1[j]); atomicAdd(&red[(oc * 8 + j) * 2 + 1], s2[j]); }
-    __syncthreads();
-    for (int k = threadIdx.x; k < CP * 2; k += 256) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * CP * 2 + k], (double)red[k]);
+    for (int k = threadIdx.x; k < CP * 2; k += 256) {
+      float t = 0.f;
+      for (int v = 0; v < vpb; ++v) t += tr[(v * OC) * 16 + k];      // thread (v, oc = k / 16) holds columns [16 oc, 16 oc + 16)
+      atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * CP * 2 + k], (double)t);
+    }
   }
 }
 
@@ -541,7 +541,7 @@ extern "C" int sp_conv_partial_finish(const float* partial, int32_t ngroups, int
   const int vpb = 256 / (CP / 8);
   int64_t want = (nvox + (int64_t)vpb * 8 - 1) / ((int64_t)vpb * 8);
   const unsigned grid = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
-  hipLaunchKernelGGL(conv_partial_finish_kernel, dim3(grid), dim3(256), (size_t)CP * 2 * sizeof(float), reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(conv_partial_finish_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      partial, ngroups, nvox, CP, bias, bias_stride, act, act_param, reinterpret_cast<bf16_t*>(y), stats, stats_nrep);
   SP_CHECK_LAUNCH("sp_conv_partial_finish");
   return SP_OK;

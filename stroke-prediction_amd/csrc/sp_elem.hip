@@ -851,7 +851,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
                                                           Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane,
                                                           double* __restrict__ stats, const SpQ8 q8) {
-  __shared__ float red[32];
+  __shared__ float red[4 * 32];
   const int p = blockIdx.y, nup = CPu >> 4;
   const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
   const int oz = (ds.D - Do) / 2, oy = (ds.H - Ho) / 2, ox = (ds.W - Wo) / 2;
@@ -928,8 +928,7 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
     }
   }
   if (stats) {       // channel c = p*16 + half*8 + 2j + {0,1}: lanes of one parity hold the same eight channels
-    if (threadIdx.x < 32) red[threadIdx.x] = 0.f;
-    __syncthreads();
+    __syncthreads();      // (red: [4 waves][32], added up in wave order -- sp_cols_sum)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float v4[4] = {s1[j].x, s2[j].x, s1[j].y, s2[j].y};         // (sum, sum^2) of channel 2j, then of channel 2j + 1
@@ -938,12 +937,12 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
         float v = v4[k];
 #pragma unroll
         for (int o = 32; o > 1; o >>= 1) v += __shfl_xor(v, o, 64);
-        if ((threadIdx.x & 63) < 2) atomicAdd(&red[(half * 8 + 2 * j + (k >> 1)) * 2 + (k & 1)], v);
+        if ((threadIdx.x & 63) < 2) red[(threadIdx.x >> 6) * 32 + (half * 8 + 2 * j + (k >> 1)) * 2 + (k & 1)] = v;
       }
     }
     __syncthreads();
     if (threadIdx.x < 32)
-      atomicAdd(&stats[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CPd * 2 + (size_t)p * 32 + threadIdx.x], (double)red[threadIdx.x]);
+      atomicAdd(&stats[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CPd * 2 + (size_t)p * 32 + threadIdx.x], (double)sp_cols_sum(red, 32, 4, threadIdx.x));
   }
 }
 
@@ -1667,9 +1666,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void out_grad_to_cl_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                               int C, int64_t DHW, int CP, int64_t total, int act, float ap,
                                                               T* __restrict__ dz, double* __restrict__ dbias) {
-  __shared__ float red[8];
-  if (threadIdx.x < 8) red[threadIdx.x] = 0.f;
-  __syncthreads();
+  __shared__ float red[4 * 8];      // [wave][channel]
   float part[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) part[j] = 0.f;
@@ -1694,10 +1691,10 @@ __global__ __launch_bounds__(256) void out_grad_to_cl_kernel(const float* __rest
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float s = wave_sum(part[j]);
-    if ((threadIdx.x & 63) == 0 && j < C) atomicAdd(&red[j], s);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 8 + j] = s;      // (ordered: sp_cols_sum)
   }
   __syncthreads();
-  if (dbias && threadIdx.x < C) atomicAdd(&dbias[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CP + threadIdx.x], (double)red[threadIdx.x]);
+  if (dbias && threadIdx.x < C) atomicAdd(&dbias[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CP + threadIdx.x], (double)sp_cols_sum(red, 8, 4, threadIdx.x));
 }
 extern "C" int sp_out_grad_to_cl(const float* dout, const float* out, int32_t B, int32_t C, int64_t DHW, int32_t CP,
                                  int32_t dtype, int32_t act, float act_param, void* dz, double* dbias_sums,
@@ -1725,18 +1722,16 @@ __global__ __launch_bounds__(256) void dice_sums_kernel(const float* __restrict_
     const float a = op[i], bb = tp[i];
     s[0] += a * bb; s[1] += a * a; s[2] += bb * bb;
   }
-  __shared__ float red[3];
-  if (threadIdx.x < 3) red[threadIdx.x] = 0.f;
-  __syncthreads();
+  __shared__ float red[4 * 3];      // [wave][moment], added up in wave order (sp_cols_sum)
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float w = wave_sum(s[k]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], w);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 3 + k] = w;
   }
   __syncthreads();
   // replica row per workgroup (rows 128 bytes or more apart): 1024 same-line fp64 atomics cost ~20 us at the tail
   if (threadIdx.x < 3)
-    atomicAdd(&sums[(size_t)((blockIdx.x + blockIdx.y) % SP_REDUCE_ROWS) * SP_DICE_PITCH(C) + c * 3 + threadIdx.x], (double)red[threadIdx.x]);
+    atomicAdd(&sums[(size_t)((blockIdx.x + blockIdx.y) % SP_REDUCE_ROWS) * SP_DICE_PITCH(C) + c * 3 + threadIdx.x], (double)sp_cols_sum(red, 3, 4, threadIdx.x));
 }
 extern "C" int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, int32_t B, int32_t C,
                             int64_t DHW, double* sums, sp_stream_t stream) {

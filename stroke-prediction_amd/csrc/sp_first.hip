@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
                                                          bf16_t* __restrict__ y, double* __restrict__ stats, int nrep,
                                                          unsigned char* __restrict__ y8, int64_t y8_plane) {
   __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];
-  __shared__ float red[32 * NT];
+  __shared__ float red[4 * 32 * NT];      // [wave][column]: added up in wave order (sp_cols_sum)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
   bf16x8 af[NT][3];
   int goff[3];
@@ -292,17 +292,16 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
     }
   }
   if (stats) {
-    for (int k = tid; k < 32 * NT; k += 256) red[k] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1 = row16_sum(s1[nt][j]), x2 = row16_sum(s2[nt][j]);
-        if (n == 0) { atomicAdd(&red[(nt * 16 + lg * 4 + j) * 2], x1); atomicAdd(&red[(nt * 16 + lg * 4 + j) * 2 + 1], x2); }
+        if (n == 0) { red[wave * (32 * NT) + (nt * 16 + lg * 4 + j) * 2] = x1; red[wave * (32 * NT) + (nt * 16 + lg * 4 + j) * 2 + 1] = x2; }
       }
     __syncthreads();
-    if (tid < 32 * NT) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * (32 * NT) + tid], (double)red[tid]);
+    if (tid < 32 * NT) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * (32 * NT) + tid], (double)sp_cols_sum(red, 32 * NT, 4, tid));
   }
 }
 
@@ -484,9 +483,8 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
   // ---- flush: D[row = co = lg*4 + j][col = r = n]; one partial block [tap = r*3 + dx][co][c] per workgroup, the four
   // waves' tiles added through LDS
   __syncthreads();
-  float* st = reinterpret_cast<float*>(dzt);
-  for (int i = tid; i < 27 * CO * 2; i += 256) st[i] = 0.f;
-  __syncthreads();
+  float* st = reinterpret_cast<float*>(dzt);      // [4 waves][27 * CO * 2] (27.6 KiB at CO = 32; the dz tile holds 32 KiB)
+  static_assert(4 * 27 * CO * 2 * 4 <= NT * DZP, "per-wave weight-gradient slabs do not fit the dz tile");
   if (n < 9) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -495,25 +493,23 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(&st[((n * 3 + d) * CO + t * 16 + lg * 4 + j) * 2 + c], acc[t][d][c][j]);
+          for (int j = 0; j < 4; ++j) st[wave * (27 * CO * 2) + ((n * 3 + d) * CO + t * 16 + lg * 4 + j) * 2 + c] = acc[t][d][c][j];
   }
   __syncthreads();
-  for (int i = tid; i < 27 * CO * 2; i += 256) part[(size_t)blockIdx.x * (27 * CO * 2) + i] = st[i];
+  for (int i = tid; i < 27 * CO * 2; i += 256) part[(size_t)blockIdx.x * (27 * CO * 2) + i] = sp_cols_sum(st, 27 * CO * 2, 4, i);      // wave order
   if (FUSED && dbias) {       // sum of dz per output channel: threads with equal tid % (2 NT) hold the same eight channels
     __syncthreads();
-    float* rd = st;           // CO floats
-    if (tid < CO) rd[tid] = 0.f;
-    __syncthreads();
+    float* rd = st;           // [4 waves][CO]
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float v = dsum[j];
       // lanes of one octet: xor-reduce over the other lane bits
 #pragma unroll
       for (int o = 32; o >= 2 * NT; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane < 2 * NT) atomicAdd(&rd[lane * 8 + j], v);
+      if (lane < 2 * NT) rd[wave * CO + lane * 8 + j] = v;
     }
     __syncthreads();
-    if (tid < CO) atomicAdd(&dbias[(blockIdx.x % SP_REDUCE_ROWS) * CO + tid], (double)rd[tid]);
+    if (tid < CO) atomicAdd(&dbias[(blockIdx.x % SP_REDUCE_ROWS) * CO + tid], (double)sp_cols_sum(rd, CO, 4, tid));
   }
 }
 
