@@ -419,6 +419,10 @@ def bench_unet(args, world, rank, dev, four_scale=False):
     images = torch.randn((args.batch, 2) + size, generator=g, device=dev)
     labels = (torch.rand((args.batch, 2) + tuple(out), generator=g, device=dev) > 0.7).float()
     batch = {"case_id": list(range(args.batch)), "images": images, "labels": labels, "clinical": None}
+    # the synthetic batch lives in the captured step's own input buffers (what a loader that writes into Learner.static_batch()'s
+    # tensors does): no device-to-device copy of resident inputs inside the step
+    if not os.environ.get("SP_BENCH_COPY_INPUTS"):      # (A/B knob: the per-step copy of the batch into the step's buffers)
+        batch = learner.static_batch(batch, 0)
 
     def step():
         return learner.train_batch(batch, 0)
@@ -439,7 +443,8 @@ def bench_unet(args, world, rank, dev, four_scale=False):
         "config": {"workload": "%s, batch %d/GPU, 2x%d^3 -> 2x%d^3, Learner.train_batch = fwd+Dice+bwd+Adam (%s)"
                                % (name, args.batch, args.size, out[0], "configs[4] topology" if four_scale else "configs[1]"),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(last.loss),
-                   "launch": launch_mode, "dp_mode": args.dp_mode if world > 1 else None,
+                   "launch": launch_mode, "input": "resident in the step's input buffers (Learner.static_batch)" if (use_graph and not os.environ.get("SP_BENCH_COPY_INPUTS")) else "resident device tensors",
+                   "dp_mode": args.dp_mode if world > 1 else None,
                    "grad_exchange": (("one all-reduce of the flat gradient buffer between the backward graph and Adam"
                                       if (use_graph and not os.environ.get("SP_DIST_GRAPH")) else
                                       "%d buckets, reverse layer order, async on the RCCL stream" % sync.nbuckets_last)
@@ -569,6 +574,7 @@ def bench_cae(args, world, rank, dev):
     labels, clinical = D.synthetic_shape_batch(args.batch, d, hw, 1234 + rank)
     batch = {"case_id": list(range(args.batch)), "images": None, "labels": labels.to(dev), "clinical": clinical.to(dev)}
     epoch = 30                                                          # latent-loss ramp factor 0.2
+    batch = learner.static_batch(batch, epoch)                          # (see the U-Net workload)
 
     def step():
         return learner.train_batch(batch, epoch)

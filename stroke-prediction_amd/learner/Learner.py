@@ -205,6 +205,28 @@ class Learner(Inference):
         a new value means a new capture"""
         return None
 
+    def static_batch(self, batch: dict, epoch=0) -> dict:
+        """graph mode: the batch with its tensors replaced by the captured step's own input buffers (filled from ``batch``).
+        An input pipeline that writes every batch straight into these tensors (``t.copy_(host_batch)``) and passes the
+        dict to ``train_batch`` saves the device-to-device copy of each step; any other batch of the same shapes is
+        copied in as before."""
+        if not self._graph_enabled:
+            return batch
+        dev = next(self._model.parameters()).device
+        tensors = {k: v for k, v in batch.items() if torch.is_tensor(v)}
+        key = (tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(tensors.items())), self.graph_key(epoch))
+        g = self._graphs.get(key)
+        if g is None:
+            if len(self._graphs) >= 4:
+                self._graphs.clear()
+            g = self._graphs[key] = dict(static={k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in tensors.items()},
+                                         warm=0, graph=None, dto=None, loss=None)
+        out = dict(batch)
+        for k, v in tensors.items():
+            g["static"][k].copy_(v, non_blocking=True)
+            out[k] = g["static"][k]
+        return out
+
     def _optimise_graph(self, batch: dict, epoch):
         if not getattr(self._optimizer, "capturable", False):
             raise RuntimeError("Learner(graph=True) needs an optimiser whose step can be captured and whose hyper-parameters "
@@ -219,7 +241,8 @@ class Learner(Inference):
             g = self._graphs[key] = dict(static={k: torch.empty(v.shape, dtype=v.dtype, device=dev) for k, v in tensors.items()},
                                          warm=0, graph=None, dto=None, loss=None)
         for k, v in tensors.items():
-            g["static"][k].copy_(v, non_blocking=True)
+            if v.data_ptr() != g["static"][k].data_ptr():      # (a batch from static_batch() IS the static buffers: nothing to copy)
+                g["static"][k].copy_(v, non_blocking=True)
         sbatch = dict(batch)
         sbatch.update(g["static"])
         # Data-parallel replicas (parallel.DataParallelSync installed model.grad_sync): the gradient all-reduce stays OUTSIDE

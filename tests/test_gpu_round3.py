@@ -358,3 +358,37 @@ def test_cae_training_steps_are_bit_identical_from_run_to_run(graph):
     assert torch.equal(a[2], b[2]) and torch.equal(a[5], b[5])
     for k in a[3]:
         assert torch.equal(a[3][k], b[3][k]), k
+
+
+def test_static_batch_skips_the_input_copy_and_changes_nothing():
+    """Learner.static_batch: a batch that already lives in the captured step's input buffers is not copied again, and the
+    trajectory equals the one of ordinary batches (bit for bit: reproducible reductions)."""
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.UnetSegmentationLearner import UnetSegmentationLearner
+
+    class Loader(list):
+        batch_size = 2
+    x, y = W.unet_inputs(2, (52, 52, 52), 3)
+    out = {}
+    for tag in ("plain", "static"):
+        batch = {"case_id": [0, 1], "images": x.to(DEV), "labels": y.to(DEV), "clinical": None}
+        model = _build(CH, 3, "bf16").train()
+        opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999), capturable=True)
+        attach_flat_grads(model)
+        learner = UnetSegmentationLearner(Loader([batch]), None, model, opt, None, 1, BatchDiceLoss([1.0]), None, "/tmp/_sb_" + tag,
+                                          graph=True, batch_metrics=False)
+        learner.GRAPH_WARMUP = 1
+        if tag == "static":
+            sb = learner.static_batch(batch, 0)
+            assert sb["images"].data_ptr() != batch["images"].data_ptr() and torch.equal(sb["images"], batch["images"])
+            batch = sb
+        losses = [learner.train_batch(batch, 0).loss for _ in range(4)]
+        if tag == "static":       # the buffers are the graph's: a new batch written into them is what the next replay trains on
+            g = next(iter(learner._graphs.values()))
+            assert g["static"]["images"].data_ptr() == batch["images"].data_ptr() and g["graph"] is not None
+            batch["images"].mul_(0.5)
+            l5 = learner.train_batch(batch, 0).loss
+            assert l5 != losses[-1]
+        out[tag] = (losses, model.flat_buffers()[0].clone() if tag == "plain" else None)
+    assert out["plain"][0] == out["static"][0], (out["plain"][0], out["static"][0])
