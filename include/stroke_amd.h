@@ -523,6 +523,8 @@ int sp_dice_bwd(const float* o, int64_t o_bstride, const float* t, int64_t t_bst
  * w1 is (CH, C), w2 is (NC, CH) row-major (the Conv3d 1x1x1 weights).  sp_head_supported lists the shapes with a
  * fused kernel; other shapes run as two generic sp_conv3d_igemm layers. */
 int sp_head_supported(int32_t C, int32_t CH, int32_t NC);
+/* the same with the storage type: (C, CH, NC) = (32, 32, 2), the head of the 4-scale network, exists for SP_BF16 only */
+int sp_head_supported_dtype(int32_t C, int32_t CH, int32_t NC, int32_t dtype);
 int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
                 const float* b1, int32_t CH, const float* w2, const float* b2, int32_t NC, float slope, float* seg,
                 sp_stream_t stream);

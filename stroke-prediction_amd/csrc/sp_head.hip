@@ -199,19 +199,20 @@ __device__ __forceinline__ void hd_split(float w, short& hi, short& lo) {
   hi = (short)h; lo = (short)f2bf(w - bf2f(h));
 }
 
-template <int CH, int NC>
+template <int CH, int NC, int CT = 1>      // CT input-channel tiles: C = 16 (the 3-scale network) or 32 (the 4-scale one)
 __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const bf16_t* __restrict__ x, int64_t nvox_per_b, int64_t total,
                                                              int CP, const float* __restrict__ w1, const float* __restrict__ b1,
                                                              const float* __restrict__ w2, const float* __restrict__ b2,
                                                              float slope, float* __restrict__ seg) {
-  constexpr int C = 16, NP = CH / 16, KV = 4 * NP;
+  constexpr int C = 16 * CT, NP = CH / 16, KV = 4 * NP, KX = 4 * CT;
   typedef typename HeadK<NP>::vec kvec;
+  typedef typename HeadK<CT>::vec xvec;              // first-stage operands: K = C
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
-  hd_bf16x4 a1h[NP], a1l[NP];
+  xvec a1h[NP], a1l[NP];
 #pragma unroll
   for (int t = 0; t < NP; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { short h, l; hd_split(w1[(16 * t + n) * C + 4 * lg + e], h, l); a1h[t][e] = h; a1l[t][e] = l; }
+    for (int e = 0; e < KX; ++e) { short h, l; hd_split(w1[(16 * t + n) * C + HeadK<CT>::k_of(lg, e)], h, l); a1h[t][e] = h; a1l[t][e] = l; }
   kvec a2h, a2l;
 #pragma unroll
   for (int e = 0; e < KV; ++e) { short h, l; hd_split(n < NC ? w2[n * CH + HeadK<NP>::k_of(lg, e)] : 0.f, h, l); a2h[e] = h; a2l[e] = l; }
@@ -227,14 +228,23 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const bf16_t* __rest
     for (int g = 0; g < 4; ++g) {
       const int64_t v = it * 256 + wave * 64 + g * 16 + n;
       const bool valid = v < total;
-      hd_bf16x4 xb = {0, 0, 0, 0};
-      if (valid) xb = *reinterpret_cast<const hd_bf16x4*>(x + v * CP + 4 * lg);
+      xvec xb;
+#pragma unroll
+      for (int e = 0; e < KX; ++e) xb[e] = 0;
+      if (valid) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const hd_bf16x4 q = *reinterpret_cast<const hd_bf16x4*>(x + v * CP + 16 * ct + 4 * lg);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xb[4 * ct + e] = q[e];
+        }
+      }
       short hb[KV];
 #pragma unroll
       for (int t = 0; t < NP; ++t) {
         f32x4 hp = {b1k[t][0], b1k[t][1], b1k[t][2], b1k[t][3]};
-        hp = SP_MFMA16_K16(a1h[t], xb, hp, 0, 0, 0);
-        hp = SP_MFMA16_K16(a1l[t], xb, hp, 0, 0, 0);
+        hp = HeadK<CT>::mma(a1h[t], xb, hp);
+        hp = HeadK<CT>::mma(a1l[t], xb, hp);
 #pragma unroll
         for (int j = 0; j < 4; ++j) hb[4 * t + j] = (short)f2bf(fmaxf(hp[j], slope * hp[j]));
       }
@@ -253,10 +263,10 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_kernel(const bf16_t* __rest
   }
 }
 
-template <int CH, int NC>
+template <int CH, int NC, int CT = 1>      // CT input-channel tiles (C = 16 CT)
 // (256, 3): without the bound hipcc splits 130 VGPRs + 44 AGPRs (2 waves per SIMD, 116 us); asked for three waves it fits
-// everything into 148 VGPRs without scratch: 81 us
-__global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ seg,
+// everything into 148 VGPRs without scratch: 81 us.  (C = 32: two waves per SIMD.)
+__global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void head_bwd_mfma_kernel(const bf16_t* __restrict__ x, const float* __restrict__ seg,
                                                              const float* __restrict__ dseg, int64_t nvox_per_b,
                                                              int64_t total, int CP, const float* __restrict__ w1,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
@@ -264,31 +274,34 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
                                                              bf16_t* __restrict__ dz, float* __restrict__ part) {
   const bool lin_x = act_x == SP_ACT_LEAKY || act_x == SP_ACT_NONE;
   const float slope_x = act_x == SP_ACT_LEAKY ? act_x_p : 1.f;
-  constexpr int C = 16, NP = CH / 16, NPL = 2 + 2 * NP, KV = 4 * NP;      // planes: X, AUX, DHP[NP], H[NP]
+  constexpr int C = 16 * CT, NP = CH / 16, NPL = CT + 1 + 2 * NP, KV = 4 * NP, KX = 4 * CT;      // planes: X[CT], AUX, DHP[NP], H[NP]
   constexpr int PLANE = 64 * 32;                                          // bytes of one 64-voxel plane
   typedef typename HeadK<NP>::vec kvec;
+  typedef typename HeadK<CT>::vec xvec;
   static_assert(NC <= 3, "AUX row = (do_0..do_{NC-1}, 1) packs into four bf16");
   __shared__ __attribute__((aligned(16))) unsigned char lds[4 * NPL * PLANE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = lane >> 4, li = lane & 15, lq = li >> 2, lp = li & 3, n = li;
   unsigned char* wt = lds + wave * NPL * PLANE;
   unsigned char* tX = wt;
-  unsigned char* tA = wt + PLANE;
-  unsigned char* tD = wt + 2 * PLANE;
-  unsigned char* tH = wt + (2 + NP) * PLANE;
+  unsigned char* tA = wt + CT * PLANE;
+  unsigned char* tD = wt + (CT + 1) * PLANE;
+  unsigned char* tH = wt + (CT + 1 + NP) * PLANE;
   // transposed-read offsets inside a 32-voxel K block (same voxel permutation for both operands)
   const int vq0 = ((lg & 1) ? 2 * lg + 1 : 2 * lg) * 4 + lq;
   const int vq1 = ((lg & 1) ? 2 * lg : 2 * lg + 1) * 4 + lq;
   const int off0 = vq0 * 32 + lp * 8, off1 = vq1 * 32 + lp * 8;
 
-  hd_bf16x4 a1h[NP], a1l[NP];                         // hp = W1 x
+  xvec a1h[NP], a1l[NP];                              // hp = W1 x
 #pragma unroll
   for (int t = 0; t < NP; ++t)
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { short h, l; hd_split(w1[(16 * t + n) * C + 4 * lg + e], h, l); a1h[t][e] = h; a1l[t][e] = l; }
-  kvec aTh, aTl;                                      // dx = W1^T dhp, K order of the chained operand
+    for (int e = 0; e < KX; ++e) { short h, l; hd_split(w1[(16 * t + n) * C + HeadK<CT>::k_of(lg, e)], h, l); a1h[t][e] = h; a1l[t][e] = l; }
+  kvec aTh[CT], aTl[CT];                              // dx = W1^T dhp (one output tile per 16 input channels), K order of the chained operand
 #pragma unroll
-  for (int e = 0; e < KV; ++e) { short h, l; hd_split(w1[HeadK<NP>::k_of(lg, e) * C + n], h, l); aTh[e] = h; aTl[e] = l; }
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int e = 0; e < KV; ++e) { short h, l; hd_split(w1[HeadK<NP>::k_of(lg, e) * C + 16 * ct + n], h, l); aTh[ct][e] = h; aTl[ct][e] = l; }
   float b1k[NP][4], w2k[NC][NP][4];
 #pragma unroll
   for (int t = 0; t < NP; ++t)
@@ -299,10 +312,18 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
       for (int c = 0; c < NC; ++c) w2k[c][t][j] = w2[c * CH + 16 * t + 4 * lg + j];
     }
 
-  f32x4 accW1[NP], accW2[NP], accB1[NP];
+  f32x4 accW1[NP][CT], accW2[NP], accB1[NP];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) accW1[p] = accW2[p] = accB1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float dbz[4] = {0.f, 0.f, 0.f, 0.f}, db2[NC];       // dbz: channels 4lg..4lg+3 of this lane's voxels
+  for (int p = 0; p < NP; ++p) {
+    accW2[p] = accB1[p] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) accW1[p][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float dbz[CT][4], db2[NC];                          // dbz: channels 16 ct + 4lg..4lg+3 of this lane's voxels
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dbz[ct][j] = 0.f;
 #pragma unroll
   for (int c = 0; c < NC; ++c) db2[c] = 0.f;
 
@@ -313,12 +334,19 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
     for (int g = 0; g < 4; ++g) {
       const int64_t v = it * 256 + wave * 64 + g * 16 + n;
       const bool valid = v < total;
-      hd_bf16x4 xb = {0, 0, 0, 0};
+      xvec xb;
+#pragma unroll
+      for (int e = 0; e < KX; ++e) xb[e] = 0;
       float dov[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) dov[c] = 0.f;
       if (valid) {
-        xb = *reinterpret_cast<const hd_bf16x4*>(x + v * CP + 4 * lg);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const hd_bf16x4 q = *reinterpret_cast<const hd_bf16x4*>(x + v * CP + 16 * ct + 4 * lg);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xb[4 * ct + e] = q[e];
+        }
         const int64_t b = fdiv((uint32_t)v, dnv), r = v - b * nvox_per_b;
         if (NC == 2) {      // the four lanes of a voxel share the loads: even quads read class 0, odd quads class 1
           const int64_t o = (b * NC + (lg & 1)) * nvox_per_b + r;
@@ -343,8 +371,8 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
       for (int t = 0; t < NP; ++t) {
         f32x4 hp = {b1k[t][0], b1k[t][1], b1k[t][2], b1k[t][3]};
-        hp = SP_MFMA16_K16(a1h[t], xb, hp, 0, 0, 0);
-        hp = SP_MFMA16_K16(a1l[t], xb, hp, 0, 0, 0);
+        hp = HeadK<CT>::mma(a1h[t], xb, hp);
+        hp = HeadK<CT>::mma(a1l[t], xb, hp);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float dh = 0.f;
@@ -357,27 +385,34 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
       kvec dv;
 #pragma unroll
       for (int e = 0; e < KV; ++e) dv[e] = db_[e];
-      f32x4 dx = {0.f, 0.f, 0.f, 0.f};
-      dx = HeadK<NP>::mma(aTh, dv, dx);
-      dx = HeadK<NP>::mma(aTl, dv, dx);
-      if (valid) {
-        float o4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float xv = bf2f((bf16_t)xb[j]);
-          o4[j] = dx[j] * (lin_x ? (xv > 0.f ? 1.f : slope_x) : act_bwd_from_y(act_x, act_x_p, xv));
-          dbz[j] += o4[j];
-        }
-        Store<bf16_t>::st4(dz + v * CP + 4 * lg, o4);
-        if (lg == 0) {
-          for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
+      for (int ct = 0; ct < CT; ++ct) {
+        f32x4 dx = {0.f, 0.f, 0.f, 0.f};
+        dx = HeadK<NP>::mma(aTh[ct], dv, dx);
+        dx = HeadK<NP>::mma(aTl[ct], dv, dx);
+        if (valid) {
+          float o4[4];
 #pragma unroll
-          for (int c = 0; c < NC; ++c) db2[c] += dov[c];
+          for (int j = 0; j < 4; ++j) {
+            const float xv = bf2f((bf16_t)xb[4 * ct + j]);
+            o4[j] = dx[j] * (lin_x ? (xv > 0.f ? 1.f : slope_x) : act_bwd_from_y(act_x, act_x_p, xv));
+            dbz[ct][j] += o4[j];
+          }
+          Store<bf16_t>::st4(dz + v * CP + 16 * ct + 4 * lg, o4);
         }
+      }
+      if (valid && lg == 0) {
+        for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) db2[c] += dov[c];
       }
       // ---- this lane's 8 bytes of its voxel's row in every plane
       const int ro = (g * 16 + n) * 32 + 8 * lg;
-      *reinterpret_cast<hd_bf16x4*>(tX + ro) = xb;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        hd_bf16x4 x4 = {xb[4 * ct], xb[4 * ct + 1], xb[4 * ct + 2], xb[4 * ct + 3]};
+        *reinterpret_cast<hd_bf16x4*>(tX + ct * PLANE + ro) = x4;
+      }
       uint32_t a0 = 0, a1 = 0;
       if (lg == 0) {
         float aux[4] = {0.f, 0.f, 0.f, 0.f};
@@ -402,13 +437,16 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       const int ko = kb * 32 * 32;
-      const bf16x8 fx = hd_tr_read2(tX + ko + off0, tX + ko + off1);
+      bf16x8 fx[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) fx[ct] = hd_tr_read2(tX + ct * PLANE + ko + off0, tX + ct * PLANE + ko + off1);
       const bf16x8 fa = hd_tr_read2(tA + ko + off0, tA + ko + off1);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const bf16x8 fd = hd_tr_read2(tD + p * PLANE + ko + off0, tD + p * PLANE + ko + off1);
         const bf16x8 fh = hd_tr_read2(tH + p * PLANE + ko + off0, tH + p * PLANE + ko + off1);
-        accW1[p] = SP_MFMA16(fd, fx, accW1[p], 0, 0, 0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) accW1[p][ct] = SP_MFMA16(fd, fx[ct], accW1[p][ct], 0, 0, 0);
         accW2[p] = SP_MFMA16(fa, fh, accW2[p], 0, 0, 0);
         accB1[p] = SP_MFMA16(fa, fd, accB1[p], 0, 0, 0);
       }
@@ -419,6 +457,7 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
   // ---- flush (MFMA result: lane holds rows lg*4 + j (A side), column li (B side)): one row of partial sums per
   // workgroup, [W1 (CH x C) | b1 (CH) | W2 (NC x CH) | b2 (NC) | sum dz (C)], added up by sp_head_grad_finish
   constexpr int NQ0 = CH * C + CH + NC * CH + NC, NQ = NQ0 + C;
+  static_assert(4 * NQ * 4 <= 4 * NPL * PLANE, "per-wave partial rows do not fit the tiles");
   __syncthreads();                                   // every wave has left its tiles
   float* st0 = reinterpret_cast<float*>(lds);
   float* stage = st0 + wave * NQ;
@@ -427,7 +466,8 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int row = lg * 4 + j;
-      stage[(p * 16 + row) * C + li] = accW1[p][j];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) stage[(p * 16 + row) * C + 16 * ct + li] = accW1[p][ct][j];
       if (row < NC) stage[CH * C + CH + row * CH + p * 16 + li] = accW2[p][j];
       if (row == NC) stage[CH * C + p * 16 + li] = accB1[p][j];
     }
@@ -437,10 +477,12 @@ __global__ __launch_bounds__(256, 3) void head_bwd_mfma_kernel(const bf16_t* __r
     if (lane == 0) stage[CH * C + CH + NC * CH + c] = s2;
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float sj = row16_sum(dbz[j]);              // over the 16 voxel lanes of this channel quad
-    if (n == 0) stage[NQ0 + 4 * lg + j] = sj;
-  }
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float sj = row16_sum(dbz[ct][j]);          // over the 16 voxel lanes of this channel quad
+      if (n == 0) stage[NQ0 + 16 * ct + 4 * lg + j] = sj;
+    }
   __syncthreads();
   for (int i = tid; i < NQ; i += 256) part[(size_t)blockIdx.x * NQ + i] = st0[i] + st0[NQ + i] + st0[2 * NQ + i] + st0[3 * NQ + i];
 }
@@ -475,12 +517,22 @@ __global__ __launch_bounds__(1024) void head_grad_finish_kernel(const float* __r
   }
 }
 
-// instantiated shapes: the wave-level reduction tile needs CH*C/8 <= 64 and NC*CH <= 64
+// instantiated shapes: the wave-level reduction tile (f32 kernels) needs CH*C/8 <= 64 and NC*CH <= 64
 #define HEAD_CASES(X) X(16, 32, 2) X(16, 16, 2) X(16, 32, 1)
+// ... and on the MFMA kernels only (16-bit storage): 32 input channels -- the head of the 4-scale network (32 -> 32 -> 2)
+#define HEAD_CASES_MFMA32(X) X(32, 32, 2)
 
 extern "C" int sp_head_supported(int32_t C, int32_t CH, int32_t NC) {
 #define X(c, h, n) if (C == c && CH == h && NC == n) return 1;
   HEAD_CASES(X)
+#undef X
+  return 0;
+}
+// the same with the storage type: the 32-input-channel shapes exist for SP_BF16 only
+extern "C" int sp_head_supported_dtype(int32_t C, int32_t CH, int32_t NC, int32_t dtype) {
+  if (sp_head_supported(C, CH, NC)) return 1;
+#define X(c, h, n) if (C == c && CH == h && NC == n && dtype == SP_BF16) return 1;
+  HEAD_CASES_MFMA32(X)
 #undef X
   return 0;
 }
@@ -490,10 +542,14 @@ extern "C" int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
                            float* seg, sp_stream_t stream) {
   SP_CHECK_ARG(x && w1 && b1 && w2 && b2 && seg && CP >= C && CP % 8 == 0, "sp_head_fwd: bad arguments");
   SP_CHECK_ARG((int64_t)B * nvox_per_b < (1ll << 31), "sp_head_fwd: 2^31 voxels or more");
-  SP_CHECK_ARG(sp_head_supported(C, CH, NC), "sp_head_fwd: no fused kernel for C=%d CH=%d NC=%d", C, CH, NC);
+  SP_CHECK_ARG(sp_head_supported_dtype(C, CH, NC, dtype), "sp_head_fwd: no fused kernel for C=%d CH=%d NC=%d dtype=%d", C, CH, NC, dtype);
   const int64_t total = (int64_t)B * nvox_per_b;
   const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X(c, h, n)                                                                                                   \
+  if (C == c && CH == h && NC == n) hipLaunchKernelGGL((head_fwd_mfma_kernel<h, n, c / 16>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg);
+  HEAD_CASES_MFMA32(X)
+#undef X
 #define X(c, h, n)                                                                                                   \
   if (C == c && CH == h && NC == n) {                                                                                \
     if (dtype == SP_BF16) hipLaunchKernelGGL((head_fwd_mfma_kernel<h, n>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg); \
@@ -517,15 +573,19 @@ extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
                            const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials,
                            sp_stream_t stream) {
   SP_CHECK_ARG(x && w1 && b1 && w2 && seg && dseg && dz && partials && CP >= C && CP % 8 == 0, "sp_head_bwd: bad arguments");
-  SP_CHECK_ARG(sp_head_supported(C, CH, NC), "sp_head_bwd: no fused kernel for C=%d CH=%d NC=%d", C, CH, NC);
-  SP_CHECK_ARG(CH * C / 8 <= 64 && NC * CH <= 64 && CH <= 64, "sp_head_bwd: reduction tile does not fit a wave");
+  SP_CHECK_ARG(sp_head_supported_dtype(C, CH, NC, dtype), "sp_head_bwd: no fused kernel for C=%d CH=%d NC=%d dtype=%d", C, CH, NC, dtype);
+  SP_CHECK_ARG(C == 32 || (CH * C / 8 <= 64 && NC * CH <= 64 && CH <= 64), "sp_head_bwd: reduction tile does not fit a wave");
   const int64_t total = (int64_t)B * nvox_per_b;
   SP_CHECK_ARG(total > 0 && total < (1ll << 31), "sp_head_bwd: empty input or 2^31 voxels or more");
   const int rec = CH + CH + C + 4;
   const int lds = (CH * C + CH + NC * CH + 256 * rec) * (int)sizeof(float);
-  SP_CHECK_ARG(lds <= 160 * 1024, "sp_head_bwd: LDS %d", lds);
+  SP_CHECK_ARG(C == 32 || lds <= 160 * 1024, "sp_head_bwd: LDS %d", lds);
   const unsigned grid = (unsigned)head_rows(total);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X(c, h, n)                                                                                                   \
+  if (C == c && CH == h && NC == n) hipLaunchKernelGGL((head_bwd_mfma_kernel<h, n, c / 16>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, partials);
+  HEAD_CASES_MFMA32(X)
+#undef X
 #define X(c, h, n)                                                                                                   \
   if (C == c && CH == h && NC == n) {                                                                                \
     static_assert(c == 16, "head_bwd_mfma_kernel is written for 16 input channels");                                 \

@@ -143,6 +143,7 @@ _SIGS = {
     "sp_dice_finalize": ([vp, vp, f64, i32, vp, vp, vp], i32),
     "sp_dice_bwd": ([vp, i64, vp, i64, vp, vp, i32, i32, i64, vp, vp], i32),
     "sp_head_supported": ([i32, i32, i32], i32),
+    "sp_head_supported_dtype": ([i32, i32, i32, i32], i32),
     "sp_head_fwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, vp, i32, f32, vp, vp], i32),
     "sp_head_bwd_rows": ([i64], i64),
     "sp_head_row_floats": ([i32, i32, i32], i32),

@@ -115,7 +115,7 @@ class UnetEngine:
         self.h0 = mk("classify.0", blast, bc, d, bn=False, k=1)
         self.h2 = mk("classify.2", bc, ncls, d, bn=False, k=1, act=L.ACT_SIGMOID, ap=0.0, out_dtype=L.SP_F32)
         # fused pointwise head where a kernel exists for (C, CH, NC); the two generic 1x1 layers otherwise
-        self.fused_head = bool(L.load().sp_head_supported(blast, bc, ncls)) and blast % 8 == 0 and not os.environ.get("SP_GENERIC_HEAD")
+        self.fused_head = bool(L.load().sp_head_supported_dtype(blast, bc, ncls, dtype)) and blast % 8 == 0 and not os.environ.get("SP_GENERIC_HEAD")
         self.layers = [c for i in range(1, 2 * S) for c in self.conv[i]] + [self.h0, self.h2]
         for l in self.layers:
             l.reserve_bwd_scratch()

@@ -435,10 +435,14 @@ def test_adam_matches_torch():
 
 
 @pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
-@pytest.mark.parametrize("C,CH,NC,CP", [(16, 32, 2, 16), (16, 16, 2, 16), (16, 32, 1, 16)])
+@pytest.mark.parametrize("C,CH,NC,CP", [(16, 32, 2, 16), (16, 16, 2, 16), (16, 32, 1, 16), (32, 32, 2, 32), (32, 32, 2, 48)])
 def test_fused_head(dtype, C, CH, NC, CP):
-    """sp_head_fwd / sp_head_bwd against autograd of the classify Sequential (Unet3D.py:49-54)."""
-    assert L.load().sp_head_supported(C, CH, NC) == 1
+    """sp_head_fwd / sp_head_bwd against autograd of the classify Sequential (Unet3D.py:49-54); 32 input channels (the head
+    of the 4-scale network) on the MFMA kernels only."""
+    if C == 32 and dtype == L.SP_F32:
+        assert L.load().sp_head_supported_dtype(C, CH, NC, dtype) == 0
+        return
+    assert L.load().sp_head_supported_dtype(C, CH, NC, dtype) == 1
     assert L.load().sp_head_supported(24, 32, 2) == 0
     torch.manual_seed(5)
     B, dims = 2, (5, 9, 13)                      # 585 voxels / sample: ragged against the 256-voxel blocks
@@ -462,7 +466,7 @@ def test_fused_head(dtype, C, CH, NC, CP):
     L.call("sp_head_fwd", O.ptr(x_cl), dtype, nv, B, CP, C, O.ptr(W1), O.ptr(B1), CH, O.ptr(W2), O.ptr(B2), NC, 0.01,
            O.ptr(seg), O.stream())
     # bf16 storage: the hidden layer is the bf16 operand of the second matrix product (2^-9 relative per element)
-    torch.testing.assert_close(seg.cpu(), seg_ref.detach(), rtol=1e-5, atol=1e-5 if dtype == L.SP_F32 else 3e-3)
+    torch.testing.assert_close(seg.cpu(), seg_ref.detach(), rtol=1e-5, atol=1e-5 if dtype == L.SP_F32 else (3e-3 if C == 16 else 5e-3))
 
     dz = torch.full_like(x_cl, 7.0)
     dbs = torch.zeros(CP, dtype=torch.float64, device=DEV)
