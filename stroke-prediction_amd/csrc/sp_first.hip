@@ -166,8 +166,11 @@ extern "C" int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t D
 // elements e = 0..7 = (dx = e / 2, c = e % 2);  W' = W * scale[c],  b' = b + sum W * shift[c]
 __global__ void first_prep_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
                                   const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f, int Cout) {
-  const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes; blockIdx.x = output tile of 16 channels
-  const int s = t >> 6, l = t & 63, co = blockIdx.x * 16 + (l & 15), g = 4 * s + (l >> 4);
+  const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes; blockIdx.x = output tile of 16 rows
+  // Cout = 32: tile t, row r holds channel (r / 4) * 8 + 4 t + r % 4 -- a lane of the forward kernel (rows 4 lg .. 4 lg + 3 of
+  // both tiles) then owns EIGHT consecutive channels of its voxel and stores them with one 16-byte instruction
+  const int s = t >> 6, l = t & 63, r_ = l & 15, g = 4 * s + (l >> 4);
+  const int co = Cout == 32 ? (r_ >> 2) * 8 + 4 * (int)blockIdx.x + (r_ & 3) : r_;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int dx = e >> 1, c = e & 1;
@@ -175,14 +178,14 @@ __global__ void first_prep_kernel(const float* __restrict__ w, const float* __re
     if (g < 9 && dx < 3 && co < Cout) v = w[(co * 2 + c) * 27 + g * 3 + dx] * (scale ? scale[c] : 1.f);
     wfrag[((size_t)blockIdx.x * 192 + t) * 8 + e] = f2bf(v);
   }
-  if (t < 16) {
-    const int cb = blockIdx.x * 16 + t;
-    float acc = (b && cb < Cout) ? b[cb] : 0.f;
-    if (shift && cb < Cout)
-      for (int c = 0; c < 2; ++c)
-        for (int k = 0; k < 27; ++k) acc = fmaf(w[(cb * 2 + c) * 27 + k], shift[c], acc);
-    bias_f[cb] = acc;
-  }
+  if (t < 16 && blockIdx.x == 0)
+    for (int cb = t; cb < Cout; cb += 16) {      // (natural channel order)
+      float acc = b ? b[cb] : 0.f;
+      if (shift)
+        for (int c = 0; c < 2; ++c)
+          for (int k = 0; k < 27; ++k) acc = fmaf(w[(cb * 2 + c) * 27 + k], shift[c], acc);
+      bias_f[cb] = acc;
+    }
 }
 
 // Cout = 16 (the 3-scale network of BASELINE.json configs[1]) or 32 (the 4-scale one, configs[4]): one or two output tiles
@@ -220,11 +223,14 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
     const int g = min(4 * s + lg, 8);                       // groups 9..11 carry zero weights: any finite data will do
     goff[s] = ((g / 3) * FT_XY + (g % 3)) * FT_XP;
   }
+  // output channel of (tile nt, row 4 lg + j): NT = 1: 4 lg + j; NT = 2: 8 lg + 4 nt + j (first_prep_kernel) -- this lane's eight
+  // values of a voxel are consecutive channels
+  constexpr int CQ = 4 * NT;                        // channels per lane and voxel
   float bj[NT][4], s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { bj[nt][j] = bias[nt * 16 + lg * 4 + j]; s1[nt][j] = s2[nt][j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { bj[nt][j] = bias[lg * CQ + nt * 4 + j]; s1[nt][j] = s2[nt][j] = 0.f; }
   const float slope = act == SP_ACT_LEAKY ? ap : 1.f;
   const bool lin = act == SP_ACT_LEAKY || act == SP_ACT_NONE;
 
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
       const bool rok = oz < P.Do && oy < P.Ho;
       const int rbase = (zz * FT_XY + yy) * FT_XP + n;
       const size_t vrow = (((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo;      // first voxel of the output row
-      bf16_t* yrow = y + vrow * (16 * NT) + lg * 4;
+      bf16_t* yrow = y + vrow * (16 * NT) + lg * CQ;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         union { uint32_t u[4]; bf16x8 v; } bq[3];
@@ -262,6 +268,8 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
           bq[s].u[0] = p[0]; bq[s].u[1] = p[1]; bq[s].u[2] = p[2]; bq[s].u[3] = p[3];
         }
         const int ox = ox0 + t * 16 + n;
+        float q[NT][4];
+        uint32_t w2[NT][2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -273,19 +281,28 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
             const float z = acc[j] + bj[nt][j];
             v[j] = lin ? fmaxf(z, slope * z) : act_fwd(act, ap, z);
           }
-          if (rok && ox < P.Wo) {
-            Store<bf16_t>::st4(yrow + (size_t)ox * (16 * NT) + nt * 16, v);
-            float q[4];
+          w2[nt][0] = sp_pack_bf16x2(v[0], v[1]); w2[nt][1] = sp_pack_bf16x2(v[2], v[3]);
+          q[nt][0] = sp_h2f_lo(w2[nt][0]); q[nt][1] = sp_h2f_hi(w2[nt][0]);      // statistics (and the e4m3 copy) of what is stored
+          q[nt][2] = sp_h2f_lo(w2[nt][1]); q[nt][3] = sp_h2f_hi(w2[nt][1]);
+        }
+        if (rok && ox < P.Wo) {
+          bf16_t* yp = yrow + (size_t)ox * (16 * NT);
+          if (NT == 2) *reinterpret_cast<uint4*>(yp) = make_uint4(w2[0][0], w2[0][1], w2[NT - 1][0], w2[NT - 1][1]);
+          else *reinterpret_cast<uint2*>(yp) = make_uint2(w2[0][0], w2[0][1]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              q[j] = bf2f(f2bf(v[j]));                      // statistics (and the e4m3 copy) of what is stored
-              s1[nt][j] += q[j]; s2[nt][j] = fmaf(q[j], q[j], s2[nt][j]);
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s1[nt][j] += q[nt][j]; s2[nt][j] = fmaf(q[nt][j], q[nt][j], s2[nt][j]); }
+          if (y8) {      // channels lg * CQ .. + CQ - 1: plane (lg * CQ) / 16, bytes (lg * CQ) % 16 .. of the voxel's 16
+            int r8[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              r8[nt] = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q[nt][0], -448.f, 448.f), __builtin_amdgcn_fmed3f(q[nt][1], -448.f, 448.f), 0, false);
+              r8[nt] = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q[nt][2], -448.f, 448.f), __builtin_amdgcn_fmed3f(q[nt][3], -448.f, 448.f), r8[nt], true);
             }
-            if (y8) {
-              int r8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q[0], -448.f, 448.f), __builtin_amdgcn_fmed3f(q[1], -448.f, 448.f), 0, false);
-              r8 = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q[2], -448.f, 448.f), __builtin_amdgcn_fmed3f(q[3], -448.f, 448.f), r8, true);
-              *reinterpret_cast<int*>(y8 + (size_t)nt * y8_plane + (vrow + ox) * 16 + lg * 4) = r8;
-            }
+            unsigned char* p8 = y8 + (size_t)((lg * CQ) >> 4) * y8_plane + (vrow + ox) * 16 + ((lg * CQ) & 15);
+            if (NT == 2) *reinterpret_cast<int2*>(p8) = make_int2(r8[0], r8[NT - 1]);
+            else *reinterpret_cast<int*>(p8) = r8[0];
           }
         }
       }
@@ -298,7 +315,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float x1 = row16_sum(s1[nt][j]), x2 = row16_sum(s2[nt][j]);
-        if (n == 0) { red[wave * (32 * NT) + (nt * 16 + lg * 4 + j) * 2] = x1; red[wave * (32 * NT) + (nt * 16 + lg * 4 + j) * 2 + 1] = x2; }
+        if (n == 0) { red[wave * (32 * NT) + (lg * CQ + nt * 4 + j) * 2] = x1; red[wave * (32 * NT) + (lg * CQ + nt * 4 + j) * 2 + 1] = x2; }
       }
     __syncthreads();
     if (tid < 32 * NT) atomicAdd(&stats[(size_t)(blockIdx.x % nrep) * (32 * NT) + tid], (double)sp_cols_sum(red, 32 * NT, 4, tid));
