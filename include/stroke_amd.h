@@ -538,6 +538,12 @@ int32_t sp_head_row_floats(int32_t C, int32_t CH, int32_t NC);
 int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
                 const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
                 const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials, sp_stream_t stream);
+/* the same with the fp8 plane-major copy of dz ([C/16][B*nvox][16 bytes], q8_fmt 0 = e4m3 / 1 = e5m2 of q8_scale * dz, rounded
+ * from the stored 16-bit value) for an fp8 data / weight gradient of the producing layer; dz == NULL: only the copy */
+int sp_head_bwd_q8(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                   const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg, const float* dseg,
+                   int32_t act_x, float act_x_param, void* dz, float* partials, void* q8, int64_t q8_plane, int32_t q8_fmt,
+                   float q8_scale, sp_stream_t stream);
 int sp_head_grad_finish(const float* partials, int64_t rows, int32_t C, int32_t CH, int32_t NC, float* gW1, float* gb1,
                         float* gW2, float* gb2, double* dbias_sums, sp_stream_t stream);
 

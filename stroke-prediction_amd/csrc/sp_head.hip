@@ -271,7 +271,9 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void head_bwd_mfma_kernel(con
                                                              int64_t total, int CP, const float* __restrict__ w1,
                                                              const float* __restrict__ b1, const float* __restrict__ w2,
                                                              float slope, int act_x, float act_x_p,
-                                                             bf16_t* __restrict__ dz, float* __restrict__ part) {
+                                                             bf16_t* __restrict__ dz, float* __restrict__ part, const SpQ8 q8) {
+  // q8.p != NULL: the fp8 plane-major copy of dz (quantised from the stored 16-bit value, as sp_quantize_f8 would); dz == NULL
+  // then skips the 16-bit tensor (both backward convolutions of the producing layer read the copy)
   const bool lin_x = act_x == SP_ACT_LEAKY || act_x == SP_ACT_NONE;
   const float slope_x = act_x == SP_ACT_LEAKY ? act_x_p : 1.f;
   constexpr int C = 16 * CT, NP = CH / 16, NPL = CT + 1 + 2 * NP, KV = 4 * NP, KX = 4 * CT;      // planes: X[CT], AUX, DHP[NP], H[NP]
@@ -398,11 +400,12 @@ __global__ __launch_bounds__(256, CT == 1 ? 3 : 2) void head_bwd_mfma_kernel(con
             o4[j] = dx[j] * (lin_x ? (xv > 0.f ? 1.f : slope_x) : act_bwd_from_y(act_x, act_x_p, xv));
             dbz[ct][j] += o4[j];
           }
-          Store<bf16_t>::st4(dz + v * CP + 16 * ct + 4 * lg, o4);
+          if (dz) Store<bf16_t>::st4(dz + v * CP + 16 * ct + 4 * lg, o4);
+          if (q8.p) *reinterpret_cast<uint32_t*>(q8.p + (size_t)ct * q8.plane + v * 16 + 4 * lg) = sp_q8_pack4(o4, q8.scale, q8.fmt);
         }
       }
       if (valid && lg == 0) {
-        for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
+        if (dz) for (int c = C; c < CP; c += 8) *reinterpret_cast<uint4*>(dz + v * CP + c) = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) db2[c] += dov[c];
       }
@@ -568,11 +571,12 @@ static inline int64_t head_rows(int64_t total) {
 extern "C" int64_t sp_head_bwd_rows(int64_t total_voxels) { return head_rows(total_voxels); }
 extern "C" int32_t sp_head_row_floats(int32_t C, int32_t CH, int32_t NC) { return CH * C + CH + NC * CH + NC + C; }
 
-extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
-                           const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
-                           const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials,
-                           sp_stream_t stream) {
-  SP_CHECK_ARG(x && w1 && b1 && w2 && seg && dseg && dz && partials && CP >= C && CP % 8 == 0, "sp_head_bwd: bad arguments");
+static int head_bwd_impl(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                         const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
+                         const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials, SpQ8 q8,
+                         sp_stream_t stream) {
+  SP_CHECK_ARG(x && w1 && b1 && w2 && seg && dseg && (dz || q8.p) && partials && CP >= C && CP % 8 == 0, "sp_head_bwd: bad arguments");
+  SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && C % 16 == 0 && q8.scale > 0.f && q8.plane >= (int64_t)B * nvox_per_b * 16), "sp_head_bwd_q8: bf16 storage, whole 16-channel planes");
   SP_CHECK_ARG(sp_head_supported_dtype(C, CH, NC, dtype), "sp_head_bwd: no fused kernel for C=%d CH=%d NC=%d dtype=%d", C, CH, NC, dtype);
   SP_CHECK_ARG(C == 32 || (CH * C / 8 <= 64 && NC * CH <= 64 && CH <= 64), "sp_head_bwd: reduction tile does not fit a wave");
   const int64_t total = (int64_t)B * nvox_per_b;
@@ -583,14 +587,14 @@ extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
   const unsigned grid = (unsigned)head_rows(total);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define X(c, h, n)                                                                                                   \
-  if (C == c && CH == h && NC == n) hipLaunchKernelGGL((head_bwd_mfma_kernel<h, n, c / 16>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, partials);
+  if (C == c && CH == h && NC == n) hipLaunchKernelGGL((head_bwd_mfma_kernel<h, n, c / 16>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, partials, q8);
   HEAD_CASES_MFMA32(X)
 #undef X
 #define X(c, h, n)                                                                                                   \
   if (C == c && CH == h && NC == n) {                                                                                \
     static_assert(c == 16, "head_bwd_mfma_kernel is written for 16 input channels");                                 \
     if (dtype == SP_BF16) {                                                                                          \
-      hipLaunchKernelGGL((head_bwd_mfma_kernel<h, n>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, partials); \
+      hipLaunchKernelGGL((head_bwd_mfma_kernel<h, n>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, seg, dseg, nvox_per_b, total, CP, w1, b1, w2, slope, act_x, act_x_param, (bf16_t*)dz, partials, q8); \
     } else {                                                                                                         \
       auto kern = head_bwd_kernel<c, h, n, float>;                                                                   \
       SP_ENSURE_LDS(kern, lds, "sp_head_bwd");                                                                       \
@@ -601,6 +605,22 @@ extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
 #undef X
   SP_CHECK_LAUNCH("sp_head_bwd");
   return SP_OK;
+}
+
+extern "C" int sp_head_bwd(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                           const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
+                           const float* dseg, int32_t act_x, float act_x_param, void* dz, float* partials,
+                           sp_stream_t stream) {
+  return head_bwd_impl(x, dtype, nvox_per_b, B, CP, C, w1, b1, CH, w2, NC, slope, seg, dseg, act_x, act_x_param, dz, partials,
+                       SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_head_bwd_q8(const void* x, int32_t dtype, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                              const float* b1, int32_t CH, const float* w2, int32_t NC, float slope, const float* seg,
+                              const float* dseg, int32_t act_x, float act_x_param, void* dz /* or NULL */, float* partials,
+                              void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_head_bwd_q8: bad fp8 output");
+  return head_bwd_impl(x, dtype, nvox_per_b, B, CP, C, w1, b1, CH, w2, NC, slope, seg, dseg, act_x, act_x_param, dz, partials,
+                       SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
 
 extern "C" int sp_head_grad_finish(const float* partials, int64_t rows, int32_t C, int32_t CH, int32_t NC, float* gW1, float* gb1,

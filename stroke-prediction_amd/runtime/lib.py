@@ -148,6 +148,7 @@ _SIGS = {
     "sp_head_bwd_rows": ([i64], i64),
     "sp_head_row_floats": ([i32, i32, i32], i32),
     "sp_head_bwd": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, i32, f32, vp, vp, i32, f32, vp, vp, vp], i32),
+    "sp_head_bwd_q8": ([vp, i32, i64, i32, i32, i32, vp, vp, i32, vp, i32, f32, vp, vp, i32, f32, vp, vp, vp, i64, i32, f32, vp], i32),
     "sp_head_grad_finish": ([vp, i64, i32, i32, i32, vp, vp, vp, vp, vp, vp], i32),
     "sp_add_f64_to_f32": ([vp, vp, i64, f32, vp], i32),
     "sp_axpby": ([vp, vp, vp, i32, i64, f32, f32, vp], i32),

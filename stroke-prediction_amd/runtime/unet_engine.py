@@ -343,10 +343,17 @@ class UnetEngine:
             rows = lib.sp_head_bwd_rows(self.batch * nv)
             if getattr(self, "_hpart", None) is None:
                 self._hpart = torch.empty(rows * lib.sp_head_row_floats(b5, bc, ncls), dtype=torch.float32, device=self.device)
-            L.call("sp_head_bwd", O.ptr(last.y), dt, nv, self.batch, last.y.shape[-1], b5,
-                   O.ptr(params["classify.0.weight"]), O.ptr(params["classify.0.bias"]), bc,
-                   O.ptr(params["classify.2.weight"]), ncls, LEAKY, O.ptr(seg), O.ptr(dseg), L.ACT_LEAKY, LEAKY,
-                   O.ptr(last.dz), O.ptr(self._hpart), O.stream())
+            q8 = last.dz8_out() if last.y.shape[-1] == b5 else None      # fp8 mode: the e5m2 copy of dz straight from this kernel
+            if q8 is not None:
+                L.call("sp_head_bwd_q8", O.ptr(last.y), dt, nv, self.batch, last.y.shape[-1], b5,
+                       O.ptr(params["classify.0.weight"]), O.ptr(params["classify.0.bias"]), bc,
+                       O.ptr(params["classify.2.weight"]), ncls, LEAKY, O.ptr(seg), O.ptr(dseg), L.ACT_LEAKY, LEAKY,
+                       O.ptr(last.dz_target()), O.ptr(self._hpart), *O._q8_args(q8, self.batch * nv), O.stream())
+            else:
+                L.call("sp_head_bwd", O.ptr(last.y), dt, nv, self.batch, last.y.shape[-1], b5,
+                       O.ptr(params["classify.0.weight"]), O.ptr(params["classify.0.bias"]), bc,
+                       O.ptr(params["classify.2.weight"]), ncls, LEAKY, O.ptr(seg), O.ptr(dseg), L.ACT_LEAKY, LEAKY,
+                       O.ptr(last.dz), O.ptr(self._hpart), O.stream())
             L.call("sp_head_grad_finish", O.ptr(self._hpart), rows, b5, bc, ncls, O.ptr(grads["classify.0.weight"]),
                    O.ptr(grads["classify.0.bias"]), O.ptr(grads["classify.2.weight"]), O.ptr(grads["classify.2.bias"]),
                    O.ptr(last.dbias_sums), O.stream())

@@ -576,3 +576,36 @@ def test_fp8_conv_with_input_channel_groups_matches_torch_on_quantised_operands(
     gg = gout.float().cpu().permute(0, 4, 1, 2, 3)
     sc = float(gref.abs().mean())
     assert float(((gg - gref).abs() / (gref.abs() + 0.5 * sc)).max()) < 1.2e-2
+
+
+def test_fused_head_backward_writes_the_e5m2_copy_of_its_input_gradient():
+    """sp_head_bwd_q8 (the 32-channel classify head of the 4-scale network, Unet3D.py:49-54): the e5m2 copy equals
+    sp_quantize_f8 of the stored dz, with and without the 16-bit tensor; partial sums unchanged"""
+    g_ = torch.Generator().manual_seed(9)
+    B, C, CH, NC, dims = 2, 32, 32, 2, (6, 9, 13)
+    nv = dims[0] * dims[1] * dims[2]
+    S = 2.0 ** 12
+    y = _to_cl(F.leaky_relu(torch.randn(B, C, *dims, generator=g_), 0.01), C)
+    w1, b1 = (torch.randn(CH, C, generator=g_) * 0.3).to(DEV), (torch.randn(CH, generator=g_) * 0.1).to(DEV)
+    w2, b2 = (torch.randn(NC, CH, generator=g_) * 0.3).to(DEV), (torch.randn(NC, generator=g_) * 0.1).to(DEV)
+    seg = torch.empty((B, NC) + dims, dtype=torch.float32, device=DEV)
+    L.call("sp_head_fwd", O.ptr(y), L.SP_BF16, nv, B, C, C, O.ptr(w1), O.ptr(b1), CH, O.ptr(w2), O.ptr(b2), NC, 0.01, O.ptr(seg), O.stream())
+    dseg = (torch.randn((B, NC) + dims, generator=g_) * 1e-3).to(DEV)
+    lib = L.load()
+    rows, nq = lib.sp_head_bwd_rows(B * nv), lib.sp_head_row_floats(C, CH, NC)
+    outs = []
+    for mode in ("plain", "q8", "q8only"):
+        dz = torch.zeros_like(y)
+        part = torch.full((rows * nq,), float("nan"), dtype=torch.float32, device=DEV)
+        dz8 = F8.alloc_f8(B, dims, C, DEV)
+        if mode == "plain":
+            L.call("sp_head_bwd", O.ptr(y), L.SP_BF16, nv, B, C, C, O.ptr(w1), O.ptr(b1), CH, O.ptr(w2), NC, 0.01, O.ptr(seg), O.ptr(dseg),
+                   L.ACT_LEAKY, 0.01, O.ptr(dz), O.ptr(part), O.stream())
+            F8.quantize(dz, dz8, F8.E5M2, S)
+        else:
+            L.call("sp_head_bwd_q8", O.ptr(y), L.SP_BF16, nv, B, C, C, O.ptr(w1), O.ptr(b1), CH, O.ptr(w2), NC, 0.01, O.ptr(seg), O.ptr(dseg),
+                   L.ACT_LEAKY, 0.01, O.ptr(dz) if mode == "q8" else None, O.ptr(part), *O._q8_args((dz8, F8.E5M2, S), B * nv), O.stream())
+        outs.append((dz, dz8, part))
+    assert float(outs[0][0].float().abs().max()) > 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][1], outs[2][1])
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][2], outs[2][2])
