@@ -128,11 +128,31 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   const int lv = lane & 15, lg = lane >> 4;
   unsigned char* ring = lds;
 
+  // Output-channel slices in ONE launch (a.nslices > 1; see csrc/sp_conv_zm8.hip): the workgroups of an XCD split into nslices
+  // teams that march over the same (column, plane) ranges at the same time -- whole output lines leave the L2, the input is
+  // fetched from HBM once.
+  const int nsl = a.nslices > 1 ? a.nslices : 1;
+  uint32_t vb, nvb;
+  int sl = 0;
+  if (nsl > 1) {
+    const uint32_t xcd = blockIdx.x & 7, jj = blockIdx.x >> 3, per = (gridDim.x >> 3) / (uint32_t)nsl;      // host: gridDim.x % (8 nsl) == 0
+    sl = (int)(jj % (uint32_t)nsl);
+    vb = xcd * per + jj / (uint32_t)nsl;
+    nvb = per * 8;
+  } else {
+    vb = xcd_remap(blockIdx.x, gridDim.x);
+    nvb = gridDim.x;
+  }
+  const int c0s = sl * NT * 16;                    // first output channel of this workgroup's slice
+  TOUT* const y_sl = reinterpret_cast<TOUT*>(a.y) + c0s;
+  const float* const bias_sl = a.bias ? a.bias + c0s : nullptr;
+  double* const stats_sl = a.stats ? a.stats + (size_t)c0s * 2 : nullptr;
+
   int kv[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) kv[s] = a.ktab[s * 4 + lg];
   const int vbase0 = (wave * MT * ITW + lv) * 32;      // this lane's voxel of the wave's first row inside a plane
-  const bf16x8* __restrict__ wf = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
+  const bf16x8* __restrict__ wf = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(a.wfrag_hi) + (size_t)sl * a.slice_wfrag_stride);
   bf16x8 w[WLDS ? 1 : 3][WLDS ? 1 : KS][WLDS ? 1 : NT];
   const unsigned char* wl = lds + WOFF + lane * 16;           // this lane's 16 bytes of fragment 0
   if (WLDS) {
@@ -166,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { bj[n][j] = a.bias ? a.bias[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
+    for (int j = 0; j < 4; ++j) { bj[n][j] = bias_sl ? bias_sl[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
   const float slope = a.act == SP_ACT_NONE ? 1.f : a.act_param;       // LeakyReLU slope (identity: 1) or the ELU's alpha
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(Q.zeros);
 #ifdef SP_ZM_STAMPS
@@ -177,10 +197,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 
   // Work = (column, output plane) pairs cut into gridDim.x equal pieces of the flattened sequence; a piece that starts
   // inside a column pays the two-plane prologue again.  XCD-aware piece id (neighbouring columns share halo in one L2).
-  const uint32_t vb = xcd_remap(blockIdx.x, gridDim.x);
   const uint64_t T = (uint64_t)Q.ncols * a.Do;
-  uint64_t pos = T * vb / gridDim.x;
-  const uint64_t pend_pos = T * (vb + 1) / gridDim.x;
+  uint64_t pos = T * vb / nvb;
+  const uint64_t pend_pos = T * (vb + 1) / nvb;
   while (pos < pend_pos) {
     const uint32_t col = (uint32_t)(pos / (uint32_t)a.Do);
     const int z0 = (int)(pos - (uint64_t)col * a.Do);
@@ -220,7 +239,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #pragma unroll
       for (int j = 0; j < NJ; ++j) plane_dma(j, false);
     };
-    TOUT* yout = reinterpret_cast<TOUT*>(a.y) + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
+    TOUT* yout = y_sl + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)yout, 0, (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)sizeof(TOUT)), 0x00020000);
     const int ox = ox0 + lv;
@@ -414,7 +433,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       for (int k = 0; k < 8; ++k) sp_zm_stamp_buf[blockIdx.x][wave][k] = zm_sum[k];
   }
 #endif
-  if (STATS && a.stats != nullptr) {
+  if (STATS && stats_sl != nullptr) {
     __syncthreads();
     float* red = reinterpret_cast<float*>(lds);      // [NW waves][NT * 32] (ordered sum: sp_cols_sum)
 #pragma unroll
@@ -427,7 +446,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     __syncthreads();
     for (int k = tid; k < NT * 32; k += 64 * NW) {
       const int c = k >> 1;
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
+      if (c0s + c < a.CPo) atomicAdd(&stats_sl[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
     }
   }
 }
@@ -452,7 +471,11 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   const uint64_t planes = (uint64_t)Q.ncols * a->Do;
   static const int slots_env_ = getenv("SP_ZM_SLOTS") ? atoi(getenv("SP_ZM_SLOTS")) : 0;
   const int slots = slots_env_ > 0 ? slots_env_ : 256;               // resident workgroups: one per CU
-  const unsigned grid = planes / 4 < (uint64_t)slots ? (unsigned)(planes / 4 > 0 ? planes / 4 : 1) : (unsigned)slots;
+  unsigned grid = planes / 4 < (uint64_t)slots ? (unsigned)(planes / 4 > 0 ? planes / 4 : 1) : (unsigned)slots;
+  if (a->nslices > 1) {      // teams of nslices workgroups per XCD (see the kernel)
+    grid = 8u * (unsigned)a->nslices * (32u / (unsigned)a->nslices);
+    SP_CHECK_ARG(planes >= (uint64_t)grid / a->nslices, "sp_conv3d_zm: too few (column, plane) pairs for %d slices in one launch", a->nslices);
+  }
   if (a->dtype_out == SP_F32) {
     if constexpr (ACT == 2) {
       sp_set_error("sp_conv3d_zm: the ELU epilogue is built for bf16 outputs");
@@ -525,6 +548,8 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
   SP_CHECK_ARG(a->group_batch == 0, "sp_conv3d_zm: no BatchNorm groups (run one launch per group)");
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE || a->act == SP_ACT_ELU, "sp_conv3d_zm: LeakyReLU, ELU or identity epilogue");
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
+  SP_CHECK_ARG(a->nslices >= 0 && a->nslices <= 16 && (a->nslices <= 1 || (a->CPo >= a->nslices * a->Cout && a->slice_wfrag_stride > 0 && a->slice_wfrag_stride % 16 == 0 && !a->y8)),
+               "sp_conv3d_zm: nslices %d (CPo %d, Cout %d per slice, slice_wfrag_stride %lld; no e4m3 copy)", a->nslices, a->CPo, a->Cout, (long long)a->slice_wfrag_stride);
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_zm: stats_nrep must be a power of two");
   SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_zm: empty output");
   SP_CHECK_ARG(!a->y8 || (a->dtype_out == SP_BF16 && a->osD == 1 && a->osH == 1 && a->osW == 1 && a->ooD == 0 && a->ooH == 0 && a->ooW == 0 &&

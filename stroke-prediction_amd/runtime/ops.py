@@ -39,7 +39,7 @@ WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient part
 # second set of weight fragments costs what the forward gains: 4.00 vs 4.00 ms per step.
 USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
 USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with too many output tiles for one z-marching launch: a launch per 32-channel slice
-ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "8000"))  # ... when the volume is large enough (measured: 32->96 @48^3 gains nothing, @166^3 40 %)
+ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "2000"))  # ... when the volume is large enough (one launch per slice: 32->96 @48^3 gains nothing, @166^3 40 %; as teams of one launch: @48^3 147 -> 119 us)
 USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
 USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
@@ -52,6 +52,7 @@ USE_DMA = True     # bf16 LDS-DMA conv path (tests flip it to compare both kerne
 # output-stationary z-marching kernel (csrc/sp_conv_zm.hip) for the stride-1 3x3x3 layers between whole 16-channel tiles whose
 # volume gives every CU a few planes to march through; SP_CONV_ZM=0 falls back to the tiled / ring kernels
 USE_ZM = os.environ.get("SP_CONV_ZM", "1") != "0"
+ZM_FUSE_SLICES = bool(int(os.environ.get("SP_ZM_FUSE_SLICES", "1")))      # output-channel slices as workgroup teams of one launch
 ZM_MIN_PLANES = int(os.environ.get("SP_CONV_ZM_MIN_PLANES", "1024"))     # (column, plane) pairs per launch below which the march is all prologue
 _ZEROS = {}
 
@@ -233,12 +234,25 @@ class ConvRunner:
             if zm is None and USE_ZM and USE_DMA and zm_batch and USE_ZM_SLICES:
                 sl = P.zm_slices(op)
                 cols = -(-op.subs[0].out_dims[1] // 16) * -(-op.subs[0].out_dims[2] // 16) if sl else 0
-                if sl and zm_batch * cols * op.subs[0].out_dims[0] >= ZM_SLICE_MIN_PLANES:
+                pairs = zm_batch * cols * op.subs[0].out_dims[0] if sl else 0
+                if sl and pairs >= ZM_SLICE_MIN_PLANES:
+                    plans = [(c0, cn, P.zm_plan(sub_op)) for c0, cn, sub_op in sl]
+                    # equal slices: one fragment pool and teams of m slices per launch (sp_conv_args.nslices, as the fp8 runner)
+                    nt0, n0 = plans[0][2]["NT"], plans[0][2]["nsteps"]
+                    fuse_m = 0
+                    if ZM_FUSE_SLICES and all(z["NT"] == nt0 and z["nsteps"] == n0 and c0 == i * nt0 * 16 for i, (c0, _, z) in enumerate(plans)):
+                        cands = [m for m in range(2, min(16, len(plans)) + 1) if len(plans) % m == 0]
+                        good = [m for m in cands if (32 // m) * m >= 29]
+                        fuse_m = (max(good) if good else max(cands, key=lambda m: ((32 // m) * m, m))) if cands else 0
+                        if fuse_m and pairs < 4 * 8 * (32 // fuse_m):
+                            fuse_m = 0
+                    frag = n0 * nt0 * 64 * 8
+                    pool = torch.empty(len(plans) * frag, dtype=torch.bfloat16, device=device) if fuse_m else None
                     zms = []
-                    for c0, cn, sub_op in sl:
-                        z = P.zm_plan(sub_op)
-                        zms.append(dict(z, c0=c0, cn=cn, ktab_d=_dev_i32(z["ktab"], device), kmap_d=_dev_i32(z["kmap"], device),
-                                        hi=torch.empty(z["nsteps"] * z["NT"] * 64 * 8, dtype=torch.bfloat16, device=device)))
+                    for i, (c0, cn, z) in enumerate(plans):
+                        hi = pool[i * frag:(i + 1) * frag] if fuse_m else torch.empty(z["nsteps"] * z["NT"] * 64 * 8, dtype=torch.bfloat16, device=device)
+                        zms.append(dict(z, c0=c0, cn=cn, ktab_d=_dev_i32(z["ktab"], device), kmap_d=_dev_i32(z["kmap"], device), hi=hi,
+                                        fuse_m=fuse_m, wstride=frag * 2))
             st["zms"] = zms
             fc = P.fc_plan(op) if (USE_FC and zm is None and zms is None) else None
             if fc is not None:      # split-K kernel for FC-like layers: its own (tap-major) K order and fragments
@@ -386,7 +400,8 @@ class ConvRunner:
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"
             if self.zms is not None:
-                for z in self.zms:
+                m = self.zms[0]["fuse_m"]
+                for z in (self.zms[::m] if m else self.zms):
                     _run_zm_impl(self, a, x_planar, batch, stats is not None, st, z=z, y=y, stats=stats, use_bias=use_bias)
                 return
             return self._run_zm(a, x_planar, batch, stats is not None, st)
@@ -458,8 +473,10 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
     a.dma, a.persist, a.zfill = 1, 5, 0
     a.octs_per_group, a.ngroups, a.opp, a.vsb = 2 * z["P"], 1, 2, 32
     a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
-    with _Timed("conv_igemm", op.flops(batch) * (z["cn"] / op.cout if sliced else 1.0),
-                "%d->%d @%s zm%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), " slices" if sliced else "",
+    m = z.get("fuse_m", 0) if sliced else 0
+    a.nslices, a.slice_wfrag_stride = (m, z["wstride"]) if m else (0, 0)
+    with _Timed("conv_igemm", op.flops(batch) * (z["cn"] * max(m, 1) / op.cout if sliced else 1.0),
+                "%d->%d @%s zm%s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), ((" %d slices in one" % m) if m else " slices") if sliced else "",
                                        " +stats" if with_stats else "")):
         L.call("sp_conv3d_zm", C.byref(a), ptr(zero_page(runner.device)), st)
 
