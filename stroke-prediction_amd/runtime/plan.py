@@ -375,6 +375,10 @@ ZM_CONFIGS = ZM_CONFIGS_NW4 if os.environ.get("SP_ZM_NW") == "4" else ZM_CONFIGS
 ZM_ITW = 18
 
 
+# (P, NT) instances that exist but lose against their own slices run as teams of one launch (SP_ZM_SPLIT="1,3;..."): measurement knob
+ZM_SPLIT = {tuple(int(v) for v in it.split(",")) for it in os.environ.get("SP_ZM_SPLIT", "").split(";") if it}
+
+
 def zm_plan(op: ConvOp):
     """K tables of the z-marching kernel for a stride-1 3x3x3 op between whole 16-channel tiles, or None.
 
@@ -392,7 +396,7 @@ def zm_plan(op: ConvOp):
     P_, NT = op.cpi // 16, -(-op.cout // 16)
     if op.cpi % 16 or op.cpo % 16 or op.cin > op.cpi or op.cpo < NT * 16:
         return None
-    if (P_, NT) not in ZM_CONFIGS:
+    if (P_, NT) not in ZM_CONFIGS or (P_, NT) in ZM_SPLIT:
         return None
     MT, nslot, nw = ZM_CONFIGS[(P_, NT)]
     ith = nw * MT + 2
@@ -517,7 +521,7 @@ def zm_slices(op: ConvOp):
         return None
     import dataclasses
     P_, nt = op.cpi // 16, op.cout // 16
-    step = 2 if (P_, 2) in ZM_CONFIGS else 1
+    step = 2 if ((P_, 2) in ZM_CONFIGS and nt % 2 == 0) else 1      # (equal slices: they then run as teams of one launch)
     if (P_, step) not in ZM_CONFIGS or nt <= step:
         return None
     out = []
