@@ -152,7 +152,8 @@ int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
  * y[m][c] (bf16) = act(sum_g partial[g][m][c] + sum_g bias[g*bias_stride + c]); stats[rep][CP][2] += (sum y, sum y^2). */
 int sp_conv_partial_finish(const float* partial, int32_t ngroups, int64_t nvox, int32_t CP, const float* bias /* or NULL */,
                            int32_t bias_stride, int32_t act, float act_param, void* y, double* stats /* or NULL */,
-                           int32_t stats_nrep, sp_stream_t stream);
+                           int32_t stats_nrep, void* y8 /* or NULL: e4m3 plane-major copy of y, [CP/16][nvox][16 bytes] */,
+                           int64_t y8_plane, sp_stream_t stream);
 int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
 /* fp32 weights -> e4m3 A fragments in the plan's K order.  kmap[(step*4+g)*2+h] = (src_tap << 16) | input 16-channel plane, or
  * -1 (zero chunk); element (co, ci, tap) = w[co*sCo + ci*sCi + tap] * fold_scale[ci] (fold_scale may be NULL).  Per output

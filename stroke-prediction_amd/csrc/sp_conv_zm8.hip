@@ -459,7 +459,8 @@ extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream
 // of Unet3D.py:95-146): one thread = one voxel x 8 channels; statistics of the stored values for the next BatchNorm.
 __global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* __restrict__ partial, int G, int64_t M, int CP,
                                                                    const float* __restrict__ bias, int bias_stride, int act, float ap,
-                                                                   bf16_t* __restrict__ y, double* __restrict__ stats, int nrep) {
+                                                                   bf16_t* __restrict__ y, double* __restrict__ stats, int nrep,
+                                                                   unsigned char* __restrict__ y8, int64_t y8_plane) {
   __shared__ __attribute__((aligned(16))) float tr[256 * 16];
   const int OC = CP / 8;
   const int pos = threadIdx.x / OC, oc = threadIdx.x - pos * OC, vpb = 256 / OC;
@@ -515,6 +516,12 @@ __global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* _
           }
         }
         *reinterpret_cast<uint4*>(y + (m0 + (int64_t)u * vpb) * CP + oc * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        if (y8) {      // e4m3 plane-major copy of the stored values: channels [8 oc, 8 oc + 8) = half a 16-byte voxel of plane oc / 2
+          const float r0[4] = {sp_h2f_lo(w4[0]), sp_h2f_hi(w4[0]), sp_h2f_lo(w4[1]), sp_h2f_hi(w4[1])};
+          const float r1[4] = {sp_h2f_lo(w4[2]), sp_h2f_hi(w4[2]), sp_h2f_lo(w4[3]), sp_h2f_hi(w4[3])};
+          *reinterpret_cast<uint2*>(y8 + (size_t)(oc >> 1) * y8_plane + (m0 + (int64_t)u * vpb) * 16 + (oc & 1) * 8) =
+              make_uint2(zm8_pack4_e4m3(r0, 1.f), zm8_pack4_e4m3(r1, 1.f));
+        }
       }
     }
   }
@@ -533,7 +540,8 @@ __global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* _
 
 extern "C" int sp_conv_partial_finish(const float* partial, int32_t ngroups, int64_t nvox, int32_t CP, const float* bias,
                                       int32_t bias_stride, int32_t act, float act_param, void* y, double* stats, int32_t stats_nrep,
-                                      sp_stream_t stream) {
+                                      void* y8, int64_t y8_plane, sp_stream_t stream) {
+  SP_CHECK_ARG(!y8 || (CP % 16 == 0 && y8_plane >= nvox * 16), "sp_conv_partial_finish: e4m3 copy needs whole 16-channel planes of >= nvox * 16 bytes");
   SP_CHECK_ARG(partial && y && ngroups >= 1 && nvox >= 1 && CP % 8 == 0 && CP >= 8 && CP <= 2048, "sp_conv_partial_finish: bad arguments");
   SP_CHECK_ARG(act == SP_ACT_NONE || act == SP_ACT_LEAKY, "sp_conv_partial_finish: LeakyReLU or identity");
   SP_CHECK_ARG(!bias || bias_stride >= CP, "sp_conv_partial_finish: bias_stride");
@@ -542,7 +550,8 @@ extern "C" int sp_conv_partial_finish(const float* partial, int32_t ngroups, int
   int64_t want = (nvox + (int64_t)vpb * 8 - 1) / ((int64_t)vpb * 8);
   const unsigned grid = (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
   hipLaunchKernelGGL(conv_partial_finish_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     partial, ngroups, nvox, CP, bias, bias_stride, act, act_param, reinterpret_cast<bf16_t*>(y), stats, stats_nrep);
+                     partial, ngroups, nvox, CP, bias, bias_stride, act, act_param, reinterpret_cast<bf16_t*>(y), stats, stats_nrep,
+                     reinterpret_cast<unsigned char*>(y8), y8_plane);
   SP_CHECK_LAUNCH("sp_conv_partial_finish");
   return SP_OK;
 }

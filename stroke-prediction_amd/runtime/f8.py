@@ -209,7 +209,7 @@ class ConvRunnerF8Split:
     """A stride-1 3x3x3 op with more input planes than an fp8 instance holds (12, 16, 24: the layers behind the concatenations and
     the 256-channel bottleneck of the 4-scale network): one ConvRunnerF8 per group of 6 or 8 input planes writes fp32 partial sums,
     ``sp_conv_partial_finish`` adds the groups (and their folded biases), applies the activation and takes the statistics.
-    Same interface as ConvRunnerF8 (no e4m3 copy of the output)."""
+    Same interface as ConvRunnerF8 (the e4m3 copy of the output comes from the finish pass)."""
 
     @staticmethod
     def groups(op):
@@ -253,7 +253,8 @@ class ConvRunnerF8Split:
 
     def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
         op, batch = self.op, self.batch
-        assert y8 is None and y.dtype == torch.bfloat16 and y.shape[4] == self.cpad == op.cpo, (tuple(y.shape), self.cpad, op.cpo)
+        assert y.dtype == torch.bfloat16 and y.shape[4] == self.cpad == op.cpo, (tuple(y.shape), self.cpad, op.cpo)
+        assert y8 is None or (self.bin == E4M3 and y8_scale == 1.0 and tuple(y8.shape) == (self.cpad // 16, batch) + tuple(op.y_dims) + (16,))
         assert tuple(x8.shape) == (op.cpi // 16, batch) + tuple(op.in_dims) + (16,), (tuple(x8.shape), op.cpi)
         nvox = batch * int(np.prod(op.y_dims))
         if self.partial is None:
@@ -262,7 +263,7 @@ class ConvRunnerF8Split:
             r.run(x8[g * self.gp:(g + 1) * self.gp], self.partial[g])
         with O._Timed("conv_partial_finish", 0.0, "%d->%d @%s x%d groups" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), self.G)):
             L.call("sp_conv_partial_finish", O.ptr(self.partial), self.G, nvox, self.cpad, O.ptr(self.bias_all) if self.has_bias else None,
-                   self.cpad, act, act_param, O.ptr(y), O.ptr(stats), stats_nrep, O.stream())
+                   self.cpad, act, act_param, O.ptr(y), O.ptr(stats), stats_nrep, O.ptr(y8), nvox * 16, O.stream())
 
 
 class WgradRunnerF8:

@@ -174,8 +174,7 @@ class ConvLayer:
     def y8_capable(self):
         """this layer's forward kernel can write the e4m3 plane-major copy of its output next to the bf16 one"""
         if self.f8_fwd is not None:
-            from . import f8 as F8
-            return isinstance(self.f8_fwd, F8.ConvRunnerF8)      # (the split form finishes in an elementwise pass: no copy)
+            return True
         return bool(self.FUSE_Q8 and self.kind == "conv" and self.G == 1 and not self.materialize and self.out_dtype == L.SP_BF16
                     and self.act in (L.ACT_NONE, L.ACT_LEAKY) and self.fwd.zm_y8_ok())
 

@@ -104,7 +104,7 @@ _SIGS = {
     "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),
     "sp_wgrad_finish_folded_scaled": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp], i32),
     "sp_conv3d_wgrad_f8": ([C.POINTER(WgradF8Args), vp], i32),
-    "sp_conv_partial_finish": ([vp, i32, i64, i32, vp, i32, i32, f32, vp, vp, i32, vp], i32),
+    "sp_conv_partial_finish": ([vp, i32, i64, i32, vp, i32, i32, f32, vp, vp, i32, vp, i64, vp], i32),
     "sp_upsample2_crop_cat_fwd": ([vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, vp], i32),
     "sp_confusion_counts": ([vp, vp, f32, i64, vp, vp], i32),
     "sp_first_supported": ([i32, i32, i32], i32),

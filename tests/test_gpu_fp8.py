@@ -541,7 +541,11 @@ def test_fp8_conv_with_input_channel_groups_matches_torch_on_quantised_operands(
     y = torch.full((B,) + tuple(op.y_dims) + (cout,), float("nan"), dtype=torch.bfloat16, device=DEV)
     nrep = 8
     stats = torch.zeros(nrep, cout, 2, dtype=torch.float64, device=DEV)
-    run.run(x8, y, L.ACT_LEAKY, LEAKY, stats, nrep)
+    y8 = F8.alloc_f8(B, op.y_dims, cout, DEV)
+    run.run(x8, y, L.ACT_LEAKY, LEAKY, stats, nrep, y8=y8)
+    r8 = F8.alloc_f8(B, op.y_dims, cout, DEV)
+    F8.quantize(y, r8, F8.E4M3, 1.0)
+    assert torch.equal(y8, r8)                     # the finish pass's e4m3 copy == sp_quantize_f8 of the stored output
     wf = w * fs.view(1, -1, 1, 1, 1)
     wq = torch.cat([nets.quant_weights_e4m3(wf[:, c0:c0 + gp].contiguous()) for c0 in range(0, cin, gp)], 1)
     bfold = b + (w * fsh.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
