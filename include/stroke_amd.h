@@ -478,6 +478,11 @@ int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* coefp, cons
 int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
                          int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
                          float act_param, void* dz, double* dbias_sums, sp_stream_t stream);
+/* the same with the fp8 plane-major copy of dz (as sp_bn_act_bwd_q8; dz == NULL: only the copy) */
+int sp_upsample2_act_bwd_q8(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat, int32_t coef_stride,
+                            int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act, float act_param,
+                            void* dz, double* dbias_sums, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale,
+                            sp_stream_t stream);
 
 /* ------------------------------------------------------------------ the same kernels with an fp8 shadow output
  * ("fp8" precision mode): besides the bf16 tensor the kernel writes q8 = fp8(q8_scale * stored value) PLANE-MAJOR,

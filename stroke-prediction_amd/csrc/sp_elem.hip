@@ -1225,7 +1225,7 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* __restrict__ y, const T* __restrict__ g,
                                                                        const float* __restrict__ coef, int CPcat, int cstride, Dims di,
                                                                        int CP, OctMap om, UpTile ut, int act, float ap,
-                                                                       T* __restrict__ dz, double* __restrict__ dbias) {
+                                                                       T* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int OC = om.OC, TY = ut.TY, TX = ut.TX, RY = ut.RY, RX = ut.RX;
   const int pos = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - pos * OC;
@@ -1368,7 +1368,9 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_tiled_kernel(const T* _
       if (valid) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) part[0][j] += o8[j];
-        Store<T>::st8(dz + ((((size_t)b * D + m) * H + yy) * W + xx) * CP + oc * 8, o8);
+        const size_t vo_ = (((size_t)b * D + m) * H + yy) * W + xx;
+        if (dz) Store<T>::st8(dz + vo_ * CP + oc * 8, o8);      // (NULL: both readers take the fp8 copy)
+        if (q8.p) sp_q8_store8(q8, (int64_t)vo_, oc, o8);
       }
     }
 #pragma unroll
@@ -1391,7 +1393,7 @@ template <int OCT, int ACT>
 __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ g,
                                                                       const float* __restrict__ coef, int CPcat, int cstride,
                                                                       Dims di, int nby, int nbx, int act, float ap,
-                                                                      bf16_t* __restrict__ dz, double* __restrict__ dbias) {
+                                                                      bf16_t* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8) {
   constexpr int CP = OCT * 8, TX = 16, TY = 256 / (16 * OCT), RY = 2 * TY + 2, RX = 2 * TX + 2;
   constexpr int NCH = RY * RX * OCT, NJ = (NCH + 255) / 256, PSB = NJ * 4096;          // plane slot
   constexpr int NYC = (TY + 2) * (TX + 2) * OCT, NJY = (NYC + 255) / 256, YSB = NJY * 4096;
@@ -1566,7 +1568,9 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
         if (valid) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) part[0][j] += o8[j];
-          Store<bf16_t>::st8(dz + ((((size_t)b * D + m) * H + yy) * W + xx) * CP + oc * 8, o8);
+          const size_t vo_ = (((size_t)b * D + m) * H + yy) * W + xx;
+          if (dz) Store<bf16_t>::st8(dz + vo_ * CP + oc * 8, o8);
+          if (q8.p) sp_q8_store8(q8, (int64_t)vo_, oc, o8);
         }
       }
 #pragma unroll
@@ -1582,7 +1586,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
 
 template <int OCT>
 static int launch_up_bwd_ring(const void* y, const void* g, const float* coef, int CPcat, int cstride, Dims di, int act, float ap,
-                              void* dz, double* dbias, hipStream_t st) {
+                              void* dz, double* dbias, SpQ8 q8, hipStream_t st) {
   constexpr int TY = 256 / (16 * OCT), NJ = ((2 * TY + 2) * 34 * OCT + 255) / 256, NJY = ((TY + 2) * 18 * OCT + 255) / 256;
   const int lds = 4 * NJ * 4096 + 2 * NJY * 4096;
   const int nby = (di.H + TY - 1) / TY, nbx = (di.W + 15) / 16;
@@ -1593,7 +1597,7 @@ static int launch_up_bwd_ring(const void* y, const void* g, const float* coef, i
     auto kern = upsample2_act_bwd_ring_kernel<OCT, A_>;                                                                \
     SP_ENSURE_LDS(kern, lds, "sp_upsample2_act_bwd");                                                                  \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, cstride, di, nby, nbx, \
-                       act, ap, (bf16_t*)dz, dbias);                                                                   \
+                       act, ap, (bf16_t*)dz, dbias, q8);                                                               \
   }
   SP_ACT_DISPATCH(act, SP_L)
 #undef SP_L
@@ -1601,19 +1605,21 @@ static int launch_up_bwd_ring(const void* y, const void* g, const float* coef, i
   return SP_OK;
 }
 
-extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
-                                    int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
-                                    float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
-  SP_CHECK_ARG(y && g && coef && dz && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
+static int upsample2_act_bwd_impl(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
+                                  int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
+                                  float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream) {
+  SP_CHECK_ARG(y && g && coef && (dz || q8.p) && CP % 8 == 0 && CPcat >= CP, "sp_upsample2_act_bwd: bad arguments");
+  SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.scale > 0.f && q8.plane >= (int64_t)B * D * H * W * 16),
+               "sp_upsample2_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   if (coef_stride <= 0) coef_stride = CPcat;
   SP_CHECK_VOX((int64_t)B * D * H * W * 8, "sp_upsample2_act_bwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
   if (dtype == SP_BF16 && (CP == 16 || CP == 32 || CP == 64) && D >= 2 && H >= 2 && W >= 2 && (int64_t)4 * H * W * CPcat * 2 < (1ll << 31) &&
       !getenv("SP_UPSAMPLE_BWD_TILED") && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
-    if (CP == 16) return launch_up_bwd_ring<2>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, ST(stream));
-    if (CP == 32) return launch_up_bwd_ring<4>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, ST(stream));
-    return launch_up_bwd_ring<8>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, ST(stream));
+    if (CP == 16) return launch_up_bwd_ring<2>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream));
+    if (CP == 32) return launch_up_bwd_ring<4>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream));
+    return launch_up_bwd_ring<8>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream));
   }
   if (256 % om.OC == 0 && D >= 2 && H >= 2 && W >= 2 && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
     // tiled path: TY x TX input columns per workgroup, z split into chunks so that ~3 workgroups per CU exist
@@ -1638,12 +1644,12 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
     auto kern = upsample2_act_bwd_tiled_kernel<bf16_t, A_>;                                                                           \
     SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");                                                                            \
     hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, coef_stride, di, \
-                       CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums);                                                         \
+                       CP, om, ut, act, act_param, (bf16_t*)dz, dbias_sums, q8);                                                     \
   } else {                                                                                                                            \
     auto kern = upsample2_act_bwd_tiled_kernel<float, A_>;                                                                            \
     SP_ENSURE_LDS(kern, (int)sh2, "sp_upsample2_act_bwd");                                                                            \
     hipLaunchKernelGGL(kern, dim3(grid2), dim3(256), sh2, ST(stream), (const float*)y, (const float*)g, coef, CPcat, coef_stride, di,  \
-                       CP, om, ut, act, act_param, (float*)dz, dbias_sums);                                                          \
+                       CP, om, ut, act, act_param, (float*)dz, dbias_sums, q8);                                                      \
   }
       SP_ACT_DISPATCH(act, SP_L)
 #undef SP_L
@@ -1651,13 +1657,27 @@ extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* 
       return SP_OK;
     }
   }
-  SP_CHECK_ARG(cat, "sp_upsample2_act_bwd: the gather fallback needs the concat buffer (same pitch as g)");
+  SP_CHECK_ARG(cat && dz && !q8.p, "sp_upsample2_act_bwd: the gather fallback needs the concat buffer (same pitch as g) and writes no fp8 copy");
   const unsigned grid = grid_for((int64_t)B * D * H * W, om.vpb);
   const size_t sh = (size_t)CP * sizeof(float);
   if (dtype == SP_BF16) hipLaunchKernelGGL(upsample2_act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, (const bf16_t*)cat, (const bf16_t*)g, coef, CPcat, coef_stride, di, CP, om, act, act_param, (bf16_t*)dz, dbias_sums);
   else hipLaunchKernelGGL(upsample2_act_bwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)cat, (const float*)g, coef, CPcat, coef_stride, di, CP, om, act, act_param, (float*)dz, dbias_sums);
   SP_CHECK_LAUNCH("sp_upsample2_act_bwd");
   return SP_OK;
+}
+extern "C" int sp_upsample2_act_bwd(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
+                                    int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t act,
+                                    float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
+  return upsample2_act_bwd_impl(y, cat, g, coef, CPcat, coef_stride, dtype, B, D, H, W, CP, act, act_param, dz, dbias_sums,
+                                SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+extern "C" int sp_upsample2_act_bwd_q8(const void* y, const void* cat, const void* g, const float* coef, int32_t CPcat,
+                                       int32_t coef_stride, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
+                                       int32_t act, float act_param, void* dz /* or NULL */, double* dbias_sums, void* q8,
+                                       int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_upsample2_act_bwd_q8: bad fp8 output");
+  return upsample2_act_bwd_impl(y, cat, g, coef, CPcat, coef_stride, dtype, B, D, H, W, CP, act, act_param, dz, dbias_sums,
+                                SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ network output side

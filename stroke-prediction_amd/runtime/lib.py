@@ -138,6 +138,7 @@ _SIGS = {
     "sp_pool_skip_act_bwd": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                               f32, vp, vp, vp], i32),
     "sp_upsample2_act_bwd": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp], i32),
+    "sp_upsample2_act_bwd_q8": ([vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, i64, i32, f32, vp], i32),
     "sp_out_grad_to_cl": ([vp, vp, i32, i32, i64, i32, i32, i32, f32, vp, vp, vp], i32),
     "sp_dice_sums": ([vp, i64, vp, i64, i32, i32, i64, vp, vp], i32),
     "sp_dice_finalize": ([vp, vp, f64, i32, vp, vp, vp], i32),

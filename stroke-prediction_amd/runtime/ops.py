@@ -809,8 +809,12 @@ def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, 
            dtype, B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), stream())
 
 
-def upsample2_act_bwd(y, cat, g, coef, dtype, act, act_param, dz, dbias, coef_stride=0):
+def upsample2_act_bwd(y, cat, g, coef, dtype, act, act_param, dz, dbias, coef_stride=0, q8=None):
     B, D, H, W, CP = y.shape
+    if q8 is not None:
+        L.call("sp_upsample2_act_bwd_q8", ptr(y), ptr(cat), ptr(g), ptr(coef), g.shape[-1], coef_stride, dtype, B, D, H, W, CP, act,
+               act_param, ptr(dz), ptr(dbias), *_q8_args(q8, B * D * H * W), stream())
+        return
     L.call("sp_upsample2_act_bwd", ptr(y), ptr(cat), ptr(g), ptr(coef), g.shape[-1], coef_stride, dtype, B, D, H, W, CP, act,
            act_param, ptr(dz), ptr(dbias), stream())
 

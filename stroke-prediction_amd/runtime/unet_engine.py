@@ -275,10 +275,15 @@ class UnetEngine:
     def _up_bwd(self, low, cat, g, coef, planar):
         """gradient of the upsampled half of a concat input -> dz of the low-resolution producer `low`"""
         dt = self.dtype
+        # fp8 mode: the ring / tiled kernels write the e5m2 copy themselves (not the gather fallback, which needs `cat`)
+        cp = low.y.shape[-1]
+        q8 = low.dz8_out() if ((planar or isinstance(g, tuple)) and cp % 16 == 0 and 256 % (cp // 8) == 0 and cp <= 256
+                               and dt == L.SP_BF16 and min(low.y.shape[1:4]) >= 2) else None
+        dz = low.dz_target() if q8 is not None else low.dz
         if isinstance(g, tuple):      # dense per-part gradient tensors (ConvLayer split_g)
-            O.upsample2_act_bwd(low.y, None, g[0], coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums, coef_stride=cat.shape[-1])
+            O.upsample2_act_bwd(low.y, None, g[0], coef, dt, L.ACT_LEAKY, LEAKY, dz, low.dbias_sums, coef_stride=cat.shape[-1], q8=q8)
         else:
-            O.upsample2_act_bwd(low.y, None if planar else cat, g, coef, dt, L.ACT_LEAKY, LEAKY, low.dz, low.dbias_sums)
+            O.upsample2_act_bwd(low.y, None if planar else cat, g, coef, dt, L.ACT_LEAKY, LEAKY, dz, low.dbias_sums, q8=q8)
 
     def _skip_bwd(self, prod, gp, coefp, cat, g, coef, c_up):
         """pool gradient + skip half of the concat gradient -> dz of the block output `prod`"""

@@ -420,6 +420,19 @@ def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
     dz28b = F8.alloc_f8(B, dims, CP, DEV)
     O.pool_skip_act_bwd(x, gp, coefp, None, gs, coefs, 32, L.SP_BF16, L.ACT_LEAKY, LEAKY, None, None, q8=(dz28b, F8.E5M2, S))
     assert torch.equal(dz28b, ref28)
+    # upsample backward (ring kernel at 32 channels, tiled kernel at 128) -> dz of the low-resolution producer (+ e5m2 copy)
+    for cpl in (32, 128):
+        ldl = (4, 5, 9)
+        ylow = cl(ldl, cpl)
+        gcat = cl(tuple(2 * d for d in ldl), cpl + 16, 1e-5)
+        cf = (torch.randn(3, cpl + 16, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+        dzl, dzl8, refl8 = torch.empty_like(ylow), F8.alloc_f8(B, ldl, cpl, DEV), F8.alloc_f8(B, ldl, cpl, DEV)
+        O.upsample2_act_bwd(ylow, None, gcat, cf, L.SP_BF16, L.ACT_LEAKY, LEAKY, dzl, None, q8=(dzl8, F8.E5M2, S))
+        F8.quantize(dzl, refl8, F8.E5M2, S)
+        assert torch.equal(dzl8, refl8) and float(dzl.float().abs().max()) > 0
+        dzl8b = F8.alloc_f8(B, ldl, cpl, DEV)
+        O.upsample2_act_bwd(ylow, None, gcat, cf, L.SP_BF16, L.ACT_LEAKY, LEAKY, None, None, q8=(dzl8b, F8.E5M2, S))
+        assert torch.equal(dzl8b, refl8)
     # upsample + crop + concat, plane-major -> cat (+ e4m3 copy)
     ld = (4, 5, 9)
     low, skip = cl(ld, 32), cl(tuple(2 * d + 4 for d in ld), 16)
