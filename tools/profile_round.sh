@@ -11,6 +11,7 @@ csvf() { find $1 -name "*counter_collection.csv" | head -1; }
 if [ "$WL" = unet ]; then
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_bench_kernel_stats.csv > gpurun_out/${TAG}_bench_kernel_stats.txt
+  python tools/rocpd_sequence.py $(db $OUT/g) > gpurun_out/${TAG}_headline_step_sequence.txt      # ordered kernels of the last step
   SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/s -o s -- python bench.py --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary > $OUT/s.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/s) gpurun_out/${TAG}_bench_kernel_stats_serial.csv > gpurun_out/${TAG}_bench_kernel_stats_serial.txt
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/f.log 2>&1
@@ -22,6 +23,8 @@ if [ "$WL" = unet ]; then
 elif [ "$WL" = unet4fp8 ]; then
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_unet4_fp8_kernel_stats.csv > gpurun_out/${TAG}_unet4_fp8_kernel_stats.txt
+  python tools/rocpd_sequence.py $(db $OUT/g) > gpurun_out/${TAG}_unet4_fp8_step_sequence.txt      # ordered kernels of the last step
+  python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-secondary --no-cpu-baseline --layers 2> /dev/null | grep -E "conv_igemm|conv_wgrad|quantize|partial" > gpurun_out/${TAG}_unet4_fp8_layers.txt
 else
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload cae --steps 5 --warmup 2 --no-cpu-baseline > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_cae_kernel_stats.csv > gpurun_out/${TAG}_cae_kernel_stats.txt
