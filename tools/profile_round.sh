@@ -24,7 +24,7 @@ elif [ "$WL" = unet4fp8 ]; then
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_unet4_fp8_kernel_stats.csv > gpurun_out/${TAG}_unet4_fp8_kernel_stats.txt
   python tools/rocpd_sequence.py $(db $OUT/g) > gpurun_out/${TAG}_unet4_fp8_step_sequence.txt      # ordered kernels of the last step
-  python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-secondary --no-cpu-baseline --layers 2> /dev/null | grep -E "conv_igemm|conv_wgrad|quantize|partial" > gpurun_out/${TAG}_unet4_fp8_layers.txt
+  python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-secondary --no-cpu-baseline --layers 2>&1 | grep -E "conv_igemm|conv_wgrad|quantize|partial" > gpurun_out/${TAG}_unet4_fp8_layers.txt
 else
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload cae --steps 5 --warmup 2 --no-cpu-baseline > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_cae_kernel_stats.csv > gpurun_out/${TAG}_cae_kernel_stats.txt
