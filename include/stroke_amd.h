@@ -39,7 +39,12 @@ enum { SP_OK = 0, SP_EINVAL = -1, SP_EHIP = -2 };
 enum { SP_REDUCE_ROWS = 8 };
 /* row pitch (doubles) of the Dice accumulator sums[SP_REDUCE_ROWS][SP_DICE_PITCH(C)]: whole 128-byte lines */
 #define SP_DICE_PITCH(C) ((3 * (C) + 15) / 16 * 16)
-enum { SP_BF16 = 0, SP_F32 = 1 };
+enum { SP_BF16 = 0, SP_F32 = 1,
+       /* bf16 PAIR: value = hi + lo with hi = bf16(value) and lo = bf16(value - hi), stored as TWO bf16 tensors of the same
+        * shape (the hi tensor is what the bf16 kernels of the backward pass read; the lo tensor lies lo_delta bytes behind it).
+        * ~17 significand bits.  Forward kernels of the "bf16x3" precision mode take and write pairs and multiply them with
+        * hi/lo weight fragments on three bf16 MFMAs per product (hi*hi + hi*lo + lo*hi, fp32 accumulate). */
+       SP_HL = 2 };
 enum { SP_ACT_NONE = 0, SP_ACT_LEAKY = 1, SP_ACT_ELU = 2, SP_ACT_SIGMOID = 3 };
 
 int sp_version(void);
@@ -117,6 +122,9 @@ typedef struct sp_conv_args {
   int32_t nslices;             /* > 1: slice s computes output channels [s*Cout, (s+1)*Cout) -- y, bias, f8_wscale, stats are the
                                   pointers of slice 0 (the others follow at + s*Cout channels), y8 at + s*NT planes */
   int64_t slice_wfrag_stride;  /* bytes between the weight fragments (wfrag_hi) of consecutive slices */
+  /* ---- bf16 pairs (dtype_in / dtype_out = SP_HL; sp_conv3d_zm and sp_conv3d_igemm forward kernels; 0 elsewhere) */
+  int64_t x_lo_delta;          /* bytes from x (hi halves) to the lo halves (a tensor of the same shape and layout) */
+  int64_t y_lo_delta;          /* the same for y */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -137,6 +145,37 @@ int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
 /* (input planes P = Cin/16, output tiles NT = Cout/16) -> rows per wave, ring slots and waves per workgroup of the kernel that
  * exists for the pair (a workgroup covers NW*MT x 16 output voxels per plane); returns SP_EINVAL when there is none */
 int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
+
+/* ------------------------------------------------------------------ bf16 pairs (SP_HL): the forward pass of the "bf16x3" mode
+ * north_star asks for logits within 1e-3 of the CPU reference; bf16 storage (8 significand bits per activation) cannot give
+ * that and fp32 storage with split MFMAs costs 4.7x the bf16 step.  In this mode every activation of the FORWARD pass is a pair
+ * of bf16 tensors (hi = bf16(v), lo = bf16(v - hi): ~17 bits), every forward convolution multiplies pairs with hi/lo weight
+ * fragments on three bf16 MFMAs per product (sp_conv3d_zm / sp_conv3d_igemm with dtype_in = dtype_out = SP_HL, x_lo_delta,
+ * y_lo_delta, wfrag_lo), and the BACKWARD pass is the bf16 one, unchanged, on the hi tensors (which are exactly the tensors the
+ * bf16 mode would have stored).  Replaces Block3x3x3.forward / Unet3D.forward (Unet3D.py:14-27,56-79) at fp32-like accuracy.
+ * The entry points below are the pair forms of the forward-only kernels; *_lo_delta = byte distance from a hi tensor to its lo
+ * tensor (same shape and layout, 16-byte aligned). */
+int sp_conv3d_zm_config_hl(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
+/* first BatchNorm's statistics of the fp32 NCDHW input as it is (sp_bn_stats_ncdhw rounds to the 16-bit type first) */
+int sp_bn_stats_ncdhw_f32(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums, int32_t nrep,
+                          sp_stream_t stream);
+/* first layer (BatchNorm3d(2) -> Conv3d(2, 16 | 32, 3) -> act, Unet3D.py:18-20): hi + lo weight fragments, y / y_lo pair */
+int sp_first_prep_hl(const float* w, const float* b, const float* scale, const float* shift, void* wfrag_hi, void* wfrag_lo,
+                     float* bias_f, int32_t Cout, sp_stream_t stream);
+int sp_first_conv_fwd_hl(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag_hi, const void* wfrag_lo,
+                         const float* bias_f, int32_t act, float act_param, void* y, void* y_lo, double* stats, int32_t nrep,
+                         int32_t Cout, sp_stream_t stream);
+/* MaxPool3d(2,2) (Unet3D.py:39,41) of the pair values, written as a pair; stats as sp_maxpool2_fwd */
+int sp_maxpool2_fwd_hl(const void* x, int64_t x_lo_delta, void* y, int64_t y_lo_delta, int32_t B, int32_t D, int32_t H, int32_t W,
+                       int32_t CP, double* stats, sp_stream_t stream);
+/* Upsample x2 + crop + concat (Unet3D.py:64-72) on pairs; cat_plane as for sp_upsample2_crop_cat_fwd (elements of one half) */
+int sp_upsample2_crop_cat_fwd_hl(const void* low, int64_t low_lo_delta, int32_t CPu, const void* skip, int64_t skip_lo_delta, int32_t CPs,
+                                 void* cat, int64_t cat_lo_delta, int32_t CPd, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds,
+                                 int32_t Hs, int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream);
+/* classify head (Unet3D.py:49-54,75-77) on a pair input: fp32 arithmetic, seg as sp_head_fwd */
+int sp_head_fwd_hl(const void* x, int64_t x_lo_delta, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                   const float* b1, int32_t CH, const float* w2, const float* b2, int32_t NC, float slope, float* seg,
+                   sp_stream_t stream);
 
 /* ------------------------------------------------------------------ fp8 (BASELINE.json configs[4]: "4-scale U-Net ... fp8 MFMA")
  * The same z-marching operation on v_mfma_f32_16x16x128_f8f6f4 (csrc/sp_conv_zm8.hip): x is an fp8 PLANE-MAJOR tensor

@@ -91,6 +91,8 @@ class Unet3D(FlatParamsMixin, nn.Module):
         self.compute_dtype = dtype           # "bf16" (fast) | "f32" (split-bf16 x3 MFMA, parity mode) | "fp8" (bf16 storage,
                                              # e4m3 / e5m2 MFMA operands where the fp8 kernel applies: runtime/f8.py) | "f16"
                                              # (IEEE-half storage: libstroke_amd_f16.so, 3 more mantissa bits at the bf16 speed)
+                                             # | "bf16x3" (forward on bf16 PAIRS, three MFMAs per product: logits within 1e-3 of
+                                             # the fp32 reference; backward = the bf16 one on the hi halves)
         n_in, widths, ch_bC, n_classes = channels[0], list(channels[1:2 * S]), channels[-2], channels[-1]
         for i in range(1, S + 1):            # down path: block_i(b_{i-1} -> b_i)
             setattr(self, "block%d" % i, Block3x3x3(n_in if i == 1 else widths[i - 2], widths[i - 1]))
@@ -125,7 +127,7 @@ class Unet3D(FlatParamsMixin, nn.Module):
             variant = _L.VARIANT_OF[self.compute_dtype]
             with _L.use(variant):
                 eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device,
-                                 f8=(self.compute_dtype == "fp8"), variant=variant)
+                                 f8=(self.compute_dtype == "fp8"), variant=variant, hl=(self.compute_dtype == "bf16x3"))
             self._engines[key] = eng
         return eng
 

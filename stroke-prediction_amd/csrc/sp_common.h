@@ -159,6 +159,47 @@ template <> struct Store<float> {
   }
 };
 
+// ---- bf16 PAIR tensors (SP_HL, the forward storage of the "bf16x3" precision mode): value = hi + lo, hi = bf16(value) in one
+// tensor, lo = bf16(value - hi) in a second tensor of the same shape `lo_delta` bytes behind it (~17 significand bits).  The hi
+// tensor alone IS the bf16 mode's tensor: the backward kernels read it unchanged.  sp_hl_t marks a pointer to the hi half.
+struct sp_hl_t { bf16_t v; };
+// four values -> their hi and lo words (two storage words per dword)
+__device__ __forceinline__ void sp_hl_split4(const float* v, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
+  h0 = sp_pack_bf16x2(v[0], v[1]);
+  h1 = sp_pack_bf16x2(v[2], v[3]);
+  l0 = sp_pack_bf16x2(v[0] - sp_h2f_lo(h0), v[1] - sp_h2f_hi(h0));
+  l1 = sp_pack_bf16x2(v[2] - sp_h2f_lo(h1), v[3] - sp_h2f_hi(h1));
+}
+// eight consecutive channels of one voxel (16-byte aligned in both halves)
+__device__ __forceinline__ void sp_hl_ld8(const sp_hl_t* p, int64_t lo_delta, float* v) {
+  const uint4 h = *reinterpret_cast<const uint4*>(p);
+  const uint4 l = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p) + lo_delta);
+  const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[2 * i] = sp_h2f_lo(hw[i]) + sp_h2f_lo(lw[i]);
+    v[2 * i + 1] = sp_h2f_hi(hw[i]) + sp_h2f_hi(lw[i]);
+  }
+}
+__device__ __forceinline__ void sp_hl_st8(sp_hl_t* p, int64_t lo_delta, const float* v) {
+  uint32_t h[4], l[4];
+  sp_hl_split4(v, h[0], h[1], l[0], l[1]);
+  sp_hl_split4(v + 4, h[2], h[3], l[2], l[3]);
+  *reinterpret_cast<uint4*>(p) = make_uint4(h[0], h[1], h[2], h[3]);
+  *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p) + lo_delta) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void sp_hl_st4(sp_hl_t* p, int64_t lo_delta, const float* v) {
+  uint32_t h0, h1, l0, l1;
+  sp_hl_split4(v, h0, h1, l0, l1);
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(p) + lo_delta) = make_uint2(l0, l1);
+}
+// eight channels of a voxel through one interface: T = bf16_t / float (lo_delta ignored) or sp_hl_t
+template <typename T> __device__ __forceinline__ void ld8x(const T* p, int64_t, float* v) { Store<T>::ld8(p, v); }
+template <> __device__ __forceinline__ void ld8x<sp_hl_t>(const sp_hl_t* p, int64_t lo_delta, float* v) { sp_hl_ld8(p, lo_delta, v); }
+template <typename T> __device__ __forceinline__ void st8x(T* p, int64_t, const float* v) { Store<T>::st8(p, v); }
+template <> __device__ __forceinline__ void st8x<sp_hl_t>(sp_hl_t* p, int64_t lo_delta, const float* v) { sp_hl_st8(p, lo_delta, v); }
+
 // ---- optional fp8 shadow output of an elementwise kernel (the "fp8" precision mode, csrc/sp_conv_zm8.hip): besides its bf16
 // tensor the kernel writes q8 = fp8(scale * bf16(value)) into a PLANE-MAJOR tensor [CP/16][nvox][16 bytes] -- the operand of
 // the next fp8 convolution -- instead of leaving that to a separate pass over HBM (sp_quantize_f8).  p == nullptr: off.

@@ -18,12 +18,13 @@
 //   * SP_F32 mode: x = hi + lo in bf16, three MFMAs per product (hi*hi, hi*lo, lo*hi), fp32
 //     accumulate: ~2^-17 relative, used for parity against the fp32 CPU reference.
 #include "sp_common.h"
+#include <type_traits>
 
 // one 8-channel chunk as loaded from global memory, kept raw until every load of a batch is in flight
 template <typename T> struct RawChunk;
 template <> struct RawChunk<bf16_t> {
   uint4 r;
-  __device__ __forceinline__ void ld(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void ld(const bf16_t* p, int64_t = 0) { r = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void unpack(float* v) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -32,9 +33,22 @@ template <> struct RawChunk<bf16_t> {
 };
 template <> struct RawChunk<float> {
   float4 a, b;
-  __device__ __forceinline__ void ld(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+  __device__ __forceinline__ void ld(const float* p, int64_t = 0) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
   __device__ __forceinline__ void unpack(float* v) const {
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+};
+// bf16 pair (SP_HL): value = hi + lo, exact in fp32; the staging below splits it again (the same two words come back)
+template <> struct RawChunk<sp_hl_t> {
+  uint4 h, l;
+  __device__ __forceinline__ void ld(const sp_hl_t* p, int64_t lo_delta) {
+    h = *reinterpret_cast<const uint4*>(p);
+    l = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p) + lo_delta);
+  }
+  __device__ __forceinline__ void unpack(float* v) const {
+    const uint32_t hw[4] = {h.x, h.y, h.z, h.w}, lw[4] = {l.x, l.y, l.z, l.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = sp_h2f_lo(hw[i]) + sp_h2f_lo(lw[i]); v[2 * i + 1] = sp_h2f_hi(hw[i]) + sp_h2f_hi(lw[i]); }
   }
 };
 #define SB 8   // staging loads in flight per thread
@@ -111,6 +125,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
     for (int m = 0; m < MT; ++m) acc[n][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const TIN* __restrict__ xin = reinterpret_cast<const TIN*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * a.CPi;
+  const TIN* __restrict__ xpl = reinterpret_cast<const TIN*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * 16;      // plane-major: sample b of plane 0
   const bf16x8* __restrict__ wf_hi = reinterpret_cast<const bf16x8*>(a.wfrag_hi);
   const bf16x8* __restrict__ wf_lo = reinterpret_cast<const bf16x8*>(a.wfrag_lo);
   const int nvox_tile = a.ITD * a.ITH * a.ITW;
@@ -157,7 +172,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
         valid |= (i0 < nchunks ? 1u : 0u) << u;
         inb |= (ok ? 1u : 0u) << u;
         const int cz = min(max(gz, 0), a.Di - 1), cy = min(max(gy, 0), a.Hi - 1), cx = min(max(gx, 0), a.Wi - 1);
-        raw[u].ld(xin + (((size_t)cz * a.Hi + cy) * a.Wi + cx) * a.CPi + cch[u]);
+        // (x_plane != 0: plane-major input [CPi/16][B][D][H][W][16], the concat buffers of the U-Net's up path)
+        const size_t vo_ = ((size_t)cz * a.Hi + cy) * a.Wi + cx;
+        raw[u].ld(a.x_plane ? xpl + (size_t)(cch[u] >> 4) * (size_t)a.x_plane + vo_ * 16 + (cch[u] & 15) : xin + vo_ * a.CPi + cch[u], a.x_lo_delta);
       }
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
@@ -303,14 +320,15 @@ __device__ __forceinline__ void conv_igemm_body(const ConvDev& P) {
         v[j] = (c0 + j < a.Cout) ? z : 0.f;
       }
       if (valid && c0 < a.CPo) {
-        if (sizeof(TOUT) == 2) {   // statistics of what is actually stored (bf16-rounded values)
+        if (sizeof(TOUT) == 2 && !std::is_same<TOUT, sp_hl_t>::value) {   // statistics of what is actually stored (bf16-rounded values)
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] += v[j] * v[j]; }
         const size_t off = (((size_t)(oz * a.osD + a.ooD) * a.YH + (oy * a.osH + a.ooH)) * a.YW + (ox * a.osW + a.ooW)) * a.CPo + c0;
-        Store<TOUT>::st4(yout + off, v);
+        if constexpr (std::is_same<TOUT, sp_hl_t>::value) sp_hl_st4(yout + off, a.y_lo_delta, v);
+        else Store<TOUT>::st4(yout + off, v);
       }
     }
   }
@@ -370,6 +388,7 @@ static int dispatch_dtype_multi(const ConvDevMulti& M, int lds_bytes, dim3 grid,
   if (di == SP_BF16 && dout == SP_BF16) return launch_conv_multi<NT, MT, 1, bf16_t, bf16_t>(M, lds_bytes, grid, st);
   if (di == SP_F32 && dout == SP_F32) return launch_conv_multi<NT, MT, 2, float, float>(M, lds_bytes, grid, st);
   if (di == SP_BF16 && dout == SP_F32) return launch_conv_multi<NT, MT, 1, bf16_t, float>(M, lds_bytes, grid, st);
+  if (di == SP_HL && dout == SP_HL) return launch_conv_multi<NT, MT, 2, sp_hl_t, sp_hl_t>(M, lds_bytes, grid, st);
   sp_set_error("sp_conv3d_igemm_multi: unsupported dtype pair in=%d out=%d", di, dout);
   return SP_EINVAL;
 }
@@ -389,6 +408,7 @@ static int dispatch_dtype(const ConvDev& P, dim3 grid, hipStream_t st) {
   if (di == SP_BF16 && dout == SP_BF16) return launch_conv<NT, MT, 1, bf16_t, bf16_t>(P, grid, st);
   if (di == SP_F32 && dout == SP_F32) return launch_conv<NT, MT, 2, float, float>(P, grid, st);
   if (di == SP_BF16 && dout == SP_F32) return launch_conv<NT, MT, 1, bf16_t, float>(P, grid, st);
+  if (di == SP_HL && dout == SP_HL) return launch_conv<NT, MT, 2, sp_hl_t, sp_hl_t>(P, grid, st);      // bf16 pairs: hi / lo go to LDS as they are
   sp_set_error("sp_conv3d_igemm: unsupported dtype pair in=%d out=%d", di, dout);
   return SP_EINVAL;
 }
@@ -441,20 +461,24 @@ static int conv_check_build(const sp_conv_args* a, ConvDev& P) {
   SP_CHECK_ARG(a->TD * a->TH == 4 * a->MT, "sp_conv3d_igemm: TD*TH (%d*%d) must equal 4*MT (%d)", a->TD, a->TH, 4 * a->MT);
   SP_CHECK_ARG(a->NTtot % a->NT == 0, "sp_conv3d_igemm: NTtot %d not a multiple of NT %d", a->NTtot, a->NT);
   SP_CHECK_ARG(a->ngroups * a->octs_per_group * 8 == a->CPi, "sp_conv3d_igemm: groups (%d x %d octets) do not cover CPi=%d", a->ngroups, a->octs_per_group, a->CPi);
-  SP_CHECK_ARG(a->dtype_in != SP_F32 || (a->wfrag_lo && a->lo_offset > 0), "sp_conv3d_igemm: f32 mode needs wfrag_lo and lo_offset");
+  SP_CHECK_ARG(a->dtype_in == SP_BF16 || (a->wfrag_lo && a->lo_offset > 0), "sp_conv3d_igemm: f32 / bf16-pair mode needs wfrag_lo and lo_offset");
+  SP_CHECK_ARG(a->dtype_in != SP_HL || (a->x_lo_delta != 0 && a->x_lo_delta % 16 == 0 && !a->dma), "sp_conv3d_igemm: bf16 pair input needs x_lo_delta (register-staged kernel)");
+  SP_CHECK_ARG(a->dtype_out != SP_HL || (a->y_lo_delta != 0 && a->y_lo_delta % 8 == 0), "sp_conv3d_igemm: bf16 pair output needs y_lo_delta");
   SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_igemm: empty output");
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_igemm: stats_nrep must be a power of two");
   // the staged tile must cover every tap of every output row of the tile
   SP_CHECK_ARG(a->ITW >= 15 * a->sW + 1 && a->ITH >= (a->TH - 1) * a->sH + 1 && a->ITD >= (a->TD - 1) * a->sD + 1, "sp_conv3d_igemm: input tile smaller than output tile");
   {
     const int planes = (a->octs_per_group + a->opp - 1) / a->opp;
-    const long tile_bytes = (long)planes * a->plane_bytes * (a->dtype_in == SP_F32 ? 2 : 1);
+    const long tile_bytes = (long)planes * a->plane_bytes * (a->dtype_in != SP_BF16 ? 2 : 1);
     const long need = ((a->steps_per_group * 16 + 15) & ~15) + tile_bytes;
     SP_CHECK_ARG(a->plane_bytes >= a->ITD * a->ITH * a->ITW * a->vsb && need <= a->lds_bytes && a->lds_bytes <= 160 * 1024,
                  "sp_conv3d_igemm: LDS plan inconsistent (need %ld, lds_bytes %d)", need, a->lds_bytes);
     SP_CHECK_ARG(a->lds_bytes >= a->NT * 16 * 2 * 4, "sp_conv3d_igemm: LDS too small for the reduction");
   }
   SP_CHECK_ARG(a->stats_mode == 0 || (a->dma && a->aux), "sp_conv3d_igemm: stats_mode 1 needs the DMA kernel and aux");
+  SP_CHECK_ARG(a->x_plane == 0 || a->dma || (a->CPi % 16 == 0 && a->x_plane >= (int64_t)a->B * a->Di * a->Hi * a->Wi * 16),
+               "sp_conv3d_igemm: plane-major input needs whole 16-channel planes (x_plane >= one plane)");
   P.a = *a;
   P.d_octs = make_fastdiv(a->octs_per_group);
   P.d_itw = make_fastdiv(a->ITW);

@@ -108,18 +108,25 @@ template <> struct ZmStore<float> {
 // ACT: 1 = bias + LeakyReLU / identity in the epilogue (forward layers), 2 = bias + ELU (the CAE's layers, Cae3D.py:41-70), 0 = the
 // accumulator is stored as it is (data gradients).
 // Q8: the e4m3 plane-major copy of the output is written as well (a.y8: the fp8 forward of the NEXT layer reads it, csrc/sp_conv_zm8.hip).
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, typename TOUT, bool Q8 = false>
+// HL: bf16 PAIR operands (SP_HL, the forward pass of the "bf16x3" precision mode): x = x_hi + x_lo in two tensors, the ring
+// slot holds the P hi planes followed by the P lo planes, the weights come as hi and lo fragments (both in LDS), every product
+// is three MFMAs (w_hi x_hi + w_hi x_lo + w_lo x_hi: ~2^-17 relative, fp32 accumulate) and the epilogue writes the output as a
+// pair again.  Three times the MFMAs on twice the bytes: the 16-channel layers move from the LDS / HBM bound towards the pipe.
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
   constexpr int ITH = NW * MT + 2, ITW = 18;
   constexpr int PCH = ITH * ITW * 2;              // 16-byte chunks of one 16-channel plane
-  constexpr int NCH = P * PCH;
+  constexpr int PP = HL ? 2 * P : P;              // bf16 planes of a ring slot
+  constexpr int NCH = PP * PCH;
+  constexpr int LOFF = P * PCH * 16;              // HL: byte offset of the lo planes inside a slot
+  static_assert(!HL || (WLDS && ACT == 1 && !Q8 && sizeof(TOUT) == 2), "pair instances: LDS weights, bias + LeakyReLU epilogue");
   constexpr int NJ = (NCH + 64 * NW - 1) / (64 * NW);   // DMA instructions per wave and input plane
   constexpr int S = NJ * NW * 1024;               // slot stride in bytes
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
-  constexpr int NS = MT * NT * (Q8 ? 2 : 1);      // store instructions of one epilogue
+  constexpr int NS = MT * NT * ((Q8 || HL) ? 2 : 1);      // store instructions of one epilogue
   static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NS) <= 63, "counted vmcnt does not fit its 6-bit field");
   constexpr int NWF = 3 * KS * NT;                // weight fragments (1 KiB each)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -157,6 +164,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   const unsigned char* wl = lds + WOFF + lane * 16;           // this lane's 16 bytes of fragment 0
   if (WLDS) {
     for (int f = wave; f < NWF; f += NW) sp_dma16(reinterpret_cast<const unsigned char*>(wf) + (size_t)f * 1024 + lane * 16, lds + WOFF + f * 1024);
+    if constexpr (HL) {      // the lo fragments behind the hi ones
+      const unsigned char* wfl = reinterpret_cast<const unsigned char*>(a.wfrag_lo) + (size_t)sl * a.slice_wfrag_stride;
+      for (int f = wave; f < NWF; f += NW) sp_dma16(wfl + (size_t)f * 1024 + lane * 16, lds + WOFF + (NWF + f) * 1024);
+    }
   } else {
 #pragma unroll
     for (int dz = 0; dz < (WLDS ? 0 : 3); ++dz)
@@ -170,12 +181,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   const int xpitch = a.x_plane ? 16 : a.CPi;      // elements per voxel of one plane's row
   uint32_t rel[NJ];
   int crd[NJ];
+  int lom = 0;                                    // HL: chunk j of this lane belongs to a lo plane
+  const int64_t lod = HL ? a.x_lo_delta : 0;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (wave + NW * j) * 64 + lane;
     const bool ok = c < NCH;
     const int cc = ok ? c : 0;
-    const int p = cc / PCH, r = cc - p * PCH;
+    const int pq = cc / PCH, r = cc - pq * PCH;
+    const int p = (HL && pq >= P) ? pq - P : pq;
+    if (HL && pq >= P) lom |= 1 << j;
     const int half = r & 1, vox = r >> 1;
     const int vy = vox / ITW, vx = vox - vy * ITW;
     const uint32_t pl = a.x_plane ? (uint32_t)p * (uint32_t)a.x_plane : (uint32_t)p * 16u;
@@ -230,7 +245,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       pl_dst0 = ring + slot * S + wave * 1024;
     };
     auto plane_dma = [&](int j, bool inloop) {
-      const unsigned char* src = ((pl_mask >> j) & 1) ? pl_src0 + rel[j] : zsrc;      // padding / overhang: the zero page
+      const unsigned char* src = ((pl_mask >> j) & 1) ? pl_src0 + rel[j] + (HL && ((lom >> j) & 1) ? lod : (int64_t)0) : zsrc;      // padding / overhang: the zero page
       unsigned char* dst = pl_dst0 + (pl_fill ? 0 : j * (NW * 1024));
       if (inloop) sp_dma16_nc(src, dst); else sp_dma16(src, dst);
     };
@@ -242,6 +257,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     TOUT* yout = y_sl + (size_t)b * a.YD * a.YH * a.YW * a.CPo;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)yout, 0, (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)sizeof(TOUT)), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs_lo = __builtin_amdgcn_make_buffer_rsrc(      // HL: the lo halves of the output
+        (void*)(reinterpret_cast<unsigned char*>(yout) + (HL ? a.y_lo_delta : 0)), 0,
+        (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)sizeof(TOUT)), 0x00020000);
     const int ox = ox0 + lv;
     const bool colok = ox < a.Wo;
     // byte offset of (row m, this lane's voxel and channel quad) inside an output plane, or "outside"
@@ -303,7 +321,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           else if (ACT == 2) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = zz > 0.f ? zz : slope * (__expf(zz) - 1.f); } \
           else v[j] = acc[R_][n][m][j];                                                                           \
         }                                                                                                         \
-        ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                                 \
+        if constexpr (HL) {                                                                                       \
+          uint32_t h0_, h1_, l0_, l1_;                                                                            \
+          sp_hl_split4(v, h0_, h1_, l0_, l1_);                                                                    \
+          const zm_u32x2 dh_ = {h0_, h1_}, dl_ = {l0_, l1_};                                                      \
+          __builtin_amdgcn_raw_buffer_store_b64(dh_, yrs, off + (uint32_t)(n * 32), 0, 0);                        \
+          __builtin_amdgcn_raw_buffer_store_b64(dl_, yrs_lo, off + (uint32_t)(n * 32), 0, 0);                     \
+        } else ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                          \
         if constexpr (Q8) {      /* of the STORED 16-bit values: the copy equals sp_quantize_f8 of y bit for bit */     \
           const uint32_t w0_ = zm_pack2(v[0], v[1]), w1_ = zm_pack2(v[2], v[3]);                                  \
           const float r_[4] = {sp_h2f_lo(w0_), sp_h2f_hi(w0_), sp_h2f_lo(w1_), sp_h2f_hi(w1_)};                   \
@@ -321,29 +345,44 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 
     // the activation fragment of row m: one address per K step (slot + this lane's voxel + the step's octet) and the row as
     // an immediate offset of the ds_read
-#define ZM_LDX(dst, s_)                                                                                           \
+#define ZM_LDX(dst, dstl, s_)                                                                                     \
   {                                                                                                               \
     const unsigned char* xa_ = sb + vbase0 + kv[s_];                                                              \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(xa_ + m * (ITW * 32)); \
+    if constexpr (HL) {                                                                                           \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) dstl[m] = *reinterpret_cast<const bf16x8*>(xa_ + LOFF + m * (ITW * 32)); \
+    }                                                                                                             \
   }
-#define ZM_LDW(dst, s_)                                                                                           \
+#define ZM_LDW(dst, dstl, s_)                                                                                     \
   if (WLDS) {                                                                                                     \
     _Pragma("unroll") for (int dz = 0; dz < 3; ++dz)                                                              \
-        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                            \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                          \
             dst[dz][n] = *reinterpret_cast<const bf16x8*>(wl + ((dz * KS + (s_)) * NT + n) * 1024);               \
+            if constexpr (HL) dstl[dz][n] = *reinterpret_cast<const bf16x8*>(wl + (NWF + (dz * KS + (s_)) * NT + n) * 1024); \
+        }                                                                                                         \
   }
 #define ZM_DMA(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KS; j < (((s_) + 1) * NJ) / KS; ++j) plane_dma(j, true);
 #define ZM_W(DZ_, s_, n_, wv) (WLDS ? wv[DZ_][n_] : w[WLDS ? 0 : DZ_][WLDS ? 0 : s_][WLDS ? 0 : n_])
-#define ZM_MMA(R_, DZ_, s_, xv, wv)                                                                               \
+    // HL: the two cross terms follow the hi x hi product into the same accumulator
+#define ZM_MMA_X(R_, DZ_, xv, xvl, wv, wvl)                                                                       \
+          if constexpr (HL) {                                                                                     \
+            acc[R_][n][m] = SP_MFMA16(wv[DZ_][n], xvl[m], acc[R_][n][m], 0, 0, 0);                                \
+            acc[R_][n][m] = SP_MFMA16(wvl[DZ_][n], xv[m], acc[R_][n][m], 0, 0, 0);                                \
+          }
+#define ZM_MMA(R_, DZ_, s_, xv, xvl, wv, wvl)                                                                     \
   _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                  \
-      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
-          acc[R_][n][m] = SP_MFMA16(ZM_W(DZ_, s_, n, wv), xv[m], acc[R_][n][m], 0, 0, 0);
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
+          acc[R_][n][m] = SP_MFMA16(ZM_W(DZ_, s_, n, wv), xv[m], acc[R_][n][m], 0, 0, 0);                         \
+          ZM_MMA_X(R_, DZ_, xv, xvl, wv, wvl)                                                                     \
+      }
     // first contribution to a new output plane: C = 0
-#define ZM_MMA0(R_, DZ_, s_, xv, wv)                                                                              \
+#define ZM_MMA0(R_, DZ_, s_, xv, xvl, wv, wvl)                                                                    \
   _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                  \
-      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
-          acc[R_][n][m] = SP_MFMA16(ZM_W(DZ_, s_, n, wv), xv[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-#define ZM_MMA_D0(R_, s_, xv, wv) if ((s_) == 0) { ZM_MMA0(R_, 0, s_, xv, wv) } else { ZM_MMA(R_, 0, s_, xv, wv) }
+      _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
+          acc[R_][n][m] = SP_MFMA16(ZM_W(DZ_, s_, n, wv), xv[m], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);             \
+          ZM_MMA_X(R_, DZ_, xv, xvl, wv, wvl)                                                                     \
+      }
+#define ZM_MMA_D0(R_, s_, xv, xvl, wv, wvl) if ((s_) == 0) { ZM_MMA0(R_, 0, s_, xv, xvl, wv, wvl) } else { ZM_MMA(R_, 0, s_, xv, xvl, wv, wvl) }
     // One step = one input plane i (phase PH = i mod 4, compile time): taps dz = 0 / 1 / 2 add into the sets PH, PH+3, PH+2
     // (mod 4) of the output planes i, i-1, i-2; set PH+1 holds plane i-3, whose epilogue is issued between this step's MFMAs.
 #define ZM_STEP(PH)                                                                                               \
@@ -369,26 +408,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     const unsigned char* sb = ring + islot * S;                                                                   \
     const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
     const int fz = (i >= 3 && i - 3 < nz) ? z0 + i - 3 : -1;       /* the plane whose epilogue rides in this step */ \
-    bf16x8 x0[MT], x1[MT];                                                                                        \
+    bf16x8 x0[MT], x1[MT], x0l[HL ? MT : 1], x1l[HL ? MT : 1];                                                    \
     bf16x8 wa[WLDS ? 3 : 1][WLDS ? NT : 1], wb[WLDS ? 3 : 1][WLDS ? NT : 1];                                      \
+    bf16x8 wal[HL ? 3 : 1][HL ? NT : 1], wbl[HL ? 3 : 1][HL ? NT : 1];                                            \
     if (v0 && v1 && v2) {                                                                                         \
       ZM_EPILOGUE((PH + 1) % 4, fz)                                                                               \
-      ZM_LDX(x0, 0)                                                                                               \
-      ZM_LDW(wa, 0)                                                                                               \
+      ZM_LDX(x0, x0l, 0)                                                                                          \
+      ZM_LDW(wa, wal, 0)                                                                                          \
       _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
-        if (s + 1 < KS) { if ((s & 1) == 0) { ZM_LDX(x1, s + 1) ZM_LDW(wb, s + 1) } else { ZM_LDX(x0, s + 1) ZM_LDW(wa, s + 1) } } \
-        if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, wa) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x0, wa) ZM_MMA_D0(PH, s, x0, wa) }  \
-        else { ZM_MMA((PH + 2) % 4, 2, s, x1, wb) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x1, wb) ZM_MMA_D0(PH, s, x1, wb) } \
+        if (s + 1 < KS) { if ((s & 1) == 0) { ZM_LDX(x1, x1l, s + 1) ZM_LDW(wb, wbl, s + 1) } else { ZM_LDX(x0, x0l, s + 1) ZM_LDW(wa, wal, s + 1) } } \
+        if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) ZM_MMA_D0(PH, s, x0, x0l, wa, wal) }  \
+        else { ZM_MMA((PH + 2) % 4, 2, s, x1, x1l, wb, wbl) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x1, x1l, wb, wbl) ZM_MMA_D0(PH, s, x1, x1l, wb, wbl) } \
       }                                                                                                           \
     } else {   /* first / last planes of a piece: guarded groups; the epilogue AFTER the loop on purpose -- placed first in */ \
                /* both branches the compiler hoists it out of them, away from the MFMAs it should hide behind */    \
       _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
-        ZM_LDX(x0, s)                                                                                             \
-        ZM_LDW(wa, s)                                                                                             \
+        ZM_LDX(x0, x0l, s)                                                                                        \
+        ZM_LDW(wa, wal, s)                                                                                        \
         ZM_DMA(s)                                                                                                 \
-        if (v2) { ZM_MMA((PH + 2) % 4, 2, s, x0, wa) }                                                            \
-        if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, wa) }                                                            \
-        if (v0) { ZM_MMA_D0(PH, s, x0, wa) }                                                                      \
+        if (v2) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) }                                                  \
+        if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) }                                                  \
+        if (v0) { ZM_MMA_D0(PH, s, x0, x0l, wa, wal) }                                                            \
       }                                                                                                           \
       ZM_EPILOGUE((PH + 1) % 4, fz)                                                                               \
     }                                                                                                             \
@@ -415,6 +455,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #undef ZM_MMA_D0
 #undef ZM_MMA0
 #undef ZM_MMA
+#undef ZM_MMA_X
 #undef ZM_W
 #undef ZM_DMA
 #undef ZM_LDW
@@ -451,14 +492,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, bool HL = false>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
-  constexpr int NCH = P * (NW * MT + 2) * 18 * 2;
+  constexpr int NCH = (HL ? 2 : 1) * P * (NW * MT + 2) * 18 * 2;
   constexpr int NJ = (NCH + 64 * NW - 1) / (64 * NW);
   constexpr int S = NJ * NW * 1024;
-  // ring (+ 1 KiB per wave where the counted-wait filler DMAs land) (+ the weight fragments)
-  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? 3 * KS * NT * 1024 : 0);
+  // ring (+ 1 KiB per wave where the counted-wait filler DMAs land) (+ the weight fragments; pairs: hi and lo)
+  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? (HL ? 2 : 1) * 3 * KS * NT * 1024 : 0);
   static_assert(lds_bytes <= 160 * 1024, "ring + weights do not fit LDS");
   ConvZmDev Q;
   Q.a = *a;
@@ -476,7 +517,11 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
     grid = 8u * (unsigned)a->nslices * (32u / (unsigned)a->nslices);
     SP_CHECK_ARG(planes >= (uint64_t)grid / a->nslices, "sp_conv3d_zm: too few (column, plane) pairs for %d slices in one launch", a->nslices);
   }
-  if (a->dtype_out == SP_F32) {
+  if constexpr (HL) {
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, true>;
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+  } else if (a->dtype_out == SP_F32) {
     if constexpr (ACT == 2) {
       sp_set_error("sp_conv3d_zm: the ELU epilogue is built for bf16 outputs");
       return SP_EINVAL;
@@ -541,9 +586,35 @@ extern "C" int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* 
   return mt ? SP_OK : SP_EINVAL;
 }
 
+// bf16 PAIR instances (dtype_in = dtype_out = SP_HL: the forward convolutions of the "bf16x3" precision mode): twice the planes in
+// the ring and hi + lo weight fragments in LDS, so the tiles are smaller where Cin * Cout grows -- (P, NT) -> (MT, NSLOT, NW);
+// runtime/plan.py (ZM_CONFIGS_HL) must agree (tests/test_cabi.py)
+extern "C" int sp_conv3d_zm_config_hl(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW) {
+  int mt = 0, ns = 3, nw = 8;
+  if (P == 1 && NT == 1) mt = 4;                               // 158 KiB: ring 3 x 40, weights 30
+  else if (P == 1 && NT == 2) mt = 2;                          // 140 KiB: ring 3 x 24, weights 60
+  else if (P == 2 && NT == 1) { mt = 4; ns = 2; nw = 4; }      // 146 KiB: ring 2 x 44, weights 54
+  else if (P == 2 && NT == 2) { mt = 2; ns = 2; nw = 4; }      // 160 KiB: ring 2 x 24, weights 108
+  else if (P == 3 && NT == 1) { mt = 2; ns = 2; nw = 4; }      // 160 KiB: ring 2 x 36, weights 84
+  if (MT) *MT = mt;
+  if (NSLOT) *NSLOT = ns;
+  if (NW) *NW = nw;
+  return mt ? SP_OK : SP_EINVAL;
+}
+
+template <int P, int NT, int MT, int NSLOT, int NW>
+static int launch_zm_hl(const sp_conv_args* a, const void* zeros, hipStream_t st) {
+  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, true, NW, true, 1, true>(a, zeros, st);
+  return launch_zm2<P, NT, MT, NSLOT, true, NW, false, 1, true>(a, zeros, st);
+}
+
 extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && zeros, "sp_conv3d_zm: null pointer");
-  SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr && a->stats_mode == 0, "sp_conv3d_zm: bf16 input, no affine on load, plain statistics");
+  const bool hl = a->dtype_in == SP_HL;
+  SP_CHECK_ARG((a->dtype_in == SP_BF16 || hl) && a->in_scale == nullptr && a->stats_mode == 0, "sp_conv3d_zm: bf16 (or bf16 pair) input, no affine on load, plain statistics");
+  SP_CHECK_ARG(!hl || (a->dtype_out == SP_HL && a->wfrag_lo && a->x_lo_delta != 0 && a->y_lo_delta != 0 && a->x_lo_delta % 16 == 0 && a->y_lo_delta % 8 == 0 &&
+                       (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && a->nslices <= 1),
+               "sp_conv3d_zm: bf16 pairs in -> bf16 pairs out with hi and lo weight fragments, bias + LeakyReLU / identity epilogue");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
   SP_CHECK_ARG(a->group_batch == 0, "sp_conv3d_zm: no BatchNorm groups (run one launch per group)");
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE || a->act == SP_ACT_ELU, "sp_conv3d_zm: LeakyReLU, ELU or identity epilogue");
@@ -557,12 +628,22 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
                           (uint64_t)a->y8_plane >= (uint64_t)a->B * a->YD * a->YH * a->YW * 16),
                "sp_conv3d_zm: y8 needs a dense bf16 output, a positive y8_scale and y8_plane >= one plane of the output");
   const int P = a->CPi / 16;
+  SP_CHECK_ARG(hl || a->dtype_out != SP_HL, "sp_conv3d_zm: a bf16 pair output needs a bf16 pair input");
   // every byte offset the kernel forms must fit 32 bits (per-sample base is 64-bit)
   const uint64_t span = a->x_plane ? (uint64_t)P * (uint64_t)a->x_plane * 2 : (uint64_t)a->Di * a->Hi * a->Wi * a->CPi * 2;
   SP_CHECK_ARG(span < (1ull << 31), "sp_conv3d_zm: input too large for 32-bit offsets");
   SP_CHECK_ARG((uint64_t)a->YD * a->YH * a->YW * a->CPo * 4 < (1ull << 31), "sp_conv3d_zm: output sample too large for a buffer descriptor");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int32_t mt = 0, ns = 0, nw = 0;
+  if (hl) {
+    SP_CHECK_ARG(sp_conv3d_zm_config_hl(P, a->NT, &mt, &ns, &nw) == SP_OK && mt == a->MT, "sp_conv3d_zm: no bf16-pair kernel for P=%d NT=%d MT=%d", P, a->NT, a->MT);
+    if (P == 1 && a->NT == 1) return launch_zm_hl<1, 1, 4, 3, 8>(a, zeros, st);
+    if (P == 1 && a->NT == 2) return launch_zm_hl<1, 2, 2, 3, 8>(a, zeros, st);
+    if (P == 2 && a->NT == 1) return launch_zm_hl<2, 1, 4, 2, 4>(a, zeros, st);
+    if (P == 2 && a->NT == 2) return launch_zm_hl<2, 2, 2, 2, 4>(a, zeros, st);
+    if (P == 3 && a->NT == 1) return launch_zm_hl<3, 1, 2, 2, 4>(a, zeros, st);
+    return SP_EINVAL;
+  }
   SP_CHECK_ARG(sp_conv3d_zm_config(P, a->NT, &mt, &ns, &nw) == SP_OK && mt == a->MT, "sp_conv3d_zm: no kernel for P=%d NT=%d MT=%d", P, a->NT, a->MT);
   // SP_ZM_VARIANT=<digit per (P,NT) class in the order 11 12 13 21 22 31>: tuning knob (tools/bench_conv.py)
   static const char* var_ = getenv("SP_ZM_VARIANT");

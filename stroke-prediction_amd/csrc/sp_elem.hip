@@ -10,6 +10,7 @@
 #include <stdlib.h>
 
 #include "sp_common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------ core
 static thread_local char g_err[512] = "";
@@ -498,7 +499,8 @@ struct Unflat {
 // MaxPool3d(2,2), floor mode (Unet3D.py:39,41)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims di, int CP,
-                                                            OctMap om, double* __restrict__ stats, const SpQ8 q8) {
+                                                            OctMap om, double* __restrict__ stats, const SpQ8 q8,
+                                                            int64_t x_lo = 0, int64_t y_lo = 0) {
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
@@ -522,11 +524,11 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
       for (int k = 0; k < 8; ++k) {
         const int iz = 2 * z + (k >> 2), iy = 2 * yy + ((k >> 1) & 1), ix = 2 * xx + (k & 1);
         float a[8];
-        Store<T>::ld8(x + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, a);
+        ld8x<T>(x + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, x_lo, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], a[j]);
       }
-      Store<T>::st8(y + v * CP + oc * 8, m);
+      st8x<T>(y + v * CP + oc * 8, y_lo, m);
       if (q8.p) sp_q8_store8(q8, v, oc, m);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { part[0][j] += m[j]; part[1][j] += m[j] * m[j]; }
@@ -545,9 +547,25 @@ static int maxpool2_fwd_impl(const void* x, void* y, int32_t dtype, int32_t B, i
   const int64_t nout = (int64_t)B * (D / 2) * (H / 2) * (W / 2);
   const unsigned grid = grid_for(nout, om.vpb * 2);
   const size_t sh = (size_t)CP * 2 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats, q8);
-  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats, q8);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats, q8, (int64_t)0, (int64_t)0);
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats, q8, (int64_t)0, (int64_t)0);
   SP_CHECK_LAUNCH("sp_maxpool2_fwd");
+  return SP_OK;
+}
+// bf16 pairs (SP_HL): x / y are the hi halves, the lo halves x_lo_delta / y_lo_delta bytes behind them; the maximum of the pair
+// VALUES (hi + lo) is written as a pair again, statistics of those values
+extern "C" int sp_maxpool2_fwd_hl(const void* x, int64_t x_lo_delta, void* y, int64_t y_lo_delta, int32_t B, int32_t D, int32_t H, int32_t W,
+                                  int32_t CP, double* stats, sp_stream_t stream) {
+  SP_CHECK_ARG(x && y && x_lo_delta && y_lo_delta && x_lo_delta % 16 == 0 && y_lo_delta % 16 == 0 && CP % 8 == 0 && D >= 2 && H >= 2 && W >= 2, "sp_maxpool2_fwd_hl: bad arguments");
+  SP_CHECK_VOX((int64_t)B * D * H * W, "sp_maxpool2_fwd_hl");
+  OctMap om = make_octmap(CP);
+  Dims di{B, D, H, W};
+  const int64_t nout = (int64_t)B * (D / 2) * (H / 2) * (W / 2);
+  const unsigned grid = grid_for(nout, om.vpb * 2);
+  const size_t sh = (size_t)CP * 2 * sizeof(float);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel<sp_hl_t>, dim3(grid), dim3(256), sh, ST(stream), (const sp_hl_t*)x, (sp_hl_t*)y, di, CP, om, stats,
+                     SpQ8{nullptr, 0, 1.f, 0}, x_lo_delta, y_lo_delta);
+  SP_CHECK_LAUNCH("sp_maxpool2_fwd_hl");
   return SP_OK;
 }
 extern "C" int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
@@ -677,7 +695,7 @@ extern "C" int sp_crop_copy(const void* src, void* dst, int32_t dtype, int32_t B
 template <typename T> struct RawOct;
 template <> struct RawOct<bf16_t> {
   uint4 r;
-  __device__ __forceinline__ void load(const bf16_t* p) { r = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void load(const bf16_t* p, int64_t = 0) { r = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void get(float* v) const {
     const uint32_t w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
@@ -686,10 +704,17 @@ template <> struct RawOct<bf16_t> {
 };
 template <> struct RawOct<float> {
   float f[8];
-  __device__ __forceinline__ void load(const float* p) { Store<float>::ld8(p, f); }
+  __device__ __forceinline__ void load(const float* p, int64_t = 0) { Store<float>::ld8(p, f); }
   __device__ __forceinline__ void get(float* v) const {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = f[i];
+  }
+};
+template <> struct RawOct<sp_hl_t> {      // bf16 pair: hi and lo words as loaded
+  uint4 h, l;
+  __device__ __forceinline__ void load(const sp_hl_t* p, int64_t lo_delta) {
+    h = *reinterpret_cast<const uint4*>(p);
+    l = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p) + lo_delta);
   }
 };
 
@@ -708,6 +733,11 @@ __device__ __forceinline__ void raw_get2(const RawOct<float>& r, f2_t* v) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) { f2_t t = {r.f[2 * i], r.f[2 * i + 1]}; v[i] = t; }
 }
+__device__ __forceinline__ void raw_get2(const RawOct<sp_hl_t>& r, f2_t* v) {
+  const uint32_t hw[4] = {r.h.x, r.h.y, r.h.z, r.h.w}, lw[4] = {r.l.x, r.l.y, r.l.z, r.l.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { f2_t t = {sp_h2f_lo(hw[i]) + sp_h2f_lo(lw[i]), sp_h2f_hi(hw[i]) + sp_h2f_hi(lw[i])}; v[i] = t; }
+}
 __device__ __forceinline__ void st8_f2(bf16_t* p, const f2_t* v) {
   uint32_t w[4];
 #pragma unroll
@@ -718,6 +748,12 @@ __device__ __forceinline__ void st8_f2(float* p, const f2_t* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
 }
+// bf16 pair: split and store both halves (the values stay what they are: the statistics see the fp32 values)
+__device__ __forceinline__ void st8_f2_hl(sp_hl_t* p, int64_t lo_delta, const f2_t* v) {
+  const float f[8] = {v[0].x, v[0].y, v[1].x, v[1].y, v[2].x, v[2].y, v[3].x, v[3].y};
+  sp_hl_st8(p, lo_delta, f);
+}
+__device__ __forceinline__ f2_t round_like(const sp_hl_t*, f2_t v) { return v; }
 __device__ __forceinline__ f2_t round_like(const bf16_t*, f2_t v) {      // one packed conversion, two bit operations
   const uint32_t u = sp_pack_bf16x2(v.x, v.y);
   f2_t r = {sp_h2f_lo(u), sp_h2f_hi(u)};
@@ -751,7 +787,7 @@ __device__ __forceinline__ f2_t round_like(const float*, f2_t v) { return v; }
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
                                                          Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane, OctMap om,
-                                                         double* __restrict__ stats) {
+                                                         double* __restrict__ stats, int64_t low_lo = 0, int64_t skip_lo = 0, int64_t cat_lo = 0) {
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
@@ -790,7 +826,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
           for (int dy = 0; dy < 3; ++dy) {
             RawOct<T> r0, r1, r2;
             const T* py = pz + (int64_t)ys[dy] * dl.W * CPu;
-            r0.load(py + (int64_t)xs[0] * CPu); r1.load(py + (int64_t)xs[1] * CPu); r2.load(py + (int64_t)xs[2] * CPu);
+            r0.load(py + (int64_t)xs[0] * CPu, low_lo); r1.load(py + (int64_t)xs[1] * CPu, low_lo); r2.load(py + (int64_t)xs[2] * CPu, low_lo);
             f2_t a0[4], a1[4], a2[4];
             raw_get2(r0, a0); raw_get2(r1, a1); raw_get2(r2, a2);
 #pragma unroll
@@ -816,7 +852,7 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
         for (int q = 0; q < 8; ++q) {
           const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
           RawOct<T> r;
-          r.load(skip + ((((int64_t)b * ds.D + zo + oz) * ds.H + yo + oy) * ds.W + xo + ox) * CPs + (oc - ocu) * 8);
+          r.load(skip + ((((int64_t)b * ds.D + zo + oz) * ds.H + yo + oy) * ds.W + xo + ox) * CPs + (oc - ocu) * 8, skip_lo);
           raw_get2(r, out[q]);
         }
       }
@@ -825,7 +861,8 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
         const int zo = 2 * z + (q >> 2), yo = 2 * yy + ((q >> 1) & 1), xo = 2 * xx + (q & 1);
         const int64_t vo = (((int64_t)b * Do + zo) * Ho + yo) * Wo + xo;
         // cat_plane != 0: plane-major concat buffer [plane][B][D][H][W][16] (dense 16-channel planes for the consumers)
-        st8_f2(cat_plane ? cat + (int64_t)(oc >> 1) * cat_plane + vo * 16 + (oc & 1) * 8 : cat + vo * CPd + oc * 8, out[q]);
+        T* const dst_ = cat_plane ? cat + (int64_t)(oc >> 1) * cat_plane + vo * 16 + (oc & 1) * 8 : cat + vo * CPd + oc * 8;
+        if constexpr (std::is_same<T, sp_hl_t>::value) st8_f2_hl(dst_, cat_lo, out[q]); else st8_f2(dst_, out[q]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const f2_t o = round_like(cat, out[q][j]);
@@ -850,7 +887,8 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const T* __restrict__ lo
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
                                                           Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane,
-                                                          double* __restrict__ stats, const SpQ8 q8) {
+                                                          double* __restrict__ stats, const SpQ8 q8,
+                                                          int64_t low_lo = 0, int64_t skip_lo = 0, int64_t cat_lo = 0) {
   __shared__ float red[4 * 32];
   const int p = blockIdx.y, nup = CPu >> 4;
   const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
@@ -885,7 +923,7 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
         for (int dy = 0; dy < 3; ++dy) {
           const T* row = base + (((int64_t)b * dl.D + zs[dz]) * dl.H + ys[dy]) * dl.W * CPu;
           RawOct<T> ra, rb;
-          ra.load(row + (int64_t)xa * CPu); rb.load(row + (int64_t)xb * CPu);
+          ra.load(row + (int64_t)xa * CPu, low_lo); rb.load(row + (int64_t)xb * CPu, low_lo);
           f2_t a[4], c[4];
           raw_get2(ra, a); raw_get2(rb, c);
 #pragma unroll
@@ -909,14 +947,15 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         RawOct<T> rr;
-        rr.load(base + ((((int64_t)b * ds.D + 2 * zl + (k >> 1) + oz) * ds.H + 2 * yl + (k & 1) + oy) * ds.W + xo + ox) * CPs);
+        rr.load(base + ((((int64_t)b * ds.D + 2 * zl + (k >> 1) + oz) * ds.H + 2 * yl + (k & 1) + oy) * ds.W + xo + ox) * CPs, skip_lo);
         raw_get2(rr, out[k]);
       }
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t vo = (((int64_t)b * Do + 2 * zl + (k >> 1)) * Ho + 2 * yl + (k & 1)) * Wo + xo;
-      if (cp) st8_f2_rounded(cp + vo * 16, out[k]);
+      if constexpr (std::is_same<T, sp_hl_t>::value) { if (cp) st8_f2_hl(cp + vo * 16, cat_lo, out[k]); }
+      else if (cp) st8_f2_rounded(cp + vo * 16, out[k]);
       if (q8.p) {
         float o8[8];
 #pragma unroll
@@ -948,7 +987,10 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
 
 static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                       int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
-                      int32_t Ws, int64_t cat_plane, double* stats, SpQ8 q8, sp_stream_t stream) {
+                      int32_t Ws, int64_t cat_plane, double* stats, SpQ8 q8, sp_stream_t stream, const int64_t* hl_lo = nullptr) {
+  static const int64_t no_lo_[3] = {0, 0, 0};
+  SP_CHECK_ARG(dtype != SP_HL || (hl_lo && hl_lo[0] && hl_lo[1] && hl_lo[2] && !q8.p && cat), "sp_upsample2_crop_cat_fwd_hl: bf16 pairs need the three lo deltas");
+  if (!hl_lo) hl_lo = no_lo_;
   // cat == NULL: only the fp8 copy (and the statistics) are wanted -- rows kernel only
   SP_CHECK_ARG(low && skip && (cat || q8.p) && CPu % 8 == 0 && CPs % 8 == 0 && CPd == CPu + CPs, "sp_upsample2_crop_cat_fwd: bad channels");
   SP_CHECK_ARG(cat || (cat_plane && CPu % 16 == 0 && CPs % 16 == 0 && (int64_t)B * D * H * W * 4 < (1ll << 31) && !getenv("SP_UPCAT_BLOCKS")),
@@ -965,8 +1007,9 @@ static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CP
     const unsigned gx = (unsigned)(want < cap ? want : cap);
     dim3 grid(gx, CPd / 16);
     SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && q8.plane >= (int64_t)B * D * H * W * 8 * 16 && q8.scale > 0.f), "sp_upsample2_crop_cat_fwd_q8: bf16 tensors only");
-    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats, q8);
-    else hipLaunchKernelGGL(upcat_rows_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, stats, q8);
+    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0);
+    else if (dtype == SP_HL) hipLaunchKernelGGL(upcat_rows_kernel<sp_hl_t>, grid, dim3(256), 0, ST(stream), (const sp_hl_t*)low, dl, CPu, (const sp_hl_t*)skip, ds, CPs, (sp_hl_t*)cat, CPd, cat_plane, stats, q8, hl_lo[0], hl_lo[1], hl_lo[2]);
+    else hipLaunchKernelGGL(upcat_rows_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0);
     SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd(rows)");
     return SP_OK;
   }
@@ -974,8 +1017,9 @@ static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CP
   const int64_t nblk = (int64_t)B * D * H * W;          // one thread-slot per 2x2x2 output block
   const unsigned grid = grid_for(nblk, om.vpb);
   const size_t sh = (size_t)CPd * 2 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, om, stats);
-  else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, om, stats);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, om, stats, (int64_t)0, (int64_t)0, (int64_t)0);
+  else if (dtype == SP_HL) hipLaunchKernelGGL(upcat_fwd_kernel<sp_hl_t>, dim3(grid), dim3(256), sh, ST(stream), (const sp_hl_t*)low, dl, CPu, (const sp_hl_t*)skip, ds, CPs, (sp_hl_t*)cat, CPd, cat_plane, om, stats, hl_lo[0], hl_lo[1], hl_lo[2]);
+  else hipLaunchKernelGGL(upcat_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, om, stats, (int64_t)0, (int64_t)0, (int64_t)0);
   SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd");
   return SP_OK;
 }
@@ -983,6 +1027,15 @@ extern "C" int sp_upsample2_crop_cat_fwd(const void* low, int32_t CPu, const voi
                                          int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
                                          int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream) {
   return upcat_impl(low, CPu, skip, CPs, cat, CPd, dtype, B, D, H, W, Ds, Hs, Ws, cat_plane, stats, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+// bf16 pairs (SP_HL): low / skip / cat are the hi halves of pair tensors, their lo halves *_lo_delta bytes behind them; the
+// interpolation runs on the pair values in fp32 and the result is split again (cat_plane: in ELEMENTS of one half, as above)
+extern "C" int sp_upsample2_crop_cat_fwd_hl(const void* low, int64_t low_lo_delta, int32_t CPu, const void* skip, int64_t skip_lo_delta, int32_t CPs,
+                                            void* cat, int64_t cat_lo_delta, int32_t CPd, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds,
+                                            int32_t Hs, int32_t Ws, int64_t cat_plane, double* stats, sp_stream_t stream) {
+  const int64_t lo[3] = {low_lo_delta, skip_lo_delta, cat_lo_delta};
+  SP_CHECK_ARG(low_lo_delta % 16 == 0 && skip_lo_delta % 16 == 0 && cat_lo_delta % 16 == 0, "sp_upsample2_crop_cat_fwd_hl: lo halves must be 16-byte aligned");
+  return upcat_impl(low, CPu, skip, CPs, cat, CPd, SP_HL, B, D, H, W, Ds, Hs, Ws, cat_plane, stats, SpQ8{nullptr, 0, 1.f, 0}, stream, lo);
 }
 extern "C" int sp_upsample2_crop_cat_fwd_q8(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                                             int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,

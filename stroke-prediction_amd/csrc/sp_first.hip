@@ -80,14 +80,16 @@ __device__ __forceinline__ void first_load_x(const FirstDev& P, int b, int oz0, 
     }
   }
 }
-template <bool INTERLEAVED>
+template <bool INTERLEAVED, bool HL = false>
 __device__ __forceinline__ void first_store_x(const float (&r)[FT_XIT][2], uint32_t* xt) {
 #pragma unroll
   for (int it = 0; it < FT_XIT; ++it) {
     const int i = threadIdx.x + it * 256;
     if (i < FT_ROWS * FT_XP) {
       if (INTERLEAVED) {
-        xt[i] = sp_pack_bf16x2(r[it][0], r[it][1]);
+        const uint32_t h = sp_pack_bf16x2(r[it][0], r[it][1]);
+        xt[i] = h;
+        if (HL) xt[FT_ROWS * FT_XP + i] = sp_pack_bf16x2(r[it][0] - sp_h2f_lo(h), r[it][1] - sp_h2f_hi(h));      // the lo tile behind the hi tile
       } else {
         bf16_t* pl = reinterpret_cast<bf16_t*>(xt);
         pl[i] = f2bf(r[it][0]);
@@ -99,10 +101,13 @@ __device__ __forceinline__ void first_store_x(const float (&r)[FT_XIT][2], uint3
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ input statistics
+// ROUND: values rounded to the 16-bit storage type first (the bf16 convolution consumes the rounded input); false: as they are
+// (the bf16-pair first layer splits the fp32 input into hi + lo and consumes ~17 bits of it)
+template <bool ROUND> __device__ __forceinline__ float first_rnd(float v) { return ROUND ? bf2f(f2bf(v)) : v; }
+template <bool ROUND>
 __global__ __launch_bounds__(256) void bn_stats_ncdhw_kernel(const float* __restrict__ x, int C, int64_t DHW, int CP,
                                                               double* __restrict__ sums, int nrep, int chunks) {
-  // grid (chunks, B*C): one contiguous chunk of one (b, c) plane per workgroup; values rounded to bf16 first (the
-  // convolution consumes the rounded input)
+  // grid (chunks, B*C): one contiguous chunk of one (b, c) plane per workgroup
   const int bc = blockIdx.y, c = bc % C;
   const float* p = x + (size_t)bc * DHW;
   const int64_t per = (DHW + chunks - 1) / chunks, i0 = (int64_t)blockIdx.x * per, i1 = min(DHW, i0 + per);
@@ -118,25 +123,25 @@ __global__ __launch_bounds__(256) void bn_stats_ncdhw_kernel(const float* __rest
       for (int u = 0; u < 4; ++u) q[u] = p4[i + 256 * u];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float v0 = bf2f(f2bf(q[u].x)), v1 = bf2f(f2bf(q[u].y)), v2 = bf2f(f2bf(q[u].z)), v3 = bf2f(f2bf(q[u].w));
+        const float v0 = first_rnd<ROUND>(q[u].x), v1 = first_rnd<ROUND>(q[u].y), v2 = first_rnd<ROUND>(q[u].z), v3 = first_rnd<ROUND>(q[u].w);
         a1[u] += (v0 + v1) + (v2 + v3);
         a2[u] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, a2[u]))));
       }
     }
     for (; i < n4; i += 256) {
       const float4 q = p4[i];
-      const float v0 = bf2f(f2bf(q.x)), v1 = bf2f(f2bf(q.y)), v2 = bf2f(f2bf(q.z)), v3 = bf2f(f2bf(q.w));
+      const float v0 = first_rnd<ROUND>(q.x), v1 = first_rnd<ROUND>(q.y), v2 = first_rnd<ROUND>(q.z), v3 = first_rnd<ROUND>(q.w);
       a1[0] += (v0 + v1) + (v2 + v3);
       a2[0] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, a2[0]))));
     }
     for (int64_t j = i0 + 4 * n4 + threadIdx.x; j < i1; j += 256) {
-      const float v = bf2f(f2bf(p[j]));
+      const float v = first_rnd<ROUND>(p[j]);
       a1[1] += v; a2[1] = fmaf(v, v, a2[1]);
     }
     s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]); s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
   } else {
     for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
-      const float v = bf2f(f2bf(p[i]));
+      const float v = first_rnd<ROUND>(p[i]);
       s1 += v; s2 = fmaf(v, v, s2);
     }
   }
@@ -151,21 +156,31 @@ __global__ __launch_bounds__(256) void bn_stats_ncdhw_kernel(const float* __rest
   }
 }
 
-extern "C" int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums,
-                                 int32_t nrep, sp_stream_t stream) {
+static int bn_stats_ncdhw_impl(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums, int32_t nrep, bool round,
+                               sp_stream_t stream) {
   SP_CHECK_ARG(x && sums && B >= 1 && C >= 1 && C <= CP && DHW >= 1 && nrep >= 1, "sp_bn_stats_ncdhw: bad arguments");
   int chunks = (int)((DHW + 8191) / 8192);          // ~2048 workgroups at B*C = 8, 128^3
   if (chunks > 1024) chunks = 1024;
-  hipLaunchKernelGGL(bn_stats_ncdhw_kernel, dim3(chunks, B * C), dim3(256), 0, ST(stream), x, C, DHW, CP, sums, nrep, chunks);
+  if (round) hipLaunchKernelGGL(bn_stats_ncdhw_kernel<true>, dim3(chunks, B * C), dim3(256), 0, ST(stream), x, C, DHW, CP, sums, nrep, chunks);
+  else hipLaunchKernelGGL(bn_stats_ncdhw_kernel<false>, dim3(chunks, B * C), dim3(256), 0, ST(stream), x, C, DHW, CP, sums, nrep, chunks);
   SP_CHECK_LAUNCH("sp_bn_stats_ncdhw");
   return SP_OK;
+}
+extern "C" int sp_bn_stats_ncdhw(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums,
+                                 int32_t nrep, sp_stream_t stream) {
+  return bn_stats_ncdhw_impl(x, B, C, DHW, CP, sums, nrep, true, stream);
+}
+extern "C" int sp_bn_stats_ncdhw_f32(const float* x, int32_t B, int32_t C, int64_t DHW, int32_t CP, double* sums,
+                                     int32_t nrep, sp_stream_t stream) {
+  return bn_stats_ncdhw_impl(x, B, C, DHW, CP, sums, nrep, false, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ weights
 // A fragment of MFMA step s (0..2), lane l: row co = l % 16, K slice j = l / 16 -> group g = 4s + j = (dz, dy),
 // elements e = 0..7 = (dx = e / 2, c = e % 2);  W' = W * scale[c],  b' = b + sum W * shift[c]
 __global__ void first_prep_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
-                                  const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f, int Cout) {
+                                  const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f, int Cout,
+                                  bf16_t* __restrict__ wfrag_lo) {
   const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes; blockIdx.x = output tile of 16 rows
   // Cout = 32: tile t, row r holds channel (r / 4) * 8 + 4 t + r % 4 -- a lane of the forward kernel (rows 4 lg .. 4 lg + 3 of
   // both tiles) then owns EIGHT consecutive channels of its voxel and stores them with one 16-byte instruction
@@ -176,7 +191,9 @@ __global__ void first_prep_kernel(const float* __restrict__ w, const float* __re
     const int dx = e >> 1, c = e & 1;
     float v = 0.f;
     if (g < 9 && dx < 3 && co < Cout) v = w[(co * 2 + c) * 27 + g * 3 + dx] * (scale ? scale[c] : 1.f);
-    wfrag[((size_t)blockIdx.x * 192 + t) * 8 + e] = f2bf(v);
+    const bf16_t hv = f2bf(v);
+    wfrag[((size_t)blockIdx.x * 192 + t) * 8 + e] = hv;
+    if (wfrag_lo) wfrag_lo[((size_t)blockIdx.x * 192 + t) * 8 + e] = f2bf(v - bf2f(hv));      // (bf16 pair: w = hi + lo)
   }
   if (t < 16 && blockIdx.x == 0)
     for (int cb = t; cb < Cout; cb += 16) {      // (natural channel order)
@@ -194,8 +211,15 @@ extern "C" int sp_first_supported(int32_t Cin, int32_t Cout, int32_t k) { return
 extern "C" int sp_first_prep_n(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
                                float* bias_f, int32_t Cout, sp_stream_t stream) {
   SP_CHECK_ARG(w && wfrag && bias_f && (Cout == 16 || Cout == 32), "sp_first_prep: null pointer / 16 or 32 output channels");
-  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f, Cout);
+  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f, Cout, (bf16_t*)nullptr);
   SP_CHECK_LAUNCH("sp_first_prep");
+  return SP_OK;
+}
+extern "C" int sp_first_prep_hl(const float* w, const float* b, const float* scale, const float* shift, void* wfrag_hi, void* wfrag_lo,
+                                float* bias_f, int32_t Cout, sp_stream_t stream) {
+  SP_CHECK_ARG(w && wfrag_hi && wfrag_lo && bias_f && (Cout == 16 || Cout == 32), "sp_first_prep_hl: null pointer / 16 or 32 output channels");
+  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag_hi, bias_f, Cout, (bf16_t*)wfrag_lo);
+  SP_CHECK_LAUNCH("sp_first_prep_hl");
   return SP_OK;
 }
 extern "C" int sp_first_prep(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
@@ -206,20 +230,26 @@ extern "C" int sp_first_prep(const float* w, const float* b, const float* scale,
 // ------------------------------------------------------------------------------------------------ forward
 // NT output tiles of 16 channels (y rows of 16 NT channels); y8 != NULL: also the e4m3 plane-major copy of y
 // ([NT][B][Do][Ho][Wo][16 bytes], the operand of an fp8 second layer -- csrc/sp_conv_zm8.hip), rounded from the stored value.
-template <int NT>
+// HL: the bf16-pair form (SP_HL output, the "bf16x3" precision mode): the fp32 input is split into hi + lo bf16 tiles, the weights
+// come as hi + lo fragments, every product is three MFMAs and y is written as a pair (y, y_lo); statistics of the fp32 values.
+template <int NT, bool HL = false>
 __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const bf16x8* __restrict__ wfrag,
                                                          const float* __restrict__ bias, int act, float ap,
                                                          bf16_t* __restrict__ y, double* __restrict__ stats, int nrep,
-                                                         unsigned char* __restrict__ y8, int64_t y8_plane) {
-  __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];
+                                                         unsigned char* __restrict__ y8, int64_t y8_plane,
+                                                         const bf16x8* __restrict__ wfrag_lo = nullptr, bf16_t* __restrict__ y_lo = nullptr) {
+  __shared__ __attribute__((aligned(16))) uint32_t xt[(HL ? 2 : 1) * FT_ROWS * FT_XP];
   __shared__ float red[4 * 32 * NT];      // [wave][column]: added up in wave order (sp_cols_sum)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lg = lane >> 4, n = lane & 15;
-  bf16x8 af[NT][3];
+  bf16x8 af[NT][3], afl[HL ? NT : 1][3];
   int goff[3];
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) af[nt][s] = wfrag[(nt * 3 + s) * 64 + lane];
+    for (int nt = 0; nt < NT; ++nt) {
+      af[nt][s] = wfrag[(nt * 3 + s) * 64 + lane];
+      if (HL) afl[nt][s] = wfrag_lo[(nt * 3 + s) * 64 + lane];
+    }
     const int g = min(4 * s + lg, 8);                       // groups 9..11 carry zero weights: any finite data will do
     goff[s] = ((g / 3) * FT_XY + (g % 3)) * FT_XP;
   }
@@ -244,7 +274,7 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
     int b, oz0, oy0, ox0;
     first_decode(P, tile, b, oz0, oy0, ox0);
     __syncthreads();                                        // the previous tile has been consumed
-    first_store_x<true>(xr, xt);
+    first_store_x<true, HL>(xr, xt);
     __syncthreads();
     if (tile + gridDim.x < P.ntiles) {                      // next tile's input: in flight during this tile's MFMAs and stores
       int b2, oz2, oy2, ox2;
@@ -261,34 +291,51 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
       bf16_t* yrow = y + vrow * (16 * NT) + lg * CQ;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        union { uint32_t u[4]; bf16x8 v; } bq[3];
+        union { uint32_t u[4]; bf16x8 v; } bq[3], bql[HL ? 3 : 1];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
           const uint32_t* p = xt + goff[s] + rbase + t * 16;
           bq[s].u[0] = p[0]; bq[s].u[1] = p[1]; bq[s].u[2] = p[2]; bq[s].u[3] = p[3];
+          if (HL) { const uint32_t* pl = p + FT_ROWS * FT_XP; bql[s].u[0] = pl[0]; bql[s].u[1] = pl[1]; bql[s].u[2] = pl[2]; bql[s].u[3] = pl[3]; }
         }
         const int ox = ox0 + t * 16 + n;
         float q[NT][4];
-        uint32_t w2[NT][2];
+        uint32_t w2[NT][2], w2l[NT][2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int s = 0; s < 3; ++s) acc = SP_MFMA16(af[nt][s], bq[s].v, acc, 0, 0, 0);
+          for (int s = 0; s < 3; ++s) {
+            acc = SP_MFMA16(af[nt][s], bq[s].v, acc, 0, 0, 0);
+            if (HL) {
+              acc = SP_MFMA16(af[nt][s], bql[s].v, acc, 0, 0, 0);
+              acc = SP_MFMA16(afl[nt][s], bq[s].v, acc, 0, 0, 0);
+            }
+          }
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float z = acc[j] + bj[nt][j];
             v[j] = lin ? fmaxf(z, slope * z) : act_fwd(act, ap, z);
           }
-          w2[nt][0] = sp_pack_bf16x2(v[0], v[1]); w2[nt][1] = sp_pack_bf16x2(v[2], v[3]);
-          q[nt][0] = sp_h2f_lo(w2[nt][0]); q[nt][1] = sp_h2f_hi(w2[nt][0]);      // statistics (and the e4m3 copy) of what is stored
-          q[nt][2] = sp_h2f_lo(w2[nt][1]); q[nt][3] = sp_h2f_hi(w2[nt][1]);
+          if (HL) {
+            sp_hl_split4(v, w2[nt][0], w2[nt][1], w2l[nt][0], w2l[nt][1]);
+            q[nt][0] = v[0]; q[nt][1] = v[1]; q[nt][2] = v[2]; q[nt][3] = v[3];      // statistics of the fp32 values
+          } else {
+            w2[nt][0] = sp_pack_bf16x2(v[0], v[1]); w2[nt][1] = sp_pack_bf16x2(v[2], v[3]);
+            q[nt][0] = sp_h2f_lo(w2[nt][0]); q[nt][1] = sp_h2f_hi(w2[nt][0]);      // statistics (and the e4m3 copy) of what is stored
+            q[nt][2] = sp_h2f_lo(w2[nt][1]); q[nt][3] = sp_h2f_hi(w2[nt][1]);
+          }
         }
         if (rok && ox < P.Wo) {
           bf16_t* yp = yrow + (size_t)ox * (16 * NT);
           if (NT == 2) *reinterpret_cast<uint4*>(yp) = make_uint4(w2[0][0], w2[0][1], w2[NT - 1][0], w2[NT - 1][1]);
           else *reinterpret_cast<uint2*>(yp) = make_uint2(w2[0][0], w2[0][1]);
+          if (HL) {
+            bf16_t* ypl = y_lo + vrow * (16 * NT) + lg * CQ + (size_t)ox * (16 * NT);
+            if (NT == 2) *reinterpret_cast<uint4*>(ypl) = make_uint4(w2l[0][0], w2l[0][1], w2l[NT - 1][0], w2l[NT - 1][1]);
+            else *reinterpret_cast<uint2*>(ypl) = make_uint2(w2l[0][0], w2l[0][1]);
+          }
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -344,12 +391,31 @@ extern "C" int sp_first_conv_fwd_n(const float* x, int32_t B, int32_t D, int32_t
   static const unsigned cap_ = getenv("SP_FIRST_BLOCKS") ? (unsigned)atoi(getenv("SP_FIRST_BLOCKS")) : 2048u;
   const unsigned grid = P.ntiles < cap_ ? P.ntiles : cap_;
   if (Cout == 16)
-    hipLaunchKernelGGL(first_fwd_kernel<1>, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
-                       (bf16_t*)y, stats, nrep, (unsigned char*)y8, y8_plane);
+    hipLaunchKernelGGL((first_fwd_kernel<1, false>), dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
+                       (bf16_t*)y, stats, nrep, (unsigned char*)y8, y8_plane, (const bf16x8*)nullptr, (bf16_t*)nullptr);
   else
-    hipLaunchKernelGGL(first_fwd_kernel<2>, dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
-                       (bf16_t*)y, stats, nrep, (unsigned char*)y8, y8_plane);
+    hipLaunchKernelGGL((first_fwd_kernel<2, false>), dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag, bias_f, act, act_param,
+                       (bf16_t*)y, stats, nrep, (unsigned char*)y8, y8_plane, (const bf16x8*)nullptr, (bf16_t*)nullptr);
   SP_CHECK_LAUNCH("sp_first_conv_fwd");
+  return SP_OK;
+}
+// the bf16-pair form: y / y_lo = hi / lo halves of the output (SP_HL), weights as hi + lo fragments from sp_first_prep_hl
+extern "C" int sp_first_conv_fwd_hl(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag_hi, const void* wfrag_lo,
+                                    const float* bias_f, int32_t act, float act_param, void* y, void* y_lo, double* stats, int32_t nrep,
+                                    int32_t Cout, sp_stream_t stream) {
+  SP_CHECK_ARG(x && wfrag_hi && wfrag_lo && bias_f && y && y_lo && B >= 1 && D >= 3 && H >= 3 && W >= 3 && (Cout == 16 || Cout == 32), "sp_first_conv_fwd_hl: bad arguments");
+  SP_CHECK_ARG(!stats || nrep >= 1, "sp_first_conv_fwd_hl: stats replicas");
+  FirstDev P;
+  SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_conv_fwd_hl: too many tiles");
+  static const unsigned cap_ = getenv("SP_FIRST_BLOCKS") ? (unsigned)atoi(getenv("SP_FIRST_BLOCKS")) : 2048u;
+  const unsigned grid = P.ntiles < cap_ ? P.ntiles : cap_;
+  if (Cout == 16)
+    hipLaunchKernelGGL((first_fwd_kernel<1, true>), dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag_hi, bias_f, act, act_param,
+                       (bf16_t*)y, stats, nrep, (unsigned char*)nullptr, (int64_t)0, (const bf16x8*)wfrag_lo, (bf16_t*)y_lo);
+  else
+    hipLaunchKernelGGL((first_fwd_kernel<2, true>), dim3(grid), dim3(256), 0, ST(stream), P, (const bf16x8*)wfrag_hi, bias_f, act, act_param,
+                       (bf16_t*)y, stats, nrep, (unsigned char*)nullptr, (int64_t)0, (const bf16x8*)wfrag_lo, (bf16_t*)y_lo);
+  SP_CHECK_LAUNCH("sp_first_conv_fwd_hl");
   return SP_OK;
 }
 extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag,

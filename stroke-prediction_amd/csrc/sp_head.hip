@@ -23,13 +23,13 @@ template <int C, int CH, int NC, typename T>
 __global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, int64_t nvox_per_b, int64_t total, int CP,
                                                         const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
-                                                        float slope, float* __restrict__ seg) {
+                                                        float slope, float* __restrict__ seg, int64_t x_lo = 0) {
   // weights are read at wave-uniform addresses through the constant address space: s_load into SGPR operands
   cfloat *cw1 = (cfloat*)w1, *cb1 = (cfloat*)b1, *cw2 = (cfloat*)w2, *cb2 = (cfloat*)b2;
   for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < total; v += (int64_t)gridDim.x * 256) {
     float xv[C];
 #pragma unroll
-    for (int c = 0; c < C; c += 8) Store<T>::ld8(x + v * CP + c, xv + c);
+    for (int c = 0; c < C; c += 8) ld8x<T>(x + v * CP + c, x_lo, xv + c);
     float o[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) o[c] = cb2[c];
@@ -556,11 +556,29 @@ extern "C" int sp_head_fwd(const void* x, int32_t dtype, int64_t nvox_per_b, int
 #define X(c, h, n)                                                                                                   \
   if (C == c && CH == h && NC == n) {                                                                                \
     if (dtype == SP_BF16) hipLaunchKernelGGL((head_fwd_mfma_kernel<h, n>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg); \
-    else hipLaunchKernelGGL((head_fwd_kernel<c, h, n, float>), dim3(grid), dim3(256), 0, st, (const float*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg); \
+    else hipLaunchKernelGGL((head_fwd_kernel<c, h, n, float>), dim3(grid), dim3(256), 0, st, (const float*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg, (int64_t)0); \
   }
   HEAD_CASES(X)
 #undef X
   SP_CHECK_LAUNCH("sp_head_fwd");
+  return SP_OK;
+}
+// bf16 pairs (SP_HL): x = the hi halves of the last block's output, its lo halves x_lo_delta bytes behind; fp32 arithmetic on
+// the pair values (the VALU kernel: 16 input channels only)
+extern "C" int sp_head_fwd_hl(const void* x, int64_t x_lo_delta, int64_t nvox_per_b, int32_t B, int32_t CP, int32_t C, const float* w1,
+                              const float* b1, int32_t CH, const float* w2, const float* b2, int32_t NC, float slope,
+                              float* seg, sp_stream_t stream) {
+  SP_CHECK_ARG(x && x_lo_delta && x_lo_delta % 16 == 0 && w1 && b1 && w2 && b2 && seg && CP >= C && CP % 8 == 0, "sp_head_fwd_hl: bad arguments");
+  SP_CHECK_ARG((int64_t)B * nvox_per_b < (1ll << 31), "sp_head_fwd_hl: 2^31 voxels or more");
+  SP_CHECK_ARG(sp_head_supported(C, CH, NC), "sp_head_fwd_hl: no fused kernel for C=%d CH=%d NC=%d", C, CH, NC);
+  const int64_t total = (int64_t)B * nvox_per_b;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define X(c, h, n)                                                                                                   \
+  if (C == c && CH == h && NC == n) hipLaunchKernelGGL((head_fwd_kernel<c, h, n, sp_hl_t>), dim3(grid), dim3(256), 0, st, (const sp_hl_t*)x, nvox_per_b, total, CP, w1, b1, w2, b2, slope, seg, x_lo_delta);
+  HEAD_CASES(X)
+#undef X
+  SP_CHECK_LAUNCH("sp_head_fwd_hl");
   return SP_OK;
 }
 

@@ -57,13 +57,18 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8, groups=1):
-        """groups > 1 (the batched passes of the CAE, runtime/cae_engine.py): the batch holds `groups` passes of batch // groups
+                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8, groups=1, hl=False):
+        """hl (the "bf16x3" precision mode): the FORWARD convolution takes and writes bf16 pairs (SP_HL: x = x_hi + x_lo in two
+        tensors, three MFMAs per product); ``self.y`` is the hi half -- the tensor the bf16 mode would have stored -- and the
+        backward side below is the bf16 one on the hi tensors, unchanged.
+        groups > 1 (the batched passes of the CAE, runtime/cae_engine.py): the batch holds `groups` passes of batch // groups
         samples each; every pass is its own BatchNorm group (own batch statistics, own scale / shift / backward coefficients),
         the convolution, its weight gradient and its data gradient run ONCE over the whole batch.  The normalised input is
         always written out per group (``xhat``), so no kernel needs an affine on its operand load and the weights never
         depend on a pass."""
         self.G = int(groups)
+        self.hl = bool(hl)
+        assert not hl or (dtype == L.SP_BF16 and kind == "conv" and groups == 1 and bank is None), "bf16 pairs: un-batched bf16-storage convolutions"
         assert batch % self.G == 0
         self.gb = batch // self.G
         self.name, self.kind = name, kind
@@ -78,14 +83,15 @@ class ConvLayer:
         # channel pitch of this layer's tensors: multiples of `pitch` (16 lets every 3x3x3 layer use the DMA kernels)
         self.cpi, self.cpo = (cpi or O.cpad(cin, pitch)), O.cpad(cout, pitch)
         mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
-        self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, dtype)
+        self.fwd_op = mk(cin, cout, k, stride, pad, in_dims, self.cpi, self.cpo, L.SP_HL if hl else dtype)
         self.out_dims = tuple(self.fwd_op.y_dims)
         self.bank = bank            # optional dict shared by the layers of all contexts of one stack (packed weights)
         self.count = float(self.gb * in_dims[0] * in_dims[1] * in_dims[2])       # voxels of ONE BatchNorm group
         # un-padded bf16 convolutions fold the BatchNorm into weights/bias so the tile can be staged by DMA
         pads = pad if isinstance(pad, (tuple, list)) else (pad,) * 3
         self.fold = bool(bn_prefix is not None and kind == "conv" and dtype == L.SP_BF16 and max(pads) == 0
-                         and all(s.tile["dma"] for s in self.fwd_op.subs) and self.G == 1)
+                         and (hl or all(s.tile["dma"] for s in self.fwd_op.subs)) and self.G == 1)
+        assert not hl or self.fold or bn_prefix is None, "bf16 pairs: BatchNorm folded into the weights (un-padded convolutions)"
         self.scratch = scratch
         # Padded bf16 convolutions behind a BatchNorm (the CAE): zero padding applies AFTER the normalisation, so the
         # BatchNorm cannot be folded into the weights, and a DMA cannot normalise on load.  The normalised input is
@@ -97,7 +103,10 @@ class ConvLayer:
                                 and self.cpo % 16 == 0 and all(s.tile["dma"] for s in self.fwd_op.subs) and O.MATERIALIZE_BN)
         if self.G > 1:
             self.materialize = bn_prefix is not None        # grouped: xhat = s_g x + t_g for EVERY layer behind a BatchNorm
+        if hl:
+            self.materialize = False
         self.xhat = None
+        self.y_lo = None
         # folded layers run without affine-on-load and with plain statistics: candidates for the z-marching kernel; so do the
         # materialised ones (the kernel pads from its zero page and has an ELU epilogue)
         zm_ok = (self.fold and act in (L.ACT_NONE, L.ACT_LEAKY) and bank is None) or \
@@ -191,7 +200,11 @@ class ConvLayer:
 
     def alloc_out(self):
         if self.y is None:
-            self.y = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.out_dtype, self.device)
+            if self.hl:      # the pair: one allocation, hi half first
+                pair = torch.empty((2, self.batch) + tuple(self.out_dims) + (self.cpo,), dtype=O.TORCH_DT[L.SP_BF16], device=self.device)
+                self.y, self.y_lo = pair[0], pair[1]
+            else:
+                self.y = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.out_dtype, self.device)
         return self.y
 
     def _bn_fwd(self, params, bufs, training):
@@ -214,12 +227,19 @@ class ConvLayer:
         if training and "__nbt_flat__" not in bufs:      # else: one increment for all BatchNorms (UnetEngine.forward)
             bufs[p + ".num_batches_tracked"].add_(1)
 
-    def forward(self, x, params, bufs, training, out_stats=None):
-        """x: channels-last input; returns the (cached) output tensor."""
+    def forward(self, x, params, bufs, training, out_stats=None, x_lo=None):
+        """x: channels-last input (hl: its hi half, x_lo the lo half); returns the (cached) output tensor (hl: its hi half, the
+        lo half is self.y_lo)."""
         if self.bn_prefix is not None:
             self._bn_fwd(params, bufs, training)
         c = self.conv_prefix
         y = self.alloc_out()
+        if self.hl:
+            assert self.fold and x_lo is not None
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
+            self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=L.SP_HL,
+                         stats_nrep=STATS_NREP, x_planar=self.x_planar, x_lo=x_lo, y_lo=self.y_lo)
+            return y
         if self.G > 1:
             src = x
             if self.materialize:
@@ -489,14 +509,15 @@ class FirstConvLayer(ConvLayer):
         assert FirstConvLayer.supported(self.cin, self.cout, self.k, self.stride, self.pad, self.dtype, self.bn_prefix)
         assert self.cpo == self.cout
         self.wfrag = torch.zeros((self.cout // 16) * 3 * 64 * 8, dtype=torch.bfloat16, device=self.device)
+        self.wfrag_lo = torch.zeros_like(self.wfrag) if self.hl else None
         self.bias_f = torch.zeros(self.cout, device=self.device)
         self.flops = 2.0 * self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2] * 27 * self.cin * self.cout
 
     def input_stats(self, images):
         """Batch statistics of the network input for the first BatchNorm (replaces bn_stats on a channels-last copy)."""
         B, Cc = images.shape[:2]
-        L.call("sp_bn_stats_ncdhw", O.ptr(images), B, Cc, images[0, 0].numel(), self.cpi, O.ptr(self.in_sums), STATS_NREP,
-               O.stream())
+        L.call("sp_bn_stats_ncdhw_f32" if self.hl else "sp_bn_stats_ncdhw", O.ptr(images), B, Cc, images[0, 0].numel(), self.cpi,
+               O.ptr(self.in_sums), STATS_NREP, O.stream())
 
     def forward(self, images, params, bufs, training, out_stats=None):
         assert images.dtype == torch.float32 and images.is_contiguous()
@@ -504,9 +525,16 @@ class FirstConvLayer(ConvLayer):
         c = self.conv_prefix
         y = self.alloc_out()
         st = O.stream()
+        D, H, W = self.in_dims
+        if self.hl:      # bf16 pairs: the fp32 input split into hi + lo inside the kernel, hi + lo weight fragments, y as a pair
+            L.call("sp_first_prep_hl", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
+                   O.ptr(self.wfrag), O.ptr(self.wfrag_lo), O.ptr(self.bias_f), self.cout, st)
+            with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first x3" % (self.cin, self.cout, D, H, W)):
+                L.call("sp_first_conv_fwd_hl", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.wfrag_lo), O.ptr(self.bias_f),
+                       self.act, self.act_param, O.ptr(y), O.ptr(self.y_lo), O.ptr(out_stats), STATS_NREP, self.cout, st)
+            return y
         L.call("sp_first_prep_n", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
                O.ptr(self.wfrag), O.ptr(self.bias_f), self.cout, st)
-        D, H, W = self.in_dims
         y8 = self.alloc_y8() if self.want_y8 else None      # (fp8 mode: the e4m3 operand of the second layer)
         with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
             L.call("sp_first_conv_fwd_n", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.bias_f), self.act,

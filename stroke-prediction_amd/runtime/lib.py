@@ -14,14 +14,16 @@ CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_wgrad_f8.hip", "sp_plan.hip", "sp_comm.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
            "sp_transform.hip"]
 
-SP_BF16, SP_F32 = 0, 1
+SP_BF16, SP_F32, SP_HL = 0, 1, 2      # SP_HL: bf16 pair (hi + lo tensors), the forward storage of the "bf16x3" mode
 # precision modes of the models (``Unet3D(dtype=...)``, ``Enc3D(dtype=...)``) -> storage type of the engine's tensors
-DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16, "f16": SP_BF16}
+DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16, "f16": SP_BF16, "bf16x3": SP_BF16}
 #   fp8: bf16 storage + fp8 MFMA operands (runtime/f8.py); f16: IEEE-half storage -- the SAME sources built with
 #   -DSP_HALF_F16 into libstroke_amd_f16.so (csrc/sp_common.h), selected per engine with ``use("f16")``; the kernels'
-#   dtype code stays SP_BF16 = "the 16-bit storage type of this library"
+#   dtype code stays SP_BF16 = "the 16-bit storage type of this library";
+#   bf16x3: the FORWARD activations are bf16 pairs (hi + lo tensors, SP_HL: ~17 bits; three MFMAs per product), the backward
+#   pass is the bf16 one on the hi tensors -- logits within 1e-3 of the fp32 reference at ~1.5x the bf16 step
 VARIANTS = {"": ("libstroke_amd.so", []), "f16": ("libstroke_amd_f16.so", ["-DSP_HALF_F16"])}
-VARIANT_OF = {"bf16": "", "f32": "", "fp8": "", "f16": "f16"}
+VARIANT_OF = {"bf16": "", "f32": "", "fp8": "", "f16": "f16", "bf16x3": ""}
 SP_REDUCE_ROWS = 8    # replica rows of the accumulators the elementwise kernels reduce into (include/stroke_amd.h)
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 
@@ -37,7 +39,7 @@ class ConvArgs(C.Structure):
                    "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32), ("x_plane", i64),
                                                                            ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32),
                                                                            ("group_batch", i32), ("nslices", i32),
-                                                                          ("slice_wfrag_stride", i64)]
+                                                                          ("slice_wfrag_stride", i64), ("x_lo_delta", i64), ("y_lo_delta", i64)]
 
 
 class WgradArgs(C.Structure):
@@ -91,6 +93,13 @@ _SIGS = {
     "sp_conv3d_igemm_multi": ([C.POINTER(ConvArgs), i32, vp], i32),
     "sp_conv3d_zm": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    "sp_conv3d_zm_config_hl": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    "sp_bn_stats_ncdhw_f32": ([vp, i32, i32, i64, i32, vp, i32, vp], i32),
+    "sp_first_prep_hl": ([vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
+    "sp_first_conv_fwd_hl": ([vp, i32, i32, i32, i32, vp, vp, vp, i32, f32, vp, vp, vp, i32, i32, vp], i32),
+    "sp_maxpool2_fwd_hl": ([vp, i64, vp, i64, i32, i32, i32, i32, i32, vp, vp], i32),
+    "sp_upsample2_crop_cat_fwd_hl": ([vp, i64, i32, vp, i64, i32, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, vp], i32),
+    "sp_head_fwd_hl": ([vp, i64, i64, i32, i32, i32, vp, vp, i32, vp, vp, i32, f32, vp, vp], i32),
     "sp_conv3d_zm8": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm8_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
     "sp_conv_prep_f8": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, f32, vp], i32),

