@@ -127,7 +127,7 @@ class Unet3D(FlatParamsMixin, nn.Module):
             variant = _L.VARIANT_OF[self.compute_dtype]
             with _L.use(variant):
                 eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device,
-                                 f8=(self.compute_dtype == "fp8"), variant=variant, hl=(self.compute_dtype == "bf16x3"))
+                                 f8=(self.compute_dtype == "fp8"), variant=variant, hl=(self.compute_dtype in ("bf16x3", "f16x3")))
             self._engines[key] = eng
         return eng
 

@@ -57,7 +57,8 @@ void load_rccl() {
 int need_rccl(const char* what) {
   std::call_once(g_once, load_rccl);
   if (!g_rccl.h || !g_rccl.get_uid || !g_rccl.init_rank || !g_rccl.destroy || !g_rccl.allreduce || !g_rccl.reduce_scatter || !g_rccl.allgather) {
-    sp_set_error("%s: librccl.so is not available in this process (%s)", what, dlerror() ? dlerror() : "symbols missing");
+    const char* why = dlerror();      // (one call: dlerror() clears the pending message)
+    sp_set_error("%s: librccl.so is not available in this process (%s)", what, why ? why : "symbols missing");
     return SP_EHIP;
   }
   return SP_OK;

@@ -83,7 +83,7 @@ class DataParallelSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.nbuckets_last = 0
         if direct is None:
-            direct = bool(os.environ.get("SP_DIST_DIRECT"))
+            direct = os.environ.get("SP_DIST_DIRECT", "0").strip().lower() in ("1", "true", "yes", "on")
         # direct: the gradient exchange goes through sp_allreduce_flat on a communicator of our own (DirectComm)
         self.direct = DirectComm(process_group) if (direct and dist.is_initialized() and torch.cuda.is_available()
                                                     and dist.get_backend(process_group) != "gloo") else None

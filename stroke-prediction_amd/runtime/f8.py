@@ -48,8 +48,13 @@ def prep_many(jobs):
             todo.append((r, w, b, fs, fsh, osc, key))
     if not todo:
         return
-    tkey = tuple((w.data_ptr(), 0 if b is None else b.data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, float(osc), r.bias.data_ptr(), r.winv.data_ptr(), r.ci0) +
-                 tuple(s["wfrag"].data_ptr() for s in r.slices) for r, w, b, fs, fsh, osc, _ in todo)
+    # the cached device table holds raw addresses and geometry only: key it on EVERYTHING it contains (as ops.prep_batch does), so
+    # an entry can only be replayed for runners that own exactly those buffers -- after Unet3D._engine evicted its engines a new
+    # runner may get the old w / bias / winv / wfrag addresses back while its kmap table lands elsewhere
+    tkey = tuple((w.data_ptr(), 0 if b is None else b.data_ptr(), O.ptr(fs) or 0, O.ptr(fsh) or 0, float(osc), r.bias.data_ptr(), r.winv.data_ptr(), r.ci0,
+                  r.op.w_sco, r.op.w_sci, r.op.cin) +
+                 tuple((s["wfrag"].data_ptr(), s["kmap_d"].data_ptr(), s["c0"], s["cn"], s["nsteps"], s["NT"]) for s in r.slices)
+                 for r, w, b, fs, fsh, osc, _ in todo)
     tab = _tables.get(tkey)
     if tab is None:
         if len(_tables) > 256:

@@ -59,7 +59,7 @@ class UnetEngine:
         O.require_gpu()
         L.load()
         assert not f8 or dtype == L.SP_BF16
-        assert not hl or (dtype == L.SP_BF16 and not f8 and variant == "")
+        assert not hl or (dtype == L.SP_BF16 and not f8)
         self.hl = bool(hl)
         self.variant = variant       # build of the library this engine's tensors belong to (lib.use): "" = bf16, "f16" = IEEE half
         assert L.current_variant() == variant, "construct and run an engine inside lib.use(engine.variant)"
@@ -164,6 +164,7 @@ class UnetEngine:
         nvox_out = batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2]
         self.loss_scale = float(2.0 ** math.ceil(math.log2(max(2, nvox_out)))) if variant == "f16" else 1.0
         self._gpriv = None
+        self._loss_scale_t = self._overflows = None
         # ---- fp8 mode: which layers run on the fp8 kernel, and where each one's e4m3 input comes from
         self.f8 = bool(f8)
         self._f8_fused = set()
@@ -357,7 +358,14 @@ class UnetEngine:
     def backward(self, dseg, seg, params, grads, ready=None):
         if self.loss_scale == 1.0:
             return self._backward(dseg, seg, params, grads, ready)
-        S = self.loss_scale
+        # IEEE-half build: the backward runs on S * gradients into a private buffer, added to the parameter gradients as 1/S of
+        # itself.  S is DYNAMIC and lives on the device (capturable: a replayed hipGraph adapts it too): a step whose scaled
+        # gradients are not all finite (an output gradient or a BatchNorm-backward coefficient pushed a 16-bit dz / g past
+        # 65504) contributes nothing and halves S for the following steps; ``overflow_steps`` counts them.
+        if self._loss_scale_t is None:
+            self._loss_scale_t = torch.full((), self.loss_scale, dtype=torch.float32, device=self.device)
+            self._overflows = torch.zeros((), dtype=torch.int64, device=self.device)
+        S = self._loss_scale_t
         names = list(grads)
         n = sum(grads[k].numel() for k in names)
         if self._gpriv is None or self._gpriv.numel() != n:
@@ -368,16 +376,28 @@ class UnetEngine:
             priv[k] = self._gpriv[off:off + grads[k].numel()].view(grads[k].shape)
             off += grads[k].numel()
         self._backward(dseg * S, seg, params, priv, None)
+        ok = torch.isfinite(self._gpriv).all()
+        inv = ok.to(torch.float32) / S                      # 0 for a step that overflowed
+        gsafe = torch.where(ok, self._gpriv, torch.zeros((), dtype=torch.float32, device=self.device))
         first = grads[names[0]]
         flat_ok = all(grads[k].is_contiguous() for k in names) and \
             all(grads[b].data_ptr() == grads[a].data_ptr() + 4 * grads[a].numel() for a, b in zip(names, names[1:]))
-        if flat_ok:      # the views of one flat buffer (runtime/flat.py): one add
-            torch.as_strided(first, (n,), (1,)).add_(self._gpriv, alpha=1.0 / S)
+        if flat_ok:      # the views of one flat buffer (runtime/flat.py): one fused multiply-add
+            torch.as_strided(first, (n,), (1,)).addcmul_(gsafe, inv)
         else:
+            off = 0
             for k in names:
-                grads[k].add_(priv[k], alpha=1.0 / S)
+                grads[k].addcmul_(gsafe[off:off + grads[k].numel()].view(grads[k].shape), inv)
+                off += grads[k].numel()
+        self._overflows.add_((~ok).to(torch.int64))
+        S.mul_(torch.where(ok, 1.0, 0.5).to(torch.float32)).clamp_(min=1.0)
         if ready is not None:
             ready("block1.")         # every gradient is final only now: one exchange
+
+    @property
+    def overflow_steps(self):
+        """f16 build: training steps whose scaled gradients overflowed (skipped, loss scale halved); host read = one sync"""
+        return 0 if self._overflows is None else int(self._overflows)
 
     def _backward(self, dseg, seg, params, grads, ready=None):
         """dseg: dL/dseg (NCDHW fp32).  Accumulates into ``grads[name]`` (fp32 tensors, parameter layout).

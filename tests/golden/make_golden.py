@@ -138,6 +138,42 @@ def gen_unet_eval128(seed, fname):
     print("wrote", fname, fx["mean"], fx["std"])
 
 
+HEAD_GAIN = {"classify.0.weight": 2.0, "classify.2.weight": 6.0}
+
+
+def gen_unet_train128(seed, fname):
+    """the headline spatial size WITH signal: a TRAIN-mode forward (batch statistics) of the reference's
+    Unet3D at 1 x 2 x 128^3 -- every BatchNorm renormalises, so the logits spread over several units (the eval-mode fixture
+    above, with untouched running statistics, has an output std of 3.6e-4: bf16-level errors hide in it)"""
+    from oracle import weights as W
+    from common.model.Unet3D import Unet3D
+    import common.dto.UnetDto as UnetDtoUtil
+    ch = [2, 16, 32, 64, 32, 16, 32, 2]
+    model = Unet3D(ch)
+    sd = W.make_state_dict(W.unet_spec(ch), seed)
+    # the generator's head weights (U(+-1/sqrt(fan_in))) squeeze every logit into +-0.7: the classify convolutions get a gain, so
+    # that the probabilities use their range (std ~0.1-0.2) and a wrong bit in any layer shows at the output
+    for k, gain in HEAD_GAIN.items():
+        sd[k] = sd[k] * gain
+    model.load_state_dict(sd)
+    model.train()
+    x, _ = W.unet_inputs(1, 128, seed)
+    with torch.no_grad():
+        dto = model(UnetDtoUtil.init_dto(x))
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+    logit = torch.log(seg.double() / (1 - seg.double()))
+    fx = {"seed": np.array(seed), "shape": np.array(seg.shape), "torch_version": np.array(torch.__version__),
+          "mean": seg.double().mean(dim=(0, 2, 3, 4)).numpy(), "std": seg.double().std(dim=(0, 2, 3, 4)).numpy(),
+          "logit_std": logit.std(dim=(0, 2, 3, 4)).numpy(), "logit_absmax": np.float64(logit.abs().max().item()),
+          "crop": seg[:, :, 40:48, 40:48, 40:48].numpy().copy(), "crop_corner": seg[:, :, :4, :4, -4:].numpy().copy(),
+          "digest": digest(seg), "head_gain_keys": np.array(sorted(HEAD_GAIN)), "head_gain": np.array([HEAD_GAIN[k] for k in sorted(HEAD_GAIN)])}
+    for n, b in model.named_buffers():
+        if n.endswith("running_mean") and n.startswith("block5"):
+            fx["buf/" + n] = b.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **fx)
+    print("wrote", fname, fx["mean"], fx["std"], fx["logit_std"], fx["logit_absmax"])
+
+
 class _FakeLoader:
     """Just enough of DataLoader for ``Learner.__init__`` (Learner.py:40-42)."""
     batch_size = 2
@@ -265,6 +301,7 @@ if __name__ == "__main__":
         gen_unet((92, 100, 96), 32, "unet4_92x100x96.npz", ch4)
     if "unet128" in which:
         gen_unet_eval128(14, "unet_eval128.npz")
+        gen_unet_train128(15, "unet_train128.npz")
     if "cae" in which:
         gen_cae([1, 16, 24, 32, 100, 200, 1], 21, "cae_200.npz")
         gen_cae([1, 16, 24, 32, 100, 800, 1], 22, "cae_800.npz")

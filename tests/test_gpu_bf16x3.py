@@ -204,18 +204,23 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
 
 
-# per-tensor relative L2 of the parameter gradients against the FP32 oracle (not a storage-point emulation): the forward is
-# fp32-faithful, so LeakyReLU branches and BatchNorm statistics are the oracle's; what remains is the bf16 rounding of the
-# backward's operands (dz, g: 2^-9 per element, averaging out over the voxel sums).  Measured: see GRAD_TOL below.
-GRAD_TOL = 3e-2
-GRAD_TOL_SMALL = 0.12      # tensors of <= 64 elements (BatchNorm gamma / beta, biases): sums with cancellation
+# Per-tensor relative L2 of the parameter gradients against the FP32 oracle (not a storage-point emulation): the forward is
+# fp32-faithful in both pair modes, so LeakyReLU branches and BatchNorm statistics are the oracle's; what remains is the 16-bit
+# rounding of the BACKWARD's operands (dz, g), which the BatchNorm-backward projections amplify.  Measured against the oracle
+# (tools/probes/x3_grad_probe.py, 44^3 / 76^3, tensors > 64 elements: worst, median | <= 64 elements: worst):
+#   f32 mode 1.2e-3, 4e-5 | 3.0e-3   and  1.5e-2, 9.6e-3 | 1.3e-2      (LeakyReLU kink flips: the floor of any comparison)
+#   f16x3    2.7e-2, 7e-4 | 2.8e-2   and  3.4e-2, 9.3e-3 | 4.8e-2      (44 x 48 x 52, seed 13: 6.3e-2 | 7.9e-2)
+#   bf16x3   9.2e-2, 6e-3 | 1.5e-1   and  9.6e-2, 2.9e-2 | 2.4e-1
+#   bf16     3.6e-1, 2.4e-1 | 6.3e-1 and  3.3e-1, 2.7e-1 | 4.7e-1
+GRAD_TOL = {"f16x3": (8e-2, 0.12), "bf16x3": (0.12, 0.3)}      # (tensors > 64 elements, <= 64 elements); f32 mode: (3e-2, 6e-2), bf16: 0.3 vs an EMULATING oracle
 
 
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16x3"])
 @pytest.mark.parametrize("size,seed", [((44, 44, 44), 11), ((44, 48, 52), 13)])
-def test_unet_bf16x3_train_step_matches_fp32_oracle(size, seed):
+def test_unet_pair_modes_train_step_matches_fp32_oracle(dtype, size, seed):
     x, y = W.unet_inputs(2, size, seed)
     seg_ref, loss_ref, g_ref, sd_ref = oracle_step(seed, x, y)
-    model = build(seed, "bf16x3").train()
+    model = build(seed, dtype).train()
     dto = model(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
     seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
     # the f32 mode's forward tolerances (tests/test_gpu_unet.py): probabilities 1e-4 abs, logits 1e-3 relative, loss 1e-5
@@ -223,7 +228,7 @@ def test_unet_bf16x3_train_step_matches_fp32_oracle(size, seed):
     logit = lambda p: torch.log(p / (1 - p))
     lr, lg = logit(seg_ref.double()), logit(seg.detach().cpu().double())
     rel = float((lg - lr).abs().max() / lr.abs().max())
-    assert rel < 1e-3, rel     # north_star: logits within 1e-3 rel
+    assert rel < (1e-4 if dtype == "f16x3" else 1e-3), rel     # north_star: logits within 1e-3 rel (f16 pairs: 22 bits, measured 6e-6)
     loss = nets.unet_loss(seg, y.to(DEV))
     assert abs(loss.item() - loss_ref) < 1e-5
     loss.backward()
@@ -231,10 +236,9 @@ def test_unet_bf16x3_train_step_matches_fp32_oracle(size, seed):
     for name, p in model.named_parameters():
         e = rel_l2(p.grad.cpu(), g_ref[name])
         worst = max(worst, e)
-        tol = GRAD_TOL_SMALL if p.numel() <= 64 else GRAD_TOL
-        if e > tol:
+        if e > GRAD_TOL[dtype][1 if p.numel() <= 64 else 0]:
             bad.append((name, e))
-    print("bf16x3 %s: max rel logit %.2e, worst gradient rel-L2 %.2e" % (size, rel, worst))
+    print("%s %s: max rel logit %.2e, worst gradient rel-L2 %.2e" % (dtype, size, rel, worst))
     assert not bad, bad
     for name, b in model.named_buffers():
         if name.endswith("num_batches_tracked"):
@@ -243,15 +247,16 @@ def test_unet_bf16x3_train_step_matches_fp32_oracle(size, seed):
             torch.testing.assert_close(b.cpu(), sd_ref[name], rtol=5e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16x3"])
 @pytest.mark.parametrize("fname", ["unet_44.npz", "unet_48.npz", "unet_44x48x52.npz"])
-def test_unet_bf16x3_matches_reference_fixture(golden_dir, fname):
-    """the forward pass directly against what the REAL reference recorded (f32-mode tolerances)"""
+def test_unet_pair_modes_match_reference_fixture(golden_dir, fname, dtype):
+    """the forward pass directly against what the REAL reference recorded (f32-mode tolerances); gradient norms as above"""
     fx = np.load(os.path.join(golden_dir, fname))
     seed = int(fx["seed"])
     size = tuple(int(s) for s in np.atleast_1d(fx["size"]))
     size = size * 3 if len(size) == 1 else size
     x, y = W.unet_inputs(2, size, seed)
-    model = build(seed, "bf16x3").train()
+    model = build(seed, dtype).train()
     dto = model(UnetDtoUtil.init_dto(x.to(DEV)))
     seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
     np.testing.assert_allclose(seg.detach().cpu().numpy(), fx["seg"], rtol=0, atol=1e-4)
@@ -260,24 +265,25 @@ def test_unet_bf16x3_matches_reference_fixture(golden_dir, fname):
     loss.backward()
     for name, p in model.named_parameters():
         gn = float(fx["gnorm/" + name])
-        assert abs(float(p.grad.double().norm()) - gn) <= (GRAD_TOL_SMALL if p.numel() <= 64 else GRAD_TOL) * gn + 1e-9, name
+        assert abs(float(p.grad.double().norm()) - gn) <= GRAD_TOL[dtype][1 if p.numel() <= 64 else 0] * gn + 1e-9, name
 
 
-def test_unet_bf16x3_eval_and_reproducibility():
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16x3"])
+def test_unet_pair_modes_eval_and_reproducibility(dtype):
     """eval-mode forward (running statistics) against the oracle; two fresh runs of three training steps agree bit for bit"""
     from stroke_prediction_amd.optim import FusedAdam
     seed, size = 21, (44, 44, 44)
     x, y = W.unet_inputs(2, size, seed)
     sd = W.make_state_dict(W.unet_spec(CH), seed)
     ref = nets.unet_forward(sd, x, training=False)
-    model = build(seed, "bf16x3").eval()
+    model = build(seed, dtype).eval()
     with torch.no_grad():
         dto = model(UnetDtoUtil.init_dto(x.to(DEV)))
     seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1).cpu()
     torch.testing.assert_close(seg, ref, rtol=0, atol=1e-4)
     outs = []
     for _ in range(2):
-        m = build(seed, "bf16x3").train()
+        m = build(seed, dtype).train()
         opt = FusedAdam(m.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
         losses = []
         for _step in range(3):
@@ -290,3 +296,30 @@ def test_unet_bf16x3_eval_and_reproducibility():
         outs.append((losses, [p.detach().clone() for p in m.parameters()]))
     assert outs[0][0] == outs[1][0]
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
+def test_f16_builds_skip_and_rescale_on_gradient_overflow():
+    """the IEEE-half builds scale the output gradients by S; a step whose scaled gradients leave half's range must not
+    reach the optimiser as inf / NaN -- it contributes nothing, S halves (on the device: works under graph replay) and the
+    engine counts it"""
+    seed, size = 23, (44, 44, 44)
+    x, y = W.unet_inputs(2, size, seed)
+    m = build(seed, "f16x3").train()
+
+    def step():
+        d = m(UnetDtoUtil.init_dto(x.to(DEV), y[:, 0:1].to(DEV), y[:, 1:2].to(DEV)))
+        loss = nets.unet_loss(torch.cat((d.outputs.core, d.outputs.penu), 1), y.to(DEV))
+        m.zero_grad()
+        loss.backward()
+        return [p.grad.detach().clone() for p in m.parameters()]
+    g0 = step()
+    eng = next(iter(m._engines.values()))
+    assert eng.overflow_steps == 0 and all(bool(torch.isfinite(g).all()) for g in g0)
+    s0 = float(eng._loss_scale_t)
+    eng._loss_scale_t.fill_(2.0 ** 60)            # every 16-bit dz of the next backward overflows
+    g1 = step()
+    assert eng.overflow_steps == 1 and float(eng._loss_scale_t) == 2.0 ** 59
+    assert all(float(g.abs().max()) == 0.0 for g in g1)
+    eng._loss_scale_t.fill_(s0)
+    g2 = step()
+    assert eng.overflow_steps == 1 and all(torch.equal(a, b) for a, b in zip(g0, g2))

@@ -70,6 +70,23 @@ def test_unet_eval128_matches_reference(golden_dir):
     np.testing.assert_allclose(seg.double().mean(dim=(0, 2, 3, 4)).numpy(), fx["mean"], rtol=1e-6)
 
 
+def test_unet_train128_matches_reference(golden_dir):
+    """the headline size with signal: train-mode forward (batch statistics), classify gain as recorded in the fixture"""
+    fx = _load(golden_dir, "unet_train128.npz")
+    sd = W.make_state_dict(W.unet_spec(UNET_CH), int(fx["seed"]))
+    for k, gain in zip(fx["head_gain_keys"], fx["head_gain"]):
+        sd[str(k)] = sd[str(k)] * float(gain)
+    x, _ = W.unet_inputs(1, 128, int(fx["seed"]))
+    with torch.no_grad():
+        seg = nets.unet_forward(sd, x, training=True)
+    assert tuple(seg.shape) == tuple(fx["shape"])
+    np.testing.assert_allclose(seg[:, :, 40:48, 40:48, 40:48].numpy(), fx["crop"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(seg[:, :, :4, :4, -4:].numpy(), fx["crop_corner"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(seg.double().mean(dim=(0, 2, 3, 4)).numpy(), fx["mean"], rtol=1e-5)
+    np.testing.assert_allclose(seg.double().std(dim=(0, 2, 3, 4)).numpy(), fx["std"], rtol=1e-5)
+    assert float(min(fx["std"])) > 0.05          # the fixture carries signal
+
+
 @pytest.mark.parametrize("fname", ["cae_200.npz", "cae_800.npz"])
 def test_cae_step_matches_reference(golden_dir, fname):
     fx = _load(golden_dir, fname)
