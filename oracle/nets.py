@@ -270,6 +270,43 @@ def cae_loss(lat, rec, core, penu, lesion, epoch):
     return loss / (5 + factor)
 
 
+def cae_prediction_forward(sd_cae, sd_enc, unet_core, unet_penu, core, penu, lesion, step, alpha=1.0, training=True):
+    """``CaeEncInference.inference_step`` CaeEncInference.py:29-42 with the branch selector the reference MEANS (it writes
+    ``dto.mode``, the models read ``dto.flag``: as written the second call trips Cae3D.py:110): the new encoder on the two U-Net
+    segmentations + lerp, the CAE's decoder on those three latents (``inputs`` branch); then the whole CAE on the manual masks
+    (``gtruth`` branch).  Returns (latents_inputs, reconstructions_inputs, latents_gtruth, reconstructions_gtruth)."""
+    lat_in = {"core": enc_forward(sd_enc, unet_core, alpha, training, "encoder"),
+              "penu": enc_forward(sd_enc, unet_penu, alpha, training, "encoder")}
+    lat_in["interpolation"] = lat_in["core"] + step * (lat_in["penu"] - lat_in["core"])
+    rec_in = {k: dec_forward(sd_cae, lat_in[k], alpha, training, "dec.decoder") for k in ("core", "penu", "interpolation")}
+    lat_gt, rec_gt = cae_forward(sd_cae, core, penu, lesion, step, alpha, training)
+    return lat_in, rec_in, lat_gt, rec_gt
+
+
+def cae_prediction_loss(lat_in, rec_in, lat_gt, lesion):
+    """``CaePredictionLearner.loss_step`` CaePredictionLearner.py:42-57."""
+    d_pf = rec_in["penu"] - rec_in["interpolation"]
+    d_pc = rec_in["penu"] - rec_in["core"]
+    loss = torch.mean(torch.abs(d_pf) - d_pf) + torch.mean(torch.abs(d_pc) - d_pc)
+    loss = loss + batch_dice_loss(rec_in["interpolation"], lesion)
+    for k in ("interpolation", "core", "penu"):
+        loss = loss + torch.mean(torch.abs(lat_gt[k] - lat_in[k]))
+    return loss / 6
+
+
+def enc_step(sd, globals_, alpha=1.0, prefix="enc."):
+    """``Enc3DStep._get_step`` Cae3D.py:137-141: sigmoid(step(reduce(globals))), reduce = conv1x1 -> ELU -> conv1x1 -> ELU."""
+    h = F.elu(F.conv3d(globals_, sd[prefix + "reduce.0.weight"], sd[prefix + "reduce.0.bias"]), alpha)
+    h = F.elu(F.conv3d(h, sd[prefix + "reduce.2.weight"], sd[prefix + "reduce.2.bias"]), alpha)
+    return torch.sigmoid(F.conv3d(h, sd[prefix + "step.weight"], sd[prefix + "step.bias"]))
+
+
+def cae_step_loss(rec, lesion):
+    """``CaeStepLearner.loss_step`` CaeStepLearner.py:15-21."""
+    d_pf = rec["penu"] - rec["interpolation"]
+    return (torch.mean(torch.abs(d_pf) - d_pf) + batch_dice_loss(rec["interpolation"], lesion)) / 2
+
+
 def cae_beta1(epoch, base=0.9, n_adapt=4):
     """``CaeReconstructionLearner.adapt_betas`` :28-40."""
     return base - 0.1 * (n_adapt - epoch) if epoch < n_adapt else base

@@ -41,7 +41,8 @@ class CaeInference(Inference):
         # created on the target device: no host->device copy of constants inside the (graph-capturable) step
         type_core = torch.zeros(n, 1, 1, 1, 1, device=dev)
         type_penumbra = torch.ones(n, 1, 1, 1, 1, device=dev)
-        time_to_treatment = time_to_treatment.to(dev)
+        if time_to_treatment is not None:        # (CaeStepLearner: the encoder predicts the step)
+            time_to_treatment = time_to_treatment.to(dev)
         globals_incl_time = globals_incl_time.to(dev)
         return CaeDtoUtil.init_dto(globals_incl_time, time_to_treatment, type_core, type_penumbra,
                                    None, None, None, None, None)

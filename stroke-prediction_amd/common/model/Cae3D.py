@@ -93,6 +93,7 @@ class _StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, opts, x, *params):
         opts = opts or {}
+        ctx.nparams = len(params)
         key, sc = opts.get("sc") or module._pool().acquire(x.shape[0], tuple(x.shape[2:]), module._dtype_code(), x.device, lane=opts.get("lane", 0))
         ctx.concurrent = bool(opts.get("concurrent"))
         with (_O.no_fork() if ctx.concurrent else contextlib.nullcontext()):
@@ -100,9 +101,11 @@ class _StackFn(torch.autograd.Function):
                              order=opts.get("order"))
         ctx.home = opts.get("home")              # the stream the call came from (concurrent passes: joined again after backward)
         ctx.module, ctx.sc = module, sc
-        ctx.lease = _Lease(module._pool(), key, sc, module)
-        module._begin_step()
-        module._n_out = getattr(module, "_n_out", 0) + 1       # passes of this stack whose backward is still to come
+        ctx.frozen = module._stack_frozen()      # only the input needs a gradient: data-gradient-only backward
+        ctx.lease = _Lease(module._pool(), key, sc, None if ctx.frozen else module)
+        if not ctx.frozen:
+            module._begin_step()
+            module._n_out = getattr(module, "_n_out", 0) + 1       # passes of this stack whose backward is still to come
         ctx.training = module.training
         ctx.need_dx = x.requires_grad
         ctx.save_for_backward(out)
@@ -116,6 +119,9 @@ class _StackFn(torch.autograd.Function):
             raise RuntimeError("%s.backward after an eval-mode forward is not supported: the fused backward uses the "
                                "batch-statistics BatchNorm formula; call model.train() for passes that need gradients"
                                % type(module).__name__)
+        if ctx.frozen:
+            dx = _frozen_backward(ctx, module, sc, dout, out)
+            return (None, None, dx) + tuple(None for _ in range(ctx.nparams))
         names, views, inplace = module._grad_targets()
         red = None
         if ctx.concurrent and inplace and "nored" not in _DBG:
@@ -147,6 +153,20 @@ class _StackFn(torch.autograd.Function):
         return (None, None, dx) + tuple(None if inplace else v for v in views)
 
 
+def _frozen_backward(ctx, module, sc, dout, out):
+    """backward through a stack whose parameters are frozen (the phase-2 learners: CaePredictionLearner.py:27,
+    train_interpolationstep_after_reconstruction.py:22): the gradient of the stack INPUT only -- data-gradient convolutions
+    and the BatchNorm-backward terms of the live batch statistics; no weight-gradient kernel runs, nothing is written to
+    the module's gradient buffers"""
+    names = [n for n, _ in module.named_parameters()]
+    shapes = [p for _, p in module.named_parameters()]
+    _, scratch = sc.private_grads(names, shapes)
+    with (_O.no_fork() if getattr(ctx, "concurrent", False) else contextlib.nullcontext()):
+        dx = sc.backward(dout, out, module._param_dict(), scratch, True, param_grads=False)
+    ctx.lease.release()
+    return dx
+
+
 # SP_CAE_BATCHED (default 1): the passes of one encoder / decoder call are stacked along the batch axis and run as ONE pass
 # through a grouped StackContext -- one launch per layer for the convolution, the weight gradient and the data gradient of all
 # passes, per-pass BatchNorm statistics, running statistics updated in pass order (runtime/layers.py, ConvLayer(groups=G)).
@@ -164,9 +184,12 @@ class _StackManyFn(torch.autograd.Function):
         x = torch.cat([t.float() for t in xs], 0)
         out = sc.forward(x, module._param_dict(), module._buffer_dict(), module.training)
         ctx.module, ctx.sc, ctx.n, ctx.B = module, sc, n, B
-        ctx.lease = _Lease(module._pool(), key, sc, module)
-        module._begin_step()
-        module._n_out = getattr(module, "_n_out", 0) + 1
+        ctx.nparams = len(args) - n
+        ctx.frozen = module._stack_frozen()
+        ctx.lease = _Lease(module._pool(), key, sc, None if ctx.frozen else module)
+        if not ctx.frozen:
+            module._begin_step()
+            module._n_out = getattr(module, "_n_out", 0) + 1
         ctx.training = module.training
         ctx.need_dx = any(t.requires_grad for t in xs)
         ctx.save_for_backward(out)
@@ -182,6 +205,10 @@ class _StackManyFn(torch.autograd.Function):
                                "batch-statistics BatchNorm formula; call model.train() for passes that need gradients"
                                % type(module).__name__)
         dout = torch.cat([torch.zeros_like(out[:B]) if d is None else d for d in douts], 0)
+        if ctx.frozen:
+            dx = _frozen_backward(ctx, module, sc, dout, out)
+            dxs = tuple(None for _ in range(n)) if dx is None else tuple(dx[i * B:(i + 1) * B] for i in range(n))
+            return (None, None) + dxs + tuple(None for _ in range(ctx.nparams))
         names, views, inplace = module._grad_targets()
         dx = sc.backward(dout, out, module._param_dict(), dict(zip(names, views)), ctx.need_dx)
         ctx.lease.release()
@@ -237,7 +264,7 @@ class CaeBase(FlatParamsMixin, nn.Module):
         if x.dtype != torch.float32:
             x = x.float()
         params = [p for _, p in self.named_parameters()]
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
+        if torch.is_grad_enabled() and (x.requires_grad or not self._stack_frozen()):
             return _StackFn.apply(self, opts, x, *params)
         opts = opts or {}
         key, sc = opts.get("sc") or self._pool().acquire(x.shape[0], tuple(x.shape[2:]), self._dtype_code(), x.device, lane=opts.get("lane", 0))
@@ -275,7 +302,7 @@ class CaeBase(FlatParamsMixin, nn.Module):
         fork_ev = None
         if conc:
             # weights that depend on the parameters only are packed once, here, before the lanes fork (shared bank)
-            with_bwd = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+            with_bwd = torch.is_grad_enabled() and not self._stack_frozen()
             scs[0][1].prepare(self._param_dict(), with_bwd)
             fork_ev = torch.cuda.Event()
             fork_ev.record(main)          # every lane starts HERE (not behind lane 0's work, which goes to the home stream)
@@ -303,7 +330,7 @@ class CaeBase(FlatParamsMixin, nn.Module):
         ins = [xs[i] for i in idx]
         params = [p for _, p in self.named_parameters()]
         outs = list(xs)
-        if torch.is_grad_enabled() and (any(t.requires_grad for t in ins) or any(p.requires_grad for p in params)):
+        if torch.is_grad_enabled() and (any(t.requires_grad for t in ins) or not self._stack_frozen()):
             res = _StackManyFn.apply(self, n, *ins, *params)
         else:
             B = ins[0].shape[0]
@@ -314,6 +341,12 @@ class CaeBase(FlatParamsMixin, nn.Module):
         for i, r in zip(idx, res):
             outs[i] = r
         return outs
+
+    def _stack_frozen(self):
+        """no parameter of the convolution stack itself wants a gradient (``freeze(True)``; the 1x1x1 step layers of an
+        ``Enc3DStep`` are torch modules outside the stack and do not count)"""
+        pre = self._PREFIX + "."
+        return not any(p.requires_grad for n, p in self.named_parameters() if n.startswith(pre))
 
     def _flat_segment(self):
         """this stack's slice of the (root's) flat gradient buffer"""

@@ -136,11 +136,14 @@ class StackContext:
             off += v.numel()
         return self._gpriv, out
 
-    def backward(self, dout, out, params, grads, need_input_grad):
-        """dout = dL/dout (NCDHW fp32).  Accumulates parameter gradients; returns dL/dx (NCDHW fp32) or None."""
+    def backward(self, dout, out, params, grads, need_input_grad, param_grads=True):
+        """dout = dL/dout (NCDHW fp32).  Accumulates parameter gradients; returns dL/dx (NCDHW fp32) or None.
+        param_grads=False: a FROZEN stack (CaePredictionLearner / CaeStepLearner: the gradient passes through the decoder into
+        a trainable encoder or into the learned step): data gradients and BatchNorm-backward terms only, `grads` is scratch."""
         dt = self.dtype
         for lay in self.layers:
             lay._init_bwd()
+            lay.param_grads = bool(param_grads)
         last = self.layers[-1]
         dout = dout.contiguous()
         if self.cout <= 8:

@@ -130,6 +130,8 @@ class ConvLayer:
             self.scale = self.shift = None
         # backward side is created lazily (inference never pays for it)
         self._bwd_ready = False
+        self.param_grads = True      # False: backward through a FROZEN layer (phase-2 learners): data gradient and BatchNorm-backward
+        #                              coefficients only -- no weight-gradient kernel, no gamma / beta / bias gradients kept
         self.y = None
         # fp8 execution (runtime/f8.py; enabled per layer by the engine in the "fp8" precision mode)
         self.f8_fwd = self.f8_dgrad = self.f8_wgrad = None
@@ -344,6 +346,14 @@ class ConvLayer:
         dx = coef0*g + coef1*x + coef2 (coef None: dx = g)."""
         c = self.conv_prefix
         w = params[c + ".weight"]
+        if not self.param_grads:
+            # frozen parameters, live BatchNorm statistics (CaePredictionLearner.py:27 freezes the CAE, Learner.run_training keeps
+            # it in train mode): the input gradient still carries the batch-statistics terms, so the (sum g, sum g x) reductions
+            # stay; `grads` is a scratch dictionary whose gamma / beta entries are discarded
+            assert getattr(self, "dgrad", None) is not None and not getattr(self, "dgrad_parts", None) and self.f8_dgrad is None
+            if self.G > 1:
+                return self._backward_grouped(x, w, params, grads, wgrad=False)
+            return self._backward_input(x, w, params, grads)
         if self.G > 1:
             return self._backward_grouped(x, w, params, grads)
         # the wgrad finish kernel also adds the bias gradient (sum of dz) and re-zeroes its accumulator
@@ -396,17 +406,19 @@ class ConvLayer:
             if f is not None:
                 f.join()
 
-    def _backward_grouped(self, x, w, params, grads):
+    def _backward_grouped(self, x, w, params, grads, wgrad=True):
         """groups > 1: one weight-gradient launch over all passes (operands: the materialised normalised input and dz -- the
         sum over the batch IS the sum over the passes), one data-gradient launch whose epilogue (or one reduction per group)
         yields the per-group BatchNorm-backward sums, one grouped finalize."""
         c = self.conv_prefix
         src = self.xhat if self.materialize else x
-        f = O.fork() if O.overlap_level() == 2 else None
+        f = O.fork() if (O.overlap_level() == 2 and wgrad) else None
         if f is not None:
             f.__enter__()
         try:
-            if self.kind == "conv":
+            if not wgrad:
+                pass
+            elif self.kind == "conv":
                 self.wgrad.run(src, self.dz, self.batch, grads[c + ".weight"], None, None,
                                dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
             else:
@@ -454,7 +466,7 @@ class ConvLayer:
             return self.g, None
         p = self.bn_prefix
         bs = self.scratch.get(self.bsums_id)
-        fused = all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA
+        fused = all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None
         if fused:      # (sum g, sum g*x) accumulated by the dgrad epilogue
             self.dgrad.run(self.dz, self.g, self.batch, stats=bs, stats_nrep=STATS_NREP, stats_mode=1, aux=x)
         else:

@@ -231,6 +231,109 @@ def gen_cae(ch, seed, fname, d=28, hw=128):
     print("\nwrote", fname, {k: float(v) for k, v in fx.items() if k.startswith("loss_epoch")})
 
 
+def phase2_inputs(seed, d=28, hw=128):
+    """synthetic batch of the phase-2 learners: labels / clinical as for phase 1, 'images' = soft U-Net-like segmentations
+    of core and penumbra (another seed's blobs, squeezed into (0.05, 0.95))"""
+    from oracle import weights as W
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    seg, _ = W.cae_inputs(2, d, hw, seed + 7)
+    images = (0.05 + 0.9 * seg[:, 0:2]).contiguous()
+    return images, labels, clinical
+
+
+def gen_cae_phase2(seed, fname, ch=(1, 16, 24, 32, 100, 200, 1), d=28, hw=128):
+    """SURVEY 8(f) N4, second half: the reference's ``CaePredictionLearner`` (new encoder against the frozen CAE) and
+    ``CaeStepLearner`` (learned interpolation step) on a synthetic batch.  The reference's own
+    ``CaeEncInference.inference_step`` cannot run (it sets ``dto.mode``, the models read ``dto.flag``: the second model call
+    asserts, recorded below as ``ref_inference_step_raises``); the harness makes the same five calls with ``dto.flag`` set to
+    what ``dto.mode`` says -- every forward, the loss and the backward are the reference's own code."""
+    from oracle import weights as W
+    from common.model.Cae3D import Cae3D, Enc3D, Dec3D, Enc3DStep
+    from common.metrics import BatchDiceLoss
+    from learner.CaePredictionLearner import CaePredictionLearner
+    from learner.CaeStepLearner import CaeStepLearner
+    import common.dto.CaeDto as CaeDtoUtil
+    ch = list(ch)
+    kw = dict(size_input_xy=hw, size_input_z=d, channels=ch, n_ch_global=5, alpha=1.0)
+    cae = Cae3D(Enc3D(**kw), Dec3D(**kw))
+    cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+    enc = Enc3D(**kw)
+    enc.load_state_dict(W.make_state_dict(W.enc_spec(ch), seed + 1))
+    images, labels, clinical = phase2_inputs(seed, d, hw)
+    batch = {"case_id": [0, 1], "images": images, "labels": labels, "clinical": clinical}
+    opt = torch.optim.Adam([p for p in enc.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999))
+    learner = CaePredictionLearner(_FakeLoader(), None, cae, enc, opt, None, n_epochs=1, path_previous_base=None,
+                                   path_outputs_base="/tmp/_golden_cae2", criterion=BatchDiceLoss([1.0]))
+    fx = {"channels": np.array(ch), "seed": np.array(seed), "d": np.array(d), "hw": np.array(hw),
+          "torch_version": np.array(torch.__version__)}
+    assert not any(p.requires_grad for p in cae.parameters())          # CaePredictionLearner.__init__ froze the CAE
+    cae.train()
+    try:
+        learner.inference_step(batch)
+        fx["ref_inference_step_raises"] = np.array(0)
+    except AssertionError:
+        fx["ref_inference_step_raises"] = np.array(1)
+    # running statistics the failed attempt moved: reload, so that the fixture describes ONE clean pass
+    cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+    enc.load_state_dict(W.make_state_dict(W.enc_spec(ch), seed + 1))
+    dto = learner.init_clinical_variables(batch, None)
+    dto.flag = CaeDtoUtil.FLAG_INPUTS
+    dto = learner.init_unet_segm_variables(batch, dto)
+    dto = enc(dto)
+    dto = cae.dec(dto)
+    dto.flag = CaeDtoUtil.FLAG_GTRUTH
+    dto = learner.init_gtruth_segm_variables(batch, dto)
+    dto = cae(dto)
+    fx["ttt"] = dto.given_variables.time_to_treatment.detach().numpy().copy()
+    for k in ("core", "penu", "interpolation"):
+        lat, rec = getattr(dto.latents.inputs, k), getattr(dto.reconstructions.inputs, k)
+        fx["lat_in_head/" + k] = lat.detach().reshape(lat.shape[0], -1)[:, :64].numpy().copy()
+        fx["lat_in_digest/" + k] = digest(lat)
+        fx["rec_in_crop/" + k] = rec.detach()[:, 0, d // 2, 60:68, 60:68].numpy().copy()
+        fx["rec_in_digest/" + k] = digest(rec)
+        fx["lat_gt_digest/" + k] = digest(getattr(dto.latents.gtruth, k))
+    loss = learner.loss_step(dto, 0)
+    fx["loss"] = np.float64(loss.item())
+    opt.zero_grad()
+    loss.backward()
+    fx.update(grads_summary(enc.named_parameters()))
+    assert all(p.grad is None for p in cae.parameters())
+    for n, b in list(cae.named_buffers()) + [("newenc." + n, b) for n, b in enc.named_buffers()]:
+        if n.endswith("num_batches_tracked"):
+            fx["nbt/" + n] = b.numpy().copy()
+        elif n.startswith("dec.decoder.0.") or n.startswith("newenc.encoder.0."):
+            fx["buf1/" + n] = b.detach().numpy().copy()
+    # ---- CaeStepLearner: Enc3DStep around the frozen encoder stack, frozen decoder (train_interpolationstep_after_reconstruction.py:21-27)
+    cae.load_state_dict(W.make_state_dict(W.cae_spec(ch), seed))
+    cae.freeze(True)
+    torch.manual_seed(seed)
+    senc = Enc3DStep(**kw)
+    senc.encoder = cae.enc.encoder
+    cae2 = Cae3D(senc, cae.dec)
+    cae2.train()
+    for n, p in senc.named_parameters():
+        if n.startswith("reduce.") or n.startswith("step."):
+            fx["step_param/" + n] = p.detach().numpy().copy()
+    params = [p for p in cae2.parameters() if p.requires_grad]
+    opt2 = torch.optim.Adam(params, lr=1e-3, weight_decay=1e-5, betas=(0.9, 0.999))
+    learner2 = CaeStepLearner(_FakeLoader(), None, cae2, opt2, None, n_epochs=1, path_previous_base=None,
+                              path_outputs_base="/tmp/_golden_cae1step", criterion=BatchDiceLoss([1.0]))
+    dto2 = learner2.inference_step(batch)
+    fx["step_value"] = senc._get_step(dto2).detach().numpy().copy()
+    for k in ("penu", "interpolation"):
+        rec = getattr(dto2.reconstructions.gtruth, k)
+        fx["step_rec_crop/" + k] = rec.detach()[:, 0, d // 2, 60:68, 60:68].numpy().copy()
+    loss2 = learner2.loss_step(dto2, 0)
+    fx["step_loss"] = np.float64(loss2.item())
+    opt2.zero_grad()
+    loss2.backward()
+    for n, p in senc.named_parameters():
+        if p.requires_grad:
+            fx["step_grad/" + n] = p.grad.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, fname), **fx)
+    print("wrote", fname, "loss", fx["loss"], "step loss", fx["step_loss"], "ref inference_step raises:", int(fx["ref_inference_step_raises"]))
+
+
 def gen_checkpoints():
     """whole-module pickles exactly as ``Learner.save_model`` writes them (``torch.save(self._model.cpu(),
     path)``, learner/Learner.py:112-114) from the REFERENCE classes -- class paths ``common.model.Unet3D.Unet3D`` /
@@ -288,7 +391,7 @@ def gen_checkpoints():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ["unet", "unet128", "cae", "unet4", "ckpt"]
+    which = sys.argv[1:] or ["unet", "unet128", "cae", "cae2", "unet4", "ckpt"]
     if "unet" in which:
         gen_unet(44, 11, "unet_44.npz")
         gen_unet(48, 12, "unet_48.npz")
@@ -302,6 +405,8 @@ if __name__ == "__main__":
     if "unet128" in which:
         gen_unet_eval128(14, "unet_eval128.npz")
         gen_unet_train128(15, "unet_train128.npz")
+    if "cae2" in which:
+        gen_cae_phase2(23, "cae_phase2_200.npz")
     if "cae" in which:
         gen_cae([1, 16, 24, 32, 100, 200, 1], 21, "cae_200.npz")
         gen_cae([1, 16, 24, 32, 100, 800, 1], 22, "cae_800.npz")

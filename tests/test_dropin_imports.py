@@ -26,6 +26,9 @@ from common.model.Cae3D import Cae3D, Enc3D, Enc3DStep, Dec3D
 from common import data, util, metrics
 from learner.UnetSegmentationLearner import UnetSegmentationLearner
 from common.model.Unet3D import Unet3D
+from learner.CaePredictionLearner import CaePredictionLearner
+from learner.CaeStepLearner import CaeStepLearner
+from common.inference.CaeEncInference import CaeEncInference
 """
 
 
@@ -34,7 +37,8 @@ def test_reference_script_import_blocks_resolve():
     exec(SCRIPT_IMPORTS, ns)
     assert ns["Cae3D"].__module__ == "common.model.Cae3D" and ns["util"].__name__ == "common.util"
     assert os.path.dirname(ns["util"].__file__).startswith(os.path.join(ROOT, "stroke-prediction_amd"))
-    for name in ("get_stroke_shape_training_data", "get_testdata", "ResamplePlaneXY", "HemisphericFlip", "ElasticDeform",
+    assert issubclass(ns["CaePredictionLearner"], ns["CaeEncInference"]) and issubclass(ns["CaeStepLearner"], ns["CaeReconstructionLearner"])
+    for name in ("get_stroke_shape_training_data", "get_stroke_prediction_training_data", "get_testdata", "ResamplePlaneXY", "HemisphericFlip", "ElasticDeform",
                  "ToTensor", "PadImages", "RandomPatch", "HemisphericFlipFixedToCaseId", "KEY_IMAGES", "DIM_CHANNEL_TORCH3D_5"):
         assert hasattr(ns["data"], name), name
     for name in ("get_args_shape_training", "get_args_unet_training", "get_args_step_training", "get_args_shape_testing",
@@ -50,7 +54,8 @@ def test_reference_script_import_blocks_resolve():
 @pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree exists in the build container only")
 def test_every_import_of_the_named_reference_scripts_resolves():
     """parse the two scripts' real import statements (text study of the reference; nothing is executed from it)"""
-    for script in ("train_shape_reconstruction.py", "train_unet_segmentation.py"):
+    for script in ("train_shape_reconstruction.py", "train_unet_segmentation.py", "train_shape_prediction.py",
+                   "train_interpolationstep_after_reconstruction.py"):
         tree = ast.parse(open(os.path.join("/root/reference", script)).read())
         block = [ast.unparse(n) for n in tree.body if isinstance(n, (ast.Import, ast.ImportFrom))]
         assert block

@@ -142,3 +142,50 @@ def test_adam_restatement_matches_torch_optim():
         nets.adam_step(mine, grads, m, v, step, lr=1e-3, betas=(0.99, 0.999), weight_decay=1e-5)
     for a, b in zip(ref, mine):
         np.testing.assert_allclose(a.detach().numpy(), b.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def phase2_inputs(seed, d=28, hw=128):
+    """the synthetic batch of tests/golden/make_golden.py:phase2_inputs"""
+    labels, clinical = W.cae_inputs(2, d, hw, seed)
+    seg, _ = W.cae_inputs(2, d, hw, seed + 7)
+    return (0.05 + 0.9 * seg[:, 0:2]).contiguous(), labels, clinical
+
+
+def test_cae_phase2_learners_match_reference(golden_dir):
+    """SURVEY 8(f) N4 second half: CaePredictionLearner (new encoder against the frozen CAE) and CaeStepLearner (learned step)
+    as restated in oracle/nets.py against what the reference's own classes computed"""
+    fx = _load(golden_dir, "cae_phase2_200.npz")
+    assert int(fx["ref_inference_step_raises"]) == 1      # the reference's CaeEncInference.inference_step asserts as written (dto.mode / dto.flag)
+    ch, seed, d, hw = [int(c) for c in fx["channels"]], int(fx["seed"]), int(fx["d"]), int(fx["hw"])
+    sd_cae = W.make_state_dict(W.cae_spec(ch), seed)
+    sd_enc = _leafify(W.make_state_dict(W.enc_spec(ch), seed + 1))
+    images, labels, clinical = phase2_inputs(seed, d, hw)
+    step = nets.time_to_treatment(clinical)
+    np.testing.assert_allclose(step.numpy(), fx["ttt"], rtol=1e-6)
+    core, penu, lesion = labels[:, 0:1], labels[:, 1:2], labels[:, 2:3]
+    lat_in, rec_in, lat_gt, rec_gt = nets.cae_prediction_forward(sd_cae, sd_enc, images[:, 0:1], images[:, 1:2], core, penu, lesion, step)
+    for k in ("core", "penu", "interpolation"):
+        np.testing.assert_allclose(lat_in[k].detach().reshape(2, -1)[:, :64].numpy(), fx["lat_in_head/" + k], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rec_in[k].detach()[:, 0, d // 2, 60:68, 60:68].numpy(), fx["rec_in_crop/" + k], rtol=1e-4, atol=1e-5)
+    loss = nets.cae_prediction_loss(lat_in, rec_in, lat_gt, lesion)
+    assert abs(loss.item() - float(fx["loss"])) < 2e-6
+    names = nets.trainable(sd_enc)
+    grads = torch.autograd.grad(loss, [sd_enc[k] for k in names])
+    for k, g in zip(names, grads):
+        gn = float(fx["gnorm/" + k])
+        assert abs(float(g.double().norm()) - gn) <= 2e-3 * gn + 1e-9, k
+    # ---- CaeStepLearner
+    sd2 = dict(W.make_state_dict(W.cae_spec(ch), seed))
+    for k in fx.files:
+        if k.startswith("step_param/"):
+            sd2["enc." + k[len("step_param/"):]] = torch.from_numpy(fx[k]).clone().requires_grad_(True)
+    stepv = nets.enc_step(sd2, clinical.float(), 1.0)
+    np.testing.assert_allclose(stepv.detach().numpy(), fx["step_value"], rtol=1e-5, atol=1e-7)
+    _, rec = nets.cae_forward(sd2, core, penu, lesion, stepv, alpha=1.0, training=True)
+    loss2 = nets.cae_step_loss(rec, lesion)
+    assert abs(loss2.item() - float(fx["step_loss"])) < 2e-6
+    sk = [k for k in sd2 if k.startswith("enc.reduce.") or k.startswith("enc.step.")]
+    g2 = torch.autograd.grad(loss2, [sd2[k] for k in sk])
+    for k, g in zip(sk, g2):
+        ref = fx["step_grad/" + k[len("enc."):]]
+        np.testing.assert_allclose(g.numpy(), ref, rtol=2e-3, atol=2e-3 * float(np.abs(ref).max()) + 1e-12)
