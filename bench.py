@@ -343,6 +343,40 @@ def conv_roofline_unet(size, channels, batch, peak_tflops, kernels):
                           % (peak_tflops, HBM_PEAK_GBS)}
 
 
+def conv_roofline_cae(d, hw, batch, peak_tflops, kernels, channels=None):
+    """The per-layer bound of SURVEY 8(d) for the CAE (VERDICT r3 missing 4): sum over the 10 encoder layers x 3 passes and the
+    12 decoder layers x 4 passes (Cae3D.py:39-76,105-107,176-220,230-233) and over forward, data gradient (none for the encoder's
+    first layer) and weight gradient of  max(FLOP / MFMA peak, bf16 operand bytes / HBM peak)  -- most of this network is 1 / 16 /
+    24-channel layers at full resolution, i.e. HBM-bound by construction -- against the measured time of the conv_igemm +
+    conv_wgrad kernel families."""
+    from stroke_prediction_amd.runtime.cae_engine import ENC_LAYERS, DEC_LAYERS, channel_map
+    from stroke_prediction_amd.runtime import plan as P
+    cm = channel_map(channels or CAE_CHANNELS)
+    ideal, flop_total, bytes_total = 0.0, 0.0, 0.0
+    for table, dims, passes in ((ENC_LAYERS, (d, hw, hw), 3), (DEC_LAYERS, None, 4)):
+        if dims is None:
+            dims = enc_out
+        for i, (kind, ci, co, k, s_, p_) in enumerate(table):
+            cin, cout = cm[ci], cm[co]
+            mk = P.conv_fwd_op if kind == "conv" else P.convT_fwd_op
+            op = mk(cin, cout, k, s_, p_, dims, -(-cin // 8) * 8, -(-cout // 8) * 8, 0)
+            vin, vout = batch * dims[0] * dims[1] * dims[2], batch * op.y_dims[0] * op.y_dims[1] * op.y_dims[2]
+            flop = 2.0 * batch * op.algo_macs * cin * cout
+            byt = (vin * cin + vout * cout) * 2.0
+            t = max(flop / (peak_tflops * 1e12), byt / (HBM_PEAK_GBS * 1e9))
+            n = 2 if (table is ENC_LAYERS and i == 0) else 3
+            ideal += passes * n * t
+            flop_total += passes * n * flop
+            bytes_total += passes * n * byt
+            dims = tuple(op.y_dims)
+        enc_out = dims
+    measured = sum(kernels[k]["time_s_per_step"] for k in ("conv_igemm", "conv_wgrad") if k in kernels)
+    return {"ideal_ms": 1e3 * ideal, "measured_ms": 1e3 * measured, "frac": ideal / measured if measured else None,
+            "algorithmic_gflop": flop_total / 1e9, "ideal_bf16_operand_mb": bytes_total / 1e6,
+            "definition": "sum over 10 encoder layers x 3 passes + 12 decoder layers x 4 passes x (fwd, dgrad, wgrad) of "
+                          "max(FLOP / %.0f TFLOP/s, bf16 operand bytes / %.0f GB/s)" % (peak_tflops, HBM_PEAK_GBS)}
+
+
 def init_dist(world, dev):
     import torch.distributed as dist
     if world > 1 or os.environ.get("SP_FORCE_SYNC"):      # SP_FORCE_SYNC: 1-rank RCCL group, rehearses capture on one GPU
@@ -609,6 +643,8 @@ def bench_cae(args, world, rank, dev):
                                       traffic_key="cae_conv_igemm" if (d == 28 and args.batch == 4 and args.dtype == "bf16") else None)
         if roof:
             res["roofline"], res["kernels"] = roof, kernels
+            if args.dtype == "bf16":
+                roof["conv_roofline"] = conv_roofline_cae(d, hw, args.batch, PEAK_TFLOPS[args.dtype], kernels)
         if d in CAE_TRAIN_GFLOP_PER_SAMPLE:
             res["train_step_tflops"] = CAE_TRAIN_GFLOP_PER_SAMPLE[d] * 1e9 * world * args.batch * args.steps / dt / 1e12
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -721,6 +757,8 @@ def secondary_workloads(args, dev):
                  "value": r["value"], "unit": r["unit"], "steps": r["steps"], "warmup": r["warmup"]}
             if r.get("roofline"):
                 c["roofline"] = {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")}
+                if r["roofline"].get("conv_roofline"):
+                    c["roofline"]["conv_roofline"] = {k: r["roofline"]["conv_roofline"][k] for k in ("ideal_ms", "measured_ms", "frac")}
             if r.get("train_step_tflops") is not None:
                 c["train_step_tflops"] = r["train_step_tflops"]
             if r.get("parity"):

@@ -632,6 +632,9 @@ int sp_comm_unique_id(void* id128);                            /* ncclGetUniqueI
 int sp_comm_init_rank(void** comm, int32_t nranks, const void* id128, int32_t rank);
 int sp_comm_destroy(void* comm);
 int sp_allreduce_flat(void* comm, float* buf, int64_t n, sp_stream_t stream);        /* buf = sum over ranks, in place */
+/* the same for the fp64 accumulators the exact data-parallel mode exchanges (BatchNorm sum / sum^2 and sum g / sum g*x rows, Dice
+ * sums: SURVEY 8e items 2-3); a few KB per call, latency-bound */
+int sp_allreduce_flat_f64(void* comm, double* buf, int64_t n, sp_stream_t stream);
 /* two-shot form for the xGMI full mesh: buf holds nranks chunks of `chunk` floats; after the reduce-scatter chunk `rank` of
  * this rank's buf is the sum; the all-gather then fills the other chunks */
 int sp_reduce_scatter_flat(void* comm, float* buf, int64_t chunk, int32_t rank, sp_stream_t stream);

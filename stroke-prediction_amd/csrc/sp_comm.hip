@@ -36,7 +36,7 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::once_flag g_once;
-const int kNcclFloat = 7, kNcclSum = 0;                        // ncclFloat32, ncclSum (rccl.h)
+const int kNcclFloat = 7, kNcclDouble = 8, kNcclSum = 0;       // ncclFloat32, ncclFloat64, ncclSum (rccl.h)
 
 void load_rccl() {
   const char* names[] = {"librccl.so.1", "librccl.so"};
@@ -99,6 +99,13 @@ extern "C" int sp_allreduce_flat(void* comm, float* buf, int64_t n, sp_stream_t 
   SP_CHECK_ARG(comm && buf && n > 0, "sp_allreduce_flat: bad arguments");
   if (int rc = need_rccl("sp_allreduce_flat")) return rc;
   return check(g_rccl.allreduce(buf, buf, (size_t)n, kNcclFloat, kNcclSum, comm, reinterpret_cast<hipStream_t>(stream)), "sp_allreduce_flat");
+}
+
+// the fp64 accumulators of the exact data-parallel mode (BatchNorm sums, Dice sums: a few KB each, include/stroke_amd.h conventions)
+extern "C" int sp_allreduce_flat_f64(void* comm, double* buf, int64_t n, sp_stream_t stream) {
+  SP_CHECK_ARG(comm && buf && n > 0, "sp_allreduce_flat_f64: bad arguments");
+  if (int rc = need_rccl("sp_allreduce_flat_f64")) return rc;
+  return check(g_rccl.allreduce(buf, buf, (size_t)n, kNcclDouble, kNcclSum, comm, reinterpret_cast<hipStream_t>(stream)), "sp_allreduce_flat_f64");
 }
 
 // two-shot form: rank r ends with the sum of elements [r*chunk, (r+1)*chunk) after the reduce-scatter (in place, at its own

@@ -250,10 +250,20 @@ class Learner(Inference):
         # call, 1.4 MB: latency-bound either way) and the fused Adam launch run eagerly.  SP_DIST_GRAPH=1 captures the
         # collectives too (works with a one-rank communicator; not rehearsable with several ranks on a one-GPU box).
         sync_fn = getattr(self._model, "grad_sync", None)
-        split = sync_fn is not None and not os.environ.get("SP_DIST_GRAPH")
-        if sync_fn is not None:
+        owner = getattr(sync_fn, "__self__", None)                   # the parallel.DataParallelSync that installed the exchange
+        direct = getattr(owner, "direct", None) is not None        # ... through a communicator of our own (capturable)
+        # how the gradient exchange meets the graph:
+        #  * direct communicator (DataParallelSync's default from 8 MB of gradients on, or SP_DIST_GRAPH=1): the WHOLE step is one
+        #    graph; the bucketed exchange sits inside it as forked branches (bucket k's all-reduce beside the backward of bucket
+        #    k+1), and so do the BatchNorm / Dice sum exchanges of the exact mode;
+        #  * torch.distributed exchange (the 1.4 MB U-Net): forward + loss + backward are one graph, then ONE all-reduce of the
+        #    flat buffer and the fused Adam launch follow eagerly; the exact mode (collectives inside forward and backward) is
+        #    then not captured at all.
+        capture_all = sync_fn is None or direct or bool(os.environ.get("SP_DIST_GRAPH"))
+        split = not capture_all
+        if sync_fn is not None and not direct:
             from stroke_prediction_amd.runtime import layers as _layers
-            if _layers.SYNC["on"]:                # exact mode exchanges BatchNorm sums inside forward and backward: no capture
+            if _layers.SYNC["on"]:                # exact mode over torch.distributed: collectives inside forward and backward
                 return self._optimise(batch, epoch)
         if g["graph"] is None:
             if g["warm"] < self.GRAPH_WARMUP:

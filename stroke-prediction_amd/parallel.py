@@ -49,10 +49,12 @@ class DirectComm:
     def all_reduce_async(self, t, two_shot=False):
         """sum of the fp32 tensor t over the ranks, in place, on the communicator's stream (ordered after everything enqueued
         on the current stream so far); ``wait`` makes the current stream wait for it"""
-        assert t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda
+        assert t.dtype in (torch.float32, torch.float64) and t.is_contiguous() and t.is_cuda
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         n = t.numel()
-        if two_shot and self.world > 1 and n % self.world == 0:
+        if t.dtype == torch.float64:       # the accumulators of the exact mode (BatchNorm / Dice sums)
+            self._L.call("sp_allreduce_flat_f64", self._comm, t.data_ptr(), n, self.stream.cuda_stream)
+        elif two_shot and self.world > 1 and n % self.world == 0:
             chunk = n // self.world
             self._L.call("sp_reduce_scatter_flat", self._comm, t.data_ptr(), chunk, self.rank, self.stream.cuda_stream)
             self._L.call("sp_allgather_flat", self._comm, t.data_ptr(), chunk, self.rank, self.stream.cuda_stream)
@@ -83,7 +85,17 @@ class DataParallelSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.nbuckets_last = 0
         if direct is None:
-            direct = os.environ.get("SP_DIST_DIRECT", "0").strip().lower() in ("1", "true", "yes", "on")
+            # default: a communicator of our own (capturable: the exchange then sits INSIDE a Learner(graph=True) step as forked
+            # branches at the bucket boundaries, bucket k travelling under the backward of bucket k+1) when there is something to
+            # overlap -- flat gradients of SP_DIST_DIRECT_MIN_BYTES (8 MB) and more: the CAE's 18.9 MB, the 4-scale net's 23.4 MB.
+            # The 1.4 MB of the default U-Net stay one torch.distributed all-reduce after the replayed graph (latency-bound
+            # either way).  SP_DIST_DIRECT=1 / 0 forces either.  UNMEASURED on more than one GPU.
+            env = os.environ.get("SP_DIST_DIRECT", "").strip().lower()
+            if env:
+                direct = env in ("1", "true", "yes", "on")
+            else:
+                nbytes = 4 * sum(p.numel() for p in model.parameters())
+                direct = nbytes >= int(os.environ.get("SP_DIST_DIRECT_MIN_BYTES", str(8 << 20)))
         # direct: the gradient exchange goes through sp_allreduce_flat on a communicator of our own (DirectComm)
         self.direct = DirectComm(process_group) if (direct and dist.is_initialized() and torch.cuda.is_available()
                                                     and dist.get_backend(process_group) != "gloo") else None
@@ -94,7 +106,7 @@ class DataParallelSync:
             self.broadcast_parameters()
             if mode == "exact":
                 from stroke_prediction_amd.runtime import layers
-                layers.SYNC.update(group=process_group, world=self.world, on=True)
+                layers.SYNC.update(group=process_group, world=self.world, on=True, direct=self.direct)
             if optimizer is not None:
                 optimizer.register_step_pre_hook(lambda *a, **k: self.sync())
 
@@ -103,7 +115,7 @@ class DataParallelSync:
             self.direct.close()
             self.direct = None
         from stroke_prediction_amd.runtime import layers
-        layers.SYNC.update(group=None, world=1, on=False)
+        layers.SYNC.update(group=None, world=1, on=False, direct=None)
         self.model.grad_sync = None
         self.model.grad_bucket_ready = None
 

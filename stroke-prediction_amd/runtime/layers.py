@@ -18,10 +18,19 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 # exact data-parallel mode (parallel.DataParallelSync(mode="exact")): BatchNorm sums are all-reduced so every rank
 # normalises with the statistics of the GLOBAL batch, as the single-process reference does
-SYNC = {"group": None, "world": 1, "on": False}
+SYNC = {"group": None, "world": 1, "on": False, "direct": None}
 
 
 def _allreduce(t):
+    """sum of an accumulator tensor over the ranks, in place, visible to what the current stream runs next.  With a
+    communicator of our own (parallel.DirectComm: ``direct``) the collective is an ``sp_allreduce_flat[_f64]`` call on that
+    communicator's stream, forked from and joined to the current one -- a node like any other inside a captured step;
+    otherwise torch.distributed's (its NCCL collectives run on the process group's stream: eager steps only)."""
+    d = SYNC.get("direct")
+    if d is not None:
+        d.all_reduce_async(t)
+        d.wait()
+        return
     import torch.distributed as dist
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=SYNC["group"])
 

@@ -84,6 +84,7 @@ _SIGS = {
     "sp_comm_init_rank": ([C.POINTER(vp), i32, vp, i32], i32),
     "sp_comm_destroy": ([vp], i32),
     "sp_allreduce_flat": ([vp, vp, i64, vp], i32),
+    "sp_allreduce_flat_f64": ([vp, vp, i64, vp], i32),
     "sp_reduce_scatter_flat": ([vp, vp, i64, i32, vp], i32),
     "sp_allgather_flat": ([vp, vp, i64, i32, vp], i32),
     "sp_surface_distances": ([vp, vp, f32, i32, vp, vp, vp, vp], i32),

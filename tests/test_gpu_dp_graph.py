@@ -1,0 +1,162 @@
+"""Data parallelism under ``Learner(graph=True)``:
+
+* with a communicator of our own (``parallel.DirectComm`` over the C ABI's ``sp_allreduce_flat[_f64]``) the WHOLE step is one
+  hipGraph -- the bucketed gradient exchange and, in the exact mode, the BatchNorm / Dice sum exchanges are forked branches inside
+  it.  A one-GPU box allows one RCCL rank, where a sum over the ranks is the identity: what is rehearsed is the capture, the
+  stream forks / joins and that replayed steps equal eager ones;
+* two gloo ranks on the one GPU, ``Learner(graph=True)`` + ``DataParallelSync`` for three steps with a ``save_model`` in between:
+  both ranks issue the SAME sequence of collectives (a rank-0-only side effect must not desynchronise the ranks) and
+  end with identical parameters.
+
+Every multi-rank number of this repository is unmeasured on hardware with N > 1."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CH = [2, 16, 32, 64, 32, 16, 32, 2]
+
+
+def _one_rank_rccl(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SP_FORCE_SYNC="1")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import stroke_prediction_amd  # noqa: F401
+    from oracle import weights as W
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.UnetSegmentationLearner import UnetSegmentationLearner
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    from stroke_prediction_amd.parallel import DataParallelSync, DirectComm
+
+    class Loader(list):
+        batch_size = 2
+    seed = 11
+    x, y = W.unet_inputs(2, (52, 52, 52), seed)
+    batch = {"case_id": [0, 1], "images": x.cuda(), "labels": y.cuda(), "clinical": torch.zeros(2, 5, 1, 1, 1)}
+    res = {}
+    counted = {"n": 0}
+    orig = DirectComm.all_reduce_async
+
+    def counting(self, t, two_shot=False):
+        counted["n"] += 1
+        counted.setdefault("dtypes", set()).add(str(t.dtype))
+        counted["captured"] = counted.get("captured", 0) + int(torch.cuda.is_current_stream_capturing())
+        return orig(self, t, two_shot)
+    DirectComm.all_reduce_async = counting
+    for mode in ("fast", "exact"):
+        for tag, graph in (("eager", False), ("graph", True)):
+            model = Unet3D(CH, dtype="f32")
+            model.load_state_dict(W.make_state_dict(W.unet_spec(CH), seed))
+            model = model.cuda().train()
+            sync = DataParallelSync(model, mode=mode, direct=True)
+            assert sync.direct is not None
+            opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999), capturable=True, grad_scale=sync.grad_scale)
+            attach_flat_grads(model)
+            learner = UnetSegmentationLearner(Loader([batch]), None, model, opt, None, 1, BatchDiceLoss([1.0]), None,
+                                              "/tmp/_dp_graph_%s_%s" % (mode, tag), graph=graph, batch_metrics=False)
+            learner.GRAPH_WARMUP = 1
+            counted.update(n=0, captured=0)
+            losses = [float(learner.train_batch(batch, 0).loss) for _ in range(4)]
+            if graph:
+                gs = [g for g in learner._graphs.values() if g["graph"] is not None]
+                res["%s_whole_step_captured" % mode] = bool(gs) and not any(g.get("split") for g in gs)
+                res["%s_collectives_in_capture" % mode] = counted["captured"]
+            res["%s_%s" % (mode, tag)] = (losses, model.flat_buffers()[0].detach().cpu().numpy().copy())
+            res["%s_dtypes" % mode] = sorted(counted.get("dtypes", []))
+            sync.close()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_direct_exchange_is_captured_inside_the_step_fast_and_exact_mode():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_rccl, args=(29761, q))
+    p.start()
+    res = q.get(timeout=900)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for mode in ("fast", "exact"):
+        assert res["%s_whole_step_captured" % mode], mode
+        # fast: the gradient buckets; exact: also 10 + 10 BatchNorm sum exchanges and the Dice sums -- all inside the capture
+        assert res["%s_collectives_in_capture" % mode] >= (2 if mode == "fast" else 20), (mode, res["%s_collectives_in_capture" % mode])
+        le, pe = res["%s_eager" % mode]
+        lg, pg = res["%s_graph" % mode]
+        assert max(abs(a - b) for a, b in zip(le, lg)) < 2e-3, (mode, le, lg)
+        # four Adam steps: run-to-run noise of the three-step fixture test (an element with |g| ~ eps moves by O(lr))
+        assert float(abs(pe - pg).max()) < 8e-3 and float(abs(pe - pg).mean()) < 2e-4, mode
+    assert "torch.float64" in res["exact_dtypes"]          # the accumulators travel as fp64 (sp_allreduce_flat_f64)
+
+
+def _two_gloo_ranks(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stroke_prediction_amd  # noqa: F401
+    from oracle import weights as W
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.learner.UnetSegmentationLearner import UnetSegmentationLearner
+    from stroke_prediction_amd.optim import FusedAdam, attach_flat_grads
+    from stroke_prediction_amd.parallel import DataParallelSync
+    log = []
+    for name in ("all_reduce", "broadcast", "barrier", "all_gather", "reduce_scatter_tensor"):
+        fn = getattr(dist, name)
+
+        def wrapped(*a, _fn=fn, _name=name, **k):
+            t = a[0] if a and torch.is_tensor(a[0]) else None
+            log.append((_name, None if t is None else (tuple(t.shape), str(t.dtype))))
+            return _fn(*a, **k)
+        setattr(dist, name, wrapped)
+
+    class Loader(list):
+        batch_size = 2
+    seed = 11
+    x, y = W.unet_inputs(4, (52, 52, 52), seed)
+    lo = 2 * rank
+    batch = {"case_id": [0, 1], "images": x[lo:lo + 2].cuda(), "labels": y[lo:lo + 2].cuda(), "clinical": torch.zeros(2, 5, 1, 1, 1)}
+    torch.manual_seed(100 + rank)                       # different initial weights per rank: broadcast_parameters must align them
+    model = Unet3D(CH, dtype="bf16").cuda().train()
+    sync = DataParallelSync(model)
+    opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999), capturable=True, grad_scale=sync.grad_scale)
+    attach_flat_grads(model)
+    learner = UnetSegmentationLearner(Loader([batch]), None, model, opt, None, 1, BatchDiceLoss([1.0]), None,
+                                      "/tmp/_dp_sym_rank%d" % rank, graph=True, batch_metrics=False)
+    learner.GRAPH_WARMUP = 1
+    for step in range(4):
+        learner.train_batch(batch, 0)
+        if step == 1:
+            learner.save_model()            # rank 0 writes, the others return: no collective, no re-capture on one rank only
+            learner.save_training()
+    captured = [g for g in learner._graphs.values() if g["graph"] is not None]
+    import hashlib
+    flat = hashlib.sha256(model.flat_buffers()[0].detach().cpu().numpy().tobytes()).hexdigest()      # (plain data through the queue)
+    q.put((rank, list(log), flat, len(captured), [bool(g.get("split")) for g in captured]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_issue_the_same_collectives_under_graph_replay_and_save():
+    world, port = 2, 29771
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_gloo_ranks, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((r[0], r[1:]) for r in (q.get(timeout=900) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (log0, flat0, n0, split0), (log1, flat1, n1, split1) = got[0], got[1]
+    assert log0 == log1, (log0, log1)                                   # the same collectives in the same order on both ranks
+    assert sum(1 for c in log0 if c[0] == "all_reduce") >= 4            # one gradient exchange per step at least
+    assert n0 == n1 == 1 and split0 == split1 == [True]                 # one capture each, exchange outside the graph (torch.distributed)
+    assert flat0 == flat1                                               # replicas stay identical, bit for bit
