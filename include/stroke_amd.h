@@ -260,6 +260,25 @@ int sp_conv3d_run(const sp_conv3d_desc* d, const sp_conv3d_plan_t* plan, const v
                   int32_t with_bias, int32_t act, float act_param, double* stats, int32_t stats_nrep, int64_t x_plane,
                   sp_stream_t stream);
 
+/* The layer's WEIGHT gradient for the same header-only caller (grad is ignored in `d`): dw[co][ci][27] (fp32, nn.Conv3d layout,
+ * ACCUMULATED into) += sum over voxels of dz[v][co] * xin[v + tap][ci] with x the layer's bf16 input [B][D][H][W][Cin] and dz the
+ * bf16 output gradient [B][D-2][H-2][W-2][Cout].  bn_scale / bn_shift (the BatchNorm in front of the conv, as sp_bn_finalize
+ * writes them): xin = scale * x + shift is folded into the finish pass (dW = scale * acc + shift * sum dz) and needs dbias_sums
+ * = sum over voxels of dz per output channel (fp64: one row, dbias_stride = 0, or SP_REDUCE_ROWS replica rows of dbias_stride
+ * doubles as sp_bn_act_bwd & co fill them); dbias_grad (or NULL) += sum dz; w_for_bn + bn_sums (or NULL): the BatchNorm-backward
+ * sums (sum g, sum g*x) of the layer's input gradient g read off the accumulator (bn_nrep replica rows of [Cin][2] doubles,
+ * zeroed by the caller), which makes the data gradient of a first layer unnecessary.  x_plane as for sp_conv3d_run. */
+typedef struct sp_conv3d_wgrad_plan_t {
+  int32_t CoT, CiT, nblocks, Do, Ho, Wo;
+  int64_t workspace_bytes, off_taps, off_tapsrc, off_acc;
+} sp_conv3d_wgrad_plan_t;
+int sp_conv3d_wgrad_plan(const sp_conv3d_desc* d, sp_conv3d_wgrad_plan_t* p);
+int sp_conv3d_wgrad_init(const sp_conv3d_desc* d, const sp_conv3d_wgrad_plan_t* p, void* workspace, sp_stream_t stream);
+int sp_conv3d_wgrad_run(const sp_conv3d_desc* d, const sp_conv3d_wgrad_plan_t* p, void* workspace, const void* x, const void* dz,
+                        float* dw, const float* bn_scale /* or NULL */, const float* bn_shift, const double* dbias_sums /* or NULL */,
+                        int32_t dbias_stride, float* dbias_grad /* or NULL */, const float* w_for_bn /* or NULL */,
+                        double* bn_sums /* or NULL */, int32_t bn_nrep, int64_t x_plane, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ FC-like layers: split-K convolution without LDS
  * The 800 <-> 100 channel layers around the CAE's latent (Cae3D.py:72-76, 178-180): a few hundred output voxels per sample,
  * K = taps x Cin in the tens of thousands.  One workgroup per (64 output voxels, 8 output tiles, TAP); a second kernel sums the

@@ -129,3 +129,76 @@ extern "C" int sp_conv3d_run(const sp_conv3d_desc* d, const sp_conv3d_plan_t* p,
   a.x_plane = x_plane;
   return sp_conv3d_zm(&a, ws + p->off_zero, stream);
 }
+
+// ------------------------------------------------------------------------------------------------ weight gradient, header only
+// dW of the same layer (Block3x3x3's conv, Unet3D.py:19,22) for a caller with this header and nothing else: the plan sizes one
+// workspace (tap tables + one partial block [27][Cout][Cin] per persistent workgroup), init uploads the tables, run = the
+// row-sliding LDS-DMA kernel (csrc/sp_wgrad_zr.hip, through sp_conv3d_wgrad) + the finish pass that adds the blocks up into dw --
+// with the layer's input BatchNorm folded (dW = s * acc + t * sum dz; the BatchNorm-backward sums come out of the same pass) or
+// without.  Mirrors ops.WgradRunner (the Python host side); tests/test_gpu_round2.py holds the two against each other.
+extern "C" int sp_conv3d_wgrad_plan(const sp_conv3d_desc* d, sp_conv3d_wgrad_plan_t* p) {
+  SP_CHECK_ARG(d && p, "sp_conv3d_wgrad_plan: null pointer");
+  SP_CHECK_ARG(d->B >= 1 && d->D >= 3 && d->H >= 3 && d->W >= 3, "sp_conv3d_wgrad_plan: volume smaller than the kernel");
+  SP_CHECK_ARG(d->Cin >= 16 && d->Cout >= 16 && d->Cin % 16 == 0 && d->Cout % 16 == 0, "sp_conv3d_wgrad_plan: channels must be multiples of 16 (pad with zero channels)");
+  memset(p, 0, sizeof(*p));
+  p->CoT = d->Cout / 16; p->CiT = d->Cin / 16;
+  p->Do = d->D - 2; p->Ho = d->H - 2; p->Wo = d->W - 2;
+  // one partial block per persistent workgroup: >= ~512 output voxels each, the (cout, cin) tile grid times the workgroups ~2 per CU
+  const int cob = p->CoT >= 4 ? 4 : (p->CoT >= 2 ? 2 : 1);
+  const int yz = ((p->CoT + cob - 1) / cob) * p->CiT;                   // (one input plane per workgroup: cib = 1)
+  const int64_t vox = (int64_t)d->B * p->Do * p->Ho * p->Wo;
+  int64_t nb = 512 / yz < vox / 512 ? 512 / yz : vox / 512;
+  nb = (nb < 8 ? 8 : nb) / 8 * 8;
+  p->nblocks = (int32_t)nb;
+  int64_t off = 0;
+  p->off_taps = off;   off += align256(27 * 3 * 4);
+  p->off_tapsrc = off; off += align256(27 * 4);
+  p->off_acc = off;    off += align256((int64_t)p->nblocks * 27 * d->Cout * d->Cin * 4);
+  p->workspace_bytes = off;
+  return SP_OK;
+}
+
+extern "C" int sp_conv3d_wgrad_init(const sp_conv3d_desc* d, const sp_conv3d_wgrad_plan_t* p, void* workspace, sp_stream_t stream) {
+  SP_CHECK_ARG(d && p && workspace, "sp_conv3d_wgrad_init: null pointer");
+  int32_t taps[27 * 3], src[27];
+  for (int t = 0; t < 27; ++t) { taps[3 * t] = t / 9; taps[3 * t + 1] = (t / 3) % 3; taps[3 * t + 2] = t % 3; src[t] = t; }
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  SP_CHECK_HIP(hipMemcpyAsync(ws + p->off_taps, taps, sizeof taps, hipMemcpyHostToDevice, st), "sp_conv3d_wgrad_init");
+  SP_CHECK_HIP(hipMemcpyAsync(ws + p->off_tapsrc, src, sizeof src, hipMemcpyHostToDevice, st), "sp_conv3d_wgrad_init");
+  SP_CHECK_HIP(hipStreamSynchronize(st), "sp_conv3d_wgrad_init");
+  return SP_OK;
+}
+
+extern "C" int sp_conv3d_wgrad_run(const sp_conv3d_desc* d, const sp_conv3d_wgrad_plan_t* p, void* workspace, const void* x, const void* dz,
+                                   float* dw, const float* bn_scale, const float* bn_shift, const double* dbias_sums, int32_t dbias_stride,
+                                   float* dbias_grad, const float* w_for_bn, double* bn_sums, int32_t bn_nrep, int64_t x_plane,
+                                   sp_stream_t stream) {
+  SP_CHECK_ARG(d && p && workspace && x && dz && dw, "sp_conv3d_wgrad_run: null pointer");
+  SP_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "sp_conv3d_wgrad_run: BatchNorm scale and shift come together");
+  SP_CHECK_ARG(!bn_scale || dbias_sums, "sp_conv3d_wgrad_run: the folded form needs dbias_sums = sum over voxels of dz per output channel");
+  SP_CHECK_ARG(!bn_sums || (bn_scale && w_for_bn && bn_nrep >= 1), "sp_conv3d_wgrad_run: BatchNorm-backward sums need the folded form and the conv weight");
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  sp_wgrad_args a;
+  memset(&a, 0, sizeof(a));
+  a.x = x; a.dz = dz;
+  a.dw_acc = reinterpret_cast<float*>(ws + p->off_acc);
+  a.taps = reinterpret_cast<const int32_t*>(ws + p->off_taps);
+  a.dtype = SP_BF16;
+  a.B = d->B; a.Di = d->D; a.Hi = d->H; a.Wi = d->W; a.CPi = d->Cin;
+  a.Do = p->Do; a.Ho = p->Ho; a.Wo = p->Wo; a.CPo = d->Cout;
+  a.sD = a.sH = a.sW = 1;
+  a.ntap = 27; a.kD = a.kH = a.kW = 3;
+  a.CoT = p->CoT; a.CiT = p->CiT;
+  a.nblocks = p->nblocks; a.dma = 1; a.parts = 1; a.cib = 1; a.zs = 1;
+  a.x_plane = x_plane;
+  int rc = sp_conv3d_wgrad(&a, stream);
+  if (rc != SP_OK) return rc;
+  const int32_t* tapsrc = reinterpret_cast<const int32_t*>(ws + p->off_tapsrc);
+  const int64_t sCo = (int64_t)d->Cin * 27, sCi = 27;                  // nn.Conv3d weight layout [Cout][Cin][27]
+  if (bn_scale)
+    return sp_wgrad_finish_folded(a.dw_acc, p->nblocks, tapsrc, 27, d->Cout, d->Cin, d->Cout, d->Cin, sCo, sCi, bn_scale, bn_shift, dbias_sums,
+                                  dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, 0, dbias_stride, stream);
+  return sp_wgrad_finish(a.dw_acc, p->nblocks, tapsrc, 27, d->Cout, d->Cin, d->Cout, d->Cin, sCo, sCi, dw, dbias_grad ? dbias_sums : nullptr,
+                         dbias_grad, d->Cout, dbias_stride, stream);
+}

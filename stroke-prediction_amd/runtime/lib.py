@@ -70,6 +70,11 @@ class Conv3dPlan(C.Structure):       # sp_conv3d_plan_t
                [(n, i64) for n in ("x_elems", "y_elems", "workspace_bytes", "off_zero", "off_ktab", "off_kmap", "off_bias", "off_wfrag")]
 
 
+class Conv3dWgradPlan(C.Structure):  # sp_conv3d_wgrad_plan_t
+    _fields_ = [(n, i32) for n in ("CoT", "CiT", "nblocks", "Do", "Ho", "Wo")] + \
+               [(n, i64) for n in ("workspace_bytes", "off_taps", "off_tapsrc", "off_acc")]
+
+
 _SIGS = {
     "sp_conv_fc_workspace": ([i32, i32, i32, i32, i32, i32, C.POINTER(i64)], i32),
     "sp_conv_fc": ([C.POINTER(ConvFcArgs), vp], i32),
@@ -78,6 +83,9 @@ _SIGS = {
     "sp_conv3d_init": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp], i32),
     "sp_conv3d_set_weights": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp, vp, vp, vp, vp], i32),
     "sp_conv3d_run": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dPlan), vp, vp, vp, i32, i32, f32, vp, i32, i64, vp], i32),
+    "sp_conv3d_wgrad_plan": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dWgradPlan)], i32),
+    "sp_conv3d_wgrad_init": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dWgradPlan), vp, vp], i32),
+    "sp_conv3d_wgrad_run": ([C.POINTER(Conv3dDesc), C.POINTER(Conv3dWgradPlan), vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, i32, i64, vp], i32),
     "sp_version": ([], i32),
     "sp_comm_available": ([], i32),
     "sp_comm_unique_id": ([vp], i32),

@@ -353,6 +353,54 @@ def test_header_only_conv3d_entry_points(cin, cout, grad, fold):
         torch.testing.assert_close(stats.sum(0)[:, 0].cpu(), got.double().sum((0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(got.numel() / cout))
 
 
+@pytest.mark.parametrize("cin,cout,fold", [(16, 16, True), (32, 16, False), (16, 32, True), (48, 16, True)])
+def test_header_only_weight_gradient_entry_points(cin, cout, fold):
+    """the third GEMM of the layer from include/stroke_amd.h alone (sp_conv3d_wgrad_plan / _init / _run: no
+    runtime/plan.py, no WgradRunner) -- dW, the bias gradient and, with the BatchNorm folded, the BatchNorm-backward sums -- against
+    F.conv3d autograd on the same bf16 operands.  Together with sp_conv3d_plan(grad = 0 / 1) a C caller trains one Block3x3x3 conv."""
+    import ctypes as C
+    lib = L.load()
+    B, dims = 2, (9, 21, 37)
+    g = torch.Generator().manual_seed(cin * 5 + cout + int(fold))
+    d = L.Conv3dDesc(B, cin, cout, *dims, 2)
+    pl = L.Conv3dWgradPlan()
+    assert lib.sp_conv3d_wgrad_plan(C.byref(d), C.byref(pl)) == 0, L.last_error()
+    assert (pl.Do, pl.Ho, pl.Wo) == tuple(x - 2 for x in dims) and pl.nblocks % 8 == 0
+    ws = torch.empty(pl.workspace_bytes, dtype=torch.uint8, device=DEV)
+    st = O.stream()
+    assert lib.sp_conv3d_wgrad_init(C.byref(d), C.byref(pl), ws.data_ptr(), st) == 0, L.last_error()
+    x = bf(torch.randn(B, cin, *dims, generator=g))
+    dz = bf(torch.randn(B, cout, pl.Do, pl.Ho, pl.Wo, generator=g))
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin))
+    scale, shift = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    xd, dzd, wd, scd, shd = _to_cl(x, cin), _to_cl(dz, cout), w.to(DEV), scale.to(DEV), shift.to(DEV)
+    dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    dbias_sums = dz.double().sum((0, 2, 3, 4)).to(DEV)                # one row (dbias_stride = 0)
+    nrep = 4
+    bn_sums = torch.zeros(nrep, cin, 2, dtype=torch.float64, device=DEV)
+    rc = lib.sp_conv3d_wgrad_run(C.byref(d), C.byref(pl), ws.data_ptr(), xd.data_ptr(), dzd.data_ptr(), dw.data_ptr(),
+                                 scd.data_ptr() if fold else None, shd.data_ptr() if fold else None, dbias_sums.data_ptr(), 0, db.data_ptr(),
+                                 wd.data_ptr() if fold else None, bn_sums.data_ptr() if fold else None, nrep, 0, st)
+    assert rc == 0, L.last_error()
+    # reference: autograd of conv3d(scale * x + shift, w) contracted with dz
+    xin = (x * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)) if fold else x
+    xin = xin.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    (F.conv3d(xin, wr) * dz).sum().backward()
+    scale_ref = float(wr.grad.abs().max())
+    assert float((dw.cpu() - wr.grad).abs().max()) < 2e-2 * scale_ref + 1e-3, (float((dw.cpu() - wr.grad).abs().max()), scale_ref)
+    torch.testing.assert_close(db.cpu(), dz.sum((0, 2, 3, 4)), rtol=1e-4, atol=1e-3)
+    if fold:      # BatchNorm-backward sums of the input gradient g = conv_transpose(dz, w): (sum g, sum g * x) per input channel
+        gin = F.conv_transpose3d(dz, w)
+        ref = torch.stack((gin.double().sum((0, 2, 3, 4)), (gin.double() * x.double()).sum((0, 2, 3, 4))), 1)
+        got = bn_sums.sum(0).cpu()
+        torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+    # descriptors the entry points must refuse, with a message
+    bad = L.Conv3dDesc(1, 24, 16, 9, 9, 9, 2)
+    assert lib.sp_conv3d_wgrad_plan(C.byref(bad), C.byref(pl)) != 0 and "multiples of 16" in L.last_error()
+
+
 @pytest.mark.parametrize("cin,cout,dims,B,pad", [(16, 16, (9, 36, 40), 2, (1, 0, 0)), (24, 24, (6, 34, 36), 1, (1, 2, 2)),
                                                  (16, 24, (5, 33, 20), 2, (1, 1, 1)), (32, 16, (4, 40, 17), 2, (0, 0, 0))])
 def test_z_marching_kernel_padded_elu(cin, cout, dims, B, pad):

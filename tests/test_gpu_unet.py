@@ -48,8 +48,12 @@ def rel_l2(a, b):
 @pytest.mark.parametrize("dtype,size,seed,tol_seg,tol_grad", [
     ("f32", (44, 44, 44), 11, 1e-4, 3e-2),
     ("f32", (44, 48, 52), 13, 1e-4, 3e-2),
-    ("bf16", (44, 44, 44), 11, 8e-3, 0.3),
-    ("bf16", (48, 48, 48), 12, 8e-3, 0.3),
+    # bf16 against the EMULATING oracle, measured (tools/probes/bf16_grad_probe.py; 44^3 / 48^3 / 60^3): tensors > 64 elements worst
+    # 0.19-0.24, median 0.15-0.18 -- two bf16 pipelines with different rounding points decorrelate at the LeakyReLU kinks; the bound
+    # below plus the median bound in the body replace round 3's 0.3.  (The modes whose gradients ARE close to fp32: f16x3 / bf16x3,
+    # tests/test_gpu_bf16x3.py.)
+    ("bf16", (44, 44, 44), 11, 8e-3, 0.26),
+    ("bf16", (48, 48, 48), 12, 8e-3, 0.26),
 ])
 def test_unet_train_step_matches_oracle(dtype, size, seed, tol_seg, tol_grad):
     x, y = W.unet_inputs(2, size, seed)
@@ -73,6 +77,9 @@ def test_unet_train_step_matches_oracle(dtype, size, seed, tol_seg, tol_grad):
     assert abs(loss.item() - loss_ref) < (1e-5 if dtype == "f32" else 5e-3)
     loss.backward()
     bad = []
+    if dtype == "bf16":
+        big = sorted(rel_l2(p.grad.cpu(), g_ref[n]) for n, p in model.named_parameters() if p.numel() > 64)
+        assert big[len(big) // 2] < 0.2, big
     for name, p in model.named_parameters():
         assert p.grad is not None, name
         e = rel_l2(p.grad.cpu(), g_ref[name])
