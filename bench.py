@@ -735,7 +735,7 @@ def secondary_workloads(args, dev):
     plan = [("cae_d28", dict(workload="cae", cae_depth=28, dtype="bf16"), True),
             ("cae_d124", dict(workload="cae", cae_depth=124, dtype="bf16"), False),
             ("unet4_bf16", dict(workload="unet4", dtype="bf16", batch=2, size=256), True),
-            ("unet4_fp8", dict(workload="unet4", dtype="fp8", batch=2, size=256), False),
+            ("unet4_fp8", dict(workload="unet4", dtype="fp8", batch=2, size=256), True),
             ("unet_f16x3", dict(workload="unet", dtype="f16x3"), False),
             ("unet_bf16x3", dict(workload="unet", dtype="bf16x3"), False),
             ("unet_f16", dict(workload="unet", dtype="f16"), False),

@@ -590,6 +590,65 @@ __global__ __launch_bounds__(32 * RL) void wgrad_finish_folded_parts_kernel(cons
   }
 }
 
+// The same for FEW, LARGE partial blocks (the 64..384-channel layers of the 4-scale network: 8-32 blocks of 1.7-7 MB).  The kernel
+// above takes 32 consecutive accumulator entries per workgroup = 32 input channels of ONE tap, and its read-modify-write of dw
+// then touches 32 different lines (dw is [co][ci][tap]: 27 floats apart) -- 1.8 M scattered 4-byte updates for 256 -> 256, 284 us
+// per launch, 2 ms of the fp8 step (profiles/r03_unet4_fp8_kernel_stats.csv).  Here a workgroup owns (one output channel, 32 input
+// channels, ALL taps): the accumulator rows come in as 128-byte pieces per (tap, block), the tile is transposed through LDS and
+// leaves as ONE contiguous 32 x ntap run of dw; the BatchNorm-backward sums are reduced over the taps first (2 atomics per input
+// channel and workgroup instead of 2 per entry).
+template <int NTAP>
+__global__ __launch_bounds__(256) void wgrad_finish_folded_tile_kernel(const float* __restrict__ acc, int nparts,
+                                                                       const int32_t* __restrict__ tapsrc, int CoP, int CiP, int Cout,
+                                                                       int Cin, int64_t sCo, int64_t sCi, const float* __restrict__ scale,
+                                                                       const float* __restrict__ shift, const double* __restrict__ dbias,
+                                                                       float* __restrict__ dw, float* __restrict__ dbias_grad,
+                                                                       const float* __restrict__ wbn, double* __restrict__ bn_sums,
+                                                                       int bn_nrep, int bn_cp, int dbs, float acc_scale) {
+  __shared__ float tile[NTAP][33];
+  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int ci0 = blockIdx.x * 32, co = blockIdx.y;
+  const int64_t total = (int64_t)NTAP * CoP * CiP;
+  if (dbias_grad && blockIdx.x == 0 && threadIdx.x == 0 && co < Cout) dbias_grad[co] += (float)sp_rows_sum(dbias, co, dbs);
+  const bool civ = ci0 + el < CiP;
+  for (int t = rl; t < NTAP; t += 8) {
+    const float* p = acc + ((int64_t)t * CoP + co) * CiP + ci0 + el;
+    float s0 = 0.f, s1 = 0.f;
+    if (civ) {
+      int r = 0;
+      for (; r + 1 < nparts; r += 2) { s0 += p[(size_t)r * total]; s1 += p[(size_t)(r + 1) * total]; }
+      if (r < nparts) s0 += p[(size_t)r * total];
+    }
+    tile[t][el] = (s0 + s1) * acc_scale;
+  }
+  __syncthreads();
+  if (co >= Cout) return;
+  const double db = sp_rows_sum(dbias, co, dbs);
+  const float dbf = (float)db;
+  // 32 x NTAP values of dw[co][ci0 .. ci0+31][:] in memory order (contiguous when sCi == NTAP and tapsrc is the identity)
+  for (int k = threadIdx.x; k < 32 * NTAP; k += 256) {
+    const int i = k / NTAP, t = k - i * NTAP;
+    const int ci = ci0 + i;
+    if (ci < Cin) {
+      const int64_t wi = co * sCo + ci * sCi + tapsrc[t];
+      dw[wi] += scale[ci] * tile[t][i] + shift[ci] * dbf;
+    }
+  }
+  if (bn_sums && threadIdx.x < 32 && ci0 + (int)threadIdx.x < Cin) {      // (sum g, sum g*x) of input channel ci: reduced over the taps first
+    const int ci = ci0 + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll 9
+    for (int t = 0; t < NTAP; ++t) {
+      const float w = wbn[co * sCo + ci * sCi + tapsrc[t]];
+      a0 += w;
+      a1 = fmaf(w, tile[t][threadIdx.x], a1);
+    }
+    double* dst = bn_sums + (size_t)((blockIdx.x + blockIdx.y) % bn_nrep) * bn_cp * 2 + ci * 2;
+    atomicAdd(dst, (double)a0 * db);
+    atomicAdd(dst + 1, (double)a1);
+  }
+}
+
 // dw[co,ci,tap] += scale[ci]*acc[tap][co][ci] + shift[ci]*dbias[co]   (BatchNorm folded out of the operand load)
 __global__ void wgrad_finish_folded_kernel(float* __restrict__ acc, const int32_t* __restrict__ tapsrc, int ntap,
                                            int CoP, int CiP, int Cout, int Cin, int64_t sCo, int64_t sCi,
@@ -624,6 +683,14 @@ static int wgrad_finish_folded_impl(float* dw_acc, int32_t nparts, const int32_t
   SP_CHECK_ARG(nparts >= 1 && Cout <= (total + 31) / 32 * 256, "sp_wgrad_finish_folded: nparts");      // (dbias_grad: one thread per output channel)
   SP_CHECK_ARG(!bn_sums || (w_for_bn && bn_nrep >= 1), "sp_wgrad_finish_folded: bn_sums needs the weights and a replica count");
   if (bn_cp <= 0) bn_cp = CiP;
+  static const int tile_max_ = getenv("SP_WGRAD_FINISH_TILE") ? atoi(getenv("SP_WGRAD_FINISH_TILE")) : 32;      // (0: off; A/B knob)
+  if (nparts > 1 && nparts <= tile_max_ && ntap == 27 && CiP % 32 == 0 && (int64_t)CoP * (CiP / 32) >= 512) {
+    hipLaunchKernelGGL(wgrad_finish_folded_tile_kernel<27>, dim3((unsigned)(CiP / 32), (unsigned)CoP), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dw_acc, nparts, tapsrc, CoP, CiP, Cout, Cin, sCo, sCi, scale, shift,
+                       dbias_sums, dw, dbias_grad, w_for_bn, bn_sums, bn_nrep, bn_cp, dbias_stride, acc_scale);
+    SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
+    return SP_OK;
+  }
   if (nparts > 1) {
     if (nparts >= 128)
       hipLaunchKernelGGL(wgrad_finish_folded_parts_kernel<32>, dim3((unsigned)((total + 31) / 32)), dim3(1024), 0,

@@ -432,3 +432,34 @@ def test_static_batch_skips_the_input_copy_and_changes_nothing():
             assert l5 != losses[-1]
         out[tag] = (losses, model.flat_buffers()[0].clone() if tag == "plain" else None)
     assert out["plain"][0] == out["static"][0], (out["plain"][0], out["static"][0])
+
+
+@pytest.mark.parametrize("cout,cin,cop,cip,nparts", [(128, 128, 128, 128, 8), (250, 150, 256, 160, 12), (64, 256, 64, 256, 32)])
+def test_tiled_weight_gradient_finish_matches_torch(cout, cin, cop, cip, nparts):
+    """sp_wgrad_finish_folded on few, large partial blocks (the 64..384-channel layers of the 4-scale network): the tiled finish
+    (one output channel x 32 input channels x all taps per workgroup, dw written as contiguous runs) against torch -- the sum
+    over the blocks, the folded BatchNorm, the bias gradient and the BatchNorm-backward sums reduced over the taps"""
+    g = torch.Generator(device=DEV).manual_seed(cout + cin)
+    acc = torch.randn(nparts, 27, cop, cip, generator=g, device=DEV)
+    scale = torch.rand(cip, generator=g, device=DEV) + 0.5
+    shift = torch.randn(cip, generator=g, device=DEV) * 0.1
+    dbias = torch.randn(cop, generator=g, device=DEV).double()
+    w = torch.randn(cout, cin, 27, generator=g, device=DEV)
+    dw = torch.randn(cout, cin, 27, generator=g, device=DEV)
+    dw0 = dw.clone()
+    db = torch.zeros(cout, device=DEV)
+    nrep = 4
+    bn = torch.zeros(nrep, cip, 2, dtype=torch.float64, device=DEV)
+    tapsrc = torch.arange(27, dtype=torch.int32, device=DEV)
+    L.call("sp_wgrad_finish_folded", O.ptr(acc), nparts, O.ptr(tapsrc), 27, cop, cip, cout, cin, cin * 27, 27, O.ptr(scale), O.ptr(shift),
+           O.ptr(dbias), O.ptr(dw), O.ptr(db), O.ptr(w), O.ptr(bn), nrep, 0, 0, O.stream())
+    a = acc.sum(0)[:, :cout, :cin].permute(1, 2, 0)                     # [co][ci][tap]
+    ref = dw0 + scale[:cin].view(1, -1, 1) * a + shift[:cin].view(1, -1, 1) * dbias[:cout].float().view(-1, 1, 1)
+    torch.testing.assert_close(dw, ref, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(db, dbias[:cout].float(), rtol=1e-6, atol=1e-6)
+    s0 = (w.double() * dbias[:cout].view(-1, 1, 1)).sum((0, 2))
+    s1 = (w.double() * a.double()).sum((0, 2))
+    got = bn.sum(0)
+    torch.testing.assert_close(got[:cin, 0], s0, rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(got[:cin, 1], s1, rtol=1e-5, atol=1e-2)
+    assert float(got[cin:].abs().max()) == 0.0 if cip > cin else True
