@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round profiles (run on the GPU box from the repo root): kernel-trace summaries of the default bench command and of
 # its serial twin, HBM traffic counters (separate --pmc passes) and the MFMA-busy counters of the conv kernels.
-# usage: tools/profile_round.sh r03 [unet|cae|unet4fp8]   (unet4fp8: kernel-trace summary of the fp8 4-scale step only)
+# usage: tools/profile_round.sh r04 [unet|cae|unet4fp8|x3]   (unet4fp8: kernel-trace summary of the fp8 4-scale step only;
+#        x3: kernel-trace summaries of the headline step in the pair modes f16x3 / bf16x3 + their per-layer tables)
 set -o pipefail
 TAG=${1:-r02}; WL=${2:-unet}
 export TMPDIR=/tmp
@@ -20,6 +21,12 @@ if [ "$WL" = unet ]; then
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $OUT/q1 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q1.log 2>&1
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/q2 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q2.log 2>&1
   python tools/pmc_sq.py $(csvf $OUT/q1) $(csvf $OUT/q2) > gpurun_out/${TAG}_mfma_busy.txt
+elif [ "$WL" = x3 ]; then
+  for DT in f16x3 bf16x3; do
+    SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/$DT -o s -- python bench.py --dtype $DT --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/$DT.log 2>&1 && \
+      python tools/rocpd_stats.py $(db $OUT/$DT) gpurun_out/${TAG}_bench_${DT}_kernel_stats_serial.csv > gpurun_out/${TAG}_bench_${DT}_kernel_stats_serial.txt
+    python bench.py --dtype $DT --steps 10 --warmup 3 --no-secondary --no-cpu-baseline --no-parity --layers 2>&1 | grep -E "conv_igemm|conv_wgrad|ms_per_step" | cut -c1-400 > gpurun_out/${TAG}_bench_${DT}_layers.txt
+  done
 elif [ "$WL" = unet4fp8 ]; then
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_unet4_fp8_kernel_stats.csv > gpurun_out/${TAG}_unet4_fp8_kernel_stats.txt
