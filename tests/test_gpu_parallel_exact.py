@@ -157,6 +157,8 @@ def test_exact_mode_cae_two_ranks_equal_single_process():
         p.join(timeout=120)
         assert p.exitcode == 0
     print("exact-mode CAE, 2 ranks vs 1 process:", res)
-    assert res["rec"] < 2e-4 and res["loss"] < 2e-5, res
-    assert res["grad"] < 2e-2, res
-    assert res["rm"] < 1e-4 and res["rv"] < 1e-3, res
+    # measured: rec 1.3e-5, loss 0, grad 1.4e-4 (the f32 mode's split-bf16 sums in another order), rm 1.5e-8, rv 1.2e-7 --
+    # a percent-level error in a world factor or a group scale is two orders of magnitude above these bounds
+    assert res["rec"] < 1e-4 and res["loss"] < 2e-6, res
+    assert res["grad"] < 1e-3, res
+    assert res["rm"] < 1e-6 and res["rv"] < 1e-5, res
