@@ -112,7 +112,13 @@ template <> struct ZmStore<float> {
 // slot holds the P hi planes followed by the P lo planes, the weights come as hi and lo fragments (both in LDS), every product
 // is three MFMAs (w_hi x_hi + w_hi x_lo + w_lo x_hi: ~2^-17 relative, fp32 accumulate) and the epilogue writes the output as a
 // pair again.  Three times the MFMAs on twice the bytes: the 16-channel layers move from the LDS / HBM bound towards the pipe.
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false>
+// STATS: 0 none; 1 per-channel sum / sum of squares of the output (forward layers); 2 (data gradients behind a BatchNorm whose
+// sums cannot come from the weight gradient -- padded convolutions, the CAE): (sum g, sum g*x) of the stored output g and the
+// layer input x read at the same position (a.aux), the pair the BatchNorm backward needs.  The x values of the plane whose
+// epilogue rides in step i+1 are fetched into registers at the top of step i.
+// BatchNorm groups (a.group_batch > 0: the batch holds B / group_batch passes with statistics of their own): the sums are flushed
+// to the rows of the sample's group whenever a workgroup's march crosses into another group.
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -127,7 +133,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
   constexpr int NS = MT * NT * ((Q8 || HL) ? 2 : 1);      // store instructions of one epilogue
-  static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NS) <= 63, "counted vmcnt does not fit its 6-bit field");
+  constexpr int NA = STATS == 2 ? MT * NT : 0;            // loads of the layer input per step (STATS 2)
+  constexpr int NSA = NS + NA;
+  static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NSA) <= 63, "counted vmcnt does not fit its 6-bit field");
+  static_assert(STATS != 2 || (ACT == 0 && !Q8 && !HL && sizeof(TOUT) == 2 && MT * NT == 4 && D == 2), "BatchNorm-backward sums: plain 16-bit data gradient, four tiles per wave");
   constexpr int NWF = 3 * KS * NT;                // weight fragments (1 KiB each)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = Q.a;
@@ -204,6 +213,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     for (int j = 0; j < 4; ++j) { bj[n][j] = bias_sl ? bias_sl[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
   const float slope = a.act == SP_ACT_NONE ? 1.f : a.act_param;       // LeakyReLU slope (identity: 1) or the ELU's alpha
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(Q.zeros);
+  // statistics flush: wave-ordered sum through LDS, one atomic per channel and workgroup into the rows of BatchNorm group g
+  const int gbatch = a.group_batch > 0 ? a.group_batch : 0x7fffffff;
+  int cur_g = -1;
+  auto flush_stats = [&](int g) {
+    float* red = reinterpret_cast<float*>(lds);      // [NW waves][NT * 32] (ordered sum: sp_cols_sum)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
+        if (lv == 0) { red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1s; red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2s; }
+        s1[n][j] = s2[n][j] = 0.f;
+      }
+    __syncthreads();
+    double* const gs = stats_sl + (size_t)g * a.stats_nrep * a.CPo * 2;
+    for (int k = tid; k < NT * 32; k += 64 * NW) {
+      const int c = k >> 1;
+      if (c0s + c < a.CPo) atomicAdd(&gs[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
+    }
+  };
+  zm_u32x2 ax[2][4];                                // STATS 2: x at this lane's four (row, tile) positions, two planes in flight
+  uint32_t axtok = 0;                               // (see the wait in ZM_STEP)
 #ifdef SP_ZM_STAMPS
   unsigned long long zm_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // 0 sync, 1 DMA issue, 2 K loop + epilogue, 3 steps, 4 total
   ZM_T(t_begin);
@@ -224,8 +255,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     uint32_t t = col;
     uint32_t q = fdiv(t, Q.d_tx); const int tx = t - q * Q.ntx; t = q;
     q = fdiv(t, Q.d_ty); const int ty = t - q * Q.nty; const int b = q;
+    if (STATS && stats_sl != nullptr) {
+      const int g = b / gbatch;
+      if (g != cur_g) {
+        if (cur_g >= 0) {       // the march enters another BatchNorm group: hand over what belongs to the last one
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          flush_stats(cur_g);
+          __syncthreads();
+        }
+        cur_g = g;
+      }
+    }
     const int oy0 = ty * (NW * MT), ox0 = tx * 16;
     const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
+    const unsigned char* auxb = STATS == 2 ? reinterpret_cast<const unsigned char*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo * 2 : nullptr;
     const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * xpitch * 2;
     int vmask = 0;                                            // in-plane validity of this lane's chunks
 #pragma unroll
@@ -305,7 +349,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 
     // epilogue of the plane held by accumulator set R: straight-line code (no branch); fz < 0 (no finished plane) turns
     // every store into an out-of-range one and every statistics term into 0 -- the instruction count never changes
-#define ZM_EPILOGUE(R_, fz_)                                                                                      \
+#define ZM_EPILOGUE(R_, fz_, AX_)                                                                                   \
   {                                                                                                               \
     const bool pv = (fz_) >= 0;                                                                                   \
     const uint32_t zoff = pv ? zbase + (uint32_t)(fz_) * zstride : 0x80000000u;                                   \
@@ -333,10 +377,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           const float r_[4] = {sp_h2f_lo(w0_), sp_h2f_hi(w0_), sp_h2f_lo(w1_), sp_h2f_hi(w1_)};                   \
           __builtin_amdgcn_raw_buffer_store_b32(zm_pack4_e4m3(r_, q8s), y8rs[n], off8, 0, 0);                     \
         }                                                                                                         \
-        if (STATS) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
+        if constexpr (STATS == 1) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
             const float u = __uint_as_float(__float_as_uint(v[j]) & msk);                                         \
             s1[n][j] += u; s2[n][j] = fmaf(u, u, s2[n][j]);                                                       \
+          }                                                                                                       \
+        }                                                                                                         \
+        if constexpr (STATS == 2) {   /* (sum g, sum g x) of the STORED g, as the tiled kernel's stats_mode 1 */        \
+          const uint32_t w0_ = zm_pack2(v[0], v[1]), w1_ = zm_pack2(v[2], v[3]);                                  \
+          const float r_[4] = {sp_h2f_lo(w0_), sp_h2f_hi(w0_), sp_h2f_lo(w1_), sp_h2f_hi(w1_)};                   \
+          const zm_u32x2 xw_ = {ax[AX_][n * MT + m][0] | axtok, ax[AX_][n * MT + m][1] | axtok};                     \
+          const float xq_[4] = {sp_h2f_lo(xw_[0]), sp_h2f_hi(xw_[0]), sp_h2f_lo(xw_[1]), sp_h2f_hi(xw_[1])};      \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const float u = __uint_as_float(__float_as_uint(r_[j]) & msk);                                        \
+            const float xx = __uint_as_float(__float_as_uint(xq_[j]) & msk);                                      \
+            s1[n][j] += u; s2[n][j] = fmaf(u, xx, s2[n][j]);                                                      \
           }                                                                                                       \
         }                                                                                                         \
       }                                                                                                           \
@@ -393,11 +448,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     /* every wave, and everyone is done with the slot that is refilled during this step. */                         \
     /* younger than plane i's DMA: the DMAs of planes i+1 .. i+D-1 and the stores of the last min(i, D-1) steps */   \
     ZM_T(ts0);                                                                                                    \
-    if (i >= D - 1) ZM_SYNC((D - 1) * (NJ + NS));                                                                 \
+    if (i >= D - 1) ZM_SYNC((D - 1) * (NJ + NSA));                                                                \
     else if (i == 0) ZM_SYNC((D - 1) * NJ);                                                                       \
-    else if (i == 1) ZM_SYNC((D - 1) * NJ + (D > 2 ? 1 : 0) * NS);                                                \
-    else if (i == 2) ZM_SYNC((D - 1) * NJ + (D > 3 ? 2 : 0) * NS);                                                \
-    else ZM_SYNC((D - 1) * NJ + (D > 4 ? 3 : 0) * NS);                                                            \
+    else if (i == 1) ZM_SYNC((D - 1) * NJ + (D > 2 ? 1 : 0) * NSA);                                               \
+    else if (i == 2) ZM_SYNC((D - 1) * NJ + (D > 3 ? 2 : 0) * NSA);                                               \
+    else ZM_SYNC((D - 1) * NJ + (D > 4 ? 3 : 0) * NSA);                                                           \
+    if constexpr (STATS == 2) {                                                                                   \
+      /* the x values for THIS step's epilogue were requested at the top of the last step, before its NJ DMAs and NS stores: */ \
+      /* all but those may be outstanding.  The wait also defines a zero token that every use of the loaded registers ORs in, */ \
+      /* so that none of them can be scheduled above it ("+v" ties on the registers themselves made the allocator spill). */   \
+      asm volatile("s_waitcnt vmcnt(%1)\n\tv_mov_b32 %0, 0" : "=v"(axtok) : "n"(NJ + NS) : "memory");               \
+      /* ... and the ones for the next step's epilogue (output plane z0 + i - 2) go out now; outside the output: the zero page */ \
+      const int fzn = (i >= 2 && i - 2 < nz) ? z0 + i - 2 : -1;                                                   \
+      const uint32_t zoffn = fzn >= 0 ? zbase + (uint32_t)fzn * zstride : 0x80000000u;                            \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                          \
+          const unsigned char* ap_ = ((zoffn | rowoff[m]) & 0x80000000u) ? zsrc : auxb + (zoffn + rowoff[m] + (uint32_t)(n * 32)); \
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(ax[((PH) + 1) & 1][n * MT + m]) : "v"(ap_) : "memory"); \
+        }                                                                                                         \
+    }                                                                                                             \
     ZM_T(ts1);                                                                                                    \
     /* the DMA of plane i+D goes out piecewise between the MFMAs below (ZM_DMA); beyond the piece's last plane the same */ \
     /* number of instructions copies the zero page into a dump area, so that the counted waits stay valid */          \
@@ -412,7 +481,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     bf16x8 wa[WLDS ? 3 : 1][WLDS ? NT : 1], wb[WLDS ? 3 : 1][WLDS ? NT : 1];                                      \
     bf16x8 wal[HL ? 3 : 1][HL ? NT : 1], wbl[HL ? 3 : 1][HL ? NT : 1];                                            \
     if (v0 && v1 && v2) {                                                                                         \
-      ZM_EPILOGUE((PH + 1) % 4, fz)                                                                               \
+      ZM_EPILOGUE((PH + 1) % 4, fz, (PH) & 1)                                                                     \
       ZM_LDX(x0, x0l, 0)                                                                                          \
       ZM_LDW(wa, wal, 0)                                                                                          \
       _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
@@ -430,7 +499,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) }                                                  \
         if (v0) { ZM_MMA_D0(PH, s, x0, x0l, wa, wal) }                                                            \
       }                                                                                                           \
-      ZM_EPILOGUE((PH + 1) % 4, fz)                                                                               \
+      ZM_EPILOGUE((PH + 1) % 4, fz, (PH) & 1)                                                                     \
     }                                                                                                             \
     ZM_T(ts3);                                                                                                    \
     ZM_ACC(0, ts1, ts0); ZM_ACC(1, ts2, ts1); ZM_ACC(2, ts3, ts2); ZM_ACC(3, 1, 0);                               \
@@ -474,25 +543,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       for (int k = 0; k < 8; ++k) sp_zm_stamp_buf[blockIdx.x][wave][k] = zm_sum[k];
   }
 #endif
-  if (STATS && stats_sl != nullptr) {
+  if (STATS && stats_sl != nullptr && cur_g >= 0) {
     __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);      // [NW waves][NT * 32] (ordered sum: sp_cols_sum)
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float x1s = row16_sum(s1[n][j]), x2s = row16_sum(s2[n][j]);
-        if (lv == 0) { red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2] = x1s; red[wave * (NT * 32) + (n * 16 + lg * 4 + j) * 2 + 1] = x2s; }
-      }
-    __syncthreads();
-    for (int k = tid; k < NT * 32; k += 64 * NW) {
-      const int c = k >> 1;
-      if (c0s + c < a.CPo) atomicAdd(&stats_sl[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
-    }
+    flush_stats(cur_g);
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, bool STATS, int ACT, bool HL = false>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
   constexpr int NCH = (HL ? 2 : 1) * P * (NW * MT + 2) * 18 * 2;
@@ -522,8 +579,8 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
   } else if (a->dtype_out == SP_F32) {
-    if constexpr (ACT == 2) {
-      sp_set_error("sp_conv3d_zm: the ELU epilogue is built for bf16 outputs");
+    if constexpr (ACT == 2 || STATS == 2) {
+      sp_set_error("sp_conv3d_zm: the ELU epilogue and the BatchNorm-backward sums are built for bf16 outputs");
       return SP_EINVAL;
     } else {
       auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, float>;
@@ -551,18 +608,26 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
 template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW>
 static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   const bool plain = a->act == SP_ACT_NONE && a->bias == nullptr;      // data gradients: nothing to do but round and store
+  if (a->stats_mode == 1) {      // data gradient + (sum g, sum g x) for the BatchNorm backward (checked by the caller: plain, stats, aux)
+    if constexpr (NW == 8 && P <= 2 && MT * NT == 4 && NSLOT == 3) {
+      return launch_zm2<P, NT, MT, NSLOT, true, NW, 2, 0>(a, zeros, st);
+    } else {
+      sp_set_error("sp_conv3d_zm: no BatchNorm-backward-sums instance for P=%d NT=%d NW=%d", P, NT, NW);
+      return SP_EINVAL;
+    }
+  }
   if (a->act == SP_ACT_ELU) {
     if constexpr (NW == 8 && P <= 2) {      // the CAE's 16 / 24 / 32-channel layers
-      if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true, 2>(a, zeros, st);
-      return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, 2>(a, zeros, st);
+      if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 1, 2>(a, zeros, st);
+      return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 0, 2>(a, zeros, st);
     } else {
       sp_set_error("sp_conv3d_zm: no ELU instance for P=%d NW=%d", P, NW);
       return SP_EINVAL;
     }
   }
-  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, true, 1>(a, zeros, st);
-  if (plain) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, 0>(a, zeros, st);
-  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, false, 1>(a, zeros, st);
+  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 1, 1>(a, zeros, st);
+  if (plain) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 0, 0>(a, zeros, st);
+  return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 0, 1>(a, zeros, st);
 }
 
 // (P, NT) -> rows per wave, ring slots, waves per workgroup; SP_EINVAL = no kernel.  runtime/plan.py (ZM_CONFIGS) must agree:
@@ -604,19 +669,21 @@ extern "C" int sp_conv3d_zm_config_hl(int32_t P, int32_t NT, int32_t* MT, int32_
 
 template <int P, int NT, int MT, int NSLOT, int NW>
 static int launch_zm_hl(const sp_conv_args* a, const void* zeros, hipStream_t st) {
-  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, true, NW, true, 1, true>(a, zeros, st);
-  return launch_zm2<P, NT, MT, NSLOT, true, NW, false, 1, true>(a, zeros, st);
+  if (a->stats) return launch_zm2<P, NT, MT, NSLOT, true, NW, 1, 1, true>(a, zeros, st);
+  return launch_zm2<P, NT, MT, NSLOT, true, NW, 0, 1, true>(a, zeros, st);
 }
 
 extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && zeros, "sp_conv3d_zm: null pointer");
   const bool hl = a->dtype_in == SP_HL;
-  SP_CHECK_ARG((a->dtype_in == SP_BF16 || hl) && a->in_scale == nullptr && a->stats_mode == 0, "sp_conv3d_zm: bf16 (or bf16 pair) input, no affine on load, plain statistics");
+  SP_CHECK_ARG((a->dtype_in == SP_BF16 || hl) && a->in_scale == nullptr && (a->stats_mode == 0 || a->stats_mode == 1), "sp_conv3d_zm: bf16 (or bf16 pair) input, no affine on load");
+  SP_CHECK_ARG(a->stats_mode == 0 || (a->stats && a->aux && a->act == SP_ACT_NONE && a->bias == nullptr && a->dtype_out == SP_BF16 && !hl && !a->y8 && a->nslices <= 1),
+               "sp_conv3d_zm: stats_mode 1 (sum g, sum g x) is for plain bf16 data gradients with statistics rows and the layer input (aux)");
   SP_CHECK_ARG(!hl || (a->dtype_out == SP_HL && a->wfrag_lo && a->x_lo_delta != 0 && a->y_lo_delta != 0 && a->x_lo_delta % 16 == 0 && a->y_lo_delta % 8 == 0 &&
                        (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && a->nslices <= 1),
                "sp_conv3d_zm: bf16 pairs in -> bf16 pairs out with hi and lo weight fragments, bias + LeakyReLU / identity epilogue");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
-  SP_CHECK_ARG(a->group_batch == 0, "sp_conv3d_zm: no BatchNorm groups (run one launch per group)");
+  SP_CHECK_ARG(a->group_batch >= 0 && (a->group_batch == 0 || (a->B % a->group_batch == 0 && a->nslices <= 1)), "sp_conv3d_zm: group_batch %d must divide the batch %d (no slices)", a->group_batch, a->B);
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE || a->act == SP_ACT_ELU, "sp_conv3d_zm: LeakyReLU, ELU or identity epilogue");
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
   SP_CHECK_ARG(a->nslices >= 0 && a->nslices <= 16 && (a->nslices <= 1 || (a->CPo >= a->nslices * a->Cout && a->slice_wfrag_stride > 0 && a->slice_wfrag_stride % 16 == 0 && !a->y8)),

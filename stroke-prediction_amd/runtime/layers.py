@@ -125,8 +125,9 @@ class ConvLayer:
             zm_ok = bool(self.materialize and kind == "conv" and dtype == L.SP_BF16 and act == L.ACT_ELU and O.ZM_CAE
                          and self.out_dtype == dtype and max(pads) <= 2 and max(strides) == 1 and k == 3
                          and self.cpi % 16 == 0 and self.cpo % 16 == 0)
+        # (groups: ONE launch over the whole batch -- the kernel hands its statistics to the rows of a sample's group)
         self.fwd = O.ConvRunner(self.fwd_op, device, share=None if (bank is None or self.fold) else bank.setdefault((name, "fwd"), {}),
-                                zm_batch=self.gb if zm_ok else None)
+                                zm_batch=(self.batch if (self.G > 1 and O.ZM_GROUPS) else self.gb) if zm_ok else None)
         if bn_prefix is not None:
             G = self.G
             self.apply_coef = torch.zeros((G, 3, self.cpi) if G > 1 else (3, self.cpi), device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift
@@ -319,8 +320,12 @@ class ConvLayer:
             self.g = tuple(self.g_parts)
         elif self.need_input_grad or (self.bn_prefix is not None and not self.bn_from_wgrad):
             # (BatchNorm sums from the weight gradient: the data gradient is a plain convolution -> z-marching candidate)
+            # batched passes behind a BatchNorm (the CAE): the z-marching data gradient with the (sum g, sum g x) epilogue,
+            # one launch over all groups -- where that instance exists; else the tiled kernel's stats_mode 1
+            zm_grouped = bool(self.G > 1 and O.ZM_GROUPS and O.ZM_CAE and self.kind == "conv" and dt == L.SP_BF16 and self.bn_prefix is not None
+                              and O.ConvRunner.zm_plan_bn_bwd_ok(P.zm_plan(dop)))
             self.dgrad = O.ConvRunner(dop, dev, share=None if self.bank is None else self.bank.setdefault((self.name, "dgrad"), {}),
-                                      zm_batch=self.batch if (self.bn_from_wgrad and self.bank is None) else None)
+                                      zm_batch=self.batch if ((self.bn_from_wgrad and self.bank is None) or zm_grouped) else None)
             self.g = O.alloc_cl(self.batch, self.in_dims, self.cpi, dt, dev)
             if self.f8_on and self.bn_from_wgrad and self.need_input_grad and self.kind == "conv":
                 from . import f8 as F8      # plain data gradient (no statistics epilogue): fp8 candidate, dz as e5m2
@@ -444,7 +449,8 @@ class ConvLayer:
                 self.dgrad.run(self.dz, self.g, self.batch)
                 return self.g, None
             bs = self.scratch.get(self.bsums_id)
-            fused = all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None
+            fused = (all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None) \
+                or self.dgrad.zm_bn_bwd_ok()
             if fused:
                 self.dgrad.run(self.dz, self.g, self.batch, stats=bs, stats_nrep=STATS_NREP, stats_mode=1, aux=x, group_batch=self.gb)
             else:

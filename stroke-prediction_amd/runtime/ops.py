@@ -41,6 +41,7 @@ USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
 USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with too many output tiles for one z-marching launch: a launch per 32-channel slice
 ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "2000"))  # ... when the volume is large enough (one launch per slice: 32->96 @48^3 gains nothing, @166^3 40 %; as teams of one launch: @48^3 147 -> 119 us)
 USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
+ZM_GROUPS = bool(int(os.environ.get("SP_ZM_GROUPS", "1")))      # batched passes: one z-marching launch over all BatchNorm groups (0: one per group, tiled data gradients)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
 USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
 USE_FC = bool(int(os.environ.get("SP_CONV_FC", "1")))      # split-K kernel for FC-like layers (deep K, tiny output volume)
@@ -276,6 +277,14 @@ class ConvRunner:
         """the z-marching kernel runs this op (and its weight fragments are the only ones packed)"""
         return self.zm is not None or self.zms is not None
 
+    @staticmethod
+    def zm_plan_bn_bwd_ok(z):
+        """the z-marching instance of plan z exists with the BatchNorm-backward-sums epilogue (stats_mode 1: sum g, sum g x)"""
+        return bool(z is not None and z["NW"] == 8 and z["P"] <= 2 and z["MT"] * z["NT"] == 4 and z["nslot"] == 3)
+
+    def zm_bn_bwd_ok(self):
+        return self.zm is not None and self.op.dtype == L.SP_BF16 and ConvRunner.zm_plan_bn_bwd_ok(self.zm)
+
     def _pack(self):
         """(kmap, nsteps, hi, lo, NTtot, first output channel, output channels) of every set of fragments the kernel(s) that
         will run this op read; all but the output-channel slices of the z-marching kernel cover the whole op"""
@@ -355,9 +364,10 @@ class ConvRunner:
         op = self.op
         assert y8 is None or (self.zm_y8_ok() and not group_batch and use_bias and act in (L.ACT_NONE, L.ACT_LEAKY))
         dtype_out = op.dtype if dtype_out is None else dtype_out
-        if group_batch and group_batch < batch and stats is not None and (self.uses_zm() or self.fc is not None):
+        zm_groups = self.zm is not None and batch == self.zm_batch     # the z-marching kernel flushes its statistics per group itself
+        if group_batch and group_batch < batch and stats is not None and ((self.uses_zm() and not zm_groups) or self.fc is not None):
             # BatchNorm groups (statistics rows per group) on a kernel that is not group-aware: one launch per group on the
-            # contiguous slices of the batch (the z-marching and split-K kernels)
+            # contiguous slices of the batch (output-channel slices of the z-marching kernel, the split-K kernel)
             assert in_scale is None and batch % group_batch == 0
             per = stats.numel() // (batch // group_batch)
             for gi in range(batch // group_batch):
@@ -404,7 +414,8 @@ class ConvRunner:
             a.y8, a.y8_plane, a.y8_scale = ptr(y8), batch * int(np.prod(op.y_dims)) * 16, 1.0
         st = stream()
         if self.uses_zm():
-            assert batch == self.zm_batch and in_scale is None and stats_mode == 0 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
+            assert batch == self.zm_batch and in_scale is None and (stats_mode == 0 or (stats_mode == 1 and self.zm_bn_bwd_ok())) \
+                and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"
             if self.zms is not None:

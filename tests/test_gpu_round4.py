@@ -1,0 +1,140 @@
+"""Round-4 GPU tests of the CAE's batched passes on the z-marching kernel (csrc/sp_conv_zm.hip):
+
+* BatchNorm groups inside ONE launch: a workgroup's march hands its output statistics to the rows of the group its current
+  sample belongs to (``sp_conv_args.group_batch``), against per-group launches and against torch;
+* the data gradient with the BatchNorm-backward sums in its epilogue (``stats_mode = 1``: sum g and sum g*x of the stored g,
+  x = the layer input read at the same position), per group, against float64 sums of the stored tensors;
+* the whole CAE step with these paths on and off.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from stroke_prediction_amd.runtime import lib as L
+from stroke_prediction_amd.runtime import ops as O
+from stroke_prediction_amd.runtime import plan as P
+
+DEV = "cuda:0"
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def _to_cl(x, cp):
+    dst = O.alloc_cl(x.shape[0], x.shape[2:], cp, L.SP_BF16, DEV)
+    O.ncdhw_to_cl(x.contiguous().to(DEV), dst, L.SP_BF16)
+    return dst
+
+
+def _from_cl(t, c):
+    out = torch.empty((t.shape[0], c) + tuple(t.shape[1:4]), dtype=torch.float32, device=DEV)
+    O.cl_to_ncdhw(t, out, L.SP_BF16)
+    return out.cpu()
+
+
+# cin, cout, input dims, padding, batch, group batch -- (P, NT) = (1,1) (2,2) (2,1) (1,2); volumes small enough that one workgroup's
+# piece of the march crosses sample and group boundaries, and ragged in every direction
+GROUP_CASES = [(16, 16, (9, 36, 40), (1, 0, 0), 6, 2), (24, 24, (6, 34, 36), (1, 2, 2), 4, 1),
+               (24, 16, (5, 33, 20), (1, 2, 2), 6, 3), (16, 24, (4, 40, 17), (1, 1, 1), 4, 2)]
+
+
+@pytest.mark.parametrize("cin,cout,dims,pad,B,gb", GROUP_CASES)
+def test_z_marching_forward_statistics_per_batchnorm_group(cin, cout, dims, pad, B, gb, monkeypatch):
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    g = torch.Generator().manual_seed(cin * 5 + cout + B)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    x = bf(torch.randn(B, cin, *dims, generator=g) * (1.0 + torch.arange(B).view(B, 1, 1, 1, 1)))      # groups of different scale
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    op = P.conv_fwd_op(cin, cout, 3, 1, pad, dims, cpi, cpo, L.SP_BF16)
+    run = O.ConvRunner(op, DEV, zm_batch=B)
+    assert run.uses_zm()
+    run.prep(w.to(DEV), b.to(DEV))
+    xs = _to_cl(x, cpi)
+    nrep, G = 4, B // gb
+    y = O.alloc_cl(B, op.y_dims, cpo, L.SP_BF16, DEV)
+    stats = torch.zeros(G * nrep * cpo * 2, dtype=torch.float64, device=DEV)
+    run.run(xs, y, B, None, None, L.ACT_ELU, 1.0, stats, stats_nrep=nrep, group_batch=gb)
+    got = _from_cl(y, cout)
+    torch.testing.assert_close(got, F.elu(F.conv3d(x, bf(w), b, padding=pad), 1.0), rtol=3e-2, atol=3e-2)
+    st = stats.view(G, nrep, cpo, 2).sum(1).cpu()
+    nvox = got[:gb].numel() / cout
+    for gi in range(G):
+        part = got[gi * gb:(gi + 1) * gb].double()
+        smax = float((gi + 1) * gb)      # (the input scale of the group's last sample)
+        torch.testing.assert_close(st[gi, :cout, 0], part.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * smax * math.sqrt(nvox))
+        torch.testing.assert_close(st[gi, :cout, 1], (part ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * smax ** 2 * math.sqrt(nvox))
+    # one launch per group (the per-group rows of a runner planned for the group batch) gives the same tensor
+    run1 = O.ConvRunner(op, DEV, zm_batch=gb)
+    run1.prep(w.to(DEV), b.to(DEV))
+    y1 = torch.empty_like(y)
+    stats1 = torch.zeros_like(stats)
+    run1.run(xs, y1, B, None, None, L.ACT_ELU, 1.0, stats1, stats_nrep=nrep, group_batch=gb)
+    assert torch.equal(y1, y)
+    torch.testing.assert_close(stats1.view(G, nrep, cpo, 2).sum(1).cpu(), st, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("cin,cout,dims,pad,B,gb", GROUP_CASES)
+def test_z_marching_data_gradient_with_batchnorm_backward_sums(cin, cout, dims, pad, B, gb, monkeypatch):
+    """g = conv^T(dz, W) on the z-marching kernel, (sum g, sum g*x) per BatchNorm group from its epilogue: the stored g against
+    torch, the sums against float64 sums over the stored g and x (exact up to the fp32 accumulation inside a workgroup), and
+    against the tiled kernel's stats_mode 1"""
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    gen = torch.Generator().manual_seed(cin * 3 + cout + B)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    out = tuple(dims[a] + 2 * pad[a] - 2 for a in range(3))
+    x = bf(torch.randn(B, cin, *dims, generator=gen) + 0.5)
+    dz = bf(torch.randn(B, cout, *out, generator=gen) * (1.0 + torch.arange(B).view(B, 1, 1, 1, 1)))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=gen) / math.sqrt(27 * cin)
+    dop = P.conv_dgrad_op(cin, cout, 3, 1, pad, dims, cpo, cpi, L.SP_BF16)
+    assert O.ConvRunner.zm_plan_bn_bwd_ok(P.zm_plan(dop))
+    nrep, G = 4, B // gb
+    xs, dzs = _to_cl(x, cpi), _to_cl(dz, cpo)
+    res = {}
+    for name, zmb in (("zm", B), ("tiled", None)):
+        run = O.ConvRunner(dop, DEV, zm_batch=zmb)
+        assert run.uses_zm() == (zmb is not None) and (zmb is None or run.zm_bn_bwd_ok())
+        run.prep(w.to(DEV))
+        gb_t = O.alloc_cl(B, dims, cpi, L.SP_BF16, DEV)
+        gb_t.fill_(7.0)
+        bs = torch.zeros(G * nrep * cpi * 2, dtype=torch.float64, device=DEV)
+        run.run(dzs, gb_t, B, stats=bs, stats_nrep=nrep, stats_mode=1, aux=xs, group_batch=gb)
+        res[name] = (_from_cl(gb_t, cin), bs.view(G, nrep, cpi, 2).sum(1).cpu())
+    gz, sz = res["zm"]
+    torch.testing.assert_close(gz, F.conv_transpose3d(dz, bf(w), padding=pad), rtol=3e-2, atol=3e-2 * B)
+    for gi in range(G):
+        sl = slice(gi * gb, (gi + 1) * gb)
+        e1 = gz[sl].double().sum(dim=(0, 2, 3, 4))
+        e2 = (gz[sl].double() * x[sl].double()).sum(dim=(0, 2, 3, 4))
+        scale = float(gz[sl].abs().max()) * math.sqrt(gz[sl].numel() / cin)
+        torch.testing.assert_close(sz[gi, :cin, 0], e1, rtol=1e-4, atol=2e-5 * scale)
+        torch.testing.assert_close(sz[gi, :cin, 1], e2, rtol=1e-4, atol=6e-5 * scale)
+        if cpi > cin:
+            assert float(sz[gi, cin:].abs().max()) == 0.0
+    gt, stl = res["tiled"]
+    torch.testing.assert_close(gz, gt, rtol=2e-2, atol=2e-2 * B)      # (another summation order before the bf16 rounding)
+    torch.testing.assert_close(sz, stl, rtol=5e-3, atol=5e-2 * B)
+
+
+def test_cae_step_grouped_z_march_equals_per_group_launches(monkeypatch):
+    """the CAE training step (batched passes) with one z-marching launch per layer over all BatchNorm groups -- forward with
+    per-group statistics, data gradients with the BatchNorm-backward sums -- against one launch per group / the tiled data
+    gradients (SP_ZM_GROUPS=0): two bf16 pipelines of the same function"""
+    from test_gpu_round3 import _cae_step      # (pytest puts tests/ on sys.path)
+    ch = [1, 16, 24, 32, 100, 200, 1]
+    outs = {}
+    for on in (False, True):
+        monkeypatch.setattr(O, "ZM_GROUPS", on)
+        outs[on] = _cae_step(ch, 29, 28, 64, "bf16", 0, batched=1)
+    a, b = outs[False], outs[True]
+    for k in a[0]:
+        d = (a[0][k] - b[0][k]).abs()
+        assert float(d.max()) <= 3e-2 and float(d.mean()) <= 2e-3, (k, float(d.max()), float(d.mean()))
+    assert abs(a[1] - b[1]) <= 3e-3, (a[1], b[1])
+    rel = float((a[2] - b[2]).double().norm() / a[2].double().norm())
+    assert rel < 6e-2, rel
