@@ -132,6 +132,16 @@ int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
  * strided convolution's data gradient -- in ONE launch when they share register blocking, data types and the register-staged
  * kernel (dma = 0); otherwise the classes are launched one after the other.  Same result either way. */
 int sp_conv3d_igemm_multi(const sp_conv_args* args, int32_t n, sp_stream_t stream);
+/* The same n classes in ONE pass over the output (csrc/sp_conv_par.hip; bf16 channels-last in and out): a workgroup owns a tile
+ * of the class grid and walks all classes for it, so the s x s x s output voxels of a class-grid voxel leave together (whole
+ * lines) and the input is fetched once; operands are gathered straight from global memory / L2, no LDS staging.
+ * args[i]: what sp_conv3d_igemm takes for class i (its wfrag_hi in the K order of its kmap, ngroups * steps_per_group K steps,
+ * Do / Ho / Wo, oo*, o0*; tensors, strides, NTtot, bias, act, stats / stats_mode / aux / group_batch of class 0 apply to all).
+ * gtab (device): two int32 per K slot of every class, class after class -- byte offset of the slot's (tap, octet) from the
+ * lane's base input voxel, and oz | (4 + oy) << 8 | (8 + ox) << 16 with the tap's offsets (0..2) from the class origin o0;
+ * gofs[i] (host, n + 1 entries): first slot of class i.  zeros: >= 16 readable zero bytes (out-of-volume taps).
+ * Replaces nn.ConvTranspose3d forward (Cae3D.py:178-204) and the data gradient of the strided nn.Conv3d layers (Cae3D.py:45-64). */
+int sp_conv3d_par(const sp_conv_args* args, int32_t n, const void* gtab, const int32_t* gofs, const void* zeros, sp_stream_t stream);
 
 /* The same operation (nn.Conv3d(3, stride 1, padding 0) forward, Unet3D.py:19,22, or its data gradient) on the
  * output-stationary z-marching kernel (csrc/sp_conv_zm.hip): a workgroup marches through the INPUT planes of a column of

@@ -41,6 +41,7 @@ USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
 USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with too many output tiles for one z-marching launch: a launch per 32-channel slice
 ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "2000"))  # ... when the volume is large enough (one launch per slice: 32->96 @48^3 gains nothing, @166^3 40 %; as teams of one launch: @48^3 147 -> 119 us)
 USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
+USE_PAR = bool(int(os.environ.get("SP_CONV_PAR", "1")))      # parity classes of transposed / strided-gradient ops: one pass over the output (csrc/sp_conv_par.hip)
 ZM_GROUPS = bool(int(os.environ.get("SP_ZM_GROUPS", "1")))      # batched passes: one z-marching launch over all BatchNorm groups (0: one per group, tiled data gradients)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
 USE_MULTI = bool(int(os.environ.get("SP_CONV_MULTI", "1")))      # parity classes of an op in one launch where the kernel allows
@@ -268,10 +269,38 @@ class ConvRunner:
         self._st = st
         self.subs = st["subs"]
         self.bias = st["bias"]
+        if "par" not in st:
+            st["par"] = self._par_tables(op, device)
+        self.par = st["par"]
         self.zm = st.get("zm")
         self.zms = st.get("zms")
         self.zm_batch = zm_batch if (self.zm is not None or self.zms is not None) else None
         self.fc = st.get("fc")
+
+    @staticmethod
+    def _par_tables(op, device):
+        """gather tables of csrc/sp_conv_par.hip for an op of several parity classes (transposed convolutions, data gradients of
+        strided ones): per K slot of every class -- in the order of the class's kmap, i.e. of its packed weight fragments --
+        (byte offset of (tap, octet) from the lane's base voxel, the tap's per-axis offsets and the octet); None when
+        the op does not go there"""
+        if not (USE_PAR and USE_DMA and op.dtype == L.SP_BF16 and 2 <= len(op.subs) <= 8):
+            return None
+        Hi, Wi = op.in_dims[1], op.in_dims[2]
+        rows, gofs = [], [0]
+        for sub in op.subs:
+            off = {t[3]: t[:3] for t in sub.taps}
+            if any(max(o) > 2 or min(o) < 0 for o in off.values()):
+                return None
+            tab = np.zeros((len(sub.kmap), 2), dtype=np.int32)
+            for k, e in enumerate(sub.kmap):
+                oz, oy, ox, oc = (0, 0, 0, 0) if e < 0 else off[int(e) >> 16] + (int(e) & 0xffff,)      # padding slots: zero weights
+                tab[k, 0] = ((oz * Hi + oy) * Wi + ox) * op.cpi * 2 + oc * 16
+                tab[k, 1] = oz | (4 + oy) << 8 | (8 + ox) << 16 | oc << 24
+            rows.append(tab)
+            gofs.append(gofs[-1] + len(sub.kmap))
+        if gofs[-1] * 8 > 60 * 1024:
+            return None
+        return dict(gtab=torch.from_numpy(np.concatenate(rows)).to(device), gofs=(C.c_int32 * len(gofs))(*gofs))
 
     def uses_zm(self):
         """the z-marching kernel runs this op (and its weight fragments are the only ones packed)"""
@@ -427,7 +456,8 @@ class ConvRunner:
         if self.fc is not None:     # (its fragments are the only ones packed: every call of this runner goes there)
             return _run_fc(self, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep,
                            stats_mode, aux, st, x_planar)
-        multi = (L.ConvArgs * len(self.subs))() if (USE_MULTI and 2 <= len(self.subs) <= 8 and not x_planar) else None
+        par = self.par is not None and in_scale is None and not x_planar and dtype_out == L.SP_BF16 and y8 is None
+        multi = (L.ConvArgs * len(self.subs))() if (par or (USE_MULTI and 2 <= len(self.subs) <= 8 and not x_planar)) else None
         for si, s in enumerate(self.subs):
             sub = s["sub"]
             t = sub.tile
@@ -462,7 +492,10 @@ class ConvRunner:
             with _Timed("conv_igemm", op.flops(batch),
                         "%d->%d @%s x%d classes%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), len(self.subs),
                                                       " +stats" if stats is not None else "")):
-                L.call("sp_conv3d_igemm_multi", multi, len(self.subs), st)
+                if par:      # all classes in one pass over the output
+                    L.call("sp_conv3d_par", multi, len(self.subs), ptr(self.par["gtab"]), self.par["gofs"], ptr(zero_page(self.device)), st)
+                else:
+                    L.call("sp_conv3d_igemm_multi", multi, len(self.subs), st)
 
 
 def wgrad_dma_ok(cpi, cpo, dtype):

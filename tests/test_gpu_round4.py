@@ -138,3 +138,69 @@ def test_cae_step_grouped_z_march_equals_per_group_launches(monkeypatch):
     assert abs(a[1] - b[1]) <= 3e-3, (a[1], b[1])
     rel = float((a[2] - b[2]).double().norm() / a[2].double().norm())
     assert rel < 6e-2, rel
+
+
+# ------------------------------------------------------------------------------------------------ parity classes in one pass
+# kind, cin, cout, k, stride, pad, input dims of the forward op, batch, group batch
+PAR_CASES = [("convT", 16, 16, 2, 2, 0, (6, 20, 22), 4, 2),          # Cae3D.py:196-204: one tap per class
+             ("convT", 24, 24, 2, 2, 0, (7, 13, 19), 2, 1),
+             ("convT", 104, 32, 3, 2, 0, (3, 12, 12), 2, 2),         # Cae3D.py:178-180: classes of unequal extent, 7 input planes
+             ("dgrad", 16, 24, 3, 2, (1, 1, 1), (12, 30, 36), 4, 2),  # Cae3D.py:45: gradient of the stride-2 convolutions
+             ("dgrad", 24, 32, 3, 2, (1, 1, 1), (6, 18, 26), 2, 1),
+             ("dgrad", 32, 100, 3, 2, (0, 0, 0), (7, 25, 25), 2, 2)]
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,pad,dims,B,gb", PAR_CASES)
+def test_parity_classes_in_one_pass(kind, cin, cout, k, s, pad, dims, B, gb, monkeypatch):
+    """csrc/sp_conv_par.hip: all parity classes of a transposed convolution (forward, ELU, output statistics per BatchNorm
+    group) or of a strided convolution's data gradient (with the (sum g, sum g*x) epilogue) in one launch -- against torch,
+    against float64 sums of the stored output, and against one launch per class"""
+    gen = torch.Generator().manual_seed(cin + 3 * cout + k)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    nrep, G = 4, B // gb
+    res = {}
+    if kind == "convT":
+        x = bf(torch.randn(B, cin, *dims, generator=gen))
+        w = torch.randn(cin, cout, k, k, k, generator=gen) / math.sqrt(cin * k ** 3 / s ** 3)
+        b = torch.randn(cout, generator=gen) * 0.1
+        op = P.convT_fwd_op(cin, cout, k, s, pad, dims, cpi, cpo, L.SP_BF16)
+        ref = F.elu(F.conv_transpose3d(x, bf(w), b, stride=s, padding=pad), 1.0)
+        src, cs, cd, act = _to_cl(x, cpi), cout, cpo, L.ACT_ELU
+    else:
+        out = tuple((dims[a] + 2 * pad[a] - k) // s + 1 for a in range(3))
+        xin = bf(torch.randn(B, cin, *dims, generator=gen) + 0.5)
+        dz = bf(torch.randn(B, cout, *out, generator=gen))
+        w = torch.randn(cout, cin, k, k, k, generator=gen) / math.sqrt(cin * k ** 3)
+        b = None
+        op = P.conv_dgrad_op(cin, cout, k, s, pad, dims, cpo, cpi, L.SP_BF16)
+        xr = xin.clone().requires_grad_(True)
+        ref = torch.autograd.grad(F.conv3d(xr, bf(w), None, stride=s, padding=pad), xr, dz)[0]
+        src, cs, cd, act = _to_cl(dz, cpo), cin, cpi, L.ACT_NONE
+        aux = _to_cl(xin, cpi)
+    assert len(op.subs) > 1
+    for name, on in (("par", True), ("classes", False)):
+        monkeypatch.setattr(O, "USE_PAR", on)
+        run = O.ConvRunner(op, DEV)
+        assert (run.par is not None) == on
+        run.prep(w.to(DEV), None if b is None else b.to(DEV))
+        y = O.alloc_cl(B, op.y_dims, cd, L.SP_BF16, DEV, zero=True)
+        st = torch.zeros(G * nrep * cd * 2, dtype=torch.float64, device=DEV)
+        if kind == "convT":
+            run.run(src, y, B, None, None, act, 1.0, st, stats_nrep=nrep, group_batch=gb)
+        else:
+            run.run(src, y, B, stats=st, stats_nrep=nrep, stats_mode=1, aux=aux, group_batch=gb)
+        res[name] = (_from_cl(y, cs), st.view(G, nrep, cd, 2).sum(1).cpu(), y)
+    got, sums, yraw = res["par"]
+    torch.testing.assert_close(got, ref, rtol=3e-2, atol=3e-2)
+    if cd > cs:
+        assert float(yraw[..., cs:].float().abs().max()) == 0.0
+    for gi in range(G):
+        sl = slice(gi * gb, (gi + 1) * gb)
+        e1 = got[sl].double().sum(dim=(0, 2, 3, 4))
+        e2 = ((got[sl].double() ** 2) if kind == "convT" else got[sl].double() * xin[sl].double()).sum(dim=(0, 2, 3, 4))
+        scale = float(got[sl].abs().max()) * math.sqrt(got[sl].numel() / cs)
+        torch.testing.assert_close(sums[gi, :cs, 0], e1, rtol=1e-4, atol=2e-5 * scale)
+        torch.testing.assert_close(sums[gi, :cs, 1], e2, rtol=1e-4, atol=2e-4 * scale)
+    # one launch per class: the same K order and the same MFMA sequence per output voxel -> the same stored tensor
+    assert torch.equal(res["classes"][2], yraw)
+    torch.testing.assert_close(res["classes"][1], sums, rtol=1e-5, atol=1e-3)
