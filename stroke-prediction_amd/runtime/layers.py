@@ -450,7 +450,7 @@ class ConvLayer:
                 return self.g, None
             bs = self.scratch.get(self.bsums_id)
             fused = (all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None) \
-                or self.dgrad.zm_bn_bwd_ok()
+                or self.dgrad.zm_bn_bwd_ok() or self.dgrad.par_ok(self.dtype)
             if fused:
                 self.dgrad.run(self.dz, self.g, self.batch, stats=bs, stats_nrep=STATS_NREP, stats_mode=1, aux=x, group_batch=self.gb)
             else:
@@ -481,7 +481,8 @@ class ConvLayer:
             return self.g, None
         p = self.bn_prefix
         bs = self.scratch.get(self.bsums_id)
-        fused = all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None
+        fused = (all(s.tile["dma"] for s in self.dgrad.op.subs) and O.USE_DMA and not self.dgrad.uses_zm() and self.dgrad.fc is None) \
+            or self.dgrad.par_ok(self.dtype)
         if fused:      # (sum g, sum g*x) accumulated by the dgrad epilogue
             self.dgrad.run(self.dz, self.g, self.batch, stats=bs, stats_nrep=STATS_NREP, stats_mode=1, aux=x)
         else:

@@ -41,6 +41,7 @@ USE_ZR = os.environ.get("SP_CONV_ZR", "0") != "0"
 USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with too many output tiles for one z-marching launch: a launch per 32-channel slice
 ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "2000"))  # ... when the volume is large enough (one launch per slice: 32->96 @48^3 gains nothing, @166^3 40 %; as teams of one launch: @48^3 147 -> 119 us)
 USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
+PAR_STRIDED = bool(int(os.environ.get("SP_CONV_PAR_STRIDED", "1")))
 USE_PAR = bool(int(os.environ.get("SP_CONV_PAR", "1")))      # parity classes of transposed / strided-gradient ops: one pass over the output (csrc/sp_conv_par.hip)
 ZM_GROUPS = bool(int(os.environ.get("SP_ZM_GROUPS", "1")))      # batched passes: one z-marching launch over all BatchNorm groups (0: one per group, tiled data gradients)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
@@ -283,7 +284,9 @@ class ConvRunner:
         strided ones): per K slot of every class -- in the order of the class's kmap, i.e. of its packed weight fragments --
         (byte offset of (tap, octet) from the lane's base voxel, the tap's per-axis offsets and the octet); None when
         the op does not go there"""
-        if not (USE_PAR and USE_DMA and op.dtype == L.SP_BF16 and 2 <= len(op.subs) <= 8):
+        # ... and strided convolutions (one class, input stride 2: Cae3D.py:45-64 forward, the data gradient of the transposed
+        # layers): the tiled kernel stages a (2 T + 1)^3 halo tile per T^3 outputs there
+        if not (USE_PAR and USE_DMA and op.dtype == L.SP_BF16 and (2 <= len(op.subs) <= 8 or (PAR_STRIDED and len(op.subs) == 1 and max(op.stride) > 1))):
             return None
         Hi, Wi = op.in_dims[1], op.in_dims[2]
         rows, gofs = [], [0]
@@ -310,6 +313,11 @@ class ConvRunner:
     def zm_plan_bn_bwd_ok(z):
         """the z-marching instance of plan z exists with the BatchNorm-backward-sums epilogue (stats_mode 1: sum g, sum g x)"""
         return bool(z is not None and z["NW"] == 8 and z["P"] <= 2 and z["MT"] * z["NT"] == 4 and z["nslot"] == 3)
+
+    def par_ok(self, dtype_out):
+        """csrc/sp_conv_par.hip runs this op (all parity classes / the strided convolution in one pass; its epilogue takes
+        statistics of either kind per BatchNorm group)"""
+        return self.par is not None and not self.uses_zm() and self.fc is None and dtype_out == L.SP_BF16
 
     def zm_bn_bwd_ok(self):
         return self.zm is not None and self.op.dtype == L.SP_BF16 and ConvRunner.zm_plan_bn_bwd_ok(self.zm)

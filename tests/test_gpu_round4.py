@@ -147,7 +147,11 @@ PAR_CASES = [("convT", 16, 16, 2, 2, 0, (6, 20, 22), 4, 2),          # Cae3D.py:
              ("convT", 104, 32, 3, 2, 0, (3, 12, 12), 2, 2),         # Cae3D.py:178-180: classes of unequal extent, 7 input planes
              ("dgrad", 16, 24, 3, 2, (1, 1, 1), (12, 30, 36), 4, 2),  # Cae3D.py:45: gradient of the stride-2 convolutions
              ("dgrad", 24, 32, 3, 2, (1, 1, 1), (6, 18, 26), 2, 1),
-             ("dgrad", 32, 100, 3, 2, (0, 0, 0), (7, 25, 25), 2, 2)]
+             ("dgrad", 32, 100, 3, 2, (0, 0, 0), (7, 25, 25), 2, 2),
+             ("conv", 16, 24, 3, 2, (1, 1, 1), (12, 30, 36), 4, 2),   # the strided convolutions themselves: one class, input stride 2
+             ("conv", 32, 100, 3, 2, (0, 0, 0), (7, 25, 25), 2, 1),
+             ("convTd", 16, 16, 2, 2, 0, (6, 20, 22), 4, 2),         # ... and the data gradient of the transposed layers
+             ("convTd", 104, 32, 3, 2, 0, (3, 12, 12), 2, 2)]
 
 
 @pytest.mark.parametrize("kind,cin,cout,k,s,pad,dims,B,gb", PAR_CASES)
@@ -166,6 +170,24 @@ def test_parity_classes_in_one_pass(kind, cin, cout, k, s, pad, dims, B, gb, mon
         op = P.convT_fwd_op(cin, cout, k, s, pad, dims, cpi, cpo, L.SP_BF16)
         ref = F.elu(F.conv_transpose3d(x, bf(w), b, stride=s, padding=pad), 1.0)
         src, cs, cd, act = _to_cl(x, cpi), cout, cpo, L.ACT_ELU
+    elif kind == "conv":
+        x = bf(torch.randn(B, cin, *dims, generator=gen))
+        w = torch.randn(cout, cin, k, k, k, generator=gen) / math.sqrt(cin * k ** 3)
+        b = torch.randn(cout, generator=gen) * 0.1
+        op = P.conv_fwd_op(cin, cout, k, s, pad, dims, cpi, cpo, L.SP_BF16)
+        ref = F.elu(F.conv3d(x, bf(w), b, stride=s, padding=pad), 1.0)
+        src, cs, cd, act = _to_cl(x, cpi), cout, cpo, L.ACT_ELU
+    elif kind == "convTd":
+        xin = bf(torch.randn(B, cin, *dims, generator=gen) + 0.5)
+        w = torch.randn(cin, cout, k, k, k, generator=gen) / math.sqrt(cout * k ** 3 / s ** 3)
+        b = None
+        xr = xin.clone().requires_grad_(True)
+        zr = F.conv_transpose3d(xr, bf(w), None, stride=s, padding=pad)
+        dz = bf(torch.randn(zr.shape, generator=gen))
+        ref = torch.autograd.grad(zr, xr, dz)[0]
+        op = P.convT_dgrad_op(cin, cout, k, s, pad, dims, cpo, cpi, L.SP_BF16)
+        src, cs, cd, act = _to_cl(dz, cpo), cin, cpi, L.ACT_NONE
+        aux = _to_cl(xin, cpi)
     else:
         out = tuple((dims[a] + 2 * pad[a] - k) // s + 1 for a in range(3))
         xin = bf(torch.randn(B, cin, *dims, generator=gen) + 0.5)
@@ -177,7 +199,7 @@ def test_parity_classes_in_one_pass(kind, cin, cout, k, s, pad, dims, B, gb, mon
         ref = torch.autograd.grad(F.conv3d(xr, bf(w), None, stride=s, padding=pad), xr, dz)[0]
         src, cs, cd, act = _to_cl(dz, cpo), cin, cpi, L.ACT_NONE
         aux = _to_cl(xin, cpi)
-    assert len(op.subs) > 1
+    assert (len(op.subs) > 1) == (kind in ("convT", "dgrad"))
     for name, on in (("par", True), ("classes", False)):
         monkeypatch.setattr(O, "USE_PAR", on)
         run = O.ConvRunner(op, DEV)
@@ -185,8 +207,10 @@ def test_parity_classes_in_one_pass(kind, cin, cout, k, s, pad, dims, B, gb, mon
         run.prep(w.to(DEV), None if b is None else b.to(DEV))
         y = O.alloc_cl(B, op.y_dims, cd, L.SP_BF16, DEV, zero=True)
         st = torch.zeros(G * nrep * cd * 2, dtype=torch.float64, device=DEV)
-        if kind == "convT":
+        if kind in ("convT", "conv"):
             run.run(src, y, B, None, None, act, 1.0, st, stats_nrep=nrep, group_batch=gb)
+        elif kind == "convTd" and not on:      # (the register-staged tiled kernel has no stats_mode 1: production reduces separately)
+            run.run(src, y, B)
         else:
             run.run(src, y, B, stats=st, stats_nrep=nrep, stats_mode=1, aux=aux, group_batch=gb)
         res[name] = (_from_cl(y, cs), st.view(G, nrep, cd, 2).sum(1).cpu(), y)
@@ -197,10 +221,11 @@ def test_parity_classes_in_one_pass(kind, cin, cout, k, s, pad, dims, B, gb, mon
     for gi in range(G):
         sl = slice(gi * gb, (gi + 1) * gb)
         e1 = got[sl].double().sum(dim=(0, 2, 3, 4))
-        e2 = ((got[sl].double() ** 2) if kind == "convT" else got[sl].double() * xin[sl].double()).sum(dim=(0, 2, 3, 4))
+        e2 = ((got[sl].double() ** 2) if kind in ("convT", "conv") else got[sl].double() * xin[sl].double()).sum(dim=(0, 2, 3, 4))
         scale = float(got[sl].abs().max()) * math.sqrt(got[sl].numel() / cs)
         torch.testing.assert_close(sums[gi, :cs, 0], e1, rtol=1e-4, atol=2e-5 * scale)
         torch.testing.assert_close(sums[gi, :cs, 1], e2, rtol=1e-4, atol=2e-4 * scale)
-    # one launch per class: the same K order and the same MFMA sequence per output voxel -> the same stored tensor
+    # one launch per class (the tiled kernel): the same K order and the same MFMA sequence per output voxel -> the same stored tensor
     assert torch.equal(res["classes"][2], yraw)
-    torch.testing.assert_close(res["classes"][1], sums, rtol=1e-5, atol=1e-3)
+    if kind != "convTd":
+        torch.testing.assert_close(res["classes"][1], sums, rtol=1e-5, atol=1e-3)
