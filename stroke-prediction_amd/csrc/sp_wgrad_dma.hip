@@ -1,5 +1,6 @@
-// bf16 fast path of the weight gradient for un-padded, stride-1 3x3x3 convolutions (every Block3x3x3 conv of
-// the U-Net, Unet3D.py:19,22).  Same GEMM view as sp_wgrad.hip (K = 32 output voxels along x, both operands
+// bf16 fast path of the weight gradient for 3x3x3 / 2x2x2 convolutions of stride 1 or 2 with padding 0..2 (every Block3x3x3
+// conv of the U-Net, Unet3D.py:19,22; round 4: the CAE's strided and, with swapped roles, transposed layers, Cae3D.py:45-64,
+// 178-204 -- the staged input tile is then the dense box the strided taps of a row tile reach, read with a voxel stride).  Same GEMM view as sp_wgrad.hip (K = 32 output voxels along x, both operands
 // through LDS and ds_read_b64_tr_b16), restructured after the conv kernel's phase analysis:
 //   * persistent workgroups, TWO LDS tile buffers: the LDS-DMA (global_load_lds_dwordx4) of tile t+1 is in
 //     flight while tile t feeds the MFMAs; one barrier per tile;
@@ -96,6 +97,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
   const int vq0 = ((lg & 1) ? 2 * lg + 1 : 2 * lg) * 4 + lq;
   const int vq1 = ((lg & 1) ? 2 * lg : 2 * lg + 1) * 4 + lq;
   const int off0 = vq0 * WD_VSB + lp * 8, off1 = vq1 * WD_VSB + lp * 8;
+  const int offb0 = vq0 * a.sW * WD_VSB + lp * 8, offb1 = vq1 * a.sW * WD_VSB + lp * 8;      // input voxel of output voxel v: v * stride + tap
   // taps of this wave: exactly WD_TW, indices clamped (the duplicate is dropped at the flush)
   int tapoff[WD_TW];
 #pragma unroll
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
     const int oz0 = tz * P.TZ, oy0 = ty * P.TY, ox0 = tx * 32;
     // input origin of the tile: output origin + o0 (o0 = -padding <= 0: the origin may lie before the volume; such
     // chunks are zero-filled below and their addresses never dereferenced)
-    const int iz0 = oz0 + a.o0D, iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
+    const int iz0 = oz0 * a.sD + a.o0D, iy0 = oy0 * a.sH + a.o0H, ix0 = ox0 * a.sW + a.o0W;
     const unsigned char* xb = reinterpret_cast<const unsigned char*>(xg) +
                               (a.x_plane ? (((((int64_t)b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * 16 + (int64_t)ci_t0 * a.x_plane) * 2
                                          : ((((int64_t)b * a.Di + iz0) * a.Hi + iy0) * a.Wi + ix0) * a.CPi * 2);
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
       const uint32_t rz = fdiv(row, P.d_ty_rows);
       const int ry = row - rz * P.TY;
       const unsigned char* arow = dzt + row * 32 * WD_VSB;
-      const unsigned char* brow = xt + (((int)rz * P.XH + ry) * P.XW) * WD_VSB;
+      const unsigned char* brow = xt + (((int)rz * a.sD * P.XH + ry * a.sH) * P.XW) * WD_VSB;
       bf16x8 af[COB];
 #pragma unroll
       for (int c = 0; c < COB; ++c) af[c] = wd_tr_read2(arow + c * dzplane + off0, arow + c * dzplane + off1);
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_dma_kernel(const WgradDmaDev P) {
 #pragma unroll
         for (int i = 0; i < CIB; ++i) {
           const unsigned char* bp = brow + i * xplane + tapoff[tt];
-          const bf16x8 bf = wd_tr_read2(bp + off0, bp + off1);
+          const bf16x8 bf = wd_tr_read2(bp + offb0, bp + offb1);
 #pragma unroll
           for (int c = 0; c < COB; ++c)
             acc[tt][c][i] = SP_MFMA16(af[c], bf, acc[tt][c][i], 0, 0, 0);
@@ -464,10 +466,15 @@ int sp_wgrad_zr_try(const sp_wgrad_args* a, hipStream_t st);   // sp_wgrad_zr.hi
 
 int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->dtype == SP_BF16 && !a->in_scale && !a->dz_scale, "sp_conv3d_wgrad(dma): bf16, no affine on load");
-  SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1 && a->o0D <= 0 && a->o0H <= 0 && a->o0W <= 0 && a->o0D >= -2 && a->o0H >= -2 && a->o0W >= -2,
-               "sp_conv3d_wgrad(dma): stride 1, padding 0..2 only");
-  SP_CHECK_ARG(a->ntap > 21 && a->ntap <= 28, "sp_conv3d_wgrad(dma): expects 22..28 taps (7 per wave)");
-  SP_CHECK_ARG(a->Di - 2 * a->o0D == a->Do + a->kD - 1 && a->Hi - 2 * a->o0H == a->Ho + a->kH - 1 && a->Wi - 2 * a->o0W == a->Wo + a->kW - 1,
+  const bool unit = a->sD == 1 && a->sH == 1 && a->sW == 1;
+  SP_CHECK_ARG(a->sD >= 1 && a->sD <= 2 && a->sH >= 1 && a->sH <= 2 && a->sW >= 1 && a->sW <= 2 &&
+               a->o0D <= 0 && a->o0H <= 0 && a->o0W <= 0 && a->o0D >= -2 && a->o0H >= -2 && a->o0W >= -2,
+               "sp_conv3d_wgrad(dma): stride 1 or 2, padding 0..2 only");
+  SP_CHECK_ARG(a->ntap >= 1 && a->ntap <= 28 && a->kD >= 1 && a->kD <= 3 && a->kH >= 1 && a->kH <= 3 && a->kW >= 1 && a->kW <= 3, "sp_conv3d_wgrad(dma): at most 3x3x3 = 28 taps (7 per wave)");
+  // every tap of every output voxel lies inside the zero-padded input (a strided convolution may leave a remainder unused)
+  SP_CHECK_ARG(a->Di - 2 * a->o0D >= (a->Do - 1) * a->sD + a->kD && a->Hi - 2 * a->o0H >= (a->Ho - 1) * a->sH + a->kH && a->Wi - 2 * a->o0W >= (a->Wo - 1) * a->sW + a->kW,
+               "sp_conv3d_wgrad(dma): input / output extents do not match a convolution with this stride and padding");
+  SP_CHECK_ARG(!unit || (a->Di - 2 * a->o0D == a->Do + a->kD - 1 && a->Hi - 2 * a->o0H == a->Ho + a->kH - 1 && a->Wi - 2 * a->o0W == a->Wo + a->kW - 1),
                "sp_conv3d_wgrad(dma): input / output extents do not match a stride-1 convolution with this padding");
   // row-sliding z-marching variant (sp_wgrad_zr.hip): un-padded layers with per-workgroup partial blocks
   {
@@ -482,7 +489,7 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   if (a->cib > 0 && a->cib <= CIB) CIB = a->cib;          // caller's blocking of the cin tiles (grid.z grows accordingly)
   // z-marching variant: one input plane per workgroup, partial-row flush, enough rows for its 8-row columns
   // (measured: two output planes per workgroup gain 30-40 %, one plane 5 % on the largest volume and nothing below)
-  if (CIB == 1 && a->parts && a->Ho >= 8 && a->Do >= 4 && a->zs &&
+  if (unit && a->ntap > 21 && CIB == 1 && a->parts && a->Ho >= 8 && a->Do >= 4 && a->zs &&
       (COB == 2 || (COB == 1 && a->zs >= 2) || (COB == 1 && (int64_t)a->B * a->Do * a->Ho * a->Wo >= 5000000))) {
     const int rc = launch_wgrad_zs(a, COB, reinterpret_cast<hipStream_t>(stream));
     if (rc <= 0) return rc;
@@ -492,13 +499,14 @@ int sp_conv3d_wgrad_dma(const sp_wgrad_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(a->x_plane == 0 || a->cib == 1, "sp_conv3d_wgrad(dma): plane-major input needs one input plane per workgroup (cib = 1)");
   // tile rows: two buffers per workgroup; prefer a shape that lets TWO workgroups share a CU (<= 75 KiB each) so
   // that every SIMD has two waves to overlap LDS latency with MFMA issue
-  static const int cand[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+  static const int cand[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
   bool found = false;
   for (int pass = 0; pass < 2 && !found; ++pass) {
     for (auto& cz : cand) {
       if (a->tile_rows > 0 && cz[0] * cz[1] != a->tile_rows) continue;
       P.TZ = cz[0]; P.TY = cz[1];
-      P.XD = P.TZ - 1 + a->kD; P.XH = P.TY - 1 + a->kH; P.XW = 31 + a->kW;
+      P.XD = (P.TZ - 1) * a->sD + a->kD; P.XH = (P.TY - 1) * a->sH + a->kH; P.XW = 31 * a->sW + a->kW;
+      if (P.XD > 255 || P.XH > 255 || P.XW > 255) continue;      // (packed tile coordinates of the border path)
       P.XV = P.XD * P.XH * P.XW; P.TV = P.TZ * P.TY * 32;
       P.nx_chunks = CIB * P.XV * 2; P.ndz_chunks = COB * P.TV * 2;
       P.njx = (P.nx_chunks + 255) / 256; P.njd = (P.ndz_chunks + 255) / 256;

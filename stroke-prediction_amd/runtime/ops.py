@@ -42,6 +42,7 @@ USE_ZM_SLICES = bool(int(os.environ.get("SP_ZM_SLICES", "1")))      # ops with t
 ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "2000"))  # ... when the volume is large enough (one launch per slice: 32->96 @48^3 gains nothing, @166^3 40 %; as teams of one launch: @48^3 147 -> 119 us)
 USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
 PAR_STRIDED = bool(int(os.environ.get("SP_CONV_PAR_STRIDED", "1")))
+WGRAD_DMA_STRIDED = bool(int(os.environ.get("SP_WGRAD_DMA_STRIDED", "1")))      # stride-2 / 2x2x2 weight gradients on the LDS-DMA kernel (0: register-staged)
 USE_PAR = bool(int(os.environ.get("SP_CONV_PAR", "1")))      # parity classes of transposed / strided-gradient ops: one pass over the output (csrc/sp_conv_par.hip)
 ZM_GROUPS = bool(int(os.environ.get("SP_ZM_GROUPS", "1")))      # batched passes: one z-marching launch over all BatchNorm groups (0: one per group, tiled data gradients)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
@@ -601,8 +602,11 @@ class WgradRunner:
         a.CoT, a.CiT = self.cot, self.cit
         a.nblocks = nblocks
         # bf16 fast path: un-padded stride-1 3x3x3 convolution -> DMA double-buffered kernel, BatchNorm folded into finish
-        self.dma = bool(USE_DMA and dtype == L.SP_BF16 and k == (3, 3, 3) and s == (1, 1, 1) and max(p) <= 2
-                        and tuple(in_dims) == tuple(d + 2 - 2 * q for d, q in zip(out_dims, p)) and cpi % 16 == 0 and cpo % 16 == 0
+        # (round 4: also stride 2 and 2x2x2 -- the CAE's strided layers and, with swapped roles, its transposed ones)
+        unit = s == (1, 1, 1) and k == (3, 3, 3) and tuple(in_dims) == tuple(d + 2 - 2 * q for d, q in zip(out_dims, p))
+        strided = (WGRAD_DMA_STRIDED and s == (2, 2, 2) and k in ((3, 3, 3), (2, 2, 2))
+                   and all(i + 2 * q >= (o - 1) * 2 + kk for i, o, q, kk in zip(in_dims, out_dims, p, k)))
+        self.dma = bool(USE_DMA and dtype == L.SP_BF16 and (unit or strided) and max(p) <= 2 and cpi % 16 == 0 and cpo % 16 == 0
                         and self.cot <= int(os.environ.get("SP_WGRAD_DMA_MAXCOT", "64")) and self.cit <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))   # (limits are knobs: the row-sliding kernel takes any tile counts -- 192->64 @88^3 2155 -> 706 us against the register-staged kernel)
         # pointwise layers (1x1x1, stride 1): streaming kernel of csrc/sp_wgrad_pw.hip, BatchNorm folded into the finish as well
         self.pw = bool(USE_PW_WGRAD and WGRAD_PARTS and dtype == L.SP_BF16 and k == (1, 1, 1) and s == (1, 1, 1) and max(p) == 0
@@ -635,7 +639,10 @@ class WgradRunner:
                 cib = min(cib, a.cib)
             yz = -(-self.cot // cob) * -(-self.cit // cib)
             vox = batch * a.Do * a.Ho * a.Wo
-            nb = max(8, min(512 // yz, vox // 512)) // 8 * 8     # multiple of 8: XCD-aware tile walk (floor 512 voxels: tools/wg_sweep.sh)
+            # multiple of 8: XCD-aware tile walk (floor 512 voxels: tools/wg_sweep.sh; strided layers stage 64-voxel tiles and are
+            # bound by the DMA latency per tile -- 32->100 @7x25x25: 8 workgroups x 36 tiles = 119 us -- : floor 128)
+            floor = 512 if (a.sD, a.sH, a.sW) == (1, 1, 1) else int(os.environ.get("SP_WGRAD_STRIDED_FLOOR", "128"))
+            nb = max(8, min(512 // yz, vox // floor)) // 8 * 8
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", nb))
             a.parts, self.nparts = 1, a.nblocks
             self.acc = torch.empty(self.nparts * total, dtype=torch.float32, device=self.device)

@@ -229,3 +229,53 @@ def test_parity_classes_in_one_pass(kind, cin, cout, k, s, pad, dims, B, gb, mon
     assert torch.equal(res["classes"][2], yraw)
     if kind != "convTd":
         torch.testing.assert_close(res["classes"][1], sums, rtol=1e-5, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------ strided weight gradients
+# kind, cin, cout, k, stride, pad, input dims of the forward op, batch, workgroups
+WGS_CASES = [("conv", 16, 24, 3, 2, (1, 1, 1), (12, 30, 70), 2, None),     # Cae3D.py:45 (ragged: 70 -> 35 output voxels per row)
+             ("conv", 24, 32, 3, 2, (1, 1, 1), (6, 18, 26), 2, 16),
+             ("conv", 32, 100, 3, 2, (0, 0, 0), (7, 25, 25), 2, None),      # Cae3D.py:62: 7 output tiles of 16, an unused input remainder
+             ("convT", 16, 16, 2, 2, 0, (6, 20, 22), 2, None),              # Cae3D.py:196-204: roles swapped, 8 taps
+             ("convT", 24, 24, 2, 2, 0, (7, 13, 19), 1, 8),
+             ("convT", 104, 32, 3, 2, 0, (3, 12, 12), 2, None)]             # Cae3D.py:178-180
+
+
+@pytest.mark.parametrize("kind,cin,cout,k,s,pad,dims,B,nblocks", WGS_CASES)
+def test_strided_weight_gradient_on_the_dma_kernel(kind, cin, cout, k, s, pad, dims, B, nblocks, monkeypatch):
+    """csrc/sp_wgrad_dma.hip with stride 2 / 2x2x2 taps (the staged input tile is the dense box the strided taps reach, read with
+    a voxel stride): the CAE's strided convolutions and -- operands swapped -- its transposed ones, against autograd on the same
+    bf16-rounded operands and against the register-staged kernel"""
+    gen = torch.Generator().manual_seed(cin * 13 + cout + k)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    x = bf(torch.randn(B, cin, *dims, generator=gen))
+    if kind == "conv":
+        wr = torch.zeros(cout, cin, k, k, k, requires_grad=True)
+        z = F.conv3d(x, wr, stride=s, padding=pad)
+    else:
+        wr = torch.zeros(cin, cout, k, k, k, requires_grad=True)
+        z = F.conv_transpose3d(x, wr, stride=s, padding=pad)
+    dz = bf(torch.randn(z.shape, generator=gen))
+    z.backward(dz)
+    od = tuple(z.shape[2:])
+    xs, dzs = _to_cl(x, cpi), _to_cl(dz, cpo)
+    if nblocks is not None:
+        monkeypatch.setenv("SP_WGRAD_BLOCKS", str(nblocks))
+    got = {}
+    for on in (True, False):
+        monkeypatch.setattr(O, "WGRAD_DMA_STRIDED", on)
+        kk = k ** 3
+        if kind == "conv":
+            wg = O.WgradRunner(cin, cout, k, s, pad, dims, od, cpi, cpo, cin * kk, kk, L.SP_BF16, DEV)
+        else:      # shifted operand = dz (on the transposed layer's output grid), fixed operand = x
+            wg = O.WgradRunner(cout, cin, k, s, pad, od, dims, cpo, cpi, cout * kk, kk, L.SP_BF16, DEV)
+        assert wg.dma == on
+        dw = torch.zeros_like(wr, device=DEV)
+        if kind == "conv":
+            wg.run(xs, dzs, B, dw)
+        else:
+            wg.run(dzs, xs, B, dw)
+        got[on] = dw.cpu()
+    scale = float(wr.grad.abs().max())
+    torch.testing.assert_close(got[True], wr.grad, rtol=2e-3, atol=2e-3 * scale)
+    torch.testing.assert_close(got[True], got[False], rtol=1e-4, atol=2e-4 * scale)
