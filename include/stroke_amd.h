@@ -510,6 +510,21 @@ int sp_bn_bwd_finalize_groups(const double* sums, int32_t nrep, double count, co
 int sp_bn_act_bwd_groups(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP, int32_t act,
                          float act_param, void* dz, double* dbias_sums, int64_t group_vox, sp_stream_t stream);
 
+/* The CAE decoder's output layer BatchNorm3d(n <= 16) -> Conv3d(n, 1, 1) -> Sigmoid (Cae3D.py:214-218) as streaming kernels
+ * (csrc/sp_pwout.hip; bf16 channels-last input of pitch 16, NCDHW fp32 output of one channel):
+ * forward straight from the RAW input -- the BatchNorm's rows (scale, -, shift) of pitch 16 per group (coef, coef_gstride floats
+ * apart; group of sample b = b / group_batch, 0: one group; NULL: no BatchNorm) folded into 16 coefficients;
+ * backward: g[b, v, c] = w_c dz with dz = dout out (1 - out) -- the gradient at the BatchNorm's output -- and, per group, the 17
+ * sums (sum dz, sum dz x_c) in nrep replica rows of 32 doubles (zeroed by the caller);
+ * finish: the BatchNorm-backward pair (sum g_c, sum g_c x_c) into replica row 0 of bn_sums ([G][bn_nrep][16][2], zeroed by the
+ * caller; NULL: skip), dw[c] += s_c sum dz x_c + t_c sum dz and dbias += sum dz (NULL: a frozen layer). */
+int sp_pwout_fwd(const void* x, int32_t B, int64_t V, int32_t Cin, int32_t CP, const float* coef, int32_t coef_gstride,
+                 int32_t group_batch, const float* w, const float* bias, float* out, sp_stream_t stream);
+int sp_pwout_bwd(const float* dout, const float* out, const void* x, int32_t B, int64_t V, int32_t Cin, int32_t CP, const float* w,
+                 int32_t group_batch, int32_t nrep, void* g, double* sums, sp_stream_t stream);
+int sp_pwout_finish(const double* sums, int32_t nrep, int32_t G, int32_t Cin, const float* w, const float* coef, int32_t coef_gstride,
+                    double* bn_sums, int32_t bn_nrep, float* dw, float* dbias, sp_stream_t stream);
+
 /* ------------------------------------------------------------------ pooling / upsampling / skip (Unet3D.py:59-72)
  * MaxPool3d(2,2) floor mode; optional output statistics [CP][2] */
 int sp_maxpool2_fwd(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,

@@ -10,10 +10,12 @@ import torch
 
 from . import lib as L
 from . import ops as O
-from .layers import ConvLayer, Scratch
+from .layers import ConvLayer, Scratch, STATS_NREP, SYNC, _allreduce
+from . import plan as P
 
 import os
 PITCH16 = not os.environ.get("SP_CAE_PITCH8")     # bf16: 16-channel pitches everywhere (24 -> 32 ...) so that the DMA kernels apply
+FUSED_OUT = bool(int(os.environ.get("SP_CAE_FUSED_OUT", "1")))      # the decoder's BatchNorm -> Conv3d(16, 1, 1) -> Sigmoid tail on csrc/sp_pwout.hip
 
 # (kind, cin_key, cout_key, kernel, stride, padding) -- the layer tables of the reference modules
 ENC_LAYERS = [
@@ -75,6 +77,13 @@ class StackContext:
         sc.finalize()
         self.x0 = O.alloc_cl(batch, in_dims, self.layers[0].cpi, dtype, device)
         self.out_dtype = self.layers[-1].out_dtype
+        # the output layer BatchNorm -> Conv3d(<= 16, 1, 1x1x1) -> Sigmoid (Cae3D.py:214-218) as three streaming kernels
+        # (csrc/sp_pwout.hip): no normalised copy of its input, no 16-channel padded output / output gradient
+        kind, _, _, k, s, p = table[-1]
+        last = self.layers[-1]
+        self.fused_out = bool(FUSED_OUT and last_sigmoid and kind == "conv" and k == 1 and s == 1 and max(P._triple(p)) == 0 and self.cout == 1
+                              and dtype == L.SP_BF16 and last.cpi == 16 and n >= 2)
+        self._out_sums = self._out_g = None
 
     def forward(self, x, params, bufs, training, bump_nbt=True, order=None):
         """x: (B, cin, D, H, W) fp32 on the device -> (B, cout, D', H', W') fp32.
@@ -89,7 +98,8 @@ class StackContext:
         # every weight re-pack of the stack that depends on the parameters only (forward fragments of the un-folded layers with
         # their biases, data-gradient fragments once the backward exists) in ONE launch -- 40-odd launches and as many bias
         # copies per call otherwise
-        O.prep_batch([(l.fwd, params[l.conv_prefix + ".weight"], params[l.conv_prefix + ".bias"]) for l in self.layers if not l.fold] +
+        O.prep_batch([(l.fwd, params[l.conv_prefix + ".weight"], params[l.conv_prefix + ".bias"]) for l in self.layers
+                      if not l.fold and not (self.fused_out and l is self.layers[-1])] +
                      [(l.dgrad, params[l.conv_prefix + ".weight"]) for l in self.layers
                       if l._bwd_ready and getattr(l, "dgrad", None) is not None and l.f8_dgrad is None])
         O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)
@@ -99,16 +109,63 @@ class StackContext:
             for gi in range(self.G):                  # statistics of the stack input, per pass
                 O.bn_stats(self.x0[gi * self.gb:(gi + 1) * self.gb], self.dtype, s0[gi * per:(gi + 1) * per])
         h = self.x0
+        out = torch.empty((self.batch, self.cout) + self.out_dims, dtype=torch.float32, device=self.device)
         for i, lay in enumerate(self.layers):
             nxt = self.layers[i + 1].in_sums if (training and i + 1 < len(self.layers)) else None
             if wait_ev is not None:
                 torch.cuda.current_stream().wait_event(wait_ev[i])
-            h = lay.forward(h, params, bufs, training, nxt)
+            if self.fused_out and i + 1 == len(self.layers):
+                self._out_forward(lay, h, params, bufs, training, out)
+            else:
+                h = lay.forward(h, params, bufs, training, nxt)
             if rec_ev is not None:
                 rec_ev[i].record()
-        out = torch.empty((self.batch, self.cout) + self.out_dims, dtype=torch.float32, device=self.device)
-        O.cl_to_ncdhw(h, out, self.out_dtype)
+        if not self.fused_out:
+            O.cl_to_ncdhw(h, out, self.out_dtype)
         return out
+
+    # ---- the fused output layer (csrc/sp_pwout.hip)
+    def _out_coef(self, lay):
+        """(pointer, group stride in floats, group batch) of the layer's BatchNorm scale / shift rows"""
+        return lay.apply_coef.data_ptr(), 3 * lay.cpi, (self.gb if self.G > 1 else 0)
+
+    def _out_forward(self, lay, x, params, bufs, training, out):
+        lay._bn_fwd(params, bufs, training)
+        c = lay.conv_prefix
+        cp, gs, gb = self._out_coef(lay)
+        V = x.numel() // x.shape[-1] // self.batch
+        L.call("sp_pwout_fwd", O.ptr(x), self.batch, V, lay.cin, lay.cpi, cp, gs, gb, O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]),
+               O.ptr(out), O.stream())
+
+    def _out_backward(self, lay, x, dout, out, params, grads, param_grads):
+        """dL/dout, out (NCDHW fp32, one channel) -> g = gradient at the layer's BatchNorm output (bf16, 16 channels), its
+        BatchNorm-backward coefficients, and the layer's parameter gradients"""
+        c, p = lay.conv_prefix, lay.bn_prefix
+        G, dev = self.G, self.device
+        if self._out_sums is None:
+            self._out_sums = torch.zeros(G * STATS_NREP * 32, dtype=torch.float64, device=dev)
+            self._out_g = torch.empty_like(x)
+            lay.coef = torch.zeros((G, 3, lay.cpi) if G > 1 else (3, lay.cpi), device=dev)
+        self._out_sums.zero_()
+        V = x.numel() // x.shape[-1] // self.batch
+        cp, gs, gb = self._out_coef(lay)
+        w = params[c + ".weight"]
+        L.call("sp_pwout_bwd", O.ptr(dout), O.ptr(out), O.ptr(x), self.batch, V, lay.cin, lay.cpi, O.ptr(w), gb, STATS_NREP,
+               O.ptr(self._out_g), O.ptr(self._out_sums), O.stream())
+        bs = lay.scratch.get(lay.bsums_id)
+        L.call("sp_pwout_finish", O.ptr(self._out_sums), STATS_NREP, G, lay.cin, O.ptr(w), cp, gs, O.ptr(bs), STATS_NREP,
+               O.ptr(grads[c + ".weight"]) if param_grads else None, O.ptr(grads[c + ".bias"]) if param_grads else None, O.stream())
+        if G > 1:
+            world = 1
+            if SYNC["on"]:
+                _allreduce(bs)
+                world = SYNC["world"]
+            L.call("sp_bn_bwd_finalize_groups", O.ptr(bs), STATS_NREP, float(lay.count * world), O.ptr(params[p + ".weight"]),
+                   O.ptr(lay.mean), O.ptr(lay.invstd), lay.cin, lay.cpi, G, O.ptr(grads[p + ".weight"]), O.ptr(grads[p + ".bias"]),
+                   O.ptr(lay.coef), 1.0 / world, O.stream())
+        else:
+            lay._bn_bwd_finalize(bs, params, grads, STATS_NREP)
+        return self._out_g, lay.coef
 
     def prepare(self, params, with_bwd):
         """Pack every weight that depends on the parameters only (forward fragments of the un-folded layers, data-gradient
@@ -141,12 +198,19 @@ class StackContext:
         param_grads=False: a FROZEN stack (CaePredictionLearner / CaeStepLearner: the gradient passes through the decoder into
         a trainable encoder or into the learned step): data gradients and BatchNorm-backward terms only, `grads` is scratch."""
         dt = self.dtype
-        for lay in self.layers:
+        for lay in (self.layers[:-1] if self.fused_out else self.layers):
             lay._init_bwd()
             lay.param_grads = bool(param_grads)
         last = self.layers[-1]
         dout = dout.contiguous()
-        if self.cout <= 8:
+        gv = (lambda t: (t.numel() // t.shape[-1] // self.G) if self.G > 1 else 0)      # voxels per BatchNorm group of a tensor
+        top = len(self.layers) - 1
+        if self.fused_out:
+            prev = self.layers[-2]
+            g, coef = self._out_backward(last, prev.y, dout, out.contiguous(), params, grads, bool(param_grads))
+            O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y))
+            top -= 1
+        elif self.cout <= 8:
             O.out_grad_to_cl(dout, out, dt, last.act, last.act_param, last.dz, last.dbias_sums)
         else:
             # wide outputs (the latent): channels-last copy of the gradient, then the activation derivative
@@ -154,8 +218,7 @@ class StackContext:
                 self._dy = O.alloc_cl(self.batch, self.out_dims, last.cpo, dt, self.device)
             O.ncdhw_to_cl(dout, self._dy, dt)
             O.bn_act_bwd(self._dy, last.y, None, dt, last.act, last.act_param, last.dz, last.dbias_sums)
-        gv = (lambda t: (t.numel() // t.shape[-1] // self.G) if self.G > 1 else 0)      # voxels per BatchNorm group of a tensor
-        for i in range(len(self.layers) - 1, -1, -1):
+        for i in range(top, -1, -1):
             lay = self.layers[i]
             x = self.layers[i - 1].y if i > 0 else self.x0
             g, coef = lay.backward(x, params, grads)

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_DIR = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(PKG_DIR, "lib", "libstroke_amd.so")   # SP_LIB_PATH: diagnostic builds (tools/)
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
-SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_par.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_wgrad_f8.hip", "sp_plan.hip", "sp_comm.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip",
+SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_par.hip", "sp_conv_zm.hip", "sp_conv_zm8.hip", "sp_wgrad.hip", "sp_wgrad_dma.hip", "sp_conv_fc.hip", "sp_wgrad_zr.hip", "sp_wgrad_pw.hip", "sp_wgrad_f8.hip", "sp_plan.hip", "sp_comm.hip", "sp_head.hip", "sp_first.hip", "sp_elem.hip", "sp_pwout.hip",
            "sp_transform.hip"]
 
 SP_BF16, SP_F32, SP_HL = 0, 1, 2      # SP_HL: bf16 pair (hi + lo tensors), the forward storage of the "bf16x3" mode
@@ -101,6 +101,9 @@ _SIGS = {
     "sp_conv_prep_weights_batch": ([vp, i32, i32, vp], i32),
     "sp_conv3d_igemm": ([C.POINTER(ConvArgs), vp], i32),
     "sp_conv3d_igemm_multi": ([C.POINTER(ConvArgs), i32, vp], i32),
+    "sp_pwout_fwd": ([vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
+    "sp_pwout_bwd": ([vp, vp, vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp], i32),
+    "sp_pwout_finish": ([vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp], i32),
     "sp_conv3d_par": ([C.POINTER(ConvArgs), i32, vp, C.POINTER(i32), vp, vp], i32),
     "sp_conv3d_zm": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
