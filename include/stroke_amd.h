@@ -125,9 +125,26 @@ typedef struct sp_conv_args {
   /* ---- bf16 pairs (dtype_in / dtype_out = SP_HL; sp_conv3d_zm and sp_conv3d_igemm forward kernels; 0 elsewhere) */
   int64_t x_lo_delta;          /* bytes from x (hi halves) to the lo halves (a tensor of the same shape and layout) */
   int64_t y_lo_delta;          /* the same for y */
+  /* ---- BatchNorm folded per group into a PADDED convolution (sp_conv3d_zm forward with the ELU epilogue; 0 / NULL elsewhere):
+   * zero padding applies after the normalisation x^ = s x + t, so next to the folded weights W s the bias depends on which taps
+   * of an output voxel fall into the padding: bias_tab[g][class][CPo] = b + sum over the VALID taps of W t, class = (cz * ny + cy)
+   * * nx + cx, c = o for o < pad, pad inside, pad + 1 + (o - (n_out - pad)) behind: 2 pad + 1 classes per axis
+   * (sp_conv_prep_folded_groups writes fragments and table) */
+  const float* bias_tab;       /* NULL: the plain bias */
+  int32_t bias_tab_gstride;    /* floats between the tables of consecutive groups */
+  int32_t pad_;
+  int64_t wfrag_gstride;       /* bytes between the weight fragments (wfrag_hi) of consecutive groups (0: one set) */
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
+/* Weight fragments and bias tables of a stride-1 3x3x3 convolution with padding (padD, padH, padW) <= 2 behind a BatchNorm whose
+ * scale / shift differ per group of the batch (the CAE's batched passes): group g's fragments (W s_g, bf16, K order of kmap) at
+ * wfrag + g * frag_gstride bytes and its table (see sp_conv_args.bias_tab) at bias_tab + g * ncls * CoutPad floats; the rows
+ * (scale, -, shift) of group g at coef + g * coef_gstride with pitch coef_pitch.  One launch.  Cae3D.py:41-70, 186-218. */
+int sp_conv_prep_folded_groups(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap, int32_t nsteps,
+                               int32_t NTtot, void* wfrag, int64_t frag_gstride, const float* coef, int32_t coef_gstride,
+                               int32_t coef_pitch, int32_t G, const float* bias, int32_t padD, int32_t padH, int32_t padW,
+                               float* bias_tab, int32_t CoutPad, sp_stream_t stream);
 /* n (<= 8) sub-convolutions of one op -- the parity classes of a stride-2 transposed convolution (Cae3D.py:178-204) or of a
  * strided convolution's data gradient -- in ONE launch when they share register blocking, data types and the register-staged
  * kernel (dma = 0); otherwise the classes are launched one after the other.  Same result either way. */

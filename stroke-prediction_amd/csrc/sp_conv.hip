@@ -656,6 +656,60 @@ extern "C" int sp_conv_prep_folded(const float* w, int64_t sCo, int64_t sCi, int
   return SP_OK;
 }
 
+// ---- BatchNorm folded per GROUP into a padded stride-1 3x3x3 convolution (the CAE's batched passes, sp_conv_args.bias_tab):
+// blocks [0, G * nprep): the fragments of group g with fold = its scale row; the rest: one wave per table entry
+// (g, class, co) = b[co] + sum over the taps that are valid for the class of sum_ci W[co][ci][tap] * shift_g[ci]
+__device__ __forceinline__ bool tap_valid_for_class(int t, int c, int p) {      // axis with padding p (k = 3): class c of 2 p + 1
+  return c < p ? t >= p - c : (c == p ? true : t < 3 - (c - p));
+}
+__global__ __launch_bounds__(256) void prep_folded_groups_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
+                                                                  const int32_t* __restrict__ kmap, int nsteps, int NTtot,
+                                                                  unsigned char* __restrict__ wfrag, int64_t frag_gstride,
+                                                                  const float* __restrict__ coef, int coef_gstride, int coef_pitch, int G,
+                                                                  int nprep, const float* __restrict__ bias, int pD, int pH, int pW,
+                                                                  float* __restrict__ tab, int CoutPad) {
+  if ((int)blockIdx.x < G * nprep) {
+    const int g = blockIdx.x / nprep, blk = blockIdx.x - g * nprep;
+    prep_wfrag_one(w, sCo, sCi, Cout, Cin, kmap, nsteps, NTtot, reinterpret_cast<bf16_t*>(wfrag + (size_t)g * frag_gstride), nullptr,
+                   coef + (size_t)g * coef_gstride, (int64_t)blk * 256 + threadIdx.x);
+    return;
+  }
+  const int nz = 2 * pD + 1, ny = 2 * pH + 1, nx = 2 * pW + 1, ncls = nz * ny * nx;
+  const int e = ((int)blockIdx.x - G * nprep) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= G * ncls * CoutPad) return;
+  const int co = e % CoutPad, cls = (e / CoutPad) % ncls, g = e / (CoutPad * ncls);
+  const int cx = cls % nx, cy = (cls / nx) % ny, cz = cls / (nx * ny);
+  const float* shift = coef + (size_t)g * coef_gstride + 2 * coef_pitch;
+  float acc = 0.f;
+  if (co < Cout)
+    for (int i = lane; i < Cin * 27; i += 64) {
+      const int ci = i / 27, tp = i - ci * 27;
+      const int tz = tp / 9, ty = (tp / 3) % 3, tx = tp % 3;
+      if (tap_valid_for_class(tz, cz, pD) && tap_valid_for_class(ty, cy, pH) && tap_valid_for_class(tx, cx, pW))
+        acc += w[co * sCo + ci * sCi + tp] * shift[ci];
+    }
+  acc = wave_sum(acc);
+  if (lane == 0) tab[e] = co < Cout ? acc + (bias ? bias[co] : 0.f) : 0.f;
+}
+extern "C" int sp_conv_prep_folded_groups(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap, int32_t nsteps,
+                                          int32_t NTtot, void* wfrag, int64_t frag_gstride, const float* coef, int32_t coef_gstride,
+                                          int32_t coef_pitch, int32_t G, const float* bias, int32_t padD, int32_t padH, int32_t padW,
+                                          float* bias_tab, int32_t CoutPad, sp_stream_t stream) {
+  SP_CHECK_ARG(w && kmap && wfrag && coef && bias_tab && nsteps > 0 && NTtot > 0 && G >= 1 && CoutPad >= Cout && coef_pitch >= Cin && coef_gstride >= 3 * coef_pitch,
+               "sp_conv_prep_folded_groups: bad arguments");
+  SP_CHECK_ARG(padD >= 0 && padD <= 2 && padH >= 0 && padH <= 2 && padW >= 0 && padW <= 2, "sp_conv_prep_folded_groups: padding 0..2");
+  const int64_t total = (int64_t)nsteps * NTtot * 64;
+  SP_CHECK_ARG(frag_gstride >= total * 16 && frag_gstride % 16 == 0, "sp_conv_prep_folded_groups: frag_gstride %lld < one fragment set (%lld bytes)", (long long)frag_gstride, (long long)total * 16);
+  const int nprep = (int)((total + 255) / 256);
+  const int ncls = (2 * padD + 1) * (2 * padH + 1) * (2 * padW + 1);
+  const int ntab = (G * ncls * CoutPad + 3) / 4;
+  hipLaunchKernelGGL(prep_folded_groups_kernel, dim3((unsigned)(G * nprep + ntab)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), w, sCo, sCi,
+                     Cout, Cin, kmap, nsteps, NTtot, reinterpret_cast<unsigned char*>(wfrag), frag_gstride, coef, coef_gstride, coef_pitch, G, nprep,
+                     bias, padD, padH, padW, bias_tab, CoutPad);
+  SP_CHECK_LAUNCH("sp_conv_prep_folded_groups");
+  return SP_OK;
+}
+
 extern "C" int sp_conv_fold_bias(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, int32_t ntaps,
                                  const float* bias, const float* shift, float* bias_out, int32_t CoutPad,
                                  sp_stream_t stream) {

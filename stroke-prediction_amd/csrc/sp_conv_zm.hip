@@ -138,6 +138,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NSA) <= 63, "counted vmcnt does not fit its 6-bit field");
   static_assert(STATS != 2 || (ACT == 0 && !Q8 && !HL && sizeof(TOUT) == 2 && MT * NT == 4 && D == 2), "BatchNorm-backward sums: plain 16-bit data gradient, four tiles per wave");
   constexpr int NWF = 3 * KS * NT;                // weight fragments (1 KiB each)
+  // PB (the ELU instances: the CAE's padded layers): the bias comes from a table in LDS indexed by the output voxel's border class
+  // (sp_conv_args.bias_tab: BatchNorm folded per group into a padded convolution); without a table its one entry is the plain bias
+  constexpr bool PB = ACT == 2;
+  constexpr int BTOFF = WOFF + (WLDS ? (HL ? 2 : 1) * NWF * 1024 : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = Q.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,6 +175,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   const bf16x8* __restrict__ wf = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(a.wfrag_hi) + (size_t)sl * a.slice_wfrag_stride);
   bf16x8 w[WLDS ? 1 : 3][WLDS ? 1 : KS][WLDS ? 1 : NT];
   const unsigned char* wl = lds + WOFF + lane * 16;           // this lane's 16 bytes of fragment 0
+  int w_group = 0;                                            // group whose fragments are loaded (wfrag_gstride != 0)
   if (WLDS) {
     for (int f = wave; f < NWF; f += NW) sp_dma16(reinterpret_cast<const unsigned char*>(wf) + (size_t)f * 1024 + lane * 16, lds + WOFF + f * 1024);
     if constexpr (HL) {      // the lo fragments behind the hi ones
@@ -233,6 +238,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       if (c0s + c < a.CPo) atomicAdd(&gs[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
     }
   };
+  // PB: border classes per axis (2 pad + 1; forward convolutions: o0 = -pad), 1 x 1 x 1 without a table
+  const int bt_pz = (PB && a.bias_tab) ? -a.o0D : 0, bt_py = (PB && a.bias_tab) ? -a.o0H : 0, bt_px = (PB && a.bias_tab) ? -a.o0W : 0;
+  const int bt_ny = 2 * bt_py + 1, bt_nx = 2 * bt_px + 1, bt_ncls = (2 * bt_pz + 1) * bt_ny * bt_nx;
+  auto bt_class = [](int o, int p, int n) { return o < p ? o : (o >= n - p ? min(2 * p, p + 1 + o - (n - p)) : p); };
   zm_u32x2 ax[2][4];                                // STATS 2: x at this lane's four (row, tile) positions, two planes in flight
   uint32_t axtok = 0;                               // (see the wait in ZM_STEP)
 #ifdef SP_ZM_STAMPS
@@ -255,13 +264,41 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     uint32_t t = col;
     uint32_t q = fdiv(t, Q.d_tx); const int tx = t - q * Q.ntx; t = q;
     q = fdiv(t, Q.d_ty); const int ty = t - q * Q.nty; const int b = q;
-    if (STATS && stats_sl != nullptr) {
+    {
       const int g = b / gbatch;
       if (g != cur_g) {
-        if (cur_g >= 0) {       // the march enters another BatchNorm group: hand over what belongs to the last one
+        if (STATS && stats_sl != nullptr && cur_g >= 0) {       // the march enters another BatchNorm group: hand over what belongs to the last one
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           __syncthreads();
           flush_stats(cur_g);
+        }
+        if constexpr (PB) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();                                     // every wave is past its last epilogue / K step of the old group
+          if (a.wfrag_gstride != 0 && g != w_group) {          // the group's own folded weights
+            const bf16x8* wg = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(wf) + (size_t)g * a.wfrag_gstride);
+            if (WLDS) {
+              for (int f = wave; f < NWF; f += NW) sp_dma16(reinterpret_cast<const unsigned char*>(wg) + (size_t)f * 1024 + lane * 16, lds + WOFF + f * 1024);
+            } else {
+#pragma unroll
+              for (int dz = 0; dz < (WLDS ? 0 : 3); ++dz)
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                  for (int n = 0; n < NT; ++n) w[dz][s][n] = wg[((size_t)(dz * KS + s) * NT + n) * 64 + lane];
+            }
+            w_group = g;
+          }
+          // bias table of the group: [class][NT * 16] floats (one class: the plain bias)
+          float* bt = reinterpret_cast<float*>(lds + BTOFF);
+          const int nent = bt_ncls * NT * 16;
+          for (int k = tid; k < nent; k += 64 * NW) {
+            const int c = k % (NT * 16), cl = k / (NT * 16);
+            bt[k] = a.bias_tab ? a.bias_tab[(size_t)g * a.bias_tab_gstride + (size_t)cl * a.CPo + c0s + c] : (bias_sl ? bias_sl[c] : 0.f);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+        } else if (STATS && stats_sl != nullptr && cur_g >= 0) {
           __syncthreads();
         }
         cur_g = g;
@@ -316,6 +353,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       rowoff[m] = ok ? (uint32_t)((((oy * a.osH + a.ooH) * a.YW + (ox * a.osW + a.ooW)) * a.CPo + lg * 4) * (int)sizeof(TOUT)) : 0x80000000u;
       rowok[m] = ok ? 0xffffffffu : 0u;
     }
+    int btrow[PB ? MT : 1];                          // PB: byte offset of (row class, column class, this lane's channel quad) in the bias table
+    if constexpr (PB) {
+      const int cxl = bt_class(min(ox, a.Wo - 1), bt_px, a.Wo);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int oy = min(oy0 + wave * MT + m, a.Ho - 1);
+        btrow[m] = ((bt_class(oy, bt_py, a.Ho) * bt_nx + cxl) * (NT * 16) + lg * 4) * 4;
+      }
+    }
     const uint32_t zstride = (uint32_t)(a.osD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
     const uint32_t zbase = (uint32_t)(a.ooD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
     // the e4m3 copy (dense output only: no phase strides): plane n of sample b, 4 bytes per lane at voxel * 16 + lg * 4
@@ -354,15 +400,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     const bool pv = (fz_) >= 0;                                                                                   \
     const uint32_t zoff = pv ? zbase + (uint32_t)(fz_) * zstride : 0x80000000u;                                   \
     const uint32_t pm = pv ? 0xffffffffu : 0u;                                                                    \
+    const unsigned char* btz_ = lds + BTOFF + (PB ? bt_class(pv ? (fz_) : 0, bt_pz, a.Do) * (bt_ny * bt_nx * NT * 64) : 0); \
     _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
       const uint32_t off = (zoff | rowoff[m]) & 0x80000000u ? 0x80000000u : zoff + rowoff[m];                     \
       const uint32_t off8 = !Q8 || ((zoff | rowoff[m]) & 0x80000000u) ? 0x80000000u : (uint32_t)(fz_) * zstride8 + rowoff8[Q8 ? m : 0]; \
       const uint32_t msk = pm & rowok[m];                                                                         \
       _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                            \
         float v[4];                                                                                               \
+        f32x4 bq_ = {0.f, 0.f, 0.f, 0.f};                                                                         \
+        if constexpr (PB) bq_ = *reinterpret_cast<const f32x4*>(btz_ + btrow[PB ? m : 0] + n * 64);               \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                           \
           if (ACT == 1) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = fmaxf(zz, slope * zz); }           \
-          else if (ACT == 2) { const float zz = acc[R_][n][m][j] + bj[n][j]; v[j] = zz > 0.f ? zz : slope * (__expf(zz) - 1.f); } \
+          else if (ACT == 2) { const float zz = acc[R_][n][m][j] + bq_[j]; v[j] = zz > 0.f ? zz : slope * (__expf(zz) - 1.f); } \
           else v[j] = acc[R_][n][m][j];                                                                           \
         }                                                                                                         \
         if constexpr (HL) {                                                                                       \
@@ -556,7 +605,8 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   constexpr int NJ = (NCH + 64 * NW - 1) / (64 * NW);
   constexpr int S = NJ * NW * 1024;
   // ring (+ 1 KiB per wave where the counted-wait filler DMAs land) (+ the weight fragments; pairs: hi and lo)
-  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? (HL ? 2 : 1) * 3 * KS * NT * 1024 : 0);
+  // (+ the bias table of the ELU instances: at most 75 border classes)
+  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? (HL ? 2 : 1) * 3 * KS * NT * 1024 : 0) + (ACT == 2 ? 75 * NT * 64 : 0);
   static_assert(lds_bytes <= 160 * 1024, "ring + weights do not fit LDS");
   ConvZmDev Q;
   Q.a = *a;
@@ -683,6 +733,14 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
                        (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && a->nslices <= 1),
                "sp_conv3d_zm: bf16 pairs in -> bf16 pairs out with hi and lo weight fragments, bias + LeakyReLU / identity epilogue");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
+  if (a->bias_tab || a->wfrag_gstride) {
+    const int pz = -a->o0D, py = -a->o0H, px = -a->o0W;
+    SP_CHECK_ARG(a->act == SP_ACT_ELU && !hl && a->nslices <= 1 && a->dtype_out == SP_BF16, "sp_conv3d_zm: bias table / per-group fragments are for the bf16 ELU instances");
+    SP_CHECK_ARG(!a->bias_tab || (pz >= 0 && pz <= 2 && py >= 0 && py <= 2 && px >= 0 && px <= 2 && (2 * pz + 1) * (2 * py + 1) * (2 * px + 1) <= 75 &&
+                                  a->bias_tab_gstride >= (2 * pz + 1) * (2 * py + 1) * (2 * px + 1) * a->CPo),
+                 "sp_conv3d_zm: bias table: padding (%d, %d, %d) gives more than 75 classes or bias_tab_gstride %d is too small", pz, py, px, a->bias_tab_gstride);
+    SP_CHECK_ARG(a->wfrag_gstride == 0 || (a->wfrag_gstride > 0 && a->wfrag_gstride % 16 == 0 && a->group_batch > 0), "sp_conv3d_zm: wfrag_gstride needs BatchNorm groups (group_batch)");
+  }
   SP_CHECK_ARG(a->group_batch >= 0 && (a->group_batch == 0 || (a->B % a->group_batch == 0 && a->nslices <= 1)), "sp_conv3d_zm: group_batch %d must divide the batch %d (no slices)", a->group_batch, a->B);
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE || a->act == SP_ACT_ELU, "sp_conv3d_zm: LeakyReLU, ELU or identity epilogue");
   SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);

@@ -85,32 +85,44 @@ __global__ __launch_bounds__(256) void pwout_bwd_kernel(const float* __restrict_
   }
 }
 
-// one workgroup: per group the BatchNorm-backward pair into replica row 0 of bn_sums ([G][bn_nrep][16][2], other rows untouched:
-// the caller zeroed them), the weight and bias gradients (+=; NULL: a frozen layer)
-__global__ __launch_bounds__(64) void pwout_finish_kernel(const double* __restrict__ sums, int nrep, int G, int Cin, const float* __restrict__ w,
-                                                          const float* __restrict__ coef, int coef_gstride, double* __restrict__ bn_sums,
-                                                          int bn_nrep, float* __restrict__ dw, float* __restrict__ dbias) {
-  const int c = threadIdx.x;
-  double dwc = 0.0, dbs = 0.0;
-  for (int g = 0; g < G; ++g) {
-    double s0 = 0.0, sx = 0.0;
-    for (int r = 0; r < nrep; ++r) {
-      s0 += sums[((size_t)g * nrep + r) * PWO_ROW];
-      if (c < 16) sx += sums[((size_t)g * nrep + r) * PWO_ROW + 1 + c];
+// one workgroup of four waves: a wave takes a group at a time, lane r its replica row r (a serial walk over G x nrep rows costs
+// 120 us of dependent loads); per group the BatchNorm-backward pair into replica row 0 of bn_sums ([G][bn_nrep][16][2], other
+// rows untouched: the caller zeroed them); the weight and bias gradients (+=; NULL: a frozen layer) add the groups up in order
+#define PWO_MAXG 16
+__global__ __launch_bounds__(256) void pwout_finish_kernel(const double* __restrict__ sums, int nrep, int G, int Cin, const float* __restrict__ w,
+                                                           const float* __restrict__ coef, int coef_gstride, double* __restrict__ bn_sums,
+                                                           int bn_nrep, float* __restrict__ dw, float* __restrict__ dbias) {
+  __shared__ double gdw[PWO_MAXG][17];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = wave; g < G; g += 4) {
+    double tot[17];
+#pragma unroll
+    for (int k = 0; k < 17; ++k) {
+      double v = 0.0;
+      for (int r = lane; r < nrep; r += 64) v += sums[((size_t)g * nrep + r) * PWO_ROW + k];
+      tot[k] = wave_sum_d(v);
     }
-    if (c < 16) {
-      const double wc = c < Cin ? (double)w[c] : 0.0;
-      if (bn_sums) {
-        bn_sums[((size_t)g * bn_nrep) * 32 + c * 2] = wc * s0;
-        bn_sums[((size_t)g * bn_nrep) * 32 + c * 2 + 1] = wc * sx;
+    const float* cf = coef ? coef + (size_t)g * coef_gstride : nullptr;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      if (lane == c) {
+        const double wc = c < Cin ? (double)w[c] : 0.0;
+        if (bn_sums) {
+          bn_sums[((size_t)g * bn_nrep) * 32 + c * 2] = wc * tot[0];
+          bn_sums[((size_t)g * bn_nrep) * 32 + c * 2 + 1] = wc * tot[1 + c];
+        }
+        gdw[g][c] = cf ? (double)cf[c] * tot[1 + c] + (double)cf[32 + c] * tot[0] : tot[1 + c];
       }
-      const float* cf = coef ? coef + (size_t)g * coef_gstride : nullptr;
-      dwc += cf ? (double)cf[c] * sx + (double)cf[32 + c] * s0 : sx;
     }
-    dbs += s0;
+    if (lane == 16) gdw[g][16] = tot[0];
   }
-  if (dw && c < Cin) dw[c] += (float)dwc;
-  if (dbias && c == 0) dbias[0] += (float)dbs;
+  __syncthreads();
+  if (threadIdx.x < 17) {
+    double t = 0.0;
+    for (int g = 0; g < G; ++g) t += gdw[g][threadIdx.x];
+    if (threadIdx.x < 16) { if (dw && (int)threadIdx.x < Cin) dw[threadIdx.x] += (float)t; }
+    else if (dbias) dbias[0] += (float)t;
+  }
 }
 
 static unsigned pwo_grid(int64_t V) {
@@ -140,9 +152,9 @@ extern "C" int sp_pwout_bwd(const float* dout, const float* out, const void* x, 
 
 extern "C" int sp_pwout_finish(const double* sums, int32_t nrep, int32_t G, int32_t Cin, const float* w, const float* coef, int32_t coef_gstride,
                                double* bn_sums, int32_t bn_nrep, float* dw, float* dbias, sp_stream_t stream) {
-  SP_CHECK_ARG(sums && w && nrep >= 1 && G >= 1 && Cin >= 1 && Cin <= 16 && (!bn_sums || bn_nrep >= 1), "sp_pwout_finish: bad arguments");
+  SP_CHECK_ARG(sums && w && nrep >= 1 && G >= 1 && G <= PWO_MAXG && Cin >= 1 && Cin <= 16 && (!bn_sums || bn_nrep >= 1), "sp_pwout_finish: bad arguments (at most %d groups)", PWO_MAXG);
   SP_CHECK_ARG(!coef || coef_gstride >= 48, "sp_pwout_finish: coef rows are (scale, -, shift) of pitch 16 per group");
-  hipLaunchKernelGGL(pwout_finish_kernel, dim3(1), dim3(64), 0, ST(stream), sums, nrep, G, Cin, w, coef, coef_gstride, bn_sums, bn_nrep, dw, dbias);
+  hipLaunchKernelGGL(pwout_finish_kernel, dim3(1), dim3(256), 0, ST(stream), sums, nrep, G, Cin, w, coef, coef_gstride, bn_sums, bn_nrep, dw, dbias);
   SP_CHECK_LAUNCH("sp_pwout_finish");
   return SP_OK;
 }

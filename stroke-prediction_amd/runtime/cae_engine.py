@@ -99,7 +99,7 @@ class StackContext:
         # their biases, data-gradient fragments once the backward exists) in ONE launch -- 40-odd launches and as many bias
         # copies per call otherwise
         O.prep_batch([(l.fwd, params[l.conv_prefix + ".weight"], params[l.conv_prefix + ".bias"]) for l in self.layers
-                      if not l.fold and not (self.fused_out and l is self.layers[-1])] +
+                      if not l.fold and not l.fold_groups and not (self.fused_out and l is self.layers[-1])] +
                      [(l.dgrad, params[l.conv_prefix + ".weight"]) for l in self.layers
                       if l._bwd_ready and getattr(l, "dgrad", None) is not None and l.f8_dgrad is None])
         O.ncdhw_to_cl(x.contiguous(), self.x0, self.dtype)

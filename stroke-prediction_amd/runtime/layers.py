@@ -128,6 +128,18 @@ class ConvLayer:
         # (groups: ONE launch over the whole batch -- the kernel hands its statistics to the rows of a sample's group)
         self.fwd = O.ConvRunner(self.fwd_op, device, share=None if (bank is None or self.fold) else bank.setdefault((name, "fwd"), {}),
                                 zm_batch=(self.batch if (self.G > 1 and O.ZM_GROUPS) else self.gb) if zm_ok else None)
+        # batched passes on the z-marching kernel: the BatchNorm folded into per-group weight fragments and a bias table over the
+        # border classes of the padded output (sp_conv_prep_folded_groups): the forward reads the RAW input, the normalised copy
+        # (still the weight gradient's operand) is written later, on the side stream of the backward
+        self.fold_groups = bool(self.G > 1 and O.FOLD_GROUPS and O.ZM_GROUPS and zm_ok and self.fwd.zm is not None and bn_prefix is not None and kind == "conv"
+                                and act == L.ACT_ELU and dtype == L.SP_BF16 and (2 * pads[0] + 1) * (2 * pads[1] + 1) * (2 * pads[2] + 1) <= 75)
+        if self.fold_groups:
+            z = self.fwd.zm
+            self._gfrag_elems = z["nsteps"] * z["NT"] * 64 * 8
+            self.gfrag = torch.empty(self.G * self._gfrag_elems, dtype=torch.bfloat16, device=device)
+            self._ncls = (2 * pads[0] + 1) * (2 * pads[1] + 1) * (2 * pads[2] + 1)
+            self.gtab = torch.empty(self.G * self._ncls * self.cpo, dtype=torch.float32, device=device)
+            self._pads = tuple(pads)
         if bn_prefix is not None:
             G = self.G
             self.apply_coef = torch.zeros((G, 3, self.cpi) if G > 1 else (3, self.cpi), device=device)     # (scale, 0, shift): rows 0 and 2 ARE scale / shift
@@ -251,6 +263,15 @@ class ConvLayer:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=L.SP_HL,
                          stats_nrep=STATS_NREP, x_planar=self.x_planar, x_lo=x_lo, y_lo=self.y_lo)
+            return y
+        if self.G > 1 and self.fold_groups:
+            op, z = self.fwd_op, self.fwd.zm
+            L.call("sp_conv_prep_folded_groups", O.ptr(params[c + ".weight"]), op.w_sco, op.w_sci, op.cout, op.cin, O.ptr(z["kmap_d"]), z["nsteps"],
+                   z["NT"], O.ptr(self.gfrag), self._gfrag_elems * 2, self.apply_coef.data_ptr(), 3 * self.cpi, self.cpi, self.G,
+                   O.ptr(params[c + ".bias"]), self._pads[0], self._pads[1], self._pads[2], O.ptr(self.gtab), self.cpo, O.stream())
+            self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
+                         stats_nrep=STATS_NREP, group_batch=self.gb, group_fold=(self.gfrag, self._gfrag_elems * 2, self.gtab, self._ncls * self.cpo))
+            self._xhat_of = None            # the normalised copy of THIS input does not exist yet (backward writes it)
             return y
         if self.G > 1:
             src = x
@@ -433,6 +454,12 @@ class ConvLayer:
             if not wgrad:
                 pass
             elif self.kind == "conv":
+                if self.fold_groups:        # the weight gradient's operand: x^ = s_g x + t_g, written here (beside the data gradient)
+                    if self.xhat is None:
+                        self.xhat = torch.empty_like(x)
+                    O.bn_act_bwd(x, x, self.apply_coef, self.dtype, L.ACT_NONE, 0.0, self.xhat, None,
+                                 group_vox=x.numel() // x.shape[-1] // self.G)
+                    src = self.xhat
                 self.wgrad.run(src, self.dz, self.batch, grads[c + ".weight"], None, None,
                                dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout)
             else:

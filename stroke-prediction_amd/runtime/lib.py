@@ -40,7 +40,8 @@ class ConvArgs(C.Structure):
                    "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "act")] + [("act_param", f32), ("dma", i32), ("zfill", i32), ("persist", i32), ("aux", vp), ("stats_mode", i32), ("stats_nrep", i32), ("ITH_zs", i32), ("x_plane", i64),
                                                                            ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32),
                                                                            ("group_batch", i32), ("nslices", i32),
-                                                                          ("slice_wfrag_stride", i64), ("x_lo_delta", i64), ("y_lo_delta", i64)]
+                                                                          ("slice_wfrag_stride", i64), ("x_lo_delta", i64), ("y_lo_delta", i64),
+                                                                          ("bias_tab", vp), ("bias_tab_gstride", i32), ("pad_", i32), ("wfrag_gstride", i64)]
 
 
 class WgradArgs(C.Structure):
@@ -104,6 +105,7 @@ _SIGS = {
     "sp_pwout_fwd": ([vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_pwout_bwd": ([vp, vp, vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp], i32),
     "sp_pwout_finish": ([vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp], i32),
+    "sp_conv_prep_folded_groups": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, i64, vp, i32, i32, i32, vp, i32, i32, i32, vp, i32, vp], i32),
     "sp_conv3d_par": ([C.POINTER(ConvArgs), i32, vp, C.POINTER(i32), vp, vp], i32),
     "sp_conv3d_zm": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),

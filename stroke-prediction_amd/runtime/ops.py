@@ -43,6 +43,11 @@ ZM_SLICE_MIN_PLANES = int(os.environ.get("SP_ZM_SLICE_MIN_PLANES", "2000"))  # .
 USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming weight-gradient kernel for pointwise layers
 PAR_STRIDED = bool(int(os.environ.get("SP_CONV_PAR_STRIDED", "1")))
 WGRAD_DMA_STRIDED = bool(int(os.environ.get("SP_WGRAD_DMA_STRIDED", "1")))      # stride-2 / 2x2x2 weight gradients on the LDS-DMA kernel (0: register-staged)
+# batched passes: BatchNorm folded per group into the z-marching forward (per-group fragments + a bias table over the border classes,
+# sp_conv_prep_folded_groups), the normalised copy written later beside the weight gradient.  OFF: measured 7.05 -> 7.18 ms/step --
+# the copy is the weight gradient's operand, so its bytes only move to the side stream of the (bandwidth-bound) backward; it pays
+# once the weight gradient reads the raw input too (border-restricted sums of dz in the folded finish: not built)
+FOLD_GROUPS = bool(int(os.environ.get("SP_FOLD_GROUPS", "0")))
 USE_PAR = bool(int(os.environ.get("SP_CONV_PAR", "1")))      # parity classes of transposed / strided-gradient ops: one pass over the output (csrc/sp_conv_par.hip)
 ZM_GROUPS = bool(int(os.environ.get("SP_ZM_GROUPS", "1")))      # batched passes: one z-marching launch over all BatchNorm groups (0: one per group, tiled data gradients)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
@@ -395,7 +400,7 @@ class ConvRunner:
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
             dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None,
-            x_lo=None, y_lo=None):
+            x_lo=None, y_lo=None, group_fold=None):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
         y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners)."""
@@ -451,6 +456,12 @@ class ConvRunner:
             assert y8.dtype == torch.uint8 and tuple(y8.shape) == (y.shape[4] // 16, batch) + tuple(op.y_dims) + (16,)
             a.y8, a.y8_plane, a.y8_scale = ptr(y8), batch * int(np.prod(op.y_dims)) * 16, 1.0
         st = stream()
+        if group_fold is not None:      # (fragments, bytes per group, bias tables, floats per group): sp_conv_prep_folded_groups
+            assert self.zm is not None and batch == self.zm_batch and group_batch and act == L.ACT_ELU and stats_mode == 0
+            gf, gfs, gt, gts = group_fold
+            a.group_batch = group_batch
+            a.bias_tab, a.bias_tab_gstride, a.wfrag_gstride = ptr(gt), gts, gfs
+            return _run_zm_impl(self, a, x_planar, batch, stats is not None, st, wfrag=gf)
         if self.uses_zm():
             assert batch == self.zm_batch and in_scale is None and (stats_mode == 0 or (stats_mode == 1 and self.zm_bn_bwd_ok())) \
                 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
@@ -514,7 +525,7 @@ def wgrad_dma_ok(cpi, cpo, dtype):
                 and -(-cpi // 16) <= int(os.environ.get("SP_WGRAD_DMA_MAXCIT", "64")))
 
 
-def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, stats=None, use_bias=True):
+def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, stats=None, use_bias=True, wfrag=None):
     op = runner.op
     sliced = z is not None
     z = runner.zm if z is None else z
@@ -524,7 +535,9 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
         a.y = y.data_ptr() + z["c0"] * esz
         a.bias = (runner.bias.data_ptr() + 4 * z["c0"]) if (runner.has_bias and use_bias) else None
         a.stats = None if stats is None else stats.data_ptr() + 16 * z["c0"]
-    a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"]), ptr(z.get("lo")), ptr(z["ktab_d"])
+    a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"] if wfrag is None else wfrag), ptr(z.get("lo")), ptr(z["ktab_d"])
+    if wfrag is not None:
+        a.bias = None
     a.Do, a.Ho, a.Wo = sub.out_dims
     a.osD, a.osH, a.osW = 1, 1, 1
     a.ooD, a.ooH, a.ooW = 0, 0, 0

@@ -279,3 +279,56 @@ def test_strided_weight_gradient_on_the_dma_kernel(kind, cin, cout, k, s, pad, d
     scale = float(wr.grad.abs().max())
     torch.testing.assert_close(got[True], wr.grad, rtol=2e-3, atol=2e-3 * scale)
     torch.testing.assert_close(got[True], got[False], rtol=1e-4, atol=2e-4 * scale)
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm folded per group
+@pytest.mark.parametrize("cin,cout,dims,pad,B,gb", GROUP_CASES + [(16, 16, (5, 37, 21), (2, 2, 1), 4, 1)])
+def test_z_marching_forward_with_batchnorm_folded_per_group(cin, cout, dims, pad, B, gb, monkeypatch):
+    """y = ELU(conv(zero-padded (s_g x + t_g))) from the RAW input: per-group weight fragments W s_g and a bias table over the border
+    classes of the output (the taps that fall into the padding contribute no W t_g) -- sp_conv_prep_folded_groups + sp_conv3d_zm
+    with bias_tab / wfrag_gstride, one launch over all groups -- against torch on the normalised, then padded input"""
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    gen = torch.Generator().manual_seed(cin + 7 * cout + B)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    G = B // gb
+    x = bf(torch.randn(B, cin, *dims, generator=gen))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=gen) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=gen) * 0.1
+    scale = torch.rand(G, cin, generator=gen) + 0.5
+    shift = torch.randn(G, cin, generator=gen)
+    coef = torch.zeros(G, 3, cpi)
+    coef[:, 0, :cin], coef[:, 2, :cin] = scale, shift
+    op = P.conv_fwd_op(cin, cout, 3, 1, pad, dims, cpi, cpo, L.SP_BF16)
+    run = O.ConvRunner(op, DEV, zm_batch=B)
+    assert run.zm is not None
+    z = run.zm
+    nfe = z["nsteps"] * z["NT"] * 64 * 8
+    ncls = (2 * pad[0] + 1) * (2 * pad[1] + 1) * (2 * pad[2] + 1)
+    gfrag = torch.empty(G * nfe, dtype=torch.bfloat16, device=DEV)
+    gtab = torch.empty(G * ncls * cpo, dtype=torch.float32, device=DEV)
+    wd, bd, cd = w.to(DEV), b.to(DEV), coef.to(DEV)
+    L.call("sp_conv_prep_folded_groups", O.ptr(wd), op.w_sco, op.w_sci, cout, cin, O.ptr(z["kmap_d"]), z["nsteps"], z["NT"], O.ptr(gfrag), nfe * 2,
+           O.ptr(cd), 3 * cpi, cpi, G, O.ptr(bd), pad[0], pad[1], pad[2], O.ptr(gtab), cpo, O.stream())
+    xs = _to_cl(x, cpi)
+    nrep = 4
+    y = O.alloc_cl(B, op.y_dims, cpo, L.SP_BF16, DEV)
+    stats = torch.zeros(G * nrep * cpo * 2, dtype=torch.float64, device=DEV)
+    run.run(xs, y, B, None, None, L.ACT_ELU, 1.0, stats, stats_nrep=nrep, group_batch=gb, group_fold=(gfrag, nfe * 2, gtab, ncls * cpo))
+    got = _from_cl(y, cout)
+    ref = torch.empty_like(got)
+    for gi in range(G):
+        sl = slice(gi * gb, (gi + 1) * gb)
+        xh = x[sl] * scale[gi].view(1, -1, 1, 1, 1) + shift[gi].view(1, -1, 1, 1, 1)
+        ref[sl] = F.elu(F.conv3d(xh, w, b, padding=pad), 1.0)
+    err = (got - ref).abs()
+    assert float(err.max()) < 8e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
+    # the border voxels are where a wrong class would show: held to the same bound on their own
+    border = torch.ones_like(ref, dtype=torch.bool)
+    border[:, :, 2:-2, 2:-2, 2:-2] = False
+    assert float(err[border].max()) < 8e-2
+    st = stats.view(G, nrep, cpo, 2).sum(1).cpu()
+    for gi in range(G):
+        part = got[gi * gb:(gi + 1) * gb].double()
+        torch.testing.assert_close(st[gi, :cout, 0], part.sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2 * math.sqrt(part.numel() / cout))
+    if cpo > cout:
+        assert float(y[..., cout:].float().abs().max()) == 0.0
