@@ -526,6 +526,22 @@ int sp_bn_bwd_finalize_groups(const double* sums, int32_t nrep, double count, co
                               float param_grad_scale, sp_stream_t stream);
 int sp_bn_act_bwd_groups(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP, int32_t act,
                          float act_param, void* dz, double* dbias_sums, int64_t group_vox, sp_stream_t stream);
+/* sp_bn_act_bwd_groups for a layer whose weight gradient reads the RAW layer input although its BatchNorm differs per group and
+ * its convolution pads (the CAE's batched passes with the BatchNorm folded per group, sp_conv_args.bias_tab): next to dz
+ * [B][D][H][W][CP] it leaves the sums of the stored dz over the border classes of that output grid -- (2 pad + 1) classes per
+ * axis, class = (cz * ny + cy) * nx + cx -- per group in cls_sums[G][ncls][CP] (fp64, zeroed by the caller; <= 75 classes). */
+int sp_bn_act_bwd_groups_cls(const void* g, const void* y, const float* coef, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
+                             int32_t CP, int32_t act, float act_param, void* dz, double* dbias_sums, int32_t group_batch,
+                             int32_t padD, int32_t padH, int32_t padW, double* cls_sums, sp_stream_t stream);
+/* ... and the finish of that layer's weight gradient (sp_conv3d_wgrad on the raw input, row-sliding kernel: partial block i
+ * belongs to group i * G / nparts): dw[co][ci][tap] += sum_g s_g[ci] A_g + t_g[ci] Sv_g[tap][co] with Sv_g the class sums whose tap
+ * lies inside the input, dbias_grad[co] += sum dz, and the BatchNorm-backward pair (sum g, sum g x) of the layer's input per group
+ * into bn_sums[G][bn_nrep][bn_cp][2] (NULL: skip) -- the data gradient then needs no statistics epilogue.  coef: rows
+ * (scale, -, shift) of pitch coef_pitch per group. */
+int sp_wgrad_finish_folded_groups(const float* dw_acc, int32_t nparts, int32_t G, int32_t CoP, int32_t CiP, int32_t Cout, int32_t Cin,
+                                  int64_t sCo, int64_t sCi, const float* coef, int32_t coef_gstride, int32_t coef_pitch,
+                                  const double* cls_sums, int32_t padD, int32_t padH, int32_t padW, const float* w, float* dw,
+                                  float* dbias_grad, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, sp_stream_t stream);
 
 /* The CAE decoder's output layer BatchNorm3d(n <= 16) -> Conv3d(n, 1, 1) -> Sigmoid (Cae3D.py:214-218) as streaming kernels
  * (csrc/sp_pwout.hip; bf16 channels-last input of pitch 16, NCDHW fp32 output of one channel):

@@ -496,6 +496,150 @@ struct Unflat {
 };
 #define SP_CHECK_VOX(n, what) SP_CHECK_ARG((int64_t)(n) < (1ll << 31), what ": 2^31 voxels or more")
 
+// The same pass for the batched CAE layers whose weight gradient reads the RAW layer input (BatchNorm folded per group, zero
+// padding AFTER the normalisation): with x^ = s x + t inside the volume and 0 in the padding,
+//   dW[tap] = s * sum_v dz[v] x[v + tap]  +  t * sum_{v: v + tap inside the input} dz[v],
+// so next to dz this variant leaves, per group, the sums of dz over the BORDER CLASSES of the output grid (2 pad + 1 classes per
+// axis: o < pad, inside, o >= n - pad; class = (cz * ny + cy) * nx + cx, sp_conv_args.bias_tab) in cls_sums[G][ncls][CP] (fp64,
+// zeroed by the caller): any tap's box sum is a sum of classes (sp_wgrad_finish_folded_groups).  Workgroups are group-pure
+// (grid.y = group); class sums go through fp64 LDS atomics (sums of fp32 values: exact, hence order-independent).
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_cls_kernel(const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ coef,
+                                                              int64_t gvox, int CP, OctMap om, int act, float ap, T* __restrict__ dz,
+                                                              double* __restrict__ dbias, int D, int H, int W, int pz, int py, int px,
+                                                              double* __restrict__ cls_sums) {
+  extern __shared__ double s_cls[];      // [ncls][CP]
+  const int gi = blockIdx.y;
+  const int ny = 2 * py + 1, nx = 2 * px + 1, ncls = (2 * pz + 1) * ny * nx;
+  const int mid = (pz * ny + py) * nx + px;
+  for (int k = threadIdx.x; k < ncls * CP; k += 256) s_cls[k] = 0.0;
+  __syncthreads();
+  const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
+  const bool active = slot < om.vpb;
+  float part[1][8];
+  float c0[8], c1[8], c2[8];
+  const float* cg = coef + (size_t)gi * 3 * CP;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    part[0][j] = 0.f;
+    c0[j] = active ? cg[oc * 8 + j] : 1.f;
+    c1[j] = active ? cg[CP + oc * 8 + j] : 0.f;
+    c2[j] = active ? cg[2 * CP + oc * 8 + j] : 0.f;
+  }
+  const Unflat unflat(D, H, W);
+  int cur = mid;
+  auto cls1 = [](int o, int p, int n) { return o < p ? o : (o >= n - p ? p + 1 + o - (n - p) : p); };
+  {
+    const int64_t chunk_ = ((gvox + gridDim.x - 1) / gridDim.x + om.vpb - 1) / om.vpb * om.vpb;
+    const int64_t v0 = (int64_t)gi * gvox, vend_ = v0 + min(gvox, ((int64_t)blockIdx.x + 1) * chunk_);
+    int64_t v = v0 + (int64_t)blockIdx.x * chunk_ + slot;
+    const int niter = (int)((min(chunk_, gvox - (int64_t)blockIdx.x * chunk_) + om.vpb - 1) / om.vpb);      // the same for every thread
+    // (z, y, x) of the walk, advanced by the voxels per workgroup each iteration: no divisions inside the loop
+    int bb = 0, z = 0, yy = 0, x = 0;
+    if (active && v < vend_) unflat(v, bb, z, yy, x);
+    int cx = cls1(x, px, W), czy = cls1(z, pz, D) * ny + cls1(yy, py, H);
+    // hand this thread's running sums to the table.  A wave's 64 / OC voxels are consecutive, so it usually changes class as ONE
+    // (the walk enters another row class): then the lanes of an octet are added up by shuffles and one lane per octet does the
+    // atomics; 128 threads flushing to one address each cost ~1000 serialised LDS operations per event otherwise
+    auto flush = [&](bool mine) {
+      const bool uni = __all(mine && cur == __builtin_amdgcn_readfirstlane(cur));
+      if (uni) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float t = part[0][j];
+          for (int o = 32; o >= om.OC; o >>= 1) t += __shfl_xor(t, o, 64);
+          if ((int)(threadIdx.x & 63) < om.OC) atomicAdd(&s_cls[cur * CP + oc * 8 + j], (double)t);
+          part[0][j] = 0.f;
+        }
+      } else if (mine) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { atomicAdd(&s_cls[cur * CP + oc * 8 + j], (double)part[0][j]); part[0][j] = 0.f; }
+      }
+    };
+    const bool pow2 = (om.OC & (om.OC - 1)) == 0 && 64 % om.OC == 0;      // (octets per voxel 1, 2, 4, 8: lanes of an octet = lane % OC)
+    for (int it = 0; it < niter; ++it, v += om.vpb) {
+      const bool ok = active && v < vend_;
+      const int cid = ok ? czy * nx + cx : cur;
+      const bool chg = cid != cur;
+      if (__any(chg)) {
+        if (pow2) flush(chg);
+        else if (chg) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { atomicAdd(&s_cls[cur * CP + oc * 8 + j], (double)part[0][j]); part[0][j] = 0.f; }
+        }
+        cur = cid;
+      }
+      if (ok) {
+        float a[8], b[8], o[8];
+        Store<T>::ld8(g + v * CP + oc * 8, a);
+        Store<T>::ld8(y + v * CP + oc * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (c0[j] * a[j] + c1[j] * b[j] + c2[j]) * act_bwd_t<ACT>(act, ap, b[j]);
+        // the STORED values (what the weight gradient multiplies) are what is summed: pack once, store, unpack
+        uint32_t wq[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[j] = sp_pack_bf16x2(o[2 * j], o[2 * j + 1]);
+        *reinterpret_cast<uint4*>(dz + v * CP + oc * 8) = make_uint4(wq[0], wq[1], wq[2], wq[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { part[0][2 * j] += sp_h2f_lo(wq[j]); part[0][2 * j + 1] += sp_h2f_hi(wq[j]); }
+      }
+      // next voxel of the walk
+      x += om.vpb;
+      if (x >= W) {
+        int dy = 0;
+        while (x >= W) { x -= W; ++dy; }
+        cx = cls1(x, px, W);
+        yy += dy;
+        while (yy >= H) { yy -= H; ++z; }
+        if (z >= D) z -= D;          // (the next sample of the group: the classes depend on (z, y, x) only)
+        czy = cls1(z, pz, D) * ny + cls1(yy, py, H);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&s_cls[cur * CP + oc * 8 + j], (double)part[0][j]);
+    }
+  }
+  __syncthreads();
+  double* out = cls_sums + (size_t)gi * ncls * CP;
+  for (int k = threadIdx.x; k < ncls * CP; k += 256) {
+    const double v = s_cls[k];
+    if (v != 0.0) atomicAdd(&out[k], v);
+  }
+  // the bias gradient's sums (all groups, replica rows as bn_act_bwd): the column totals of this workgroup's table
+  if (dbias) {
+    for (int c = threadIdx.x; c < CP; c += 256) {
+      double t = 0.0;
+      for (int cl = 0; cl < ncls; ++cl) t += s_cls[cl * CP + c];
+      atomicAdd(&dbias[(size_t)((blockIdx.x + blockIdx.y) % SP_REDUCE_ROWS) * CP + c], t);
+    }
+  }
+}
+extern "C" int sp_bn_act_bwd_groups_cls(const void* g, const void* y, const float* coef, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
+                                        int32_t CP, int32_t act, float act_param, void* dz, double* dbias_sums, int32_t group_batch,
+                                        int32_t padD, int32_t padH, int32_t padW, double* cls_sums, sp_stream_t stream) {
+  SP_CHECK_ARG(g && y && coef && dz && cls_sums && dtype == SP_BF16 && CP % 8 == 0 && CP <= 64, "sp_bn_act_bwd_groups_cls: bf16 tensors of at most 64 channels");
+  SP_CHECK_ARG(group_batch > 0 && B % group_batch == 0 && D >= 1 && H >= 1 && W >= 1, "sp_bn_act_bwd_groups_cls: the groups must tile the batch");
+  SP_CHECK_ARG(padD >= 0 && padD <= 2 && padH >= 0 && padH <= 2 && padW >= 0 && padW <= 2 && D >= 2 * padD && H >= 2 * padH && W >= 2 * padW &&
+               (2 * padD + 1) * (2 * padH + 1) * (2 * padW + 1) <= 75, "sp_bn_act_bwd_groups_cls: padding 0..2, at most 75 classes");
+  const int64_t gvox = (int64_t)group_batch * D * H * W;
+  SP_CHECK_VOX((int64_t)B * D * H * W, "sp_bn_act_bwd_groups_cls");
+  const int G = B / group_batch, ncls = (2 * padD + 1) * (2 * padH + 1) * (2 * padW + 1);
+  OctMap om = make_octmap(CP);
+  // few, long workgroups: the class table (zeroing, flush, column totals: ~3 ncls CP LDS operations) is a fixed cost per workgroup
+  unsigned gx = grid_for(gvox, om.vpb * 4);
+  const unsigned cap = (unsigned)(2048 / G > 0 ? 2048 / G : 1);
+  if (gx > cap) gx = cap;
+  const size_t sh = (size_t)ncls * CP * sizeof(double);
+#define SP_L(A_)                                                                                                                       \
+  hipLaunchKernelGGL((bn_act_bwd_cls_kernel<bf16_t, A_>), dim3(gx, G), dim3(256), sh, ST(stream), (const bf16_t*)g, (const bf16_t*)y, coef, gvox, \
+                     CP, om, act, act_param, (bf16_t*)dz, dbias_sums, D, H, W, padD, padH, padW, cls_sums)
+  SP_ACT_DISPATCH(act, SP_L)
+#undef SP_L
+  SP_CHECK_LAUNCH("sp_bn_act_bwd_groups_cls");
+  return SP_OK;
+}
+
 // MaxPool3d(2,2), floor mode (Unet3D.py:39,41)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims di, int CP,

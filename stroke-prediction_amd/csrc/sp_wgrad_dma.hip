@@ -717,6 +717,121 @@ static int wgrad_finish_folded_impl(float* dw_acc, int32_t nparts, const int32_t
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded");
   return SP_OK;
 }
+// ---- folded finish of a PADDED stride-1 3x3x3 layer whose BatchNorm differs per group of the batch (the CAE's batched passes;
+// sp_conv_args.bias_tab is the forward's side of the same fold).  The weight gradient ran on the RAW input x (zero padded), into
+// per-workgroup partial blocks whose index order follows the samples (sp_wgrad_zr.hip), so blocks [g nb / G, (g + 1) nb / G) belong
+// to group g.  With x^ = s_g x + t_g inside the volume and 0 in the padding:
+//   dW[co][ci][tap] += sum_g  s_g[ci] A_g[tap][co][ci] + t_g[ci] Sv_g[tap][co],     A_g = the group's partial blocks added up,
+//   Sv_g[tap][co] = sum of dz over the output voxels whose tap lies inside the input = a sum of border classes of cls_sums
+//   (sp_bn_act_bwd_groups_cls); dbias[co] += sum_g sum_classes; and the BatchNorm-backward pair of the layer's input, per group,
+//   (sum_v g, sum_v g x)[ci] = sum_{tap, co} W[co][ci][tap] (Sv_g[tap][co], A_g[tap][co][ci])   (g = the data gradient: it needs no
+//   statistics epilogue and no second read of x then).
+__device__ __forceinline__ bool fg_tap_valid(int t, int c, int p) { return c < p ? t >= p - c : (c == p ? true : t < 3 - (c - p)); }
+// a workgroup = 32 consecutive accumulator entries x 8 row lanes that split the group's partial blocks (a serial walk over the
+// blocks per entry, 27 workgroups in all, took 116 us of dependent loads)
+__global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const float* __restrict__ acc, int nb, int G, int CoP, int CiP, int Cout, int Cin,
+                                                                          int64_t sCo, int64_t sCi, const float* __restrict__ coef, int coef_gstride,
+                                                                          int coef_pitch, const double* __restrict__ cls, int pz, int py, int px,
+                                                                          const float* __restrict__ w, float* __restrict__ dw, float* __restrict__ dbias_grad,
+                                                                          double* __restrict__ bn_sums, int bn_nrep, int bn_cp) {
+  __shared__ float red[8][33];
+  __shared__ double bred[2][32];
+  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int64_t total = (int64_t)27 * CoP * CiP;
+  const int64_t e = (int64_t)blockIdx.x * 32 + el;
+  const bool in = e < total;
+  const int ci = in ? (int)(e % CiP) : 0, co = in ? (int)((e / CiP) % CoP) : 0, tap = in ? (int)(e / ((int64_t)CiP * CoP)) : 0;
+  const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
+  const int ny = 2 * py + 1, nx = 2 * px + 1, ncls = (2 * pz + 1) * ny * nx;
+  const int per = nb / G;
+  const bool real = in && co < Cout && ci < Cin;
+  const float wv = (real && rl == 0) ? w[co * sCo + ci * sCi + tap] : 0.f;
+  // Sv[g][pair]: the class sums whose tap lies inside the input, for the (tap, co) pairs of this workgroup's 32 entries (at most
+  // 32 / CiP + 1 of them): a row lane takes a (group, pair), its 32 lanes the classes (one thread walking 75 classes x G groups of
+  // fp64 loads cost 60 us)
+  __shared__ double svs[16][8];
+  const int64_t e0 = (int64_t)blockIdx.x * 32;
+  const int pair0 = (int)(e0 / CiP);                                   // first (tap * CoP + co) of the workgroup
+  const int npair = (int)((min(e0 + 31, total - 1)) / CiP) - pair0 + 1;
+  for (int q = rl; q < G * npair; q += 8) {
+    const int g = q / npair, pr = pair0 + q % npair;
+    const int pco = pr % CoP, ptap = pr / CoP;
+    const int ptz = ptap / 9, pty = (ptap / 3) % 3, ptx = ptap % 3;
+    double t = 0.0;
+    for (int cl = el; cl < ncls; cl += 32) {
+      const int cx = cl % nx, cy = (cl / nx) % ny, cz = cl / (nx * ny);
+      if (fg_tap_valid(ptz, cz, pz) && fg_tap_valid(pty, cy, py) && fg_tap_valid(ptx, cx, px)) t += cls[((size_t)g * ncls + cl) * CoP + pco];
+    }
+    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 32);
+    if (el == 0 && g < 16 && q % npair < 8) svs[g][q % npair] = t;
+  }
+  __syncthreads();
+  float dwv = 0.f;
+  for (int g = 0; g < G; ++g) {
+    float a0 = 0.f, a1 = 0.f;
+    if (in) {
+      // eight independent loads in flight per thread (a two-load loop waits a memory round trip per iteration: 16 us per group)
+      const float* p = acc + (size_t)g * per * total + e;
+      for (int b = rl; b < per; b += 64) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (b + 8 * k < per) ? p[(size_t)(b + 8 * k) * total] : 0.f;
+        a0 += (t[0] + t[2]) + (t[4] + t[6]);
+        a1 += (t[1] + t[3]) + (t[5] + t[7]);
+      }
+    }
+    red[rl][el] = a0 + a1;
+    __syncthreads();
+    if (rl == 0) {
+      float A = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) A += red[r][el];
+      const double Sv = in ? svs[g][(int)(e / CiP) - pair0] : 0.0;
+      const float* cf = coef + (size_t)g * coef_gstride;
+      if (real) dwv += cf[ci] * A + cf[2 * coef_pitch + ci] * (float)Sv;
+      bred[0][el] = (double)wv * Sv;
+      bred[1][el] = (double)wv * (double)A;
+      if (dbias_grad && in && tap == 0 && ci == 0 && co < Cout) {
+        double t = 0.0;
+        for (int cl = 0; cl < ncls; ++cl) t += cls[((size_t)g * ncls + cl) * CoP + co];
+        atomicAdd(&dbias_grad[co], (float)t);
+      }
+    }
+    __syncthreads();
+    // the BatchNorm-backward pair: this workgroup's entries of one input channel first (32 consecutive entries: ci repeats with
+    // period CiP), then one atomic per (workgroup, ci) into a replica row
+    if (bn_sums && rl == 0) {
+      const int c0 = (int)(((int64_t)blockIdx.x * 32) % CiP);
+      const int first = ((el - c0) % CiP + CiP) % CiP;      // el plays the channel here
+      if (el < CiP && el < Cin && first < 32) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = first; k < 32; k += CiP) { s0 += bred[0][k]; s1 += bred[1][k]; }
+        double* o = bn_sums + ((size_t)g * bn_nrep + (blockIdx.x % bn_nrep)) * bn_cp * 2 + (size_t)el * 2;
+        atomicAdd(&o[0], s0);
+        atomicAdd(&o[1], s1);
+      }
+    }
+    __syncthreads();
+  }
+  if (real && rl == 0) dw[co * sCo + ci * sCi + tap] += dwv;
+}
+extern "C" int sp_wgrad_finish_folded_groups(const float* dw_acc, int32_t nparts, int32_t G, int32_t CoP, int32_t CiP, int32_t Cout, int32_t Cin,
+                                             int64_t sCo, int64_t sCi, const float* coef, int32_t coef_gstride, int32_t coef_pitch,
+                                             const double* cls_sums, int32_t padD, int32_t padH, int32_t padW, const float* w, float* dw,
+                                             float* dbias_grad, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, sp_stream_t stream) {
+  SP_CHECK_ARG(dw_acc && coef && cls_sums && w && dw && G >= 1 && nparts >= G && nparts % G == 0 && G <= 16 && CoP >= Cout && CiP >= Cin && CiP >= 8,
+               "sp_wgrad_finish_folded_groups: %d partial blocks for %d groups, tiles %d x %d", nparts, G, CoP, CiP);
+  SP_CHECK_ARG(padD >= 0 && padD <= 2 && padH >= 0 && padH <= 2 && padW >= 0 && padW <= 2 && coef_pitch >= Cin && coef_gstride >= 3 * coef_pitch,
+               "sp_wgrad_finish_folded_groups: padding 0..2, coefficient rows (scale, -, shift)");
+  SP_CHECK_ARG(!bn_sums || (bn_nrep >= 1 && bn_cp >= Cin), "sp_wgrad_finish_folded_groups: bn_sums rows");
+  const int64_t total = (int64_t)27 * CoP * CiP;
+  hipLaunchKernelGGL(wgrad_finish_folded_groups_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dw_acc,
+                     nparts, G, CoP, CiP, Cout, Cin, sCo, sCi, coef, coef_gstride, coef_pitch, cls_sums, padD, padH, padW, w, dw, dbias_grad, bn_sums,
+                     bn_nrep, bn_cp);
+  SP_CHECK_LAUNCH("sp_wgrad_finish_folded_groups");
+  return SP_OK;
+}
+
 extern "C" int sp_wgrad_finish_folded(float* dw_acc, int32_t nparts, const int32_t* tapsrc, int32_t ntap, int32_t CoP, int32_t CiP,
                                       int32_t Cout, int32_t Cin, int64_t sCo, int64_t sCi, const float* scale,
                                       const float* shift, const double* dbias_sums, float* dw, float* dbias_grad,

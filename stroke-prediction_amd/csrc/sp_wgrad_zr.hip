@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_zr_kernel(const WgradZrDev P) {
   // ---- flush: this workgroup's block of partial sums (waves sharing a channel pair are added through LDS first)
   ZR_SYNC(0);
   const int CoP = a.CoT * 16, CiP = a.CiT * 16;
-  float* prow = a.dw_acc + (size_t)blockIdx.x * 27 * CoP * CiP;
+  float* prow = a.dw_acc + (size_t)vb * 27 * CoP * CiP;      // block vb took piece vb of the (sample-major) march: consecutive blocks = consecutive samples (group-aware finish)
   if (C::RS == 1) {
     if (co_t0 + wco < a.CoT && ci_t0 + wci < a.CiT) {
 #pragma unroll

@@ -208,7 +208,7 @@ class StackContext:
         if self.fused_out:
             prev = self.layers[-2]
             g, coef = self._out_backward(last, prev.y, dout, out.contiguous(), params, grads, bool(param_grads))
-            O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y))
+            O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y), cls=prev.cls_arg())
             top -= 1
         elif self.cout <= 8:
             O.out_grad_to_cl(dout, out, dt, last.act, last.act_param, last.dz, last.dbias_sums)
@@ -224,7 +224,8 @@ class StackContext:
             g, coef = lay.backward(x, params, grads)
             if i > 0:
                 prev = self.layers[i - 1]
-                O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y) if coef is not None else 0)
+                O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y) if coef is not None else 0,
+                             cls=prev.cls_arg() if coef is not None else None)
             elif need_input_grad:
                 if not hasattr(self, "_dx"):
                     self._dx = O.alloc_cl(self.batch, self.in_dims, lay.cpi, dt, self.device)

@@ -133,6 +133,8 @@ class ConvLayer:
         # (still the weight gradient's operand) is written later, on the side stream of the backward
         self.fold_groups = bool(self.G > 1 and O.FOLD_GROUPS and O.ZM_GROUPS and zm_ok and self.fwd.zm is not None and bn_prefix is not None and kind == "conv"
                                 and act == L.ACT_ELU and dtype == L.SP_BF16 and (2 * pads[0] + 1) * (2 * pads[1] + 1) * (2 * pads[2] + 1) <= 75)
+        self.raw_wgrad = bool(self.fold_groups and O.RAW_WGRAD and tuple(P._triple(stride)) == (1, 1, 1) and k == 3
+                              and self.cpi % 16 == 0 and self.cpo % 16 == 0 and not os.environ.get("SP_WGRAD_ZR") == "0")
         if self.fold_groups:
             z = self.fwd.zm
             self._gfrag_elems = z["nsteps"] * z["NT"] * 64 * 8
@@ -368,6 +370,8 @@ class ConvLayer:
 
     def reserve_bwd_scratch(self):
         self.dbias_sums_id = self.scratch.reserve(self.cpo * L.SP_REDUCE_ROWS)     # replica rows, see include/stroke_amd.h
+        if getattr(self, "raw_wgrad", False):
+            self.cls_sums_id = self.scratch.reserve(self.G * self._ncls * self.cpo)      # border-class sums of dz per group
         if self.bn_prefix is not None:
             self.bsums_id = self.scratch.reserve(self.G * self.cpi * 2 * STATS_NREP)
 
@@ -441,11 +445,45 @@ class ConvLayer:
             if f is not None:
                 f.join()
 
+    def cls_arg(self):
+        """what the pass that forms this layer's dz needs when the weight gradient reads the raw input (ops.bn_act_bwd(cls=...))"""
+        if not (self.raw_wgrad and self.param_grads):
+            return None
+        return (self.gb, self._pads, self.scratch.get(self.cls_sums_id))
+
+    def _backward_grouped_raw(self, x, w, params, grads):
+        """batched passes, BatchNorm folded per group, padded convolution: the weight gradient on the RAW input into group-pure
+        partial blocks; its finish (side stream) applies each group's scale / shift with the border-class sums of dz
+        (sp_wgrad_finish_folded_groups) and yields the BatchNorm-backward sums, so the data gradient beside it is a plain one"""
+        c, p = self.conv_prefix, self.bn_prefix
+        wg = self.wgrad
+        wg.groups = self.G
+        bs = self.scratch.get(self.bsums_id)
+        f = O.fork()
+        with f:
+            wg.run_raw(x, self.dz, self.batch)
+            L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, self.G, wg.cot * 16, wg.cit * 16, self.cout, self.cin, wg.w_sco, wg.w_sci,
+                   self.apply_coef.data_ptr(), 3 * self.cpi, self.cpi, O.ptr(self.scratch.get(self.cls_sums_id)), self._pads[0], self._pads[1],
+                   self._pads[2], O.ptr(w), O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(bs), STATS_NREP, self.cpi, O.stream())
+        self.dgrad.prep(w)
+        self.dgrad.run(self.dz, self.g, self.batch)
+        f.join()
+        world = 1
+        if SYNC["on"]:
+            _allreduce(bs)
+            world = SYNC["world"]
+        L.call("sp_bn_bwd_finalize_groups", O.ptr(bs), STATS_NREP, float(self.count * world), O.ptr(params[p + ".weight"]),
+               O.ptr(self.mean), O.ptr(self.invstd), self.cin, self.cpi, self.G, O.ptr(grads[p + ".weight"]),
+               O.ptr(grads[p + ".bias"]), O.ptr(self.coef), 1.0 / world, O.stream())
+        return self.g, self.coef
+
     def _backward_grouped(self, x, w, params, grads, wgrad=True):
         """groups > 1: one weight-gradient launch over all passes (operands: the materialised normalised input and dz -- the
         sum over the batch IS the sum over the passes), one data-gradient launch whose epilogue (or one reduction per group)
         yields the per-group BatchNorm-backward sums, one grouped finalize."""
         c = self.conv_prefix
+        if self.raw_wgrad and wgrad and self.param_grads:
+            return self._backward_grouped_raw(x, w, params, grads)
         src = self.xhat if self.materialize else x
         f = O.fork() if (O.overlap_level() == 2 and wgrad) else None
         if f is not None:

@@ -1,5 +1,6 @@
 """Thin Python drivers over the C ABI: torch owns device memory and the stream; every op below
 enqueues hand-written gfx950 kernels through ``libstroke_amd.so`` (no torch compute kernels)."""
+import math
 import os
 import ctypes as C
 
@@ -44,10 +45,11 @@ USE_PW_WGRAD = bool(int(os.environ.get("SP_WGRAD_PW", "1")))      # streaming we
 PAR_STRIDED = bool(int(os.environ.get("SP_CONV_PAR_STRIDED", "1")))
 WGRAD_DMA_STRIDED = bool(int(os.environ.get("SP_WGRAD_DMA_STRIDED", "1")))      # stride-2 / 2x2x2 weight gradients on the LDS-DMA kernel (0: register-staged)
 # batched passes: BatchNorm folded per group into the z-marching forward (per-group fragments + a bias table over the border classes,
-# sp_conv_prep_folded_groups), the normalised copy written later beside the weight gradient.  OFF: measured 7.05 -> 7.18 ms/step --
-# the copy is the weight gradient's operand, so its bytes only move to the side stream of the (bandwidth-bound) backward; it pays
-# once the weight gradient reads the raw input too (border-restricted sums of dz in the folded finish: not built)
-FOLD_GROUPS = bool(int(os.environ.get("SP_FOLD_GROUPS", "0")))
+# sp_conv_prep_folded_groups).  Alone (the normalised copy written later, beside the weight gradient) it measured 7.05 -> 7.18 ms/step:
+# the copy's bytes only move to the side stream of the bandwidth-bound backward; it pays with RAW_WGRAD below
+FOLD_GROUPS = bool(int(os.environ.get("SP_FOLD_GROUPS", "1")))
+# ... and the weight gradient of those layers on the RAW input (border-class sums of dz, group-aware folded finish): no normalised copy at all
+RAW_WGRAD = bool(int(os.environ.get("SP_RAW_WGRAD", "1")))
 USE_PAR = bool(int(os.environ.get("SP_CONV_PAR", "1")))      # parity classes of transposed / strided-gradient ops: one pass over the output (csrc/sp_conv_par.hip)
 ZM_GROUPS = bool(int(os.environ.get("SP_ZM_GROUPS", "1")))      # batched passes: one z-marching launch over all BatchNorm groups (0: one per group, tiled data gradients)
 ZM_CAE = bool(int(os.environ.get("SP_ZM_CAE", "1")))      # z-marching kernel (ELU epilogue, padding) for the CAE's materialised 3x3x3 layers
@@ -656,6 +658,9 @@ class WgradRunner:
             # bound by the DMA latency per tile -- 32->100 @7x25x25: 8 workgroups x 36 tiles = 119 us -- : floor 128)
             floor = 512 if (a.sD, a.sH, a.sW) == (1, 1, 1) else int(os.environ.get("SP_WGRAD_STRIDED_FLOOR", "128"))
             nb = max(8, min(512 // yz, vox // floor)) // 8 * 8
+            if getattr(self, "groups", 1) > 1:      # group-aware finish: the partial blocks of a group are consecutive
+                q = 8 * self.groups // math.gcd(8, self.groups)
+                nb = max(q, nb // q * q)
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", nb))
             a.parts, self.nparts = 1, a.nblocks
             self.acc = torch.empty(self.nparts * total, dtype=torch.float32, device=self.device)
@@ -696,6 +701,22 @@ class WgradRunner:
         if defer_finish:
             return finish          # the caller runs it (e.g. on the side stream, next to the data-gradient conv)
         finish()
+
+    def run_raw(self, x, dz, batch):
+        """the kernel only, on the RAW input, into this runner's partial blocks (self.acc, self.nparts): the caller finishes
+        (layers.ConvLayer._backward_grouped_raw: sp_wgrad_finish_folded_groups)"""
+        a = self.args
+        assert self.dma and x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
+        assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi) and tuple(dz.shape) == (batch, a.Do, a.Ho, a.Wo, a.CPo)
+        if self.acc is None or self.acc_batch != batch:
+            self._alloc_acc(batch)
+        assert a.parts == 1 and self.nparts % getattr(self, "groups", 1) == 0
+        a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
+        a.dma, a.in_scale, a.in_shift, a.dz_scale, a.dz_shift = 1, None, None, None, None
+        a.B, a.zs, a.x_plane = batch, int(WGRAD_ZS), 0
+        with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout,
+                    "%d->%d @%dx%dx%d dma raw" % (self.cin, self.cout, a.Di, a.Hi, a.Wi)):
+            L.call("sp_conv3d_wgrad", C.byref(a), stream())
 
     def _finish(self, fold, dw, in_scale, in_shift, dbias_sums, dbias_grad, nbias, bn_w, bn_sums, bn_nrep):
         st = stream()
@@ -822,8 +843,17 @@ def _q8_args(q8, nvox):
     return ptr(t), nvox * 16, int(fmt), float(scale)
 
 
-def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None, group_vox=0):
+def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None, group_vox=0, cls=None):
+    """cls = (group batch, (padD, padH, padW), class sums): the layer whose dz this forms reads the RAW input in its weight gradient
+    (ConvLayer.raw_wgrad): the border-class sums of dz come out of the same pass (sp_bn_act_bwd_groups_cls)"""
     nvox = y.numel() // y.shape[-1]
+    if cls is not None:
+        gb, pads, sums = cls
+        assert q8 is None and coef is not None and y.dim() == 5
+        B, D, H, W, CP = y.shape
+        L.call("sp_bn_act_bwd_groups_cls", ptr(g), ptr(y), ptr(coef), dtype, B, D, H, W, CP, act, act_param, ptr(dz), ptr(dbias), gb,
+               pads[0], pads[1], pads[2], ptr(sums), stream())
+        return
     if group_vox:       # coef is a [G][3][CP] table, one per group of group_vox consecutive voxels (batched CAE passes)
         assert q8 is None and coef is not None
         L.call("sp_bn_act_bwd_groups", ptr(g), ptr(y), ptr(coef), dtype, nvox, y.shape[-1], act, act_param, ptr(dz), ptr(dbias),

@@ -78,7 +78,7 @@ def test_prediction_learner_matches_reference_fixture(golden_dir, dtype, tol_out
         tol = tol_grad if p.numel() > 16 else max(2e-2, 4 * tol_grad)
         # bf16: the gradient of the FIRST BatchNorm's single gamma is zero in exact arithmetic (the next BatchNorm removes any
         # scale of the one input channel; 1e-5 in the reference comes from its eps terms) -- storage noise: an absolute floor
-        floor = 1e-4 if (dtype == "bf16" and p.numel() <= 16) else 1e-9
+        floor = 3e-4 if (dtype == "bf16" and p.numel() <= 16) else 1e-9      # (1.4e-4 measured since the decoder's forward folds its BatchNorms per group)
         if abs(float(p.grad.double().norm()) - gn) > tol * gn + floor:
             bad.append((n, float(p.grad.double().norm()), gn))
     assert not bad, bad

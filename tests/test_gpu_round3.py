@@ -333,7 +333,9 @@ def test_cae_batched_passes_equal_sequential_passes(dtype):
             assert int(a[3][k]) == int(b[3][k]) == (3 if k.startswith("enc.") else 4), k
         else:
             d = float((a[3][k] - b[3][k]).abs().max())
-            assert d <= (2e-5 if dtype == "f32" else 5e-3) * float(a[3][k].abs().max() + 1e-2), (k, d)
+            # (bf16: the batched path folds the BatchNorm of its padded layers per group -- weights rounded after the fold -- where the
+            # sequential one normalises on the operand load: 5.8e-3 measured on the latent's running mean)
+            assert d <= (2e-5 if dtype == "f32" else 1e-2) * float(a[3][k].abs().max() + 1e-2), (k, d)
     rel = float((a[2] - b[2]).double().norm() / a[2].double().norm())
     print("batched vs sequential: flat gradient rel-L2 %.2e (%s)" % (rel, dtype))
     assert rel < tol[3], rel

@@ -332,3 +332,66 @@ def test_z_marching_forward_with_batchnorm_folded_per_group(cin, cout, dims, pad
         torch.testing.assert_close(st[gi, :cout, 0], part.sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2 * math.sqrt(part.numel() / cout))
     if cpo > cout:
         assert float(y[..., cout:].float().abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ weight gradient on the raw input
+@pytest.mark.parametrize("cin,cout,dims,pad,B,gb", [(16, 16, (9, 36, 40), (1, 0, 0), 6, 2), (24, 24, (6, 34, 36), (1, 2, 2), 4, 1),
+                                                    (24, 16, (5, 33, 20), (1, 2, 2), 8, 2), (16, 24, (4, 40, 17), (1, 1, 1), 4, 2)])
+def test_weight_gradient_on_the_raw_input_with_batchnorm_folded_per_group(cin, cout, dims, pad, B, gb, monkeypatch):
+    """y = conv(zero-padded (s_g x + t_g)): dW, dbias and the BatchNorm-backward sums (sum g, sum g x) of the layer input, from
+    (a) the border-class sums of dz that the pass forming dz leaves (sp_bn_act_bwd_groups_cls), (b) the weight gradient kernel on the
+    RAW x with group-pure partial blocks, (c) sp_wgrad_finish_folded_groups -- against autograd through the normalised input"""
+    gen = torch.Generator().manual_seed(cin * 17 + cout + B)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    G = B // gb
+    out = tuple(dims[a] + 2 * pad[a] - 2 for a in range(3))
+    x = bf(torch.randn(B, cin, *dims, generator=gen) + 0.3)
+    gup = bf(torch.randn(B, cout, *out, generator=gen))                # what arrives from above; dz = gup here (identity coefficients)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=gen) / math.sqrt(27 * cin)).requires_grad_(True)
+    bias = torch.zeros(cout, requires_grad=True)
+    scale = torch.rand(G, cin, generator=gen) + 0.5
+    shift = torch.randn(G, cin, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    gidx = torch.arange(B) // gb
+    xh = xr * scale[gidx].view(B, cin, 1, 1, 1) + shift[gidx].view(B, cin, 1, 1, 1)
+    xh.retain_grad()
+    F.conv3d(xh, w, bias, padding=pad).backward(gup)
+    ghat = xh.grad                                                      # gradient at the BatchNorm's output
+    # ---- (a) dz and its border-class sums
+    xs, gs = _to_cl(x, cpi), _to_cl(gup, cpo)
+    ident = torch.zeros(G, 3, cpo, device=DEV)
+    ident[:, 0] = 1.0
+    dz = torch.empty_like(gs)
+    ncls = (2 * pad[0] + 1) * (2 * pad[1] + 1) * (2 * pad[2] + 1)
+    cls = torch.zeros(G * ncls * cpo, dtype=torch.float64, device=DEV)
+    dbs = torch.zeros(L.SP_REDUCE_ROWS * cpo, dtype=torch.float64, device=DEV)
+    O.bn_act_bwd(gs, gs, ident, L.SP_BF16, L.ACT_NONE, 0.0, dz, dbs, cls=(gb, pad, cls))
+    assert torch.equal(dz, gs)
+    tot = cls.view(G, ncls, cpo).sum(1).cpu()
+    for gi in range(G):
+        torch.testing.assert_close(tot[gi, :cout], gup[gi * gb:(gi + 1) * gb].double().sum(dim=(0, 2, 3, 4)), rtol=1e-9, atol=1e-6)
+    torch.testing.assert_close(dbs.view(L.SP_REDUCE_ROWS, cpo).sum(0).cpu()[:cout], gup.double().sum(dim=(0, 2, 3, 4)), rtol=1e-9, atol=1e-6)
+    # ---- (b) + (c)
+    wg = O.WgradRunner(cin, cout, 3, 1, pad, dims, out, cpi, cpo, cin * 27, 27, L.SP_BF16, DEV)
+    wg.groups = G
+    wg.run_raw(xs, dz, B)
+    coef = torch.zeros(G, 3, cpi, device=DEV)
+    coef[:, 0, :cin], coef[:, 2, :cin] = scale.to(DEV), shift.to(DEV)
+    dw = torch.zeros(cout, cin, 3, 3, 3, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    nrep = 4
+    bs = torch.zeros(G * nrep * cpi * 2, dtype=torch.float64, device=DEV)
+    wd = w.detach().to(DEV)
+    L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, G, wg.cot * 16, wg.cit * 16, cout, cin, wg.w_sco, wg.w_sci, O.ptr(coef), 3 * cpi, cpi,
+           O.ptr(cls), pad[0], pad[1], pad[2], O.ptr(wd), O.ptr(dw), O.ptr(db), O.ptr(bs), nrep, cpi, O.stream())
+    sw = float(w.grad.abs().max())
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-3 * sw)
+    torch.testing.assert_close(db.cpu(), bias.grad, rtol=1e-4, atol=1e-3)
+    got = bs.view(G, nrep, cpi, 2).sum(1).cpu()
+    for gi in range(G):
+        sl = slice(gi * gb, (gi + 1) * gb)
+        e1 = ghat[sl].double().sum(dim=(0, 2, 3, 4))
+        e2 = (ghat[sl].double() * x[sl].double()).sum(dim=(0, 2, 3, 4))
+        sc = float(ghat[sl].abs().max()) * math.sqrt(ghat[sl].numel() / cin)
+        torch.testing.assert_close(got[gi, :cin, 0], e1, rtol=2e-3, atol=2e-3 * sc)
+        torch.testing.assert_close(got[gi, :cin, 1], e2, rtol=2e-3, atol=2e-3 * sc)
