@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
   // Sv[g][pair]: the class sums whose tap lies inside the input, for the (tap, co) pairs of this workgroup's 32 entries (at most
   // 32 / CiP + 1 of them): a row lane takes a (group, pair), its 32 lanes the classes (one thread walking 75 classes x G groups of
   // fp64 loads cost 60 us)
-  __shared__ double svs[16][8];
+  __shared__ double svs[16][8], sva[16][8];
   const int64_t e0 = (int64_t)blockIdx.x * 32;
   const int pair0 = (int)(e0 / CiP);                                   // first (tap * CoP + co) of the workgroup
   const int npair = (int)((min(e0 + 31, total - 1)) / CiP) - pair0 + 1;
@@ -757,13 +757,15 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
     const int g = q / npair, pr = pair0 + q % npair;
     const int pco = pr % CoP, ptap = pr / CoP;
     const int ptz = ptap / 9, pty = (ptap / 3) % 3, ptx = ptap % 3;
-    double t = 0.0;
+    double t = 0.0, ta = 0.0;
     for (int cl = el; cl < ncls; cl += 32) {
       const int cx = cl % nx, cy = (cl / nx) % ny, cz = cl / (nx * ny);
-      if (fg_tap_valid(ptz, cz, pz) && fg_tap_valid(pty, cy, py) && fg_tap_valid(ptx, cx, px)) t += cls[((size_t)g * ncls + cl) * CoP + pco];
+      const double v = cls[((size_t)g * ncls + cl) * CoP + pco];
+      ta += v;                                                          // (all classes: the bias gradient's sum dz)
+      if (fg_tap_valid(ptz, cz, pz) && fg_tap_valid(pty, cy, py) && fg_tap_valid(ptx, cx, px)) t += v;
     }
-    for (int o = 16; o > 0; o >>= 1) t += __shfl_xor(t, o, 32);
-    if (el == 0 && g < 16 && q % npair < 8) svs[g][q % npair] = t;
+    for (int o = 16; o > 0; o >>= 1) { t += __shfl_xor(t, o, 32); ta += __shfl_xor(ta, o, 32); }
+    if (el == 0 && g < 16 && q % npair < 8) { svs[g][q % npair] = t; sva[g][q % npair] = ta; }
   }
   __syncthreads();
   float dwv = 0.f;
@@ -791,11 +793,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
       if (real) dwv += cf[ci] * A + cf[2 * coef_pitch + ci] * (float)Sv;
       bred[0][el] = (double)wv * Sv;
       bred[1][el] = (double)wv * (double)A;
-      if (dbias_grad && in && tap == 0 && ci == 0 && co < Cout) {
-        double t = 0.0;
-        for (int cl = 0; cl < ncls; ++cl) t += cls[((size_t)g * ncls + cl) * CoP + co];
-        atomicAdd(&dbias_grad[co], (float)t);
-      }
+      if (dbias_grad && in && tap == 0 && ci == 0 && co < Cout) atomicAdd(&dbias_grad[co], (float)sva[g][(int)(e / CiP) - pair0]);
     }
     __syncthreads();
     // the BatchNorm-backward pair: this workgroup's entries of one input channel first (32 consecutive entries: ci repeats with
