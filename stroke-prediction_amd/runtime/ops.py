@@ -46,7 +46,7 @@ PAR_STRIDED = bool(int(os.environ.get("SP_CONV_PAR_STRIDED", "1")))
 WGRAD_DMA_STRIDED = bool(int(os.environ.get("SP_WGRAD_DMA_STRIDED", "1")))      # stride-2 / 2x2x2 weight gradients on the LDS-DMA kernel (0: register-staged)
 # batched passes: BatchNorm folded per group into the z-marching forward (per-group fragments + a bias table over the border classes,
 # sp_conv_prep_folded_groups).  Alone (the normalised copy written later, beside the weight gradient) it measured 7.05 -> 7.18 ms/step:
-# the copy's bytes only move to the side stream of the bandwidth-bound backward; it pays with RAW_WGRAD below
+# the copy's bytes only move to the side stream of the bandwidth-bound backward; with RAW_WGRAD below 6.91 -> 6.51
 FOLD_GROUPS = bool(int(os.environ.get("SP_FOLD_GROUPS", "1")))
 # ... and the weight gradient of those layers on the RAW input (border-class sums of dz, group-aware folded finish): no normalised copy at all
 RAW_WGRAD = bool(int(os.environ.get("SP_RAW_WGRAD", "1")))
