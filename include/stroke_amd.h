@@ -636,6 +636,20 @@ int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bs
 /* loss = 1 - sum_c w_c (2 I_c + eps)/(O_c + T_c + eps);  coef[c] = (ca, cb): d loss/d o = ca*t + cb*o */
 int sp_dice_finalize(const double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
                      sp_stream_t stream);
+/* The CAE reconstruction loss (CaeReconstructionLearner.py:52-70) in three launches:
+ *   [ mean(|p-i| - (p-i)) + mean(|p-c| - (p-c)) + Dice(c, tc) + Dice(p, tp) + Dice(l, tl) + factor * mean|zi - zl| ] / (5 + factor)
+ * c, p, l, i: the reconstructions (B, 1, DHW) fp32 with batch strides *bs (elements; slices of a stacked tensor are read in place),
+ * t*: the ground truths, zi / zl: the latents (nlat elements each, dense).  Dice = 1 - w (2 I + eps) / (O + T + eps) over batch and
+ * volume (metrics.py:16-28, one class).  sums: SP_REDUCE_ROWS x 16 doubles, zeroed by the caller; coef: 8 floats for the backward.
+ * sp_cae_loss_bwd: dense (B, DHW) gradients of c, p, l, i and (nlat) of zi, zl, times the upstream scalar *up (device memory). */
+int sp_cae_loss_fwd(const float* c, int64_t cbs, const float* p, int64_t pbs, const float* l, int64_t lbs, const float* i, int64_t ibs,
+                    const float* tc, int64_t tcbs, const float* tp, int64_t tpbs, const float* tl, int64_t tlbs, int32_t B, int64_t DHW,
+                    const float* zi, const float* zl, int64_t nlat, float dice_weight, double eps, float factor, double* sums,
+                    float* loss, float* coef, sp_stream_t stream);
+int sp_cae_loss_bwd(const float* c, int64_t cbs, const float* p, int64_t pbs, const float* l, int64_t lbs, const float* i, int64_t ibs,
+                    const float* tc, int64_t tcbs, const float* tp, int64_t tpbs, const float* tl, int64_t tlbs, int32_t B, int64_t DHW,
+                    const float* coef, const float* up, float* dc, float* dp, float* dl, float* di, const float* zi, const float* zl,
+                    int64_t nlat, float* dzi, float* dzl, sp_stream_t stream);
 /* dout (contiguous) = *upstream * (ca[c]*t + cb[c]*o); upstream: device pointer to the scalar gradient (NULL = 1) */
 int sp_dice_bwd(const float* o, int64_t o_bstride, const float* t, int64_t t_bstride, const float* coef,
                 const float* upstream, int32_t B, int32_t C, int64_t DHW, float* dout, sp_stream_t stream);

@@ -123,6 +123,70 @@ class BatchDiceLoss(LossModule):
         return _DiceFn.apply(outputs, targets, tuple(float(w) for w in self._label_weights), float(self._epsilon))
 
 
+class _CaeLossFn(torch.autograd.Function):
+    """CaeReconstructionLearner.loss_step (reference :52-70) as three HIP launches (sp_cae_loss_fwd / _bwd) instead of ~60 torch and
+    Dice kernels: [ mean(|p-i|-(p-i)) + mean(|p-c|-(p-c)) + Dice(c) + Dice(p) + Dice(l) + f mean|zi - zl| ] / (5 + f).  The four
+    gradients come back as consecutive slices of ONE tensor in the order the reconstructions lie in memory, so that a decoder
+    call that produced them stacked on the batch axis (Cae3D._StackManyFn) takes the buffer as it is."""
+
+    @staticmethod
+    def forward(ctx, c, p, l, i, tc, tp, tl, zi, zl, factor, weight, eps):
+        from stroke_prediction_amd.runtime import lib as L, ops as O
+        recs = [_batch_strided(t) for t in (c, p, l, i)]
+        gts = [_batch_strided(t) for t in (tc, tp, tl)]
+        zi_, zl_ = zi.contiguous().float(), zl.contiguous().float()
+        B = c.shape[0]
+        dhw = c.numel() // B
+        dev = c.device
+        sums = torch.zeros(L.SP_REDUCE_ROWS, 16, dtype=torch.float64, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        coef = torch.empty(8, dtype=torch.float32, device=dev)
+        args = []
+        for t, bs in recs + gts:
+            args += [O.ptr(t), bs]
+        L.call("sp_cae_loss_fwd", *args, B, dhw, O.ptr(zi_), O.ptr(zl_), zi_.numel(), float(weight), float(eps), float(factor),
+               O.ptr(sums), O.ptr(loss), O.ptr(coef), O.stream())
+        ctx.save_for_backward(*[t for t, _ in recs + gts], zi_, zl_, coef)
+        ctx.strides = [bs for _, bs in recs + gts]
+        ctx.shapes = (tuple(c.shape), tuple(zi.shape), tuple(zl.shape))
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        from stroke_prediction_amd.runtime import lib as L, ops as O
+        *ts, zi_, zl_, coef = ctx.saved_tensors
+        B = ts[0].shape[0]
+        dhw = ts[0].numel() // B
+        up = gloss if (gloss.dtype == torch.float32 and gloss.is_contiguous()) else gloss.float().contiguous()
+        # slot k of the gradient buffer for the reconstruction that lies k-th in memory (equal spacing = slices of one stacked tensor)
+        order = sorted(range(4), key=lambda k: ts[k].data_ptr())
+        dall = torch.empty((4 * B,) + ctx.shapes[0][1:], dtype=torch.float32, device=ts[0].device)
+        d = [None] * 4
+        for slot, k in enumerate(order):
+            d[k] = dall[slot * B:(slot + 1) * B]
+        dzi, dzl = torch.empty_like(zi_), torch.empty_like(zl_)
+        args = []
+        for t, bs in zip(ts, ctx.strides):
+            args += [O.ptr(t), bs]
+        L.call("sp_cae_loss_bwd", *args, B, dhw, O.ptr(coef), O.ptr(up), O.ptr(d[0]), O.ptr(d[1]), O.ptr(d[2]), O.ptr(d[3]),
+               O.ptr(zi_), O.ptr(zl_), zi_.numel(), O.ptr(dzi), O.ptr(dzl), O.stream())
+        return d[0], d[1], d[2], d[3], None, None, None, dzi.view(ctx.shapes[1]), dzl.view(ctx.shapes[2]), None, None, None
+
+
+def cae_reconstruction_loss(rec, gt, lat, factor, criterion):
+    """The loss of CaeReconstructionLearner.loss_step on the fused kernels, or None when they do not apply (host tensors, the
+    exact data-parallel mode -- its means and Dice sums are global --, several label classes): the caller composes it then."""
+    import os
+    from stroke_prediction_amd.runtime.layers import SYNC
+    ts = (rec.core, rec.penu, rec.lesion, rec.interpolation, gt.core, gt.penu, gt.lesion)
+    if os.environ.get("SP_CAE_FUSED_LOSS", "1") == "0" or SYNC["on"] or not isinstance(criterion, BatchDiceLoss) or len(criterion._label_weights) != 1 \
+            or criterion._dim != 1 or any(t is None or not t.is_cuda or t.dim() != 5 or t.shape[1] != 1 or t.shape != ts[0].shape for t in ts) \
+            or lat.interpolation is None or lat.lesion is None or lat.interpolation.shape != lat.lesion.shape:
+        return None
+    return _CaeLossFn.apply(rec.core, rec.penu, rec.lesion, rec.interpolation, gt.core.float(), gt.penu.float(), gt.lesion.float(),
+                            lat.interpolation, lat.lesion, float(factor), float(criterion._label_weights[0]), float(criterion._epsilon))
+
+
 def _stacked_base(parts):
     """The (B, n, ...) fp32 tensor whose consecutive channel slices are exactly ``parts`` (each (B, 1, ...)), or None."""
     base = getattr(parts[0], "_base", None)

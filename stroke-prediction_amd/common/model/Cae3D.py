@@ -204,7 +204,13 @@ class _StackManyFn(torch.autograd.Function):
             raise RuntimeError("%s.backward after an eval-mode forward is not supported: the fused backward uses the "
                                "batch-statistics BatchNorm formula; call model.train() for passes that need gradients"
                                % type(module).__name__)
-        dout = torch.cat([torch.zeros_like(out[:B]) if d is None else d for d in douts], 0)
+        base = getattr(douts[0], "_base", None) if douts[0] is not None else None
+        if base is not None and base.is_contiguous() and tuple(base.shape) == tuple(out.shape) and base.dtype == out.dtype and \
+                all(d is not None and getattr(d, "_base", None) is base and d.is_contiguous() and tuple(d.shape) == tuple(out[:B].shape)
+                    and d.data_ptr() == base.data_ptr() + k * d.numel() * d.element_size() for k, d in enumerate(douts)):
+            dout = base             # the gradients arrive stacked already (metrics._CaeLossFn): no concatenation
+        else:
+            dout = torch.cat([torch.zeros_like(out[:B]) if d is None else d for d in douts], 0)
         if ctx.frozen:
             dx = _frozen_backward(ctx, module, sc, dout, out)
             dxs = tuple(None for _ in range(n)) if dx is None else tuple(dx[i * B:(i + 1) * B] for i in range(n))

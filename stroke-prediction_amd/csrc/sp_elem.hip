@@ -1982,6 +1982,129 @@ extern "C" int sp_dice_finalize(const double* sums, const float* weights, double
   SP_CHECK_LAUNCH("sp_dice_finalize");
   return SP_OK;
 }
+
+// ---- the CAE reconstruction loss as three launches (CaeReconstructionLearner.py:52-70):
+//   [ mean(|p - i| - (p - i)) + mean(|p - c| - (p - c)) + Dice(c, tc) + Dice(p, tp) + Dice(l, tl) + f mean|zi - zl| ] / (5 + f)
+// c, p, l, i = the four reconstructions (B, 1, D, H, W), t* the ground truths, z* the latents.  Composed of torch operators and three
+// BatchDiceLoss calls it is ~60 kernels between the forward and the backward of a step (0.3 ms of a 6.5 ms step).
+// sums (replica rows of 16 doubles): 0 hinge(p, i), 1 hinge(p, c), 2-4 Dice(c), 5-7 Dice(p), 8-10 Dice(l), 11 sum |zi - zl|
+__global__ __launch_bounds__(256) void cae_loss_sums_kernel(const float* __restrict__ c, int64_t cbs, const float* __restrict__ p, int64_t pbs,
+                                                            const float* __restrict__ l, int64_t lbs, const float* __restrict__ ii, int64_t ibs,
+                                                            const float* __restrict__ tc, int64_t tcbs, const float* __restrict__ tp, int64_t tpbs,
+                                                            const float* __restrict__ tl, int64_t tlbs, int64_t DHW, double* __restrict__ sums,
+                                                            int B, const float* __restrict__ zi, const float* __restrict__ zl, int64_t nlat) {
+  __shared__ float red[4 * 11];      // [wave][sum], added up in wave order (sp_cols_sum)
+  if ((int)blockIdx.y == B) {        // the latent term: sum |zi - zl| -> column 11
+    float t = 0.f;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nlat; k += (int64_t)gridDim.x * 256) t += fabsf(zi[k] - zl[k]);
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sums[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * 16 + 11], (double)((red[0] + red[1]) + (red[2] + red[3])));
+    return;
+  }
+  const int b = blockIdx.y;
+  c += b * cbs; p += b * pbs; l += b * lbs; ii += b * ibs; tc += b * tcbs; tp += b * tpbs; tl += b * tlbs;
+  float s[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) s[k] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < DHW; v += (int64_t)gridDim.x * 256) {
+    const float vc = c[v], vp = p[v], vl = l[v], vi = ii[v], a = tc[v], bq = tp[v], d = tl[v];
+    const float d1 = vp - vi, d2 = vp - vc;
+    s[0] += fabsf(d1) - d1; s[1] += fabsf(d2) - d2;
+    s[2] += vc * a; s[3] += vc * vc; s[4] += a * a;
+    s[5] += vp * bq; s[6] += vp * vp; s[7] += bq * bq;
+    s[8] += vl * d; s[9] += vl * vl; s[10] += d * d;
+  }
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const float w = wave_sum(s[k]);
+    if ((threadIdx.x & 63) == 0) red[(threadIdx.x >> 6) * 11 + k] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 11)
+    atomicAdd(&sums[(size_t)((blockIdx.x + blockIdx.y) % SP_REDUCE_ROWS) * 16 + threadIdx.x], (double)sp_cols_sum(red, 11, 4, threadIdx.x));
+}
+// one thread: the loss and the backward's coefficients
+//   coef: 0 hinge scale 1 / (N (5 + f)); (1, 2) (3, 4) (5, 6) Dice (ca, cb) / (5 + f) of c, p, l; 7 latent scale f / (nlat (5 + f))
+__global__ void cae_loss_finalize_kernel(const double* __restrict__ sums, int64_t nlat, double N, float w, double eps, float factor,
+                                         float* __restrict__ loss, float* __restrict__ coef) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double lat = nlat > 0 ? sp_rows_sum(sums, 11, 16) / (double)nlat : 0.0;
+  const double den0 = 5.0 + (double)factor;
+  double acc = sp_rows_sum(sums, 0, 16) / N + sp_rows_sum(sums, 1, 16) / N;
+  for (int k = 0; k < 3; ++k) {
+    const double num = 2.0 * sp_rows_sum(sums, 2 + 3 * k, 16) + eps;
+    const double den = sp_rows_sum(sums, 3 + 3 * k, 16) + sp_rows_sum(sums, 4 + 3 * k, 16) + eps;
+    acc += 1.0 - (double)w * num / den;
+    coef[1 + 2 * k] = (float)(-2.0 * w / den / den0);
+    coef[2 + 2 * k] = (float)(2.0 * w * num / (den * den) / den0);
+  }
+  acc += (double)factor * lat;
+  *loss = (float)(acc / den0);
+  coef[0] = (float)(1.0 / (N * den0));
+  coef[7] = nlat > 0 ? (float)((double)factor / ((double)nlat * den0)) : 0.f;
+}
+// gradients of the four reconstructions (dense (B, DHW) each, at dc / dp / dl / di) and of the two latents; up: dL/dloss on the device
+__global__ __launch_bounds__(256) void cae_loss_bwd_kernel(const float* __restrict__ c, int64_t cbs, const float* __restrict__ p, int64_t pbs,
+                                                           const float* __restrict__ l, int64_t lbs, const float* __restrict__ ii, int64_t ibs,
+                                                           const float* __restrict__ tc, int64_t tcbs, const float* __restrict__ tp, int64_t tpbs,
+                                                           const float* __restrict__ tl, int64_t tlbs, int64_t DHW, int B, const float* __restrict__ coef,
+                                                           const float* __restrict__ up, float* __restrict__ dc, float* __restrict__ dp,
+                                                           float* __restrict__ dl, float* __restrict__ di, const float* __restrict__ zi,
+                                                           const float* __restrict__ zl, int64_t nlat, float* __restrict__ dzi, float* __restrict__ dzl) {
+  const float go = up[0];
+  if ((int)blockIdx.y == B) {      // the latents
+    const float ls = coef[7] * go;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nlat; k += (int64_t)gridDim.x * 256) {
+      const float d = zi[k] - zl[k];
+      const float g = d > 0.f ? ls : (d < 0.f ? -ls : 0.f);
+      dzi[k] = g; dzl[k] = -g;
+    }
+    return;
+  }
+  const int b = blockIdx.y;
+  c += b * cbs; p += b * pbs; l += b * lbs; ii += b * ibs; tc += b * tcbs; tp += b * tpbs; tl += b * tlbs;
+  dc += (int64_t)b * DHW; dp += (int64_t)b * DHW; dl += (int64_t)b * DHW; di += (int64_t)b * DHW;
+  const float hs = coef[0] * go;
+  const float cac = coef[1] * go, cbc = coef[2] * go, cap = coef[3] * go, cbp = coef[4] * go, cal = coef[5] * go, cbl = coef[6] * go;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < DHW; v += (int64_t)gridDim.x * 256) {
+    const float vc = c[v], vp = p[v], vl = l[v], vi = ii[v];
+    const float d1 = vp - vi, d2 = vp - vc;
+    const float g1 = ((d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f)) - 1.f) * hs;      // d/dd (|d| - d), sign(0) = 0 as torch.abs
+    const float g2 = ((d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f)) - 1.f) * hs;
+    dp[v] = g1 + g2 + (cap * tp[v] + cbp * vp);
+    di[v] = -g1;
+    dc[v] = -g2 + (cac * tc[v] + cbc * vc);
+    dl[v] = cal * tl[v] + cbl * vl;
+  }
+}
+extern "C" int sp_cae_loss_fwd(const float* c, int64_t cbs, const float* p, int64_t pbs, const float* l, int64_t lbs, const float* i, int64_t ibs,
+                               const float* tc, int64_t tcbs, const float* tp, int64_t tpbs, const float* tl, int64_t tlbs, int32_t B, int64_t DHW,
+                               const float* zi, const float* zl, int64_t nlat, float dice_weight, double eps, float factor, double* sums,
+                               float* loss, float* coef, sp_stream_t stream) {
+  SP_CHECK_ARG(c && p && l && i && tc && tp && tl && sums && loss && coef && B >= 1 && B <= 65534 && DHW >= 1 && (nlat == 0 || (zi && zl)), "sp_cae_loss_fwd: bad arguments");
+  int64_t gx = (DHW + 256 * 8 - 1) / (256 * 8);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(cae_loss_sums_kernel, dim3((unsigned)gx, B + (nlat > 0 ? 1 : 0)), dim3(256), 0, ST(stream), c, cbs, p, pbs, l, lbs, i, ibs, tc, tcbs, tp, tpbs, tl,
+                     tlbs, DHW, sums, B, zi, zl, nlat);
+  hipLaunchKernelGGL(cae_loss_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), sums, nlat, (double)B * (double)DHW, dice_weight, eps, factor, loss, coef);
+  SP_CHECK_LAUNCH("sp_cae_loss_fwd");
+  return SP_OK;
+}
+extern "C" int sp_cae_loss_bwd(const float* c, int64_t cbs, const float* p, int64_t pbs, const float* l, int64_t lbs, const float* i, int64_t ibs,
+                               const float* tc, int64_t tcbs, const float* tp, int64_t tpbs, const float* tl, int64_t tlbs, int32_t B, int64_t DHW,
+                               const float* coef, const float* up, float* dc, float* dp, float* dl, float* di, const float* zi, const float* zl,
+                               int64_t nlat, float* dzi, float* dzl, sp_stream_t stream) {
+  SP_CHECK_ARG(c && p && l && i && tc && tp && tl && coef && up && dc && dp && dl && di && B >= 1 && B <= 65534 && DHW >= 1 && (nlat == 0 || (zi && zl && dzi && dzl)),
+               "sp_cae_loss_bwd: bad arguments");
+  int64_t gx = (DHW + 256 * 8 - 1) / (256 * 8);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(cae_loss_bwd_kernel, dim3((unsigned)gx, B + (nlat > 0 ? 1 : 0)), dim3(256), 0, ST(stream), c, cbs, p, pbs, l, lbs, i, ibs, tc, tcbs, tp, tpbs,
+                     tl, tlbs, DHW, B, coef, up, dc, dp, dl, di, zi, zl, nlat, dzi, dzl);
+  SP_CHECK_LAUNCH("sp_cae_loss_bwd");
+  return SP_OK;
+}
 // do[b,c,v] = up * (ca[c]*t + cb[c]*o), up = *upstream (the scalar gradient of the loss, read on the device)
 __global__ void dice_bwd_kernel(const float* __restrict__ o, int64_t obs, const float* __restrict__ t, int64_t tbs,
                                 const float* __restrict__ coef, const float* __restrict__ upstream, int C, int64_t DHW,

@@ -104,6 +104,8 @@ _SIGS = {
     "sp_conv3d_igemm_multi": ([C.POINTER(ConvArgs), i32, vp], i32),
     "sp_bn_act_bwd_groups_cls": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, i32, i32, i32, vp, vp], i32),
     "sp_wgrad_finish_folded_groups": ([vp, i32, i32, i32, i32, i32, i32, i64, i64, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp], i32),
+    "sp_cae_loss_fwd": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, i64, f32, f64, f32, vp, vp, vp, vp], i32),
+    "sp_cae_loss_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp], i32),
     "sp_pwout_fwd": ([vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_pwout_bwd": ([vp, vp, vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp], i32),
     "sp_pwout_finish": ([vp, i32, i32, i32, vp, vp, i32, vp, i32, vp, vp, vp], i32),

@@ -395,3 +395,41 @@ def test_weight_gradient_on_the_raw_input_with_batchnorm_folded_per_group(cin, c
         sc = float(ghat[sl].abs().max()) * math.sqrt(ghat[sl].numel() / cin)
         torch.testing.assert_close(got[gi, :cin, 0], e1, rtol=2e-3, atol=2e-3 * sc)
         torch.testing.assert_close(got[gi, :cin, 1], e2, rtol=2e-3, atol=2e-3 * sc)
+
+
+# ------------------------------------------------------------------------------------------------ fused reconstruction loss
+@pytest.mark.parametrize("factor", [0.0, 0.36])
+def test_fused_cae_reconstruction_loss_equals_the_composed_one(factor, monkeypatch):
+    """metrics.cae_reconstruction_loss (sp_cae_loss_fwd / _bwd: three launches) against the reference's own recipe composed of torch
+    operators and BatchDiceLoss calls (CaeReconstructionLearner.py:52-70): value and the gradients of the four reconstructions
+    (slices of one stacked tensor, as the batched decoder hands them out) and of the two latents"""
+    from types import SimpleNamespace as NS
+    from stroke_prediction_amd.common import metrics
+    g = torch.Generator().manual_seed(3)
+    B, dims = 2, (5, 12, 20)
+    stacked = torch.rand(4 * B, 1, *dims, generator=g).to(DEV).requires_grad_(True)
+    gts = [(torch.rand(B, 1, *dims, generator=g) > 0.6).float().to(DEV) for _ in range(3)]
+    zi = torch.randn(B, 50, 1, 2, 2, generator=g).to(DEV).requires_grad_(True)
+    zl = torch.randn(B, 50, 1, 2, 2, generator=g).to(DEV).requires_grad_(True)
+    crit = metrics.BatchDiceLoss([1.0])
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setenv("SP_CAE_FUSED_LOSS", "1" if fused else "0")
+        for t in (stacked, zi, zl):
+            t.grad = None
+        parts = [stacked[k * B:(k + 1) * B] for k in range(4)]          # decoder passes: core, penu, lesion, interpolation
+        rec = NS(core=parts[0], penu=parts[1], lesion=parts[2], interpolation=parts[3])
+        gt = NS(core=gts[0], penu=gts[1], lesion=gts[2])
+        lat = NS(interpolation=zi, lesion=zl)
+        loss = metrics.cae_reconstruction_loss(rec, gt, lat, factor, crit)
+        assert (loss is not None) == fused
+        if loss is None:
+            d1, d2 = rec.penu - rec.interpolation, rec.penu - rec.core
+            loss = (torch.mean(torch.abs(d1) - d1) + torch.mean(torch.abs(d2) - d2) + crit(rec.core, gt.core) + crit(rec.penu, gt.penu)
+                    + crit(rec.lesion, gt.lesion) + factor * torch.mean(torch.abs(zi - zl))) / (5 + factor)
+        (loss * 1.7).backward()
+        res[fused] = (float(loss), stacked.grad.clone(), zi.grad.clone(), zl.grad.clone())
+    a, b = res[True], res[False]
+    assert abs(a[0] - b[0]) < 2e-6, (a[0], b[0])
+    for k in (1, 2, 3):
+        torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-9)
