@@ -465,6 +465,18 @@ def bench_unet(args, world, rank, dev, four_scale=False):
         step()
     dt, last = timed_steps(step, args, world, dev)
     ms = 1e3 * dt / args.steps
+    # what a loader pays that does NOT write into the step's own buffers: the device-to-device copy of one batch (outside the timed
+    # region; reported next to the line so that the resident-input number can be read either way)
+    copy_us = None
+    if use_graph and not os.environ.get("SP_BENCH_COPY_INPUTS") and batch["images"].data_ptr() != images.data_ptr():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            batch["images"].copy_(images)
+            batch["labels"].copy_(labels)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_us = e0.elapsed_time(e1) * 1e3 / 20
     vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
     launch_mode = ("hipGraph (Learner(graph=True))" if world == 1 or os.environ.get("SP_DIST_GRAPH") else
                    "hipGraph of forward + loss + backward, then all-reduce and Adam (Learner(graph=True))") if use_graph else "eager"
@@ -478,6 +490,7 @@ def bench_unet(args, world, rank, dev, four_scale=False):
                                % (name, args.batch, args.size, out[0], "configs[4] topology" if four_scale else "configs[1]"),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(last.loss),
                    "launch": launch_mode, "input": "resident in the step's input buffers (Learner.static_batch)" if (use_graph and not os.environ.get("SP_BENCH_COPY_INPUTS")) else "resident device tensors",
+                   "input_copy_us": copy_us,      # device-to-device copy of one batch into those buffers, NOT in ms_per_step
                    "dp_mode": args.dp_mode if world > 1 else None,
                    "grad_exchange": (("one all-reduce of the flat gradient buffer between the backward graph and Adam"
                                       if (use_graph and not os.environ.get("SP_DIST_GRAPH")) else

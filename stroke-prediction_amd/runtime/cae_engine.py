@@ -221,7 +221,7 @@ class StackContext:
         for i in range(top, -1, -1):
             lay = self.layers[i]
             x = self.layers[i - 1].y if i > 0 else self.x0
-            g, coef = lay.backward(x, params, grads)
+            g, coef = lay.backward(x, params, grads, want_g=(i > 0 or need_input_grad))
             if i > 0:
                 prev = self.layers[i - 1]
                 O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y) if coef is not None else 0,

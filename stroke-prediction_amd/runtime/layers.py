@@ -379,10 +379,13 @@ class ConvLayer:
     def dbias_sums(self):
         return self.scratch.get(self.dbias_sums_id).view(L.SP_REDUCE_ROWS, self.cpo)
 
-    def backward(self, x, params, grads):
+    def backward(self, x, params, grads, want_g=True):
         """Given self.dz (gradient at the pre-activation output) and self.dbias_sums already filled by the
         producer of dz: accumulate parameter gradients, return (g, coef) describing the input gradient
-        dx = coef0*g + coef1*x + coef2 (coef None: dx = g)."""
+        dx = coef0*g + coef1*x + coef2 (coef None: dx = g).
+        want_g=False: nobody reads g (the first layer of a stack whose input needs no gradient) -- honoured where the
+        BatchNorm-backward sums do not come from the data gradient (the raw-input weight gradient of the batched CAE layers)."""
+        self._want_g = bool(want_g)
         c = self.conv_prefix
         w = params[c + ".weight"]
         if not self.param_grads:
@@ -465,8 +468,9 @@ class ConvLayer:
             L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, self.G, wg.cot * 16, wg.cit * 16, self.cout, self.cin, wg.w_sco, wg.w_sci,
                    self.apply_coef.data_ptr(), 3 * self.cpi, self.cpi, O.ptr(self.scratch.get(self.cls_sums_id)), self._pads[0], self._pads[1],
                    self._pads[2], O.ptr(w), O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(bs), STATS_NREP, self.cpi, O.stream())
-        self.dgrad.prep(w)
-        self.dgrad.run(self.dz, self.g, self.batch)
+        if getattr(self, "_want_g", True):      # (else: the BatchNorm's own gradients below are all that is left of this layer's input side)
+            self.dgrad.prep(w)
+            self.dgrad.run(self.dz, self.g, self.batch)
         f.join()
         world = 1
         if SYNC["on"]:
