@@ -332,6 +332,10 @@ typedef struct sp_conv_fc_args {
   float act_param;
   int32_t stats_mode, stats_nrep, dtype_out;
   int64_t x_plane;         /* != 0: x is plane-major [CPi/16][B][D][H][W][16] with this many elements per plane */
+  /* batched passes (the CAE): samples [g*group_batch, (g+1)*group_batch) are BatchNorm group g -- its statistics rows at
+   * stats + g*stats_nrep*CPo*2, its in_scale / in_shift rows at + g*coef_gstride floats; one launch for all groups (0: one group) */
+  int32_t group_batch;
+  int32_t coef_gstride;
 } sp_conv_fc_args;
 int sp_conv_fc_workspace(int32_t B, int32_t Do, int32_t Ho, int32_t Wo, int32_t Cout, int32_t ntap, int64_t* floats);
 int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream);

@@ -115,8 +115,11 @@ __global__ __launch_bounds__(256) void conv_fc_finish_kernel(const ConvFcDev P) 
   float s1[8], s2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  // BatchNorm groups: grid.y = group, its voxels [mlo, mhi), its statistics rows
+  const int Mg = a.group_batch > 0 ? a.group_batch * a.Do * a.Ho * a.Wo : P.M;
+  const int mlo = (int)blockIdx.y * Mg, mhi = min(P.M, mlo + Mg);
   if (active) {
-    for (int m = blockIdx.x * vpb + pos; m < P.M; m += gridDim.x * vpb) {
+    for (int m = mlo + blockIdx.x * vpb + pos; m < mhi; m += gridDim.x * vpb) {
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_fc_finish_kernel(const ConvFcDev P) 
     __syncthreads();
     // columns: (channel, {sum, second sum}); rows: the vpb voxel slots of this workgroup
     const int ncol = a.CPo * 2;
-    double* o = a.stats + (size_t)(blockIdx.x & (a.stats_nrep - 1)) * ncol;
+    double* o = a.stats + ((size_t)blockIdx.y * a.stats_nrep + (blockIdx.x & (a.stats_nrep - 1))) * ncol;
     for (int col = threadIdx.x; col < ncol; col += 256) {
       float tsum = 0.f;
       for (int k = 0; k < vpb; ++k) tsum += s_red[(k * OC) * 16 + col];
@@ -191,6 +194,10 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
   const uint4* wf = reinterpret_cast<const uint4*>(a.wfrag) + (size_t)nt0 * 64 + lane;
   uint4 aq[SPT][NTB];
   float sc[SPT][8], sh[SPT][8];
+  // BatchNorm groups: grid.z = group, its voxels [mlo, mhi), its scale / shift rows and statistics rows
+  const int grp = blockIdx.z;
+  const int Mg = a.group_batch > 0 ? a.group_batch * a.Do * a.Ho * a.Wo : P.M;
+  const int mlo = grp * Mg, mhi = min(P.M, mlo + Mg);
 #pragma unroll
   for (int s = 0; s < SPT; ++s) {
 #pragma unroll
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const bool ok = a.in_scale && oct < P.octs;
-      sc[s][j] = ok ? a.in_scale[oct * 8 + j] : 1.f;
-      sh[s][j] = ok ? a.in_shift[oct * 8 + j] : 0.f;
+      sc[s][j] = ok ? a.in_scale[(size_t)grp * a.coef_gstride + oct * 8 + j] : 1.f;
+      sh[s][j] = ok ? a.in_shift[(size_t)grp * a.coef_gstride + oct * 8 + j] : 0.f;
     }
   }
   float bj[NTB][4], s1[NTB][4], s2[NTB][4];
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
       bj[n][j] = (a.bias && c < a.Cout) ? a.bias[c] : 0.f;
       s1[n][j] = s2[n][j] = 0.f;
     }
-  const int ntile = (P.M + 15) / 16;
+  const int ntile = (mhi - mlo + 15) / 16;
   constexpr int TPW = 4;             // tiles in flight per wave: the loads of four tiles are issued before the first is used (eight: no change)
   for (int base = (blockIdx.x * 4 + wave) * TPW; base < ntile; base += gridDim.x * 4 * TPW) {
     uint4 raw[TPW][SPT];
@@ -220,14 +227,14 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
     bool ins[TPW];
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
-      const int m = (base + u) * 16 + vl;
-      mm[u] = m;
-      uint32_t t = (uint32_t)(m < P.M ? m : P.M - 1);
+      const int m = mlo + (base + u) * 16 + vl;
+      mm[u] = m < mhi ? m : P.M;              // (>= P.M: outside -- the tile tail of a group must not reach into the next one)
+      uint32_t t = (uint32_t)(m < mhi ? m : mhi - 1);
       uint32_t q = fdiv(t, P.d_w); const int ox = t - q * a.Wo; t = q;
       q = fdiv(t, P.d_h); const int oy = t - q * a.Ho; t = q;
       q = fdiv(t, P.d_d); const int oz = t - q * a.Do; const int b = q;
       const int iz = oz * a.sD + a.o0D + tp[0], iy = oy * a.sH + a.o0H + tp[1], ix = ox * a.sW + a.o0W + tp[2];
-      ins[u] = m < P.M && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
+      ins[u] = m < mhi && (unsigned)iz < (unsigned)a.Di && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi;
       const int64_t vox = (((int64_t)b * a.Di + iz) * a.Hi + iy) * a.Wi + ix;
       const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.x) + vox * (a.x_plane ? 16 : a.CPi);
 #pragma unroll
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(const ConvFcDev P) {
     __syncthreads();
     for (int i = threadIdx.x; i < nn * 32; i += 256) {
       const int c = nt0 * 16 + (i >> 1);
-      if (c < a.CPo) atomicAdd(&a.stats[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NTB * 32, 4, i));
+      if (c < a.CPo) atomicAdd(&a.stats[((size_t)grp * a.stats_nrep + (blockIdx.x & (a.stats_nrep - 1))) * a.CPo * 2 + (size_t)c * 2 + (i & 1)], (double)sp_cols_sum(red, NTB * 32, 4, i));
     }
   }
 }
@@ -322,6 +329,8 @@ extern "C" int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(!a->stats || a->stats_mode == 0 || (a->stats_mode == 1 && a->aux && a->dtype_out == SP_BF16), "sp_conv_fc: statistics mode");
   const int64_t M = (int64_t)a->B * a->Do * a->Ho * a->Wo;
   SP_CHECK_ARG(M >= 1 && M < (a->partial ? (1ll << 24) : (1ll << 31) - 16), "sp_conv_fc: output volume");
+  SP_CHECK_ARG(a->group_batch >= 0 && (a->group_batch == 0 || (a->B % a->group_batch == 0 && a->coef_gstride >= 0)), "sp_conv_fc: group_batch %d must divide the batch %d", a->group_batch, a->B);
+  const unsigned G = a->group_batch > 0 ? (unsigned)(a->B / a->group_batch) : 1u;
   ConvFcDev P;
   P.a = *a;
   P.M = (int32_t)M;
@@ -330,10 +339,11 @@ extern "C" int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream) {
     P.spt = (P.octs + 3) / 4;
     P.NTtot = (a->Cout + 15) / 16;
     P.d_w = make_fastdiv(a->Wo); P.d_h = make_fastdiv(a->Ho); P.d_d = make_fastdiv(a->Do);
-    const int64_t tiles = (M + 15) / 16;
-    unsigned gx = (unsigned)((tiles + 15) / 16 < 2048 ? (tiles + 15) / 16 : 2048);
+    const int64_t tiles = (M / G + 15) / 16;
+    unsigned gx = (unsigned)((tiles + 15) / 16 < 2048 / G ? (tiles + 15) / 16 : 2048 / G);
+    if (gx < 1) gx = 1;
     const int ntb = P.NTtot >= 4 ? 4 : (P.NTtot >= 2 ? 2 : 1);
-    dim3 grid(gx, (unsigned)((P.NTtot + ntb - 1) / ntb));
+    dim3 grid(gx, (unsigned)((P.NTtot + ntb - 1) / ntb), G);
     hipStream_t st0 = reinterpret_cast<hipStream_t>(stream);
 #define PW_CASE(S_, N_)                                                                                              \
   if (P.spt == S_ && ntb == N_) {                                                                                    \
@@ -356,10 +366,11 @@ extern "C" int sp_conv_fc(const sp_conv_fc_args* a, sp_stream_t stream) {
   SP_CHECK_LAUNCH("sp_conv_fc(partial)");
   const int vpb = 256 / (a->CPo / 8) > 0 ? 256 / (a->CPo / 8) : 1;
   SP_CHECK_ARG(a->CPo / 8 <= 256, "sp_conv_fc: too many output channels");
-  unsigned fg = (unsigned)((M + vpb - 1) / vpb);
-  if (fg > 1024) fg = 1024;
-  if (a->dtype_out == SP_BF16) hipLaunchKernelGGL(conv_fc_finish_kernel<bf16_t>, dim3(fg), dim3(256), 0, st, P);
-  else hipLaunchKernelGGL(conv_fc_finish_kernel<float>, dim3(fg), dim3(256), 0, st, P);
+  unsigned fg = (unsigned)((M / G + vpb - 1) / vpb);
+  if (fg > 1024 / G) fg = 1024 / G;
+  if (fg < 1) fg = 1;
+  if (a->dtype_out == SP_BF16) hipLaunchKernelGGL(conv_fc_finish_kernel<bf16_t>, dim3(fg, G), dim3(256), 0, st, P);
+  else hipLaunchKernelGGL(conv_fc_finish_kernel<float>, dim3(fg, G), dim3(256), 0, st, P);
   SP_CHECK_LAUNCH("sp_conv_fc(finish)");
   return SP_OK;
 }

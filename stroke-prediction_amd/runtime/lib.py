@@ -58,7 +58,8 @@ class WgradF8Args(C.Structure):      # sp_wgrad_f8_args
 class ConvFcArgs(C.Structure):       # sp_conv_fc_args
     _fields_ = [(n, vp) for n in ("x", "y", "wfrag", "in_scale", "in_shift", "bias", "stats", "aux", "partial", "taps")] + \
                [(n, i32) for n in ("B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "Cout", "sD", "sH", "sW", "o0D", "o0H", "o0W",
-                                   "ntap", "act")] + [("act_param", f32), ("stats_mode", i32), ("stats_nrep", i32), ("dtype_out", i32), ("x_plane", i64)]
+                                   "ntap", "act")] + [("act_param", f32), ("stats_mode", i32), ("stats_nrep", i32), ("dtype_out", i32), ("x_plane", i64),
+                                                                         ("group_batch", i32), ("coef_gstride", i32)]
 
 
 class Conv3dDesc(C.Structure):       # sp_conv3d_desc

@@ -402,7 +402,7 @@ class ConvRunner:
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
             dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None,
-            x_lo=None, y_lo=None, group_fold=None):
+            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
         y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners)."""
@@ -410,7 +410,7 @@ class ConvRunner:
         assert y8 is None or (self.zm_y8_ok() and not group_batch and use_bias and act in (L.ACT_NONE, L.ACT_LEAKY))
         dtype_out = op.dtype if dtype_out is None else dtype_out
         zm_groups = self.zm is not None and batch == self.zm_batch     # the z-marching kernel flushes its statistics per group itself
-        if group_batch and group_batch < batch and stats is not None and ((self.uses_zm() and not zm_groups) or self.fc is not None):
+        if group_batch and group_batch < batch and stats is not None and (self.uses_zm() and not zm_groups):
             # BatchNorm groups (statistics rows per group) on a kernel that is not group-aware: one launch per group on the
             # contiguous slices of the batch (output-channel slices of the z-marching kernel, the split-K kernel)
             assert in_scale is None and batch % group_batch == 0
@@ -477,7 +477,7 @@ class ConvRunner:
             return self._run_zm(a, x_planar, batch, stats is not None, st)
         if self.fc is not None:     # (its fragments are the only ones packed: every call of this runner goes there)
             return _run_fc(self, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep,
-                           stats_mode, aux, st, x_planar)
+                           stats_mode, aux, st, x_planar, group_batch=group_batch, coef_gstride=coef_gstride)
         par = self.par is not None and in_scale is None and not x_planar and dtype_out == L.SP_BF16 and y8 is None
         multi = (L.ConvArgs * len(self.subs))() if (par or (USE_MULTI and 2 <= len(self.subs) <= 8 and not x_planar)) else None
         for si, s in enumerate(self.subs):
@@ -558,7 +558,7 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
 
 
 def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtype_out, use_bias, stats_nrep, stats_mode, aux, st,
-            x_planar=False):
+            x_planar=False, group_batch=0, coef_gstride=0):
     """split-K kernel for FC-like layers (csrc/sp_conv_fc.hip)"""
     op, f = runner.op, runner.fc
     sub = op.subs[0]
@@ -584,6 +584,7 @@ def _run_fc(runner, x, y, batch, in_scale, in_shift, act, act_param, stats, dtyp
     a.stats_mode, a.stats_nrep = stats_mode, stats_nrep
     a.dtype_out = op.dtype if dtype_out is None else dtype_out
     a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
+    a.group_batch, a.coef_gstride = (group_batch, coef_gstride) if (group_batch and group_batch < batch) else (0, 0)
     with _Timed("conv_igemm", op.flops(batch), "%d->%d @%s %s%s" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), "pw" if f["pointwise"] else "fc",
                                                                     " +stats" if stats is not None else "")):
         L.call("sp_conv_fc", C.byref(a), st)
