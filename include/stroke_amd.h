@@ -404,6 +404,9 @@ typedef struct sp_wgrad_args {
                             larger spatial tile (less halo re-read) at the price of re-reading dz per cin group */
   int64_t x_plane;       /* dma kernel, cib == 1: != 0 -> x is plane-major [CPi/16][B][D][H][W][16], elements per plane */
   int32_t zs;            /* dma kernel: 1 = allow the z-marching ring variant (cib == 1, parts == 1, Cout <= 32 per group) */
+  int32_t groups;        /* pointwise kernel, parts == 1: > 1 -> the batch holds this many equal BatchNorm groups and partial block i covers
+                            voxels of group i * groups / nblocks only (nblocks % groups == 0): sp_wgrad_finish_folded_groups.  (The
+                            row-sliding 3x3x3 kernel is group-pure whenever nblocks % groups == 0.) */
 } sp_wgrad_args;
 int sp_conv3d_wgrad(const sp_wgrad_args* a, sp_stream_t stream);
 /* BatchNorm folded out of the operand load (un-padded convolutions):
@@ -542,7 +545,7 @@ int sp_bn_act_bwd_groups_cls(const void* g, const void* y, const float* coef, in
  * lies inside the input, dbias_grad[co] += sum dz, and the BatchNorm-backward pair (sum g, sum g x) of the layer's input per group
  * into bn_sums[G][bn_nrep][bn_cp][2] (NULL: skip) -- the data gradient then needs no statistics epilogue.  coef: rows
  * (scale, -, shift) of pitch coef_pitch per group. */
-int sp_wgrad_finish_folded_groups(const float* dw_acc, int32_t nparts, int32_t G, int32_t CoP, int32_t CiP, int32_t Cout, int32_t Cin,
+int sp_wgrad_finish_folded_groups(const float* dw_acc, int32_t nparts, int32_t ntap /* 27, or 1 (pointwise: padding 0) */, int32_t G, int32_t CoP, int32_t CiP, int32_t Cout, int32_t Cin,
                                   int64_t sCo, int64_t sCi, const float* coef, int32_t coef_gstride, int32_t coef_pitch,
                                   const double* cls_sums, int32_t padD, int32_t padH, int32_t padW, const float* w, float* dw,
                                   float* dbias_grad, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, sp_stream_t stream);

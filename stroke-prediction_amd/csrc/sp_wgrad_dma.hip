@@ -729,7 +729,7 @@ static int wgrad_finish_folded_impl(float* dw_acc, int32_t nparts, const int32_t
 __device__ __forceinline__ bool fg_tap_valid(int t, int c, int p) { return c < p ? t >= p - c : (c == p ? true : t < 3 - (c - p)); }
 // a workgroup = 32 consecutive accumulator entries x 8 row lanes that split the group's partial blocks (a serial walk over the
 // blocks per entry, 27 workgroups in all, took 116 us of dependent loads)
-__global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const float* __restrict__ acc, int nb, int G, int CoP, int CiP, int Cout, int Cin,
+__global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const float* __restrict__ acc, int nb, int ntap, int G, int CoP, int CiP, int Cout, int Cin,
                                                                           int64_t sCo, int64_t sCi, const float* __restrict__ coef, int coef_gstride,
                                                                           int coef_pitch, const double* __restrict__ cls, int pz, int py, int px,
                                                                           const float* __restrict__ w, float* __restrict__ dw, float* __restrict__ dbias_grad,
@@ -737,12 +737,11 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
   __shared__ float red[8][33];
   __shared__ double bred[2][32];
   const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  const int64_t total = (int64_t)27 * CoP * CiP;
+  const int64_t total = (int64_t)ntap * CoP * CiP;
   const int64_t e = (int64_t)blockIdx.x * 32 + el;
   const bool in = e < total;
   const int ci = in ? (int)(e % CiP) : 0, co = in ? (int)((e / CiP) % CoP) : 0, tap = in ? (int)(e / ((int64_t)CiP * CoP)) : 0;
-  const int tz = tap / 9, ty = (tap / 3) % 3, tx = tap % 3;
-  const int ny = 2 * py + 1, nx = 2 * px + 1, ncls = (2 * pz + 1) * ny * nx;
+  const int ny = 2 * py + 1, nx = 2 * px + 1, ncls = (2 * pz + 1) * ny * nx;      // (ntap == 1: padding 0, one class)
   const int per = nb / G;
   const bool real = in && co < Cout && ci < Cin;
   const float wv = (real && rl == 0) ? w[co * sCo + ci * sCi + tap] : 0.f;
@@ -756,7 +755,7 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
   for (int q = rl; q < G * npair; q += 8) {
     const int g = q / npair, pr = pair0 + q % npair;
     const int pco = pr % CoP, ptap = pr / CoP;
-    const int ptz = ptap / 9, pty = (ptap / 3) % 3, ptx = ptap % 3;
+    const int ptz = ntap == 27 ? ptap / 9 : 1, pty = ntap == 27 ? (ptap / 3) % 3 : 1, ptx = ntap == 27 ? ptap % 3 : 1;      // (pointwise: the centre, always inside)
     double t = 0.0, ta = 0.0;
     for (int cl = el; cl < ncls; cl += 32) {
       const int cx = cl % nx, cy = (cl / nx) % ny, cz = cl / (nx * ny);
@@ -813,18 +812,19 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
   }
   if (real && rl == 0) dw[co * sCo + ci * sCi + tap] += dwv;
 }
-extern "C" int sp_wgrad_finish_folded_groups(const float* dw_acc, int32_t nparts, int32_t G, int32_t CoP, int32_t CiP, int32_t Cout, int32_t Cin,
+extern "C" int sp_wgrad_finish_folded_groups(const float* dw_acc, int32_t nparts, int32_t ntap, int32_t G, int32_t CoP, int32_t CiP, int32_t Cout, int32_t Cin,
                                              int64_t sCo, int64_t sCi, const float* coef, int32_t coef_gstride, int32_t coef_pitch,
                                              const double* cls_sums, int32_t padD, int32_t padH, int32_t padW, const float* w, float* dw,
                                              float* dbias_grad, double* bn_sums, int32_t bn_nrep, int32_t bn_cp, sp_stream_t stream) {
+  SP_CHECK_ARG((ntap == 27 || (ntap == 1 && padD == 0 && padH == 0 && padW == 0)), "sp_wgrad_finish_folded_groups: 27 taps, or one (pointwise, padding 0)");
   SP_CHECK_ARG(dw_acc && coef && cls_sums && w && dw && G >= 1 && nparts >= G && nparts % G == 0 && G <= 16 && CoP >= Cout && CiP >= Cin && CiP >= 8,
                "sp_wgrad_finish_folded_groups: %d partial blocks for %d groups, tiles %d x %d", nparts, G, CoP, CiP);
   SP_CHECK_ARG(padD >= 0 && padD <= 2 && padH >= 0 && padH <= 2 && padW >= 0 && padW <= 2 && coef_pitch >= Cin && coef_gstride >= 3 * coef_pitch,
                "sp_wgrad_finish_folded_groups: padding 0..2, coefficient rows (scale, -, shift)");
   SP_CHECK_ARG(!bn_sums || (bn_nrep >= 1 && bn_cp >= Cin), "sp_wgrad_finish_folded_groups: bn_sums rows");
-  const int64_t total = (int64_t)27 * CoP * CiP;
+  const int64_t total = (int64_t)ntap * CoP * CiP;
   hipLaunchKernelGGL(wgrad_finish_folded_groups_kernel, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dw_acc,
-                     nparts, G, CoP, CiP, Cout, Cin, sCo, sCi, coef, coef_gstride, coef_pitch, cls_sums, padD, padH, padW, w, dw, dbias_grad, bn_sums,
+                     nparts, ntap, G, CoP, CiP, Cout, Cin, sCo, sCi, coef, coef_gstride, coef_pitch, cls_sums, padD, padH, padW, w, dw, dbias_grad, bn_sums,
                      bn_nrep, bn_cp);
   SP_CHECK_LAUNCH("sp_wgrad_finish_folded_groups");
   return SP_OK;

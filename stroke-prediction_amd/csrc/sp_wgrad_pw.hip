@@ -45,8 +45,13 @@ __global__ __launch_bounds__(256) void wgrad_pw_kernel(const WgradPwDev P) {
   for (int c = 0; c < COT; ++c)
 #pragma unroll
     for (int i = 0; i < CIT; ++i) acc[c][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int64_t nchunk = (P.M + 31) / 32;
-  const int64_t stride = (int64_t)gridDim.x * 4;
+  // BatchNorm groups (a.groups > 1; host: nblocks % groups == 0, voxels per group a multiple of 32): a workgroup's chunks stay inside
+  // its group, so the partial blocks of a group are consecutive (sp_wgrad_finish_folded_groups)
+  const int ngr = a.groups > 1 ? a.groups : 1;
+  const int64_t ncg = (P.M + 31) / 32 / ngr;                 // chunks per group (one group: all)
+  const int bpg = gridDim.x / ngr, grp = blockIdx.x / bpg, lb = blockIdx.x - grp * bpg;
+  const int64_t nchunk = ngr > 1 ? (grp + 1) * ncg : (P.M + 31) / 32;
+  const int64_t stride = (int64_t)bpg * 4;
   auto issue = [&](int64_t chunk, int buf) {
     const int64_t v = chunk * 32 + dv;
     const bool ok = chunk < nchunk && v < P.M;
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void wgrad_pw_kernel(const WgradPwDev P) {
       sp_dma16_nc(oki ? xg + (v * a.CPi + (ci_t0 + i) * 16 + dh * 8) * 2 : zeros, dst + (COT + i) * 1024);
     }
   };
-  int64_t chunk = (int64_t)blockIdx.x * 4 + wave;
+  int64_t chunk = (ngr > 1 ? grp * ncg : (int64_t)0) + (int64_t)lb * 4 + wave;
   issue(chunk, 0);
   int buf = 0;
   for (; chunk < nchunk; chunk += stride) {
@@ -119,6 +124,10 @@ int sp_wgrad_pw_try(const sp_wgrad_args* a, hipStream_t st) {
   WgradPwDev P;
   P.a = *a;
   P.M = (int64_t)a->B * a->Do * a->Ho * a->Wo;
+  if (a->groups > 1) {
+    SP_CHECK_ARG(a->nblocks % a->groups == 0 && a->B % a->groups == 0 && (P.M / a->groups) % 32 == 0,
+                 "sp_conv3d_wgrad(pointwise): %d groups need nblocks %d %% groups == 0 and a multiple of 32 voxels per group", a->groups, a->nblocks);
+  }
   const int COT = (a->CoT % 2 == 0) ? 2 : 1, CIT = (a->CiT % 2 == 0) ? 2 : 1;
   dim3 grid(a->nblocks, a->CoT / COT, a->CiT / CIT);
 #define PW_CASE(C_, I_)                                                                       \

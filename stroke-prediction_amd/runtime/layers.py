@@ -135,6 +135,15 @@ class ConvLayer:
                                 and act == L.ACT_ELU and dtype == L.SP_BF16 and (2 * pads[0] + 1) * (2 * pads[1] + 1) * (2 * pads[2] + 1) <= 75)
         self.raw_wgrad = bool(self.fold_groups and O.RAW_WGRAD and tuple(P._triple(stride)) == (1, 1, 1) and k == 3
                               and self.cpi % 16 == 0 and self.cpo % 16 == 0 and not os.environ.get("SP_WGRAD_ZR") == "0")
+        # ... and the 1x1x1 layers (Cae3D.py:214-216): the pointwise kernel applies each group's scale / shift on its operand load
+        # (exact: no padding), the weight gradient reads the raw input the same way
+        self.raw_pw = bool(self.G > 1 and O.RAW_WGRAD and O.ZM_GROUPS and bn_prefix is not None and kind == "conv" and k == 1
+                           and tuple(P._triple(stride)) == (1, 1, 1) and max(pads) == 0 and dtype == L.SP_BF16 and act == L.ACT_ELU
+                           and self.out_dtype == dtype and self.fwd.fc is not None and self.fwd.fc["pointwise"]
+                           and (self.gb * in_dims[0] * in_dims[1] * in_dims[2]) % 32 == 0)
+        if self.raw_pw:
+            self.raw_wgrad = True
+            self._ncls, self._pads = 1, (0, 0, 0)
         if self.fold_groups:
             z = self.fwd.zm
             self._gfrag_elems = z["nsteps"] * z["NT"] * 64 * 8
@@ -274,6 +283,11 @@ class ConvLayer:
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
                          stats_nrep=STATS_NREP, group_batch=self.gb, group_fold=(self.gfrag, self._gfrag_elems * 2, self.gtab, self._ncls * self.cpo))
             self._xhat_of = None            # the normalised copy of THIS input does not exist yet (backward writes it)
+            return y
+        if self.G > 1 and self.raw_pw:
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
+            self.fwd.run(x, y, self.batch, self.apply_coef[:, 0], self.apply_coef[:, 2], self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
+                         stats_nrep=STATS_NREP, group_batch=self.gb, coef_gstride=3 * self.cpi)
             return y
         if self.G > 1:
             src = x
@@ -465,7 +479,7 @@ class ConvLayer:
         f = O.fork()
         with f:
             wg.run_raw(x, self.dz, self.batch)
-            L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, self.G, wg.cot * 16, wg.cit * 16, self.cout, self.cin, wg.w_sco, wg.w_sci,
+            L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, wg.ntap, self.G, wg.cot * 16, wg.cit * 16, self.cout, self.cin, wg.w_sco, wg.w_sci,
                    self.apply_coef.data_ptr(), 3 * self.cpi, self.cpi, O.ptr(self.scratch.get(self.cls_sums_id)), self._pads[0], self._pads[1],
                    self._pads[2], O.ptr(w), O.ptr(grads[c + ".weight"]), O.ptr(grads[c + ".bias"]), O.ptr(bs), STATS_NREP, self.cpi, O.stream())
         if getattr(self, "_want_g", True):      # (else: the BatchNorm's own gradients below are all that is left of this layer's input side)

@@ -47,7 +47,7 @@ class ConvArgs(C.Structure):
 class WgradArgs(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "dz", "in_scale", "in_shift", "dz_scale", "dz_shift", "dw_acc", "taps")] + \
                [(n, i32) for n in ("dtype", "B", "Di", "Hi", "Wi", "CPi", "Do", "Ho", "Wo", "CPo", "sD", "sH", "sW",
-                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64), ("zs", i32)]
+                                   "o0D", "o0H", "o0W", "ntap", "kD", "kH", "kW", "CoT", "CiT", "nblocks", "dma", "tile_rows", "parts", "cib")] + [("x_plane", i64), ("zs", i32), ("groups", i32)]
 
 
 class WgradF8Args(C.Structure):      # sp_wgrad_f8_args
@@ -104,7 +104,7 @@ _SIGS = {
     "sp_conv3d_igemm": ([C.POINTER(ConvArgs), vp], i32),
     "sp_conv3d_igemm_multi": ([C.POINTER(ConvArgs), i32, vp], i32),
     "sp_bn_act_bwd_groups_cls": ([vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, i32, i32, i32, i32, vp, vp], i32),
-    "sp_wgrad_finish_folded_groups": ([vp, i32, i32, i32, i32, i32, i32, i64, i64, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp], i32),
+    "sp_wgrad_finish_folded_groups": ([vp, i32, i32, i32, i32, i32, i32, i32, i64, i64, vp, i32, i32, vp, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp], i32),
     "sp_cae_loss_fwd": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, i64, f32, f64, f32, vp, vp, vp, vp], i32),
     "sp_cae_loss_bwd": ([vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp], i32),
     "sp_pwout_fwd": ([vp, i32, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),

@@ -691,6 +691,7 @@ class WgradRunner:
         a.dz_scale, a.dz_shift = ptr(dz_scale), ptr(dz_shift)
         a.B = batch
         a.zs = int(WGRAD_ZS)
+        a.groups = 0
         a.x_plane = 0
         if x_planar:
             assert a.dma and a.cib == 1, "plane-major input: DMA weight-gradient kernel, one plane per workgroup"
@@ -707,14 +708,15 @@ class WgradRunner:
         """the kernel only, on the RAW input, into this runner's partial blocks (self.acc, self.nparts): the caller finishes
         (layers.ConvLayer._backward_grouped_raw: sp_wgrad_finish_folded_groups)"""
         a = self.args
-        assert self.dma and x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
+        assert (self.dma or self.pw) and x.dtype == TORCH_DT[self.dtype] and dz.dtype == TORCH_DT[self.dtype]
         assert tuple(x.shape) == (batch, a.Di, a.Hi, a.Wi, a.CPi) and tuple(dz.shape) == (batch, a.Do, a.Ho, a.Wo, a.CPo)
         if self.acc is None or self.acc_batch != batch:
             self._alloc_acc(batch)
         assert a.parts == 1 and self.nparts % getattr(self, "groups", 1) == 0
         a.x, a.dz, a.dw_acc, a.taps = ptr(x), ptr(dz), ptr(self.acc), ptr(self.taps)
-        a.dma, a.in_scale, a.in_shift, a.dz_scale, a.dz_shift = 1, None, None, None, None
+        a.dma, a.in_scale, a.in_shift, a.dz_scale, a.dz_shift = int(self.dma), None, None, None, None
         a.B, a.zs, a.x_plane = batch, int(WGRAD_ZS), 0
+        a.groups = getattr(self, "groups", 1)
         with _Timed("conv_wgrad", 2 * batch * a.Do * a.Ho * a.Wo * self.ntap * self.cin * self.cout,
                     "%d->%d @%dx%dx%d dma raw" % (self.cin, self.cout, a.Di, a.Hi, a.Wi)):
             L.call("sp_conv3d_wgrad", C.byref(a), stream())

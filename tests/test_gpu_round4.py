@@ -382,7 +382,7 @@ def test_weight_gradient_on_the_raw_input_with_batchnorm_folded_per_group(cin, c
     nrep = 4
     bs = torch.zeros(G * nrep * cpi * 2, dtype=torch.float64, device=DEV)
     wd = w.detach().to(DEV)
-    L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, G, wg.cot * 16, wg.cit * 16, cout, cin, wg.w_sco, wg.w_sci, O.ptr(coef), 3 * cpi, cpi,
+    L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, 27, G, wg.cot * 16, wg.cit * 16, cout, cin, wg.w_sco, wg.w_sci, O.ptr(coef), 3 * cpi, cpi,
            O.ptr(cls), pad[0], pad[1], pad[2], O.ptr(wd), O.ptr(dw), O.ptr(db), O.ptr(bs), nrep, cpi, O.stream())
     sw = float(w.grad.abs().max())
     torch.testing.assert_close(dw.cpu(), w.grad, rtol=2e-3, atol=2e-3 * sw)
@@ -433,3 +433,67 @@ def test_fused_cae_reconstruction_loss_equals_the_composed_one(factor, monkeypat
     assert abs(a[0] - b[0]) < 2e-6, (a[0], b[0])
     for k in (1, 2, 3):
         torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-9)
+
+
+def test_pointwise_layer_on_the_raw_input_per_group(monkeypatch):
+    """the CAE's 1x1x1 16 -> 16 layer in the batched passes: forward with each group's BatchNorm applied on the operand load (one launch,
+    statistics per group), weight gradient on the raw input with group-pure partial blocks + the group-aware folded finish"""
+    gen = torch.Generator().manual_seed(77)
+    cin = cout = 16
+    B, gb, dims = 4, 2, (4, 16, 32)
+    G = B // gb
+    x = bf(torch.randn(B, cin, *dims, generator=gen) + 0.2)
+    w = (torch.randn(cout, cin, 1, 1, 1, generator=gen) / 4).requires_grad_(True)
+    bias = (torch.randn(cout, generator=gen) * 0.1).requires_grad_(True)
+    scale, shift = torch.rand(G, cin, generator=gen) + 0.5, torch.randn(G, cin, generator=gen)
+    gidx = torch.arange(B) // gb
+    xr = x.clone().requires_grad_(True)
+    xh = xr * scale[gidx].view(B, cin, 1, 1, 1) + shift[gidx].view(B, cin, 1, 1, 1)
+    xh.retain_grad()
+    yref = F.elu(F.conv3d(xh, w, bias), 1.0)
+    dy = bf(torch.randn(yref.shape, generator=gen))
+    # ---- forward
+    op = P.conv_fwd_op(cin, cout, 1, 1, 0, dims, cin, cout, L.SP_BF16)
+    run = O.ConvRunner(op, DEV)
+    assert run.fc is not None and run.fc["pointwise"]
+    run.prep(w.detach().to(DEV), bias.detach().to(DEV))
+    coef = torch.zeros(G, 3, cin, device=DEV)
+    coef[:, 0], coef[:, 2] = scale.to(DEV), shift.to(DEV)
+    xs = _to_cl(x, cin)
+    y = O.alloc_cl(B, dims, cout, L.SP_BF16, DEV)
+    nrep = 4
+    st = torch.zeros(G * nrep * cout * 2, dtype=torch.float64, device=DEV)
+    run.run(xs, y, B, coef[:, 0], coef[:, 2], L.ACT_ELU, 1.0, st, stats_nrep=nrep, group_batch=gb, coef_gstride=3 * cin)
+    got = _from_cl(y, cout)
+    torch.testing.assert_close(got, yref.detach(), rtol=3e-2, atol=3e-2)
+    sums = st.view(G, nrep, cout, 2).sum(1).cpu()
+    for gi in range(G):
+        torch.testing.assert_close(sums[gi, :, 0], got[gi * gb:(gi + 1) * gb].double().sum(dim=(0, 2, 3, 4)), rtol=1e-4, atol=1e-2)
+    # ---- backward: dz = dy * ELU'(y) taken from torch; weight gradient on the raw input
+    yref.backward(dy)
+    dzt = bf(dy * torch.where(yref.detach() > 0, torch.ones_like(dy), yref.detach() + 1.0))
+    dzs = _to_cl(dzt, cout)
+    cls = torch.zeros(G * 1 * cout, dtype=torch.float64, device=DEV)
+    ident = torch.zeros(G, 3, cout, device=DEV)
+    ident[:, 0] = 1.0
+    dz2 = torch.empty_like(dzs)
+    O.bn_act_bwd(dzs, dzs, ident, L.SP_BF16, L.ACT_NONE, 0.0, dz2, None, cls=(gb, (0, 0, 0), cls))
+    wg = O.WgradRunner(cin, cout, 1, 1, 0, dims, dims, cin, cout, cin, 1, L.SP_BF16, DEV)
+    assert wg.pw
+    wg.groups = G
+    wg.run_raw(xs, dz2, B)
+    dw = torch.zeros(cout, cin, 1, 1, 1, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    bs = torch.zeros(G * nrep * cin * 2, dtype=torch.float64, device=DEV)
+    L.call("sp_wgrad_finish_folded_groups", O.ptr(wg.acc), wg.nparts, 1, G, wg.cot * 16, wg.cit * 16, cout, cin, wg.w_sco, wg.w_sci, O.ptr(coef), 3 * cin, cin,
+           O.ptr(cls), 0, 0, 0, O.ptr(w.detach().to(DEV)), O.ptr(dw), O.ptr(db), O.ptr(bs), nrep, cin, O.stream())
+    # reference gradients with the SAME (bf16-rounded) dz: dW = sum dz x^, dbias = sum dz
+    dw_ref = torch.einsum("bovwx,bivwx->oi", dzt.double(), xh.detach().double()).float().view(cout, cin, 1, 1, 1)
+    torch.testing.assert_close(dw.cpu(), dw_ref, rtol=3e-3, atol=3e-3 * float(dw_ref.abs().max()))
+    torch.testing.assert_close(db.cpu(), dzt.double().sum(dim=(0, 2, 3, 4)).float(), rtol=1e-4, atol=1e-3)
+    ghat = torch.einsum("bovwx,oi->bivwx", dzt.double(), w.detach().double().view(cout, cin))
+    gotb = bs.view(G, nrep, cin, 2).sum(1).cpu()
+    for gi in range(G):
+        sl = slice(gi * gb, (gi + 1) * gb)
+        torch.testing.assert_close(gotb[gi, :, 0], ghat[sl].sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2)
+        torch.testing.assert_close(gotb[gi, :, 1], (ghat[sl] * x[sl].double()).sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2)
