@@ -1,10 +1,14 @@
-"""Round-4 GPU tests of the CAE's batched passes on the z-marching kernel (csrc/sp_conv_zm.hip):
+"""Round-4 GPU tests of the CAE's batched passes (one launch per layer over all BatchNorm groups):
 
-* BatchNorm groups inside ONE launch: a workgroup's march hands its output statistics to the rows of the group its current
-  sample belongs to (``sp_conv_args.group_batch``), against per-group launches and against torch;
-* the data gradient with the BatchNorm-backward sums in its epilogue (``stats_mode = 1``: sum g and sum g*x of the stored g,
-  x = the layer input read at the same position), per group, against float64 sums of the stored tensors;
-* the whole CAE step with these paths on and off.
+* csrc/sp_conv_zm.hip: per-group output statistics inside one launch (``group_batch``); the data gradient with the
+  BatchNorm-backward sums in its epilogue (``stats_mode = 1``); the BatchNorm folded per group into a PADDED convolution
+  (per-group fragments + a bias table over the border classes: ``sp_conv_prep_folded_groups``);
+* csrc/sp_conv_par.hip: all parity classes of a transposed / strided-gradient convolution -- and strided convolutions -- in one pass;
+* csrc/sp_wgrad_dma.hip: stride-2 / 2x2x2 weight gradients on the LDS-DMA kernel; the weight gradient of the padded layers on the
+  RAW input (border-class sums of dz from ``sp_bn_act_bwd_groups_cls``, group-pure partial blocks, ``sp_wgrad_finish_folded_groups``),
+  and the same for the pointwise layer (csrc/sp_conv_fc.hip with per-group scale / shift on the operand load, csrc/sp_wgrad_pw.hip);
+* the reconstruction loss as three launches (``metrics.cae_reconstruction_loss``);
+* the whole CAE step with the grouped z-march on and off.
 """
 import math
 
