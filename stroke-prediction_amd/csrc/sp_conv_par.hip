@@ -19,7 +19,8 @@
 // 2x2x2 transposed layer 144 -> 69 us (3.6 TB/s); the five class ops of a CAE step 946 -> 470 us.  An LDS-staged variant (tile and
 // all weight fragments in one LDS-DMA burst) was 10-30 % faster on single ops and 0.1 ms SLOWER in the step, where these ops run
 // beside the weight gradients of the side stream (57 KiB of LDS per workgroup); writing the x classes as dense half rows changed
-// nothing either (the interleaved 32-byte pieces merge in L2).  Neither is kept.
+// nothing either (the interleaved 32-byte pieces merge in L2); issuing ALL loads of a class (up to 8 steps) before its first MFMA,
+// with 2 rows per wave and 4 or 8 waves, was 5-60 % slower than this one-step-ahead loop (fewer waves per CU).  None is kept.
 //
 // Epilogue as the tiled kernel's: bias, activation, 16-bit store, statistics of the stored values -- plain (sum, sum of squares:
 // the next layer's BatchNorm) or stats_mode 1 (sum g, sum g*x with x = a.aux read at the same position: the BatchNorm backward of
