@@ -501,3 +501,21 @@ def test_pointwise_layer_on_the_raw_input_per_group(monkeypatch):
         sl = slice(gi * gb, (gi + 1) * gb)
         torch.testing.assert_close(gotb[gi, :, 0], ghat[sl].sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2)
         torch.testing.assert_close(gotb[gi, :, 1], (ghat[sl] * x[sl].double()).sum(dim=(0, 2, 3, 4)), rtol=2e-3, atol=2e-2)
+
+
+def test_cae_training_trajectory_with_and_without_the_raw_input_path(monkeypatch):
+    """eight CaeReconstructionLearner.train_batch steps (bf16, batched passes, hipGraph replay) with the round-4 paths -- BatchNorm
+    folded per group into the padded layers, weight gradients on the raw input, pointwise layer on the raw input, fused loss -- and
+    with all of them off: the loss curves stay together (two bf16 pipelines of the same function) and fall"""
+    from test_gpu_round3 import _cae_step
+    ch = [1, 16, 24, 32, 100, 200, 1]
+    curves = {}
+    for on in (True, False):
+        monkeypatch.setattr(O, "FOLD_GROUPS", on)
+        monkeypatch.setattr(O, "RAW_WGRAD", on)
+        monkeypatch.setenv("SP_CAE_FUSED_LOSS", "1" if on else "0")
+        curves[on] = _cae_step(ch, 41, 28, 64, "bf16", 0, graph=True, steps=8, batched=1, warmup=2)[4]      # (two eager steps: the second sees the weights Adam changed, as every captured step will)
+    a, b = curves[True], curves[False]
+    assert len(a) == len(b) == 8
+    assert max(abs(x - y) for x, y in zip(a, b)) < 4e-3, (a, b)
+    assert a[-1] < a[0] - 0.01 and b[-1] < b[0] - 0.01, (a, b)
