@@ -133,11 +133,11 @@ class ConvLayer:
         # (still the weight gradient's operand) is written later, on the side stream of the backward
         self.fold_groups = bool(self.G > 1 and O.FOLD_GROUPS and O.ZM_GROUPS and zm_ok and self.fwd.zm is not None and bn_prefix is not None and kind == "conv"
                                 and act == L.ACT_ELU and dtype == L.SP_BF16 and (2 * pads[0] + 1) * (2 * pads[1] + 1) * (2 * pads[2] + 1) <= 75)
-        self.raw_wgrad = bool(self.fold_groups and O.RAW_WGRAD and tuple(P._triple(stride)) == (1, 1, 1) and k == 3
+        self.raw_wgrad = bool(self.fold_groups and O.RAW_WGRAD and O.WGRAD_PARTS and tuple(P._triple(stride)) == (1, 1, 1) and k == 3
                               and self.cpi % 16 == 0 and self.cpo % 16 == 0 and not os.environ.get("SP_WGRAD_ZR") == "0")
         # ... and the 1x1x1 layers (Cae3D.py:214-216): the pointwise kernel applies each group's scale / shift on its operand load
         # (exact: no padding), the weight gradient reads the raw input the same way
-        self.raw_pw = bool(self.G > 1 and O.RAW_WGRAD and O.ZM_GROUPS and bn_prefix is not None and kind == "conv" and k == 1
+        self.raw_pw = bool(self.G > 1 and O.RAW_WGRAD and O.WGRAD_PARTS and O.USE_PW_WGRAD and O.ZM_GROUPS and bn_prefix is not None and kind == "conv" and k == 1
                            and tuple(P._triple(stride)) == (1, 1, 1) and max(pads) == 0 and dtype == L.SP_BF16 and act == L.ACT_ELU
                            and self.out_dtype == dtype and self.fwd.fc is not None and self.fwd.fc["pointwise"]
                            and (self.gb * in_dims[0] * in_dims[1] * in_dims[2]) % 32 == 0)
