@@ -282,7 +282,6 @@ class ConvLayer:
                    O.ptr(params[c + ".bias"]), self._pads[0], self._pads[1], self._pads[2], O.ptr(self.gtab), self.cpo, O.stream())
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
                          stats_nrep=STATS_NREP, group_batch=self.gb, group_fold=(self.gfrag, self._gfrag_elems * 2, self.gtab, self._ncls * self.cpo))
-            self._xhat_of = None            # the normalised copy of THIS input does not exist yet (backward writes it)
             return y
         if self.G > 1 and self.raw_pw:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
