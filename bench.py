@@ -33,8 +33,8 @@ CHANNELS = [2, 16, 32, 64, 32, 16, 32, 2]
 CHANNELS4 = [2, 32, 64, 128, 256, 128, 64, 32, 32, 2]       # configs[4] with ch_bC = 32
 CAE_CHANNELS = [1, 16, 24, 32, 100, 800, 1]
 # dense MFMA peaks (MI355X_MICROARCH.md): bf16 2.5 PFLOP/s; f32 mode = 3 bf16 MFMAs per product; fp8 (MX-scaled) 5 PFLOP/s
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 2500.0 / 3.0, "fp8": 5000.0, "bf16x3": 2500.0, "f16x3": 2500.0}      # bf16x3: forward convolutions run 3 MFMAs per product (priced in its own line), backward = bf16
-DTYPES = ["bf16", "f32", "fp8", "f16", "bf16x3", "f16x3"]      # precision modes the models accept (fp8: bf16 storage + e4m3 / e5m2 MFMA operands, runtime/f8.py)
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 2500.0 / 3.0, "fp8": 5000.0, "fp8b": 5000.0, "bf16x3": 2500.0, "f16x3": 2500.0}      # bf16x3: forward convolutions run 3 MFMAs per product (priced in its own line), backward = bf16
+DTYPES = ["bf16", "f32", "fp8", "fp8b", "f16", "bf16x3", "f16x3"]      # precision modes the models accept (fp8: bf16 storage + e4m3 / e5m2 MFMA operands, runtime/f8.py)
 HBM_PEAK_GBS = 8000.0
 TRAIN_GFLOP_PER_SAMPLE_128 = 345.7                        # SURVEY.md 8d (fwd + dgrad + wgrad)
 CAE_TRAIN_GFLOP_PER_SAMPLE = {28: 305.5, 124: 1431.0}     # SURVEY.md 8d (3 enc + 4 dec passes)
@@ -749,6 +749,7 @@ def secondary_workloads(args, dev):
             ("cae_d124", dict(workload="cae", cae_depth=124, dtype="bf16"), False),
             ("unet4_bf16", dict(workload="unet4", dtype="bf16", batch=2, size=256), True),
             ("unet4_fp8", dict(workload="unet4", dtype="fp8", batch=2, size=256), True),
+            ("unet4_fp8b", dict(workload="unet4", dtype="fp8b", batch=2, size=256), False),
             ("unet_f16x3", dict(workload="unet", dtype="f16x3"), False),
             ("unet_bf16x3", dict(workload="unet", dtype="bf16x3"), False),
             ("unet_f16", dict(workload="unet", dtype="f16"), False),

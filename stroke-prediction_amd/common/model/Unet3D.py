@@ -89,7 +89,8 @@ class Unet3D(FlatParamsMixin, nn.Module):
         self.channel_dim = channel_dim
         self.channels_crop = channels_crop
         self.compute_dtype = dtype           # "bf16" (fast) | "f32" (split-bf16 x3 MFMA, parity mode) | "fp8" (bf16 storage,
-                                             # e4m3 / e5m2 MFMA operands where the fp8 kernel applies: runtime/f8.py) | "f16"
+                                             # e4m3 / e5m2 MFMA operands where the fp8 kernel applies: runtime/f8.py) | "fp8b"
+                                             # (the bf16 forward with the fp8 backward: gradient directions of the bf16 mode) | "f16"
                                              # (IEEE-half storage: libstroke_amd_f16.so, 3 more mantissa bits at the bf16 speed)
                                              # | "bf16x3" (forward on bf16 PAIRS, three MFMAs per product: logits within 1e-3 of
                                              # the fp32 reference; backward = the bf16 one on the hi halves)
@@ -127,7 +128,7 @@ class Unet3D(FlatParamsMixin, nn.Module):
             variant = _L.VARIANT_OF[self.compute_dtype]
             with _L.use(variant):
                 eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device,
-                                 f8=(self.compute_dtype == "fp8"), variant=variant, hl=(self.compute_dtype in ("bf16x3", "f16x3")))
+                                 f8=(self.compute_dtype in ("fp8", "fp8b")), f8_fwd=(self.compute_dtype == "fp8"), variant=variant, hl=(self.compute_dtype in ("bf16x3", "f16x3")))
             self._engines[key] = eng
         return eng
 

@@ -8,6 +8,9 @@ quantisation pass), weights e4m3 with a power-of-two scale per output channel, o
 with fp32 accumulation; BatchNorm statistics, bias, activations, Dice and Adam stay fp32, the stored activations every other
 kernel reads stay bf16.  The first layer (2 input channels), the classify head and the forward / data gradient of the layers with
 12 or 24 input planes run on the bf16 kernels.
+
+``Unet3D(dtype="fp8b")`` keeps the bf16 forward and runs only the backward (data and weight gradients) on these kernels: the
+direction the "fp8" mode's gradients lose against the f32 mode is the e4m3 forward's alone (tools/probes/f8_cos_knobs.sh).
 """
 import ctypes as C
 import math
@@ -22,6 +25,7 @@ from . import plan as P
 
 F8_MIN_PLANES = int(os.environ.get("SP_F8_MIN_PLANES", "128"))      # (column, plane) pairs below which the march is all prologue (measured: 128 -> 128 @46^3 169 -> 110 us, 128 -> 256 @28^3 117 -> 69 us against the bf16 tiled kernel)
 E4M3, E5M2 = 0, 1
+FWD = bool(int(os.environ.get("SP_F8_FWD", "1")))           # forward convolutions on the fp8 kernel (0: bf16 forward, fp8 backward only)
 DGRAD = bool(int(os.environ.get("SP_F8_DGRAD", "1")))       # data-gradient convolutions on the fp8 kernel too (0: forward only)
 WGRAD = bool(int(os.environ.get("SP_F8_WGRAD", "1")))       # weight gradients of the fp8 layers on fp8 operands as well (0: from the bf16 tensors)
 FUSE_SLICES = bool(int(os.environ.get("SP_F8_FUSE_SLICES", "1")))  # the output-channel slices of an op in one launch (0: one launch each)

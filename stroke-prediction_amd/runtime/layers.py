@@ -174,14 +174,15 @@ class ConvLayer:
         self.want_y8 = False
         self.f8_grad_scale = 1.0
 
-    def enable_f8(self, grad_scale):
+    def enable_f8(self, grad_scale, fwd=True):
         """fp8 MFMA operands for this layer's forward and data-gradient convolution where the fp8 z-marching kernel has an
         instance for its shape (folded BatchNorm, stride 1, 3x3x3, 32..96 input channels); returns whether the forward runs
-        in fp8.  The engine then provides ``self.x8`` (e4m3 plane-major copy of the input) before every forward."""
+        in fp8.  The engine then provides ``self.x8`` (e4m3 plane-major copy of the input) before every forward.
+        fwd=False (the "fp8b" mode): the forward stays on the bf16 kernel, data and weight gradient run in fp8."""
         from . import f8 as F8
         self.f8_on = True
         self.f8_grad_scale = float(grad_scale)
-        if (self.fold and self.kind == "conv" and self.dtype == L.SP_BF16 and self.out_dtype == L.SP_BF16 and self.bank is None
+        if (fwd and F8.FWD and self.fold and self.kind == "conv" and self.dtype == L.SP_BF16 and self.out_dtype == L.SP_BF16 and self.bank is None
                 and self.act in (L.ACT_NONE, L.ACT_LEAKY)):
             if F8.ConvRunnerF8.applicable(self.fwd_op, self.batch):
                 self.f8_fwd = F8.ConvRunnerF8(self.fwd_op, self.device, self.batch, F8.E4M3)

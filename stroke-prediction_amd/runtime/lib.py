@@ -16,15 +16,16 @@ SOURCES = ["sp_conv.hip", "sp_conv_dma.hip", "sp_conv_par.hip", "sp_conv_zm.hip"
 
 SP_BF16, SP_F32, SP_HL = 0, 1, 2      # SP_HL: bf16 pair (hi + lo tensors), the forward storage of the "bf16x3" mode
 # precision modes of the models (``Unet3D(dtype=...)``, ``Enc3D(dtype=...)``) -> storage type of the engine's tensors
-DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16, "f16": SP_BF16, "bf16x3": SP_BF16, "f16x3": SP_BF16}
-#   fp8: bf16 storage + fp8 MFMA operands (runtime/f8.py); f16: IEEE-half storage -- the SAME sources built with
+DTYPE_CODES = {"bf16": SP_BF16, "f32": SP_F32, "fp8": SP_BF16, "fp8b": SP_BF16, "f16": SP_BF16, "bf16x3": SP_BF16, "f16x3": SP_BF16}
+#   fp8: bf16 storage + fp8 MFMA operands (runtime/f8.py); fp8b: the bf16 forward with the fp8 BACKWARD (data and weight
+#   gradients on e5m2 / e4m3 operands) -- the forward, and with it the direction of the gradients, is the bf16 mode's; f16: IEEE-half storage -- the SAME sources built with
 #   -DSP_HALF_F16 into libstroke_amd_f16.so (csrc/sp_common.h), selected per engine with ``use("f16")``; the kernels'
 #   dtype code stays SP_BF16 = "the 16-bit storage type of this library";
 #   bf16x3: the FORWARD activations are bf16 pairs (hi + lo tensors, SP_HL: ~17 bits; three MFMAs per product), the backward
 #   pass is the bf16 one on the hi tensors -- logits within 1e-3 of the fp32 reference at ~1.5x the bf16 step;
 #   f16x3: the same in the IEEE-half build (pairs of halves: ~22 bits forward; the backward is the f16 mode's, 8x closer than bf16)
 VARIANTS = {"": ("libstroke_amd.so", []), "f16": ("libstroke_amd_f16.so", ["-DSP_HALF_F16"])}
-VARIANT_OF = {"bf16": "", "f32": "", "fp8": "", "f16": "f16", "bf16x3": "", "f16x3": "f16"}
+VARIANT_OF = {"bf16": "", "f32": "", "fp8": "", "fp8b": "", "f16": "f16", "bf16x3": "", "f16x3": "f16"}
 SP_REDUCE_ROWS = 8    # replica rows of the accumulators the elementwise kernels reduce into (include/stroke_amd.h)
 ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 

@@ -49,9 +49,11 @@ class UnetEngine:
     blocks S+1..2S-1 go up; up block u concatenates the upsampled output of block u-1 with the centre crop of down
     block 2S-u."""
 
-    def __init__(self, channels, batch, dims, dtype, device, f8=False, variant="", hl=False):
+    def __init__(self, channels, batch, dims, dtype, device, f8=False, variant="", hl=False, f8_fwd=True):
         """f8: the "fp8" precision mode -- storage stays bf16 (dtype), the 3x3x3 layers the fp8 kernel has an instance for
-        run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py).
+        run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py).  f8_fwd=False ("fp8b"): only the
+        backward does -- every forward convolution is the bf16 one (its epilogue, or the pooling / concatenation kernel, writes
+        the e4m3 copy the weight gradient reads), data and weight gradients run on the fp8 kernels.
         hl: the "bf16x3" precision mode -- every activation of the FORWARD pass is a bf16 pair (hi + lo tensors, ~17 bits), the
         forward convolutions run three MFMAs per product (hi*hi + hi*lo + lo*hi with hi / lo weight fragments), pooling /
         concatenation / head work on the pair values; the BACKWARD pass is the bf16 one on the hi tensors, which are exactly the
@@ -178,7 +180,7 @@ class UnetEngine:
                 c1, c2 = self.conv[i]
                 for lay in (c1, c2):
                     if not isinstance(lay, FirstConvLayer):
-                        lay.enable_f8(gs)
+                        lay.enable_f8(gs, fwd=f8_fwd)
                 if c2.f8_fwd is not None:
                     if c1.y8_capable():      # (an fp8 layer, or the bf16 z-marching first layer: its epilogue writes the copy)
                         c1.want_y8 = True

@@ -362,7 +362,7 @@ def test_unet4_fp8_mode_trains_like_the_bf16_mode():
     keep = F8.F8_MIN_PLANES
     F8.F8_MIN_PLANES = 8
     try:
-        for mode in ("bf16", "fp8"):
+        for mode in ("bf16", "fp8", "fp8b"):
             model = LargeUnet3D(CH4, dtype=mode)
             model.load_state_dict(W.make_state_dict(W.unet_spec(CH4), seed))
             model = model.to(DEV).train()
@@ -383,11 +383,66 @@ def test_unet4_fp8_mode_trains_like_the_bf16_mode():
             final[mode] = losses
     finally:
         F8.F8_MIN_PLANES = keep
-    b, f = final["bf16"], final["fp8"]
-    print("bf16", " ".join("%.3f" % v for v in b[::5]), "| fp8", " ".join("%.3f" % v for v in f[::5]))
-    assert abs(b[0] - f[0]) < 5e-3
-    assert f[-1] < 0.6 * f[0], f                         # it learns ...
-    assert abs(f[-1] - b[-1]) < 0.25 * (b[0] - b[-1]), (b[-1], f[-1])      # ... as far as the bf16 mode does, give or take a quarter of the way
+    b = final["bf16"]
+    for mode in ("fp8", "fp8b"):      # (fp8b: bf16 forward, fp8 backward)
+        f = final[mode]
+        print("bf16", " ".join("%.3f" % v for v in b[::5]), "| %s" % mode, " ".join("%.3f" % v for v in f[::5]))
+        assert abs(b[0] - f[0]) < 5e-3
+        assert f[-1] < 0.6 * f[0], f                         # it learns ...
+        assert abs(f[-1] - b[-1]) < 0.25 * (b[0] - b[-1]), (mode, b[-1], f[-1])      # ... as far as the bf16 mode does, give or take a quarter of the way
+
+
+def test_fp8b_mode_keeps_the_bf16_forward_and_the_direction_of_its_gradients():
+    """``dtype="fp8b"`` (a defensible fp8 recipe): the forward is the bf16 mode's, the data and weight
+    gradients run on the fp8 kernels.  tools/probes/f8_cos_knobs.sh showed where the fp8 mode loses the gradient's direction:
+    with the fp8 data / weight gradients switched off one by one the per-tensor cosines against the f32 mode do not move in the
+    third digit (0.19 first block .. 0.95 last) -- it is the e4m3 FORWARD (LeakyReLU branch flips under 3-mantissa-bit operand
+    noise), so per-channel activation scales cannot repair it and the backward can stay in fp8 at no cost in direction.
+    Held here, 2 x 2 x 156^3, every 3x3x3 weight tensor against the f32 mode: cosine >= 0.9 for the last three blocks and the
+    head, >= 0.8 everywhere, within 0.03 of the bf16 mode's (measured 0.844 - 1.000; bf16 0.865 - 1.000; fp8 0.19 - 0.95)."""
+    seed, size = 5, (156, 156, 156)
+    torch.manual_seed(seed)
+    x = torch.randn((2, 2) + size, device=DEV)
+    y = None
+    grads, segs = {}, {}
+    for mode in ("f32", "bf16", "fp8b"):
+        model = LargeUnet3D(CH4, dtype=mode)
+        model.load_state_dict(W.make_state_dict(W.unet_spec(CH4), seed))
+        model = model.to(DEV).train()
+        if y is None:
+            torch.manual_seed(seed + 1)
+            y = (torch.rand((2, 2) + tuple(model.output_size(size)), device=DEV) > 0.7).float()
+        dto = model(UnetDtoUtil.init_dto(x, y[:, 0:1], y[:, 1:2]))
+        seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1)
+        nets.unet_loss(seg, y).backward()
+        segs[mode] = seg.detach().clone()
+        grads[mode] = {k: p.grad.detach().double().reshape(-1).clone() for k, p in model.named_parameters()}
+        if mode == "fp8b":
+            lays = next(iter(model._engines.values())).layers
+            assert all(l.f8_fwd is None for l in lays)
+            assert sum(l.f8_dgrad is not None for l in lays) >= 8 and sum(l.f8_wgrad is not None for l in lays) >= 10, \
+                ([l.conv_prefix for l in lays if l.f8_dgrad is not None], [l.conv_prefix for l in lays if l.f8_wgrad is not None])
+        model._engines.clear()
+        del model, dto
+        torch.cuda.empty_cache()
+    # the forward: the bf16 mode's kernels, bit for bit (their epilogues write the e4m3 copies next to the same bf16 values)
+    d = float((segs["fp8b"] - segs["bf16"]).abs().max())
+    print("fp8b forward vs bf16 forward: max |d seg| %.3e" % d)
+    assert d == 0.0
+
+    def cos(a, b):
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+    rows = []
+    for k, g in grads["fp8b"].items():
+        if g.numel() > 64 and k.endswith(".weight"):
+            c8, c16 = cos(g, grads["f32"][k]), cos(grads["bf16"][k], grads["f32"][k])
+            rows.append((k.replace(".bn_conv_relu_2x", ""), round(c8, 3), round(c16, 3)))
+            assert c8 > 0.8 and c8 > c16 - 0.03, (k, c8, c16)
+            if k.startswith(("block5", "block6", "block7", "classify")):
+                assert c8 > 0.9, (k, c8)
+            r = float(g.norm() / (grads["f32"][k].norm() + 1e-30))
+            assert 0.9 < r < 1.1, (k, r)
+    print("weight-gradient cosine vs the f32 mode (fp8b, bf16):", rows)
 
 
 def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
