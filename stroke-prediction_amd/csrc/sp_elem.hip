@@ -59,7 +59,7 @@ static inline unsigned grid_for(int64_t nvox, int vpb) {
 // without; 4 replica rows already remove that (47 us).  Replicas interleaved within a line do not help.
 template <int NS>
 __device__ __forceinline__ void block_channel_reduce(const float part[NS][8], int oc, bool active, int CP,
-                                                     double* __restrict__ out, float* red) {
+                                                     double* __restrict__ out, float* red, int pitch = 0) {
   __shared__ __attribute__((aligned(16))) float s_tr[256 * 8 * NS];
   (void)oc; (void)red;
   const int n = CP * NS, OC = CP >> 3;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void block_channel_reduce(const float part[NS][8], in
     }
   }
   __syncthreads();
-  double* o = out + (size_t)(blockIdx.x % SP_REDUCE_ROWS) * n;
+  double* o = out + (size_t)(blockIdx.x % SP_REDUCE_ROWS) * (pitch ? pitch : n);      // (pitch: the columns are a slice of wider rows)
   if (n <= 256) {
     const int S = 256 / n, col = threadIdx.x % n, grp = threadIdx.x / n;
     float a0 = 0.f, a1 = 0.f;
@@ -1034,12 +1034,19 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
                                                           double* __restrict__ stats, const SpQ8 q8,
                                                           int64_t low_lo = 0, int64_t skip_lo = 0, int64_t cat_lo = 0) {
   __shared__ float red[4 * 32];
-  const int p = blockIdx.y, nup = CPu >> 4;
+  // 1-D grid of gx * np workgroups, gx a multiple of 8: workgroup id -> (chunk, plane) such that the np planes of a chunk are
+  // CONSECUTIVE workgroups of ONE XCD (ids 8 apart share an L2).  A plane takes 32 bytes of every source voxel; with the planes
+  // of a chunk far apart in time (plane = blockIdx.y) every 64-byte sector of the skip tensor and every 128-byte line of the low
+  // tensor came in once per plane.
+  const int np = CPd >> 4, nup = CPu >> 4;
+  const uint32_t gx = gridDim.x / np, t = blockIdx.x >> 3;
+  const int p = t % np;
+  const uint32_t cx = (t / np) * 8 + (blockIdx.x & 7);
   const int Do = 2 * dl.D, Ho = 2 * dl.H, Wo = 2 * dl.W;
   const int oz = (ds.D - Do) / 2, oy = (ds.H - Ho) / 2, ox = (ds.W - Wo) / 2;
   const int64_t total = (int64_t)dl.B * dl.D * dl.H * Wo * 2;
-  const int64_t chunk = ((total + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
-  const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(total, i0 + chunk);
+  const int64_t chunk = ((total + gx - 1) / gx + 255) / 256 * 256;
+  const int64_t i0 = (int64_t)cx * chunk, i1 = min(total, i0 + chunk);
   const int half = threadIdx.x & 1;                   // chunk and stride are even: a thread keeps its channel half
   const FastDiv d_w2 = make_fastdiv(Wo * 2), d_h = make_fastdiv(dl.H), d_d = make_fastdiv(dl.D);
   f2_t s1[4], s2[4];
@@ -1125,7 +1132,7 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
     }
     __syncthreads();
     if (threadIdx.x < 32)
-      atomicAdd(&stats[(size_t)(blockIdx.x % SP_REDUCE_ROWS) * CPd * 2 + (size_t)p * 32 + threadIdx.x], (double)sp_cols_sum(red, 32, 4, threadIdx.x));
+      atomicAdd(&stats[(size_t)(cx % SP_REDUCE_ROWS) * CPd * 2 + (size_t)p * 32 + threadIdx.x], (double)sp_cols_sum(red, 32, 4, threadIdx.x));
   }
 }
 
@@ -1147,9 +1154,10 @@ static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CP
   Dims dl{B, D, H, W}, ds{B, Ds, Hs, Ws};
   if (cat_plane && CPu % 16 == 0 && CPs % 16 == 0 && (int64_t)B * D * H * W * 4 < (1ll << 31) && !getenv("SP_UPCAT_BLOCKS")) {
     const int64_t total = (int64_t)B * D * H * W * 4;     // (output x, channel half) pairs over the source rows
-    const int64_t want = (total + 1023) / 1024, cap = 2048 / (CPd / 16) + 1;
-    const unsigned gx = (unsigned)(want < cap ? want : cap);
-    dim3 grid(gx, CPd / 16);
+    static const int cap_total_ = getenv("SP_UPCAT_CAP") ? atoi(getenv("SP_UPCAT_CAP")) : 8192;
+    const int64_t want = (total + 1023) / 1024, cap = cap_total_ / (CPd / 16) + 1;
+    const unsigned gx = ((unsigned)(want < cap ? want : cap) + 7) / 8 * 8;
+    dim3 grid(gx * (unsigned)(CPd / 16));
     SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && q8.plane >= (int64_t)B * D * H * W * 8 * 16 && q8.scale > 0.f), "sp_upsample2_crop_cat_fwd_q8: bf16 tensors only");
     if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0);
     else if (dtype == SP_HL) hipLaunchKernelGGL(upcat_rows_kernel<sp_hl_t>, grid, dim3(256), 0, ST(stream), (const sp_hl_t*)low, dl, CPu, (const sp_hl_t*)skip, ds, CPs, (sp_hl_t*)cat, CPd, cat_plane, stats, q8, hl_lo[0], hl_lo[1], hl_lo[2]);
@@ -1590,8 +1598,12 @@ template <int OCT, int ACT>
 __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_t* __restrict__ y, const bf16_t* __restrict__ g,
                                                                       const float* __restrict__ coef, int CPcat, int cstride,
                                                                       Dims di, int nby, int nbx, int act, float ap,
-                                                                      bf16_t* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8) {
+                                                                      bf16_t* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8,
+                                                                      int CPy) {
+  // CPy: channel pitch of y / dz (and width of the coefficient rows); blockIdx.y = group of CP channels of it (128 / 256-channel
+  // tensors run as 2 / 4 groups of 64: the tile of a wider group would not fit the ring)
   constexpr int CP = OCT * 8, TX = 16, TY = 256 / (16 * OCT), RY = 2 * TY + 2, RX = 2 * TX + 2;
+  const int cg0 = blockIdx.y * CP;
   constexpr int NCH = RY * RX * OCT, NJ = (NCH + 255) / 256, PSB = NJ * 4096;          // plane slot
   constexpr int NYC = (TY + 2) * (TX + 2) * OCT, NJY = (NYC + 255) / 256, YSB = NJY * 4096;
   constexpr int NS = 4, DP = 3;
@@ -1606,11 +1618,11 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
   float c0[8], c1[8], c2[8], part[1][8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int c = oc * 8 + j;
+    const int c = cg0 + oc * 8 + j;
     c0[j] = coef[c]; c1[j] = coef[cstride + c]; c2[j] = 8.f * coef[2 * cstride + c];
     part[0][j] = 0.f;
   }
-  const int64_t gplane_b = (int64_t)Ho * Wo * CPcat * 2, yplane_b = (int64_t)H * W * CP * 2;
+  const int64_t gplane_b = (int64_t)Ho * Wo * CPcat * 2, yplane_b = (int64_t)H * W * CPy * 2;
   const uint32_t ncols = (uint32_t)di.B * nby * nbx;
   const uint64_t T = (uint64_t)ncols * D;
   uint64_t wpos = T * blockIdx.x / gridDim.x;
@@ -1638,7 +1650,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
       c = c < NCH ? c : NCH - 1;
       const int vi = c / OCT, o_ = c - vi * OCT, vy = vi / RX, vx = vi - vy * RX;
       const int gy = min(max(2 * y0 - 1 + vy, 0), Ho - 1), gx = min(max(2 * x0 - 1 + vx, 0), Wo - 1);
-      relp[j] = (uint32_t)(((gy * Wo + gx) * CPcat + o_ * 8) * 2);
+      relp[j] = (uint32_t)(((gy * Wo + gx) * CPcat + cg0 + o_ * 8) * 2);
     }
 #pragma unroll
     for (int j = 0; j < NJY; ++j) {
@@ -1646,7 +1658,7 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
       c = c < NYC ? c : NYC - 1;
       const int vi = c / OCT, o_ = c - vi * OCT, vy = vi / (TX + 2), vx = vi - vy * (TX + 2);
       const int sy = min(max(y0 - 1 + vy, 0), H - 1), sx = min(max(x0 - 1 + vx, 0), W - 1);
-      rely[j] = (uint32_t)(((sy * W + sx) * CP + o_ * 8) * 2);
+      rely[j] = (uint32_t)(((sy * W + sx) * CPy + cg0 + o_ * 8) * 2);
     }
     const unsigned char* gb_ = reinterpret_cast<const unsigned char*>(g) + (int64_t)b * Do * gplane_b;
     const unsigned char* yb_ = reinterpret_cast<const unsigned char*>(y) + (int64_t)b * D * yplane_b;
@@ -1766,8 +1778,8 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
 #pragma unroll
           for (int j = 0; j < 8; ++j) part[0][j] += o8[j];
           const size_t vo_ = (((size_t)b * D + m) * H + yy) * W + xx;
-          if (dz) Store<bf16_t>::st8(dz + vo_ * CP + oc * 8, o8);
-          if (q8.p) sp_q8_store8(q8, (int64_t)vo_, oc, o8);
+          if (dz) Store<bf16_t>::st8(dz + vo_ * CPy + cg0 + oc * 8, o8);
+          if (q8.p) sp_q8_store8(q8, (int64_t)vo_, blockIdx.y * OCT + oc, o8);
         }
       }
 #pragma unroll
@@ -1778,23 +1790,25 @@ __global__ __launch_bounds__(256) void upsample2_act_bwd_ring_kernel(const bf16_
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (dbias) block_channel_reduce<1>(part, oc, true, CP, dbias, red);
+  if (dbias) block_channel_reduce<1>(part, oc, true, CP, dbias + cg0, red, CPy);
 }
 
 template <int OCT>
 static int launch_up_bwd_ring(const void* y, const void* g, const float* coef, int CPcat, int cstride, Dims di, int act, float ap,
-                              void* dz, double* dbias, SpQ8 q8, hipStream_t st) {
+                              void* dz, double* dbias, SpQ8 q8, hipStream_t st, int groups = 1) {
   constexpr int TY = 256 / (16 * OCT), NJ = ((2 * TY + 2) * 34 * OCT + 255) / 256, NJY = ((TY + 2) * 18 * OCT + 255) / 256;
   const int lds = 4 * NJ * 4096 + 2 * NJY * 4096;
   const int nby = (di.H + TY - 1) / TY, nbx = (di.W + 15) / 16;
   const int64_t T = (int64_t)di.B * nby * nbx * di.D;
-  const unsigned grid = (unsigned)(T < 256 ? T : 256);
+  const int per = 256 / groups;                       // one workgroup per CU over all channel groups
+  const dim3 grid((unsigned)(T < per ? T : per), (unsigned)groups);
+  const int CPy = OCT * 8 * groups;
 #define SP_L(A_)                                                                                                       \
   {                                                                                                                    \
     auto kern = upsample2_act_bwd_ring_kernel<OCT, A_>;                                                                \
     SP_ENSURE_LDS(kern, lds, "sp_upsample2_act_bwd");                                                                  \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, cstride, di, nby, nbx, \
-                       act, ap, (bf16_t*)dz, dbias, q8);                                                               \
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, (const bf16_t*)y, (const bf16_t*)g, coef, CPcat, cstride, di, nby, nbx, \
+                       act, ap, (bf16_t*)dz, dbias, q8, CPy);                                                          \
   }
   SP_ACT_DISPATCH(act, SP_L)
 #undef SP_L
@@ -1812,11 +1826,17 @@ static int upsample2_act_bwd_impl(const void* y, const void* cat, const void* g,
   SP_CHECK_VOX((int64_t)B * D * H * W * 8, "sp_upsample2_act_bwd");
   OctMap om = make_octmap(CP);
   Dims di{B, D, H, W};
-  if (dtype == SP_BF16 && (CP == 16 || CP == 32 || CP == 64) && D >= 2 && H >= 2 && W >= 2 && (int64_t)4 * H * W * CPcat * 2 < (1ll << 31) &&
-      !getenv("SP_UPSAMPLE_BWD_TILED") && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
+  static const bool ring_groups_ = !getenv("SP_UPSAMPLE_BWD_NO_GROUPS");      // (A/B knob: 128 / 256 channels on the tiled kernel)
+  if (dtype == SP_BF16 && (CP == 16 || CP == 32 || CP == 64 || (ring_groups_ && (CP == 128 || CP == 256))) && D >= 2 && H >= 2 && W >= 2 &&
+      (int64_t)4 * H * W * CPcat * 2 < (1ll << 31) && !getenv("SP_UPSAMPLE_BWD_TILED") && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
     if (CP == 16) return launch_up_bwd_ring<2>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream));
     if (CP == 32) return launch_up_bwd_ring<4>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream));
-    return launch_up_bwd_ring<8>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream));
+    // 64 channels as two groups of 32: the 4-row tile of the 32-channel instance has less halo (1.33x against 1.59x), and the
+    // two groups of a position run side by side on one XCD (workgroup ids 128 apart), sharing the lines they both touch
+    // (64 -> 32 @84^3 + 168^3: 596 -> 559 us; fp8 4-scale step 19.8 -> 19.6 ms)
+    static const bool split64_ = getenv("SP_UPBWD_NO_SPLIT64") == nullptr;
+    if (split64_ && CP == 64) return launch_up_bwd_ring<4>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream), 2);
+    return launch_up_bwd_ring<8>(y, g, coef, CPcat, coef_stride, di, act, act_param, dz, dbias_sums, q8, ST(stream), CP / 64);
   }
   if (256 % om.OC == 0 && D >= 2 && H >= 2 && W >= 2 && !getenv("SP_UPSAMPLE_BWD_GATHER")) {
     // tiled path: TY x TX input columns per workgroup, z split into chunks so that ~3 workgroups per CU exist

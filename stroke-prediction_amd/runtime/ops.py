@@ -761,6 +761,13 @@ def prep_batch(pairs):
                  tuple((0 if sub.get("ktab_zr") is None else sub["hi_zr"].data_ptr()) for sub in r.subs)
                  for r, w, b, _ in todo)
     tab = _prep_tables.get(tkey)
+    if tab is None and torch.cuda.is_current_stream_capturing():
+        # a set of runners no eager step has re-packed together (a runner whose packing was settled by the previous backward):
+        # building the table is a host-to-device copy, which a capture refuses -- the per-runner launches take every address
+        # as a kernel argument and are captured as they are
+        for r, w, b, _ in todo:
+            r.prep(w, b)
+        return
     if tab is None:
         if len(_prep_tables) > 64:
             _prep_tables.clear()

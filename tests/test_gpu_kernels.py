@@ -529,9 +529,10 @@ def test_bn_bwd_sums_from_wgrad():
 
 
 @pytest.mark.parametrize("dtype", [L.SP_F32, L.SP_BF16])
-@pytest.mark.parametrize("C0,ldims", [(32, (9, 7, 21)), (64, (5, 6, 9)), (16, (3, 17, 18))])
+@pytest.mark.parametrize("C0,ldims", [(32, (9, 7, 21)), (64, (5, 6, 9)), (16, (3, 17, 18)), (128, (6, 5, 19)), (256, (4, 3, 17))])
 def test_upsample2_act_bwd_tiled(dtype, C0, ldims):
-    """sp_upsample2_act_bwd (tiled z-marching kernel; several patches, z chunks and ragged edges) against autograd of
+    """sp_upsample2_act_bwd (tiled z-marching kernel; several patches, z chunks and ragged edges; bf16: the LDS-DMA ring
+    kernel, 128 / 256 channels as 2 / 4 groups of 64) against autograd of
     F.interpolate(trilinear x2) composed with the BatchNorm-backward affine form (Unet3D.py:67-72 backward)."""
     g = torch.Generator().manual_seed(21)
     B, C1 = 2, 16

@@ -305,7 +305,12 @@ def test_f16_mode_train_step_matches_the_oracle_and_the_fixture():
         rel = float((a - b).norm() / (b.norm() + 1e-30))
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         small = b.numel() <= 64
-        if rel > (0.5 if small else 0.12) or cos < (0.9 if small else 0.99):
+        # the bound is the spread of this quantity, not its value for one seed: at 4 x 4 x 4 outputs the parameter gradients are
+        # sums with heavy cancellation and a last-bit change of one BatchNorm statistic redraws the f16 rounding noise of
+        # everything behind it.  Measured over seeds 11..16 (tools/probes/f16_rel.py), first-layer weight (the worst tensor):
+        # 0.113 0.148 0.111 0.110 0.086 0.179 -- and 0.140 0.150 0.111 0.114 0.085 0.182 after the concatenation kernel's
+        # workgroups were re-ordered (another grouping of the same fp32 partial sums); classify.0: 0.006 .. 0.065.
+        if rel > (0.5 if small else 0.25) or cos < (0.9 if small else 0.97):
             bad.append((k, rel, cos))
     assert not bad, bad
 
