@@ -1,12 +1,12 @@
-# serial (SP_OVERLAP=0) kernel durations of the fp8 4-scale step next to the HBM traffic of every kernel (separate --pmc passes)
+# usage: serial_traffic.sh [dtype [workload]] -- serial (SP_OVERLAP=0) kernel durations of a training step next to the HBM traffic of every kernel (separate --pmc passes)
 set -o pipefail
 export TMPDIR=/tmp
-DT=${1:-fp8}
+DT=${1:-fp8}; WL=${2:-unet4}
 OUT=gpurun_out/prof_fp8serial; rm -rf $OUT; mkdir -p $OUT
-SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/s -o s -- python bench.py --workload unet4 --dtype $DT --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-secondary > $OUT/s.log 2>&1 &&
+SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/s -o s -- python bench.py --workload $WL --dtype $DT --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-secondary > $OUT/s.log 2>&1 &&
 python tools/rocpd_sequence.py $(find $OUT/s -name "*.db" | head -1) > gpurun_out/${DT}_serial_sequence.txt &&
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o f -- python bench.py --workload unet4 --dtype $DT --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-secondary > $OUT/f.log 2>&1 &&
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -o w -- python bench.py --workload unet4 --dtype $DT --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-secondary > $OUT/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/f -o f -- python bench.py --workload $WL --dtype $DT --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-secondary > $OUT/f.log 2>&1 &&
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/w -o w -- python bench.py --workload $WL --dtype $DT --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing --no-secondary > $OUT/w.log 2>&1
 python - $OUT $DT <<'PY'
 import csv, glob, sys, collections
 out, dt = sys.argv[1], sys.argv[2]
@@ -36,11 +36,11 @@ for (k, fv), (_, wv) in zip(f, w):
     d = dq[k].popleft() if dq[k] else float("nan")
     fb, wb = 2 * fv / 1024, wv / 1024          # KB -> MB; gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md)
     t = tot[k]; t[0] += 1; t[1] += d; t[2] += fb; t[3] += wb
-    if d == d and d > 100:
-        print("%-84s %9.1f %10.1f %10.1f %8.2f" % (k[:84], d, fb, wb, (fb + wb) / d / 1e0 * 1e-3 * 1e3 / 1e3))
+    if d == d and d > float(__import__("os").environ.get("MIN_US", "100")):
+        print("%-84s %9.1f %10.1f %10.1f %8.2f" % (k[:84], d, fb, wb, (fb + wb) / d))
 print()
 print("%-84s %4s %9s %10s %10s %8s" % ("kernel (sum over the step)", "n", "us", "fetch MB", "write MB", "TB/s"))
 for k, t in sorted(tot.items(), key=lambda kv: -kv[1][1])[:40]:
-    print("%-84s %4d %9.1f %10.1f %10.1f %8.2f" % (k[:84], t[0], t[1], t[2], t[3], (t[2] + t[3]) / max(t[1], 1e-9) / 1e3))
+    print("%-84s %4d %9.1f %10.1f %10.1f %8.2f" % (k[:84], t[0], t[1], t[2], t[3], (t[2] + t[3]) / max(t[1], 1e-9)))
 PY
 rm -rf $OUT

@@ -21,6 +21,7 @@ if [ "$WL" = unet ]; then
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $OUT/q1 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q1.log 2>&1
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/q2 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q2.log 2>&1
   python tools/pmc_sq.py $(csvf $OUT/q1) $(csvf $OUT/q2) > gpurun_out/${TAG}_mfma_busy.txt
+  MIN_US=20 bash tools/probes/serial_traffic.sh bf16 unet > gpurun_out/${TAG}_bench_serial_traffic.txt 2>&1      # every kernel of the step: serial duration next to its HBM bytes
 elif [ "$WL" = x3 ]; then
   for DT in f16x3 bf16x3; do
     SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/$DT -o s -- python bench.py --dtype $DT --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/$DT.log 2>&1 && \
@@ -32,6 +33,8 @@ elif [ "$WL" = unet4fp8 ]; then
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_unet4_fp8_kernel_stats.csv > gpurun_out/${TAG}_unet4_fp8_kernel_stats.txt
   python tools/rocpd_sequence.py $(db $OUT/g) > gpurun_out/${TAG}_unet4_fp8_step_sequence.txt      # ordered kernels of the last step
   python bench.py --workload unet4 --dtype fp8 --steps 5 --warmup 2 --no-secondary --no-cpu-baseline --layers 2>&1 | grep -E "conv_igemm|conv_wgrad|quantize|partial" > gpurun_out/${TAG}_unet4_fp8_layers.txt
+  bash tools/probes/serial_traffic.sh fp8 unet4 > gpurun_out/${TAG}_unet4_fp8_serial_traffic.txt 2>&1
+  python tools/probes/finish_probe.py > gpurun_out/${TAG}_unet4_fp8_finish_isolated.txt 2>&1
 else
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload cae --steps 5 --warmup 2 --no-cpu-baseline > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_cae_kernel_stats.csv > gpurun_out/${TAG}_cae_kernel_stats.txt
