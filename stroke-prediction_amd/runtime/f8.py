@@ -60,6 +60,10 @@ def prep_many(jobs):
                  tuple((s["wfrag"].data_ptr(), s["kmap_d"].data_ptr(), s["c0"], s["cn"], s["nsteps"], s["NT"]) for s in r.slices)
                  for r, w, b, fs, fsh, osc, _ in todo)
     tab = _tables.get(tkey)
+    if tab is None and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("fp8 weight re-pack: this set of layers has not been re-packed together in an eager step, and its address "
+                           "table is a host-to-device copy that a graph capture refuses -- run one more eager step before "
+                           "capturing (Learner.GRAPH_WARMUP)")
     if tab is None:
         if len(_tables) > 256:
             _tables.clear()

@@ -135,3 +135,17 @@ def test_product_model_refuses_cpu():
     model = Unet3D(CH)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(UnetDtoUtil.init_dto(torch.zeros(2, 2, 44, 44, 44)))
+
+
+def test_precision_modes_are_one_list():
+    """every precision mode the bench offers is one the models accept (and the other way round), each with a library variant;
+    an unknown mode is refused by name before anything touches the GPU"""
+    import importlib.util
+    from stroke_prediction_amd.runtime import lib as L
+    spec = importlib.util.spec_from_file_location("_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert set(bench.DTYPES) == set(L.DTYPE_CODES) == set(L.VARIANT_OF) == set(bench.PEAK_TFLOPS)
+    assert {"fp8", "fp8b", "bf16x3", "f16x3"} <= set(L.DTYPE_CODES)
+    assert all(v in L.VARIANTS for v in L.VARIANT_OF.values())
+    assert Unet3D(CH, dtype="fp8b").compute_dtype == "fp8b"
