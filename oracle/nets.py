@@ -78,25 +78,31 @@ class _F8Conv(torch.autograd.Function):
     (csrc/sp_wgrad_f8.hip) -- through the folded weights this is also where the BatchNorm-backward sums of x come from."""
 
     @staticmethod
-    def forward(ctx, x, wf, bf, grad_scale, wgrad8=False):
-        wq = quant_weights_e4m3(wf)
+    def forward(ctx, x, wf, bf, grad_scale, wgrad8=False, fwd8=True, dgrad8=True, q=None):
+        """fwd8 / dgrad8 False: that convolution stays the 16-bit one (q = the storage rounding of its weights) -- the "fp8b"
+        mode keeps the bf16 forward and runs the data and weight gradients in fp8"""
         ctx.save_for_backward(x, wf)
         ctx.S = grad_scale
-        ctx.wgrad8 = bool(wgrad8)
-        return F.conv3d(round_e4m3(x), wq, bf)
+        ctx.wgrad8, ctx.dgrad8, ctx.q = bool(wgrad8), bool(dgrad8), q
+        if fwd8:
+            return F.conv3d(round_e4m3(x), quant_weights_e4m3(wf), bf)
+        return F.conv3d(x, q(wf) if q is not None else wf, bf)
 
     @staticmethod
     def backward(ctx, g):
         x, wf = ctx.saved_tensors
         gq = round_e5m2(g * ctx.S) / ctx.S
-        # the data gradient packs the weights with one scale per INPUT channel of the convolution (its output channels)
-        wq = quant_weights_e4m3(wf.transpose(0, 1).contiguous()).transpose(0, 1).contiguous()
-        gx = torch.nn.grad.conv3d_input(x.shape, wq, gq)
-        if ctx.wgrad8:
-            gw = torch.nn.grad.conv3d_weight(round_e4m3(x), wq.shape, gq)
+        if ctx.dgrad8:
+            # the data gradient packs the weights with one scale per INPUT channel of the convolution (its output channels)
+            wq = quant_weights_e4m3(wf.transpose(0, 1).contiguous()).transpose(0, 1).contiguous()
+            gx = torch.nn.grad.conv3d_input(x.shape, wq, gq)
         else:
-            gw = torch.nn.grad.conv3d_weight(x, wq.shape, g)
-        return gx, gw, g.sum(dim=(0, 2, 3, 4)), None, None
+            gx = torch.nn.grad.conv3d_input(x.shape, ctx.q(wf) if ctx.q is not None else wf, g)
+        if ctx.wgrad8:
+            gw = torch.nn.grad.conv3d_weight(round_e4m3(x), wf.shape, gq)
+        else:
+            gw = torch.nn.grad.conv3d_weight(x, wf.shape, g)
+        return gx, gw, g.sum(dim=(0, 2, 3, 4)), None, None, None, None, None
 
 
 def f8_grad_scale(n_out_voxels):
@@ -143,6 +149,9 @@ def _bn_folded_conv(sd, bn_p, cv_p, x, training, q, f8=None):
     bf = b + (w * shift.view(1, -1, 1, 1, 1)).sum(dim=(1, 2, 3, 4))
     if f8 is not None and cv_p in f8["layers"]:
         return _F8Conv.apply(x, w * scale.view(1, -1, 1, 1, 1), bf, f8["grad_scale"], cv_p in f8.get("wgrad", ()))
+    if f8 is not None and (cv_p in f8.get("dgrad", ()) or cv_p in f8.get("wgrad", ())):      # "fp8b": fp8 backward only
+        return _F8Conv.apply(x, w * scale.view(1, -1, 1, 1, 1), bf, f8["grad_scale"], cv_p in f8.get("wgrad", ()), False,
+                             cv_p in f8.get("dgrad", ()), q)
     wf = q(w * scale.view(1, -1, 1, 1, 1))
     return F.conv3d(x, wf, bf)
 
@@ -171,7 +180,9 @@ def unet_forward(sd, x, training=True, return_all=False, q=_ident, f8=None):
     """``Unet3D.forward`` Unet3D.py:56-79 (three scales) and ``LargeUnet3D.forward`` Unet3D.py:118-146 (four): the number
     of scales S follows from the block count of the state dict (2S - 1 blocks).  Returns sigmoid probs (B,2,...).
     ``q=round_bf16`` emulates the bf16 storage points of the HIP fast path (see ``unet_block``); ``f8=dict(layers={conv
-    prefixes}, grad_scale=S)`` additionally runs those convolutions with fp8 operands (``_F8Conv``; needs q=round_bf16)."""
+    prefixes}, grad_scale=S)`` additionally runs those convolutions with fp8 operands (``_F8Conv``; needs q=round_bf16); the keys
+    ``dgrad`` / ``wgrad`` name the layers whose data / weight gradient alone runs on fp8 operands (the "fp8b" mode: ``layers``
+    empty, the forward stays the bf16 one)."""
     nblocks = len({k.split(".")[0] for k in sd if k.startswith("block")})
     S = (nblocks + 1) // 2
     outs = {}
