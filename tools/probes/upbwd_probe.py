@@ -10,13 +10,15 @@ import stroke_prediction_amd  # noqa: F401,E402
 from stroke_prediction_amd.runtime import lib as L, ops as O, f8 as F8  # noqa: E402
 
 DEV = "cuda"
-SHAPES = [(256, 24, 128), (128, 44, 64), (64, 84, 32)]      # (low channels, low extent, skip channels)
+SHAPES = [(256, 24, 128), (128, 44, 64), (64, 84, 32), (64, 84, 0)]      # (low channels, low extent, skip channels; 0: a DENSE gradient tensor); B = 2
+if len(sys.argv) > 1 and sys.argv[1] == "headline":          # the 3-scale step at 4 x 2 x 128^3, and the same with a DENSE gradient tensor
+    SHAPES = [(32, 46, 16), (32, 46, 0), (64, 23, 32), (64, 23, 0)]
 
 
 def main():
     torch.manual_seed(0)
     for cu, d, cs in SHAPES:
-        B = 2
+        B = 4 if len(sys.argv) > 1 and sys.argv[1] == "headline" else 2
         y = torch.randn(B, d, d, d, cu, device=DEV).bfloat16()
         g = (torch.randn(B, 2 * d, 2 * d, 2 * d, cu + cs, device=DEV) * 1e-6).bfloat16()
         coef = torch.randn(3, cu + cs, device=DEV) * 0.5
