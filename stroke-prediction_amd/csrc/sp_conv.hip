@@ -462,7 +462,7 @@ static int conv_check_build(const sp_conv_args* a, ConvDev& P) {
   SP_CHECK_ARG(a->NTtot % a->NT == 0, "sp_conv3d_igemm: NTtot %d not a multiple of NT %d", a->NTtot, a->NT);
   SP_CHECK_ARG(a->ngroups * a->octs_per_group * 8 == a->CPi, "sp_conv3d_igemm: groups (%d x %d octets) do not cover CPi=%d", a->ngroups, a->octs_per_group, a->CPi);
   SP_CHECK_ARG(a->dtype_in == SP_BF16 || (a->wfrag_lo && a->lo_offset > 0), "sp_conv3d_igemm: f32 / bf16-pair mode needs wfrag_lo and lo_offset");
-  SP_CHECK_ARG(a->dtype_in != SP_HL || (a->x_lo_delta != 0 && a->x_lo_delta % 16 == 0 && !a->dma), "sp_conv3d_igemm: bf16 pair input needs x_lo_delta (register-staged kernel)");
+  SP_CHECK_ARG(a->dtype_in != SP_HL || (a->x_lo_delta != 0 && a->x_lo_delta % 16 == 0), "sp_conv3d_igemm: bf16 pair input needs x_lo_delta");
   SP_CHECK_ARG(a->dtype_out != SP_HL || (a->y_lo_delta != 0 && a->y_lo_delta % 8 == 0), "sp_conv3d_igemm: bf16 pair output needs y_lo_delta");
   SP_CHECK_ARG(a->Do > 0 && a->Ho > 0 && a->Wo > 0 && a->B > 0, "sp_conv3d_igemm: empty output");
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_igemm: stats_nrep must be a power of two");

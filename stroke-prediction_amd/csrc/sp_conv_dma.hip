@@ -45,8 +45,12 @@ extern __device__ unsigned long long sp_stamp_buf[32768][SP_NSTAMP];
 // KS > 0: compile-time number of K steps per group, all weight fragments of the group resident in registers
 // (no guards inside the unrolled loop: guards make hipcc shuttle the accumulators between VGPRs and AGPRs
 // around every step).  KS == 0: run-time step count (even, the planner pads), fragments prefetched one step ahead.
-template <int NT, int MT, int KS, typename TOUT>
+// HL (bf16 pairs, the forward of the "bf16x3" / "f16x3" modes; run-time K loop only): the hi and the lo tile are staged side by
+// side (a.lo_offset behind each other, the lo halves of x a.x_lo_delta bytes behind the hi ones), hi and lo weight fragments
+// stream together, a product is three MFMAs (w_hi x_hi + w_hi x_lo + w_lo x_hi) into one accumulator, the output is split again.
+template <int NT, int MT, int KS, typename TOUT, bool HL = false>
 __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm_dma_kernel(const ConvDmaDev P) {
+  static_assert(!HL || KS == 0, "bf16 pairs: run-time K loop only");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = P.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
                                         : xin + goff + (cx * a.CPi + (oct0 + (ch & opp_mask)) * 8);
 #ifndef SP_NO_DMA
           sp_dma16(src, tile + (lo & 0xffffff));
+          if constexpr (HL) sp_dma16(reinterpret_cast<const unsigned char*>(src) + a.x_lo_delta, tile + a.lo_offset + (lo & 0xffffff));
 #endif
         }
       }
@@ -131,8 +136,10 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
     const size_t gstep0 = (size_t)grp * a.steps_per_group;
     const size_t fstride = (size_t)a.NTtot * 64;
     const bf16x8* wp = wf_hi + (gstep0 * a.NTtot + nt0) * 64 + lane;
+    const bf16x8* wpl = HL ? reinterpret_cast<const bf16x8*>(a.wfrag_lo) + (gstep0 * a.NTtot + nt0) * 64 + lane : nullptr;
     bf16x8 wreg[KS > 0 ? KS : 1][NT];
     bf16x8 wa0[NT], wa1[NT];
+    bf16x8 wl0[HL ? NT : 1], wl1[HL ? NT : 1], wl2[HL ? NT : 1], wl3[HL ? NT : 1];
     if (KS > 0) {
 #pragma unroll
       for (int s = 0; s < KS; ++s)
@@ -141,6 +148,10 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
     } else {
 #pragma unroll
       for (int n = 0; n < NT; ++n) wa0[n] = wp[(size_t)n * 64];
+      if constexpr (HL) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) wl0[n] = wpl[(size_t)n * 64];
+      }
     }
     if (grp == 0) STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -159,8 +170,10 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
           const uint32_t vz = fdiv(row, P.d_ith);
           const int vy = row - vz * a.ITH;
           const int gz = iz0 + (int)vz, gy = iy0 + vy, gx = ix0 + vx;
-          if (!((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi))
+          if (!((unsigned)gz < (unsigned)a.Di && (unsigned)gy < (unsigned)a.Hi && (unsigned)gx < (unsigned)a.Wi)) {
             *reinterpret_cast<uint4*>(tile + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
+            if constexpr (HL) *reinterpret_cast<uint4*>(tile + a.lo_offset + (size_t)i * 16) = make_uint4(0, 0, 0, 0);
+          }
         }
       }
       __syncthreads();
@@ -169,14 +182,27 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
     // ---- K loop: the activation fragments of step s+1 are read from LDS while step s runs on the MFMA pipe;
     // static ping-pong buffers (no register copies)
     bf16x8 x0[MT], x1[MT];
+    bf16x8 xl0[HL ? MT : 1], xl1[HL ? MT : 1];
 #define SP_LDX(dst, koff_)                                                                            \
   _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(tile + vbase[m] + (koff_));
+#define SP_LDXL(dst, koff_)                                                                           \
+  if constexpr (HL) { _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(tile + a.lo_offset + vbase[m] + (koff_)); }
 #define SP_MMA(wv, xv)                                                                                \
   _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                      \
       _Pragma("unroll") for (int n = 0; n < NT; ++n) acc[n][m] = SP_MFMA16(wv[n], xv[m], acc[n][m], 0, 0, 0);
+    // the two cross terms of a pair product (the hi x hi term is SP_MMA)
+#define SP_MMAL(wv, wlv, xv, xlv)                                                                     \
+  if constexpr (HL) {                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                    \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                              \
+          acc[n][m] = SP_MFMA16(wv[n], xlv[m], acc[n][m], 0, 0, 0);                                   \
+          acc[n][m] = SP_MFMA16(wlv[n], xv[m], acc[n][m], 0, 0, 0);                                   \
+        }                                                                                             \
+  }
     {
       const int k0 = ktab_l[lg];
       SP_LDX(x0, k0)
+      SP_LDXL(xl0, k0)
     }
     if (KS > 0) {
 #pragma unroll
@@ -193,31 +219,38 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
       // sets); the activation fragments come from LDS one step ahead as before.  steps_per_group is even (host plan).
       const int nst = a.steps_per_group;
       bf16x8 wa2[NT], wa3[NT];
-#define SP_LDW(dst, step_)                                                                            \
+#define SP_LDW(dst, dstl, step_)                                                                      \
   { const int st_ = (step_) < nst ? (step_) : nst - 1;                                                \
-    _Pragma("unroll") for (int n = 0; n < NT; ++n) dst[n] = wp[(size_t)st_ * fstride + (size_t)n * 64]; }
-      SP_LDW(wa1, 1)
-      SP_LDW(wa2, 2)
+    _Pragma("unroll") for (int n = 0; n < NT; ++n) dst[n] = wp[(size_t)st_ * fstride + (size_t)n * 64]; \
+    if constexpr (HL) { _Pragma("unroll") for (int n = 0; n < NT; ++n) dstl[n] = wpl[(size_t)st_ * fstride + (size_t)n * 64]; } }
+      SP_LDW(wa1, wl1, 1)
+      SP_LDW(wa2, wl2, 2)
       for (int s = 0; s < nst; s += 4) {
-        SP_LDW(wa3, s + 3)
-        { const int kn = ktab_l[(s + 1) * 4 + lg]; SP_LDX(x1, kn) }
+        SP_LDW(wa3, wl3, s + 3)
+        { const int kn = ktab_l[(s + 1) * 4 + lg]; SP_LDX(x1, kn) SP_LDXL(xl1, kn) }
         SP_MMA(wa0, x0)
-        SP_LDW(wa0, s + 4)
-        if (s + 2 < nst) { const int kn = ktab_l[(s + 2) * 4 + lg]; SP_LDX(x0, kn) }
+        SP_MMAL(wa0, wl0, x0, xl0)
+        SP_LDW(wa0, wl0, s + 4)
+        if (s + 2 < nst) { const int kn = ktab_l[(s + 2) * 4 + lg]; SP_LDX(x0, kn) SP_LDXL(xl0, kn) }
         SP_MMA(wa1, x1)
+        SP_MMAL(wa1, wl1, x1, xl1)
         if (s + 2 < nst) {
-          SP_LDW(wa1, s + 5)
-          { const int kn = ktab_l[(s + 3) * 4 + lg]; SP_LDX(x1, kn) }
+          SP_LDW(wa1, wl1, s + 5)
+          { const int kn = ktab_l[(s + 3) * 4 + lg]; SP_LDX(x1, kn) SP_LDXL(xl1, kn) }
           SP_MMA(wa2, x0)
-          SP_LDW(wa2, s + 6)
-          if (s + 4 < nst) { const int kn = ktab_l[(s + 4) * 4 + lg]; SP_LDX(x0, kn) }
+          SP_MMAL(wa2, wl2, x0, xl0)
+          SP_LDW(wa2, wl2, s + 6)
+          if (s + 4 < nst) { const int kn = ktab_l[(s + 4) * 4 + lg]; SP_LDX(x0, kn) SP_LDXL(xl0, kn) }
           SP_MMA(wa3, x1)
+          SP_MMAL(wa3, wl3, x1, xl1)
         }
       }
 #undef SP_LDW
     }
 #undef SP_LDX
+#undef SP_LDXL
 #undef SP_MMA
+#undef SP_MMAL
   }
 
   STAMP(3);
@@ -264,15 +297,16 @@ __global__ __launch_bounds__(256, ((NT == 1 && KS > 0) ? 4 : 1)) void conv_igemm
 #ifdef SP_NO_STORE
         if (v[0] == 123456.f)
 #endif
-        Store<TOUT>::st4(yout + (size_t)obase[m] + c0, v);
+        if constexpr (HL) sp_hl_st4(yout + (size_t)obase[m] + c0, a.y_lo_delta, v);
+        else Store<TOUT>::st4(yout + (size_t)obase[m] + c0, v);
         if (want_stats) {
-          if (sizeof(TOUT) == 2) {   // statistics of what is stored
+          if (sizeof(TOUT) == 2 && !HL) {   // statistics of what is stored (pairs: of the fp32 value)
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = bf2f(f2bf(v[j]));
           }
           if (a.stats_mode == 1) {   // BatchNorm-backward sums: (sum g, sum g*x), x read at the same position
-            float xv[4];
-            Store<TOUT>::ld4(reinterpret_cast<const TOUT*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo + (size_t)obase[m] + c0, xv);
+            float xv[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (!HL) Store<TOUT>::ld4(reinterpret_cast<const TOUT*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo + (size_t)obase[m] + c0, xv);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s1[n][j] += v[j]; s2[n][j] = fmaf(v[j], xv[j], s2[n][j]); }
           } else {
@@ -1016,6 +1050,15 @@ static int launch_out(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
   if (P.a.dtype_out == SP_F32) return launch_dma<NT, MT, KS, float>(P, grid, st);
   return launch_dma<NT, MT, KS, bf16_t>(P, grid, st);
 }
+// bf16 pairs in and out: the run-time K loop with hi / lo tiles and fragments
+template <int NT, int MT>
+static int launch_hl(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
+  auto kern = conv_igemm_dma_kernel<NT, MT, 0, sp_hl_t, true>;
+  SP_ENSURE_LDS(kern, P.a.lds_bytes, "sp_conv3d_igemm");
+  hipLaunchKernelGGL(kern, grid, dim3(256), P.a.lds_bytes, st, P);
+  SP_CHECK_LAUNCH("sp_conv3d_igemm(dma, pairs)");
+  return SP_OK;
+}
 
 // resident-weight variants exist for KS*NT <= 16 and KS in {1, 2, 4, 7, 14}
 template <int NT, int MT>
@@ -1029,7 +1072,11 @@ static int dispatch_dma(const ConvDmaDev& P, dim3 grid, hipStream_t st) {
 }
 
 int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
-  SP_CHECK_ARG(a->dtype_in == SP_BF16 && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 input and no affine on load");
+  const bool hl = a->dtype_in == SP_HL;
+  SP_CHECK_ARG((a->dtype_in == SP_BF16 || hl) && a->in_scale == nullptr, "sp_conv3d_igemm(dma): needs bf16 (or bf16-pair) input and no affine on load");
+  SP_CHECK_ARG(!hl || (a->dtype_out == SP_HL && a->wfrag_lo && a->lo_offset > 0 && a->x_lo_delta != 0 && a->y_lo_delta != 0 && a->persist == 0 &&
+                       a->steps_per_group % 2 == 0 && a->stats_mode == 0 && a->group_batch == 0),
+               "sp_conv3d_igemm(dma): bf16 pairs need lo fragments, lo tile offset, lo deltas of x and y, an even step count, the tiled kernel");
   SP_CHECK_ARG(a->group_batch == 0 || (a->persist == 0 && a->group_batch > 0 && a->B % a->group_batch == 0),
                "sp_conv3d_igemm(dma): BatchNorm groups (group_batch %d, B %d) need the tiled kernel (persist 0) and whole groups", a->group_batch, a->B);
   if (a->persist == 3 || a->persist == 4) return launch_zs(a, reinterpret_cast<hipStream_t>(stream));      // z-marching plans (ktab in their format)
@@ -1050,7 +1097,9 @@ int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
   SP_CHECK_ARG(P.njobs <= 128, "sp_conv3d_igemm(dma): %d DMA jobs per group (max 128)", P.njobs);
   P.d_segs = make_fastdiv(P.segs_per_row);
   P.d_rows = make_fastdiv(P.nrows);
-  const long need = ((a->steps_per_group * 16 + 15) & ~15) + (long)P.nruns * 1024;
+  // (pairs: every DMA job and the zero fill write whole chunks of their own tile only, so the lo tile may start right behind the hi one)
+  const long need = ((a->steps_per_group * 16 + 15) & ~15) + (hl ? a->lo_offset + (long)P.group_chunks * 16 : (long)P.nruns * 1024);
+  SP_CHECK_ARG(!hl || a->lo_offset >= (long)P.group_chunks * 16, "sp_conv3d_igemm(dma): lo tile offset %d inside the hi tile (%ld bytes)", a->lo_offset, (long)P.group_chunks * 16);
   SP_CHECK_ARG(need <= a->lds_bytes && a->lds_bytes <= 160 * 1024, "sp_conv3d_igemm(dma): LDS plan too small (need %ld, have %d)", need, a->lds_bytes);
   P.d_itw = make_fastdiv(a->ITW);
   P.d_ith = make_fastdiv(a->ITH);
@@ -1072,6 +1121,13 @@ int sp_conv3d_igemm_dma(const sp_conv_args* a, sp_stream_t stream) {
       ((a->steps_per_group * 16 + 15) & ~15) + 2 * ((P.nruns * 1024 + 1023) / 1024 * 1024) <= 76 * 1024) {
     if (a->steps_per_group == 14) return launch_persist<8, 14>(P, st);
     return launch_persist<8, 7>(P, st);
+  }
+  if (hl) {
+#define SP_CASE_HL(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return launch_hl<NT_, MT_>(P, grid, st)
+    SP_CASE_HL(1, 8); SP_CASE_HL(2, 8); SP_CASE_HL(4, 8); SP_CASE_HL(1, 4); SP_CASE_HL(2, 4); SP_CASE_HL(4, 4); SP_CASE_HL(2, 2); SP_CASE_HL(4, 2);
+#undef SP_CASE_HL
+    sp_set_error("sp_conv3d_igemm(dma): no bf16-pair kernel for NT=%d MT=%d", a->NT, a->MT);
+    return SP_EINVAL;
   }
 #define SP_CASE(NT_, MT_) if (a->NT == NT_ && a->MT == MT_) return dispatch_dma<NT_, MT_>(P, grid, st)
   SP_CASE(1, 8); SP_CASE(2, 8); SP_CASE(3, 8); SP_CASE(4, 8);

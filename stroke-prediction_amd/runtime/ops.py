@@ -492,7 +492,7 @@ class ConvRunner:
                       "plane_bytes", "lo_offset", "steps_per_group", "lds_bytes", "zfill"):
                 setattr(a, k, t[k])
             a.dma = int(t["dma"] and in_scale is None and USE_DMA)
-            a.persist = 0 if a.group_batch else int(USE_PERSIST)      # (BatchNorm groups: the tiled kernel only)
+            a.persist = 0 if (a.group_batch or op.dtype == L.SP_HL) else int(USE_PERSIST)      # (BatchNorm groups, bf16 pairs: the tiled kernel only)
             a.x_plane = 0
             if x_planar:
                 assert (a.dma or op.dtype == L.SP_HL) and t["opp"] == 2, "plane-major input: DMA kernel (or the bf16-pair register-staged one) with 16-channel planes only"

@@ -255,7 +255,7 @@ def _plan_sub(op: ConvOp, sub: SubConv, force_rows=None):
         ppg -= 1
     opg = ppg * opp
     ngroups = octs // opg
-    dma = int(op.dtype == 0 and vsb == opp * 16)
+    dma = int((op.dtype == 0 or (op.dtype == 2 and HL_DMA)) and vsb == opp * 16)      # (dtype 2: bf16 pairs, hi and lo tiles side by side)
     if dma:   # the DMA kernel's job table holds 128 (plane, row, segment) jobs per group
         jobs_per_plane = itd * ith * (-(-(itw * opp) // 64))
         while ppg > 1 and (ppg * jobs_per_plane > 128 or nplanes_total % ppg):
@@ -269,7 +269,7 @@ def _plan_sub(op: ConvOp, sub: SubConv, force_rows=None):
         seq.append(None)
     steps = len(seq) // 4
     nt_guess = _pick_nt(-(-op.cout // 16))[0]
-    resident = steps in (1, 2, 4, 7, 14) and steps * nt_guess <= 16
+    resident = steps in (1, 2, 4, 7, 14) and steps * nt_guess <= 16 and op.dtype != 2      # (pairs: the run-time K loop only)
     zs_steps = steps in (7, 14)       # the z-marching variant keeps up to 14 x 3 weight fragments itself
     if dma and not resident and steps % 2:      # run-time K loop of the DMA kernel works on step pairs
         seq += [None] * 4
@@ -302,7 +302,7 @@ def _plan_sub(op: ConvOp, sub: SubConv, force_rows=None):
     # in-plane offset inside a (32 + ext_y - 1) x ITW plane slot, with the tap's z index in the low two bits.
     sub.ktab_zs = None
     sub.kmap_zr = sub.ktab_zr = None
-    if (dma and s == (1, 1, 1) and ngroups == 1 and opg == 2 and op.cpi == 16 and zs_steps
+    if (dma and op.dtype == 0 and s == (1, 1, 1) and ngroups == 1 and opg == 2 and op.cpi == 16 and zs_steps
             and -(-op.cout // 16) <= 2 and ext[0] <= 3 and mt == 8      # (three output tiles: 359 VGPRs, measured 1.7x slower)
             and sub.out_dims[1] >= 32):
         kz = np.zeros(steps * 4, dtype=np.int32)
@@ -376,6 +376,7 @@ ZM_CONFIGS = ZM_CONFIGS_NW4 if os.environ.get("SP_ZM_NW") == "4" else ZM_CONFIGS
 # weight fragments in LDS -> smaller tiles / two ring slots where Cin x Cout grows.  Mirrors sp_conv3d_zm_config_hl.
 ZM_CONFIGS_HL = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (2, 1): (4, 2, 4), (2, 2): (2, 2, 4), (3, 1): (2, 2, 4)}
 ZM_ITW = 18
+HL_DMA = bool(int(os.environ.get("SP_HL_DMA", "1")))      # bf16-pair layers without a z-marching instance on the LDS-DMA tiled kernel (0: register-staged)
 
 
 # (P, NT) instances that exist but lose against their own slices run as teams of one launch (SP_ZM_SPLIT="1,3;..."): measurement knob

@@ -3,7 +3,7 @@
 Forward pass on bf16 PAIRS (SP_HL: every activation = hi + lo bf16 tensors, ~17 significand bits; every product three MFMAs
 with hi / lo weight fragments), backward pass = the bf16 one on the hi halves.  Tests:
 
-* the pair kernels alone (z-marching instances, the register-staged fallback incl. plane-major input, first layer, max-pool,
+* the pair kernels alone (z-marching instances, the LDS-DMA tiled kernel with pairs incl. plane-major input, first layer, max-pool,
   upsample + crop + concat, head) against float64 torch on the pair VALUES -- tolerances ~1e-5 of the output scale, i.e. what
   16-17 bits give, three orders below the bf16 kernels' 3e-2;
 * the network against the CPU oracle and the reference's fixtures with the F32-MODE forward tolerances (probabilities 1e-4,
@@ -67,7 +67,8 @@ HL_CONV_CASES = [   # cin, cout, input dims, batch, expect z-marching, plane-maj
 
 @pytest.mark.parametrize("cin,cout,dims,B,zm,planar", HL_CONV_CASES)
 def test_pair_convolution_matches_float64(cin, cout, dims, B, zm, planar, monkeypatch):
-    """sp_conv3d_zm (bf16-pair instances) and the register-staged sp_conv3d_igemm fallback: valid 3x3x3 convolution + bias +
+    """sp_conv3d_zm (bf16-pair instances) and sp_conv3d_igemm for the shapes without one (the LDS-DMA tiled kernel with hi / lo tiles;
+    SP_HL_DMA=0: the register-staged one): valid 3x3x3 convolution + bias +
     LeakyReLU + statistics on pair operands against float64 torch on the pair values"""
     monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
     g = torch.Generator().manual_seed(cin * 11 + cout)
