@@ -2,6 +2,7 @@
 enqueues hand-written gfx950 kernels through ``libstroke_amd.so`` (no torch compute kernels)."""
 import math
 import os
+import sys
 import ctypes as C
 
 import numpy as np
@@ -664,6 +665,9 @@ class WgradRunner:
                 nb = max(q, nb // q * q)
             a.nblocks = int(os.environ.get("SP_WGRAD_BLOCKS", nb))
             a.parts, self.nparts = 1, a.nblocks
+            if os.environ.get("SP_WGRAD_DEBUG"):
+                print("wgrad %d->%d @%dx%dx%d batch %d: %d partial blocks of %.2f MB (tile grid %d, groups %d)" % (
+                    self.cin, self.cout, a.Di, a.Hi, a.Wi, batch, a.nblocks, total * 4 / 1e6, yz, getattr(self, "groups", 1)), file=sys.stderr)
             self.acc = torch.empty(self.nparts * total, dtype=torch.float32, device=self.device)
         else:
             a.parts, self.nparts = 0, 1
