@@ -39,6 +39,7 @@ else
   rocprofv3 --kernel-trace --stats -d $OUT/g -o g -- python bench.py --workload cae --steps 5 --warmup 2 --no-cpu-baseline > $OUT/g.log 2>&1 && \
     python tools/rocpd_stats.py $(db $OUT/g) gpurun_out/${TAG}_cae_kernel_stats.csv > gpurun_out/${TAG}_cae_kernel_stats.txt
   python tools/rocpd_sequence.py $(db $OUT/g) > gpurun_out/${TAG}_cae_step_sequence.txt      # ordered kernels of the last step
+  MIN_US=30 bash tools/probes/serial_traffic.sh bf16 cae > gpurun_out/${TAG}_cae_serial_traffic.txt 2>&1
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/f -o f -- python bench.py --workload cae --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing > $OUT/f.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/w -o w -- python bench.py --workload cae --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-kernel-timing > $OUT/w.log 2>&1
   python tools/pmc_traffic.py $(csvf $OUT/f) $(csvf $OUT/w) ${TAG}_cae cae_ "bench.py --workload cae --steps 1 --warmup 1 --no-graph, CAE B=4 1x28x128x128 bf16" > gpurun_out/${TAG}_cae_pmc_traffic.txt
