@@ -1154,7 +1154,10 @@ static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CP
   Dims dl{B, D, H, W}, ds{B, Ds, Hs, Ws};
   if (cat_plane && CPu % 16 == 0 && CPs % 16 == 0 && (int64_t)B * D * H * W * 4 < (1ll << 31) && !getenv("SP_UPCAT_BLOCKS")) {
     const int64_t total = (int64_t)B * D * H * W * 4;     // (output x, channel half) pairs over the source rows
+    // workgroups over all planes: 2048 left 2064 workgroups for 1024 resident ones (a third, nearly empty round); swept 2048 .. 65536
+    // at 2 x 168^3 x 96 channels: 752 / 664 / 630 / 643 / 642 us (SP_UPCAT_CAP: the sweep's knob)
     static const int cap_total_ = getenv("SP_UPCAT_CAP") ? atoi(getenv("SP_UPCAT_CAP")) : 8192;
+    SP_CHECK_ARG(cap_total_ >= 8, "sp_upsample2_crop_cat_fwd: SP_UPCAT_CAP %d", cap_total_);
     const int64_t want = (total + 1023) / 1024, cap = cap_total_ / (CPd / 16) + 1;
     const unsigned gx = ((unsigned)(want < cap ? want : cap) + 7) / 8 * 8;
     dim3 grid(gx * (unsigned)(CPd / 16));
