@@ -487,6 +487,11 @@ int sp_first_wgrad_n(const float* x, const void* dz, int32_t B, int32_t D, int32
 int sp_first_wgrad_fused_n(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,
                            int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks, double* dbias_sums,
                            int32_t Cout, sp_stream_t stream);
+/* the same with y as its e4m3 plane-major copy (what sp_first_conv_fwd_n wrote to y8 / y8_plane; the "fp8" precision mode stores no
+ * 16-bit y of the first layer: y = NULL there) -- runtime/layers.py:FirstConvLayer.backward */
+int sp_first_wgrad_fused_y8(const float* x, const void* g, const void* y8, int64_t y8_plane, const float* coef, int32_t act,
+                            float act_param, int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks,
+                            double* dbias_sums, int32_t Cout, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ layout
  * NCDHW fp32 (reference layout, README.md:13 / data.py:305) <-> channels-last-3d */

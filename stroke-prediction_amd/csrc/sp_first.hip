@@ -328,9 +328,11 @@ __global__ __launch_bounds__(256) void first_fwd_kernel(const FirstDev P, const 
           }
         }
         if (rok && ox < P.Wo) {
-          bf16_t* yp = yrow + (size_t)ox * (16 * NT);
-          if (NT == 2) *reinterpret_cast<uint4*>(yp) = make_uint4(w2[0][0], w2[0][1], w2[NT - 1][0], w2[NT - 1][1]);
-          else *reinterpret_cast<uint2*>(yp) = make_uint2(w2[0][0], w2[0][1]);
+          if (y) {      // (NULL: fp8 mode, every reader takes the e4m3 copy)
+            bf16_t* yp = yrow + (size_t)ox * (16 * NT);
+            if (NT == 2) *reinterpret_cast<uint4*>(yp) = make_uint4(w2[0][0], w2[0][1], w2[NT - 1][0], w2[NT - 1][1]);
+            else *reinterpret_cast<uint2*>(yp) = make_uint2(w2[0][0], w2[0][1]);
+          }
           if (HL) {
             bf16_t* ypl = y_lo + vrow * (16 * NT) + lg * CQ + (size_t)ox * (16 * NT);
             if (NT == 2) *reinterpret_cast<uint4*>(ypl) = make_uint4(w2l[0][0], w2l[0][1], w2l[NT - 1][0], w2l[NT - 1][1]);
@@ -383,7 +385,7 @@ static int first_geometry(FirstDev& P, const float* x, int B, int D, int H, int 
 extern "C" int sp_first_conv_fwd_n(const float* x, int32_t B, int32_t D, int32_t H, int32_t W, const void* wfrag,
                                    const float* bias_f, int32_t act, float act_param, void* y, double* stats, int32_t nrep,
                                    int32_t Cout, void* y8, int64_t y8_plane, sp_stream_t stream) {
-  SP_CHECK_ARG(x && wfrag && bias_f && y && B >= 1 && D >= 3 && H >= 3 && W >= 3 && (Cout == 16 || Cout == 32), "sp_first_conv_fwd: bad arguments");
+  SP_CHECK_ARG(x && wfrag && bias_f && (y || y8) && B >= 1 && D >= 3 && H >= 3 && W >= 3 && (Cout == 16 || Cout == 32), "sp_first_conv_fwd: bad arguments (y may be NULL when the e4m3 copy is asked for)");
   SP_CHECK_ARG(!stats || nrep >= 1, "sp_first_conv_fwd: stats replicas");
   SP_CHECK_ARG(!y8 || y8_plane >= (int64_t)B * (D - 2) * (H - 2) * (W - 2) * 16, "sp_first_conv_fwd: y8_plane smaller than a plane of the output");
   FirstDev P;
@@ -432,11 +434,13 @@ extern "C" int sp_first_conv_fwd(const float* x, int32_t B, int32_t D, int32_t H
 // FUSED: dz is not read but formed on the fly, dz = (c0*g + c1*y + c2) * act'(y) (BatchNorm backward of the NEXT layer
 // and the activation derivative, i.e. sp_bn_act_bwd), and its per-channel sum is accumulated for the bias gradient --
 // the 2 x 256 MB round trip of dz through HBM and one launch disappear (nobody else reads this layer's dz).
-template <bool FUSED, int ACT, int NT>      // ACT >= 0: activation fixed at compile time (no per-element branch chain); NT output tiles
+// Y8 (with FUSED): y comes as its e4m3 plane-major copy [NT][B][Do][Ho][Wo][16 bytes] (fp8 mode: the 16-bit tensor is not stored) --
+// yg then points at that copy, y8_plane = bytes per plane.
+template <bool FUSED, int ACT, int NT, bool Y8 = false>      // ACT >= 0: activation fixed at compile time (no per-element branch chain); NT output tiles
 __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, const bf16_t* __restrict__ dzg,
                                                            const bf16_t* __restrict__ gg, const bf16_t* __restrict__ yg,
                                                            const float* __restrict__ coef, int act, float ap,
-                                                           double* __restrict__ dbias, float* __restrict__ part) {
+                                                           double* __restrict__ dbias, float* __restrict__ part, int64_t y8_plane = 0) {
   constexpr int CO = 16 * NT;                                                  // output channels (row pitch of dz / g / y)
   constexpr int DZP = FT_TZ * FT_TY * FT_TX * 32;                              // bytes of one 16-channel plane of the dz tile
   __shared__ __attribute__((aligned(16))) uint32_t xt[FT_ROWS * FT_XP];        // planar: [c][row][x] bf16
@@ -480,8 +484,14 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
       gq[it] = yq[it] = make_uint4(0, 0, 0, 0);
       if (oz < P.Do && oy < P.Ho && ox < P.Wo) {
         const size_t o = ((((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox) * CO + q8 * 8;
-        if (FUSED) { gq[it] = *reinterpret_cast<const uint4*>(gg + o); yq[it] = *reinterpret_cast<const uint4*>(yg + o); }
-        else gq[it] = *reinterpret_cast<const uint4*>(dzg + o);
+        if (FUSED) {
+          gq[it] = *reinterpret_cast<const uint4*>(gg + o);
+          if constexpr (Y8) {
+            const size_t v_ = (((size_t)b * P.Do + oz) * P.Ho + oy) * P.Wo + ox;
+            const uint2 t8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(yg) + (size_t)(q8 >> 1) * y8_plane + v_ * 16 + (q8 & 1) * 8);
+            yq[it] = make_uint4(t8.x, t8.y, 0, 0);
+          } else yq[it] = *reinterpret_cast<const uint4*>(yg + o);
+        } else gq[it] = *reinterpret_cast<const uint4*>(dzg + o);
       }
     }
   };
@@ -507,7 +517,12 @@ __global__ __launch_bounds__(256) void first_wgrad_kernel(const FirstDev P, cons
         if (FUSED) {
           float g8[8], y8[8], d8[8];
           raw8_to_f32(gq[it], g8);
-          raw8_to_f32(yq[it], y8);
+          if constexpr (Y8) {
+            typedef float f2v_ __attribute__((ext_vector_type(2)));
+            const f2v_ a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yq[it].x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yq[it].x, true);
+            const f2v_ a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yq[it].y, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yq[it].y, true);
+            y8[0] = a0[0]; y8[1] = a0[1]; y8[2] = a1[0]; y8[3] = a1[1]; y8[4] = a2[0]; y8[5] = a2[1]; y8[6] = a3[0]; y8[7] = a3[1];
+          } else raw8_to_f32(yq[it], y8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             d8[j] = (k0[j] * g8[j] + k1[j] * y8[j] + k2[j]) * act_bwd_from_y(ACT >= 0 ? ACT : act, ap, y8[j]);
@@ -629,6 +644,24 @@ extern "C" int sp_first_wgrad_fused_n(const float* x, const void* g, const void*
   else { if (act == SP_ACT_LEAKY) SP_FW(SP_ACT_LEAKY, 2); else SP_FW(-1, 2); }
 #undef SP_FW
   SP_CHECK_LAUNCH("sp_first_wgrad_fused");
+  return SP_OK;
+}
+// the same with y as its e4m3 plane-major copy (sp_first_conv_fwd_n's y8 / y8_plane: the fp8 mode stores no 16-bit y)
+extern "C" int sp_first_wgrad_fused_y8(const float* x, const void* g, const void* y8, int64_t y8_plane, const float* coef, int32_t act,
+                                       float act_param, int32_t B, int32_t D, int32_t H, int32_t W, float* partials, int32_t nblocks,
+                                       double* dbias_sums, int32_t Cout, sp_stream_t stream) {
+  SP_CHECK_ARG(x && g && y8 && coef && partials && dbias_sums && B >= 1 && D >= 3 && H >= 3 && W >= 3 && nblocks >= 1 && (Cout == 16 || Cout == 32),
+               "sp_first_wgrad_fused_y8: bad arguments");
+  SP_CHECK_ARG(y8_plane >= (int64_t)B * (D - 2) * (H - 2) * (W - 2) * 16, "sp_first_wgrad_fused_y8: y8_plane smaller than a plane of the output");
+  FirstDev P;
+  SP_CHECK_ARG(first_geometry(P, x, B, D, H, W) == 0, "sp_first_wgrad_fused_y8: too many tiles");
+#define SP_FW(A_, N_)                                                                                                             \
+  hipLaunchKernelGGL((first_wgrad_kernel<true, A_, N_, true>), dim3(nblocks), dim3(256), 0, ST(stream), P, nullptr, (const bf16_t*)g, \
+                     (const bf16_t*)y8, coef, act, act_param, dbias_sums, partials, y8_plane)
+  if (Cout == 16) { if (act == SP_ACT_LEAKY) SP_FW(SP_ACT_LEAKY, 1); else SP_FW(-1, 1); }
+  else { if (act == SP_ACT_LEAKY) SP_FW(SP_ACT_LEAKY, 2); else SP_FW(-1, 2); }
+#undef SP_FW
+  SP_CHECK_LAUNCH("sp_first_wgrad_fused_y8");
   return SP_OK;
 }
 extern "C" int sp_first_wgrad_fused(const float* x, const void* g, const void* y, const float* coef, int32_t act, float act_param,

@@ -623,6 +623,7 @@ class FirstConvLayer(ConvLayer):
         self.wfrag_lo = torch.zeros_like(self.wfrag) if self.hl else None
         self.bias_f = torch.zeros(self.cout, device=self.device)
         self.flops = 2.0 * self.batch * self.out_dims[0] * self.out_dims[1] * self.out_dims[2] * 27 * self.cin * self.cout
+        self.store_y = True      # False (set by the engine, fp8 mode): only the e4m3 copy of the output is written and read
 
     def input_stats(self, images):
         """Batch statistics of the network input for the first BatchNorm (replaces bn_stats on a channels-last copy)."""
@@ -647,9 +648,10 @@ class FirstConvLayer(ConvLayer):
         L.call("sp_first_prep_n", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
                O.ptr(self.wfrag), O.ptr(self.bias_f), self.cout, st)
         y8 = self.alloc_y8() if self.want_y8 else None      # (fp8 mode: the e4m3 operand of the second layer)
-        with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
+        assert self.store_y or y8 is not None
+        with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first%s" % (self.cin, self.cout, D, H, W, "" if self.store_y else " (e4m3 only)")):
             L.call("sp_first_conv_fwd_n", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.bias_f), self.act,
-                   self.act_param, O.ptr(y), O.ptr(out_stats), STATS_NREP, self.cout, O.ptr(y8),
+                   self.act_param, O.ptr(y) if self.store_y else None, O.ptr(out_stats), STATS_NREP, self.cout, O.ptr(y8),
                    0 if y8 is None else y8[0].numel(), st)
         return y
 
@@ -675,10 +677,14 @@ class FirstConvLayer(ConvLayer):
         D, H, W = self.in_dims
         bs = self.scratch.get(self.bsums_id)
         with O._Timed("conv_wgrad", self.flops, "%d->%d @%dx%dx%d first" % (self.cin, self.cout, D, H, W)):
-            if g is not None:
+            if g is not None and not self.store_y:      # y as its e4m3 copy (the 16-bit tensor was not written)
+                L.call("sp_first_wgrad_fused_y8", O.ptr(images), O.ptr(g), O.ptr(self.y8), self.y8[0].numel(), O.ptr(coef), self.act,
+                       self.act_param, self.batch, D, H, W, O.ptr(self.partials), self.nparts, O.ptr(self.dbias_sums), self.cout, st)
+            elif g is not None:
                 L.call("sp_first_wgrad_fused_n", O.ptr(images), O.ptr(g), O.ptr(self.y), O.ptr(coef), self.act, self.act_param,
                        self.batch, D, H, W, O.ptr(self.partials), self.nparts, O.ptr(self.dbias_sums), self.cout, st)
             else:
+                assert self.store_y, "the un-fused first-layer backward reads the 16-bit output"
                 L.call("sp_first_wgrad_n", O.ptr(images), O.ptr(self.dz), self.batch, D, H, W, O.ptr(self.partials), self.nparts,
                        self.cout, st)
         L.call("sp_wgrad_finish_folded", O.ptr(self.partials), self.nparts, O.ptr(self.tapsrc), 27, self.cout, 2, self.cout,

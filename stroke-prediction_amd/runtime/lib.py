@@ -148,6 +148,7 @@ _SIGS = {
     "sp_first_conv_fwd_n": ([vp, i32, i32, i32, i32, vp, vp, i32, f32, vp, vp, i32, i32, vp, i64, vp], i32),
     "sp_first_wgrad_n": ([vp, vp, i32, i32, i32, i32, vp, i32, i32, vp], i32),
     "sp_first_wgrad_fused_n": ([vp, vp, vp, vp, i32, f32, i32, i32, i32, i32, vp, i32, vp, i32, vp], i32),
+    "sp_first_wgrad_fused_y8": ([vp, vp, vp, i64, vp, i32, f32, i32, i32, i32, i32, vp, i32, vp, i32, vp], i32),
     "sp_ncdhw_to_cl": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_cl_to_ncdhw": ([vp, vp, i32, i32, i32, i64, i32, vp], i32),
     "sp_bn_stats": ([vp, i32, i64, i32, vp, vp], i32),

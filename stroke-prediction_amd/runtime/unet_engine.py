@@ -19,6 +19,8 @@ from . import lib as L
 from . import ops as O
 from .layers import ConvLayer, FirstConvLayer, Scratch
 
+F8_Y1_E4M3 = bool(int(os.environ.get("SP_F8_Y1_E4M3", "1")))      # fp8 mode: the first layer's output lives as its e4m3 copy only (0: A/B)
+
 LEAKY = 0.01
 
 
@@ -237,6 +239,14 @@ class UnetEngine:
         for i in range(1, S + 1):
             c1, c2 = self.conv[i]
             self._f8_input(c1, x)
+            if i == 1 and self.f8 and self.first_packed and F8_Y1_E4M3 and c2.f8_fwd is not None and c1.want_y8 and c1.cpo in (16, 32):
+                # fp8 mode: every reader of the first layer's output takes its e4m3 copy -- the second layer's forward and (fp8) weight
+                # gradient as their operand, the first layer's own weight-gradient kernel for act'(y) and the BatchNorm-backward term
+                # (sp_first_wgrad_fused_y8) -- so the 16-bit tensor, the largest of the step, is not written
+                if training:
+                    c2.x8 = c1.alloc_y8()          # (what _f8_input(c2, y1) does after the first layer ran; the backward plan looks at it)
+                    c2._init_bwd()
+                c1.store_y = bool(training and c2.f8_wgrad is None)
             y1 = c1.forward(x, params, bufs, training, st(c2))
             self._f8_input(c2, y1)
             y2 = c2.forward(y1, params, bufs, training)

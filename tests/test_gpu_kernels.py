@@ -644,3 +644,21 @@ def test_first_layer_packed(CO):
            O.ptr(p_fus), nparts, O.ptr(dbs3), CO, O.stream())
     torch.testing.assert_close(p_fus.view(nparts, -1).sum(0), p_ref.view(nparts, -1).sum(0), rtol=1e-4, atol=1e-3)
     torch.testing.assert_close(dbs3.sum(0), dbs2.sum(0), rtol=1e-5, atol=1e-4)
+    # fp8 mode: the 16-bit output is not stored at all (y = NULL: same e4m3 copy, same statistics) and the fused weight gradient
+    # takes y as that copy -- bit for bit what the 16-bit kernel makes of the de-quantised e4m3 values
+    y8b = F8.alloc_f8(B, od, CO, DEV)
+    st2 = torch.zeros(nrep, CO, 2, dtype=torch.float64, device=DEV)
+    L.call("sp_first_conv_fwd_n", O.ptr(xd), B, dims[0], dims[1], dims[2], O.ptr(wfrag), O.ptr(bias_f), L.ACT_LEAKY, 0.01, None,
+           O.ptr(st2), nrep, CO, O.ptr(y8b), y8b[0].numel(), O.stream())
+    assert torch.equal(y8b, y8)
+    torch.testing.assert_close(st2.sum(0), st.sum(0), rtol=1e-12, atol=1e-9)
+    yq8 = y8.view(torch.float8_e4m3fn).float()                      # (P, B, D, H, W, 16) -> channels-last bf16 (exact: 3 mantissa bits)
+    y_deq = yq8.permute(1, 2, 3, 4, 0, 5).reshape(B, *od, CO).to(torch.bfloat16).contiguous()
+    p_a, p_b = torch.full_like(p_ref, float("nan")), torch.full_like(p_ref, float("nan"))
+    dbs_a, dbs_b = O.reduce_rows(CO, 1, DEV), O.reduce_rows(CO, 1, DEV)
+    L.call("sp_first_wgrad_fused_n", O.ptr(xd), O.ptr(g_cl), O.ptr(y_deq), O.ptr(cd), L.ACT_LEAKY, 0.01, B, dims[0], dims[1], dims[2],
+           O.ptr(p_a), nparts, O.ptr(dbs_a), CO, O.stream())
+    L.call("sp_first_wgrad_fused_y8", O.ptr(xd), O.ptr(g_cl), O.ptr(y8), y8[0].numel(), O.ptr(cd), L.ACT_LEAKY, 0.01, B, dims[0], dims[1],
+           dims[2], O.ptr(p_b), nparts, O.ptr(dbs_b), CO, O.stream())
+    assert torch.equal(p_a, p_b) and float(p_b.abs().sum()) > 0
+    torch.testing.assert_close(dbs_b.sum(0), dbs_a.sum(0), rtol=1e-12, atol=1e-9)
