@@ -621,6 +621,11 @@ int sp_upsample2_act_bwd_q8(const void* y, const void* cat, const void* g, const
 int sp_bn_act_bwd_q8(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP, int32_t act,
                      float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale,
                      sp_stream_t stream);
+/* ... with y given as its e4m3 plane-major copy ([CP/16][nvox][16 bytes], y8_plane bytes per plane): the "fp8" precision mode
+ * stores no 16-bit output for a layer all of whose readers take the copy (sp_conv3d_zm8 with y = NULL); q8 may be NULL */
+int sp_bn_act_bwd_y8(const void* g, const void* y8, int64_t y8_plane, const float* coef, int64_t nvox, int32_t CP, int32_t act,
+                     float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale,
+                     sp_stream_t stream);
 int sp_maxpool2_fwd_q8(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
                        double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream);
 int sp_upsample2_crop_cat_fwd_q8(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,

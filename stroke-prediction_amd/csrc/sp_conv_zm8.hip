@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm8_kernel(const ConvZm8
     };
     unsigned char* yout = y_sl + (size_t)b * a.YD * a.YH * a.YW * a.CPo * OB;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)yout, 0, (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)OB), 0x00020000);
+        (void*)yout, 0, a.y ? (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)OB) : 0, 0x00020000);      // (y == NULL: no records, every store is dropped -- only the e4m3 copy leaves)
     // the e4m3 copy: plane n of this launch, sample b -- one descriptor per output tile
     __amdgpu_buffer_rsrc_t y8rs[NT];
     if (Q8) {
@@ -420,7 +420,7 @@ extern "C" int sp_conv3d_zm8_config(int32_t P, int32_t NT, int32_t* MT, int32_t*
 }
 
 extern "C" int sp_conv3d_zm8(const sp_conv_args* a, const void* zeros, sp_stream_t stream) {
-  SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && a->f8_wscale && zeros && a->in_scale == nullptr, "sp_conv3d_zm8: null pointer (or affine-on-load requested)");
+  SP_CHECK_ARG(a && a->x && (a->y || a->y8) && a->wfrag_hi && a->ktab && a->f8_wscale && zeros && a->in_scale == nullptr, "sp_conv3d_zm8: null pointer (or affine-on-load requested; y may be NULL when the e4m3 copy is asked for)");
   SP_CHECK_ARG((a->dtype_out == SP_BF16 || a->dtype_out == SP_F32) && a->stats_mode == 0 && a->x_plane > 0, "sp_conv3d_zm8: bf16 output (or fp32 partial sums), plain statistics, plane-major fp8 input");
   SP_CHECK_ARG(a->dtype_out == SP_BF16 || (a->bias == nullptr && a->act == SP_ACT_NONE && a->stats == nullptr && a->y8 == nullptr),
                "sp_conv3d_zm8: fp32 partial sums take no bias / activation / statistics / e4m3 copy (sp_conv_partial_finish applies them)");

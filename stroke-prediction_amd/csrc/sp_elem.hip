@@ -402,8 +402,9 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                           const float* __restrict__ coef, int64_t nvox, int CP,
                                                           OctMap om, int act, float ap, T* __restrict__ dz,
-                                                          double* __restrict__ dbias, const SpQ8 q8, int64_t gvox) {
+                                                          double* __restrict__ dbias, const SpQ8 q8, int64_t gvox, int64_t y8_plane = 0) {
   // gvox > 0: voxels [g*gvox, (g+1)*gvox) use the coefficient table coef + g*3*CP (the batched passes of the CAE)
+  // y8_plane > 0: y is the e4m3 plane-major copy [CP/16][nvox][16 bytes] of the activations (fp8 mode: no 16-bit tensor was stored)
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
@@ -431,7 +432,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
       }
       float a[8], b[8], o[8];
       Store<T>::ld8(g + v * CP + oc * 8, a);
-      Store<T>::ld8(y + v * CP + oc * 8, b);
+      if (y8_plane) {
+        typedef float f2v_ __attribute__((ext_vector_type(2)));
+        const uint2 t8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(y) + (int64_t)(oc >> 1) * y8_plane + v * 16 + (oc & 1) * 8);
+        const f2v_ a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.x, true);
+        const f2v_ a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.y, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.y, true);
+        b[0] = a0[0]; b[1] = a0[1]; b[2] = a1[0]; b[3] = a1[1]; b[4] = a2[0]; b[5] = a2[1]; b[6] = a3[0]; b[7] = a3[1];
+      } else Store<T>::ld8(y + v * CP + oc * 8, b);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         o[j] = (c0[j] * a[j] + c1[j] * b[j] + c2[j]) * act_bwd_t<ACT>(act, ap, b[j]);
@@ -444,8 +451,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_kernel(const T* __restrict__ g
   if (dbias) block_channel_reduce<1>(part, oc, active, CP, dbias, red);
 }
 static int bn_act_bwd_impl(const void* g, const void* y, const float* coef, int32_t dtype, int64_t nvox, int32_t CP,
-                           int32_t act, float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream, int64_t gvox = 0) {
+                           int32_t act, float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream, int64_t gvox = 0,
+                           int64_t y8_plane = 0) {
   SP_CHECK_ARG(g && y && (dz || q8.p) && CP % 8 == 0 && CP <= 2048, "sp_bn_act_bwd: bad arguments");
+  SP_CHECK_ARG(y8_plane == 0 || (dtype == SP_BF16 && CP % 16 == 0 && y8_plane >= nvox * 16), "sp_bn_act_bwd_y8: y as e4m3 planes needs bf16 gradients, whole 16-channel planes of >= nvox * 16 bytes");
   SP_CHECK_ARG(gvox == 0 || (coef && gvox > 0 && nvox % gvox == 0), "sp_bn_act_bwd_groups: the groups must tile the tensor");
   SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= nvox * 16 && q8.scale > 0.f), "sp_bn_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   OctMap om = make_octmap(CP);
@@ -453,7 +462,7 @@ static int bn_act_bwd_impl(const void* g, const void* y, const float* coef, int3
   const size_t sh = (size_t)CP * sizeof(float);
 #define SP_L(A_)                                                                                                                   \
   if (dtype == SP_BF16) hipLaunchKernelGGL((bn_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)g, \
-                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums, q8, gvox); \
+                                           (const bf16_t*)y, coef, nvox, CP, om, act, act_param, (bf16_t*)dz, dbias_sums, q8, gvox, y8_plane); \
   else hipLaunchKernelGGL((bn_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)g, (const float*)y,   \
                           coef, nvox, CP, om, act, act_param, (float*)dz, dbias_sums, q8, gvox)
   SP_ACT_DISPATCH(act, SP_L)
@@ -476,6 +485,15 @@ extern "C" int sp_bn_act_bwd_q8(const void* g, const void* y, const float* coef,
   SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1), "sp_bn_act_bwd_q8: bad fp8 output");
   return bn_act_bwd_impl(g, y, coef, dtype, nvox, CP, act, act_param, dz, dbias_sums,
                          SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
+}
+// y given as its e4m3 plane-major copy (the fp8 mode stores no 16-bit output for layers all of whose readers take the copy);
+// q8 may be NULL (then dz must not be)
+extern "C" int sp_bn_act_bwd_y8(const void* g, const void* y8, int64_t y8_plane, const float* coef, int64_t nvox, int32_t CP,
+                                int32_t act, float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane,
+                                int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(y8_plane > 0 && (!q8 || q8_fmt == 0 || q8_fmt == 1), "sp_bn_act_bwd_y8: bad arguments");
+  return bn_act_bwd_impl(g, y8, coef, SP_BF16, nvox, CP, act, act_param, dz, dbias_sums,
+                         SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8 ? q8_scale : 1.f, q8_fmt}, stream, 0, y8_plane);
 }
 
 // ------------------------------------------------------------------------------------------------ pool / upsample / crop fwd

@@ -167,10 +167,12 @@ class ConvRunnerF8:
         (x out_scale: the reciprocal of the scale the B operand was quantised with)."""
         prep_many([(self, w, b, fold_scale, fold_shift, out_scale)])      # one launch for all slices
 
-    def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
+    def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0, store=True):
         """y bf16: the finished output; y fp32: this op's partial sums (one input-channel group of a larger convolution --
-        no bias, activation, statistics; ConvRunnerF8Split adds the groups up)"""
+        no bias, activation, statistics; ConvRunnerF8Split adds the groups up).  store=False (with y8): the 16-bit output is not
+        written (y only gives the shape) -- every reader takes the e4m3 copy"""
         op, batch = self.op, self.batch
+        assert store or (y8 is not None and y.dtype == torch.bfloat16)
         sub = op.subs[0]
         partial = y.dtype == torch.float32
         assert x8.dtype == torch.uint8 and tuple(x8.shape) == (op.cpi // 16, batch) + tuple(op.in_dims) + (16,), \
@@ -203,7 +205,7 @@ class ConvRunnerF8:
         nl = len(self.slices) // self.fuse_m if self.fused else 0
         for s in (self.slices[::self.fuse_m] if self.fused else self.slices):
             c0 = s["c0"]
-            a.y = y.data_ptr() + y.element_size() * c0
+            a.y = (y.data_ptr() + y.element_size() * c0) if store else None
             a.bias = (self.bias.data_ptr() + 4 * c0) if (self.has_bias and not partial) else None
             a.f8_wscale = self.winv.data_ptr() + 4 * c0
             a.stats = None if stats is None else stats.data_ptr() + 16 * c0

@@ -172,6 +172,7 @@ class ConvLayer:
         self.x8 = self.y8 = self.dz8 = None
         self.dz8_ready = False      # set by the kernel that formed dz when it also wrote the fp8 copy (dz8_out)
         self.want_y8 = False
+        self.store_y = True       # False (engine, fp8 mode): the 16-bit output is not written, its readers take self.y8
         self.f8_grad_scale = 1.0
 
     def enable_f8(self, grad_scale, fwd=True):
@@ -311,7 +312,12 @@ class ConvLayer:
             return y
         if self.f8_fwd is not None:       # fp8 operands: x8 = e4m3 copy of x (engine), BatchNorm folded into the e4m3 weights
             self.f8_fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
-            self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=self.alloc_y8() if self.want_y8 else None)
+            y8 = self.alloc_y8() if self.want_y8 else None
+            if not self.store_y:      # (set by the engine: every reader of this output takes the e4m3 copy)
+                assert y8 is not None and isinstance(self.f8_fwd, F8_PLAIN_RUNNER())
+                self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=y8, store=False)
+            else:
+                self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=y8)
         elif self.fold:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
@@ -604,6 +610,11 @@ class ConvLayer:
             world = SYNC["world"]      # sums are global now: every rank holds the full dgamma/dbeta -> scale by 1/world
         O.bn_bwd_finalize(bs, self.count * world, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
                           grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=nrep, pscale=1.0 / world)
+
+
+def F8_PLAIN_RUNNER():
+    from . import f8 as F8
+    return F8.ConvRunnerF8
 
 
 class FirstConvLayer(ConvLayer):

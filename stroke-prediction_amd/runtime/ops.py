@@ -857,10 +857,16 @@ def _q8_args(q8, nvox):
     return ptr(t), nvox * 16, int(fmt), float(scale)
 
 
-def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None, group_vox=0, cls=None):
+def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None, group_vox=0, cls=None, y8=None):
     """cls = (group batch, (padD, padH, padW), class sums): the layer whose dz this forms reads the RAW input in its weight gradient
-    (ConvLayer.raw_wgrad): the border-class sums of dz come out of the same pass (sp_bn_act_bwd_groups_cls)"""
+    (ConvLayer.raw_wgrad): the border-class sums of dz come out of the same pass (sp_bn_act_bwd_groups_cls).
+    y8: the e4m3 plane-major copy of y (runtime/f8.py: alloc_f8) -- read INSTEAD of y (fp8 mode: y was not stored; y gives the shape)"""
     nvox = y.numel() // y.shape[-1]
+    if y8 is not None:
+        assert cls is None and not group_vox and dtype == L.SP_BF16 and y8.dtype == torch.uint8 and y8.numel() == nvox * y.shape[-1]
+        q = _q8_args(q8, nvox) if q8 is not None else (None, 0, 0, 1.0)
+        L.call("sp_bn_act_bwd_y8", ptr(g), ptr(y8), nvox * 16, ptr(coef), nvox, y.shape[-1], act, act_param, ptr(dz), ptr(dbias), *q, stream())
+        return
     if cls is not None:
         gb, pads, sums = cls
         assert q8 is None and coef is not None and y.dim() == 5

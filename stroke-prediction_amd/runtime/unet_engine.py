@@ -239,6 +239,8 @@ class UnetEngine:
         for i in range(1, S + 1):
             c1, c2 = self.conv[i]
             self._f8_input(c1, x)
+            if i > 1:
+                self._f8_e4m3_only(c1, c2, training)
             if i == 1 and self.f8 and self.first_packed and F8_Y1_E4M3 and c2.f8_fwd is not None and c1.want_y8 and c1.cpo in (16, 32):
                 # fp8 mode: every reader of the first layer's output takes its e4m3 copy -- the second layer's forward and (fp8) weight
                 # gradient as their operand, the first layer's own weight-gradient kernel for act'(y) and the BatchNorm-backward term
@@ -266,6 +268,7 @@ class UnetEngine:
                 keep = training and c1.f8_wgrad is None
             O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u], q8=q8, store=keep)
             self._f8_input(c1, self.cat[u])
+            self._f8_e4m3_only(c1, c2, training)
             y1 = c1.forward(self.cat[u], params, bufs, training, st(c2))
             self._f8_input(c2, y1)
             low = c2.forward(y1, params, bufs, training)
@@ -316,6 +319,22 @@ class UnetEngine:
                O.ptr(params["classify.0.bias"]), self.channels[-2], O.ptr(params["classify.2.weight"]),
                O.ptr(params["classify.2.bias"]), self.ncls, LEAKY, O.ptr(seg), O.stream())
         return seg
+
+    def _f8_e4m3_only(self, c1, c2, training):
+        """fp8 mode: the first convolution of a block whose output is read by fp8 kernels only -- the second convolution's forward
+        and weight gradient take its e4m3 copy as their operand, sp_bn_act_bwd_y8 takes it for act'(y) and the BatchNorm-backward
+        term -- does not write the 16-bit tensor (``c1.store_y = False``)"""
+        from . import f8 as F8
+        c1.store_y = True
+        if not (self.f8 and F8_Y1_E4M3 and isinstance(c1.f8_fwd, F8.ConvRunnerF8) and c1.want_y8 and c2.f8_fwd is not None
+                and self.f8_src.get(c2, (None,))[0] == "y8"):
+            return
+        if training:
+            c2.x8 = c1.alloc_y8()
+            c2._init_bwd()
+            if c2.f8_wgrad is None:
+                return
+        c1.store_y = False
 
     def _f8_fused_input(self, lay):
         """fp8 mode: (lay.x8, e4m3, 1.0) when the pooling / concatenation kernel that writes lay's input should write its e4m3
@@ -464,7 +483,7 @@ class UnetEngine:
         for u in range(2 * S - 1, S, -1):
             c1, c2 = self.conv[u]
             g, coef = c2.backward(c1.y, params, grads)
-            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out())
+            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out(), y8=None if c1.store_y else c1.y8)
             gu, coefu = c1.backward(self.cat[u], params, grads)
             if ready is not None and u == S + 1:     # every up block and the head are final: their all-reduce bucket may start
                 ready("block%d." % (S + 1))
@@ -474,7 +493,7 @@ class UnetEngine:
             c1, c2 = self.conv[i]
             g, coef = c2.backward(c1.y, params, grads)
             if i > 1:
-                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out())
+                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out(), y8=None if c1.store_y else c1.y8)
                 gp, coefp = c1.backward(self.pooled[i - 1], params, grads)
                 if ready is not None and i == 2:
                     ready("block2.")

@@ -498,6 +498,54 @@ def test_unet4_fp8b_mode_matches_the_emulating_oracle():
             assert rel < 0.52 and cos > 0.88, (k, rel, cos)
 
 
+def test_e4m3_only_activations_equal_the_stored_ones():
+    """fp8 mode, a block's first convolution whose output only fp8 kernels read: sp_conv3d_zm8 with y = NULL writes the same e4m3 copy
+    and statistics and nothing else; sp_bn_act_bwd_y8 (y from the copy) is bit for bit sp_bn_act_bwd on the de-quantised values"""
+    g_ = torch.Generator().manual_seed(23)
+    cin, cout, dims, B = 32, 64, (10, 40, 36), 2
+    x = bf(torch.randn(B, cin, *dims, generator=g_) * 1.5)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g_) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g_) * 0.1
+    fs, fsh = torch.rand(cin, generator=g_) + 0.5, torch.randn(cin, generator=g_) * 0.2
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
+    keep = F8.F8_MIN_PLANES
+    F8.F8_MIN_PLANES = 1
+    try:
+        run = F8.ConvRunnerF8(op, DEV, B, F8.E4M3)
+    finally:
+        F8.F8_MIN_PLANES = keep
+    x8 = F8.alloc_f8(B, dims, cin, DEV)
+    F8.quantize(_to_cl(x, cin), x8, F8.E4M3, 1.0)
+    run.prep(w.to(DEV), b.to(DEV), fs.to(DEV), fsh.to(DEV))
+    nrep = 8
+    outs = []
+    for store in (True, False):
+        y = torch.full((B,) + tuple(op.y_dims) + (cout,), 7.0, dtype=torch.bfloat16, device=DEV)
+        y8 = F8.alloc_f8(B, op.y_dims, cout, DEV)
+        stats = torch.zeros(nrep, cout, 2, dtype=torch.float64, device=DEV)
+        run.run(x8, y, L.ACT_LEAKY, LEAKY, stats, nrep, y8=y8, store=store)
+        outs.append((y, y8, stats.sum(0)))
+    assert torch.equal(outs[0][1], outs[1][1]) and float(outs[0][0].float().abs().max()) > 0
+    assert bool((outs[1][0] == 7.0).all())                                  # nothing was written to y
+    torch.testing.assert_close(outs[1][2], outs[0][2], rtol=1e-12, atol=1e-9)
+    # backward of the activation + BatchNorm: y from the e4m3 copy
+    y8 = outs[0][1]
+    od = tuple(op.y_dims)
+    y_deq = y8.view(torch.float8_e4m3fn).float().permute(1, 2, 3, 4, 0, 5).reshape(B, *od, cout).to(torch.bfloat16).contiguous()
+    g = (torch.randn(B, *od, cout, generator=g_) * 1e-5).bfloat16().to(DEV)
+    coef = (torch.randn(3, cout, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+    S = 2.0 ** 18
+    res = []
+    for use8 in (False, True):
+        dz = torch.empty_like(g)
+        dz8 = F8.alloc_f8(B, od, cout, DEV)
+        sums = O.reduce_rows(cout, 1, DEV)
+        O.bn_act_bwd(g, y_deq, coef, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz, sums, q8=(dz8, F8.E5M2, S), y8=y8 if use8 else None)
+        res.append((dz, dz8, sums.sum(0)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and float(res[0][0].float().abs().max()) > 0
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-12, atol=1e-20)
+
+
 def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
     """the four elementwise kernels that can write the fp8 operand of the next convolution themselves (sp_*_q8) produce
     exactly what sp_quantize_f8 makes of the bf16 tensor they store"""
