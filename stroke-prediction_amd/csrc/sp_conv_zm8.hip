@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void conv_partial_finish_kernel(const float* _
             s1[2 * j + 1] += q1; s2[2 * j + 1] = fmaf(q1, q1, s2[2 * j + 1]);
           }
         }
-        *reinterpret_cast<uint4*>(y + (m0 + (int64_t)u * vpb) * CP + oc * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        if (y) *reinterpret_cast<uint4*>(y + (m0 + (int64_t)u * vpb) * CP + oc * 8) = make_uint4(w4[0], w4[1], w4[2], w4[3]);      // (NULL: only the e4m3 copy is wanted)
         if (y8) {      // e4m3 plane-major copy of the stored values: channels [8 oc, 8 oc + 8) = half a 16-byte voxel of plane oc / 2
           const float r0[4] = {sp_h2f_lo(w4[0]), sp_h2f_hi(w4[0]), sp_h2f_lo(w4[1]), sp_h2f_hi(w4[1])};
           const float r1[4] = {sp_h2f_lo(w4[2]), sp_h2f_hi(w4[2]), sp_h2f_lo(w4[3]), sp_h2f_hi(w4[3])};
@@ -542,7 +542,7 @@ extern "C" int sp_conv_partial_finish(const float* partial, int32_t ngroups, int
                                       int32_t bias_stride, int32_t act, float act_param, void* y, double* stats, int32_t stats_nrep,
                                       void* y8, int64_t y8_plane, sp_stream_t stream) {
   SP_CHECK_ARG(!y8 || (CP % 16 == 0 && y8_plane >= nvox * 16), "sp_conv_partial_finish: e4m3 copy needs whole 16-channel planes of >= nvox * 16 bytes");
-  SP_CHECK_ARG(partial && y && ngroups >= 1 && nvox >= 1 && CP % 8 == 0 && CP >= 8 && CP <= 2048, "sp_conv_partial_finish: bad arguments");
+  SP_CHECK_ARG(partial && (y || y8) && ngroups >= 1 && nvox >= 1 && CP % 8 == 0 && CP >= 8 && CP <= 2048, "sp_conv_partial_finish: bad arguments (y may be NULL when the e4m3 copy is asked for)");
   SP_CHECK_ARG(act == SP_ACT_NONE || act == SP_ACT_LEAKY, "sp_conv_partial_finish: LeakyReLU or identity");
   SP_CHECK_ARG(!bias || bias_stride >= CP, "sp_conv_partial_finish: bias_stride");
   SP_CHECK_ARG(!stats || stats_nrep >= 1, "sp_conv_partial_finish: stats replicas");

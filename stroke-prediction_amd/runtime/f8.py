@@ -266,8 +266,9 @@ class ConvRunnerF8Split:
     def prep_jobs(self, w, out_scale):
         return [(r, w, None, None, None, out_scale) for r in self.runners]
 
-    def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0):
+    def run(self, x8, y, act=L.ACT_NONE, act_param=0.0, stats=None, stats_nrep=1, y8=None, y8_scale=1.0, store=True):
         op, batch = self.op, self.batch
+        assert store or y8 is not None
         assert y.dtype == torch.bfloat16 and y.shape[4] == self.cpad == op.cpo, (tuple(y.shape), self.cpad, op.cpo)
         assert y8 is None or (self.bin == E4M3 and y8_scale == 1.0 and tuple(y8.shape) == (self.cpad // 16, batch) + tuple(op.y_dims) + (16,))
         assert tuple(x8.shape) == (op.cpi // 16, batch) + tuple(op.in_dims) + (16,), (tuple(x8.shape), op.cpi)
@@ -278,7 +279,7 @@ class ConvRunnerF8Split:
             r.run(x8[g * self.gp:(g + 1) * self.gp], self.partial[g])
         with O._Timed("conv_partial_finish", 0.0, "%d->%d @%s x%d groups" % (op.cin, op.cout, "x".join(map(str, op.in_dims)), self.G)):
             L.call("sp_conv_partial_finish", O.ptr(self.partial), self.G, nvox, self.cpad, O.ptr(self.bias_all) if self.has_bias else None,
-                   self.cpad, act, act_param, O.ptr(y), O.ptr(stats), stats_nrep, O.ptr(y8), nvox * 16, O.stream())
+                   self.cpad, act, act_param, O.ptr(y) if store else None, O.ptr(stats), stats_nrep, O.ptr(y8), nvox * 16, O.stream())
 
 
 class WgradRunnerF8:

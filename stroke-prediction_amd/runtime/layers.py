@@ -314,7 +314,7 @@ class ConvLayer:
             self.f8_fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
             y8 = self.alloc_y8() if self.want_y8 else None
             if not self.store_y:      # (set by the engine: every reader of this output takes the e4m3 copy)
-                assert y8 is not None and isinstance(self.f8_fwd, F8_PLAIN_RUNNER())
+                assert y8 is not None
                 self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=y8, store=False)
             else:
                 self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=y8)
@@ -610,11 +610,6 @@ class ConvLayer:
             world = SYNC["world"]      # sums are global now: every rank holds the full dgamma/dbeta -> scale by 1/world
         O.bn_bwd_finalize(bs, self.count * world, params[p + ".weight"], self.mean, self.invstd, self.cin, self.cpi,
                           grads[p + ".weight"], grads[p + ".bias"], self.coef, nrep=nrep, pscale=1.0 / world)
-
-
-def F8_PLAIN_RUNNER():
-    from . import f8 as F8
-    return F8.ConvRunnerF8
 
 
 class FirstConvLayer(ConvLayer):

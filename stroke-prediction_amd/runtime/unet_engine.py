@@ -326,7 +326,7 @@ class UnetEngine:
         term -- does not write the 16-bit tensor (``c1.store_y = False``)"""
         from . import f8 as F8
         c1.store_y = True
-        if not (self.f8 and F8_Y1_E4M3 and isinstance(c1.f8_fwd, F8.ConvRunnerF8) and c1.want_y8 and c2.f8_fwd is not None
+        if not (self.f8 and F8_Y1_E4M3 and isinstance(c1.f8_fwd, (F8.ConvRunnerF8, F8.ConvRunnerF8Split)) and c1.want_y8 and c2.f8_fwd is not None
                 and self.f8_src.get(c2, (None,))[0] == "y8"):
             return
         if training:
