@@ -628,15 +628,28 @@ int sp_bn_act_bwd_y8(const void* g, const void* y8, int64_t y8_plane, const floa
                      sp_stream_t stream);
 int sp_maxpool2_fwd_q8(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
                        double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream);
+/* ... with the input as its e4m3 plane-major copy (the "fp8" mode stores no 16-bit output for a convolution all of whose readers take
+ * the copy); y may be NULL (only the e4m3 copy of the pooled tensor is wanted) -- runtime/unet_engine.py */
+int sp_maxpool2_fwd_x8(const void* x8, int64_t x8_plane, void* y, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, double* stats,
+                       void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream);
 int sp_upsample2_crop_cat_fwd_q8(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                                  int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs, int32_t Ws,
                                  int64_t cat_plane, double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale,
                                  sp_stream_t stream);
+/* ... with the skip tensor as its e4m3 plane-major copy ([CPs/16][B][Ds][Hs][Ws][16 bytes]); plane-major output only */
+int sp_upsample2_crop_cat_fwd_q8s8(const void* low, int32_t CPu, const void* skip8, int64_t skip8_plane, int32_t CPs, void* cat, int32_t CPd,
+                                   int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs, int32_t Ws, int64_t cat_plane,
+                                   double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream);
 int sp_pool_skip_act_bwd_q8(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
                             const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
                             int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc,
                             int32_t Wc, int32_t act, float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane,
                             int32_t q8_fmt, float q8_scale, sp_stream_t stream);
+/* ... with y as its e4m3 plane-major copy; q8 may be NULL */
+int sp_pool_skip_act_bwd_y8(const void* y8, int64_t y8_plane, const void* gp, const float* coefp, const void* gs, const float* coefs,
+                            int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride, int32_t B, int32_t D, int32_t H, int32_t W,
+                            int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act, float act_param, void* dz, double* dbias_sums,
+                            void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ network output side + Dice (Unet3D.py:53,75-77;
  * metrics.py:16-28).  dz[b,v,c] = dout[b,c,v]*act'(out[b,c,v]) : NCDHW fp32 -> channels-last */

@@ -105,6 +105,20 @@ class _F8Conv(torch.autograd.Function):
         return gx, gw, g.sum(dim=(0, 2, 3, 4)), None, None, None, None, None
 
 
+class _SteE4m3(torch.autograd.Function):
+    """a tensor that exists as its e4m3 copy only (the fp8 mode's block outputs that pooling / the skip crop read): every reader
+    sees the rounded values -- BatchNorm statistics included --, the gradient passes straight through (the backward kernels form
+    act'(y) and the pooling argmax from the same rounded values)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return round_e4m3(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
 def f8_grad_scale(n_out_voxels):
     """runtime/f8.py:grad_scale_for"""
     return float(2.0 ** math.ceil(math.log2(64.0 * max(1, n_out_voxels))))
@@ -182,13 +196,15 @@ def unet_forward(sd, x, training=True, return_all=False, q=_ident, f8=None):
     ``q=round_bf16`` emulates the bf16 storage points of the HIP fast path (see ``unet_block``); ``f8=dict(layers={conv
     prefixes}, grad_scale=S)`` additionally runs those convolutions with fp8 operands (``_F8Conv``; needs q=round_bf16); the keys
     ``dgrad`` / ``wgrad`` name the layers whose data / weight gradient alone runs on fp8 operands (the "fp8b" mode: ``layers``
-    empty, the forward stays the bf16 one)."""
+    empty, the forward stays the bf16 one); ``y2_e4m3`` = the down blocks whose output is stored as e4m3 only."""
     nblocks = len({k.split(".")[0] for k in sd if k.startswith("block")})
     S = (nblocks + 1) // 2
     outs = {}
     h = q(x)
     for i in range(1, S + 1):                              # down: block, pool (Unet3D.py:57-63 / :119-128)
         outs[i] = unet_block(sd, "block%d" % i, h, training, q, f8)
+        if f8 is not None and i in f8.get("y2_e4m3", ()):      # this block's output lives as its e4m3 copy only (pool and skip crop read that)
+            outs[i] = _SteE4m3.apply(outs[i])
         if i < S:
             h = F.max_pool3d(outs[i], 2, 2)
     low = outs[S]

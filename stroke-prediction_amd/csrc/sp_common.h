@@ -223,6 +223,15 @@ __device__ __forceinline__ uint32_t sp_q8_pack4(const float* v, float s, int fmt
   }
   return (uint32_t)r;
 }
+// the other direction: channels [8 oc, 8 oc + 8) of voxel v from an e4m3 plane-major tensor [C/16][nvox][16 bytes] (plane bytes per
+// 16-channel plane) -- the fp8 mode's activations that were never stored in 16 bits
+__device__ __forceinline__ void sp_ld8_e4m3(const void* base, int64_t plane, int64_t v, int oc, float* out) {
+  typedef float f2v_ __attribute__((ext_vector_type(2)));
+  const uint2 t8 = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(base) + (int64_t)(oc >> 1) * plane + v * 16 + (oc & 1) * 8);
+  const f2v_ a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.x, true);
+  const f2v_ a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.y, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)t8.y, true);
+  out[0] = a0[0]; out[1] = a0[1]; out[2] = a1[0]; out[3] = a1[1]; out[4] = a2[0]; out[5] = a2[1]; out[6] = a3[0]; out[7] = a3[1];
+}
 // channels [8 oc, 8 oc + 8) of voxel v
 __device__ __forceinline__ void sp_q8_store8(const SpQ8& q, int64_t v, int oc, const float* vals) {
   *reinterpret_cast<uint2*>(q.p + (int64_t)(oc >> 1) * q.plane + v * 16 + (oc & 1) * 8) =

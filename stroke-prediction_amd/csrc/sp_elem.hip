@@ -662,7 +662,8 @@ extern "C" int sp_bn_act_bwd_groups_cls(const void* g, const void* y, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, Dims di, int CP,
                                                             OctMap om, double* __restrict__ stats, const SpQ8 q8,
-                                                            int64_t x_lo = 0, int64_t y_lo = 0) {
+                                                            int64_t x_lo = 0, int64_t y_lo = 0, int64_t x8_plane = 0) {
+  // x8_plane > 0: x is the e4m3 plane-major copy of the input (the fp8 mode stored no 16-bit tensor); y may then be NULL
   extern __shared__ float red[];
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
   const bool active = slot < om.vpb;
@@ -686,11 +687,13 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
       for (int k = 0; k < 8; ++k) {
         const int iz = 2 * z + (k >> 2), iy = 2 * yy + ((k >> 1) & 1), ix = 2 * xx + (k & 1);
         float a[8];
-        ld8x<T>(x + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8, x_lo, a);
+        const int64_t vi_ = (((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix;
+        if (x8_plane) sp_ld8_e4m3(x, x8_plane, vi_, oc, a);
+        else ld8x<T>(x + vi_ * CP + oc * 8, x_lo, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], a[j]);
       }
-      st8x<T>(y + v * CP + oc * 8, y_lo, m);
+      if (y) st8x<T>(y + v * CP + oc * 8, y_lo, m);
       if (q8.p) sp_q8_store8(q8, v, oc, m);
 #pragma unroll
       for (int j = 0; j < 8; ++j) { part[0][j] += m[j]; part[1][j] += m[j] * m[j]; }
@@ -699,8 +702,9 @@ __global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const T* __restrict__
   if (stats) block_channel_reduce<2>(part, oc, active, CP, stats, red);
 }
 static int maxpool2_fwd_impl(const void* x, void* y, int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W,
-                             int32_t CP, double* stats, SpQ8 q8, sp_stream_t stream) {
-  SP_CHECK_ARG(x && y && CP % 8 == 0 && D >= 2 && H >= 2 && W >= 2, "sp_maxpool2_fwd: bad arguments");
+                             int32_t CP, double* stats, SpQ8 q8, sp_stream_t stream, int64_t x8_plane = 0) {
+  SP_CHECK_ARG(x && (y || q8.p) && CP % 8 == 0 && D >= 2 && H >= 2 && W >= 2, "sp_maxpool2_fwd: bad arguments");
+  SP_CHECK_ARG(x8_plane == 0 || (dtype == SP_BF16 && CP % 16 == 0 && x8_plane >= (int64_t)B * D * H * W * 16), "sp_maxpool2_fwd_x8: e4m3 input planes of >= B D H W 16 bytes");
   SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= (int64_t)B * (D / 2) * (H / 2) * (W / 2) * 16 && q8.scale > 0.f),
                "sp_maxpool2_fwd_q8: bf16 tensors of whole 16-channel planes");
   SP_CHECK_VOX((int64_t)B * D * H * W, "sp_maxpool2_fwd");
@@ -709,10 +713,17 @@ static int maxpool2_fwd_impl(const void* x, void* y, int32_t dtype, int32_t B, i
   const int64_t nout = (int64_t)B * (D / 2) * (H / 2) * (W / 2);
   const unsigned grid = grid_for(nout, om.vpb * 2);
   const size_t sh = (size_t)CP * 2 * sizeof(float);
-  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats, q8, (int64_t)0, (int64_t)0);
-  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats, q8, (int64_t)0, (int64_t)0);
+  if (dtype == SP_BF16) hipLaunchKernelGGL(maxpool2_fwd_kernel<bf16_t>, dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)x, (bf16_t*)y, di, CP, om, stats, q8, (int64_t)0, (int64_t)0, x8_plane);
+  else hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid), dim3(256), sh, ST(stream), (const float*)x, (float*)y, di, CP, om, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0);
   SP_CHECK_LAUNCH("sp_maxpool2_fwd");
   return SP_OK;
+}
+// the input as its e4m3 plane-major copy (the fp8 mode: the producing convolution stored no 16-bit tensor); y may be NULL (only the
+// e4m3 copy of the result is wanted)
+extern "C" int sp_maxpool2_fwd_x8(const void* x8, int64_t x8_plane, void* y, int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP,
+                                  double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(x8_plane > 0 && (!q8 || q8_fmt == 0 || q8_fmt == 1), "sp_maxpool2_fwd_x8: bad arguments");
+  return maxpool2_fwd_impl(x8, y, SP_BF16, B, D, H, W, CP, stats, SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8 ? q8_scale : 1.f, q8_fmt}, stream, x8_plane);
 }
 // bf16 pairs (SP_HL): x / y are the hi halves, the lo halves x_lo_delta / y_lo_delta bytes behind them; the maximum of the pair
 // VALUES (hi + lo) is written as a pair again, statistics of those values
@@ -1050,7 +1061,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ low, Dims dl, int CPu, const T* __restrict__ skip,
                                                           Dims ds, int CPs, T* __restrict__ cat, int CPd, int64_t cat_plane,
                                                           double* __restrict__ stats, const SpQ8 q8,
-                                                          int64_t low_lo = 0, int64_t skip_lo = 0, int64_t cat_lo = 0) {
+                                                          int64_t low_lo = 0, int64_t skip_lo = 0, int64_t cat_lo = 0, int64_t skip8_plane = 0) {
+  // skip8_plane > 0: skip is the e4m3 plane-major copy [CPs/16][B][Ds][Hs][Ws][16 bytes] of the skip tensor (fp8 mode: no 16-bit one)
   __shared__ float red[4 * 32];
   // 1-D grid of gx * np workgroups, gx a multiple of 8: workgroup id -> (chunk, plane) such that the np planes of a chunk are
   // CONSECUTIVE workgroups of ONE XCD (ids 8 apart share an L2).  A plane takes 32 bytes of every source voxel; with the planes
@@ -1115,9 +1127,17 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
       const T* base = skip + (p - nup) * 16 + half * 8;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        RawOct<T> rr;
-        rr.load(base + ((((int64_t)b * ds.D + 2 * zl + (k >> 1) + oz) * ds.H + 2 * yl + (k & 1) + oy) * ds.W + xo + ox) * CPs, skip_lo);
-        raw_get2(rr, out[k]);
+        const int64_t vs_ = (((int64_t)b * ds.D + 2 * zl + (k >> 1) + oz) * ds.H + 2 * yl + (k & 1) + oy) * ds.W + xo + ox;
+        if (skip8_plane) {
+          float f8_[8];
+          sp_ld8_e4m3(skip, skip8_plane, vs_, 2 * (p - nup) + half, f8_);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { out[k][j].x = f8_[2 * j]; out[k][j].y = f8_[2 * j + 1]; }
+        } else {
+          RawOct<T> rr;
+          rr.load(base + vs_ * CPs, skip_lo);
+          raw_get2(rr, out[k]);
+        }
       }
     }
 #pragma unroll
@@ -1156,7 +1176,8 @@ __global__ __launch_bounds__(256) void upcat_rows_kernel(const T* __restrict__ l
 
 static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CPs, void* cat, int32_t CPd,
                       int32_t dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
-                      int32_t Ws, int64_t cat_plane, double* stats, SpQ8 q8, sp_stream_t stream, const int64_t* hl_lo = nullptr) {
+                      int32_t Ws, int64_t cat_plane, double* stats, SpQ8 q8, sp_stream_t stream, const int64_t* hl_lo = nullptr,
+                      int64_t skip8_plane = 0) {
   static const int64_t no_lo_[3] = {0, 0, 0};
   SP_CHECK_ARG(dtype != SP_HL || (hl_lo && hl_lo[0] && hl_lo[1] && hl_lo[2] && !q8.p && cat), "sp_upsample2_crop_cat_fwd_hl: bf16 pairs need the three lo deltas");
   if (!hl_lo) hl_lo = no_lo_;
@@ -1180,13 +1201,14 @@ static int upcat_impl(const void* low, int32_t CPu, const void* skip, int32_t CP
     const unsigned gx = ((unsigned)(want < cap ? want : cap) + 7) / 8 * 8;
     dim3 grid(gx * (unsigned)(CPd / 16));
     SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && q8.plane >= (int64_t)B * D * H * W * 8 * 16 && q8.scale > 0.f), "sp_upsample2_crop_cat_fwd_q8: bf16 tensors only");
-    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0);
+    SP_CHECK_ARG(skip8_plane == 0 || (dtype == SP_BF16 && skip8_plane >= (int64_t)B * Ds * Hs * Ws * 16), "sp_upsample2_crop_cat_fwd_q8s8: e4m3 skip planes of >= B Ds Hs Ws 16 bytes");
+    if (dtype == SP_BF16) hipLaunchKernelGGL(upcat_rows_kernel<bf16_t>, grid, dim3(256), 0, ST(stream), (const bf16_t*)low, dl, CPu, (const bf16_t*)skip, ds, CPs, (bf16_t*)cat, CPd, cat_plane, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0, skip8_plane);
     else if (dtype == SP_HL) hipLaunchKernelGGL(upcat_rows_kernel<sp_hl_t>, grid, dim3(256), 0, ST(stream), (const sp_hl_t*)low, dl, CPu, (const sp_hl_t*)skip, ds, CPs, (sp_hl_t*)cat, CPd, cat_plane, stats, q8, hl_lo[0], hl_lo[1], hl_lo[2]);
     else hipLaunchKernelGGL(upcat_rows_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)low, dl, CPu, (const float*)skip, ds, CPs, (float*)cat, CPd, cat_plane, stats, q8, (int64_t)0, (int64_t)0, (int64_t)0);
     SP_CHECK_LAUNCH("sp_upsample2_crop_cat_fwd(rows)");
     return SP_OK;
   }
-  SP_CHECK_ARG(!q8.p, "sp_upsample2_crop_cat_fwd_q8: the fp8 copy is written by the plane-major (row-ordered) kernel only: cat_plane != 0, channel counts multiples of 16");
+  SP_CHECK_ARG(!q8.p && !skip8_plane, "sp_upsample2_crop_cat_fwd_q8: the fp8 copy is written (and an e4m3 skip tensor read) by the plane-major (row-ordered) kernel only: cat_plane != 0, channel counts multiples of 16");
   const int64_t nblk = (int64_t)B * D * H * W;          // one thread-slot per 2x2x2 output block
   const unsigned grid = grid_for(nblk, om.vpb);
   const size_t sh = (size_t)CPd * 2 * sizeof(float);
@@ -1218,6 +1240,15 @@ extern "C" int sp_upsample2_crop_cat_fwd_q8(const void* low, int32_t CPu, const 
   return upcat_impl(low, CPu, skip, CPs, cat, CPd, dtype, B, D, H, W, Ds, Hs, Ws, cat_plane, stats,
                     SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream);
 }
+// the skip tensor as its e4m3 plane-major copy (fp8 mode: the producing convolution stored no 16-bit tensor); low stays 16-bit
+extern "C" int sp_upsample2_crop_cat_fwd_q8s8(const void* low, int32_t CPu, const void* skip8, int64_t skip8_plane, int32_t CPs, void* cat,
+                                              int32_t CPd, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ds, int32_t Hs,
+                                              int32_t Ws, int64_t cat_plane, double* stats, void* q8, int64_t q8_plane, int32_t q8_fmt,
+                                              float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(q8 && (q8_fmt == 0 || q8_fmt == 1) && skip8_plane > 0 && cat_plane > 0, "sp_upsample2_crop_cat_fwd_q8s8: bad arguments (plane-major output only)");
+  return upcat_impl(low, CPu, skip8, CPs, cat, CPd, SP_BF16, B, D, H, W, Ds, Hs, Ws, cat_plane, stats,
+                    SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8_scale, q8_fmt}, stream, nullptr, skip8_plane);
+}
 
 // ------------------------------------------------------------------------------------------------ fused backward pieces
 // Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
@@ -1227,7 +1258,8 @@ template <typename T, int ACT>
 __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
     const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, int ccs0, int cstride, Dims di, int CP, Dims dc,
-    OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8) {
+    OctMap om, int act, float ap, T* __restrict__ dz, double* __restrict__ dbias, const SpQ8 q8, int64_t y8_plane = 0) {
+  // y8_plane > 0: y is its e4m3 plane-major copy (fp8 mode: no 16-bit tensor was stored)
   extern __shared__ float red[];
   float* cpl = red + CP;                              // pool-side coefficients [3][CP]: used once per window -> LDS, not VGPRs
   const int slot = fdiv(threadIdx.x, om.d_oc), oc = threadIdx.x - slot * om.OC;
@@ -1256,6 +1288,7 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
       uf_(v, b, wz, wy, wx);
       const bool pooled = gp && wz < Dp && wy < Hp && wx < Wp;
       RawOct<T> yr[8];
+      uint2 yr8[8];
       float m[8]; int am[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = 0; }
@@ -1263,14 +1296,24 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int iz = min(2 * wz + (k >> 2), di.D - 1), iy = min(2 * wy + ((k >> 1) & 1), di.H - 1), ix = min(2 * wx + (k & 1), di.W - 1);
-        yr[k].load(y + ((((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix) * CP + oc * 8);
+        const int64_t vi_ = (((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix;
+        if (y8_plane) yr8[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(y) + (int64_t)(oc >> 1) * y8_plane + vi_ * 16 + (oc & 1) * 8);
+        else yr[k].load(y + vi_ * CP + oc * 8);
       }
+      auto get_y = [&](int k, float* out) {
+        if (y8_plane) {
+          typedef float f2v_ __attribute__((ext_vector_type(2)));
+          const f2v_ a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].x, true);
+          const f2v_ a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].y, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].y, true);
+          out[0] = a0[0]; out[1] = a0[1]; out[2] = a1[0]; out[3] = a1[1]; out[4] = a2[0]; out[5] = a2[1]; out[6] = a3[0]; out[7] = a3[1];
+        } else yr[k].get(out);
+      };
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int iz = 2 * wz + (k >> 2), iy = 2 * wy + ((k >> 1) & 1), ix = 2 * wx + (k & 1);
         if (iz < di.D && iy < di.H && ix < di.W) {
           float yv[8];
-          yr[k].get(yv);
+          get_y(k, yv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) if (yv[j] > m[j]) { m[j] = yv[j]; am[j] = k; }
         }
@@ -1292,7 +1335,7 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
         const int iz = 2 * wz + (k >> 2), iy = 2 * wy + ((k >> 1) & 1), ix = 2 * wx + (k & 1);
         if (iz < di.D && iy < di.H && ix < di.W) {
           float d[8], yv[8];
-          yr[k].get(yv);
+          get_y(k, yv);
 #pragma unroll
           for (int j = 0; j < 8; ++j) d[j] = (pooled && am[j] == k) ? dp[j] : 0.f;
           const int qz = iz - cz, qy = iy - cy, qx = ix - cx;
@@ -1322,8 +1365,9 @@ static int pool_skip_impl(const void* y, const void* gp, const float* coefp, con
                           const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
                           int32_t dtype, int32_t B, int32_t D,
                           int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc, int32_t act,
-                          float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream) {
+                          float act_param, void* dz, double* dbias_sums, SpQ8 q8, sp_stream_t stream, int64_t y8_plane = 0) {
   SP_CHECK_ARG(y && (dz || q8.p) && CP % 8 == 0, "sp_pool_skip_act_bwd: bad arguments");
+  SP_CHECK_ARG(y8_plane == 0 || (dtype == SP_BF16 && CP % 16 == 0 && y8_plane >= (int64_t)B * D * H * W * 16), "sp_pool_skip_act_bwd_y8: e4m3 planes of >= B D H W 16 bytes");
   SP_CHECK_ARG(!q8.p || (dtype == SP_BF16 && CP % 16 == 0 && q8.plane >= (int64_t)B * D * H * W * 16 && q8.scale > 0.f),
                "sp_pool_skip_act_bwd_q8: bf16 tensors of whole 16-channel planes");
   SP_CHECK_VOX((int64_t)B * D * H * W, "sp_pool_skip_act_bwd");
@@ -1338,7 +1382,7 @@ static int pool_skip_impl(const void* y, const void* gp, const float* coefp, con
 #define SP_L(A_)                                                                                                                          \
   if (dtype == SP_BF16) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
                                            (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0,   \
-                                           coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums, q8);                      \
+                                           coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums, q8, y8_plane);            \
   else hipLaunchKernelGGL((pool_skip_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, \
                           coefp, (const float*)cat, (const float*)gs, coefs, cs0, CPcat, coef_c0, coef_stride, di, CP, dc, om, act,       \
                           act_param, (float*)dz, dbias_sums, q8)
@@ -1354,6 +1398,16 @@ extern "C" int sp_pool_skip_act_bwd(const void* y, const void* gp, const float* 
                                     float act_param, void* dz, double* dbias_sums, sp_stream_t stream) {
   return pool_skip_impl(y, gp, coefp, cat, gs, coefs, cs0, CPcat, coef_c0, coef_stride, dtype, B, D, H, W, CP, Dc, Hc, Wc, act,
                         act_param, dz, dbias_sums, SpQ8{nullptr, 0, 1.f, 0}, stream);
+}
+// y given as its e4m3 plane-major copy (fp8 mode: the producing convolution stored no 16-bit tensor); q8 may be NULL
+extern "C" int sp_pool_skip_act_bwd_y8(const void* y8, int64_t y8_plane, const void* gp, const float* coefp, const void* gs,
+                                       const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,
+                                       int32_t B, int32_t D, int32_t H, int32_t W, int32_t CP, int32_t Dc, int32_t Hc, int32_t Wc,
+                                       int32_t act, float act_param, void* dz, double* dbias_sums, void* q8, int64_t q8_plane,
+                                       int32_t q8_fmt, float q8_scale, sp_stream_t stream) {
+  SP_CHECK_ARG(y8_plane > 0 && (!q8 || q8_fmt == 0 || q8_fmt == 1), "sp_pool_skip_act_bwd_y8: bad arguments");
+  return pool_skip_impl(y8, gp, coefp, nullptr, gs, coefs, cs0, CPcat, coef_c0, coef_stride, SP_BF16, B, D, H, W, CP, Dc, Hc, Wc, act,
+                        act_param, dz, dbias_sums, SpQ8{reinterpret_cast<unsigned char*>(q8), q8_plane, q8 ? q8_scale : 1.f, q8_fmt}, stream, y8_plane);
 }
 extern "C" int sp_pool_skip_act_bwd_q8(const void* y, const void* gp, const float* coefp, const void* cat, const void* gs,
                                        const float* coefs, int32_t cs0, int32_t CPcat, int32_t coef_c0, int32_t coef_stride,

@@ -163,6 +163,9 @@ _SIGS = {
     "sp_maxpool2_fwd_q8": ([vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, i64, i32, f32, vp], i32),
     "sp_bn_act_bwd_q8": ([vp, vp, vp, i32, i64, i32, i32, f32, vp, vp, vp, i64, i32, f32, vp], i32),
     "sp_bn_act_bwd_y8": ([vp, vp, i64, vp, i64, i32, i32, f32, vp, vp, vp, i64, i32, f32, vp], i32),
+    "sp_maxpool2_fwd_x8": ([vp, i64, vp, i32, i32, i32, i32, i32, vp, vp, i64, i32, f32, vp], i32),
+    "sp_upsample2_crop_cat_fwd_q8s8": ([vp, i32, vp, i64, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, vp, i64, i32, f32, vp], i32),
+    "sp_pool_skip_act_bwd_y8": ([vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp, vp, i64, i32, f32, vp], i32),
     "sp_upsample2_crop_cat_fwd_q8": ([vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, vp, vp, i64, i32, f32, vp], i32),
     "sp_pool_skip_act_bwd_q8": ([vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                  f32, vp, vp, vp, i64, i32, f32, vp], i32),

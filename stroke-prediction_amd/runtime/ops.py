@@ -887,8 +887,14 @@ def bn_act_bwd(g, y, coef, dtype, act, act_param, dz, dbias, q8=None, group_vox=
            ptr(dbias), stream())
 
 
-def maxpool2_fwd(x, y, dtype, stats=None, q8=None):
+def maxpool2_fwd(x, y, dtype, stats=None, q8=None, x8=None):
+    """x8: the e4m3 plane-major copy of x, read INSTEAD of x (fp8 mode: x was not stored; x gives the shape)"""
     B, D, H, W, CP = x.shape
+    if x8 is not None:
+        assert dtype == L.SP_BF16 and x8.dtype == torch.uint8 and x8.numel() == x.numel()
+        q = _q8_args(q8, y.numel() // CP) if q8 is not None else (None, 0, 0, 1.0)
+        L.call("sp_maxpool2_fwd_x8", ptr(x8), B * D * H * W * 16, ptr(y), B, D, H, W, CP, ptr(stats), *q, stream())
+        return
     if q8 is not None:
         L.call("sp_maxpool2_fwd_q8", ptr(x), ptr(y), dtype, B, D, H, W, CP, ptr(stats), *_q8_args(q8, y.numel() // CP), stream())
         return
@@ -900,13 +906,19 @@ def upsample2_fwd(x, y, dtype, stats=None):
     L.call("sp_upsample2_fwd", ptr(x), ptr(y), dtype, B, D, H, W, CP, y.shape[-1], ptr(stats), stream())
 
 
-def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False, q8=None, store=True):
+def upsample2_crop_cat_fwd(low, skip, cat, dtype, stats=None, planar=False, q8=None, store=True, skip8=None):
     """cat = concat(upsample2(low), centre_crop(skip)) in one pass (+ per-channel (sum, sum^2) of cat into stats).
     planar: cat (same shape) is written plane-major [C/16][B][D][H][W][16] for the DMA consumers (x_planar=True).
-    store=False (with q8): the 16-bit tensor is not written -- every reader takes the fp8 copy."""
+    store=False (with q8): the 16-bit tensor is not written -- every reader takes the fp8 copy.
+    skip8 (with q8): the e4m3 plane-major copy of skip, read INSTEAD of skip (fp8 mode: skip was not stored; skip gives the shape)"""
     B, D, H, W, CPu = low.shape
     _, Ds, Hs, Ws, CPs = skip.shape
     assert tuple(cat.shape) == (B, 2 * D, 2 * H, 2 * W, CPu + CPs), (tuple(cat.shape), tuple(low.shape), tuple(skip.shape))
+    if skip8 is not None:
+        assert q8 is not None and planar and CPu % 16 == 0 and CPs % 16 == 0 and dtype == L.SP_BF16 and skip8.numel() == skip.numel()
+        L.call("sp_upsample2_crop_cat_fwd_q8s8", ptr(low), CPu, ptr(skip8), B * Ds * Hs * Ws * 16, CPs, ptr(cat) if store else None, CPu + CPs,
+               B, D, H, W, Ds, Hs, Ws, B * 8 * D * H * W * 16, ptr(stats), *_q8_args(q8, B * 8 * D * H * W), stream())
+        return
     if q8 is not None:
         assert planar and CPu % 16 == 0 and CPs % 16 == 0
         L.call("sp_upsample2_crop_cat_fwd_q8", ptr(low), CPu, ptr(skip), CPs, ptr(cat) if store else None, CPu + CPs, dtype, B, D, H, W, Ds, Hs, Ws,
@@ -923,14 +935,21 @@ def crop_copy(src, dst, c0, dtype, stats=None):
     L.call("sp_crop_copy", ptr(src), ptr(dst), dtype, B, Ds, Hs, Ws, CPs, Dd, Hd, Wd, CPd, c0, ptr(stats), stream())
 
 
-def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias, coef_c0=0, coef_stride=0, q8=None):
+def pool_skip_act_bwd(y, gp, coefp, cat, gs, coefs, cs0, dtype, act, act_param, dz, dbias, coef_c0=0, coef_stride=0, q8=None, y8=None):
     """gs: gradient tensor holding the skip part in channels [cs0, cs0+CP) (pitch gs.shape[-1]); coefs indexed with
-    (coef_c0, coef_stride) when the gradient is a dense tensor of the skip part only (else like the gradient)."""
+    (coef_c0, coef_stride) when the gradient is a dense tensor of the skip part only (else like the gradient).
+    y8: the e4m3 plane-major copy of y, read INSTEAD of y (fp8 mode: y was not stored; y gives the shape)"""
     B, D, H, W, CP = y.shape
     if gs is not None:
         _, Dc, Hc, Wc, CPcat = gs.shape
     else:
         Dc = Hc = Wc = CPcat = 0
+    if y8 is not None:
+        assert dtype == L.SP_BF16 and y8.dtype == torch.uint8 and y8.numel() == y.numel()
+        q = _q8_args(q8, B * D * H * W) if q8 is not None else (None, 0, 0, 1.0)
+        L.call("sp_pool_skip_act_bwd_y8", ptr(y8), B * D * H * W * 16, ptr(gp), ptr(coefp), ptr(gs), ptr(coefs), cs0, CPcat, coef_c0, coef_stride,
+               B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), *q, stream())
+        return
     if q8 is not None:
         L.call("sp_pool_skip_act_bwd_q8", ptr(y), ptr(gp), ptr(coefp), ptr(cat), ptr(gs), ptr(coefs), cs0, CPcat, coef_c0, coef_stride,
                dtype, B, D, H, W, CP, Dc, Hc, Wc, act, act_param, ptr(dz), ptr(dbias), *_q8_args(q8, B * D * H * W), stream())

@@ -19,6 +19,7 @@ from . import lib as L
 from . import ops as O
 from .layers import ConvLayer, FirstConvLayer, Scratch
 
+F8_Y2_E4M3 = bool(int(os.environ.get("SP_F8_Y2_E4M3", "1")))      # ... and the down blocks' second activations (pooling / skip crop / pool backward read the copy)
 F8_Y1_E4M3 = bool(int(os.environ.get("SP_F8_Y1_E4M3", "1")))      # fp8 mode: the first layer's output lives as its e4m3 copy only (0: A/B)
 
 LEAKY = 0.01
@@ -251,9 +252,11 @@ class UnetEngine:
                 c1.store_y = bool(training and c2.f8_wgrad is None)
             y1 = c1.forward(x, params, bufs, training, st(c2))
             self._f8_input(c2, y1)
+            self._f8_y2_e4m3_only(i, training)
             y2 = c2.forward(y1, params, bufs, training)
             if i < S:
-                O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]), q8=self._f8_fused_input(self.conv[i + 1][0]))
+                O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]), q8=self._f8_fused_input(self.conv[i + 1][0]),
+                               x8=None if c2.store_y else c2.y8)
                 x = self.pooled[i]
         low = y2
         for u in range(S + 1, 2 * S):
@@ -266,7 +269,10 @@ class UnetEngine:
                 if training:
                     c1._init_bwd()
                 keep = training and c1.f8_wgrad is None
-            O.upsample2_crop_cat_fwd(low, self.conv[2 * S - u][1].y, self.cat[u], dt, st(c1), planar=self.cat_planar[u], q8=q8, store=keep)
+            sk = self.conv[2 * S - u][1]
+            assert sk.store_y or q8 is not None
+            O.upsample2_crop_cat_fwd(low, sk.y, self.cat[u], dt, st(c1), planar=self.cat_planar[u], q8=q8, store=keep,
+                                     skip8=None if sk.store_y else sk.y8)
             self._f8_input(c1, self.cat[u])
             self._f8_e4m3_only(c1, c2, training)
             y1 = c1.forward(self.cat[u], params, bufs, training, st(c2))
@@ -336,6 +342,25 @@ class UnetEngine:
                 return
         c1.store_y = False
 
+    def _f8_y2_e4m3_only(self, i, training):
+        """fp8 mode, down block i: the second convolution's output is read by the pooling kernel, by the concatenation of up block
+        2S - i (its skip half) and by sp_pool_skip_act_bwd -- all three take the e4m3 copy (sp_maxpool2_fwd_x8,
+        sp_upsample2_crop_cat_fwd_q8s8, sp_pool_skip_act_bwd_y8), so the 16-bit tensor is not written"""
+        from . import f8 as F8
+        S = self.scales
+        c2 = self.conv[i][1]
+        c2.store_y = True
+        if not (self.f8 and F8_Y2_E4M3 and i < S and isinstance(c2.f8_fwd, (F8.ConvRunnerF8, F8.ConvRunnerF8Split)) and c2.cpo % 16 == 0):
+            return
+        u = 2 * S - i
+        cu1 = self.conv[u][0]
+        src = self.f8_src.get(cu1)
+        if not (self.cat_planar.get(u) and self.conv[u - 1][1].cpo % 16 == 0 and src is not None and src[0] == "quant" and ConvLayer.FUSE_Q8
+                and (training or cu1 not in self._f8_train_only)):      # (the row-ordered concat kernel with its e4m3 output: _f8_fused_input(cu1))
+            return
+        c2.want_y8 = True
+        c2.store_y = False
+
     def _f8_fused_input(self, lay):
         """fp8 mode: (lay.x8, e4m3, 1.0) when the pooling / concatenation kernel that writes lay's input should write its e4m3
         copy as well (the separate quantisation pass is then skipped once), else None"""
@@ -380,10 +405,10 @@ class UnetEngine:
         dt = self.dtype
         if isinstance(g, tuple):
             O.pool_skip_act_bwd(prod.y, gp, coefp, None, g[1], coef, 0, dt, L.ACT_LEAKY, LEAKY, prod.dz_target(), prod.dbias_sums,
-                                coef_c0=c_up, coef_stride=cat.shape[-1], q8=prod.dz8_out())
+                                coef_c0=c_up, coef_stride=cat.shape[-1], q8=prod.dz8_out(), y8=None if prod.store_y else prod.y8)
         else:
             O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz_target(), prod.dbias_sums,
-                                q8=prod.dz8_out())
+                                q8=prod.dz8_out(), y8=None if prod.store_y else prod.y8)
 
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dseg, seg, params, grads, ready=None):

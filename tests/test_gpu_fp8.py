@@ -228,7 +228,8 @@ def test_unet4_fp8_mode_matches_the_fp8_emulating_oracle():
     n_out = int(np.prod(seg.shape)) // 2
     wg8 = {l.conv_prefix for l in eng.layers if l.f8_wgrad is not None}
     assert F8.WGRAD == (len(wg8) > 0), wg8
-    f8 = dict(layers=names, grad_scale=nets.f8_grad_scale(n_out), wgrad=wg8)
+    y2 = {i for i in range(1, eng.scales) if not eng.conv[i][1].store_y}      # down blocks whose output lives as its e4m3 copy only
+    f8 = dict(layers=names, grad_scale=nets.f8_grad_scale(n_out), wgrad=wg8, y2_e4m3=y2)
     sd = W.make_state_dict(W.unet_spec(CH4), seed)
     tr = nets.trainable(sd)
     for k in tr:
@@ -544,6 +545,67 @@ def test_e4m3_only_activations_equal_the_stored_ones():
         res.append((dz, dz8, sums.sum(0)))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and float(res[0][0].float().abs().max()) > 0
     torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-12, atol=1e-20)
+
+
+def test_readers_of_an_e4m3_only_block_output_equal_the_16_bit_ones():
+    """fp8 mode, second convolution of a down block: its output exists as the e4m3 copy only.  The three kernels that read it --
+    pooling, the skip half of the concatenation, pool + skip backward -- give bit for bit what the 16-bit kernels make of the
+    de-quantised values (e4m3 values are exact in bf16)"""
+    g_ = torch.Generator().manual_seed(31)
+    B, CP, dims = 2, 32, (10, 12, 22)
+    S = 2.0 ** 18
+
+    def cl(shape_dims, cp, scale=1.0):
+        return (torch.randn((B,) + tuple(shape_dims) + (cp,), generator=g_) * scale).bfloat16().to(DEV)
+
+    def e4m3_of(t):          # (plane-major e4m3 copy, its de-quantised channels-last bf16 twin)
+        t8 = F8.alloc_f8(B, t.shape[1:4], t.shape[-1], DEV)
+        F8.quantize(t, t8, F8.E4M3, 1.0)
+        deq = t8.view(torch.float8_e4m3fn).float().permute(1, 2, 3, 4, 0, 5).reshape(t.shape).to(torch.bfloat16).contiguous()
+        return t8, deq
+    y8, y = e4m3_of(cl(dims, CP))
+    # pooling
+    pd = tuple(d // 2 for d in dims)
+    res = []
+    for use8 in (False, True):
+        p = torch.full((B,) + pd + (CP,), 7.0, dtype=torch.bfloat16, device=DEV)
+        p8 = F8.alloc_f8(B, pd, CP, DEV)
+        st = O.reduce_rows(CP, 2, DEV)
+        O.maxpool2_fwd(y, p, L.SP_BF16, st, q8=(p8, F8.E4M3, 1.0), x8=y8 if use8 else None)
+        res.append((p, p8, st.sum(0)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and float(res[0][0].float().abs().max()) > 0
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-12, atol=1e-9)
+    # pool + skip backward
+    gp = cl(pd, CP, 1e-5)
+    cd = tuple(d - 4 for d in dims)
+    gs = cl(cd, 64, 1e-5)
+    coefp = (torch.randn(3, CP, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+    coefs = (torch.randn(3, 64, generator=g_) * torch.tensor([1.0, 1e-6, 1e-6]).view(3, 1)).to(DEV)
+    res = []
+    for use8 in (False, True):
+        dz, dz8 = torch.empty_like(y), F8.alloc_f8(B, dims, CP, DEV)
+        db = O.reduce_rows(CP, 1, DEV)
+        O.pool_skip_act_bwd(y, gp, coefp, None, gs, coefs, 32, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz, db, q8=(dz8, F8.E5M2, S), y8=y8 if use8 else None)
+        res.append((dz, dz8, db.sum(0)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and float(res[0][0].float().abs().max()) > 0
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-12, atol=1e-20)
+    # skip half of the concatenation (plane-major, e4m3 output; the 16-bit output with and without)
+    ld = (4, 5, 9)
+    low = cl(ld, 32)
+    sk8, sk = e4m3_of(cl(tuple(2 * d + 4 for d in ld), 16))
+    od = tuple(2 * d for d in ld)
+    res = []
+    for use8 in (False, True):
+        cat = torch.full((B,) + od + (48,), 7.0, dtype=torch.bfloat16, device=DEV)
+        cat8 = F8.alloc_f8(B, od, 48, DEV)
+        st = O.reduce_rows(48, 2, DEV)
+        O.upsample2_crop_cat_fwd(low, sk, cat, L.SP_BF16, st, planar=True, q8=(cat8, F8.E4M3, 1.0), skip8=sk8 if use8 else None)
+        res.append((cat, cat8, st.sum(0)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[1][2], res[0][2], rtol=1e-12, atol=1e-9)
+    cat8b = F8.alloc_f8(B, od, 48, DEV)
+    O.upsample2_crop_cat_fwd(low, sk, res[0][0], L.SP_BF16, None, planar=True, q8=(cat8b, F8.E4M3, 1.0), store=False, skip8=sk8)
+    assert torch.equal(cat8b, res[0][1])
 
 
 def test_fused_fp8_shadow_outputs_equal_the_quantisation_pass():
