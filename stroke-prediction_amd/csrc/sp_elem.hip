@@ -1254,7 +1254,7 @@ extern "C" int sp_upsample2_crop_cat_fwd_q8s8(const void* low, int32_t CPu, cons
 // Block output y feeds MaxPool3d(2,2) (-> next block's BN) and, centre-cropped, the skip concat.
 // One thread = one 2x2x2 window x 8 channels: argmax is the FIRST maximum in (z,y,x) scan order
 // (ATen max_pool3d), pool gradient = coefp0*gp + coefp1*p + coefp2 with p = max recomputed here.
-template <typename T, int ACT>
+template <typename T, int ACT, bool Y8 = false>      // Y8: y is its e4m3 plane-major copy (a compile-time switch: both register sets at once spill)
 __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
     const T* __restrict__ y, const T* __restrict__ gp, const float* __restrict__ coefp, const T* __restrict__ cat,
     const T* __restrict__ gs, const float* __restrict__ coefs, int cs0, int CPcat, int ccs0, int cstride, Dims di, int CP, Dims dc,
@@ -1287,8 +1287,8 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
       int b, wz, wy, wx;
       uf_(v, b, wz, wy, wx);
       const bool pooled = gp && wz < Dp && wy < Hp && wx < Wp;
-      RawOct<T> yr[8];
-      uint2 yr8[8];
+      RawOct<T> yr[Y8 ? 1 : 8];
+      uint2 yr8[Y8 ? 8 : 1];
       float m[8]; int am[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) { m[j] = -INFINITY; am[j] = 0; }
@@ -1297,11 +1297,11 @@ __global__ __launch_bounds__(256, 4) void pool_skip_act_bwd_kernel(
       for (int k = 0; k < 8; ++k) {
         const int iz = min(2 * wz + (k >> 2), di.D - 1), iy = min(2 * wy + ((k >> 1) & 1), di.H - 1), ix = min(2 * wx + (k & 1), di.W - 1);
         const int64_t vi_ = (((int64_t)b * di.D + iz) * di.H + iy) * di.W + ix;
-        if (y8_plane) yr8[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(y) + (int64_t)(oc >> 1) * y8_plane + vi_ * 16 + (oc & 1) * 8);
+        if constexpr (Y8) yr8[k] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned char*>(y) + (int64_t)(oc >> 1) * y8_plane + vi_ * 16 + (oc & 1) * 8);
         else yr[k].load(y + vi_ * CP + oc * 8);
       }
       auto get_y = [&](int k, float* out) {
-        if (y8_plane) {
+        if constexpr (Y8) {
           typedef float f2v_ __attribute__((ext_vector_type(2)));
           const f2v_ a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].x, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].x, true);
           const f2v_ a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].y, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)yr8[k].y, true);
@@ -1380,7 +1380,10 @@ static int pool_skip_impl(const void* y, const void* gp, const float* coefp, con
   const unsigned grid = grid_for(nwin, om.vpb);
   const size_t sh = (size_t)CP * 7 * sizeof(float);
 #define SP_L(A_)                                                                                                                          \
-  if (dtype == SP_BF16) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
+  if (dtype == SP_BF16 && y8_plane) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_, true>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
+                                           (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0,   \
+                                           coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums, q8, y8_plane);            \
+  else if (dtype == SP_BF16) hipLaunchKernelGGL((pool_skip_act_bwd_kernel<bf16_t, A_>), dim3(grid), dim3(256), sh, ST(stream), (const bf16_t*)y, \
                                            (const bf16_t*)gp, coefp, (const bf16_t*)cat, (const bf16_t*)gs, coefs, cs0, CPcat, coef_c0,   \
                                            coef_stride, di, CP, dc, om, act, act_param, (bf16_t*)dz, dbias_sums, q8, y8_plane);            \
   else hipLaunchKernelGGL((pool_skip_act_bwd_kernel<float, A_>), dim3(grid), dim3(256), sh, ST(stream), (const float*)y, (const float*)gp, \
