@@ -799,11 +799,13 @@ __global__ __launch_bounds__(256) void wgrad_finish_folded_groups_kernel(const f
     // period CiP), then one atomic per (workgroup, ci) into a replica row
     if (bn_sums && rl == 0) {
       const int c0 = (int)(((int64_t)blockIdx.x * 32) % CiP);
-      const int first = ((el - c0) % CiP + CiP) % CiP;      // el plays the channel here
-      if (el < CiP && el < Cin && first < 32) {
+      // a lane plays the channels el, el + 32, ... (CiP > 32: the 48- and 64-channel tiles; one pass otherwise)
+      for (int ch = el; ch < CiP && ch < Cin; ch += 32) {
+        const int first = ((ch - c0) % CiP + CiP) % CiP;
+        if (first >= 32) continue;
         double s0 = 0.0, s1 = 0.0;
         for (int k = first; k < 32; k += CiP) { s0 += bred[0][k]; s1 += bred[1][k]; }
-        double* o = bn_sums + ((size_t)g * bn_nrep + (blockIdx.x % bn_nrep)) * bn_cp * 2 + (size_t)el * 2;
+        double* o = bn_sums + ((size_t)g * bn_nrep + (blockIdx.x % bn_nrep)) * bn_cp * 2 + (size_t)ch * 2;
         atomicAdd(&o[0], s0);
         atomicAdd(&o[1], s1);
       }

@@ -340,7 +340,10 @@ def test_z_marching_forward_with_batchnorm_folded_per_group(cin, cout, dims, pad
 
 # ------------------------------------------------------------------------------------------------ weight gradient on the raw input
 @pytest.mark.parametrize("cin,cout,dims,pad,B,gb", [(16, 16, (9, 36, 40), (1, 0, 0), 6, 2), (24, 24, (6, 34, 36), (1, 2, 2), 4, 1),
-                                                    (24, 16, (5, 33, 20), (1, 2, 2), 8, 2), (16, 24, (4, 40, 17), (1, 1, 1), 4, 2)])
+                                                    (24, 16, (5, 33, 20), (1, 2, 2), 8, 2), (16, 24, (4, 40, 17), (1, 1, 1), 4, 2),
+                                                    # input tiles wider than 32 channels: the finish kernel's BatchNorm-backward sums walk the channels in
+                                                    # strides of 32 (channels >= 32 were dropped)
+                                                    (48, 16, (5, 33, 20), (1, 1, 1), 4, 2), (64, 16, (4, 21, 18), (1, 0, 0), 4, 2)])
 def test_weight_gradient_on_the_raw_input_with_batchnorm_folded_per_group(cin, cout, dims, pad, B, gb, monkeypatch):
     """y = conv(zero-padded (s_g x + t_g)): dW, dbias and the BatchNorm-backward sums (sum g, sum g x) of the layer input, from
     (a) the border-class sums of dz that the pass forming dz leaves (sp_bn_act_bwd_groups_cls), (b) the weight gradient kernel on the
@@ -439,15 +442,16 @@ def test_fused_cae_reconstruction_loss_equals_the_composed_one(factor, monkeypat
         torch.testing.assert_close(a[k], b[k], rtol=1e-5, atol=1e-9)
 
 
-def test_pointwise_layer_on_the_raw_input_per_group(monkeypatch):
+@pytest.mark.parametrize("cin", [16, 48, 64])
+def test_pointwise_layer_on_the_raw_input_per_group(cin, monkeypatch):
     """the CAE's 1x1x1 16 -> 16 layer in the batched passes: forward with each group's BatchNorm applied on the operand load (one launch,
     statistics per group), weight gradient on the raw input with group-pure partial blocks + the group-aware folded finish"""
     gen = torch.Generator().manual_seed(77)
-    cin = cout = 16
+    cout = 16
     B, gb, dims = 4, 2, (4, 16, 32)
     G = B // gb
     x = bf(torch.randn(B, cin, *dims, generator=gen) + 0.2)
-    w = (torch.randn(cout, cin, 1, 1, 1, generator=gen) / 4).requires_grad_(True)
+    w = (torch.randn(cout, cin, 1, 1, 1, generator=gen) / math.sqrt(cin)).requires_grad_(True)
     bias = (torch.randn(cout, generator=gen) * 0.1).requires_grad_(True)
     scale, shift = torch.rand(G, cin, generator=gen) + 0.5, torch.randn(G, cin, generator=gen)
     gidx = torch.arange(B) // gb
