@@ -6,7 +6,8 @@
 // What the tiled kernel (sp_conv_dma.hip, conv_igemm_dma_kernel) and the ring kernel (conv_igemm_zs_kernel) leave on the
 // table, by their own phase stamps: stage -> K loop -> store run one after the other inside a workgroup, every input
 // plane is staged 2-3 times (z halo), and with Cout = 16 every activation fragment read from LDS feeds ONE MFMA.
-// Here a workgroup owns a COLUMN of TH x 16 output voxels and marches through the INPUT planes of that column:
+// Here a workgroup owns a COLUMN of th x tw output voxels (<= 16 NW MT of them, flattened row-major onto the MFMA column
+// groups: ConvZmDev.tw / th) and marches through the INPUT planes of that column:
 //
 //   * an input plane zi contributes to the three output planes zi, zi-1, zi-2 (taps dz = 0, 1, 2).  The wave keeps the
 //     accumulators of all three in registers, so a plane is staged ONCE, lives in LDS for exactly one step, and every
@@ -22,7 +23,7 @@
 //     zero page, so every wave issues the same number of DMA instructions per plane and the waits can be counted.
 //
 // K table (host, runtime/plan.py): ktab[s * 4 + g] = byte offset inside a slot of the octet lane group g reads in step s
-// ((plane p * ITH + dy) * 18 + dx) * 32 + octet * 16; weight fragments: [(dz * KS + s) * NT + n] * 64 lanes, packed by
+// (plane p * ITH * 18 + dy * (tw + 2) + dx) * 32 + octet * 16 (a plane keeps its compile-time pitch of ITH x 18 voxels); weight fragments: [(dz * KS + s) * NT + n] * 64 lanes, packed by
 // sp_conv_prep_weights / sp_conv_prep_folded from the matching kmap (the BatchNorm of the un-padded forward convolution is
 // folded into weights and bias there, as for every DMA kernel).
 #include "sp_common.h"
@@ -34,6 +35,11 @@ struct ConvZmDev {
   int32_t nty, ntx;
   uint32_t ncols;
   FastDiv d_tx, d_ty;
+  // the workgroup's output tile: th rows of tw voxels, tw * th <= 16 NW MT.  The 16 voxels of an MFMA column group are 16
+  // CONSECUTIVE voxels of the flattened (row, column) index, so a tile need not be 16 wide: rows of 50 run as 25 x 10 tiles
+  // (250 of 256 slots used) instead of four 16-wide tiles per row (a.TH / a.ITW; 0: the classic NW MT rows x 16)
+  int32_t tw, th, itw;
+  FastDiv d_tw, d_itw;
 };
 
 // ---- diagnostic build (-DSP_ZM_STAMPS, tools/stamp_zm.py): cycles per step segment, summed per wave -----------------
@@ -171,7 +177,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   int kv[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) kv[s] = a.ktab[s * 4 + lg];
-  const int vbase0 = (wave * MT * ITW + lv) * 32;      // this lane's voxel of the wave's first row inside a plane
+  // this lane's voxel of column group m inside a staged plane: flattened tile index f -> (row, column); groups past the tile
+  // (tw th < 16 NW MT) read voxel 0 and never store
+  const int tw = Q.tw, th = Q.th, itw = Q.itw;
+  int vbo[MT];
+  // (row, column) of group m inside the tile, or row -1: recomputed where a piece sets up its store offsets (once per piece)
+  // instead of living in 2 MT registers across the march
+  auto tile_rc = [&](int m, int& fy, int& fx, bool per_piece = true) {
+    int f = (wave * MT + m) * 16 + lv;
+    if (per_piece) asm volatile("" : "+v"(f));      // (opaque: or the compiler hoists the results out of the piece loop -- and spills)
+    fy = (int)fdiv((uint32_t)f, Q.d_tw);
+    fx = f - fy * tw;
+    if (f >= tw * th) { fy = -1; fx = 0; }
+  };
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    int fy, fx;
+    tile_rc(m, fy, fx, false);
+    vbo[m] = fy >= 0 ? (fy * itw + fx) * 32 : 0;
+  }
   const bf16x8* __restrict__ wf = reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(a.wfrag_hi) + (size_t)sl * a.slice_wfrag_stride);
   bf16x8 w[WLDS ? 1 : 3][WLDS ? 1 : KS][WLDS ? 1 : NT];
   const unsigned char* wl = lds + WOFF + lane * 16;           // this lane's 16 bytes of fragment 0
@@ -206,10 +230,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     const int p = (HL && pq >= P) ? pq - P : pq;
     if (HL && pq >= P) lom |= 1 << j;
     const int half = r & 1, vox = r >> 1;
-    const int vy = vox / ITW, vx = vox - vy * ITW;
+    const int vy = (int)fdiv((uint32_t)vox, Q.d_itw), vx = vox - vy * itw;
     const uint32_t pl = a.x_plane ? (uint32_t)p * (uint32_t)a.x_plane : (uint32_t)p * 16u;
     rel[j] = (pl + (uint32_t)((vy * a.Wi + vx) * xpitch + half * 8)) * 2u;
-    crd[j] = vy | (vx << 8) | (ok ? 0 : (1 << 30));
+    crd[j] = (vy & 0xff) | (vx << 8) | ((ok && vy < th + 2) ? 0 : (1 << 30));      // (chunks past the (th + 2) x (tw + 2) halo tile: zero page)
   }
   float bj[NT][4], s1[NT][4], s2[NT][4];
 #pragma unroll
@@ -304,7 +328,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         cur_g = g;
       }
     }
-    const int oy0 = ty * (NW * MT), ox0 = tx * 16;
+    const int oy0 = ty * th, ox0 = tx * tw;
     const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
     const unsigned char* auxb = STATS == 2 ? reinterpret_cast<const unsigned char*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo * 2 : nullptr;
     const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * xpitch * 2;
@@ -341,25 +365,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     const __amdgpu_buffer_rsrc_t yrs_lo = __builtin_amdgcn_make_buffer_rsrc(      // HL: the lo halves of the output
         (void*)(reinterpret_cast<unsigned char*>(yout) + (HL ? a.y_lo_delta : 0)), 0,
         (int)((uint32_t)a.YD * a.YH * a.YW * a.CPo * (uint32_t)sizeof(TOUT)), 0x00020000);
-    const int ox = ox0 + lv;
-    const bool colok = ox < a.Wo;
-    // byte offset of (row m, this lane's voxel and channel quad) inside an output plane, or "outside"
+    // byte offset of (column group m: this lane's voxel and channel quad) inside an output plane, or "outside"
     uint32_t rowoff[MT];
     uint32_t rowok[MT];       // all-ones / zero bit mask (a float 0/1 factor would turn the garbage of a row outside the output into NaN)
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int oy = oy0 + wave * MT + m;
-      const bool ok = colok && oy < a.Ho;
+      int fy, fx;
+      tile_rc(m, fy, fx);
+      const int oy = oy0 + fy, ox = ox0 + fx;
+      const bool ok = fy >= 0 && ox < a.Wo && oy < a.Ho;
       rowoff[m] = ok ? (uint32_t)((((oy * a.osH + a.ooH) * a.YW + (ox * a.osW + a.ooW)) * a.CPo + lg * 4) * (int)sizeof(TOUT)) : 0x80000000u;
       rowok[m] = ok ? 0xffffffffu : 0u;
     }
     int btrow[PB ? MT : 1];                          // PB: byte offset of (row class, column class, this lane's channel quad) in the bias table
     if constexpr (PB) {
-      const int cxl = bt_class(min(ox, a.Wo - 1), bt_px, a.Wo);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int oy = min(oy0 + wave * MT + m, a.Ho - 1);
-        btrow[m] = ((bt_class(oy, bt_py, a.Ho) * bt_nx + cxl) * (NT * 16) + lg * 4) * 4;
+        int fy, fx;
+        tile_rc(m, fy, fx);
+        const int oy = min(oy0 + max(fy, 0), a.Ho - 1), ox = min(ox0 + fx, a.Wo - 1);
+        btrow[m] = ((bt_class(oy, bt_py, a.Ho) * bt_nx + bt_class(ox, bt_px, a.Wo)) * (NT * 16) + lg * 4) * 4;
       }
     }
     const uint32_t zstride = (uint32_t)(a.osD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
@@ -377,8 +402,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
             (int)((uint32_t)a.YD * a.YH * a.YW * 16u), 0x00020000);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        const int oy = oy0 + wave * MT + m;
-        rowoff8[m] = (colok && oy < a.Ho) ? (uint32_t)((oy * a.YW + ox) * 16 + lg * 4) : 0x80000000u;
+        int fy, fx;
+        tile_rc(m, fy, fx);
+        const int oy = oy0 + fy, ox = ox0 + fx;
+        rowoff8[m] = (fy >= 0 && ox < a.Wo && oy < a.Ho) ? (uint32_t)((oy * a.YW + ox) * 16 + lg * 4) : 0x80000000u;
       }
     }
 
@@ -447,14 +474,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     }                                                                                                             \
   }
 
-    // the activation fragment of row m: one address per K step (slot + this lane's voxel + the step's octet) and the row as
-    // an immediate offset of the ds_read
+    // the activation fragment of column group m: slot + this lane's voxel of the group + the step's octet
 #define ZM_LDX(dst, dstl, s_)                                                                                     \
   {                                                                                                               \
-    const unsigned char* xa_ = sb + vbase0 + kv[s_];                                                              \
-    _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(xa_ + m * (ITW * 32)); \
+    const unsigned char* xa_ = sb + kv[s_];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) dst[m] = *reinterpret_cast<const bf16x8*>(xa_ + vbo[m]);        \
     if constexpr (HL) {                                                                                           \
-      _Pragma("unroll") for (int m = 0; m < MT; ++m) dstl[m] = *reinterpret_cast<const bf16x8*>(xa_ + LOFF + m * (ITW * 32)); \
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) dstl[m] = *reinterpret_cast<const bf16x8*>(xa_ + LOFF + vbo[m]); \
     }                                                                                                             \
   }
 #define ZM_LDW(dst, dstl, s_)                                                                                     \
@@ -611,8 +637,16 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   ConvZmDev Q;
   Q.a = *a;
   Q.zeros = zeros;
-  Q.ntx = (a->Wo + 15) / 16;
-  Q.nty = (a->Ho + NW * MT - 1) / (NW * MT);
+  // tile of the flattened M index (a->ITW = tw + 2, a->TH = th); 0 / unset: NW MT rows of 16
+  Q.tw = a->ITW > 2 ? a->ITW - 2 : 16;
+  Q.th = a->ITW > 2 ? a->TH : NW * MT;
+  Q.itw = Q.tw + 2;
+  SP_CHECK_ARG(Q.tw >= 1 && Q.th >= 1 && Q.tw * Q.th <= 16 * NW * MT && Q.itw * (Q.th + 2) <= (NW * MT + 2) * 18 && Q.th + 2 <= 255 && Q.itw <= 255,
+               "sp_conv3d_zm: tile %d x %d does not fit the instance (%d voxels, halo tile %d)", Q.th, Q.tw, 16 * NW * MT, (NW * MT + 2) * 18);
+  Q.d_tw = make_fastdiv(Q.tw);
+  Q.d_itw = make_fastdiv(Q.itw);
+  Q.ntx = (a->Wo + Q.tw - 1) / Q.tw;
+  Q.nty = (a->Ho + Q.th - 1) / Q.th;
   Q.ncols = (uint32_t)(a->B * Q.nty * Q.ntx);
   Q.d_tx = make_fastdiv(Q.ntx);
   Q.d_ty = make_fastdiv(Q.nty);
@@ -668,7 +702,8 @@ static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   }
   if (a->act == SP_ACT_ELU) {
     if constexpr (NW == 8 && P <= 2) {      // the CAE's 16 / 24 / 32-channel layers
-      if (a->stats) return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 1, 2>(a, zeros, st);
+      // (with statistics the register-weight form of (1, 1) is past 256 registers: its weights in LDS)
+      if (a->stats) return launch_zm2<P, NT, MT, NSLOT, true, NW, 1, 2>(a, zeros, st);
       return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 0, 2>(a, zeros, st);
     } else {
       sp_set_error("sp_conv3d_zm: no ELU instance for P=%d NW=%d", P, NW);

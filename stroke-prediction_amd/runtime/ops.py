@@ -234,7 +234,7 @@ class ConvRunner:
             st["subs"] = subs
             zm = P.zm_plan(op) if (USE_ZM and USE_DMA and zm_batch) else None
             if zm is not None:
-                cols = -(-op.subs[0].out_dims[1] // zm["TH"]) * -(-op.subs[0].out_dims[2] // 16)
+                cols = -(-op.subs[0].out_dims[1] // zm["TH"]) * -(-op.subs[0].out_dims[2] // zm["TW"])
                 if zm_batch * cols * op.subs[0].out_dims[0] < ZM_MIN_PLANES:
                     zm = None       # too few (column, plane) pairs: the march would be all prologue
             if zm is not None:      # its own K order -> its own weight fragments (they replace the tiled kernel's: one re-pack per step)
@@ -546,6 +546,7 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
     a.ooD, a.ooH, a.ooW = 0, 0, 0
     a.o0D, a.o0H, a.o0W = sub.o0
     a.MT, a.NT, a.NTtot = z["MT"], z["NT"], z["NT"]
+    a.TD, a.TH, a.ITD, a.ITH, a.ITW = 1, z["TH"], 1, z["TH"] + 2, z["TW"] + 2      # the workgroup's tile (plan.zm_tile)
     a.Cout = z["NT"] * 16            # whole tiles: channels past op.cout have zero weights and bias
     a.dma, a.persist, a.zfill = 1, 5, 0
     a.octs_per_group, a.ngroups, a.opp, a.vsb = 2 * z["P"], 1, 2, 32

@@ -383,13 +383,43 @@ HL_DMA = bool(int(os.environ.get("SP_HL_DMA", "1")))      # bf16-pair layers wit
 ZM_SPLIT = {tuple(int(v) for v in it.split(",")) for it in os.environ.get("SP_ZM_SPLIT", "").split(";") if it}
 
 
-def zm_plan(op: ConvOp):
+ZM_TILE = os.environ.get("SP_ZM_TILE", "auto")      # "16": the classic NW MT rows x 16 voxels everywhere (A/B runs)
+
+
+def zm_tile(ho, wo, nw, mt):
+    """(tw, th): the output tile of a z-marching workgroup -- th rows of tw voxels, flattened row-major onto the NW MT column
+    groups of 16 (csrc/sp_conv_zm.hip: ConvZmDev.tw / th).  Fewest tiles per plane first (every tile costs the same MFMAs
+    whatever its fill: 50-voxel rows run as 25 x 10 instead of 16 x 16 tiles, 25 instead of 16 tiles per plane), then the
+    least staged halo, then the classic shape.  Limits: tw th <= 16 NW MT voxels, (tw + 2)(th + 2) <= (NW MT + 2) 18 staged."""
+    rows = nw * mt
+    if ZM_TILE == "16":
+        return 16, rows
+    best = None
+    for tw in range(4, min(wo, 253) + 1):
+        for th in range(2, min(ho, 253) + 1):
+            if tw * th > 16 * rows or (tw + 2) * (th + 2) > (rows + 2) * 18:
+                continue
+            tiles = -(-wo // tw) * -(-ho // th)
+            key = (tiles, tiles * (tw + 2) * (th + 2), 0 if (tw, th) == (16, rows) else 1, -tw)
+            if best is None or key < best[0]:
+                best = (key, (tw, th))
+    dflt = -(-wo // 16) * -(-ho // rows)
+    # under 10 % fewer tiles: keep the classic shape -- a column group that straddles two rows reads LDS with a 2-voxel skew
+    # (bank conflicts): 60 x 60 planes as 20 x 12 tiles (15 instead of 16) measured 8-13 % SLOWER, 50 x 50 as 25 x 10 (10
+    # instead of 16) 32 % faster, 88 x 88 as 22 x 22 (16 instead of 18) 14 % faster (profiles/r05_zm_tiles.txt)
+    if best is None or best[0][0] > 0.9 * dflt:
+        return 16, rows
+    return best[1]
+
+
+def zm_plan(op: ConvOp, tile=None):
     """K tables of the z-marching kernel for a stride-1 3x3x3 op between whole 16-channel tiles, or None.
 
     One input plane feeds the three output planes above it (taps dz = 0, 1, 2); the K loop of a step runs over the 18 P
     in-plane octets (dy, dx, plane p, octet o) in that order, four per step:
-      ktab[s*4 + g]            byte offset of the octet inside a ring slot: ((p*ITH + dy)*18 + dx)*32 + o*16
+      ktab[s*4 + g]            byte offset of the octet inside a ring slot: (p*ITH*18 + dy*(TW + 2) + dx)*32 + o*16
       kmap[(dz*KS + s)*4 + g]  (source tap << 16) | input octet for sp_conv_prep_weights, -1 for the padding octets
+    tile: (TW, TH) output tile of a workgroup (zm_tile; None: chosen from the op's output plane).
     """
     if op.dtype not in (0, 2) or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
         return None
@@ -404,7 +434,9 @@ def zm_plan(op: ConvOp):
     if (P_, NT) not in configs or ((P_, NT) in ZM_SPLIT and op.dtype == 0):
         return None
     MT, nslot, nw = configs[(P_, NT)]
-    ith = nw * MT + 2
+    ith = nw * MT + 2                        # compile-time plane pitch of a ring slot: ITH x 18 voxels
+    tw, th = tile if tile is not None else zm_tile(sub.out_dims[1], sub.out_dims[2], nw, MT)
+    assert tw * th <= 16 * nw * MT and (tw + 2) * (th + 2) <= ith * ZM_ITW
     ks = (18 * P_ + 3) // 4
     src = {(t[0], t[1], t[2]): t[3] for t in sub.taps}
     ktab = np.zeros(ks * 4, dtype=np.int32)
@@ -413,12 +445,12 @@ def zm_plan(op: ConvOp):
         t2d, rest = divmod(e, 2 * P_)
         p, o = divmod(rest, 2)
         dy, dx = divmod(t2d, 3)
-        ktab[e] = ((p * ith + dy) * ZM_ITW + dx) * 32 + o * 16
+        ktab[e] = (p * ith * ZM_ITW + dy * (tw + 2) + dx) * 32 + o * 16
         for dz in range(3):
             kmap[dz * ks * 4 + e] = (src[(dz, dy, dx)] << 16) | (p * 2 + o)
     for e in range(18 * P_, ks * 4):
         ktab[e] = ktab[e - 2]                # zero-weight padding octets: any valid, conflict-free address
-    return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=nw * MT, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)
+    return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=th, TW=tw, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)
 
 
 # ------------------------------------------------------------------------------------------------ fp8 z-marching plan

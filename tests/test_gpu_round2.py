@@ -184,6 +184,9 @@ ZM_CASES = [
     # cin, cout, dims, batch -- ragged rows / columns / few planes, every (P, NT) kernel, forward and data gradient
     (16, 16, (7, 37, 21), 2), (16, 16, (3, 70, 35), 1), (16, 32, (6, 19, 33), 2), (16, 48, (5, 21, 18), 1),
     (32, 16, (9, 35, 17), 1), (32, 32, (6, 20, 40), 2), (48, 16, (5, 19, 37), 1),
+    # planes whose rows are no multiple of 16: the flattened (row, column) tiles of plan.zm_tile -- 50 x 50 outputs as 25 x 10
+    # tiles (52 x 52 for the data gradient), 88 x 88 as 22 x 22, a 25 x 25 plane
+    (32, 32, (4, 52, 52), 1), (16, 16, (4, 90, 90), 1), (48, 16, (4, 27, 27), 2), (16, 48, (3, 50, 50), 1),
 ]
 
 
@@ -200,6 +203,8 @@ def test_z_marching_kernel_matches_conv3d(cin, cout, dims, B):
     op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, L.SP_BF16)
     run = O.ConvRunner(op, DEV, zm_batch=B)
     assert run.uses_zm()
+    if dims[1:] == (52, 52):
+        assert (run.zm["TW"], run.zm["TH"]) == (25, 10)
     run.prep(w.to(DEV), b.to(DEV))
     xs = _to_cl(x, cin)
     y = O.alloc_cl(B, op.y_dims, cout, L.SP_BF16, DEV)

@@ -154,9 +154,9 @@ def emulate_zm(op, zm, x_cl, w_flat):
                     continue
                 src, octet = km >> 16, km & 0xffff
                 off = int(zm["ktab"][e])
-                p, rem = divmod(off, ith * P.ZM_ITW * 32)
+                p, rem = divmod(off, ith * P.ZM_ITW * 32)      # (a plane keeps the pitch of the instance's largest halo tile)
                 vox, r2 = divmod(rem, 32)
-                dy, dx = divmod(vox, P.ZM_ITW)
+                dy, dx = divmod(vox, zm["TW"] + 2)
                 assert r2 % 16 == 0 and octet == p * 2 + r2 // 16, "kmap / ktab disagree on the channel octet"
                 assert dy < 3 and dx < 3
                 iy, ix = qy + sub.o0[1] + dy, qx + sub.o0[2] + dx
@@ -196,6 +196,22 @@ def test_z_marching_tables(cin, cout):
     assert P.zm_plan(P.conv_fwd_op(16, 24, 3, 2, 1, dims, 16, 24)) is None         # strided
 
 
+def test_zm_tile_covers_the_plane_with_the_fewest_tiles():
+    """plan.zm_tile: the flattened (row, column) tile of a z-marching workgroup -- never more tiles than the classic NW MT x 16
+    shape, within the instance's voxel and halo budgets, and the shapes the headline network's planes get"""
+    for rows in (8, 16, 32):
+        for ho, wo in ((50, 50), (60, 60), (58, 58), (90, 90), (88, 88), (124, 124), (46, 46), (25, 25), (126, 128), (7, 300), (3, 5)):
+            tw, th = P.zm_tile(ho, wo, rows // 4, 4)
+            assert tw * th <= 16 * rows and (tw + 2) * (th + 2) <= (rows + 2) * 18
+            assert -(-wo // tw) * -(-ho // th) <= -(-wo // 16) * -(-ho // rows)
+    assert P.zm_tile(50, 50, 4, 4) == (25, 10)           # 10 tiles per plane instead of 16
+    assert P.zm_tile(48, 48, 4, 4) == (16, 16)           # the classic shape where it divides the plane
+    op = P.conv_dgrad_op(32, 32, 3, 1, 0, (50, 50, 50), 32, 32)
+    z = P.zm_plan(op)
+    assert (z["TW"], z["TH"]) == P.zm_tile(50, 50, z["NW"], z["MT"])
+    assert int(z["ktab"].max()) + 16 <= z["P"] * z["ITH"] * P.ZM_ITW * 32
+
+
 def test_fc_plan_tables():
     """runtime/plan.py:fc_plan (split-K kernel for the FC-like layers): tap-major K order, steps per tap padded to the kernel's
     prefetch depth, every (tap, octet) exactly once, padding entries -1"""
@@ -217,10 +233,11 @@ def test_fc_plan_tables():
 
 
 def test_zm_plan_accepts_padded_channel_counts_and_padding():
-    """the CAE's 24-channel layers (pitch 32) and padded convolutions get z-marching plans; the tables only depend on (P, NT)"""
+    """the CAE's 24-channel layers (pitch 32) and padded convolutions get z-marching plans; the tables only depend on (P, NT) and
+    the workgroup's tile"""
     from stroke_prediction_amd.runtime import plan as P
-    a = P.zm_plan(P.conv_fwd_op(24, 24, 3, 1, (1, 2, 2), (8, 40, 40), 32, 32, 0))
-    b = P.zm_plan(P.conv_fwd_op(32, 32, 3, 1, 0, (8, 40, 40), 32, 32, 0))
+    a = P.zm_plan(P.conv_fwd_op(24, 24, 3, 1, (1, 2, 2), (8, 40, 40), 32, 32, 0), tile=(16, 16))
+    b = P.zm_plan(P.conv_fwd_op(32, 32, 3, 1, 0, (8, 40, 40), 32, 32, 0), tile=(16, 16))
     assert a is not None and (a["P"], a["NT"]) == (2, 2)
     np.testing.assert_array_equal(a["ktab"], b["ktab"])
     np.testing.assert_array_equal(a["kmap"], b["kmap"])
