@@ -59,6 +59,40 @@ void sp_last_error(char* buf, size_t n);
  * with xin = x*in_scale[ci]+in_shift[ci] inside the input volume (BatchNorm applied on load,
  * Unet3D.py:18,21) and 0 outside it (zero padding AFTER the norm, Cae3D.py:41).
  */
+/* BatchNorm finalize folded into the kernel that consumes its result (sp_conv_prep_folded_bn, sp_first_prep_bn): the arguments of
+ * sp_bn_finalize.  Every workgroup of the consumer derives scale / shift of all C channels itself (same arithmetic, same order:
+ * identical values everywhere); workgroup 0 also writes scale / shift / mean / invstd and updates the running statistics. */
+typedef struct sp_bn_fin_args {
+  const double* sums;      /* [nrep][CP][2] (sum x, sum x^2), replicas are added; unused when !training */
+  const float* gamma;      /* [C]; NULL = no BatchNorm folded in (the plain entry point's behaviour) */
+  const float* beta;
+  float* running_mean;     /* [C], updated when training (momentum, unbiased variance) */
+  float* running_var;
+  float* scale;            /* [CP] outputs (what the backward reads): scale, shift, mean, invstd */
+  float* shift;
+  float* mean;
+  float* invstd;
+  double count;            /* voxels per channel */
+  float momentum, eps;
+  int32_t nrep, training, C, CP;
+} sp_bn_fin_args;
+
+/* BatchNorm BACKWARD finalize folded into its consumer (sp_conv3d_zm with stats_mode 2): the arguments of sp_bn_bwd_finalize.
+ * dx = c0 g + c1 x + c2 with c0 = gamma invstd, c1 = -gamma invstd^2 dgamma / N, c2 = -c0 dbeta / N - c1 mean,
+ * dgamma = (S2 - mean S1) invstd, dbeta = S1, (S1, S2) = (sum g, sum g x) = sums added over the replicas. */
+typedef struct sp_bn_bwd_args {
+  const double* sums;      /* [nrep][CP][2]; NULL = unused */
+  const float* gamma;      /* [C] */
+  const float* mean;       /* [CP] */
+  const float* invstd;     /* [CP] */
+  float* dgamma;           /* [C] += pscale * dgamma (workgroup 0), or NULL */
+  float* dbeta;
+  float* coef;             /* optional output [3][CP] (workgroup 0), or NULL */
+  double count;
+  float pscale;
+  int32_t nrep, C, CP;
+} sp_bn_bwd_args;
+
 typedef struct sp_conv_args {
   /* tensors */
   const void* x;         /* [B][Di][Hi][Wi][CPi] */
@@ -134,6 +168,14 @@ typedef struct sp_conv_args {
   int32_t bias_tab_gstride;    /* floats between the tables of consecutive groups */
   int32_t pad_;
   int64_t wfrag_gstride;       /* bytes between the weight fragments (wfrag_hi) of consecutive groups (0: one set) */
+  /* ---- sp_conv3d_zm, stats_mode 2: the data gradient g = conv^T(dz_above, W) of the SECOND convolution of a block is not stored;
+   * its epilogue applies the BatchNorm backward of that convolution's input BatchNorm and the activation derivative of the block's
+   * first convolution, dz = (c0 g + c1 x + c2) act'(x) with x = aux (the first convolution's output = the BatchNorm's input), and
+   * writes dz to y -- what sp_bn_act_bwd would have made of a stored g in a second pass over both tensors (Unet3D.py:18-24 backward).
+   * The coefficients come from bnb (the kernel finalizes them itself: the weight gradient's finish kernel has left the sums);
+   * dz_sums[SP_REDUCE_ROWS][CPo] += sum over voxels of dz (the first convolution's bias gradient / folded weight-gradient term). */
+  sp_bn_bwd_args bnb;
+  double* dz_sums;
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -374,6 +416,16 @@ int sp_conv_prep_folded(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, 
                         int32_t nsteps, int32_t NTtot, void* wfrag_hi, void* wfrag_lo, const float* fold_scale,
                         int32_t ntaps, const float* bias, const float* fold_shift, float* bias_out, int32_t CoutPad,
                         sp_stream_t stream);
+
+/* sp_conv_prep_folded with the BatchNorm finalize (sp_bn_finalize) inside: fold_scale / fold_shift are computed from bn->sums by
+ * every workgroup of the re-pack kernel and written to bn->scale / bn->shift by the first -- one launch per layer and step instead
+ * of two on the forward's dependent chain (conv N -> statistics -> [finalize -> re-pack] -> conv N+1) */
+int sp_conv_prep_folded_bn(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,
+                           int32_t nsteps, int32_t NTtot, void* wfrag_hi, void* wfrag_lo, int32_t ntaps, const float* bias,
+                           float* bias_out, int32_t CoutPad, const sp_bn_fin_args* bn, sp_stream_t stream);
+/* the same for the packed first layer (sp_first_prep_n / sp_first_prep_hl: wfrag_lo NULL or the lo fragments) */
+int sp_first_prep_bn(const float* w, const float* b, void* wfrag, void* wfrag_lo, float* bias_f, int32_t Cout,
+                     const sp_bn_fin_args* bn, sp_stream_t stream);
 
 /* ------------------------------------------------------------------ weight gradient
  * dw[co,ci,tap] += sum_{b,o} dz[b,o,co] * xin[b, o*s + o0 + tapoff(tap), ci]

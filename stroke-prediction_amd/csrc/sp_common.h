@@ -309,6 +309,67 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// ---- BatchNorm finalize by ONE workgroup (sp_bn_fin_args; blockDim.x a multiple of 32, at most 256; every thread calls it):
+// afterwards sc[c] / sh[c] (LDS, CP floats each) hold scale / shift of every channel.  Used by sp_bn_finalize (one workgroup) and
+// inside the consumers that fold the result into weights (sp_conv_prep_folded_bn, sp_first_prep_bn: EVERY workgroup derives the
+// values -- same loads, same order, same bits -- and the first one publishes them).  Two phases per chunk of 128 channels: 32-lane
+// groups split the replica rows (all loads of a thread independent: one memory round trip, whole 512-byte lines per group), then one
+// thread per channel adds the groups' partial sums in group order and finalizes in fp64.  (A wave per channel in a loop -- the
+// stand-alone kernel's old form, one channel per workgroup -- costs a dependent round trip per channel: 50 us for 96 channels.)
+// publish: this workgroup also writes the outputs the backward reads (scale, shift, mean, invstd) and updates the running statistics.
+__device__ __forceinline__ void sp_bn_fin_block(const sp_bn_fin_args& f, bool publish, float* sc, float* sh) {
+  __shared__ double sp_bn_part_[8][128][2];
+  const int t = threadIdx.x, ngrp = blockDim.x >> 5, grp = t >> 5, l32 = t & 31;
+  for (int cb = 0; cb < f.CP; cb += 128) {
+    const int cn = min(128, f.CP - cb);
+    if (f.training) {
+      for (int c = l32; c < cn; c += 32) {
+        double s1 = 0, s2 = 0;
+        if (cb + c < f.C) {
+          const double* p = f.sums + ((size_t)grp * f.CP + cb + c) * 2;
+          for (int r = grp; r < f.nrep; r += ngrp, p += (size_t)ngrp * f.CP * 2) { s1 += p[0]; s2 += p[1]; }
+        }
+        sp_bn_part_[grp][c][0] = s1;
+        sp_bn_part_[grp][c][1] = s2;
+      }
+      __syncthreads();
+    }
+    for (int c = t; c < cn; c += blockDim.x) {
+      const int ch = cb + c;
+      float scv = 0.f, shv = 0.f, mean = 0.f, invstd = 0.f;
+      if (ch < f.C) {
+        if (f.training) {
+          double s1 = 0, s2 = 0;
+          for (int g = 0; g < ngrp; ++g) { s1 += sp_bn_part_[g][c][0]; s2 += sp_bn_part_[g][c][1]; }
+          const double m = s1 / f.count;
+          double var = s2 / f.count - m * m;
+          if (var < 0) var = 0;
+          mean = (float)m;
+          invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+          if (publish && f.running_mean) {
+            const double unb = f.count > 1 ? var * f.count / (f.count - 1) : var;
+            f.running_mean[ch] = (1.f - f.momentum) * f.running_mean[ch] + f.momentum * (float)m;
+            f.running_var[ch] = (1.f - f.momentum) * f.running_var[ch] + f.momentum * (float)unb;
+          }
+        } else {
+          mean = f.running_mean[ch];
+          invstd = 1.f / sqrtf(f.running_var[ch] + f.eps);
+        }
+        scv = f.gamma[ch] * invstd;
+        shv = f.beta[ch] - mean * scv;
+      }
+      sc[ch] = scv;
+      sh[ch] = shv;
+      if (publish) {
+        f.scale[ch] = scv;
+        f.shift[ch] = shv;
+        if (f.mean) { f.mean[ch] = mean; f.invstd[ch] = invstd; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // XCD-aware bijective remap of a linear workgroup id: workgroups that share halo data get
 // consecutive ids on ONE XCD (b and b+8 share an XCD under round-robin dispatch; speed only).
 __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {

@@ -593,12 +593,21 @@ __global__ void fold_bias_kernel(const float* __restrict__ w, int64_t sCo, int64
 }
 // re-pack + BatchNorm fold of the weights AND of the bias in one launch (the two kernels above, blocks [0, nprep)
 // and [nprep, nprep + CoutPad/4)): one ~5 us dispatch less per layer and step
+// BN: the BatchNorm finalize runs inside (sp_conv_prep_folded_bn): every workgroup derives scale / shift of the Cin input channels
+// into LDS (sp_bn_fin_block: the arithmetic of sp_bn_finalize), workgroup 0 publishes them and the running statistics
+template <bool BN>
 __global__ __launch_bounds__(256) void prep_folded_kernel(const float* __restrict__ w, int64_t sCo, int64_t sCi, int Cout, int Cin,
                                                            const int32_t* __restrict__ kmap, int nsteps, int NTtot,
                                                            bf16_t* __restrict__ hi, bf16_t* __restrict__ lo,
                                                            const float* __restrict__ fold, int nprep, int ntaps,
                                                            const float* __restrict__ bias, const float* __restrict__ shift,
-                                                           float* __restrict__ out, int CoutPad) {
+                                                           float* __restrict__ out, int CoutPad, const sp_bn_fin_args bn) {
+  extern __shared__ float bn_lds[];      // BN: [2][bn.CP] scale, shift
+  if constexpr (BN) {
+    sp_bn_fin_block(bn, blockIdx.x == 0, bn_lds, bn_lds + bn.CP);
+    fold = bn_lds;
+    shift = bn_lds + bn.CP;
+  }
   if ((int)blockIdx.x < nprep) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (step, ntile, lane)
     const int64_t total = (int64_t)nsteps * NTtot * 64;
@@ -648,11 +657,28 @@ extern "C" int sp_conv_prep_folded(const float* w, int64_t sCo, int64_t sCi, int
                "sp_conv_prep_folded: bad arguments");
   const int64_t total = (int64_t)nsteps * NTtot * 64;
   const int nprep = (int)((total + 255) / 256);
-  hipLaunchKernelGGL(prep_folded_kernel, dim3((unsigned)(nprep + (CoutPad + 3) / 4)), dim3(256), 0,
+  hipLaunchKernelGGL(prep_folded_kernel<false>, dim3((unsigned)(nprep + (CoutPad + 3) / 4)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), w, sCo, sCi, Cout, Cin, kmap, nsteps, NTtot,
                      reinterpret_cast<bf16_t*>(wfrag_hi), reinterpret_cast<bf16_t*>(wfrag_lo), fold_scale, nprep, ntaps, bias,
-                     fold_shift, bias_out, CoutPad);
+                     fold_shift, bias_out, CoutPad, sp_bn_fin_args{});
   SP_CHECK_LAUNCH("sp_conv_prep_folded");
+  return SP_OK;
+}
+extern "C" int sp_conv_prep_folded_bn(const float* w, int64_t sCo, int64_t sCi, int32_t Cout, int32_t Cin, const int32_t* kmap,
+                                      int32_t nsteps, int32_t NTtot, void* wfrag_hi, void* wfrag_lo, int32_t ntaps, const float* bias,
+                                      float* bias_out, int32_t CoutPad, const sp_bn_fin_args* bn, sp_stream_t stream) {
+  SP_CHECK_ARG(w && kmap && wfrag_hi && bias_out && bn && nsteps > 0 && NTtot > 0 && CoutPad >= Cout, "sp_conv_prep_folded_bn: bad arguments");
+  SP_CHECK_ARG(bn->gamma && bn->beta && bn->scale && bn->shift && bn->C == Cin && bn->CP >= Cin && bn->CP <= 4096 && bn->nrep >= 1 &&
+               (bn->training ? (bn->sums != nullptr && bn->count > 0) : (bn->running_mean && bn->running_var)),
+               "sp_conv_prep_folded_bn: BatchNorm arguments (C %d for %d input channels, pitch %d, %s statistics)", bn->C, Cin, bn->CP,
+               bn->training ? "batch" : "running");
+  const int64_t total = (int64_t)nsteps * NTtot * 64;
+  const int nprep = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(prep_folded_kernel<true>, dim3((unsigned)(nprep + (CoutPad + 3) / 4)), dim3(256), (size_t)bn->CP * 2 * sizeof(float),
+                     reinterpret_cast<hipStream_t>(stream), w, sCo, sCi, Cout, Cin, kmap, nsteps, NTtot,
+                     reinterpret_cast<bf16_t*>(wfrag_hi), reinterpret_cast<bf16_t*>(wfrag_lo), (const float*)nullptr, nprep, ntaps, bias,
+                     (const float*)nullptr, bias_out, CoutPad, *bn);
+  SP_CHECK_LAUNCH("sp_conv_prep_folded_bn");
   return SP_OK;
 }
 

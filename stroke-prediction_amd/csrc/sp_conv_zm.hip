@@ -122,6 +122,12 @@ template <> struct ZmStore<float> {
 // sums cannot come from the weight gradient -- padded convolutions, the CAE): (sum g, sum g*x) of the stored output g and the
 // layer input x read at the same position (a.aux), the pair the BatchNorm backward needs.  The x values of the plane whose
 // epilogue rides in step i+1 are fetched into registers at the top of step i.
+// STATS 3 (a.stats_mode 2; the second convolution's data gradient of a U-Net block, Unet3D.py:18-24 backward): the data gradient g
+// is not stored at all -- the epilogue forms the dz of the block's FIRST convolution from it, dz = (c0 g + c1 x + c2) act'(x), x =
+// a.aux = the first convolution's output (prefetched like STATS 2), with the BatchNorm-backward coefficients finalized in this
+// kernel's prologue from the sums the weight gradient's finish kernel left (a.bnb; workgroup 0 adds dgamma / dbeta), and
+// accumulates sum dz per channel into a.dz_sums: the separate passes sp_bn_bwd_finalize and sp_bn_act_bwd (read g, read x, write
+// dz) are gone.
 // BatchNorm groups (a.group_batch > 0: the batch holds B / group_batch passes with statistics of their own): the sums are flushed
 // to the rows of the sample's group whenever a workgroup's march crosses into another group.
 template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false>
@@ -139,10 +145,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
   constexpr int NS = MT * NT * ((Q8 || HL) ? 2 : 1);      // store instructions of one epilogue
-  constexpr int NA = STATS == 2 ? MT * NT : 0;            // loads of the layer input per step (STATS 2)
+  constexpr int NA = STATS >= 2 ? MT * NT : 0;            // loads of the layer input per step (STATS 2, 3)
   constexpr int NSA = NS + NA;
   static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NSA) <= 63, "counted vmcnt does not fit its 6-bit field");
-  static_assert(STATS != 2 || (ACT == 0 && !Q8 && !HL && sizeof(TOUT) == 2 && MT * NT == 4 && D == 2), "BatchNorm-backward sums: plain 16-bit data gradient, four tiles per wave");
+  static_assert(STATS < 2 || (ACT == 0 && !Q8 && !HL && sizeof(TOUT) == 2 && MT * NT == 4 && D == 2), "BatchNorm-backward sums / fused dz: plain 16-bit data gradient, four tiles per wave");
   constexpr int NWF = 3 * KS * NT;                // weight fragments (1 KiB each)
   // PB (the ELU instances: the CAE's padded layers): the bias comes from a table in LDS indexed by the output voxel's border class
   // (sp_conv_args.bias_tab: BatchNorm folded per group into a padded convolution); without a table its one entry is the plain bias
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   const int c0s = sl * NT * 16;                    // first output channel of this workgroup's slice
   TOUT* const y_sl = reinterpret_cast<TOUT*>(a.y) + c0s;
   const float* const bias_sl = a.bias ? a.bias + c0s : nullptr;
-  double* const stats_sl = a.stats ? a.stats + (size_t)c0s * 2 : nullptr;
+  double* const stats_sl = STATS == 3 ? a.dz_sums : (a.stats ? a.stats + (size_t)c0s * 2 : nullptr);      // (STATS 3: only "is there an accumulator")
 
   int kv[KS];
 #pragma unroll
@@ -241,6 +247,42 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #pragma unroll
     for (int j = 0; j < 4; ++j) { bj[n][j] = bias_sl ? bias_sl[n * 16 + lg * 4 + j] : 0.f; s1[n][j] = s2[n][j] = 0.f; }
   const float slope = a.act == SP_ACT_NONE ? 1.f : a.act_param;       // LeakyReLU slope (identity: 1) or the ELU's alpha
+  // STATS 3: the BatchNorm-backward coefficients of this lane's channels.  Channel c = tid / 16 is finalized by 16 lanes that split
+  // the replica rows (bn_bwd_finalize_kernel's arithmetic), handed over through LDS (the ring is not in use yet).
+  float cf0[STATS == 3 ? NT : 1][4], cf1[STATS == 3 ? NT : 1][4], cf2[STATS == 3 ? NT : 1][4];
+  if constexpr (STATS == 3) {
+    static_assert(STATS != 3 || 64 * NW / 16 >= NT * 16, "one 16-lane group per output channel");
+    const sp_bn_bwd_args& bb = a.bnb;
+    float* cfl = reinterpret_cast<float*>(lds);      // [3][NT * 16]
+    const int c = tid >> 4, sub = tid & 15;
+    if (c < NT * 16) {
+      double t1 = 0, t2 = 0;
+      if (c < bb.C)
+        for (int r = sub; r < bb.nrep; r += 16) { t1 += bb.sums[((size_t)r * bb.CP + c) * 2]; t2 += bb.sums[((size_t)r * bb.CP + c) * 2 + 1]; }
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 16); t2 += __shfl_xor(t2, o, 16); }
+      if (sub == 0) {
+        float k0 = 0.f, k1 = 0.f, k2 = 0.f;
+        if (c < bb.C) {
+          const double mu = bb.mean[c], is = bb.invstd[c], ga = bb.gamma[c];
+          const double dg = (t2 - mu * t1) * is, db = t1;
+          const double c0 = ga * is, c1 = -ga * is * is * dg / bb.count;
+          k0 = (float)c0; k1 = (float)c1; k2 = (float)(-c0 * db / bb.count - c1 * mu);
+          if (blockIdx.x == 0 && bb.dgamma) { bb.dgamma[c] += bb.pscale * (float)dg; bb.dbeta[c] += bb.pscale * (float)db; }
+        }
+        cfl[c] = k0; cfl[NT * 16 + c] = k1; cfl[2 * NT * 16 + c] = k2;
+        if (blockIdx.x == 0 && bb.coef && c < bb.CP) { bb.coef[c] = k0; bb.coef[bb.CP + c] = k1; bb.coef[2 * bb.CP + c] = k2; }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        cf0[n][j] = cfl[n * 16 + lg * 4 + j]; cf1[n][j] = cfl[NT * 16 + n * 16 + lg * 4 + j]; cf2[n][j] = cfl[2 * NT * 16 + n * 16 + lg * 4 + j];
+      }
+    __syncthreads();      // (every lane holds its coefficients before the first plane lands in the ring)
+  }
   const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(Q.zeros);
   // statistics flush: wave-ordered sum through LDS, one atomic per channel and workgroup into the rows of BatchNorm group g
   const int gbatch = a.group_batch > 0 ? a.group_batch : 0x7fffffff;
@@ -256,10 +298,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         s1[n][j] = s2[n][j] = 0.f;
       }
     __syncthreads();
-    double* const gs = stats_sl + (size_t)g * a.stats_nrep * a.CPo * 2;
-    for (int k = tid; k < NT * 32; k += 64 * NW) {
-      const int c = k >> 1;
-      if (c0s + c < a.CPo) atomicAdd(&gs[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
+    if constexpr (STATS == 3) {      // sum dz into the replica rows of the first convolution's bias-gradient accumulator
+      for (int k = tid; k < NT * 32; k += 64 * NW) {
+        const int c = k >> 1;
+        if ((k & 1) == 0 && c0s + c < a.CPo) atomicAdd(&a.dz_sums[(size_t)(blockIdx.x & (SP_REDUCE_ROWS - 1)) * a.CPo + c0s + c], (double)sp_cols_sum(red, NT * 32, NW, k));
+      }
+    } else {
+      double* const gs = stats_sl + (size_t)g * a.stats_nrep * a.CPo * 2;
+      for (int k = tid; k < NT * 32; k += 64 * NW) {
+        const int c = k >> 1;
+        if (c0s + c < a.CPo) atomicAdd(&gs[(size_t)(blockIdx.x & (a.stats_nrep - 1)) * a.CPo * 2 + (size_t)c * 2 + (k & 1)], (double)sp_cols_sum(red, NT * 32, NW, k));
+      }
     }
   };
   // PB: border classes per axis (2 pad + 1; forward convolutions: o0 = -pad), 1 x 1 x 1 without a table
@@ -330,7 +379,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     }
     const int oy0 = ty * th, ox0 = tx * tw;
     const int iy0 = oy0 + a.o0H, ix0 = ox0 + a.o0W;
-    const unsigned char* auxb = STATS == 2 ? reinterpret_cast<const unsigned char*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo * 2 : nullptr;
+    const unsigned char* auxb = STATS >= 2 ? reinterpret_cast<const unsigned char*>(a.aux) + (size_t)b * a.YD * a.YH * a.YW * a.CPo * 2 : nullptr;
     const unsigned char* xin = reinterpret_cast<const unsigned char*>(a.x) + (size_t)b * a.Di * a.Hi * a.Wi * xpitch * 2;
     int vmask = 0;                                            // in-plane validity of this lane's chunks
 #pragma unroll
@@ -441,6 +490,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           else if (ACT == 2) { const float zz = acc[R_][n][m][j] + bq_[j]; v[j] = zz > 0.f ? zz : slope * (__expf(zz) - 1.f); } \
           else v[j] = acc[R_][n][m][j];                                                                           \
         }                                                                                                         \
+        if constexpr (STATS == 3) {   /* dz = (c0 g + c1 x + c2) act'(x) of the ROUNDED g (what sp_bn_act_bwd would read back) */ \
+          const uint32_t g0_ = zm_pack2(v[0], v[1]), g1_ = zm_pack2(v[2], v[3]);                                  \
+          const float gr_[4] = {sp_h2f_lo(g0_), sp_h2f_hi(g0_), sp_h2f_lo(g1_), sp_h2f_hi(g1_)};                  \
+          const zm_u32x2 xw_ = {ax[AX_][n * MT + m][0] | axtok, ax[AX_][n * MT + m][1] | axtok};                     \
+          const float xq_[4] = {sp_h2f_lo(xw_[0]), sp_h2f_hi(xw_[0]), sp_h2f_lo(xw_[1]), sp_h2f_hi(xw_[1])};      \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const float o_ = (cf0[STATS == 3 ? n : 0][j] * gr_[j] + cf1[STATS == 3 ? n : 0][j] * xq_[j] + cf2[STATS == 3 ? n : 0][j]) * (xq_[j] > 0.f ? 1.f : slope); \
+            v[j] = o_;                                                                                            \
+            s1[n][j] += __uint_as_float(__float_as_uint(o_) & msk);                                               \
+          }                                                                                                       \
+        }                                                                                                         \
         if constexpr (HL) {                                                                                       \
           uint32_t h0_, h1_, l0_, l1_;                                                                            \
           sp_hl_split4(v, h0_, h1_, l0_, l1_);                                                                    \
@@ -528,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     else if (i == 1) ZM_SYNC((D - 1) * NJ + (D > 2 ? 1 : 0) * NSA);                                               \
     else if (i == 2) ZM_SYNC((D - 1) * NJ + (D > 3 ? 2 : 0) * NSA);                                               \
     else ZM_SYNC((D - 1) * NJ + (D > 4 ? 3 : 0) * NSA);                                                           \
-    if constexpr (STATS == 2) {                                                                                   \
+    if constexpr (STATS >= 2) {                                                                                   \
       /* the x values for THIS step's epilogue were requested at the top of the last step, before its NJ DMAs and NS stores: */ \
       /* all but those may be outstanding.  The wait also defines a zero token that every use of the loaded registers ORs in, */ \
       /* so that none of them can be scheduled above it ("+v" ties on the registers themselves made the allocator spill). */   \
@@ -663,8 +723,8 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
   } else if (a->dtype_out == SP_F32) {
-    if constexpr (ACT == 2 || STATS == 2) {
-      sp_set_error("sp_conv3d_zm: the ELU epilogue and the BatchNorm-backward sums are built for bf16 outputs");
+    if constexpr (ACT == 2 || STATS >= 2) {
+      sp_set_error("sp_conv3d_zm: the ELU epilogue and the BatchNorm-backward epilogues are built for bf16 outputs");
       return SP_EINVAL;
     } else {
       auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, float>;
@@ -692,11 +752,12 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
 template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW>
 static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   const bool plain = a->act == SP_ACT_NONE && a->bias == nullptr;      // data gradients: nothing to do but round and store
-  if (a->stats_mode == 1) {      // data gradient + (sum g, sum g x) for the BatchNorm backward (checked by the caller: plain, stats, aux)
-    if constexpr (NW == 8 && P <= 2 && MT * NT == 4 && NSLOT == 3) {
+  if (a->stats_mode == 1 || a->stats_mode == 2) {      // data gradient + (sum g, sum g x) for the BatchNorm backward (checked by the caller: plain, stats, aux), or
+    if constexpr (NW == 8 && P <= 2 && MT * NT == 4 && NSLOT == 3) {      // with the whole BatchNorm / activation backward in its epilogue (dz out)
+      if (a->stats_mode == 2) return launch_zm2<P, NT, MT, NSLOT, true, NW, 3, 0>(a, zeros, st);
       return launch_zm2<P, NT, MT, NSLOT, true, NW, 2, 0>(a, zeros, st);
     } else {
-      sp_set_error("sp_conv3d_zm: no BatchNorm-backward-sums instance for P=%d NT=%d NW=%d", P, NT, NW);
+      sp_set_error("sp_conv3d_zm: no BatchNorm-backward instance for P=%d NT=%d NW=%d", P, NT, NW);
       return SP_EINVAL;
     }
   }
@@ -761,9 +822,14 @@ static int launch_zm_hl(const sp_conv_args* a, const void* zeros, hipStream_t st
 extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream) {
   SP_CHECK_ARG(a && a->x && a->y && a->wfrag_hi && a->ktab && zeros, "sp_conv3d_zm: null pointer");
   const bool hl = a->dtype_in == SP_HL;
-  SP_CHECK_ARG((a->dtype_in == SP_BF16 || hl) && a->in_scale == nullptr && (a->stats_mode == 0 || a->stats_mode == 1), "sp_conv3d_zm: bf16 (or bf16 pair) input, no affine on load");
-  SP_CHECK_ARG(a->stats_mode == 0 || (a->stats && a->aux && a->act == SP_ACT_NONE && a->bias == nullptr && a->dtype_out == SP_BF16 && !hl && !a->y8 && a->nslices <= 1),
+  SP_CHECK_ARG((a->dtype_in == SP_BF16 || hl) && a->in_scale == nullptr && (a->stats_mode >= 0 && a->stats_mode <= 2), "sp_conv3d_zm: bf16 (or bf16 pair) input, no affine on load");
+  SP_CHECK_ARG(a->stats_mode != 1 || (a->stats && a->aux && a->act == SP_ACT_NONE && a->bias == nullptr && a->dtype_out == SP_BF16 && !hl && !a->y8 && a->nslices <= 1),
                "sp_conv3d_zm: stats_mode 1 (sum g, sum g x) is for plain bf16 data gradients with statistics rows and the layer input (aux)");
+  // stats_mode 2: act / act_param describe the FIRST convolution's activation (its derivative from x = aux), not an epilogue of this one
+  SP_CHECK_ARG(a->stats_mode != 2 || (a->aux && a->dz_sums && a->bnb.sums && a->bnb.gamma && a->bnb.mean && a->bnb.invstd && a->bnb.count > 0 && a->bnb.nrep >= 1 &&
+                                      a->bnb.C <= a->Cout && a->bnb.CP >= a->bnb.C && (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && a->bias == nullptr &&
+                                      a->dtype_out == SP_BF16 && !hl && !a->y8 && a->nslices <= 1 && a->group_batch == 0 && a->stats == nullptr),
+               "sp_conv3d_zm: stats_mode 2 (dz = BatchNorm / LeakyReLU backward of the data gradient) needs aux, dz_sums, bnb and a plain bf16 data gradient");
   SP_CHECK_ARG(!hl || (a->dtype_out == SP_HL && a->wfrag_lo && a->x_lo_delta != 0 && a->y_lo_delta != 0 && a->x_lo_delta % 16 == 0 && a->y_lo_delta % 8 == 0 &&
                        (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && a->nslices <= 1),
                "sp_conv3d_zm: bf16 pairs in -> bf16 pairs out with hi and lo weight fragments, bias + LeakyReLU / identity epilogue");
@@ -811,10 +877,10 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
   if (nw == 4) {
     if (P == 1 && a->NT == 1) return launch_zm<1, 1, 8, 3, false, 4>(a, zeros, st);
     if (P == 1 && a->NT == 2) return launch_zm<1, 2, 4, 3, true, 4>(a, zeros, st);
-    if (P == 1 && a->NT == 3) return launch_zm<1, 3, 4, 3, true, 4>(a, zeros, st);
+    if (P == 1 && a->NT == 3) return launch_zm<1, 3, 4, 3, true, 4>(a, zeros, st);      // (register weights: 180 + 192 accumulator registers spill)
     if (P == 2 && a->NT == 1) return launch_zm<2, 1, 8, 3, true, 4>(a, zeros, st);
     if (P == 2 && a->NT == 2) return launch_zm<2, 2, 4, 3, true, 4>(a, zeros, st);
-    if (P == 3 && a->NT == 1) return launch_zm<3, 1, 4, 3, true, 4>(a, zeros, st);
+    if (P == 3 && a->NT == 1) return v(5) == 1 ? launch_zm<3, 1, 4, 3, false, 4>(a, zeros, st) : launch_zm<3, 1, 4, 3, true, 4>(a, zeros, st);
     return SP_EINVAL;
   }
   if (P == 1 && a->NT == 1) return v(0) == 1 ? launch_zm<1, 1, 4, 3, true, 8>(a, zeros, st) : launch_zm<1, 1, 4, 3, false, 8>(a, zeros, st);

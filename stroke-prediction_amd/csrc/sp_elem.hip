@@ -227,51 +227,22 @@ extern "C" int sp_bn_bwd_reduce(const void* g, const void* x, int32_t dtype, int
 
 // nn.BatchNorm3d (training): normalise with biased batch variance, update running stats with the
 // unbiased one (momentum); eval: running stats.  Pad channels (c >= C) get scale = shift = 0.
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* running_mean, float* running_var,
-                                   float momentum, float eps, int training, int C, int CP, float* scale, float* shift,
-                                   float* mean_out, float* invstd_out) {
-  const int c = blockIdx.x;                 // one wave per channel; lanes gather the replicas
-  const int lane = threadIdx.x;
-  if (c >= C) {
-    if (lane == 0) { scale[c] = 0.f; shift[c] = 0.f; if (mean_out) { mean_out[c] = 0.f; invstd_out[c] = 0.f; } }
-    return;
-  }
-  float mean, invstd;
-  if (training) {
-    double s1 = 0, s2 = 0;
-    for (int r = lane; r < nrep; r += 64) { s1 += sums[((size_t)r * CP + c) * 2]; s2 += sums[((size_t)r * CP + c) * 2 + 1]; }
-    s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    if (lane != 0) return;
-    const double m = s1 / count;
-    double var = s2 / count - m * m;
-    if (var < 0) var = 0;
-    mean = (float)m;
-    invstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-      const double unb = count > 1 ? var * count / (count - 1) : var;
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
-    }
-  } else {
-    if (lane != 0) return;
-    mean = running_mean[c];
-    invstd = 1.f / sqrtf(running_var[c] + eps);
-  }
-  const float sc = gamma[c] * invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - mean * sc;
-  if (mean_out) { mean_out[c] = mean; invstd_out[c] = invstd; }
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const sp_bn_fin_args f) {
+  extern __shared__ float bn_fin_lds[];      // [2][CP]: scale, shift (also what the fused consumers keep in LDS)
+  sp_bn_fin_block(f, true, bn_fin_lds, bn_fin_lds + f.CP);
 }
 extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, int32_t training,
                               int32_t C, int32_t CP, float* scale, float* shift, float* mean, float* invstd,
                               sp_stream_t stream) {
-  SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP, "sp_bn_finalize: bad arguments");
+  SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP && CP <= 4096, "sp_bn_finalize: bad arguments");
   SP_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "sp_bn_finalize: missing statistics");
   SP_CHECK_ARG(nrep >= 1, "sp_bn_finalize: nrep");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, training, C, CP, scale, shift, mean, invstd);
+  sp_bn_fin_args f;
+  f.sums = sums; f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
+  f.scale = scale; f.shift = shift; f.mean = mean; f.invstd = mean ? invstd : nullptr;
+  f.count = count; f.momentum = momentum; f.eps = eps; f.nrep = nrep; f.training = training; f.C = C; f.CP = CP;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), (size_t)CP * 2 * sizeof(float), ST(stream), f);
   SP_CHECK_LAUNCH("sp_bn_finalize");
   return SP_OK;
 }

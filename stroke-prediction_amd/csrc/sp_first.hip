@@ -178,10 +178,18 @@ extern "C" int sp_bn_stats_ncdhw_f32(const float* x, int32_t B, int32_t C, int64
 // ------------------------------------------------------------------------------------------------ weights
 // A fragment of MFMA step s (0..2), lane l: row co = l % 16, K slice j = l / 16 -> group g = 4s + j = (dz, dy),
 // elements e = 0..7 = (dx = e / 2, c = e % 2);  W' = W * scale[c],  b' = b + sum W * shift[c]
+// bn.gamma != NULL (sp_first_prep_bn): scale / shift are finalized here from the batch (or running) statistics of the two input
+// channels -- every workgroup derives them, workgroup 0 publishes them (sp_bn_fin_block) -- instead of by a launch of their own
 __global__ void first_prep_kernel(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ scale,
                                   const float* __restrict__ shift, bf16_t* __restrict__ wfrag, float* __restrict__ bias_f, int Cout,
-                                  bf16_t* __restrict__ wfrag_lo) {
+                                  bf16_t* __restrict__ wfrag_lo, const sp_bn_fin_args bn) {
   const int t = threadIdx.x;               // 192 threads = 3 steps x 64 lanes; blockIdx.x = output tile of 16 rows
+  __shared__ float bn_sc[2][16];
+  if (bn.gamma) {
+    sp_bn_fin_block(bn, blockIdx.x == 0, bn_sc[0], bn_sc[1]);
+    scale = bn_sc[0];
+    shift = bn_sc[1];
+  }
   // Cout = 32: tile t, row r holds channel (r / 4) * 8 + 4 t + r % 4 -- a lane of the forward kernel (rows 4 lg .. 4 lg + 3 of
   // both tiles) then owns EIGHT consecutive channels of its voxel and stores them with one 16-byte instruction
   const int s = t >> 6, l = t & 63, r_ = l & 15, g = 4 * s + (l >> 4);
@@ -211,15 +219,26 @@ extern "C" int sp_first_supported(int32_t Cin, int32_t Cout, int32_t k) { return
 extern "C" int sp_first_prep_n(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,
                                float* bias_f, int32_t Cout, sp_stream_t stream) {
   SP_CHECK_ARG(w && wfrag && bias_f && (Cout == 16 || Cout == 32), "sp_first_prep: null pointer / 16 or 32 output channels");
-  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f, Cout, (bf16_t*)nullptr);
+  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag, bias_f, Cout, (bf16_t*)nullptr, sp_bn_fin_args{});
   SP_CHECK_LAUNCH("sp_first_prep");
   return SP_OK;
 }
 extern "C" int sp_first_prep_hl(const float* w, const float* b, const float* scale, const float* shift, void* wfrag_hi, void* wfrag_lo,
                                 float* bias_f, int32_t Cout, sp_stream_t stream) {
   SP_CHECK_ARG(w && wfrag_hi && wfrag_lo && bias_f && (Cout == 16 || Cout == 32), "sp_first_prep_hl: null pointer / 16 or 32 output channels");
-  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag_hi, bias_f, Cout, (bf16_t*)wfrag_lo);
+  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, scale, shift, (bf16_t*)wfrag_hi, bias_f, Cout, (bf16_t*)wfrag_lo, sp_bn_fin_args{});
   SP_CHECK_LAUNCH("sp_first_prep_hl");
+  return SP_OK;
+}
+extern "C" int sp_first_prep_bn(const float* w, const float* b, void* wfrag, void* wfrag_lo, float* bias_f, int32_t Cout,
+                                const sp_bn_fin_args* bn, sp_stream_t stream) {
+  SP_CHECK_ARG(w && wfrag && bias_f && bn && (Cout == 16 || Cout == 32), "sp_first_prep_bn: null pointer / 16 or 32 output channels");
+  SP_CHECK_ARG(bn->gamma && bn->beta && bn->scale && bn->shift && bn->C == 2 && bn->CP >= 2 && bn->CP <= 16 && bn->nrep >= 1 &&
+               (bn->training ? (bn->sums != nullptr && bn->count > 0) : (bn->running_mean && bn->running_var)),
+               "sp_first_prep_bn: BatchNorm arguments (2 input channels, pitch <= 16)");
+  hipLaunchKernelGGL(first_prep_kernel, dim3(Cout / 16), dim3(192), 0, ST(stream), w, b, (const float*)nullptr, (const float*)nullptr, (bf16_t*)wfrag,
+                     bias_f, Cout, (bf16_t*)wfrag_lo, *bn);
+  SP_CHECK_LAUNCH("sp_first_prep_bn");
   return SP_OK;
 }
 extern "C" int sp_first_prep(const float* w, const float* b, const float* scale, const float* shift, void* wfrag,

@@ -6,6 +6,7 @@ BN-conv-ELU triples of Cae3D.py:39-76,176-220).  Forward is ONE kernel per sub-c
 epilogue); backward is wgrad + dgrad + one reduction, with the BatchNorm backward expressed as
 per-channel coefficients ``dx = c0*g + c1*x + c2`` that the consumer of ``g`` applies on load.
 """
+import ctypes as C
 import os
 
 import torch
@@ -244,13 +245,27 @@ class ConvLayer:
                 self.y = O.alloc_cl(self.batch, self.out_dims, self.cpo, self.out_dtype, self.device)
         return self.y
 
-    def _bn_fwd(self, params, bufs, training):
-        """Finalize the input BatchNorm (batch statistics from in_sums, running buffers) into scale/shift."""
+    def _bn_fwd(self, params, bufs, training, fused=False):
+        """Finalize the input BatchNorm (batch statistics from in_sums, running buffers) into scale/shift.
+        fused: the finalize itself runs inside the weight re-pack kernel -- returns its arguments (lib.BnFinArgs) instead of
+        launching sp_bn_finalize."""
         p = self.bn_prefix
         world = 1
         if training and SYNC["on"]:
             _allreduce(self.in_sums)
             world = SYNC["world"]
+        if fused:
+            assert self.G == 1
+            f = L.BnFinArgs()
+            f.sums = O.ptr(self.in_sums if training else None)
+            f.gamma, f.beta = O.ptr(params[p + ".weight"]), O.ptr(params[p + ".bias"])
+            f.running_mean, f.running_var = O.ptr(bufs[p + ".running_mean"]), O.ptr(bufs[p + ".running_var"])
+            f.scale, f.shift, f.mean, f.invstd = O.ptr(self.scale), O.ptr(self.shift), O.ptr(self.mean), O.ptr(self.invstd)
+            f.count, f.momentum, f.eps = float(self.count * world), BN_MOMENTUM, BN_EPS
+            f.nrep, f.training, f.C, f.CP = STATS_NREP, int(training), self.cin, self.cpi
+            if training and "__nbt_flat__" not in bufs:
+                bufs[p + ".num_batches_tracked"].add_(1)
+            return f
         if self.G > 1:
             L.call("sp_bn_finalize_groups", O.ptr(self.in_sums if training else None), STATS_NREP, float(self.count * world),
                    O.ptr(params[p + ".weight"]), O.ptr(params[p + ".bias"]), O.ptr(bufs[p + ".running_mean"]),
@@ -267,13 +282,16 @@ class ConvLayer:
     def forward(self, x, params, bufs, training, out_stats=None, x_lo=None):
         """x: channels-last input (hl: its hi half, x_lo the lo half); returns the (cached) output tensor (hl: its hi half, the
         lo half is self.y_lo)."""
+        # folded layers: the BatchNorm finalize rides in the re-pack kernel of the weights it is folded into
+        bn = None
         if self.bn_prefix is not None:
-            self._bn_fwd(params, bufs, training)
+            fuse = bool(self.fold and self.G == 1 and self.f8_fwd is None and self.fwd.can_fuse_bn())
+            bn = self._bn_fwd(params, bufs, training, fused=fuse)
         c = self.conv_prefix
         y = self.alloc_out()
         if self.hl:
             assert self.fold and x_lo is not None
-            self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift, bn=bn)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=L.SP_HL,
                          stats_nrep=STATS_NREP, x_planar=self.x_planar, x_lo=x_lo, y_lo=self.y_lo)
             return y
@@ -319,7 +337,7 @@ class ConvLayer:
             else:
                 self.f8_fwd.run(self.x8, y, self.act, self.act_param, out_stats, STATS_NREP, y8=y8)
         elif self.fold:
-            self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift)
+            self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift, bn=bn)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
                          stats_nrep=STATS_NREP, x_planar=self.x_planar, y8=self.alloc_y8() if self.want_y8 else None)
         else:
@@ -399,10 +417,25 @@ class ConvLayer:
     def dbias_sums(self):
         return self.scratch.get(self.dbias_sums_id).view(L.SP_REDUCE_ROWS, self.cpo)
 
-    def backward(self, x, params, grads, want_g=True):
+    def can_fuse_dz(self, producer):
+        """backward(fuse_dz=...) applies: this layer's data gradient runs on a z-marching instance with the BatchNorm / activation
+        backward epilogue (sp_conv3d_zm stats_mode 2), its BatchNorm-backward sums come from the weight gradient, and `producer`
+        (the layer whose output is this layer's input) takes a plain 16-bit dz"""
+        if not (O.FUSE_DZ and self._bwd_ready and producer._bwd_ready):
+            return False
+        return bool(self.G == 1 and self.param_grads and self.bn_from_wgrad and self.need_input_grad and self.dtype == L.SP_BF16
+                    and self.f8_wgrad is None and self.f8_dgrad is None and not getattr(self, "dgrad_parts", None)
+                    and getattr(self, "dgrad", None) is not None and self.dgrad.zm_bn_bwd_ok()
+                    and producer.store_y and producer.dz_target() is producer.dz and producer.dz8_out() is None
+                    and producer.act in (L.ACT_LEAKY, L.ACT_NONE) and producer.y is not None and producer.y.shape[-1] == self.cpi)
+
+    def backward(self, x, params, grads, want_g=True, fuse_dz=None):
         """Given self.dz (gradient at the pre-activation output) and self.dbias_sums already filled by the
         producer of dz: accumulate parameter gradients, return (g, coef) describing the input gradient
         dx = coef0*g + coef1*x + coef2 (coef None: dx = g).
+        fuse_dz = (dz_out, dz_sums, act, act_param) (``can_fuse_dz``): the data gradient is not stored -- its kernel's epilogue
+        applies this layer's BatchNorm backward and the producer's activation derivative (x is the producer's output) and writes the
+        producer's dz and sum dz; returns (None, None).
         want_g=False: nobody reads g (the first layer of a stack whose input needs no gradient) -- honoured where the
         BatchNorm-backward sums do not come from the data gradient (the raw-input weight gradient of the batched CAE layers)."""
         self._want_g = bool(want_g)
@@ -430,6 +463,22 @@ class ConvLayer:
                 run_wgrad = lambda: self.wgrad.run(x, self.dz, self.batch, grads[c + ".weight"], self.scale, self.shift,
                                                    dbias_sums=self.dbias_sums, dbias_grad=grads[c + ".bias"], nbias=self.cout,
                                                    bn_w=w, bn_sums=bs, bn_nrep=STATS_NREP, defer_finish=True, x_planar=self.x_planar)
+            if fuse_dz is not None:
+                # the data gradient's prologue finalizes the BatchNorm backward from the sums of the finish kernel: one stream, in order
+                run_wgrad()()
+                world = 1
+                if SYNC["on"]:
+                    _allreduce(bs)
+                    world = SYNC["world"]
+                p = self.bn_prefix
+                dz_out, dz_sums, act, ap = fuse_dz
+                self.dgrad.prep(w)
+                self.dgrad.run(self.dz, dz_out, self.batch, None, None, act, ap, None, stats_mode=2, aux=x, dz_sums=dz_sums,
+                               bnb=dict(sums=bs, nrep=STATS_NREP, count=self.count * world, gamma=params[p + ".weight"], mean=self.mean,
+                                        invstd=self.invstd, C=self.cin, CP=self.cpi, dgamma=grads[p + ".weight"], dbeta=grads[p + ".bias"],
+                                        pscale=1.0 / world))
+                self.dz8_ready = False
+                return None, None
             whole = O.overlap_level() == 2      # the weight-gradient kernel itself runs beside the data gradient
             finish = None if whole else run_wgrad()
             # finish + BatchNorm-backward finalize on the side stream, beside the data-gradient convolution
@@ -639,20 +688,25 @@ class FirstConvLayer(ConvLayer):
 
     def forward(self, images, params, bufs, training, out_stats=None):
         assert images.dtype == torch.float32 and images.is_contiguous()
-        self._bn_fwd(params, bufs, training)
+        bn = self._bn_fwd(params, bufs, training, fused=O.FUSE_BN_FINALIZE)
         c = self.conv_prefix
         y = self.alloc_out()
         st = O.stream()
         D, H, W = self.in_dims
+        if bn is not None:      # the BatchNorm finalize inside the re-pack kernel
+            L.call("sp_first_prep_bn", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.wfrag), O.ptr(self.wfrag_lo),
+                   O.ptr(self.bias_f), self.cout, C.byref(bn), st)
         if self.hl:      # bf16 pairs: the fp32 input split into hi + lo inside the kernel, hi + lo weight fragments, y as a pair
-            L.call("sp_first_prep_hl", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
-                   O.ptr(self.wfrag), O.ptr(self.wfrag_lo), O.ptr(self.bias_f), self.cout, st)
+            if bn is None:
+                L.call("sp_first_prep_hl", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
+                       O.ptr(self.wfrag), O.ptr(self.wfrag_lo), O.ptr(self.bias_f), self.cout, st)
             with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first x3" % (self.cin, self.cout, D, H, W)):
                 L.call("sp_first_conv_fwd_hl", O.ptr(images), self.batch, D, H, W, O.ptr(self.wfrag), O.ptr(self.wfrag_lo), O.ptr(self.bias_f),
                        self.act, self.act_param, O.ptr(y), O.ptr(self.y_lo), O.ptr(out_stats), STATS_NREP, self.cout, st)
             return y
-        L.call("sp_first_prep_n", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
-               O.ptr(self.wfrag), O.ptr(self.bias_f), self.cout, st)
+        if bn is None:
+            L.call("sp_first_prep_n", O.ptr(params[c + ".weight"]), O.ptr(params[c + ".bias"]), O.ptr(self.scale), O.ptr(self.shift),
+                   O.ptr(self.wfrag), O.ptr(self.bias_f), self.cout, st)
         y8 = self.alloc_y8() if self.want_y8 else None      # (fp8 mode: the e4m3 operand of the second layer)
         assert self.store_y or y8 is not None
         with O._Timed("conv_igemm", self.flops, "%d->%d @%dx%dx%d first%s" % (self.cin, self.cout, D, H, W, "" if self.store_y else " (e4m3 only)")):

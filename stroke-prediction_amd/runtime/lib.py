@@ -32,6 +32,16 @@ ACT_NONE, ACT_LEAKY, ACT_ELU, ACT_SIGMOID = 0, 1, 2, 3
 i32, i64, f32, f64, vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 
 
+class BnFinArgs(C.Structure):      # sp_bn_fin_args
+    _fields_ = [(n, vp) for n in ("sums", "gamma", "beta", "running_mean", "running_var", "scale", "shift", "mean", "invstd")] + \
+               [("count", f64), ("momentum", f32), ("eps", f32), ("nrep", i32), ("training", i32), ("C", i32), ("CP", i32)]
+
+
+class BnBwdArgs(C.Structure):      # sp_bn_bwd_args
+    _fields_ = [(n, vp) for n in ("sums", "gamma", "mean", "invstd", "dgamma", "dbeta", "coef")] + \
+               [("count", f64), ("pscale", f32), ("nrep", i32), ("C", i32), ("CP", i32)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [(n, vp) for n in ("x", "y", "wfrag_hi", "wfrag_lo", "in_scale", "in_shift", "bias", "stats", "ktab")] + \
                [(n, i32) for n in (
@@ -42,7 +52,8 @@ class ConvArgs(C.Structure):
                                                                            ("y8", vp), ("y8_plane", i64), ("f8_wscale", vp), ("y8_scale", f32), ("f8_bin", i32),
                                                                            ("group_batch", i32), ("nslices", i32),
                                                                           ("slice_wfrag_stride", i64), ("x_lo_delta", i64), ("y_lo_delta", i64),
-                                                                          ("bias_tab", vp), ("bias_tab_gstride", i32), ("pad_", i32), ("wfrag_gstride", i64)]
+                                                                          ("bias_tab", vp), ("bias_tab_gstride", i32), ("pad_", i32), ("wfrag_gstride", i64),
+                                                                          ("bnb", BnBwdArgs), ("dz_sums", vp)]
 
 
 class WgradArgs(C.Structure):
@@ -130,6 +141,8 @@ _SIGS = {
     "sp_conv_prep_weights": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, vp], i32),
     "sp_conv_fold_bias": ([vp, i64, i64, i32, i32, i32, vp, vp, vp, i32, vp], i32),
     "sp_conv_prep_folded": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, vp], i32),
+    "sp_conv_prep_folded_bn": ([vp, i64, i64, i32, i32, vp, i32, i32, vp, vp, i32, vp, vp, i32, C.POINTER(BnFinArgs), vp], i32),
+    "sp_first_prep_bn": ([vp, vp, vp, vp, vp, i32, C.POINTER(BnFinArgs), vp], i32),
     "sp_conv3d_wgrad": ([C.POINTER(WgradArgs), vp], i32),
     "sp_wgrad_finish": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, i32, i32, vp], i32),
     "sp_wgrad_finish_folded": ([vp, i32, vp, i32, i32, i32, i32, i32, i64, i64, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp], i32),

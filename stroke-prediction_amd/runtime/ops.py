@@ -32,6 +32,8 @@ def bump_param_epoch():
     PARAM_EPOCH[0] += 1
 
 
+FUSE_BN_FINALIZE = bool(int(os.environ.get("SP_FUSE_BN_FINALIZE", "1")))   # sp_bn_finalize inside the weight re-pack kernel of the folded layers (one launch less per layer)
+FUSE_DZ = bool(int(os.environ.get("SP_FUSE_DZ", "1")))   # the second convolution's data gradient writes the first one's dz (BatchNorm / activation backward in its epilogue)
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
 MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
 WGRAD_PARTS = not os.environ.get("SP_WGRAD_ATOMICS")      # weight-gradient partial blocks + summing finish instead of fp32 atomics
@@ -353,10 +355,16 @@ class ConvRunner:
     def has_bias(self, v):
         self._st["has_bias"] = v
 
-    def prep(self, w, b=None, fold_scale=None, fold_shift=None):
+    def can_fuse_bn(self):
+        """prep(bn=...) exists for this runner: one set of fragments, re-packed by sp_conv_prep_folded"""
+        return FUSE_BN_FINALIZE and len(self._pack()) == 1
+
+    def prep(self, w, b=None, fold_scale=None, fold_shift=None, bn=None):
         """Re-pack the current fp32 weights (any layout described by the plan's strides) and bias.
         fold_scale / fold_shift: fold a BatchNorm (x*scale+shift on the input channels) into weights and bias
-        -- exact only for un-padded convolutions."""
+        -- exact only for un-padded convolutions.
+        bn (lib.BnFinArgs, ``can_fuse_bn()``): the BatchNorm finalize runs inside the re-pack kernel (sp_conv_prep_folded_bn), which
+        writes fold_scale / fold_shift (= bn.scale / bn.shift) itself."""
         op = self.op
         assert w.dtype == torch.float32 and w.is_contiguous()
         if fold_scale is None:
@@ -370,6 +378,16 @@ class ConvRunner:
         else:
             self._st["prep_key"] = None
         packs = self._pack()
+        if bn is not None:
+            assert len(packs) == 1 and fold_scale is not None and fold_shift is not None
+            kmap, nsteps, hi, lo, nttot, _, _ = packs[0]
+            ntaps = w.numel() // (op.cin * op.cout)
+            L.call("sp_conv_prep_folded_bn", ptr(w), op.w_sco, op.w_sci, op.cout, op.cin, ptr(kmap), nsteps, nttot, ptr(hi), ptr(lo), ntaps,
+                   ptr(b), ptr(self.bias), nttot * 16, C.byref(bn), stream())
+            self.has_bias = True
+            if not self.uses_zm() and self.fc is None:
+                self._prep_zr(w, fold_scale)
+            return
         if fold_scale is not None and fold_shift is not None and len(packs) == 1:
             kmap, nsteps, hi, lo, nttot, _, _ = packs[0]
             ntaps = w.numel() // (op.cin * op.cout)
@@ -403,10 +421,14 @@ class ConvRunner:
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
             dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None,
-            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0):
+            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0, bnb=None, dz_sums=None):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
-        y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners)."""
+        y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners).
+        stats_mode 2 (z-marching data gradients, ``zm_bn_bwd_ok()``): y receives dz = (c0 g + c1 aux + c2) act'(aux) instead of the data
+        gradient g -- bnb = dict(sums, nrep, count, gamma, mean, invstd, C, CP, dgamma, dbeta, pscale[, coef]) are sp_bn_bwd_finalize's
+        arguments (the kernel finalizes the coefficients itself), dz_sums the (SP_REDUCE_ROWS, CPo) accumulator of sum dz; act /
+        act_param describe the activation whose derivative is taken."""
         op = self.op
         assert y8 is None or (self.zm_y8_ok() and not group_batch and use_bias and act in (L.ACT_NONE, L.ACT_LEAKY))
         dtype_out = op.dtype if dtype_out is None else dtype_out
@@ -452,6 +474,14 @@ class ConvRunner:
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
         a.group_batch = group_batch if (group_batch and group_batch < batch and stats is not None) else 0
+        if stats_mode == 2:
+            assert self.zm_bn_bwd_ok() and bnb is not None and dz_sums is not None and aux is not None and stats is None and not group_batch
+            assert dz_sums.dtype == torch.float64 and dz_sums.numel() == L.SP_REDUCE_ROWS * y.shape[4]
+            b = a.bnb
+            b.sums, b.gamma, b.mean, b.invstd = ptr(bnb["sums"]), ptr(bnb["gamma"]), ptr(bnb["mean"]), ptr(bnb["invstd"])
+            b.dgamma, b.dbeta, b.coef = ptr(bnb.get("dgamma")), ptr(bnb.get("dbeta")), ptr(bnb.get("coef"))
+            b.count, b.pscale, b.nrep, b.C, b.CP = float(bnb["count"]), float(bnb.get("pscale", 1.0)), int(bnb["nrep"]), int(bnb["C"]), int(bnb["CP"])
+            a.dz_sums = ptr(dz_sums)
         if op.dtype == L.SP_HL:
             a.x_lo_delta, a.y_lo_delta = x_lo.data_ptr() - x.data_ptr(), y_lo.data_ptr() - y.data_ptr()
         if y8 is not None:
@@ -466,7 +496,7 @@ class ConvRunner:
             a.bias_tab, a.bias_tab_gstride, a.wfrag_gstride = ptr(gt), gts, gfs
             return _run_zm_impl(self, a, x_planar, batch, stats is not None, st, wfrag=gf)
         if self.uses_zm():
-            assert batch == self.zm_batch and in_scale is None and (stats_mode == 0 or (stats_mode == 1 and self.zm_bn_bwd_ok())) \
+            assert batch == self.zm_batch and in_scale is None and (stats_mode == 0 or (stats_mode in (1, 2) and self.zm_bn_bwd_ok())) \
                 and act in (L.ACT_NONE, L.ACT_LEAKY, L.ACT_ELU), \
                 "this runner packed its weights for the z-marching kernel (ConvRunner(zm_batch=...)): batch size, " \
                 "affine-on-load, statistics mode and activation must be what was promised"

@@ -410,6 +410,15 @@ class UnetEngine:
             O.pool_skip_act_bwd(prod.y, gp, coefp, cat, g, coef, c_up, dt, L.ACT_LEAKY, LEAKY, prod.dz_target(), prod.dbias_sums,
                                 q8=prod.dz8_out(), y8=None if prod.store_y else prod.y8)
 
+    def _block_inner_bwd(self, c1, c2, params, grads):
+        """backward of a block's second convolution down to the dz of its first one (Unet3D.py:18-24: BatchNorm -> conv -> LeakyReLU
+        -> BatchNorm -> conv): where the data gradient's kernel has the epilogue, g never reaches memory (ConvLayer.can_fuse_dz)"""
+        if c2.can_fuse_dz(c1):
+            c2.backward(c1.y, params, grads, fuse_dz=(c1.dz, c1.dbias_sums, L.ACT_LEAKY, LEAKY))
+            return
+        g, coef = c2.backward(c1.y, params, grads)
+        O.bn_act_bwd(g, c1.y, coef, self.dtype, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out(), y8=None if c1.store_y else c1.y8)
+
     # ------------------------------------------------------------------------------------------ backward
     def backward(self, dseg, seg, params, grads, ready=None):
         if self.loss_scale == 1.0:
@@ -507,8 +516,7 @@ class UnetEngine:
         skip = {}                     # down block index -> (concat buffer, its gradient, coefficients, channels of the upsampled part)
         for u in range(2 * S - 1, S, -1):
             c1, c2 = self.conv[u]
-            g, coef = c2.backward(c1.y, params, grads)
-            O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out(), y8=None if c1.store_y else c1.y8)
+            self._block_inner_bwd(c1, c2, params, grads)
             gu, coefu = c1.backward(self.cat[u], params, grads)
             if ready is not None and u == S + 1:     # every up block and the head are final: their all-reduce bucket may start
                 ready("block%d." % (S + 1))
@@ -516,15 +524,16 @@ class UnetEngine:
             skip[2 * S - u] = (self.cat[u], gu, coefu, self.channels[u - 1])
         for i in range(S, 0, -1):
             c1, c2 = self.conv[i]
-            g, coef = c2.backward(c1.y, params, grads)
             if i > 1:
-                O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz_target(), c1.dbias_sums, q8=c1.dz8_out(), y8=None if c1.store_y else c1.y8)
+                self._block_inner_bwd(c1, c2, params, grads)
                 gp, coefp = c1.backward(self.pooled[i - 1], params, grads)
                 if ready is not None and i == 2:
                     ready("block2.")
                 cat, gu, coefu, c_up = skip[i - 1]
                 self._skip_bwd(self.conv[i - 1][1], gp, coefp, cat, gu, coefu, c_up)
-            elif self.first_packed and coef is not None and c1.cpo in (16, 32):
+                continue
+            g, coef = c2.backward(c1.y, params, grads)
+            if self.first_packed and coef is not None and c1.cpo in (16, 32):
                 c1.backward(self.x0, params, grads, g=g, coef=coef)     # dz formed inside the weight-gradient kernel
             else:
                 O.bn_act_bwd(g, c1.y, coef, dt, L.ACT_LEAKY, LEAKY, c1.dz, c1.dbias_sums)

@@ -1,0 +1,219 @@
+"""Round-5 GPU tests: launches folded into their consumers on the headline step's dependent chain.
+
+* ``sp_conv_prep_folded_bn`` / ``sp_first_prep_bn``: the BatchNorm finalize (Unet3D.py:18,21 -- batch statistics -> scale / shift,
+  running buffers) inside the weight re-pack kernel of the convolution it is folded into: bit-identical fragments, bias, scale /
+  shift / mean / invstd and running statistics with ``sp_bn_finalize`` + ``sp_conv_prep_folded`` / ``sp_first_prep_n``;
+* ``sp_conv3d_zm`` with ``stats_mode = 2``: the data gradient of a block's second convolution with the BatchNorm backward and the
+  first convolution's LeakyReLU derivative in its epilogue (dz out, coefficients finalized in the kernel's prologue) against the
+  three-kernel path it replaces (data gradient -> ``sp_bn_bwd_finalize`` -> ``sp_bn_act_bwd``) and against float64 torch;
+* the whole training step with both on and off: same losses, gradients and BatchNorm buffers.
+"""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from stroke_prediction_amd.runtime import lib as L
+from stroke_prediction_amd.runtime import ops as O
+from stroke_prediction_amd.runtime import plan as P
+from stroke_prediction_amd.runtime import layers as LY
+
+DEV = "cuda:0"
+LEAKY = 0.01
+
+
+def bf(t):
+    return t.bfloat16().float()
+
+
+def _to_cl(x, cp):
+    dst = O.alloc_cl(x.shape[0], x.shape[2:], cp, L.SP_BF16, DEV)
+    O.ncdhw_to_cl(x.contiguous().to(DEV), dst, L.SP_BF16)
+    return dst
+
+
+def _from_cl(t, c):
+    out = torch.empty((t.shape[0], c) + tuple(t.shape[1:4]), dtype=torch.float32, device=DEV)
+    O.cl_to_ncdhw(t, out, L.SP_BF16)
+    return out.cpu()
+
+
+def _bn_args(sums, nrep, count, gamma, beta, rm, rv, training, c, cp, scale, shift, mean, invstd):
+    f = L.BnFinArgs()
+    f.sums, f.gamma, f.beta = O.ptr(sums), O.ptr(gamma), O.ptr(beta)
+    f.running_mean, f.running_var = O.ptr(rm), O.ptr(rv)
+    f.scale, f.shift, f.mean, f.invstd = O.ptr(scale), O.ptr(shift), O.ptr(mean), O.ptr(invstd)
+    f.count, f.momentum, f.eps = float(count), 0.1, 1e-5
+    f.nrep, f.training, f.C, f.CP = nrep, int(training), c, cp
+    return f
+
+
+@pytest.mark.parametrize("cin,cout,training", [(16, 16, True), (48, 16, True), (96, 32, True), (32, 32, False), (24, 24, True)])
+def test_batchnorm_finalize_inside_the_weight_repack_kernel(cin, cout, training):
+    g = torch.Generator().manual_seed(cin + cout)
+    cpi, cpo = O.cpad(cin, 16), O.cpad(cout, 16)
+    dims = (9, 20, 36)
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cpi, cpo, L.SP_BF16)
+    w = (torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)).to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    gamma, beta = (torch.rand(cin, generator=g) + 0.5).to(DEV), (torch.randn(cin, generator=g) * 0.1).to(DEV)
+    nrep, count = 64, 4321.0
+    s1 = torch.randn(nrep, cpi, generator=g, dtype=torch.float64) * 30
+    s2 = s1 ** 2 / count * nrep + torch.rand(nrep, cpi, generator=g, dtype=torch.float64) * 80      # positive variances
+    sums = torch.stack((s1, s2), -1).contiguous().to(DEV)
+    res = []
+    for fused in (False, True):
+        run = O.ConvRunner(op, DEV, zm_batch=2)
+        assert run.can_fuse_bn()
+        rm, rv = torch.linspace(-1, 1, cin, device=DEV), torch.linspace(0.5, 2, cin, device=DEV)
+        scale, shift, mean, invstd = (torch.full((cpi,), 7.0, device=DEV) for _ in range(4))
+        if fused:
+            f = _bn_args(sums, nrep, count, gamma, beta, rm, rv, training, cin, cpi, scale, shift, mean, invstd)
+            run.prep(w, b, scale, shift, bn=f)
+        else:
+            O.bn_finalize(sums, count, gamma, beta, rm, rv, 0.1, 1e-5, training, cin, cpi, scale, shift, mean, invstd, nrep=nrep)
+            run.prep(w, b, scale, shift)
+        torch.cuda.synchronize()
+        z = run.zm if run.uses_zm() else run.subs[0]
+        res.append((z["hi"].clone(), run.bias.clone(), scale, shift, mean, invstd, rm, rv))
+    for a, bb in zip(*res):
+        assert torch.equal(a, bb)
+    assert float(res[1][2][:cin].abs().min()) > 0 and (cpi == cin or float(res[1][2][cin:].abs().max()) == 0)
+
+
+@pytest.mark.parametrize("cout,hl", [(16, False), (32, False), (16, True)])
+def test_first_layer_repack_with_the_batchnorm_finalize_inside(cout, hl):
+    g = torch.Generator().manual_seed(cout)
+    w = (torch.randn(cout, 2, 3, 3, 3, generator=g) / 7).to(DEV)
+    b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+    gamma, beta = (torch.rand(2, generator=g) + 0.5).to(DEV), (torch.randn(2, generator=g) * 0.1).to(DEV)
+    nrep, count, cp = 64, 99999.0, 16
+    s1 = torch.randn(nrep, cp, generator=g, dtype=torch.float64) * 30
+    s2 = s1 ** 2 / count * nrep + torch.rand(nrep, cp, generator=g, dtype=torch.float64) * 80
+    sums = torch.stack((s1, s2), -1).contiguous().to(DEV)
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(2, device=DEV), torch.ones(2, device=DEV)
+        scale, shift, mean, invstd = (torch.full((cp,), 7.0, device=DEV) for _ in range(4))
+        wf = torch.zeros((cout // 16) * 3 * 64 * 8, dtype=torch.bfloat16, device=DEV)
+        wl = torch.zeros_like(wf) if hl else None
+        bias_f = torch.zeros(cout, device=DEV)
+        if fused:
+            f = _bn_args(sums, nrep, count, gamma, beta, rm, rv, True, 2, cp, scale, shift, mean, invstd)
+            L.call("sp_first_prep_bn", O.ptr(w), O.ptr(b), O.ptr(wf), O.ptr(wl), O.ptr(bias_f), cout, C.byref(f), O.stream())
+        else:
+            O.bn_finalize(sums, count, gamma, beta, rm, rv, 0.1, 1e-5, True, 2, cp, scale, shift, mean, invstd, nrep=nrep)
+            if hl:
+                L.call("sp_first_prep_hl", O.ptr(w), O.ptr(b), O.ptr(scale), O.ptr(shift), O.ptr(wf), O.ptr(wl), O.ptr(bias_f), cout, O.stream())
+            else:
+                L.call("sp_first_prep_n", O.ptr(w), O.ptr(b), O.ptr(scale), O.ptr(shift), O.ptr(wf), O.ptr(bias_f), cout, O.stream())
+        torch.cuda.synchronize()
+        res.append((wf, bias_f, scale, shift, mean, invstd, rm, rv) + ((wl,) if hl else ()))
+    for a, bb in zip(*res):
+        assert torch.equal(a, bb)
+
+
+# cin (of the second convolution = channels of x / dz_out), cout, input dims of the second convolution, batch: the (P, NT) instances
+# (1, 1) and (2, 2) of the headline network's blocks, (1, 2) / (2, 1), ragged planes, a flattened tile (52 x 52 -> 25 x 10)
+DZ_CASES = [(16, 16, (9, 36, 40), 2), (32, 32, (7, 21, 37), 2), (32, 16, (6, 33, 18), 1), (16, 32, (5, 19, 50), 2), (32, 32, (4, 52, 52), 1)]
+
+
+@pytest.mark.parametrize("cin,cout,dims,B", DZ_CASES)
+def test_data_gradient_with_the_batchnorm_and_activation_backward_in_its_epilogue(cin, cout, dims, B, monkeypatch):
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    g = torch.Generator().manual_seed(cin * 3 + cout + B)
+    od = tuple(d - 2 for d in dims)
+    x = bf(torch.randn(B, cin, *dims, generator=g))                       # the first convolution's output (LeakyReLU applied)
+    dzu = bf(torch.randn(B, cout, *od, generator=g))                      # dz of the second convolution
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    gamma = (torch.rand(cin, generator=g) + 0.5).to(DEV)
+    mean, invstd = (torch.randn(cin, generator=g) * 0.2).to(DEV), (torch.rand(cin, generator=g) + 0.7).to(DEV)
+    dop = P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin, L.SP_BF16)
+    run = O.ConvRunner(dop, DEV, zm_batch=B)
+    assert run.zm_bn_bwd_ok()
+    run.prep(w.to(DEV))
+    xs, dzs = _to_cl(x, cin), _to_cl(dzu, cout)
+    count = float(B * dims[0] * dims[1] * dims[2])
+    nrep = 64
+    # ---- the three-kernel path: g stored, (sum g, sum g x) from its epilogue, finalize, elementwise pass
+    gbuf = O.alloc_cl(B, dims, cin, L.SP_BF16, DEV)
+    bs = torch.zeros(nrep * cin * 2, dtype=torch.float64, device=DEV)
+    run.run(dzs, gbuf, B, stats=bs, stats_nrep=nrep, stats_mode=1, aux=xs)
+    dgam_a, dbet_a = torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
+    coef = torch.zeros(3, cin, device=DEV)
+    O.bn_bwd_finalize(bs, count, gamma, mean, invstd, cin, cin, dgam_a, dbet_a, coef, nrep=nrep)
+    dz_a = torch.empty_like(gbuf)
+    sums_a = torch.zeros(L.SP_REDUCE_ROWS, cin, dtype=torch.float64, device=DEV)
+    O.bn_act_bwd(gbuf, xs, coef, L.SP_BF16, L.ACT_LEAKY, LEAKY, dz_a, sums_a)
+    # ---- one kernel
+    dz_b = torch.full_like(gbuf, 7.0)
+    sums_b = torch.zeros(L.SP_REDUCE_ROWS, cin, dtype=torch.float64, device=DEV)
+    dgam_b, dbet_b = torch.zeros(cin, device=DEV), torch.zeros(cin, device=DEV)
+    coef_b = torch.zeros(3, cin, device=DEV)
+    run.run(dzs, dz_b, B, None, None, L.ACT_LEAKY, LEAKY, None, stats_mode=2, aux=xs, dz_sums=sums_b,
+            bnb=dict(sums=bs, nrep=nrep, count=count, gamma=gamma, mean=mean, invstd=invstd, C=cin, CP=cin, dgamma=dgam_b, dbeta=dbet_b, coef=coef_b))
+    torch.cuda.synchronize()
+    assert torch.equal(coef, coef_b) and torch.equal(dgam_a, dgam_b) and torch.equal(dbet_a, dbet_b)
+    a, b_ = _from_cl(dz_a, cin), _from_cl(dz_b, cin)
+    # the same arithmetic on the same rounded g up to the contraction of c0 g + c1 x + c2 into fmas: a last-bit difference at most
+    scale = float(a.abs().max())
+    assert float((a - b_).abs().max()) <= 2.0 ** -7 * scale and float((a != b_).float().mean()) < 0.02
+    torch.testing.assert_close(sums_b.sum(0).cpu(), sums_a.sum(0).cpu(), rtol=1e-6, atol=1e-4 * math.sqrt(count))
+    # ---- float64 reference of the whole chain from the stored g's definition
+    gref = F.conv_transpose3d(dzu.double(), bf(w).double())
+    cf = coef.double().cpu()
+    ref = (cf[0].view(1, -1, 1, 1, 1) * bf(gref.float()).double() + cf[1].view(1, -1, 1, 1, 1) * x.double() + cf[2].view(1, -1, 1, 1, 1)) \
+        * torch.where(x > 0, 1.0, LEAKY).double()
+    torch.testing.assert_close(b_.double(), ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
+
+
+def _train_steps(dtype, fuse, monkeypatch, steps=3, dims=(52, 52, 52)):
+    import stroke_prediction_amd  # noqa: F401
+    from oracle import weights as W
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.optim import FusedAdam
+    monkeypatch.setattr(O, "FUSE_BN_FINALIZE", fuse)
+    monkeypatch.setattr(O, "FUSE_DZ", fuse)
+    ch = [2, 16, 32, 64, 32, 16, 32, 2]
+    x, y = W.unet_inputs(2, dims, 11)
+    model = Unet3D(ch, dtype=dtype)
+    model.load_state_dict(W.make_state_dict(W.unet_spec(ch), 11))
+    model = model.to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    crit = BatchDiceLoss([1.0])
+    xd, yd = x.to(DEV), y.to(DEV)
+    losses, g0 = [], None
+    for _ in range(steps):
+        dto = model(UnetDtoUtil.init_dto(xd, yd[:, 0:1], yd[:, 1:2]))
+        loss = (crit(dto.outputs.core, dto.given_variables.core) + crit(dto.outputs.penu, dto.given_variables.penu)) / 2
+        opt.zero_grad()
+        loss.backward()
+        if g0 is None:
+            g0 = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+        opt.step()
+        losses.append(float(loss))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return losses, g0, sd
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
+def test_training_steps_with_and_without_the_folded_launches(dtype, monkeypatch):
+    """three Adam steps of the 3-scale U-Net: BatchNorm finalize inside the re-pack kernels (bit-identical by construction) and the
+    dz epilogue of the second convolutions' data gradients (last-bit differences of dz) against the un-fused launches"""
+    la, ga, sa = _train_steps(dtype, False, monkeypatch)
+    lb, gb, sb = _train_steps(dtype, True, monkeypatch)
+    assert abs(la[0] - lb[0]) < 1e-7                       # the first forward is bit-identical
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 2e-3, (la, lb)
+    for k in ga:
+        den = float(ga[k].norm()) + 1e-12
+        assert float((ga[k] - gb[k]).norm()) / den < 2e-2, (k, float((ga[k] - gb[k]).norm()) / den)
+    for k in sa:
+        if "running" in k or "num_batches" in k:
+            torch.testing.assert_close(sa[k].float(), sb[k].float(), rtol=1e-3, atol=1e-4)
