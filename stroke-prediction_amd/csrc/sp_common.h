@@ -325,9 +325,18 @@ __device__ __forceinline__ void sp_bn_fin_block(const sp_bn_fin_args& f, bool pu
     if (f.training) {
       for (int c = l32; c < cn; c += 32) {
         double s1 = 0, s2 = 0;
-        if (cb + c < f.C) {
-          const double* p = f.sums + ((size_t)grp * f.CP + cb + c) * 2;
-          for (int r = grp; r < f.nrep; r += ngrp, p += (size_t)ngrp * f.CP * 2) { s1 += p[0]; s2 += p[1]; }
+        if (cb + c < f.C) {      // eight independent 16-byte loads per trip (64 replica rows over 8 groups: one trip)
+          const size_t rs = (size_t)f.CP * 2;
+          const double* p = f.sums + (size_t)grp * rs + (size_t)(cb + c) * 2;
+          int r = grp;
+          for (; r + 7 * ngrp < f.nrep; r += 8 * ngrp, p += 8 * ngrp * rs) {
+            double2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = *reinterpret_cast<const double2*>(p + (size_t)k * ngrp * rs);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { s1 += v[k].x; s2 += v[k].y; }
+          }
+          for (; r < f.nrep; r += ngrp, p += ngrp * rs) { s1 += p[0]; s2 += p[1]; }
         }
         sp_bn_part_[grp][c][0] = s1;
         sp_bn_part_[grp][c][1] = s2;

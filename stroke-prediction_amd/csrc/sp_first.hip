@@ -203,14 +203,18 @@ __global__ void first_prep_kernel(const float* __restrict__ w, const float* __re
     wfrag[((size_t)blockIdx.x * 192 + t) * 8 + e] = hv;
     if (wfrag_lo) wfrag_lo[((size_t)blockIdx.x * 192 + t) * 8 + e] = f2bf(v - bf2f(hv));      // (bf16 pair: w = hi + lo)
   }
-  if (t < 16 && blockIdx.x == 0)
-    for (int cb = t; cb < Cout; cb += 16) {      // (natural channel order)
-      float acc = b ? b[cb] : 0.f;
-      if (shift)
-        for (int c = 0; c < 2; ++c)
-          for (int k = 0; k < 27; ++k) acc = fmaf(w[(cb * 2 + c) * 27 + k], shift[c], acc);
-      bias_f[cb] = acc;
+  if (t < Cout && blockIdx.x == 0) {      // (natural channel order; one thread per channel, its 54 loads independent)
+    const int cb = t;
+    float acc = b ? b[cb] : 0.f;
+    if (shift) {
+      float wv[54];
+#pragma unroll
+      for (int k = 0; k < 54; ++k) wv[k] = w[cb * 54 + k];
+#pragma unroll
+      for (int k = 0; k < 54; ++k) acc = fmaf(wv[k], shift[k / 27], acc);
     }
+    bias_f[cb] = acc;
+  }
 }
 
 // Cout = 16 (the 3-scale network of BASELINE.json configs[1]) or 32 (the 4-scale one, configs[4]): one or two output tiles

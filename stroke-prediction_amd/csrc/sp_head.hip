@@ -499,8 +499,17 @@ __global__ __launch_bounds__(1024) void head_grad_finish_kernel(const float* __r
   const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cl;
   double acc = 0.0;
-  if (col < NQ)
-    for (int r = rg; r < rows; r += 16) acc += (double)part[(size_t)r * NQ + col];
+  if (col < NQ) {      // (eight independent loads per trip: a plain loop pays a memory round trip per row -- 48 of them)
+    int r = rg;
+    for (; r + 7 * 16 < rows; r += 8 * 16) {
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = part[(size_t)(r + 16 * k) * NQ + col];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += (double)t[k];
+    }
+    for (; r < rows; r += 16) acc += (double)part[(size_t)r * NQ + col];
+  }
   red[rg][cl] = acc;
   __syncthreads();
   if (rg == 0 && col < NQ) {
