@@ -176,6 +176,11 @@ typedef struct sp_conv_args {
    * dz_sums[SP_REDUCE_ROWS][CPo] += sum over voxels of dz (the first convolution's bias gradient / folded weight-gradient term). */
   sp_bn_bwd_args bnb;
   double* dz_sums;
+  /* ---- sp_conv3d_zm forward layers (P, NT) = (1, 1) / (2, 2): MaxPool3d(2, 2) (floor) of the output rides in the epilogue
+   * (Unet3D.py:59,62): pool_y [B][YD/2][YH/2][YW/2][CPo] (SP_HL: the lo half pool_lo_delta bytes behind) is written next to y, and
+   * `stats` then receives the statistics of the POOLED tensor -- the next block's BatchNorm input -- instead of y's */
+  void* pool_y;
+  int64_t pool_lo_delta;
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);

@@ -130,7 +130,12 @@ template <> struct ZmStore<float> {
 // dz) are gone.
 // BatchNorm groups (a.group_batch > 0: the batch holds B / group_batch passes with statistics of their own): the sums are flushed
 // to the rows of the sample's group whenever a workgroup's march crosses into another group.
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false>
+// POOL (a.pool_y; the second convolution of a down block, Unet3D.py:58-62): MaxPool3d(2) of the output rides in the epilogue --
+// x pairs by DPP, y pairs from the wave's two row groups, z pairs from a register set held across one step (pieces start at even
+// planes, so which step holds and which emits is known at compile time) -- and the statistics the kernel accumulates are those of the
+// POOLED tensor (the next block's BatchNorm input; nobody needs the un-pooled tensor's): sp_maxpool2_fwd's pass over the largest
+// activations of the network (read 8, write 1) is gone.
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false, bool POOL = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -144,7 +149,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int S = NJ * NW * 1024;               // slot stride in bytes
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
-  constexpr int NS = MT * NT * ((Q8 || HL) ? 2 : 1);      // store instructions of one epilogue
+  static_assert(!POOL || (ACT == 1 && STATS == 1 && !Q8 && MT % 2 == 0 && sizeof(TOUT) == 2), "pooling epilogue: forward layers with statistics, 16-bit output, row pairs inside a wave");
+  constexpr int NSP = POOL ? (MT / 2) * NT * (HL ? 2 : 1) : 0;      // pooled stores of one epilogue (issued every step: the hold steps' are dropped)
+  constexpr int NS = MT * NT * ((Q8 || HL) ? 2 : 1) + NSP;      // store instructions of one epilogue
   constexpr int NA = STATS >= 2 ? MT * NT : 0;            // loads of the layer input per step (STATS 2, 3)
   constexpr int NSA = NS + NA;
   static_assert(D >= 1 && D <= 5 && (D - 1) * (NJ + NSA) <= 63, "counted vmcnt does not fit its 6-bit field");
@@ -325,14 +332,18 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 
   // Work = (column, output plane) pairs cut into gridDim.x equal pieces of the flattened sequence; a piece that starts
   // inside a column pays the two-plane prologue again.  XCD-aware piece id (neighbouring columns share halo in one L2).
-  const uint64_t T = (uint64_t)Q.ncols * a.Do;
+  // (POOL: the unit is a PAIR of planes, so every piece starts at an even plane)
+  const uint32_t DoU = POOL ? (uint32_t)(a.Do + 1) / 2 : (uint32_t)a.Do;
+  const uint64_t T = (uint64_t)Q.ncols * DoU;
   uint64_t pos = T * vb / nvb;
   const uint64_t pend_pos = T * (vb + 1) / nvb;
+  float phold[POOL ? MT / 2 : 1][POOL ? NT : 1][4];      // POOL: (x, y)-pooled values of the even plane, until the odd one's epilogue
   while (pos < pend_pos) {
-    const uint32_t col = (uint32_t)(pos / (uint32_t)a.Do);
-    const int z0 = (int)(pos - (uint64_t)col * a.Do);
-    const int z1 = (int)min((uint64_t)a.Do, (uint64_t)z0 + (pend_pos - pos));
-    pos += (uint64_t)(z1 - z0);
+    const uint32_t col = (uint32_t)(pos / DoU);
+    const int u0 = (int)(pos - (uint64_t)col * DoU);
+    const int u1 = (int)min((uint64_t)DoU, (uint64_t)u0 + (pend_pos - pos));
+    pos += (uint64_t)(u1 - u0);
+    const int z0 = POOL ? 2 * u0 : u0, z1 = POOL ? min(a.Do, 2 * u1) : u1;
     const int nz = z1 - z0, nin = nz + 2;                     // output planes of this piece, input planes they need
     uint32_t t = col;
     uint32_t q = fdiv(t, Q.d_tx); const int tx = t - q * Q.ntx; t = q;
@@ -436,6 +447,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         btrow[m] = ((bt_class(oy, bt_py, a.Ho) * bt_nx + bt_class(ox, bt_px, a.Wo)) * (NT * 16) + lg * 4) * 4;
       }
     }
+    // POOL: the pooled tensor of sample b [YD/2][YH/2][YW/2][CPo] (HL: its lo half pool_lo_delta bytes behind) and the offset of
+    // this lane's pooled voxel per row pair (even lanes of even rows whose 2 x 2 window lies inside the output)
+    const int Dp = a.YD >> 1, Hp = a.YH >> 1, Wp = a.YW >> 1;
+    const uint32_t psz = (uint32_t)Dp * Hp * Wp * a.CPo * 2u;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(POOL ? reinterpret_cast<unsigned char*>(a.pool_y) + (size_t)b * psz : nullptr), 0, (int)(POOL ? psz : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t prs_lo = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((POOL && HL) ? reinterpret_cast<unsigned char*>(a.pool_y) + a.pool_lo_delta + (size_t)b * psz : nullptr), 0, (int)((POOL && HL) ? psz : 0u), 0x00020000);
+    uint32_t poff[POOL ? MT / 2 : 1];
+    if constexpr (POOL) {
+#pragma unroll
+      for (int mp = 0; mp < MT / 2; ++mp) {
+        const int oy = oy0 + wave * MT + 2 * mp, ox = ox0 + lv;      // (classic tile: checked by the host)
+        const bool ok = (lv & 1) == 0 && (oy >> 1) < Hp && (ox >> 1) < Wp;
+        poff[mp] = ok ? (uint32_t)((((oy >> 1) * Wp + (ox >> 1)) * a.CPo + lg * 4) * 2) : 0x80000000u;
+      }
+    }
+    const uint32_t pzstride = (uint32_t)(Hp * Wp * a.CPo * 2);
     const uint32_t zstride = (uint32_t)(a.osD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
     const uint32_t zbase = (uint32_t)(a.ooD * a.YH * a.YW * a.CPo * (int)sizeof(TOUT));
     // the e4m3 copy (dense output only: no phase strides): plane n of sample b, 4 bytes per lane at voxel * 16 + lg * 4
@@ -471,9 +500,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 
     // epilogue of the plane held by accumulator set R: straight-line code (no branch); fz < 0 (no finished plane) turns
     // every store into an out-of-range one and every statistics term into 0 -- the instruction count never changes
-#define ZM_EPILOGUE(R_, fz_, AX_)                                                                                   \
+#define ZM_EPILOGUE(R_, fz_, AX_, EMIT_)                                                                            \
   {                                                                                                               \
     const bool pv = (fz_) >= 0;                                                                                   \
+    /* POOL: plane fz is odd in the EMIT_ steps (pieces start at even planes): its pooled plane (fz_ >> 1), if inside */ \
+    const uint32_t pzo_ = (POOL && (EMIT_) && pv && ((fz_) >> 1) < Dp) ? (uint32_t)((fz_) >> 1) * pzstride : 0x80000000u; \
     const uint32_t zoff = pv ? zbase + (uint32_t)(fz_) * zstride : 0x80000000u;                                   \
     const uint32_t pm = pv ? 0xffffffffu : 0u;                                                                    \
     const unsigned char* btz_ = lds + BTOFF + (PB ? bt_class(pv ? (fz_) : 0, bt_pz, a.Do) * (bt_ny * bt_nx * NT * 64) : 0); \
@@ -513,7 +544,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           const float r_[4] = {sp_h2f_lo(w0_), sp_h2f_hi(w0_), sp_h2f_lo(w1_), sp_h2f_hi(w1_)};                   \
           __builtin_amdgcn_raw_buffer_store_b32(zm_pack4_e4m3(r_, q8s), y8rs[n], off8, 0, 0);                     \
         }                                                                                                         \
-        if constexpr (STATS == 1) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
+        if constexpr (STATS == 1 && !POOL) {   /* of the fp32 values (what an fp32 BatchNorm would see; the bf16 rounding averages out) */  \
           _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
             const float u = __uint_as_float(__float_as_uint(v[j]) & msk);                                         \
             s1[n][j] += u; s2[n][j] = fmaf(u, u, s2[n][j]);                                                       \
@@ -531,6 +562,46 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           }                                                                                                       \
         }                                                                                                         \
       }                                                                                                           \
+    }                                                                                                             \
+    /* POOL: a loop nest of its own (the activation of the two row groups is recomputed from the accumulators: a few VALU */ \
+    /* instructions instead of 8 NT live registers across the row loop above) */                                   \
+    if constexpr (POOL) {                                                                                         \
+      _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                              \
+        _Pragma("unroll") for (int mp = 0; mp < MT / 2; ++mp) {                                                   \
+          float o_[4];                                                                                            \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                         \
+            const float za_ = acc[R_][n][2 * mp][j] + bj[n][j], zb_ = acc[R_][n][2 * mp + 1][j] + bj[n][j];       \
+            float pm_ = fmaxf(fmaxf(za_, slope * za_), fmaxf(zb_, slope * zb_));      /* y pair: row groups 2 mp, 2 mp + 1 */ \
+            pm_ = fmaxf(pm_, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, pm_), 0xB1, 0xF, 0xF, true)));   /* x pair: lanes lv, lv ^ 1 */ \
+            o_[j] = (EMIT_) ? fmaxf(phold[POOL ? mp : 0][POOL ? n : 0][j], pm_) : pm_;      /* z pair: the plane held since the last step */ \
+            if (!(EMIT_)) phold[POOL ? mp : 0][POOL ? n : 0][j] = pm_;                                             \
+          }                                                                                                       \
+          const uint32_t po_ = ((pzo_ | poff[POOL ? mp : 0]) & 0x80000000u) ? 0x80000000u : pzo_ + poff[POOL ? mp : 0] + (uint32_t)(n * 32); \
+          const uint32_t pmsk_ = (po_ & 0x80000000u) ? 0u : 0xffffffffu;                                          \
+          if constexpr (HL) {                                                                                     \
+            uint32_t h0_, h1_, l0_, l1_;                                                                          \
+            sp_hl_split4(o_, h0_, h1_, l0_, l1_);                                                                 \
+            const zm_u32x2 dh_ = {h0_, h1_}, dl_ = {l0_, l1_};                                                    \
+            __builtin_amdgcn_raw_buffer_store_b64(dh_, prs, po_, 0, 0);                                           \
+            __builtin_amdgcn_raw_buffer_store_b64(dl_, prs_lo, po_, 0, 0);                                        \
+            if (EMIT_) {      /* (compile time: the hold steps' masked zero terms are not folded away -- and spill) */    \
+              _Pragma("unroll") for (int j = 0; j < 4; ++j) {      /* statistics of the pair values */             \
+                const float u = __uint_as_float(__float_as_uint(o_[j]) & pmsk_);                                  \
+                s1[n][j] += u; s2[n][j] = fmaf(u, u, s2[n][j]);                                                   \
+              }                                                                                                   \
+            }                                                                                                     \
+          } else {                                                                                                \
+            const zm_u32x2 d_ = {zm_pack2(o_[0], o_[1]), zm_pack2(o_[2], o_[3])};                                 \
+            __builtin_amdgcn_raw_buffer_store_b64(d_, prs, po_, 0, 0);                                            \
+            if (EMIT_) {                                                                                          \
+              const float r_[4] = {sp_h2f_lo(d_[0]), sp_h2f_hi(d_[0]), sp_h2f_lo(d_[1]), sp_h2f_hi(d_[1])};      /* of the STORED values, as sp_maxpool2_fwd */ \
+              _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+                const float u = __uint_as_float(__float_as_uint(r_[j]) & pmsk_);                                  \
+                s1[n][j] += u; s2[n][j] = fmaf(u, u, s2[n][j]);                                                   \
+              }                                                                                                   \
+            }                                                                                                     \
+          }                                                                                                       \
+        }                                                                                                         \
     }                                                                                                             \
   }
 
@@ -616,7 +687,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     bf16x8 wa[WLDS ? 3 : 1][WLDS ? NT : 1], wb[WLDS ? 3 : 1][WLDS ? NT : 1];                                      \
     bf16x8 wal[HL ? 3 : 1][HL ? NT : 1], wbl[HL ? 3 : 1][HL ? NT : 1];                                            \
     if (v0 && v1 && v2) {                                                                                         \
-      ZM_EPILOGUE((PH + 1) % 4, fz, (PH) & 1)                                                                     \
+      ZM_EPILOGUE((PH + 1) % 4, fz, (PH) & 1, ((PH) & 1) == 0)                                                    \
       ZM_LDX(x0, x0l, 0)                                                                                          \
       ZM_LDW(wa, wal, 0)                                                                                          \
       _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
@@ -634,7 +705,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) }                                                  \
         if (v0) { ZM_MMA_D0(PH, s, x0, x0l, wa, wal) }                                                            \
       }                                                                                                           \
-      ZM_EPILOGUE((PH + 1) % 4, fz, (PH) & 1)                                                                     \
+      ZM_EPILOGUE((PH + 1) % 4, fz, (PH) & 1, ((PH) & 1) == 0)                                                    \
     }                                                                                                             \
     ZM_T(ts3);                                                                                                    \
     ZM_ACC(0, ts1, ts0); ZM_ACC(1, ts2, ts1); ZM_ACC(2, ts3, ts2); ZM_ACC(3, 1, 0);                               \
@@ -684,7 +755,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false, bool POOL = false>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
   constexpr int NCH = (HL ? 2 : 1) * P * (NW * MT + 2) * 18 * 2;
@@ -718,7 +789,12 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
     grid = 8u * (unsigned)a->nslices * (32u / (unsigned)a->nslices);
     SP_CHECK_ARG(planes >= (uint64_t)grid / a->nslices, "sp_conv3d_zm: too few (column, plane) pairs for %d slices in one launch", a->nslices);
   }
-  if constexpr (HL) {
+  if constexpr (POOL) {
+    SP_CHECK_ARG(Q.tw == 16 && Q.th == NW * MT && a->dtype_out != SP_F32 && !a->y8, "sp_conv3d_zm: the pooling epilogue needs the classic %d x 16 tile and a 16-bit output", NW * MT);
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, HL, true>;
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+  } else if constexpr (HL) {
     auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, true>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
@@ -749,6 +825,11 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   return SP_OK;
 }
 
+#ifdef SP_ZM_PROBE      // tools/kres.py -DSP_ZM_PROBE: resource usage of a few instances without compiling all of them
+extern "C" int sp_zm_probe(const sp_conv_args* a, const void* z, hipStream_t st) {
+  return launch_zm2<2, 2, 2, 3, true, 8, 1, 1, false, true>(a, z, st) + launch_zm2<1, 1, 4, 3, true, 8, 1, 1, true, true>(a, z, st) + launch_zm2<2, 2, 2, 3, true, 8, 1, 1>(a, z, st);
+}
+#else
 template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW>
 static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   const bool plain = a->act == SP_ACT_NONE && a->bias == nullptr;      // data gradients: nothing to do but round and store
@@ -768,6 +849,14 @@ static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
       return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 0, 2>(a, zeros, st);
     } else {
       sp_set_error("sp_conv3d_zm: no ELU instance for P=%d NW=%d", P, NW);
+      return SP_EINVAL;
+    }
+  }
+  if (a->pool_y) {      // MaxPool3d(2) of the output in the epilogue, statistics of the pooled tensor
+    if constexpr (NW == 8 && NSLOT == 3 && ((P == 1 && NT == 1 && MT == 4) || (P == 2 && NT == 2 && MT == 2))) {
+      return launch_zm2<P, NT, MT, NSLOT, true, NW, 1, 1, false, true>(a, zeros, st);      // (weights in LDS: the register form of (1, 1) spills with the pooled set)
+    } else {
+      sp_set_error("sp_conv3d_zm: no pooling-epilogue instance for P=%d NT=%d NW=%d", P, NT, NW);
       return SP_EINVAL;
     }
   }
@@ -815,6 +904,14 @@ extern "C" int sp_conv3d_zm_config_hl(int32_t P, int32_t NT, int32_t* MT, int32_
 
 template <int P, int NT, int MT, int NSLOT, int NW>
 static int launch_zm_hl(const sp_conv_args* a, const void* zeros, hipStream_t st) {
+  if (a->pool_y) {      // MaxPool3d(2) of the pair values in the epilogue
+    if constexpr ((P == 1 && NT == 1 && MT == 4) || (P == 2 && NT == 2 && MT == 2)) {
+      return launch_zm2<P, NT, MT, NSLOT, true, NW, 1, 1, true, true>(a, zeros, st);
+    } else {
+      sp_set_error("sp_conv3d_zm: no pooling-epilogue pair instance for P=%d NT=%d", P, NT);
+      return SP_EINVAL;
+    }
+  }
   if (a->stats) return launch_zm2<P, NT, MT, NSLOT, true, NW, 1, 1, true>(a, zeros, st);
   return launch_zm2<P, NT, MT, NSLOT, true, NW, 0, 1, true>(a, zeros, st);
 }
@@ -834,6 +931,11 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
                        (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && a->nslices <= 1),
                "sp_conv3d_zm: bf16 pairs in -> bf16 pairs out with hi and lo weight fragments, bias + LeakyReLU / identity epilogue");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
+  SP_CHECK_ARG(!a->pool_y || (a->stats && a->stats_mode == 0 && a->act != SP_ACT_ELU && a->group_batch == 0 && a->nslices <= 1 && !a->y8 && !a->bias_tab &&
+                              a->osD == 1 && a->osH == 1 && a->osW == 1 && a->ooD == 0 && a->ooH == 0 && a->ooW == 0 && a->YD == a->Do && a->YH == a->Ho && a->YW == a->Wo &&
+                              a->YD >= 2 && a->YH >= 2 && a->YW >= 2 && (!hl || (a->pool_lo_delta != 0 && a->pool_lo_delta % 8 == 0)) &&
+                              (uint64_t)(a->YD / 2) * (a->YH / 2) * (a->YW / 2) * a->CPo * 2 < (1ull << 31)),
+               "sp_conv3d_zm: pool_y (MaxPool3d(2) in the epilogue) needs a dense forward layer with statistics (of the pooled tensor), LeakyReLU / identity");
   if (a->bias_tab || a->wfrag_gstride) {
     const int pz = -a->o0D, py = -a->o0H, px = -a->o0W;
     SP_CHECK_ARG(a->act == SP_ACT_ELU && !hl && a->nslices <= 1 && a->dtype_out == SP_BF16, "sp_conv3d_zm: bias table / per-group fragments are for the bf16 ELU instances");
@@ -890,3 +992,5 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
   if (P == 2 && a->NT == 2) return launch_zm<2, 2, 2, 3, true, 8>(a, zeros, st);
   return SP_EINVAL;
 }
+
+#endif

@@ -67,7 +67,7 @@ class Scratch:
 class ConvLayer:
     def __init__(self, name, kind, cin, cout, k, stride, pad, in_dims, batch, dtype, device, scratch,
                  bn_prefix=None, conv_prefix=None, act=L.ACT_NONE, act_param=0.0, out_dtype=None,
-                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8, groups=1, hl=False):
+                 need_input_grad=True, cpi=None, bank=None, split_g=None, pitch=8, groups=1, hl=False, pooled=False):
         """hl (the "bf16x3" precision mode): the FORWARD convolution takes and writes bf16 pairs (SP_HL: x = x_hi + x_lo in two
         tensors, three MFMAs per product); ``self.y`` is the hi half -- the tensor the bf16 mode would have stored -- and the
         backward side below is the bf16 one on the hi tensors, unchanged.
@@ -127,8 +127,11 @@ class ConvLayer:
                          and self.out_dtype == dtype and max(pads) <= 2 and max(strides) == 1 and k == 3
                          and self.cpi % 16 == 0 and self.cpo % 16 == 0)
         # (groups: ONE launch over the whole batch -- the kernel hands its statistics to the rows of a sample's group)
+        # pooled: MaxPool3d(2) follows this layer (the second convolution of a down block): the forward kernel keeps the classic tile,
+        # the shape its pooling epilogue is written for
         self.fwd = O.ConvRunner(self.fwd_op, device, share=None if (bank is None or self.fold) else bank.setdefault((name, "fwd"), {}),
-                                zm_batch=(self.batch if (self.G > 1 and O.ZM_GROUPS) else self.gb) if zm_ok else None)
+                                zm_batch=(self.batch if (self.G > 1 and O.ZM_GROUPS) else self.gb) if zm_ok else None,
+                                zm_tile="classic" if (pooled and O.FUSE_POOL) else None)
         # batched passes on the z-marching kernel: the BatchNorm folded into per-group weight fragments and a bias table over the
         # border classes of the padded output (sp_conv_prep_folded_groups): the forward reads the RAW input, the normalised copy
         # (still the weight gradient's operand) is written later, on the side stream of the backward
@@ -279,9 +282,16 @@ class ConvLayer:
         if training and "__nbt_flat__" not in bufs:      # else: one increment for all BatchNorms (UnetEngine.forward)
             bufs[p + ".num_batches_tracked"].add_(1)
 
-    def forward(self, x, params, bufs, training, out_stats=None, x_lo=None):
+    def can_pool(self):
+        """forward(pool=...) applies: the forward kernel has the MaxPool3d(2) epilogue for this layer's shape"""
+        return bool(self.G == 1 and self.fold and self.f8_fwd is None and not self.want_y8 and self.store_y and self.kind == "conv"
+                    and self.act in (L.ACT_NONE, L.ACT_LEAKY) and self.out_dtype == self.dtype and self.fwd.zm_pool_ok())
+
+    def forward(self, x, params, bufs, training, out_stats=None, x_lo=None, pool=None):
         """x: channels-last input (hl: its hi half, x_lo the lo half); returns the (cached) output tensor (hl: its hi half, the
-        lo half is self.y_lo)."""
+        lo half is self.y_lo).
+        pool = (pooled, pooled_lo | None) (``can_pool()``): the kernel also writes MaxPool3d(2) of the output, and out_stats receives
+        the statistics of the pooled tensor."""
         # folded layers: the BatchNorm finalize rides in the re-pack kernel of the weights it is folded into
         bn = None
         if self.bn_prefix is not None:
@@ -293,8 +303,9 @@ class ConvLayer:
             assert self.fold and x_lo is not None
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift, bn=bn)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=L.SP_HL,
-                         stats_nrep=STATS_NREP, x_planar=self.x_planar, x_lo=x_lo, y_lo=self.y_lo)
+                         stats_nrep=STATS_NREP, x_planar=self.x_planar, x_lo=x_lo, y_lo=self.y_lo, pool=pool)
             return y
+        assert pool is None or (self.fold and self.f8_fwd is None), "pool: folded bf16 layers (can_pool)"
         if self.G > 1 and self.fold_groups:
             op, z = self.fwd_op, self.fwd.zm
             L.call("sp_conv_prep_folded_groups", O.ptr(params[c + ".weight"]), op.w_sco, op.w_sci, op.cout, op.cin, O.ptr(z["kmap_d"]), z["nsteps"],
@@ -339,7 +350,7 @@ class ConvLayer:
         elif self.fold:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"], self.scale, self.shift, bn=bn)
             self.fwd.run(x, y, self.batch, None, None, self.act, self.act_param, out_stats, dtype_out=self.out_dtype,
-                         stats_nrep=STATS_NREP, x_planar=self.x_planar, y8=self.alloc_y8() if self.want_y8 else None)
+                         stats_nrep=STATS_NREP, x_planar=self.x_planar, y8=self.alloc_y8() if self.want_y8 else None, pool=pool)
         else:
             self.fwd.prep(params[c + ".weight"], params[c + ".bias"])
             self.fwd.run(x, y, self.batch, self.scale, self.shift, self.act, self.act_param, out_stats,

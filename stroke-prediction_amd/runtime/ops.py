@@ -33,6 +33,7 @@ def bump_param_epoch():
 
 
 FUSE_BN_FINALIZE = bool(int(os.environ.get("SP_FUSE_BN_FINALIZE", "1")))   # sp_bn_finalize inside the weight re-pack kernel of the folded layers (one launch less per layer)
+FUSE_POOL = bool(int(os.environ.get("SP_FUSE_POOL", "1")))   # MaxPool3d(2) in the epilogue of the down blocks' second convolution (training steps)
 FUSE_DZ = bool(int(os.environ.get("SP_FUSE_DZ", "1")))   # the second convolution's data gradient writes the first one's dz (BatchNorm / activation backward in its epilogue)
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
 MATERIALIZE_BN = not os.environ.get("SP_NO_MATERIALIZE_BN")   # padded convs behind a BatchNorm: write the normalised input once, then DMA kernels (layers.py)
@@ -208,12 +209,13 @@ class ConvRunner:
     def _run_zm(self, a, x_planar, batch, with_stats, st):
         return _run_zm_impl(self, a, x_planar, batch, with_stats, st)
 
-    def __init__(self, op: P.ConvOp, device, share=None, zm_batch=None):
+    def __init__(self, op: P.ConvOp, device, share=None, zm_batch=None, zm_tile=None):
         """share: a dict owned by the caller; runners built for the SAME op geometry that pass the same dict use
         one set of packed weights / tables (the 3 encoder and 4 decoder passes of a CAE step).
         zm_batch: the caller promises to run this op with that batch size, without affine-on-load, with plain (or no)
         statistics and a LeakyReLU / identity epilogue: the z-marching kernel is used where a plan exists and the volume
-        gives it enough planes, and the weights are packed in ITS K order only."""
+        gives it enough planes, and the weights are packed in ITS K order only.
+        zm_tile: plan.zm_plan's tile argument ("classic" for the layers whose epilogue pools)."""
         self.op = op
         self.device = device
         st = share if share is not None else {}
@@ -234,7 +236,7 @@ class ConvRunner:
                              hi_zr=torch.empty(15 * op.nttot * 64 * 8, dtype=torch.bfloat16, device=device))
                 subs.append(d)
             st["subs"] = subs
-            zm = P.zm_plan(op) if (USE_ZM and USE_DMA and zm_batch) else None
+            zm = P.zm_plan(op, tile=zm_tile) if (USE_ZM and USE_DMA and zm_batch) else None
             if zm is not None:
                 cols = -(-op.subs[0].out_dims[1] // zm["TH"]) * -(-op.subs[0].out_dims[2] // zm["TW"])
                 if zm_batch * cols * op.subs[0].out_dims[0] < ZM_MIN_PLANES:
@@ -330,6 +332,14 @@ class ConvRunner:
         statistics of either kind per BatchNorm group)"""
         return self.par is not None and not self.uses_zm() and self.fc is None and dtype_out == L.SP_BF16
 
+    def zm_pool_ok(self):
+        """run(pool=...) applies: a z-marching instance with the MaxPool3d(2) epilogue ((P, NT) = (1, 1) / (2, 2), rows in pairs per
+        wave, the classic 16-voxel-wide tile) -- the second convolutions of the down blocks"""
+        z = self.zm
+        return bool(FUSE_POOL and z is not None and self.zms is None and (z["P"], z["NT"]) in ((1, 1), (2, 2)) and z["MT"] % 2 == 0
+                    and (z["NW"] == 8 or self.op.dtype == L.SP_HL) and z["TW"] == 16 and z["TH"] == z["NW"] * z["MT"]
+                    and min(self.op.y_dims) >= 2 and tuple(self.op.subs[0].out_dims) == tuple(self.op.y_dims))
+
     def zm_bn_bwd_ok(self):
         return self.zm is not None and self.op.dtype == L.SP_BF16 and ConvRunner.zm_plan_bn_bwd_ok(self.zm)
 
@@ -421,10 +431,12 @@ class ConvRunner:
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
             dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None,
-            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0, bnb=None, dz_sums=None):
+            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0, bnb=None, dz_sums=None, pool=None):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
         y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners).
+        pool = (pooled, pooled_lo | None) (``zm_pool_ok()``): MaxPool3d(2) of the output is written to `pooled` by the same kernel and
+        `stats` receives the statistics of the POOLED tensor.
         stats_mode 2 (z-marching data gradients, ``zm_bn_bwd_ok()``): y receives dz = (c0 g + c1 aux + c2) act'(aux) instead of the data
         gradient g -- bnb = dict(sums, nrep, count, gamma, mean, invstd, C, CP, dgamma, dbeta, pscale[, coef]) are sp_bn_bwd_finalize's
         arguments (the kernel finalizes the coefficients itself), dz_sums the (SP_REDUCE_ROWS, CPo) accumulator of sum dz; act /
@@ -474,6 +486,14 @@ class ConvRunner:
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
         a.group_batch = group_batch if (group_batch and group_batch < batch and stats is not None) else 0
+        if pool is not None:
+            pooled, pooled_lo = pool
+            assert self.zm_pool_ok() and stats is not None and stats_mode == 0 and not group_batch and y8 is None and group_fold is None
+            assert tuple(pooled.shape) == (batch,) + tuple(d // 2 for d in op.y_dims) + (y.shape[4],) and pooled.dtype == y.dtype and pooled.is_contiguous()
+            a.pool_y = ptr(pooled)
+            if op.dtype == L.SP_HL:
+                assert pooled_lo is not None and pooled_lo.shape == pooled.shape and pooled_lo.is_contiguous()
+                a.pool_lo_delta = pooled_lo.data_ptr() - pooled.data_ptr()
         if stats_mode == 2:
             assert self.zm_bn_bwd_ok() and bnb is not None and dz_sums is not None and aux is not None and stats is None and not group_batch
             assert dz_sums.dtype == torch.float64 and dz_sums.numel() == L.SP_REDUCE_ROWS * y.shape[4]

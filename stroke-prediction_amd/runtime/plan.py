@@ -419,7 +419,7 @@ def zm_plan(op: ConvOp, tile=None):
     in-plane octets (dy, dx, plane p, octet o) in that order, four per step:
       ktab[s*4 + g]            byte offset of the octet inside a ring slot: (p*ITH*18 + dy*(TW + 2) + dx)*32 + o*16
       kmap[(dz*KS + s)*4 + g]  (source tap << 16) | input octet for sp_conv_prep_weights, -1 for the padding octets
-    tile: (TW, TH) output tile of a workgroup (zm_tile; None: chosen from the op's output plane).
+    tile: (TW, TH) output tile of a workgroup (zm_tile; None: chosen from the op's output plane; "classic": NW MT rows of 16).
     """
     if op.dtype not in (0, 2) or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
         return None
@@ -435,6 +435,8 @@ def zm_plan(op: ConvOp, tile=None):
         return None
     MT, nslot, nw = configs[(P_, NT)]
     ith = nw * MT + 2                        # compile-time plane pitch of a ring slot: ITH x 18 voxels
+    if tile == "classic":                    # (the pooling epilogue pairs rows inside a wave and lanes inside a row)
+        tile = (16, nw * MT)
     tw, th = tile if tile is not None else zm_tile(sub.out_dims[1], sub.out_dims[2], nw, MT)
     assert tw * th <= 16 * nw * MT and (tw + 2) * (th + 2) <= ith * ZM_ITW
     ks = (18 * P_ + 3) // 4

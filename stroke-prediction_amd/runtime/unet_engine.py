@@ -81,7 +81,7 @@ class UnetEngine:
                                                                     {3: 44, 4: 92}.get(S, 0)))
         self.scratch = sc = Scratch(device)
         mk = lambda name, ci, co, d, bn=True, k=3, act=L.ACT_LEAKY, ap=LEAKY, out_dtype=None, blk=None, idx=None, \
-            need_g=True, cpi=None, split=None: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc,
+            need_g=True, cpi=None, split=None, pooled=False: ConvLayer(name, "conv", ci, co, k, 1, 0, d, batch, dtype, device, sc, pooled=pooled,
                                              bn_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx)) if bn else None,
                                              conv_prefix=("%s.bn_conv_relu_2x.%d" % (blk, idx + 1)) if bn else name,
                                              act=act, act_param=ap, out_dtype=out_dtype, need_input_grad=need_g, cpi=cpi,
@@ -106,7 +106,7 @@ class UnetEngine:
                                     act=L.ACT_LEAKY, act_param=LEAKY, need_input_grad=False, cpi=O.cpad(n_in, 16), hl=hl)
             else:
                 c1 = mk("b%dc1" % i, ci, co, d, blk="block%d" % i, idx=0, need_g=(i > 1), cpi=O.cpad(ci, 16) if i == 1 else None)
-            c2 = mk("b%dc2" % i, co, co, sub(d, 2), blk="block%d" % i, idx=3)
+            c2 = mk("b%dc2" % i, co, co, sub(d, 2), blk="block%d" % i, idx=3, pooled=(i < S))
             self.conv[i] = (c1, c2)
             d = sub(d, 4)
             if i < S:
@@ -253,6 +253,11 @@ class UnetEngine:
             y1 = c1.forward(x, params, bufs, training, st(c2))
             self._f8_input(c2, y1)
             self._f8_y2_e4m3_only(i, training)
+            if i < S and training and not self.f8 and c2.can_pool():
+                # MaxPool3d(2) in the convolution's epilogue: the pooled tensor and ITS statistics (the next BatchNorm's) from one kernel
+                y2 = c2.forward(y1, params, bufs, training, st(self.conv[i + 1][0]), pool=(self.pooled[i], None))
+                x = self.pooled[i]
+                continue
             y2 = c2.forward(y1, params, bufs, training)
             if i < S:
                 O.maxpool2_fwd(y2, self.pooled[i], dt, st(self.conv[i + 1][0]), q8=self._f8_fused_input(self.conv[i + 1][0]),
@@ -299,6 +304,11 @@ class UnetEngine:
         for i in range(1, S + 1):
             c1, c2 = self.conv[i]
             y1 = c1.forward(x, params, bufs, training, st(c2)) if i == 1 else c1.forward(x, params, bufs, training, st(c2), x_lo=x_lo)
+            if i < S and training and c2.can_pool():
+                p, p_lo = self.pooled[i], self.pooled_lo[i]
+                y2 = c2.forward(y1, params, bufs, training, st(self.conv[i + 1][0]), x_lo=c1.y_lo, pool=(p, p_lo))
+                x, x_lo = p, p_lo
+                continue
             y2 = c2.forward(y1, params, bufs, training, x_lo=c1.y_lo)
             if i < S:
                 p, p_lo = self.pooled[i], self.pooled_lo[i]

@@ -6,7 +6,9 @@
 * ``sp_conv3d_zm`` with ``stats_mode = 2``: the data gradient of a block's second convolution with the BatchNorm backward and the
   first convolution's LeakyReLU derivative in its epilogue (dz out, coefficients finalized in the kernel's prologue) against the
   three-kernel path it replaces (data gradient -> ``sp_bn_bwd_finalize`` -> ``sp_bn_act_bwd``) and against float64 torch;
-* the whole training step with both on and off: same losses, gradients and BatchNorm buffers.
+* ``sp_conv3d_zm`` with ``pool_y``: MaxPool3d(2) (Unet3D.py:59,62) in the epilogue of the down blocks' second convolution, with the
+  statistics of the pooled tensor, against the convolution followed by ``sp_maxpool2_fwd`` (bit-identical tensors);
+* the whole training step with all of them on and off: same losses, gradients and BatchNorm buffers.
 """
 import ctypes as C
 import math
@@ -171,6 +173,64 @@ def test_data_gradient_with_the_batchnorm_and_activation_backward_in_its_epilogu
     torch.testing.assert_close(b_.double(), ref, rtol=2e-2, atol=2e-2 * float(ref.abs().max()))
 
 
+# cin = cout, input dims, batch, bf16 pairs: (1, 1) and (2, 2) instances; odd output extents (floor pooling), pieces that start in
+# the middle of a column
+POOL_CASES = [(16, (10, 38, 40), 2, False), (32, (9, 23, 37), 2, False), (16, (7, 70, 21), 1, False), (32, (12, 36, 36), 1, False),
+              (16, (9, 38, 24), 2, True), (32, (8, 22, 38), 1, True)]
+
+
+@pytest.mark.parametrize("c,dims,B,hl", POOL_CASES)
+def test_maxpool_in_the_convolution_epilogue(c, dims, B, hl, monkeypatch):
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    g = torch.Generator().manual_seed(c + dims[1] + B)
+    dt = L.SP_HL if hl else L.SP_BF16
+    op = P.conv_fwd_op(c, c, 3, 1, 0, dims, c, c, dt)
+    run = O.ConvRunner(op, DEV, zm_batch=B, zm_tile="classic")
+    assert run.zm_pool_ok()
+    w = (torch.randn(c, c, 3, 3, 3, generator=g) / math.sqrt(27 * c)).to(DEV)
+    b = (torch.randn(c, generator=g) * 0.1).to(DEV)
+    sc, sh = (torch.rand(c, generator=g) + 0.5).to(DEV), (torch.randn(c, generator=g) * 0.1).to(DEV)
+    run.prep(w, b, sc, sh)
+    x = torch.randn(B, c, *dims, generator=g)
+    xs = _to_cl(bf(x), c)
+    xl = _to_cl(bf(x - bf(x)), c) if hl else None
+    od, pd = tuple(op.y_dims), tuple(d // 2 for d in op.y_dims)
+    nrep = 64
+
+    def outs():
+        y = torch.full((2 if hl else 1, B) + od + (c,), 7.0, dtype=torch.bfloat16, device=DEV)
+        p = torch.full((2 if hl else 1, B) + pd + (c,), 7.0, dtype=torch.bfloat16, device=DEV)
+        return y, p, torch.zeros(nrep * c * 2, dtype=torch.float64, device=DEV)
+    kw = dict(dtype_out=dt, stats_nrep=nrep)
+    # ---- convolution, then the pooling kernel
+    ya, pa, sa = outs()
+    if hl:
+        run.run(xs, ya[0], B, None, None, L.ACT_LEAKY, LEAKY, None, x_lo=xl, y_lo=ya[1], **kw)
+        L.call("sp_maxpool2_fwd_hl", O.ptr(ya[0]), ya[1].data_ptr() - ya[0].data_ptr(), O.ptr(pa[0]), pa[1].data_ptr() - pa[0].data_ptr(), B, *od, c,
+               O.ptr(sa), O.stream())
+    else:
+        run.run(xs, ya[0], B, None, None, L.ACT_LEAKY, LEAKY, None, **kw)
+        O.maxpool2_fwd(ya[0], pa[0], L.SP_BF16, sa)
+    # ---- one kernel
+    yb, pb, sb = outs()
+    if hl:
+        run.run(xs, yb[0], B, None, None, L.ACT_LEAKY, LEAKY, sb, x_lo=xl, y_lo=yb[1], pool=(pb[0], pb[1]), **kw)
+    else:
+        run.run(xs, yb[0], B, None, None, L.ACT_LEAKY, LEAKY, sb, pool=(pb[0], None), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)
+    if hl:      # the pair kernels pool hi + lo values; the epilogue pools the fp32 values the pairs were split from: equal to 2^-16
+        va, vb = pa[0].float() + pa[1].float(), pb[0].float() + pb[1].float()
+        assert float((va - vb).abs().max()) <= 2.0 ** -14 * float(va.abs().max())
+    else:
+        assert torch.equal(pa, pb)
+    # SP_REDUCE_ROWS replica rows (the pooling kernel) against the convolution's stats_nrep rows
+    ta = sa.view(-1)[:L.SP_REDUCE_ROWS * c * 2].view(L.SP_REDUCE_ROWS, c, 2).sum(0).cpu()
+    tb = sb.view(nrep, c, 2).sum(0).cpu()
+    n = pa[0].numel() / c
+    torch.testing.assert_close(tb, ta, rtol=1e-5, atol=1e-3 * math.sqrt(n))
+
+
 def _train_steps(dtype, fuse, monkeypatch, steps=3, dims=(52, 52, 52)):
     import stroke_prediction_amd  # noqa: F401
     from oracle import weights as W
@@ -180,6 +240,7 @@ def _train_steps(dtype, fuse, monkeypatch, steps=3, dims=(52, 52, 52)):
     from stroke_prediction_amd.optim import FusedAdam
     monkeypatch.setattr(O, "FUSE_BN_FINALIZE", fuse)
     monkeypatch.setattr(O, "FUSE_DZ", fuse)
+    monkeypatch.setattr(O, "FUSE_POOL", fuse)
     ch = [2, 16, 32, 64, 32, 16, 32, 2]
     x, y = W.unet_inputs(2, dims, 11)
     model = Unet3D(ch, dtype=dtype)
@@ -204,11 +265,12 @@ def _train_steps(dtype, fuse, monkeypatch, steps=3, dims=(52, 52, 52)):
 
 @pytest.mark.parametrize("dtype", ["bf16", "bf16x3"])
 def test_training_steps_with_and_without_the_folded_launches(dtype, monkeypatch):
-    """three Adam steps of the 3-scale U-Net: BatchNorm finalize inside the re-pack kernels (bit-identical by construction) and the
-    dz epilogue of the second convolutions' data gradients (last-bit differences of dz) against the un-fused launches"""
+    """three Adam steps of the 3-scale U-Net: BatchNorm finalize inside the re-pack kernels (bit-identical by construction), pooling
+    in the convolution epilogue (same tensors, statistics summed in another order) and the dz epilogue of the second convolutions'
+    data gradients (last-bit differences of dz) against the un-fused launches"""
     la, ga, sa = _train_steps(dtype, False, monkeypatch)
     lb, gb, sb = _train_steps(dtype, True, monkeypatch)
-    assert abs(la[0] - lb[0]) < 1e-7                       # the first forward is bit-identical
+    assert abs(la[0] - lb[0]) < (2e-6 if dtype == "bf16x3" else 2e-4)      # (the pooled statistics are summed in another order)
     for a, b in zip(la, lb):
         assert abs(a - b) < 2e-3, (la, lb)
     for k in ga:
