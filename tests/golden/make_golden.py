@@ -174,6 +174,54 @@ def gen_unet_train128(seed, fname):
     print("wrote", fname, fx["mean"], fx["std"], fx["logit_std"], fx["logit_absmax"])
 
 
+def grad_sample_index(numel, n=64):
+    """the fixed positions of a gradient tensor the 128^3 training-step fixture keeps (the tests index with the same function)"""
+    return np.unique(np.linspace(0, numel - 1, num=min(n, numel)).round().astype(np.int64))
+
+
+def gen_unet_trainstep128(seed, fname, batch=2):
+    """forward + backward + one Adam step of the reference at the HEADLINE spatial size (VERDICT r4 "next" 3): Unet3D in train mode on
+    batch x 2 x 128^3 (Unet3D.py:56-79), the segmentation loss (UnetSegmentationLearner.py:21-28, metrics.py:16-28), loss.backward(),
+    torch.optim.Adam as train_unet_segmentation.py:32 builds it.  Kept: the loss, norm / head / a fixed 64-element sample of every
+    parameter gradient, every BatchNorm buffer after the step, parameter norms after the step, a crop of the output.  Same weights
+    as gen_unet_train128 (classify gains: outputs with signal)."""
+    from oracle import weights as W
+    from common.model.Unet3D import Unet3D
+    import common.dto.UnetDto as UnetDtoUtil
+    from common.metrics import BatchDiceLoss
+    ch = [2, 16, 32, 64, 32, 16, 32, 2]
+    model = Unet3D(ch)
+    sd = W.make_state_dict(W.unet_spec(ch), seed)
+    for k, gain in HEAD_GAIN.items():
+        sd[k] = sd[k] * gain
+    model.load_state_dict(sd)
+    model.train()
+    x, y = W.unet_inputs(batch, 128, seed)
+    crit = BatchDiceLoss([1.0])
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    dto = model(UnetDtoUtil.init_dto(x, y[:, 0:1], y[:, 1:2]))
+    loss = (crit(dto.outputs.core, dto.given_variables.core) + crit(dto.outputs.penu, dto.given_variables.penu)) / 2
+    opt.zero_grad()
+    loss.backward()
+    seg = torch.cat((dto.outputs.core, dto.outputs.penu), 1).detach()
+    fx = {"seed": np.array(seed), "batch": np.array(batch), "shape": np.array(seg.shape), "torch_version": np.array(torch.__version__),
+          "loss": np.float64(loss.item()), "crop": seg[:, :, 40:48, 40:48, 40:48].numpy().copy(), "digest": digest(seg),
+          "std": seg.double().std(dim=(0, 2, 3, 4)).numpy(),
+          "head_gain_keys": np.array(sorted(HEAD_GAIN)), "head_gain": np.array([HEAD_GAIN[k] for k in sorted(HEAD_GAIN)])}
+    fx.update(grads_summary(model.named_parameters()))
+    for n, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1)
+        fx["gsample/" + n] = g[torch.from_numpy(grad_sample_index(g.numel()))].numpy().copy()
+    opt.step()
+    for n, b in model.named_buffers():
+        if not n.endswith("num_batches_tracked"):
+            fx["buf1/" + n] = b.detach().numpy().copy()
+    for n, p in model.named_parameters():
+        fx["pnorm1/" + n] = np.float64(p.detach().double().norm().item())
+    np.savez_compressed(os.path.join(HERE, fname), **fx)
+    print("wrote", fname, "loss", fx["loss"], "std", fx["std"])
+
+
 class _FakeLoader:
     """Just enough of DataLoader for ``Learner.__init__`` (Learner.py:40-42)."""
     batch_size = 2
@@ -391,7 +439,7 @@ def gen_checkpoints():
 if __name__ == "__main__":
     torch.set_num_threads(8)
     import_reference()
-    which = sys.argv[1:] or ["unet", "unet128", "cae", "cae2", "unet4", "ckpt"]
+    which = sys.argv[1:] or ["unet", "unet128", "unet128step", "cae", "cae2", "unet4", "ckpt"]
     if "unet" in which:
         gen_unet(44, 11, "unet_44.npz")
         gen_unet(48, 12, "unet_48.npz")
@@ -405,6 +453,8 @@ if __name__ == "__main__":
     if "unet128" in which:
         gen_unet_eval128(14, "unet_eval128.npz")
         gen_unet_train128(15, "unet_train128.npz")
+    if "unet128step" in which:
+        gen_unet_trainstep128(15, "unet_trainstep128.npz")
     if "cae2" in which:
         gen_cae_phase2(23, "cae_phase2_200.npz")
     if "cae" in which:

@@ -279,3 +279,89 @@ def test_training_steps_with_and_without_the_folded_launches(dtype, monkeypatch)
     for k in sa:
         if "running" in k or "num_batches" in k:
             torch.testing.assert_close(sa[k].float(), sb[k].float(), rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------ the headline size, backward included
+GOLDEN = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+def grad_sample_index(numel, n=64):
+    """tests/golden/make_golden.py:grad_sample_index"""
+    import numpy as np
+    return np.unique(np.linspace(0, numel - 1, num=min(n, numel)).round().astype(np.int64))
+
+
+# mode -> bounds on: |loss - ref|; the worst per-tensor |norm / ref norm - 1|; per tensor, the rms error of the 64-element sample in
+# units of the tensor's rms gradient -- worst and median over the 44 tensors; the cosine of all samples (each tensor scaled to unit
+# rms).  Measured on MI355X (profiles/r05_trainstep128_parity.txt), bounds at 1.5-2 x the measurement:
+#   f32     loss 1e-7   norm 3.7e-2   worst 3.9e-2   median 7.8e-3   cosine 0.99997
+#   f16x3        <1e-7       1.2e-2         4.5e-2          6.4e-3          0.99990
+#   bf16x3       1e-7        2.4e-1         3.3e-1          2.2e-2          0.99893
+#   f16          1.1e-5      1.8e-1         1.8e-1          6.2e-2          0.99704
+#   bf16         1.6e-5      1.9e-1         4.1e-1          1.8e-1          0.97731
+# The f32 mode's gradient error is LeakyReLU(0.01) branch flips of near-zero pre-activations under another fp32 summation order
+# (the pair mode f16x3, whose forward is as exact, lands at the same place); the worst tensors of every mode are the first
+# BatchNorm's gamma / beta, whose gradients are cancelling sums.
+TRAINSTEP_BOUNDS = {
+    "f32":    dict(loss=2e-5, norm=6e-2, worst=8e-2, median=1.5e-2, cos=0.9999),
+    "f16x3":  dict(loss=2e-5, norm=4e-2, worst=1e-1, median=1.5e-2, cos=0.9995),
+    "bf16x3": dict(loss=2e-5, norm=4e-1, worst=5e-1, median=5e-2, cos=0.997),
+    "f16":    dict(loss=1e-4, norm=3e-1, worst=3e-1, median=1e-1, cos=0.99),
+    "bf16":   dict(loss=1e-4, norm=3e-1, worst=6e-1, median=2.7e-1, cos=0.96),
+}
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16x3", "bf16x3", "f16", "bf16"])
+def test_unet_trainstep128_fixture_through_the_hip_path(dtype):
+    """one training step at 2 x 2 x 128^3 against what the REFERENCE recorded (tests/golden/unet_trainstep128.npz: loss, gradient norms,
+    heads and samples, BatchNorm buffers and parameter norms after Adam): every precision mode with a bound of its own"""
+    import numpy as np
+    import stroke_prediction_amd  # noqa: F401
+    from oracle import weights as W
+    from stroke_prediction_amd.common.model.Unet3D import Unet3D
+    import stroke_prediction_amd.common.dto.UnetDto as UnetDtoUtil
+    from stroke_prediction_amd.common.metrics import BatchDiceLoss
+    from stroke_prediction_amd.optim import FusedAdam
+    fx = np.load(__import__("os").path.join(GOLDEN, "unet_trainstep128.npz"))
+    bd = TRAINSTEP_BOUNDS[dtype]
+    seed, B = int(fx["seed"]), int(fx["batch"])
+    ch = [2, 16, 32, 64, 32, 16, 32, 2]
+    sd = W.make_state_dict(W.unet_spec(ch), seed)
+    for k, gain in zip(fx["head_gain_keys"], fx["head_gain"]):
+        sd[str(k)] = sd[str(k)] * float(gain)
+    model = Unet3D(ch, dtype=dtype)
+    model.load_state_dict(sd)
+    model = model.to(DEV).train()
+    opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, betas=(0.99, 0.999))
+    crit = BatchDiceLoss([1.0])
+    x, y = W.unet_inputs(B, 128, seed)
+    xd, yd = x.to(DEV), y.to(DEV)
+    dto = model(UnetDtoUtil.init_dto(xd, yd[:, 0:1], yd[:, 1:2]))
+    loss = (crit(dto.outputs.core, dto.given_variables.core) + crit(dto.outputs.penu, dto.given_variables.penu)) / 2
+    opt.zero_grad()
+    loss.backward()
+    lv = float(loss.detach())
+    assert abs(lv - float(fx["loss"])) < bd["loss"], (lv, float(fx["loss"]))
+    errs, dots, na, nb, worst_norm = [], 0.0, 0.0, 0.0, 0.0
+    for k, p in model.named_parameters():
+        g = p.grad.detach().reshape(-1).double().cpu()
+        gn = float(fx["gnorm/" + k])
+        worst_norm = max(worst_norm, abs(float(g.norm()) / gn - 1.0))
+        ref = torch.from_numpy(fx["gsample/" + k]).double()
+        got = g[torch.from_numpy(grad_sample_index(g.numel()))]
+        rms = gn / math.sqrt(g.numel())
+        errs.append(float((got - ref).norm()) / math.sqrt(len(ref)) / rms)
+        dots += float(got @ ref) / rms ** 2; na += float(got @ got) / rms ** 2; nb += float(ref @ ref) / rms ** 2
+    errs.sort()
+    cos = dots / math.sqrt(na * nb)
+    print("trainstep128 %s: loss %.7f (ref %.7f), norm ratio worst %.2e, sample error / rms worst %.2e median %.2e, cosine %.5f"
+          % (dtype, lv, float(fx["loss"]), worst_norm, errs[-1], errs[len(errs) // 2], cos))
+    assert worst_norm < bd["norm"] and errs[-1] < bd["worst"] and errs[len(errs) // 2] < bd["median"] and cos > bd["cos"]
+    opt.step()
+    tol = 1e-5 if dtype in ("f32", "f16x3", "bf16x3") else 2e-2
+    for k, b in model.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            np.testing.assert_allclose(b.detach().cpu().numpy(), fx["buf1/" + k], rtol=max(tol, 2e-5), atol=tol, err_msg=k)
+    for k, p in model.named_parameters():
+        ref = float(fx["pnorm1/" + k])      # (Adam moves every element by ~lr: elements whose gradient sign differs move the other way)
+        assert abs(float(p.detach().double().norm()) - ref) <= 2e-3 * ref + 1e-3 * math.sqrt(p.numel()), k
