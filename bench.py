@@ -343,6 +343,60 @@ def conv_roofline_unet(size, channels, batch, peak_tflops, kernels):
                           % (peak_tflops, HBM_PEAK_GBS)}
 
 
+def step_roofline_unet(size, channels, batch, peak_tflops, ms_per_step):
+    """The WHOLE training step against its module-level roofline (VERDICT r4 "next" 5): sum over every module of the step of
+    max(FLOP / MFMA peak, algorithmic bytes / HBM peak), every module reading each input once and writing each output once --
+    the ten 3x3x3 layers x (forward, data gradient, weight gradient) as in conv_roofline, plus the passes the reference runs as
+    modules of their own (Unet3D.py:56-79, metrics.py:16-28): input statistics, 2 max-pools, 2 upsample + crop + concat, the
+    pointwise head, the Dice sums, and in the backward the head, one (read g, read y, write dz) pass per convolution output
+    (BatchNorm + LeakyReLU backward, carrying the pool / upsample / skip transposes) and Adam.  A fused implementation may beat
+    single terms (the pooling pass is gone since round 5); the sum is the yardstick, not a bound on what fusion can reach.
+    bytes_measured: rocprofv3 FETCH_SIZE x2 + WRITE_SIZE over every kernel of a step (profiles/traffic.json "step")."""
+    c, d, B = channels, size, batch
+    E = 2.0                                                   # bf16 bytes per activation element
+    items = []                                                # (name, flop, bytes)
+    conv_layers, skips = [], []
+    for blk in range(3):
+        cin, cout = c[blk], c[blk + 1]
+        conv_layers += [(cin, cout, d), (cout, cout, d - 2)]
+        d -= 4
+        if blk < 2:
+            skips.append((cout, d))
+            items.append(("maxpool", 0.0, B * cout * (d ** 3 + (d // 2) ** 3) * E))
+            d //= 2
+    for up, (cs, ds) in zip((4, 5), reversed(skips)):
+        lowc = c[up - 1]
+        items.append(("upsample+crop+cat", 0.0, B * (lowc * d ** 3 + cs * (2 * d) ** 3 + (lowc + cs) * (2 * d) ** 3) * E))
+        d *= 2
+        conv_layers += [(lowc + cs, c[up], d), (c[up], c[up], d - 2)]
+        d -= 4
+    nout = B * d ** 3
+    items.append(("input statistics", 0.0, B * c[0] * size ** 3 * 4.0))
+    for i, (cin, cout, din) in enumerate(conv_layers):
+        vin, vout = B * din ** 3, B * (din - 2) ** 3
+        fl = 2.0 * 27 * cin * cout * vout
+        by = vin * cin * (4.0 if i == 0 else E) + vout * cout * E
+        for p in (("fwd", "wgrad") if i == 0 else ("fwd", "dgrad", "wgrad")):
+            items.append(("conv %d->%d @%d %s" % (cin, cout, din, p), fl, by))
+        if i + 1 < len(conv_layers) or True:
+            items.append(("dz of conv %d->%d @%d" % (cin, cout, din), 0.0, 3 * vout * cout * E))      # read g, read y, write dz
+    items.pop()                                               # (the last convolution's dz is the head's backward below)
+    items.append(("head fwd", 2.0 * nout * (c[5] * c[6] + c[6] * c[7]), nout * (c[5] * E + c[7] * 4.0)))
+    items.append(("dice sums + backward", 0.0, nout * c[7] * 4.0 * 4))
+    items.append(("head bwd", 6.0 * nout * (c[5] * c[6] + c[6] * c[7]), nout * (2 * c[5] * E + 2 * c[7] * 4.0)))
+    nparam = sum(27 * a * b + b + 2 * a for a, b, _ in conv_layers) + c[5] * c[6] + c[6] + c[6] * c[7] + c[7]
+    items.append(("adam", 0.0, 28.0 * nparam))
+    ideal = sum(max(fl / (peak_tflops * 1e12), by / (HBM_PEAK_GBS * 1e9)) for _, fl, by in items)
+    out = {"ideal_ms": 1e3 * ideal, "measured_ms": ms_per_step, "frac": 1e3 * ideal / ms_per_step,
+           "flops_algorithmic": sum(fl for _, fl, _ in items), "bytes_algorithmic": sum(by for _, _, by in items), "bytes_measured": None}
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            out["bytes_measured"] = json.load(f)["step"]["bytes_per_step"]
+    except Exception:
+        pass
+    return out
+
+
 def conv_roofline_cae(d, hw, batch, peak_tflops, kernels, channels=None):
     """The per-layer bound of SURVEY 8(d) for the CAE (VERDICT r3 missing 4): sum over the 10 encoder layers x 3 passes and the
     12 decoder layers x 4 passes (Cae3D.py:39-76,105-107,176-220,230-233) and over forward, data gradient (none for the encoder's
@@ -375,6 +429,28 @@ def conv_roofline_cae(d, hw, batch, peak_tflops, kernels, channels=None):
             "algorithmic_gflop": flop_total / 1e9, "ideal_bf16_operand_mb": bytes_total / 1e6,
             "definition": "sum over 10 encoder layers x 3 passes + 12 decoder layers x 4 passes x (fwd, dgrad, wgrad) of "
                           "max(FLOP / %.0f TFLOP/s, bf16 operand bytes / %.0f GB/s)" % (peak_tflops, HBM_PEAK_GBS)}
+
+
+def rccl_proof(sync, world, dev):
+    """{ranks, backend, direct, two_shot} for the bench line of an N-rank run: `ranks` is the result of all-reducing a one over the
+    process group (and over the DirectComm communicator when the gradient exchange runs on it) -- N only if N ranks took part."""
+    import torch.distributed as dist
+    out = {"ranks": None, "backend": None, "direct": None, "two_shot": None}
+    if not dist.is_initialized():
+        return out
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    out["ranks"], out["backend"] = int(one.item()), dist.get_backend()
+    d = getattr(sync, "direct", None)
+    out["direct"] = d is not None
+    if d is not None:
+        t = torch.ones(1, device=dev)
+        d.all_reduce_async(t)
+        d.wait()
+        torch.cuda.synchronize()
+        out["ranks_direct"] = int(t.item())
+        out["two_shot"] = bool(getattr(d, "two_shot", False))
+    return out
 
 
 def init_dist(world, dev):
@@ -478,20 +554,22 @@ def bench_unet(args, world, rank, dev, four_scale=False):
         torch.cuda.synchronize()
         copy_us = e0.elapsed_time(e1) * 1e3 / 20
     vox = world * args.batch * size[0] * size[1] * size[2] * args.steps
+    rccl = rccl_proof(sync, world, dev)
     launch_mode = ("hipGraph (Learner(graph=True))" if world == 1 or os.environ.get("SP_DIST_GRAPH") else
                    "hipGraph of forward + loss + backward, then all-reduce and Adam (Learner(graph=True))") if use_graph else "eager"
-    name = ("4-scale 3D U-Net --channels %s" % " ".join(map(str, CHANNELS4))) if four_scale else \
-        "3D U-Net --channels 2 16 32 64 32 16 32 2"
+    name = ("4-scale U-Net %s" % " ".join(map(str, CHANNELS4))) if four_scale else "U-Net 2 16 32 64 32 16 32 2"
     res = {
         "metric": "train-step voxels/sec, 3D U-Net Bx2x%d^3" % args.size, "value": vox / dt, "unit": "voxels/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "%s, batch %d/GPU, 2x%d^3 -> 2x%d^3, Learner.train_batch = fwd+Dice+bwd+Adam (%s)"
-                               % (name, args.batch, args.size, out[0], "configs[4] topology" if four_scale else "configs[1]"),
+        "config": {"workload": "%s: %s, B=%d/GPU, 2x%d^3 -> 2x%d^3, train_batch = fwd+Dice+bwd+Adam"
+                               % ("configs[4] net" if four_scale else "configs[1]", name, args.batch, args.size, out[0]),
                    "global_batch": world * args.batch, "parallelism": "dp%d" % world, "loss": float(last.loss),
                    "launch": launch_mode, "input": "resident in the step's input buffers (Learner.static_batch)" if (use_graph and not os.environ.get("SP_BENCH_COPY_INPUTS")) else "resident device tensors",
                    "input_copy_us": copy_us,      # device-to-device copy of one batch into those buffers, NOT in ms_per_step
                    "dp_mode": args.dp_mode if world > 1 else None,
+                   # proof that the collectives saw N ranks: the sum of an all-reduce of ones over the group the gradients travel on
+                   "rccl_ranks": rccl["ranks"], "rccl_backend": rccl["backend"], "rccl_direct": rccl["direct"], "rccl_two_shot": rccl["two_shot"],
                    "grad_exchange": (("one all-reduce of the flat gradient buffer between the backward graph and Adam"
                                       if (use_graph and not os.environ.get("SP_DIST_GRAPH")) else
                                       "%d buckets, reverse layer order, async on the RCCL stream" % sync.nbuckets_last)
@@ -504,8 +582,15 @@ def bench_unet(args, world, rank, dev, four_scale=False):
         roof, kernels = roofline_from(agg, per_layer, nprof, ms, args.dtype, sys.stderr if args.layers else None, traffic_key=tkey)
         if roof:
             res["roofline"], res["kernels"] = roof, kernels
-            if not four_scale and args.dtype == "bf16":
-                roof["conv_roofline"] = conv_roofline_unet(args.size, channels, args.batch, PEAK_TFLOPS[args.dtype], kernels)
+            if not four_scale and args.dtype in ("bf16", "f16", "bf16x3", "f16x3"):
+                cr = roof["conv_roofline"] = conv_roofline_unet(args.size, channels, args.batch, PEAK_TFLOPS[args.dtype], kernels)
+                # flat copies: the driver's record keeps the scalar entries of `roofline` only
+                roof.update({"conv_ideal_ms": cr["ideal_ms"], "conv_measured_ms": cr["measured_ms"], "conv_frac": cr["frac"]})
+                if args.dtype in ("bf16", "f16"):
+                    sr = roof["step"] = step_roofline_unet(args.size, channels, args.batch, PEAK_TFLOPS[args.dtype], ms)
+                    roof.update({"step_ideal_ms": sr["ideal_ms"], "step_measured_ms": sr["measured_ms"], "step_frac": sr["frac"],
+                                 "step_bytes_algorithmic": sr["bytes_algorithmic"], "step_bytes_measured": sr["bytes_measured"],
+                                 "step_flops_algorithmic": sr["flops_algorithmic"]})
         if args.size == 128 and not four_scale:
             res["train_step_tflops"] = TRAIN_GFLOP_PER_SAMPLE_128 * 1e9 * world * args.batch * args.steps / dt / 1e12
     if rank == 0 and world == 1 and not args.no_parity and not four_scale and args.dtype in ("bf16", "f16"):
@@ -725,7 +810,29 @@ def main():
     res = run_workload(args, world, rank, dev)
     if args.workload == "unet" and world == 1 and rank == 0 and not args.no_secondary and args.dtype == "bf16" and args.size == 128:
         res["secondary"] = secondary_workloads(args, dev)
+        tolerance_mode_into_config(res)
     return finish(res, rank)
+
+
+def tolerance_mode_into_config(res, mode="bf16x3"):
+    """The co-headline (VERDICT r4 "next" 4): BASELINE configs[1] names bf16, north_star a 1e-3 logit tolerance that bf16 storage
+    cannot meet; `bf16x3` (forward on bf16 pairs) is the fast mode that does.  Its step time, conv roofline and distance from the
+    f32 mode go into `config` as flat scalars (the driver's record keeps those), next to the full objects in `secondary`."""
+    sec = res.get("secondary", {}).get("unet_" + mode)
+    if not sec or "ms_per_step" not in sec:
+        return
+    c = res["config"]
+    c["tolerance_mode"] = mode
+    c["tolerance_mode_ms_per_step"] = sec["ms_per_step"]
+    c["tolerance_mode_voxels_per_s"] = sec["value"]
+    rf = sec.get("roofline") or {}
+    c["tolerance_mode_mfma_frac"] = rf.get("frac")
+    c["tolerance_mode_conv_frac"] = (rf.get("conv_roofline") or {}).get("frac")
+    par = res.get("parity") or {}
+    worst = [v[mode]["max_abs_logit_over_max_logit"] for v in par.values() if isinstance(v, dict) and mode in v]
+    c["tolerance_mode_max_rel_logit"] = max(worst) if worst else None      # vs the f32 mode, worst of trained / random-init x eval / train
+    worst = [v[res["dtype"]]["max_abs_logit_over_max_logit"] for v in par.values() if isinstance(v, dict) and res["dtype"] in v]
+    c["headline_mode_max_rel_logit"] = max(worst) if worst else None
 
 
 def run_workload(args, world, rank, dev):

@@ -78,6 +78,7 @@ class _UnetFn(torch.autograd.Function):
 class Unet3D(FlatParamsMixin, nn.Module):
     FLAT_NBT = True      # every BatchNorm runs exactly once per forward: their step counters advance together
     N_SCALES = 3
+    ENGINE_CACHE = 4     # engines kept per model (one per input shape and precision mode), least recently used evicted first
 
     def __init__(self, channels=[2, 32, 64, 128, 64, 32, 32, 2], channel_dim=1, channels_crop=[2, 3, 4],
                  dtype="bf16"):
@@ -122,9 +123,13 @@ class Unet3D(FlatParamsMixin, nn.Module):
         dt = _L.DTYPE_CODES[self.compute_dtype]
         key = (tuple(images.shape), self.compute_dtype, images.device.index)
         eng = self._engines.get(key)
+        if eng is not None:
+            self._engines[key] = self._engines.pop(key)      # most recently used last
         if eng is None:
-            if len(self._engines) >= 4:
-                self._engines.clear()
+            # at most ENGINE_CACHE engines (each holds the activations of one input shape): the least recently used one goes, the
+            # others -- and the hipGraphs captured over their buffers (Learner(graph=True)) -- stay valid
+            while len(self._engines) >= self.ENGINE_CACHE:
+                self._engines.pop(next(iter(self._engines)))
             variant = _L.VARIANT_OF[self.compute_dtype]
             with _L.use(variant):
                 eng = UnetEngine(self.channels, images.shape[0], tuple(images.shape[2:]), dt, images.device,

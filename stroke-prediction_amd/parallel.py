@@ -13,6 +13,7 @@ all-reduce SUMS and the optimiser must NOT divide (``grad_scale`` = 1); BatchNor
 every rank already holds in full, are pre-scaled by 1/world.
 """
 import os
+import sys
 
 import torch
 import torch.distributed as dist
@@ -24,8 +25,9 @@ class DirectComm:
     (any backend), the collectives run on a stream of ours -- forked from the launching stream and joined before the
     optimiser -- so they can sit inside a captured step as a parallel graph branch.  ``two_shot``: reduce-scatter +
     all-gather over a padded copy-free view (every xGMI link carries 1/world of the buffer at once) instead of one
-    all-reduce.  UNMEASURED on more than one GPU (this build's boxes have one): opt-in, ``DataParallelSync(direct=True)`` or
-    SP_DIST_DIRECT=1."""
+    all-reduce; an element count that is no multiple of the rank count sends its short tail through a plain all-reduce
+    (``two_shot_plan``).  UNMEASURED on more than one GPU (this build's boxes have one): OPT-IN, ``DataParallelSync(direct=True)`` or
+    SP_DIST_DIRECT=1, two-shot on top with SP_DIST_TWO_SHOT=1."""
 
     def __init__(self, group=None, device=None):
         import ctypes as C
@@ -45,19 +47,30 @@ class DirectComm:
             L.call("sp_comm_init_rank", C.byref(self._comm), self.world, uid, self.rank)
         self.stream = torch.cuda.Stream(device=self.device)
         self._L = L
+        self.two_shot = os.environ.get("SP_DIST_TWO_SHOT", "").strip().lower() in ("1", "true", "yes", "on")
 
-    def all_reduce_async(self, t, two_shot=False):
+    @staticmethod
+    def two_shot_plan(n, world):
+        """(chunk, tail): elements [0, world * chunk) go through reduce-scatter + all-gather (rank r owns [r * chunk, (r + 1) * chunk)),
+        the last `tail` = n - world * chunk < world elements through a plain all-reduce; chunk == 0: all of it does"""
+        chunk = n // world
+        return chunk, n - chunk * world
+
+    def all_reduce_async(self, t, two_shot=None):
         """sum of the fp32 tensor t over the ranks, in place, on the communicator's stream (ordered after everything enqueued
         on the current stream so far); ``wait`` makes the current stream wait for it"""
         assert t.dtype in (torch.float32, torch.float64) and t.is_contiguous() and t.is_cuda
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
         n = t.numel()
+        two_shot = self.two_shot if two_shot is None else two_shot
+        chunk, tail = self.two_shot_plan(n, self.world)
         if t.dtype == torch.float64:       # the accumulators of the exact mode (BatchNorm / Dice sums)
             self._L.call("sp_allreduce_flat_f64", self._comm, t.data_ptr(), n, self.stream.cuda_stream)
-        elif two_shot and self.world > 1 and n % self.world == 0:
-            chunk = n // self.world
+        elif two_shot and chunk > 0:       # (a single rank runs it too: the rehearsal of the call sequence on a one-GPU box)
             self._L.call("sp_reduce_scatter_flat", self._comm, t.data_ptr(), chunk, self.rank, self.stream.cuda_stream)
             self._L.call("sp_allgather_flat", self._comm, t.data_ptr(), chunk, self.rank, self.stream.cuda_stream)
+            if tail:
+                self._L.call("sp_allreduce_flat", self._comm, t.data_ptr() + 4 * chunk * self.world, tail, self.stream.cuda_stream)
         else:
             self._L.call("sp_allreduce_flat", self._comm, t.data_ptr(), n, self.stream.cuda_stream)
 
@@ -85,17 +98,15 @@ class DataParallelSync:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.nbuckets_last = 0
         if direct is None:
-            # default: a communicator of our own (capturable: the exchange then sits INSIDE a Learner(graph=True) step as forked
-            # branches at the bucket boundaries, bucket k travelling under the backward of bucket k+1) when there is something to
-            # overlap -- flat gradients of SP_DIST_DIRECT_MIN_BYTES (8 MB) and more: the CAE's 18.9 MB, the 4-scale net's 23.4 MB.
-            # The 1.4 MB of the default U-Net stay one torch.distributed all-reduce after the replayed graph (latency-bound
-            # either way).  SP_DIST_DIRECT=1 / 0 forces either.  UNMEASURED on more than one GPU.
+            # OPT-IN (the path has never run with more than one rank): SP_DIST_DIRECT=1 or direct=True gives the exchange a
+            # communicator of our own -- capturable: it then sits INSIDE a Learner(graph=True) step as forked branches at the bucket
+            # boundaries, bucket k travelling under the backward of bucket k+1, which pays for flat gradients of several MB (the CAE's
+            # 18.9 MB, the 4-scale net's 23.4 MB).  Default: torch.distributed's all-reduce after the replayed backward graph.
             env = os.environ.get("SP_DIST_DIRECT", "").strip().lower()
-            if env:
-                direct = env in ("1", "true", "yes", "on")
-            else:
-                nbytes = 4 * sum(p.numel() for p in model.parameters())
-                direct = nbytes >= int(os.environ.get("SP_DIST_DIRECT_MIN_BYTES", str(8 << 20)))
+            direct = env in ("1", "true", "yes", "on")
+            if direct:
+                print("stroke_prediction_amd.parallel: gradient exchange on a communicator of our own (SP_DIST_DIRECT) -- "
+                      "unmeasured on more than one GPU", file=sys.stderr)
         # direct: the gradient exchange goes through sp_allreduce_flat on a communicator of our own (DirectComm)
         self.direct = DirectComm(process_group) if (direct and dist.is_initialized() and torch.cuda.is_available()
                                                     and dist.get_backend(process_group) != "gloo") else None

@@ -104,6 +104,16 @@ def _run_cae(rank, world, port, q):
     ch = [1, 16, 24, 32, 100, 200, 1]
     d, hw, seed = 28, 64, 23
     labels, clinical = W.cae_inputs(4, d, hw, seed)
+    # every collective a rank issues, in order (VERDICT r4 "next" 6c: the exact mode's sequence must be the same on all ranks)
+    log = []
+    for name in ("all_reduce", "broadcast", "all_gather", "reduce_scatter_tensor"):
+        fn = getattr(dist, name)
+
+        def wrapped(*a, _fn=fn, _name=name, **k):
+            t = a[0] if a and torch.is_tensor(a[0]) else None
+            log.append((_name, None if t is None else (tuple(t.shape), str(t.dtype))))
+            return _fn(*a, **k)
+        setattr(dist, name, wrapped)
 
     class Loader(list):
         batch_size = 2
@@ -127,6 +137,7 @@ def _run_cae(rank, world, port, q):
 
     ref = run(fresh(), labels, clinical) if rank == 0 else None
     dist.barrier()
+    del log[:]
     cae = fresh()
     sync = DataParallelSync(cae, mode="exact")
     lo, hi = rank * 2, rank * 2 + 2
@@ -134,6 +145,7 @@ def _run_cae(rank, world, port, q):
     cae._after_backward()
     grad = cae.flat_buffers()[1].clone().cpu()
     sync.close()
+    q.put(("log", rank, list(log)))
     if rank == 0:
         rrec, rloss, rgrad, rbufs = ref
         q.put(dict(rec=float((rec - rrec[lo:hi]).abs().max()), loss=abs(loss - rloss), grad=float((grad - rgrad).norm() / rgrad.norm()),
@@ -152,11 +164,17 @@ def test_exact_mode_cae_two_ranks_equal_single_process():
     procs = [ctx.Process(target=_run_cae, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = q.get(timeout=600)
+    got = [q.get(timeout=600) for _ in range(world + 1)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    print("exact-mode CAE, 2 ranks vs 1 process:", res)
+    res = [g for g in got if isinstance(g, dict)][0]
+    logs = {g[1]: g[2] for g in got if isinstance(g, tuple) and g[0] == "log"}
+    # the same collectives, in the same order, with the same shapes and dtypes on both ranks: the encoder's 3 and the decoder's 4
+    # passes exchange their BatchNorm sums (forward and backward) and the Dice sums, then the gradient
+    assert logs[0] == logs[1], (logs[0], logs[1])
+    assert sum(1 for c in logs[0] if c[0] == "all_reduce" and c[1] is not None and c[1][1] == "torch.float64") >= 40, len(logs[0])
+    print("exact-mode CAE, 2 ranks vs 1 process:", res, "collectives per rank:", len(logs[0]))
     # measured: rec 1.3e-5, loss 0, grad 1.4e-4 (the f32 mode's split-bf16 sums in another order), rm 1.5e-8, rv 1.2e-7 --
     # a percent-level error in a world factor or a group scale is two orders of magnitude above these bounds
     assert res["rec"] < 1e-4 and res["loss"] < 2e-6, res

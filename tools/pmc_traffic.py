@@ -38,6 +38,12 @@ for name, pats in fam.items():
     if n == 0:
         continue
     out[prefix + name] = {"launches": n, "fetch_bytes_per_launch": fb / n, "write_bytes_per_launch": wb / n, "bytes_per_launch": (fb + wb) / n}
+# the whole step: every kernel of the pass divided by the steps it ran (one fused Adam launch per step)
+nstep = sum(v[1] for k, v in f.items() if "adam_hyp_kernel" in k or "adam_kernel" in k)
+if nstep:
+    out[prefix + "step"] = {"steps": nstep, "fetch_bytes_per_step": sum(v[0] for v in f.values()) * 2 * 1024 / nstep,
+                            "write_bytes_per_step": sum(v[0] for v in w.values()) * 1024 / nstep}
+    out[prefix + "step"]["bytes_per_step"] = out[prefix + "step"]["fetch_bytes_per_step"] + out[prefix + "step"]["write_bytes_per_step"]
 out["_source" + ("_" + prefix.rstrip("_") if prefix else "")] = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python %s`; FETCH_SIZE doubled per the gfx950 correction; see profiles/%s_pmc_traffic.md" % (workload, tag)
 json.dump(out, open(tj, "w"), indent=1)
 # the GPU box returns gpurun_out/ only: leave copies there (copy them into profiles/ after the call)
