@@ -311,11 +311,21 @@ int sp_quantize_f8(const void* src, int32_t CP, int64_t src_plane, void* dst, in
 typedef struct sp_conv3d_desc {
   int32_t B, Cin, Cout, D, H, W;
   int32_t grad;
+  /* round 5 (zero = the un-padded nn.Conv3d above): the CAE's layers (Cae3D.py:41-70, 178-218) on the same kernel --
+   * padD / padH / padW in 0..2: nn.Conv3d(Cin, Cout, 3, stride 1, padding (padD, padH, padW)); zero padding comes from the
+   *   kernel's zero page, so a BatchNorm in FRONT of a padded layer cannot be folded by sp_conv3d_set_weights (the padding is
+   *   applied after the normalisation: give the kernel the normalised tensor, or sp_conv_prep_folded_groups' bias table);
+   * transposed = 1: nn.ConvTranspose3d(Cin, Cout, 3, stride 1, padding pad) -- w is [Cin][Cout][3][3][3], the output extent
+   *   D + 2 - 2 padD (the "full" correlation with the mirrored kernel, cropped by the padding); grad must be 0;
+   * act of sp_conv3d_run may be SP_ACT_ELU (act_param = alpha) for (Cin/16, Cout/16) pairs of up to 2 input planes. */
+  int32_t padD, padH, padW;
+  int32_t transposed;
 } sp_conv3d_desc;
 typedef struct sp_conv3d_plan_t {
   int32_t cin_op, cout_op;             /* channels the op reads / writes (swapped for the data gradient) */
   int32_t P, NT, MT, NW, NSLOT, KS, nsteps, ITH;
-  int32_t Di, Hi, Wi, Do, Ho, Wo, o0;  /* extents of x and y, input coordinate of (output 0, tap 0) */
+  int32_t Di, Hi, Wi, Do, Ho, Wo, o0;  /* extents of x and y, input coordinate of (output 0, tap 0) (o0: the D axis') */
+  int32_t o0H, o0W, mirror;            /* ... of the H and W axes; mirror: the kernel's taps are the weight's, point-mirrored */
   int64_t x_elems, y_elems;            /* bf16 elements of x and y */
   int64_t workspace_bytes;
   int64_t off_zero, off_ktab, off_kmap, off_bias, off_wfrag;   /* layout of the workspace */

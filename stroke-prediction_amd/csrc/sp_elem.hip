@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_cls_kernel(const T* __restrict
         cx = cls1(x, px, W);
         yy += dy;
         while (yy >= H) { yy -= H; ++z; }
-        if (z >= D) z -= D;          // (the next sample of the group: the classes depend on (z, y, x) only)
+        while (z >= D) z -= D;       // (the next sample(s) of the group: the classes depend on (z, y, x) only; tiny volumes may wrap more than once)
         czy = cls1(z, pz, D) * ny + cls1(yy, py, H);
       }
     }

@@ -19,20 +19,37 @@ static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 extern "C" int sp_conv3d_plan(const sp_conv3d_desc* d, sp_conv3d_plan_t* p) {
   SP_CHECK_ARG(d && p, "sp_conv3d_plan: null pointer");
-  SP_CHECK_ARG(d->B >= 1 && d->D >= 3 && d->H >= 3 && d->W >= 3, "sp_conv3d_plan: volume smaller than the kernel");
+  SP_CHECK_ARG(d->B >= 1 && d->D >= 1 && d->H >= 1 && d->W >= 1, "sp_conv3d_plan: empty volume");
   SP_CHECK_ARG(d->Cin >= 16 && d->Cout >= 16 && d->Cin % 16 == 0 && d->Cout % 16 == 0, "sp_conv3d_plan: channels must be multiples of 16 (pad with zero channels)");
+  SP_CHECK_ARG(d->padD >= 0 && d->padD <= 2 && d->padH >= 0 && d->padH <= 2 && d->padW >= 0 && d->padW <= 2, "sp_conv3d_plan: padding 0..2 per axis");
+  SP_CHECK_ARG(!d->transposed || !d->grad, "sp_conv3d_plan: transposed = 1 describes the forward of nn.ConvTranspose3d (grad = 0)");
+  const int pd[3] = {d->padD, d->padH, d->padW}, in[3] = {d->D, d->H, d->W};
+  for (int ax = 0; ax < 3; ++ax)
+    SP_CHECK_ARG(d->transposed ? in[ax] + 2 - 2 * pd[ax] >= 1 : in[ax] + 2 * pd[ax] >= 3, "sp_conv3d_plan: volume smaller than the kernel");
   memset(p, 0, sizeof(*p));
   // the op's own roles: the data gradient reads Cout-channel dz on the conv's output grid and writes Cin channels
   p->cin_op = d->grad ? d->Cout : d->Cin;
   p->cout_op = d->grad ? d->Cin : d->Cout;
+  p->mirror = (d->grad || d->transposed) ? 1 : 0;
   p->P = p->cin_op / 16; p->NT = p->cout_op / 16;
   SP_CHECK_ARG(sp_conv3d_zm_config(p->P, p->NT, &p->MT, &p->NSLOT, &p->NW) == SP_OK,
                "sp_conv3d_plan: no z-marching kernel for %d input planes x %d output tiles (use sp_conv3d_igemm with a host plan)", p->P, p->NT);
   p->KS = (18 * p->P + 3) / 4;
   p->nsteps = 3 * p->KS;
   p->ITH = p->NW * p->MT + 2;
-  if (!d->grad) { p->Di = d->D; p->Hi = d->H; p->Wi = d->W; p->Do = d->D - 2; p->Ho = d->H - 2; p->Wo = d->W - 2; p->o0 = 0; }
-  else { p->Di = d->D - 2; p->Hi = d->H - 2; p->Wi = d->W - 2; p->Do = d->D; p->Ho = d->H; p->Wo = d->W; p->o0 = -2; }
+  if (d->transposed) {      // y = full correlation of x with the mirrored kernel, cropped by the padding: out = in + 2 - 2 pad
+    p->Di = d->D; p->Hi = d->H; p->Wi = d->W;
+    p->Do = d->D + 2 - 2 * d->padD; p->Ho = d->H + 2 - 2 * d->padH; p->Wo = d->W + 2 - 2 * d->padW;
+    p->o0 = -(2 - d->padD); p->o0H = -(2 - d->padH); p->o0W = -(2 - d->padW);
+  } else if (!d->grad) {
+    p->Di = d->D; p->Hi = d->H; p->Wi = d->W;
+    p->Do = d->D + 2 * d->padD - 2; p->Ho = d->H + 2 * d->padH - 2; p->Wo = d->W + 2 * d->padW - 2;
+    p->o0 = -d->padD; p->o0H = -d->padH; p->o0W = -d->padW;
+  } else {                  // data gradient of the (padded) convolution: dz on the conv's output grid in, the conv's input grid out
+    p->Di = d->D + 2 * d->padD - 2; p->Hi = d->H + 2 * d->padH - 2; p->Wi = d->W + 2 * d->padW - 2;
+    p->Do = d->D; p->Ho = d->H; p->Wo = d->W;
+    p->o0 = -(2 - d->padD); p->o0H = -(2 - d->padH); p->o0W = -(2 - d->padW);
+  }
   p->x_elems = (int64_t)d->B * p->Di * p->Hi * p->Wi * p->cin_op;
   p->y_elems = (int64_t)d->B * p->Do * p->Ho * p->Wo * p->cout_op;
   int64_t off = 0;
@@ -57,7 +74,7 @@ extern "C" int sp_conv3d_tables(const sp_conv3d_desc* d, const sp_conv3d_plan_t*
     ktab[e] = ((pl * p->ITH + dy) * SP_PLAN_ITW + dx) * 32 + o * 16;
     for (int dz = 0; dz < 3; ++dz) {
       const int tap = (dz * 3 + dy) * 3 + dx;
-      kmap[dz * KS * 4 + e] = ((d->grad ? 26 - tap : tap) << 16) | (pl * 2 + o);
+      kmap[dz * KS * 4 + e] = ((p->mirror ? 26 - tap : tap) << 16) | (pl * 2 + o);
     }
   }
   for (int e = n; e < 4 * KS; ++e) ktab[e] = ktab[e - 2];      // zero-weight padding octets: any valid, conflict-free address
@@ -83,12 +100,16 @@ extern "C" int sp_conv3d_set_weights(const sp_conv3d_desc* d, const sp_conv3d_pl
   SP_CHECK_ARG(d && p && workspace && w, "sp_conv3d_set_weights: null pointer");
   SP_CHECK_ARG((bn_scale == nullptr) == (bn_shift == nullptr), "sp_conv3d_set_weights: BatchNorm scale and shift come together");
   SP_CHECK_ARG(!d->grad || (!bias && !bn_scale), "sp_conv3d_set_weights: the data gradient takes the plain weights");
+  SP_CHECK_ARG(!bn_scale || (!d->transposed && d->padD == 0 && d->padH == 0 && d->padW == 0),
+               "sp_conv3d_set_weights: a BatchNorm folds into un-padded convolutions only (zero padding applies after the normalisation)");
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   const int32_t* kmap = reinterpret_cast<const int32_t*>(ws + p->off_kmap);
   void* hi = ws + p->off_wfrag;
   float* bias_out = reinterpret_cast<float*>(ws + p->off_bias);
   // element (co', ci', tap) of the op = w[co][ci][tap] of the nn.Conv3d weight [Cout][Cin][27]; roles swap for the gradient
-  const int64_t sCo = d->grad ? 27 : (int64_t)d->Cin * 27, sCi = d->grad ? (int64_t)d->Cin * 27 : 27;
+  // (nn.ConvTranspose3d keeps [Cin][Cout][27]: the op's input channel is the slow index)
+  const int64_t sCo = d->grad ? 27 : (d->transposed ? 27 : (int64_t)d->Cin * 27);
+  const int64_t sCi = d->grad ? (int64_t)d->Cin * 27 : (d->transposed ? (int64_t)d->Cout * 27 : 27);
   if (bn_scale)
     return sp_conv_prep_folded(w, sCo, sCi, p->cout_op, p->cin_op, kmap, p->nsteps, p->NT, hi, nullptr, bn_scale, 27, bias, bn_shift,
                                bias_out, p->NT * 16, stream);
@@ -118,7 +139,8 @@ extern "C" int sp_conv3d_run(const sp_conv3d_desc* d, const sp_conv3d_plan_t* p,
   a.osD = a.osH = a.osW = 1;
   a.Cout = p->cout_op;
   a.sD = a.sH = a.sW = 1;
-  a.o0D = a.o0H = a.o0W = p->o0;
+  const bool legacy = !d->transposed && d->padD == 0 && d->padH == 0 && d->padW == 0;      // (plans filled by an older caller: o0 only)
+  a.o0D = p->o0; a.o0H = legacy ? p->o0 : p->o0H; a.o0W = legacy ? p->o0 : p->o0W;
   a.TD = 1; a.TH = p->NW * p->MT;
   a.ITD = 1; a.ITH = p->ITH; a.ITW = SP_PLAN_ITW;
   a.MT = p->MT; a.NT = a.NTtot = p->NT;

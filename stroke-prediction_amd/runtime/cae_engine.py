@@ -224,6 +224,9 @@ class StackContext:
             g, coef = lay.backward(x, params, grads, want_g=(i > 0 or need_input_grad))
             if i > 0:
                 prev = self.layers[i - 1]
+                # a layer whose weight gradient runs on the raw input needs the border-class sums of its dz from THIS pass: without
+                # coefficients (no BatchNorm in front of `lay`) nobody would write them -- no layer table has that case
+                assert coef is not None or prev.cls_arg() is None, "raw-input weight gradient of %s: its dz comes without class sums" % prev.name
                 O.bn_act_bwd(g, prev.y, coef, dt, prev.act, prev.act_param, prev.dz, prev.dbias_sums, group_vox=gv(prev.y) if coef is not None else 0,
                              cls=prev.cls_arg() if coef is not None else None)
             elif need_input_grad:

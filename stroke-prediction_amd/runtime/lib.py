@@ -75,12 +75,12 @@ class ConvFcArgs(C.Structure):       # sp_conv_fc_args
 
 
 class Conv3dDesc(C.Structure):       # sp_conv3d_desc
-    _fields_ = [(n, i32) for n in ("B", "Cin", "Cout", "D", "H", "W", "grad")]
+    _fields_ = [(n, i32) for n in ("B", "Cin", "Cout", "D", "H", "W", "grad", "padD", "padH", "padW", "transposed")]
 
 
 class Conv3dPlan(C.Structure):       # sp_conv3d_plan_t
     _fields_ = [(n, i32) for n in ("cin_op", "cout_op", "P", "NT", "MT", "NW", "NSLOT", "KS", "nsteps", "ITH",
-                                   "Di", "Hi", "Wi", "Do", "Ho", "Wo", "o0")] + \
+                                   "Di", "Hi", "Wi", "Do", "Ho", "Wo", "o0", "o0H", "o0W", "mirror")] + \
                [(n, i64) for n in ("x_elems", "y_elems", "workspace_bytes", "off_zero", "off_ktab", "off_kmap", "off_bias", "off_wfrag")]
 
 

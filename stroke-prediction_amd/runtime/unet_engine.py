@@ -52,6 +52,8 @@ class UnetEngine:
     blocks S+1..2S-1 go up; up block u concatenates the upsampled output of block u-1 with the centre crop of down
     block 2S-u."""
 
+    LOSS_SCALE_GROWTH_STEPS = 200      # f16 build: clean steps after which a halved loss scale doubles again
+
     def __init__(self, channels, batch, dims, dtype, device, f8=False, variant="", hl=False, f8_fwd=True):
         """f8: the "fp8" precision mode -- storage stays bf16 (dtype), the 3x3x3 layers the fp8 kernel has an instance for
         run their forward and data-gradient MFMAs on e4m3 / e5m2 operands (runtime/f8.py).  f8_fwd=False ("fp8b"): only the
@@ -440,6 +442,7 @@ class UnetEngine:
         if self._loss_scale_t is None:
             self._loss_scale_t = torch.full((), self.loss_scale, dtype=torch.float32, device=self.device)
             self._overflows = torch.zeros((), dtype=torch.int64, device=self.device)
+            self._clean_steps = torch.zeros((), dtype=torch.int64, device=self.device)
         S = self._loss_scale_t
         names = list(grads)
         n = sum(grads[k].numel() for k in names)
@@ -465,7 +468,12 @@ class UnetEngine:
                 grads[k].addcmul_(gsafe[off:off + grads[k].numel()].view(grads[k].shape), inv)
                 off += grads[k].numel()
         self._overflows.add_((~ok).to(torch.int64))
-        S.mul_(torch.where(ok, 1.0, 0.5).to(torch.float32)).clamp_(min=1.0)
+        # halve on overflow; after LOSS_SCALE_GROWTH_STEPS clean steps in a row double again, up to the initial scale (a
+        # scale that only shrinks gives up gradient range for good after a few early overflows).  All on the device: capturable.
+        self._clean_steps = torch.where(ok, self._clean_steps + 1, torch.zeros_like(self._clean_steps))
+        grow = self._clean_steps >= self.LOSS_SCALE_GROWTH_STEPS
+        S.mul_(torch.where(ok, torch.where(grow, 2.0, 1.0), 0.5).to(torch.float32)).clamp_(min=1.0, max=self.loss_scale)
+        self._clean_steps = torch.where(grow, torch.zeros_like(self._clean_steps), self._clean_steps)
         if ready is not None:
             ready("block1.")         # every gradient is final only now: one exchange
 

@@ -71,13 +71,30 @@ def test_conv3d_plan_tables_match_the_planner():
                 continue
             assert rc == 0, L.last_error()
             assert (pl.P, pl.NT, pl.MT, pl.NW, pl.KS, pl.nsteps, pl.ITH) == (z["P"], z["NT"], z["MT"], z["NW"], z["KS"], z["nsteps"], z["ITH"])
-            assert (pl.Do, pl.Ho, pl.Wo) == tuple(op.subs[0].out_dims) and (pl.o0,) * 3 == tuple(op.subs[0].o0)
+            assert (pl.Do, pl.Ho, pl.Wo) == tuple(op.subs[0].out_dims) and (pl.o0, pl.o0H, pl.o0W) == tuple(op.subs[0].o0)
             assert (pl.Di, pl.Hi, pl.Wi) == tuple(op.in_dims)
             ktab = np.zeros(4 * pl.KS, np.int32); kmap = np.zeros(12 * pl.KS, np.int32)
             assert lib.sp_conv3d_tables(C.byref(d), C.byref(pl), ktab.ctypes.data, kmap.ctypes.data) == 0
             np.testing.assert_array_equal(ktab, z["ktab"])
             np.testing.assert_array_equal(kmap, z["kmap"])
             assert pl.workspace_bytes >= pl.off_wfrag + pl.nsteps * pl.NT * 1024 and pl.off_ktab >= 256
+    # round 5: padded convolutions and their data gradients (the CAE's stride-1 layers) and stride-1 transposed convolutions
+    for cin, cout, pad in ((16, 16, (1, 0, 0)), (32, 32, (1, 2, 2)), (16, 32, (1, 1, 1))):
+        for kind in ("fwd", "grad", "convT"):
+            dims = (9, 20, 22)
+            d = L.Conv3dDesc(2, cin, cout, *dims, 1 if kind == "grad" else 0, *pad, 1 if kind == "convT" else 0)
+            pl = L.Conv3dPlan()
+            op = {"fwd": lambda: P.conv_fwd_op(cin, cout, 3, 1, pad, dims, cin, cout, 0),
+                  "grad": lambda: P.conv_dgrad_op(cin, cout, 3, 1, pad, dims, cout, cin, 0),
+                  "convT": lambda: P.convT_fwd_op(cin, cout, 3, 1, pad, dims, cin, cout, 0)}[kind]()
+            z = P.zm_plan(op, tile="classic")
+            assert z is not None and lib.sp_conv3d_plan(C.byref(d), C.byref(pl)) == 0, L.last_error()
+            assert (pl.Di, pl.Hi, pl.Wi) == tuple(op.in_dims) and (pl.Do, pl.Ho, pl.Wo) == tuple(op.subs[0].out_dims), (kind, pad)
+            assert (pl.o0, pl.o0H, pl.o0W) == tuple(op.subs[0].o0), (kind, pad, (pl.o0, pl.o0H, pl.o0W), op.subs[0].o0)
+            ktab = np.zeros(4 * pl.KS, np.int32); kmap = np.zeros(12 * pl.KS, np.int32)
+            assert lib.sp_conv3d_tables(C.byref(d), C.byref(pl), ktab.ctypes.data, kmap.ctypes.data) == 0
+            np.testing.assert_array_equal(ktab, z["ktab"])
+            np.testing.assert_array_equal(kmap, z["kmap"])
     # channel counts without a kernel, and malformed descriptors, are refused with a message
     bad = L.Conv3dDesc(1, 64, 64, 20, 20, 20, 0)
     assert lib.sp_conv3d_plan(C.byref(bad), C.byref(L.Conv3dPlan())) == -1 and "sp_conv3d_plan" in L.last_error()
