@@ -266,6 +266,10 @@ def kernel_profile(eager_step, nsteps, world):
         dist.barrier()
     torch.cuda.synchronize()
     prof, O.PROFILE = O.PROFILE, None
+    if os.environ.get("SP_LAYER_ORDER"):      # tools/layer_table.py: (tag, detail, flops) of ONE step's launches, in order
+        n1 = len(prof) // nsteps
+        with open(os.environ["SP_LAYER_ORDER"], "w") as f:
+            json.dump([[tag, detail, flops] for tag, flops, _, _, detail in prof[:n1]], f)
     agg, per_layer = {}, {}
     for tag, flops, e0, e1, detail in prof:
         ms = e0.elapsed_time(e1)

@@ -394,15 +394,21 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 // Same, WITHOUT the "memory" clobber: for DMAs placed inside an MFMA loop.  The clobber makes the statement a barrier for the
 // compiler's own LDS reads and stores, which could then no longer be prefetched / interleaved across it.  Only for DMAs whose
 // destination no instruction between the surrounding barriers touches (the kernel's own waits + s_barrier order it).
+// -DSP_DMA_NT (diagnostic build, tools/build_variant_all.sh): the non-temporal cache policy on every LDS-DMA load
+#ifdef SP_DMA_NT
+#define SP_DMA_POLICY " nt"
+#else
+#define SP_DMA_POLICY ""
+#endif
 __device__ __forceinline__ void sp_dma16_nc(const void* src, const void* lds_dst) {
   typedef __attribute__((address_space(3))) void sp_lds_void;
   const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(sp_lds_void*)lds_dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base));
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" SP_DMA_POLICY ::"v"(src), "s"(base));
 }
 __device__ __forceinline__ void sp_dma16(const void* src, const void* lds_dst) {
   typedef __attribute__((address_space(3))) void sp_lds_void;
   const uint32_t base = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(sp_lds_void*)lds_dst);
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" SP_DMA_POLICY ::"v"(src), "s"(base) : "memory");
 }
 
 

@@ -251,29 +251,44 @@ extern "C" int sp_bn_finalize(const double* sums, int32_t nrep, double count, co
 // Cae3D.py:105-107,230-233): sums [G][nrep][CP][2]; scale / shift at scale + g*coef_stride (the rows of a [G][3][CP] table),
 // mean / invstd [G][CP]; the running statistics take the G momentum updates IN GROUP ORDER (one thread per channel), exactly
 // as the reference's G sequential module calls do.
-__global__ void bn_finalize_groups_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
+// (round 5: one WAVE per group -- the groups' replica gathers are one memory round trip side by side, not G in a row: 6.6 -> ~4 us
+// per launch, 22 launches per CAE step -- then one thread walks the groups in order for the running statistics; same sums, same
+// order, same bits as the serial form)
+__global__ __launch_bounds__(1024) void bn_finalize_groups_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
                                           const float* __restrict__ beta, float* running_mean, float* running_var,
                                           float momentum, float eps, int training, int C, int CP, int G, int coef_stride,
                                           float* scale, float* shift, float* mean_out, float* invstd_out) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+  __shared__ double s_m[16], s_var[16];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (c < C && training) {
+    for (int g = wv; g < G; g += nw) {
+      const double* sg = sums + (size_t)g * nrep * CP * 2;
+      double s1 = 0, s2 = 0;
+      for (int r = lane; r < nrep; r += 64) { s1 += sg[((size_t)r * CP + c) * 2]; s2 += sg[((size_t)r * CP + c) * 2 + 1]; }
+      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
+      if (lane == 0) {
+        const double m = s1 / count;
+        double var = s2 / count - m * m;
+        s_m[g] = m;
+        s_var[g] = var < 0 ? 0 : var;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float rm = 0.f, rv = 1.f;
   if (c < C && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
   for (int g = 0; g < G; ++g) {
     float* sc_o = scale + (size_t)g * coef_stride;
     float* sh_o = shift + (size_t)g * coef_stride;
     if (c >= C) {
-      if (lane == 0) { sc_o[c] = 0.f; sh_o[c] = 0.f; if (mean_out) { mean_out[(size_t)g * CP + c] = 0.f; invstd_out[(size_t)g * CP + c] = 0.f; } }
+      sc_o[c] = 0.f; sh_o[c] = 0.f;
+      if (mean_out) { mean_out[(size_t)g * CP + c] = 0.f; invstd_out[(size_t)g * CP + c] = 0.f; }
       continue;
     }
     float mean, invstd;
     if (training) {
-      const double* sg = sums + (size_t)g * nrep * CP * 2;
-      double s1 = 0, s2 = 0;
-      for (int r = lane; r < nrep; r += 64) { s1 += sg[((size_t)r * CP + c) * 2]; s2 += sg[((size_t)r * CP + c) * 2 + 1]; }
-      s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-      const double m = s1 / count;
-      double var = s2 / count - m * m;
-      if (var < 0) var = 0;
+      const double m = s_m[g], var = s_var[g];
       mean = (float)m;
       invstd = (float)(1.0 / sqrt(var + (double)eps));
       const double unb = count > 1 ? var * count / (count - 1) : var;
@@ -283,14 +298,12 @@ __global__ void bn_finalize_groups_kernel(const double* __restrict__ sums, int n
       mean = rm;
       invstd = 1.f / sqrtf(rv + eps);
     }
-    if (lane == 0) {
-      const float sc = gamma[c] * invstd;
-      sc_o[c] = sc;
-      sh_o[c] = beta[c] - mean * sc;
-      if (mean_out) { mean_out[(size_t)g * CP + c] = mean; invstd_out[(size_t)g * CP + c] = invstd; }
-    }
+    const float sc = gamma[c] * invstd;
+    sc_o[c] = sc;
+    sh_o[c] = beta[c] - mean * sc;
+    if (mean_out) { mean_out[(size_t)g * CP + c] = mean; invstd_out[(size_t)g * CP + c] = invstd; }
   }
-  if (training && running_mean && c < C && lane == 0) { running_mean[c] = rm; running_var[c] = rv; }
+  if (training && running_mean && c < C) { running_mean[c] = rm; running_var[c] = rv; }
 }
 extern "C" int sp_bn_finalize_groups(const double* sums, int32_t nrep, double count, const float* gamma, const float* beta,
                                      float* running_mean, float* running_var, float momentum, float eps, int32_t training,
@@ -299,42 +312,49 @@ extern "C" int sp_bn_finalize_groups(const double* sums, int32_t nrep, double co
   SP_CHECK_ARG(gamma && beta && scale && shift && C <= CP && G >= 1 && coef_stride >= CP, "sp_bn_finalize_groups: bad arguments");
   SP_CHECK_ARG(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "sp_bn_finalize_groups: missing statistics");
   SP_CHECK_ARG(nrep >= 1, "sp_bn_finalize_groups: nrep");
-  hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep, count, gamma, beta,
+  SP_CHECK_ARG(G <= 16, "sp_bn_finalize_groups: at most 16 groups");
+  hipLaunchKernelGGL(bn_finalize_groups_kernel, dim3(CP), dim3(64 * G), 0, ST(stream), sums, nrep, count, gamma, beta,
                      running_mean, running_var, momentum, eps, training, C, CP, G, coef_stride, scale, shift, mean, invstd);
   SP_CHECK_LAUNCH("sp_bn_finalize_groups");
   return SP_OK;
 }
 
 // backward: sums [G][nrep][CP][2], mean / invstd [G][CP], coef [G][3][CP]; dgamma / dbeta accumulate the G groups
-__global__ void bn_bwd_finalize_groups_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_groups_kernel(const double* __restrict__ sums, int nrep, double count, const float* __restrict__ gamma,
                                               const float* __restrict__ mean, const float* __restrict__ invstd, int C, int CP, int G,
                                               float* dgamma, float* dbeta, float* coef, float pscale) {
-  const int c = blockIdx.x, lane = threadIdx.x;
-  float dg_acc = 0.f, db_acc = 0.f;
-  for (int g = 0; g < G; ++g) {
+  __shared__ float s_dg[16], s_db[16];      // (one wave per group; thread 0 adds the groups in order: the serial form's sums)
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int g = wv; g < G; g += nw) {
     float* cf = coef + (size_t)g * 3 * CP;
     if (c >= C) { if (lane == 0) { cf[c] = 0.f; cf[CP + c] = 0.f; cf[2 * CP + c] = 0.f; } continue; }
     const double* sg = sums + (size_t)g * nrep * CP * 2;
     double s1 = 0, s2 = 0;
     for (int r = lane; r < nrep; r += 64) { s1 += sg[((size_t)r * CP + c) * 2]; s2 += sg[((size_t)r * CP + c) * 2 + 1]; }
     s1 = wave_sum_d(s1); s2 = wave_sum_d(s2);
-    const double mu = mean[(size_t)g * CP + c], is = invstd[(size_t)g * CP + c], ga = gamma[c];
-    const double dg = (s2 - mu * s1) * is, db = s1;
-    dg_acc += pscale * (float)dg; db_acc += pscale * (float)db;
-    const double c0 = ga * is, c1 = -ga * is * is * dg / count;
     if (lane == 0) {
+      const double mu = mean[(size_t)g * CP + c], is = invstd[(size_t)g * CP + c], ga = gamma[c];
+      const double dg = (s2 - mu * s1) * is, db = s1;
+      s_dg[g] = pscale * (float)dg; s_db[g] = pscale * (float)db;
+      const double c0 = ga * is, c1 = -ga * is * is * dg / count;
       cf[c] = (float)c0;
       cf[CP + c] = (float)c1;
       cf[2 * CP + c] = (float)(-c0 * db / count - c1 * mu);
     }
   }
-  if (c < C && lane == 0 && dgamma) { dgamma[c] += dg_acc; dbeta[c] += db_acc; }
+  __syncthreads();
+  if (threadIdx.x == 0 && c < C && dgamma) {
+    float dg_acc = 0.f, db_acc = 0.f;
+    for (int g = 0; g < G; ++g) { dg_acc += s_dg[g]; db_acc += s_db[g]; }
+    dgamma[c] += dg_acc; dbeta[c] += db_acc;
+  }
 }
 extern "C" int sp_bn_bwd_finalize_groups(const double* sums, int32_t nrep, double count, const float* gamma, const float* mean,
                                          const float* invstd, int32_t C, int32_t CP, int32_t G, float* dgamma, float* dbeta,
                                          float* coef, float param_grad_scale, sp_stream_t stream) {
   SP_CHECK_ARG(sums && gamma && mean && invstd && coef && count > 0 && G >= 1, "sp_bn_bwd_finalize_groups: bad arguments");
-  hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(CP), dim3(64), 0, ST(stream), sums, nrep < 1 ? 1 : nrep, count, gamma, mean,
+  SP_CHECK_ARG(G <= 16, "sp_bn_bwd_finalize_groups: at most 16 groups");
+  hipLaunchKernelGGL(bn_bwd_finalize_groups_kernel, dim3(CP), dim3(64 * G), 0, ST(stream), sums, nrep < 1 ? 1 : nrep, count, gamma, mean,
                      invstd, C, CP, G, dgamma, dbeta, coef, param_grad_scale);
   SP_CHECK_LAUNCH("sp_bn_bwd_finalize_groups");
   return SP_OK;

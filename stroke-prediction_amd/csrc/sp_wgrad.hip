@@ -290,6 +290,12 @@ __device__ __forceinline__ bool wgrad_part_sum(const float* __restrict__ acc, in
   float s = 0.f;
   if (idx < total) {
     int r = rl;
+    for (; r + 56 < nparts; r += 64) {      // eight independent loads per trip (four: 17 us per launch at 512 blocks, latency-bound)
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = acc[(size_t)(r + 8 * k) * total + idx];
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
     for (; r + 24 < nparts; r += 32) {
       const float a0 = acc[(size_t)r * total + idx], a1 = acc[(size_t)(r + 8) * total + idx];
       const float a2 = acc[(size_t)(r + 16) * total + idx], a3 = acc[(size_t)(r + 24) * total + idx];

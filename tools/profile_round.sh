@@ -21,7 +21,10 @@ if [ "$WL" = unet ]; then
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --output-format csv -d $OUT/q1 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q1.log 2>&1
   rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/q2 -o q -- python bench.py --steps 2 --warmup 1 --no-graph --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/q2.log 2>&1
   python tools/pmc_sq.py $(csvf $OUT/q1) $(csvf $OUT/q2) > gpurun_out/${TAG}_mfma_busy.txt
-  MIN_US=20 bash tools/probes/serial_traffic.sh bf16 unet > gpurun_out/${TAG}_bench_serial_traffic.txt 2>&1      # every kernel of the step: serial duration next to its HBM bytes
+  SP_LAYER_ORDER=$OUT/layers.json python bench.py --steps 3 --warmup 1 --no-parity --no-cpu-baseline --no-secondary --layers > $OUT/l.log 2>&1
+  SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/s2 -o s -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-timing --no-secondary --no-parity > $OUT/s2.log 2>&1 && python tools/rocpd_sequence.py $(db $OUT/s2) > $OUT/serial_seq.txt
+  python tools/layer_table.py $OUT/serial_seq.txt $(csvf $OUT/f) $(csvf $OUT/w) $(csvf $OUT/q1) $OUT/layers.json > gpurun_out/${TAG}_bench_layers.txt 2>&1      # per conv launch: us, TFLOP/s, HBM MB, MFMA busy
+  MIN_US=12 bash tools/probes/serial_traffic.sh bf16 unet > gpurun_out/${TAG}_bench_serial_traffic.txt 2>&1      # every kernel of the step: serial duration next to its HBM bytes
 elif [ "$WL" = x3 ]; then
   for DT in f16x3 bf16x3; do
     SP_OVERLAP=0 rocprofv3 --kernel-trace --stats -d $OUT/$DT -o s -- python bench.py --dtype $DT --steps 10 --warmup 3 --no-parity --no-cpu-baseline --no-secondary --no-kernel-timing > $OUT/$DT.log 2>&1 && \
