@@ -854,7 +854,7 @@ static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   }
   if (a->pool_y) {      // MaxPool3d(2) of the output in the epilogue, statistics of the pooled tensor
     if constexpr (NW == 8 && NSLOT == 3 && ((P == 1 && NT == 1 && MT == 4) || (P == 2 && NT == 2 && MT == 2))) {
-      return launch_zm2<P, NT, MT, NSLOT, true, NW, 1, 1, false, true>(a, zeros, st);      // (weights in LDS: the register form of (1, 1) spills with the pooled set)
+      return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 1, 1, false, true>(a, zeros, st);
     } else {
       sp_set_error("sp_conv3d_zm: no pooling-epilogue instance for P=%d NT=%d NW=%d", P, NT, NW);
       return SP_EINVAL;
