@@ -472,7 +472,10 @@ class UnetEngine:
         # scale that only shrinks gives up gradient range for good after a few early overflows).  All on the device: capturable.
         self._clean_steps = torch.where(ok, self._clean_steps + 1, torch.zeros_like(self._clean_steps))
         grow = self._clean_steps >= self.LOSS_SCALE_GROWTH_STEPS
-        S.mul_(torch.where(ok, torch.where(grow, 2.0, 1.0), 0.5).to(torch.float32)).clamp_(min=1.0, max=self.loss_scale)
+        before = S.clone()
+        S.mul_(torch.where(ok, torch.where(grow, 2.0, 1.0), 0.5).to(torch.float32)).clamp_(min=1.0)
+        # (growth stops at the initial scale; a scale above it -- set by hand -- only shrinks)
+        S.copy_(torch.where(grow & ok, torch.minimum(S, before.clamp(min=self.loss_scale)), S))
         self._clean_steps = torch.where(grow, torch.zeros_like(self._clean_steps), self._clean_steps)
         if ready is not None:
             ready("block1.")         # every gradient is final only now: one exchange
