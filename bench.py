@@ -574,7 +574,7 @@ def bench_unet(args, world, rank, dev, four_scale=False):
                    "dp_mode": args.dp_mode if world > 1 else None,
                    # VERDICT r4 "next" 8: which fp8 recipe is which (cosines of the weight gradients against the f32 mode)
                    "precision_note": {"fp8b": "configs[4] TRAINING mode: bf16 forward, fp8 data/weight gradients; gradient cosines of the bf16 mode (0.89 whole-gradient vs f32)",
-                                      "fp8": "THROUGHPUT mode, direction-lossy: e4m3 forward flips LeakyReLU branches (whole-gradient cosine 0.39 vs f32 at random init); use fp8b to train"
+                                      "fp8": "THROUGHPUT mode: e4m3 forward flips LeakyReLU branches (whole-gradient cosine 0.39 vs f32 at random init on random targets); trains like f32/bf16/fp8b on a learnable target (profiles/r05_f8_train_curve.txt); fp8b keeps the bf16 gradient directions"
                                       }.get(args.dtype),
                    # proof that the collectives saw N ranks: the sum of an all-reduce of ones over the group the gradients travel on
                    "rccl_ranks": rccl["ranks"], "rccl_backend": rccl["backend"], "rccl_direct": rccl["direct"], "rccl_two_shot": rccl["two_shot"],
