@@ -181,6 +181,11 @@ typedef struct sp_conv_args {
    * `stats` then receives the statistics of the POOLED tensor -- the next block's BatchNorm input -- instead of y's */
   void* pool_y;
   int64_t pool_lo_delta;
+  /* ---- sp_conv3d_zm data gradients of a layer whose input is a channel concatenation (Unet3D.py:66-67,71-72): output tiles
+   * [0, split_nt) go to y (channel pitch CPo), the others to y2 [B][YD][YH][YW][CPo2] -- two dense tensors for the two consumers of
+   * the gradient (upsample backward / pool + skip backward) from one launch */
+  void* y2;
+  int32_t split_nt, CPo2;
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);

@@ -135,7 +135,10 @@ template <> struct ZmStore<float> {
 // planes, so which step holds and which emits is known at compile time) -- and the statistics the kernel accumulates are those of the
 // POOLED tensor (the next block's BatchNorm input; nobody needs the un-pooled tensor's): sp_maxpool2_fwd's pass over the largest
 // activations of the network (read 8, write 1) is gone.
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false, bool POOL = false>
+// SPLIT (a.y2; the data gradient of a layer whose input is a channel concatenation, Unet3D.py:66-67,71-72): output tiles [0, split_nt)
+// go to y (pitch CPo), the rest to a SECOND dense tensor y2 (pitch CPo2) -- the two consumers of such a gradient (upsample backward,
+// pool / skip backward) then read whole lines instead of 64 / 32 bytes of every 96-byte row, from ONE launch.
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false, bool POOL = false, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int S = NJ * NW * 1024;               // slot stride in bytes
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
+  static_assert(!SPLIT || (ACT == 0 && STATS == 0 && !Q8 && !HL && !POOL && NT >= 2 && sizeof(TOUT) == 2), "split output: plain 16-bit data gradients of two or more output tiles");
   static_assert(!POOL || (ACT == 1 && STATS == 1 && !Q8 && MT % 2 == 0 && sizeof(TOUT) == 2), "pooling epilogue: forward layers with statistics, 16-bit output, row pairs inside a wave");
   constexpr int NSP = POOL ? (MT / 2) * NT * (HL ? 2 : 1) : 0;      // pooled stores of one epilogue (issued every step: the hold steps' are dropped)
   constexpr int NS = MT * NT * ((Q8 || HL) ? 2 : 1) + NSP;      // store instructions of one epilogue
@@ -437,6 +441,21 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       rowoff[m] = ok ? (uint32_t)((((oy * a.osH + a.ooH) * a.YW + (ox * a.osW + a.ooW)) * a.CPo + lg * 4) * (int)sizeof(TOUT)) : 0x80000000u;
       rowok[m] = ok ? 0xffffffffu : 0u;
     }
+    // SPLIT: the second output tensor of sample b and this lane's offsets in it (same voxels, its own channel pitch)
+    const __amdgpu_buffer_rsrc_t yrs2 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(SPLIT ? reinterpret_cast<unsigned char*>(a.y2) + (size_t)b * a.YD * a.YH * a.YW * a.CPo2 * sizeof(TOUT) : nullptr), 0,
+        (int)(SPLIT ? (uint32_t)a.YD * a.YH * a.YW * a.CPo2 * (uint32_t)sizeof(TOUT) : 0u), 0x00020000);
+    uint32_t rowoff2[SPLIT ? MT : 1];
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        int fy, fx;
+        tile_rc(m, fy, fx);
+        const int oy = oy0 + fy, ox = ox0 + fx;
+        rowoff2[m] = (fy >= 0 && ox < a.Wo && oy < a.Ho) ? (uint32_t)(((oy * a.YW + ox) * a.CPo2 + lg * 4) * (int)sizeof(TOUT)) : 0x80000000u;
+      }
+    }
+    const uint32_t zstride2 = (uint32_t)(a.YH * a.YW * a.CPo2 * (int)sizeof(TOUT));
     int btrow[PB ? MT : 1];                          // PB: byte offset of (row class, column class, this lane's channel quad) in the bias table
     if constexpr (PB) {
 #pragma unroll
@@ -538,6 +557,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
           const zm_u32x2 dh_ = {h0_, h1_}, dl_ = {l0_, l1_};                                                      \
           __builtin_amdgcn_raw_buffer_store_b64(dh_, yrs, off + (uint32_t)(n * 32), 0, 0);                        \
           __builtin_amdgcn_raw_buffer_store_b64(dl_, yrs_lo, off + (uint32_t)(n * 32), 0, 0);                     \
+        } else if constexpr (SPLIT) {      /* tiles past split_nt: the second tensor (uniform select, no branch) */                \
+          const bool sec_ = n >= a.split_nt;                                                                      \
+          const uint32_t o2_ = (!pv || (rowoff2[SPLIT ? m : 0] & 0x80000000u)) ? 0x80000000u : (uint32_t)(fz_) * zstride2 + rowoff2[SPLIT ? m : 0]; \
+          const uint32_t os_ = sec_ ? ((o2_ & 0x80000000u) ? o2_ : o2_ + (uint32_t)((n - a.split_nt) * 16 * (int)sizeof(TOUT))) : off + (uint32_t)(n * 16 * (int)sizeof(TOUT)); \
+          ZmStore<TOUT>::st4(sec_ ? yrs2 : yrs, os_, v);                                                          \
         } else ZmStore<TOUT>::st4(yrs, off + (uint32_t)(n * 16 * (int)sizeof(TOUT)), v);                          \
         if constexpr (Q8) {      /* of the STORED 16-bit values: the copy equals sp_quantize_f8 of y bit for bit */     \
           const uint32_t w0_ = zm_pack2(v[0], v[1]), w1_ = zm_pack2(v[2], v[3]);                                  \
@@ -755,7 +779,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false, bool POOL = false>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false, bool POOL = false, bool SPLIT = false>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
   constexpr int NCH = (HL ? 2 : 1) * P * (NW * MT + 2) * 18 * 2;
@@ -789,7 +813,11 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
     grid = 8u * (unsigned)a->nslices * (32u / (unsigned)a->nslices);
     SP_CHECK_ARG(planes >= (uint64_t)grid / a->nslices, "sp_conv3d_zm: too few (column, plane) pairs for %d slices in one launch", a->nslices);
   }
-  if constexpr (POOL) {
+  if constexpr (SPLIT) {
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, false, false, true>;
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+  } else if constexpr (POOL) {
     SP_CHECK_ARG(Q.tw == 16 && Q.th == NW * MT && a->dtype_out != SP_F32 && !a->y8, "sp_conv3d_zm: the pooling epilogue needs the classic %d x 16 tile and a 16-bit output", NW * MT);
     auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, HL, true>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
@@ -857,6 +885,14 @@ static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
       return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 1, 1, false, true>(a, zeros, st);
     } else {
       sp_set_error("sp_conv3d_zm: no pooling-epilogue instance for P=%d NT=%d NW=%d", P, NT, NW);
+      return SP_EINVAL;
+    }
+  }
+  if (a->y2) {      // the data gradient of a concatenating layer: two dense output tensors from one launch
+    if constexpr (NW == 8 && P == 1 && NT == 3) {
+      return launch_zm2<P, NT, MT, NSLOT, WLDS, NW, 0, 0, false, false, true>(a, zeros, st);
+    } else {
+      sp_set_error("sp_conv3d_zm: no split-output instance for P=%d NT=%d NW=%d", P, NT, NW);
       return SP_EINVAL;
     }
   }
@@ -931,6 +967,11 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
                        (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && a->nslices <= 1),
                "sp_conv3d_zm: bf16 pairs in -> bf16 pairs out with hi and lo weight fragments, bias + LeakyReLU / identity epilogue");
   SP_CHECK_ARG(a->sD == 1 && a->sH == 1 && a->sW == 1, "sp_conv3d_zm: stride 1 only");
+  SP_CHECK_ARG(!a->y2 || (a->split_nt >= 1 && a->split_nt < a->NT && a->CPo2 >= (a->NT - a->split_nt) * 16 && a->CPo >= a->split_nt * 16 && a->act == SP_ACT_NONE && a->bias == nullptr &&
+                         !a->stats && a->stats_mode == 0 && a->dtype_out == SP_BF16 && !hl && !a->y8 && !a->pool_y && a->nslices <= 1 && a->group_batch == 0 &&
+                         a->osD == 1 && a->osH == 1 && a->osW == 1 && a->ooD == 0 && a->ooH == 0 && a->ooW == 0 &&
+                         (uint64_t)a->YD * a->YH * a->YW * a->CPo2 * 2 < (1ull << 31)),
+               "sp_conv3d_zm: y2 (split output) is for plain dense bf16 data gradients: tiles [0, split_nt) to y, the rest to y2 (pitch CPo2)");
   SP_CHECK_ARG(!a->pool_y || (a->stats && a->stats_mode == 0 && a->act != SP_ACT_ELU && a->group_batch == 0 && a->nslices <= 1 && !a->y8 && !a->bias_tab &&
                               a->osD == 1 && a->osH == 1 && a->osW == 1 && a->ooD == 0 && a->ooH == 0 && a->ooW == 0 && a->YD == a->Do && a->YH == a->Ho && a->YW == a->Wo &&
                               a->YD >= 2 && a->YH >= 2 && a->YW >= 2 && (!hl || (a->pool_lo_delta != 0 && a->pool_lo_delta % 8 == 0)) &&
@@ -946,7 +987,7 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
   }
   SP_CHECK_ARG(a->group_batch >= 0 && (a->group_batch == 0 || (a->B % a->group_batch == 0 && a->nslices <= 1)), "sp_conv3d_zm: group_batch %d must divide the batch %d (no slices)", a->group_batch, a->B);
   SP_CHECK_ARG(a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE || a->act == SP_ACT_ELU, "sp_conv3d_zm: LeakyReLU, ELU or identity epilogue");
-  SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= a->Cout, "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
+  SP_CHECK_ARG(a->CPi % 16 == 0 && a->NT == a->NTtot && a->Cout == 16 * a->NT && a->CPo >= (a->y2 ? 16 * a->split_nt : a->Cout), "sp_conv3d_zm: whole 16-channel tiles (CPi %d, Cout %d, NT %d)", a->CPi, a->Cout, a->NT);
   SP_CHECK_ARG(a->nslices >= 0 && a->nslices <= 16 && (a->nslices <= 1 || (a->CPo >= a->nslices * a->Cout && a->slice_wfrag_stride > 0 && a->slice_wfrag_stride % 16 == 0 && !a->y8)),
                "sp_conv3d_zm: nslices %d (CPo %d, Cout %d per slice, slice_wfrag_stride %lld; no e4m3 copy)", a->nslices, a->CPo, a->Cout, (long long)a->slice_wfrag_stride);
   SP_CHECK_ARG(!a->stats || (a->stats_nrep >= 1 && (a->stats_nrep & (a->stats_nrep - 1)) == 0), "sp_conv3d_zm: stats_nrep must be a power of two");

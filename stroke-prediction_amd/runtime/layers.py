@@ -381,7 +381,18 @@ class ConvLayer:
         # run at all for the first layer of a network, whose input gradient nobody wants.
         self.bn_from_wgrad = bool(self.bn_prefix is not None and self.kind == "conv" and self.wgrad.folds(self.scale)
                                   and max(P._triple(p)) == 0 and O.BN_SUMS_FROM_WGRAD and self.G == 1)
-        if self.split_g and self.kind == "conv" and self.need_input_grad and self.bn_from_wgrad:
+        self.split_one = False
+        if self.split_g and self.kind == "conv" and self.need_input_grad and self.bn_from_wgrad and self.split_g % 16 == 0 and (cin - self.split_g) % 16 == 0 \
+                and self.cpi == cin and dt == L.SP_BF16 and not self.f8_on:
+            # ONE launch, two dense tensors (sp_conv3d_zm with y2: round 5) where the z-marching instance exists
+            probe = O.ConvRunner(dop, dev, zm_batch=self.batch if self.bank is None else None)
+            if probe.zm_split_ok():
+                self.dgrad, self.split_one = probe, True
+                self.g_parts = [O.alloc_cl(self.batch, self.in_dims, self.split_g, dt, dev), O.alloc_cl(self.batch, self.in_dims, cin - self.split_g, dt, dev)]
+                self.g = tuple(self.g_parts)
+        if self.split_one:
+            pass
+        elif self.split_g and self.kind == "conv" and self.need_input_grad and self.bn_from_wgrad and os.environ.get("SP_SPLIT_G"):
             # gradient of a channel-concatenated input as one dense tensor per part: both consumers (upsample backward,
             # pool/skip backward) then read whole lines instead of 64 / 32 bytes of every 96-byte row
             self.dgrad_parts, self.g_parts = [], []
@@ -654,7 +665,10 @@ class ConvLayer:
             self.f8_dgrad.prep(w, out_scale=1.0 / S)
             self.f8_dgrad.run(self.dz8, self.g)
             return
-        if getattr(self, "dgrad_parts", None):
+        if getattr(self, "split_one", False):
+            self.dgrad.prep(w)
+            self.dgrad.run(self.dz, self.g_parts[0], self.batch, y2=self.g_parts[1], split_nt=self.split_g // 16)
+        elif getattr(self, "dgrad_parts", None):
             for (runner, woff), g in zip(self.dgrad_parts, self.g_parts):
                 runner.prep(w.view(-1)[woff:])
                 runner.run(self.dz, g, self.batch)

@@ -53,7 +53,7 @@ class ConvArgs(C.Structure):
                                                                            ("group_batch", i32), ("nslices", i32),
                                                                           ("slice_wfrag_stride", i64), ("x_lo_delta", i64), ("y_lo_delta", i64),
                                                                           ("bias_tab", vp), ("bias_tab_gstride", i32), ("pad_", i32), ("wfrag_gstride", i64),
-                                                                          ("bnb", BnBwdArgs), ("dz_sums", vp), ("pool_y", vp), ("pool_lo_delta", i64)]
+                                                                          ("bnb", BnBwdArgs), ("dz_sums", vp), ("pool_y", vp), ("pool_lo_delta", i64), ("y2", vp), ("split_nt", i32), ("CPo2", i32)]
 
 
 class WgradArgs(C.Structure):

@@ -33,6 +33,7 @@ def bump_param_epoch():
 
 
 FUSE_BN_FINALIZE = bool(int(os.environ.get("SP_FUSE_BN_FINALIZE", "1")))   # sp_bn_finalize inside the weight re-pack kernel of the folded layers (one launch less per layer)
+SPLIT_G = bool(int(os.environ.get("SP_SPLIT_G1", "1")))   # one-launch split of a concatenating layer's data gradient into two dense tensors (ConvRunner.zm_split_ok)
 FUSE_POOL = bool(int(os.environ.get("SP_FUSE_POOL", "1")))   # MaxPool3d(2) in the epilogue of the down blocks' second convolution (training steps)
 FUSE_DZ = bool(int(os.environ.get("SP_FUSE_DZ", "1")))   # the second convolution's data gradient writes the first one's dz (BatchNorm / activation backward in its epilogue)
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
@@ -340,6 +341,13 @@ class ConvRunner:
                     and (z["NW"] == 8 or self.op.dtype == L.SP_HL) and z["TW"] == 16 and z["TH"] == z["NW"] * z["MT"]
                     and min(self.op.y_dims) >= 2 and tuple(self.op.subs[0].out_dims) == tuple(self.op.y_dims))
 
+    def zm_split_ok(self):
+        """run(y2=..., split_nt=...) applies: the z-marching instance with two output tensors ((P, NT) = (1, 3): 16 -> 48, the data
+        gradient of the 3-scale network's last concatenating layer)"""
+        z = self.zm
+        return bool(SPLIT_G and z is not None and self.zms is None and self.op.dtype == L.SP_BF16 and (z["P"], z["NT"]) == (1, 3) and z["NW"] == 8
+                    and tuple(self.op.subs[0].out_dims) == tuple(self.op.y_dims))
+
     def zm_bn_bwd_ok(self):
         return self.zm is not None and self.op.dtype == L.SP_BF16 and ConvRunner.zm_plan_bn_bwd_ok(self.zm)
 
@@ -431,10 +439,12 @@ class ConvRunner:
 
     def run(self, x, y, batch, in_scale=None, in_shift=None, act=L.ACT_NONE, act_param=0.0, stats=None,
             dtype_out=None, use_bias=True, stats_nrep=1, stats_mode=0, aux=None, x_planar=False, group_batch=0, y8=None,
-            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0, bnb=None, dz_sums=None, pool=None):
+            x_lo=None, y_lo=None, group_fold=None, coef_gstride=0, bnb=None, dz_sums=None, pool=None, y2=None, split_nt=0):
         """x_planar: x (shaped (B, D, H, W, CPi) like any input) is stored plane-major [CPi/16][B][D][H][W][16] -- the concat
         buffers written by upsample2_crop_cat_fwd(planar=True); DMA kernel only.
         y8: plane-major uint8 tensor (runtime/f8.alloc_f8) that receives the e4m3 copy of the output (``zm_y8_ok()`` runners).
+        y2 / split_nt (``zm_split_ok()``; data gradients of a concatenating layer): output tiles [0, split_nt) go to y (a tensor of
+        split_nt * 16 channels or more), the others to the second dense tensor y2.
         pool = (pooled, pooled_lo | None) (``zm_pool_ok()``): MaxPool3d(2) of the output is written to `pooled` by the same kernel and
         `stats` receives the statistics of the POOLED tensor.
         stats_mode 2 (z-marching data gradients, ``zm_bn_bwd_ok()``): y receives dz = (c0 g + c1 aux + c2) act'(aux) instead of the data
@@ -467,7 +477,7 @@ class ConvRunner:
             assert x_lo.dtype == x.dtype and y_lo.dtype == y.dtype and x_lo.is_contiguous() and y_lo.is_contiguous()
             assert not group_batch and stats_mode == 0 and y8 is None and in_scale is None
         assert tuple(x.shape) == (batch,) + tuple(op.in_dims) + (op.cpi,), (tuple(x.shape), op.in_dims, op.cpi)
-        assert tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= op.cpo
+        assert tuple(y.shape[:4]) == (batch,) + tuple(op.y_dims) and y.shape[4] >= (op.cpo if y2 is None else split_nt * 16)
         a = L.ConvArgs()
         a.x, a.y = ptr(x), ptr(y)
         a.in_scale, a.in_shift = ptr(in_scale), ptr(in_shift)
@@ -486,6 +496,10 @@ class ConvRunner:
         a.NT, a.NTtot = op.nt, op.nttot
         a.act, a.act_param = act, act_param
         a.group_batch = group_batch if (group_batch and group_batch < batch and stats is not None) else 0
+        if y2 is not None:
+            assert self.zm_split_ok() and 1 <= split_nt < self.zm["NT"] and stats is None and stats_mode == 0 and act == L.ACT_NONE and y8 is None and pool is None
+            assert tuple(y2.shape[:4]) == tuple(y.shape[:4]) and y2.shape[4] >= (self.zm["NT"] - split_nt) * 16 and y2.dtype == y.dtype and y2.is_contiguous()
+            a.y2, a.split_nt, a.CPo2 = ptr(y2), int(split_nt), y2.shape[4]
         if pool is not None:
             pooled, pooled_lo = pool
             assert self.zm_pool_ok() and stats is not None and stats_mode == 0 and not group_batch and y8 is None and group_fold is None

@@ -113,7 +113,10 @@ class UnetEngine:
             d = sub(d, 4)
             if i < S:
                 d = half(d)
-        split_ok = lambda cu, cs: cu if (256 % (cu // 8) == 0 and cu % 16 == 0 and cs % 16 == 0 and os.environ.get("SP_SPLIT_G")) else None   # measured: two data-gradient launches cost more (+45 us) than the dense reads save -> opt-in
+        # gradient of a concatenated input as two dense tensors: from ONE data-gradient launch where that instance exists (the layer
+        # decides: ConvLayer.split_one); two launches cost more (+45 us) than the dense reads save -> SP_SPLIT_G opt-in only
+        split_ok = lambda cu, cs: cu if (256 % (cu // 8) == 0 and cu % 16 == 0 and cs % 16 == 0 and not hl_or_f8) else None
+        hl_or_f8 = bool(f8)
         for u in range(S + 1, 2 * S):                   # ---- up path: d = output dims of block u-1
             cu, cs, co = bch[u - 2], bch[2 * S - u - 1], bch[u - 1]
             assert cu % 8 == 0, "up-path channel counts must be multiples of 8"

@@ -231,6 +231,30 @@ def test_maxpool_in_the_convolution_epilogue(c, dims, B, hl, monkeypatch):
     torch.testing.assert_close(tb, ta, rtol=1e-5, atol=1e-3 * math.sqrt(n))
 
 
+def test_data_gradient_of_a_concatenating_layer_as_two_dense_tensors(monkeypatch):
+    """sp_conv3d_zm with y2 / split_nt: the 16 -> 48 data gradient (block 5's first convolution, Unet3D.py:71-72) writes its first 32
+    channels (the upsampled half) and its last 16 (the skip half) into two dense tensors from one launch: bit-identical with the
+    channel slices of the one-tensor form"""
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    g = torch.Generator().manual_seed(9)
+    cin, cout, dims, B = 48, 16, (7, 30, 37), 2
+    dz = bf(torch.randn(B, cout, *(d - 2 for d in dims), generator=g))
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    dop = P.conv_dgrad_op(cin, cout, 3, 1, 0, dims, cout, cin, L.SP_BF16)
+    run = O.ConvRunner(dop, DEV, zm_batch=B)
+    assert run.zm_split_ok()
+    run.prep(w.to(DEV))
+    dzs = _to_cl(dz, cout)
+    whole = torch.full((B,) + dims + (cin,), 7.0, dtype=torch.bfloat16, device=DEV)
+    run.run(dzs, whole, B)
+    a = torch.full((B,) + dims + (32,), 7.0, dtype=torch.bfloat16, device=DEV)
+    b = torch.full((B,) + dims + (16,), 7.0, dtype=torch.bfloat16, device=DEV)
+    run.run(dzs, a, B, y2=b, split_nt=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a, whole[..., :32]) and torch.equal(b, whole[..., 32:])
+    torch.testing.assert_close(_from_cl(whole, cin), F.conv_transpose3d(dz, bf(w)), rtol=3e-2, atol=3e-2)
+
+
 def _train_steps(dtype, fuse, monkeypatch, steps=3, dims=(52, 52, 52)):
     import stroke_prediction_amd  # noqa: F401
     from oracle import weights as W
@@ -241,6 +265,7 @@ def _train_steps(dtype, fuse, monkeypatch, steps=3, dims=(52, 52, 52)):
     monkeypatch.setattr(O, "FUSE_BN_FINALIZE", fuse)
     monkeypatch.setattr(O, "FUSE_DZ", fuse)
     monkeypatch.setattr(O, "FUSE_POOL", fuse)
+    monkeypatch.setattr(O, "SPLIT_G", fuse)
     ch = [2, 16, 32, 64, 32, 16, 32, 2]
     x, y = W.unet_inputs(2, dims, 11)
     model = Unet3D(ch, dtype=dtype)
