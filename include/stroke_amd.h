@@ -186,6 +186,11 @@ typedef struct sp_conv_args {
    * the gradient (upsample backward / pool + skip backward) from one launch */
   void* y2;
   int32_t split_nt, CPo2;
+  /* ---- sp_conv3d_zm "plane-serial" forward layers (round 5; 48 -> 16 in the pair mode, 96 -> 32): pser_planes = CPi / 16 > 0 --
+   * the march takes one 16-channel plane per sub-step and streams that plane's weight fragments through LDS; wfrag_hi / _lo in
+   * the order [plane][(dz KS1 + s) NT + n] with KS1 = 5 (the one-plane K table), ktab = the one-plane table
+   * (runtime/plan.py:zm_pser_plan); MT / slots / waves: sp_conv3d_zm_config_ps */
+  int32_t pser_planes, pad2_;
 } sp_conv_args;
 
 int sp_conv3d_igemm(const sp_conv_args* a, sp_stream_t stream);
@@ -224,6 +229,8 @@ int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_t stream);
 /* (input planes P = Cin/16, output tiles NT = Cout/16) -> rows per wave, ring slots and waves per workgroup of the kernel that
  * exists for the pair (a workgroup covers NW*MT x 16 output voxels per plane); returns SP_EINVAL when there is none */
 int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW);
+/* the plane-serial instances (sp_conv_args.pser_planes): NT output tiles, hl = bf16 pairs */
+int sp_conv3d_zm_config_ps(int32_t NT, int32_t hl, int32_t* MT, int32_t* NSLOT, int32_t* NW);
 
 /* ------------------------------------------------------------------ bf16 pairs (SP_HL): the forward pass of the "bf16x3" mode
  * north_star asks for logits within 1e-3 of the CPU reference; bf16 storage (8 significand bits per activation) cannot give

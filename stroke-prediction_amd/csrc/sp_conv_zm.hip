@@ -138,7 +138,14 @@ template <> struct ZmStore<float> {
 // SPLIT (a.y2; the data gradient of a layer whose input is a channel concatenation, Unet3D.py:66-67,71-72): output tiles [0, split_nt)
 // go to y (pitch CPo), the rest to a SECOND dense tensor y2 (pitch CPo2) -- the two consumers of such a gradient (upsample backward,
 // pool / skip backward) then read whole lines instead of 64 / 32 bytes of every 96-byte row, from ONE launch.
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false, bool POOL = false, bool SPLIT = false>
+// PS ("plane-serial", a.pser_planes = PT input planes of 16 channels; round 5): layers whose weight fragments do not fit LDS beside
+// a ring of whole plane SETS (48 -> 16 in the pair mode, 96 -> 32) march through (input z plane, channel plane) SUB-STEPS instead:
+// the ring holds ONE 16-channel plane per slot (the kernel's P is 1), the accumulators of an output plane collect PT sub-steps per
+// input plane, and the weight fragments of one channel plane (3 KS NT KiB, pairs twice that) stream through TWO LDS buffers --
+// the next sub-step's fragments are DMA'd from L2 (every workgroup walks the same PT sets: they stay hot) at the top of a
+// sub-step, before its share of the plane prefetch, so the counted wait of the next sub-step covers them.  Fragment order in
+// memory: [plane p][(dz KS + s) NT + n] (runtime/plan.py:zm_pser_plan).
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, typename TOUT, bool Q8 = false, bool HL = false, bool POOL = false, bool SPLIT = false, bool PS = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmDev Q) {
   constexpr int WPS = NW / 4;
   constexpr int KS = (18 * P + 3) / 4;            // in-plane K steps (32 channels-taps each)
@@ -152,6 +159,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int S = NJ * NW * 1024;               // slot stride in bytes
   constexpr int WOFF = NSLOT * S + NW * 1024;     // LDS offset of the weight fragments (WLDS), behind the ring and the dump area
   constexpr int D = NSLOT - 1;                    // prefetch distance in planes
+  static_assert(!PS || (P == 1 && WLDS && !Q8 && !POOL && !SPLIT && STATS <= 1 && ACT == 1 && (NSLOT == 2 || NSLOT == 3)), "plane-serial instances: forward layers, weights streamed through LDS");
   static_assert(!SPLIT || (ACT == 0 && STATS == 0 && !Q8 && !HL && !POOL && NT >= 2 && sizeof(TOUT) == 2), "split output: plain 16-bit data gradients of two or more output tiles");
   static_assert(!POOL || (ACT == 1 && STATS == 1 && !Q8 && MT % 2 == 0 && sizeof(TOUT) == 2), "pooling epilogue: forward layers with statistics, 16-bit output, row pairs inside a wave");
   constexpr int NSP = POOL ? (MT / 2) * NT * (HL ? 2 : 1) : 0;      // pooled stores of one epilogue (issued every step: the hold steps' are dropped)
@@ -164,7 +172,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   // PB (the ELU instances: the CAE's padded layers): the bias comes from a table in LDS indexed by the output voxel's border class
   // (sp_conv_args.bias_tab: BatchNorm folded per group into a padded convolution); without a table its one entry is the plain bias
   constexpr bool PB = ACT == 2;
-  constexpr int BTOFF = WOFF + (WLDS ? (HL ? 2 : 1) * NWF * 1024 : 0);
+  constexpr int WB = (HL ? 2 : 1) * NWF * 1024;      // bytes of one set of weight fragments in LDS (PS: two such buffers)
+  constexpr int NJW = PS ? (((HL ? 2 : 1) * NWF + NW - 1) / NW) : 0;      // PS: weight DMA instructions per wave and sub-step
+  constexpr bool PSPIPE = PS && !HL && NT == 1;      // PS: double-buffered fragment reads (the other instances spill with them)
+  constexpr int BTOFF = WOFF + (WLDS ? (PS ? 2 : 1) * WB : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = Q.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,11 +418,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     unsigned char* pl_dst0 = nullptr;
     int pl_mask = 0;
     bool pl_fill = false;                                     // filler DMAs (zero page -> dump area) beyond the last plane
-    auto plane_begin = [&](int i, int slot) {
+    const int64_t ps_plane = a.x_plane ? a.x_plane * 2 : 32;      // PS: bytes from channel plane p to p + 1 (plane-major / channels-last)
+    auto plane_begin = [&](int i, int slot, int pch = 0) {
       const int iz = z0 + a.o0D + i;
       pl_mask = ((unsigned)iz < (unsigned)a.Di) ? vmask : 0;
-      pl_src0 = xin + (((int64_t)iz * a.Hi + iy0) * a.Wi + ix0) * (int64_t)(xpitch * 2);
+      pl_src0 = xin + (PS ? (int64_t)pch * ps_plane : (int64_t)0) + (((int64_t)iz * a.Hi + iy0) * a.Wi + ix0) * (int64_t)(xpitch * 2);
       pl_dst0 = ring + slot * S + wave * 1024;
+    };
+    // PS: the fragments of channel plane pch into weight buffer `buf` (pch < 0: fillers only): NJW instructions in every wave
+    const unsigned char* const wfb = reinterpret_cast<const unsigned char*>(a.wfrag_hi);
+    const unsigned char* const wflb = reinterpret_cast<const unsigned char*>(a.wfrag_lo);
+    auto w_dma = [&](int pch, int buf, bool inloop) {
+#pragma unroll
+      for (int k = 0; k < NJW; ++k) {
+        const int f = wave + NW * k;
+        const bool ok = pch >= 0 && f < (HL ? 2 : 1) * NWF;
+        const unsigned char* src = !ok ? zsrc : ((HL && f >= NWF) ? wflb + ((size_t)pch * NWF + (f - NWF)) * 1024 + lane * 16 : wfb + ((size_t)pch * NWF + f) * 1024 + lane * 16);
+        unsigned char* dst = ok ? lds + WOFF + buf * WB + f * 1024 : ring + NSLOT * S + wave * 1024;
+        if (inloop) sp_dma16_nc(src, dst); else sp_dma16(src, dst);
+      }
     };
     auto plane_dma = [&](int j, bool inloop) {
       const unsigned char* src = ((pl_mask >> j) & 1) ? pl_src0 + rel[j] + (HL && ((lom >> j) & 1) ? lod : (int64_t)0) : zsrc;      // padding / overhang: the zero page
@@ -512,10 +537,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     // of a plane (dz = 0, K step 0) takes a zero C operand.
     f32x4 acc[4][NT][MT];
 
+    const int PT = PS ? a.pser_planes : 1;                    // channel planes per input z plane (PS)
     ZM_SYNC(0);                                               // the previous piece has been consumed
+    if constexpr (PS) {
 #pragma unroll
-    for (int k = 0; k < NSLOT - 1; ++k)
-      if (k < nin) load_plane(k, k);
+      for (int k = 0; k < NSLOT - 1; ++k) {                   // sub-steps 0 .. D-1: (input plane k / PT, channel plane k % PT)
+        const int ik = k / PT, pk = k - ik * PT;
+        if (ik < nin) {
+          plane_begin(ik, k, pk);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) plane_dma(j, false);
+        }
+      }
+      w_dma(0, 0, false);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NSLOT - 1; ++k)
+        if (k < nin) load_plane(k, k);
+    }
 
     // epilogue of the plane held by accumulator set R: straight-line code (no branch); fz < 0 (no finished plane) turns
     // every store into an out-of-range one and every statistics term into 0 -- the instruction count never changes
@@ -646,6 +685,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
             if constexpr (HL) dstl[dz][n] = *reinterpret_cast<const bf16x8*>(wl + (NWF + (dz * KS + (s_)) * NT + n) * 1024); \
         }                                                                                                         \
   }
+#define ZM_LDW_B(dst, dstl, s_, wb_)                                                                              \
+  {                                                                                                               \
+    _Pragma("unroll") for (int dz = 0; dz < 3; ++dz)                                                              \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) {                                                          \
+            dst[dz][n] = *reinterpret_cast<const bf16x8*>((wb_) + ((dz * KS + (s_)) * NT + n) * 1024);            \
+            if constexpr (HL) dstl[dz][n] = *reinterpret_cast<const bf16x8*>((wb_) + (NWF + (dz * KS + (s_)) * NT + n) * 1024); \
+        }                                                                                                         \
+  }
 #define ZM_DMA(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KS; j < (((s_) + 1) * NJ) / KS; ++j) plane_dma(j, true);
 #define ZM_W(DZ_, s_, n_, wv) (WLDS ? wv[DZ_][n_] : w[WLDS ? 0 : DZ_][WLDS ? 0 : s_][WLDS ? 0 : n_])
     // HL: the two cross terms follow the hi x hi product into the same accumulator
@@ -738,8 +785,85 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     islot = islot + 1 == NSLOT ? 0 : islot + 1;                                                                   \
   }
 
+    // PS: one step = PT sub-steps (channel planes) of input plane i; the accumulator roles are those of ZM_STEP.  Sub-step t:
+    // its plane (issued D sub-steps ago) and its weights (issued at the top of sub-step t - 1, BEFORE that sub-step's plane
+    // DMAs and stores) have landed once all but the youngest NJ + NS operations are done; every sub-step issues exactly NJW + NJ
+    // + NS operations (fillers / dropped stores where there is nothing to do), so the count holds from sub-step D on.
+#define ZM_STEP_PS(PH)                                                                                            \
+  {                                                                                                               \
+    const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
+    const int fz = (i >= 3 && i - 3 < nz) ? z0 + i - 3 : -1;                                                      \
+    const int npl = i < nin ? PT : 1;      /* (the step behind the last plane carries an epilogue only) */        \
+    for (int pc = 0; pc < npl; ++pc) {                                                                            \
+      if (D >= 2 && tsub >= D) ZM_SYNC(NJ + NS);                                                                  \
+      else ZM_SYNC(0);                                                                                            \
+      {      /* the next sub-step's weights first ... */                                                         \
+        int pn = pc + 1, in_ = i;                                                                                 \
+        if (pn >= PT) { pn = 0; ++in_; }                                                                          \
+        w_dma(in_ < nin ? pn : -1, wbuf ^ 1, false);      /* (with the memory clobber: the epilogue's stores -- whose data are */ \
+                                                          /* ready at the top of the sub-step -- must not be hoisted above them)  */ \
+      }                                                                                                           \
+      {      /* ... then the plane D sub-steps ahead, piecewise between the MFMAs below */                       \
+        int pa = pc + D, ia = i;                                                                                  \
+        while (pa >= PT) { pa -= PT; ++ia; }                                                                      \
+        pl_fill = false;                                                                                          \
+        if (ia < nin) plane_begin(ia, (tslot + D) % NSLOT, pa);                                                   \
+        else { pl_mask = 0; pl_fill = true; pl_dst0 = ring + NSLOT * S + wave * 1024; }                           \
+      }                                                                                                           \
+      const unsigned char* sb = ring + tslot * S;                                                                 \
+      const unsigned char* wlb = wl + wbuf * WB;                                                                  \
+      if (pc == 0) {      /* first contribution to output plane i */                                             \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                            \
+          _Pragma("unroll") for (int m = 0; m < MT; ++m) acc[PH][n][m] = f32x4{0.f, 0.f, 0.f, 0.f};               \
+      }                                                                                                           \
+      bf16x8 x0[MT], x1[MT], x0l[HL ? MT : 1], x1l[HL ? MT : 1];                                                  \
+      bf16x8 wa[3][NT], wb[3][NT], wal[HL ? 3 : 1][HL ? NT : 1], wbl[HL ? 3 : 1][HL ? NT : 1];                    \
+      /* the epilogue of plane i - 3 rides in the first sub-step; the others issue as many dropped stores (counted waits) */ \
+      const zm_u32x2 zz_ = {0u, 0u};                                                                              \
+      if (PSPIPE && v0 && v1 && v2) {      /* fragment reads of K step s + 1 in flight under the MFMAs of step s, as ZM_STEP's fast path */ \
+        if (pc == 0) { ZM_EPILOGUE((PH + 1) % 4, fz, 0, false) }                                                  \
+        else { _Pragma("unroll") for (int k = 0; k < NS; ++k) __builtin_amdgcn_raw_buffer_store_b64(zz_, yrs, 0x80000000u, 0, 0); } \
+        ZM_LDX(x0, x0l, 0)                                                                                        \
+        ZM_LDW_B(wa, wal, 0, wlb)                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                          \
+          if (s + 1 < KS) { if ((s & 1) == 0) { ZM_LDX(x1, x1l, s + 1) ZM_LDW_B(wb, wbl, s + 1, wlb) } else { ZM_LDX(x0, x0l, s + 1) ZM_LDW_B(wa, wal, s + 1, wlb) } } \
+          if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) ZM_MMA(PH, 0, s, x0, x0l, wa, wal) } \
+          else { ZM_MMA((PH + 2) % 4, 2, s, x1, x1l, wb, wbl) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x1, x1l, wb, wbl) ZM_MMA(PH, 0, s, x1, x1l, wb, wbl) } \
+        }                                                                                                         \
+      } else {                                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                          \
+          ZM_LDX(x0, x0l, s)                                                                                      \
+          ZM_LDW_B(wa, wal, s, wlb)                                                                               \
+          ZM_DMA(s)                                                                                               \
+          if (v2) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) }                                                \
+          if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) }                                                \
+          if (v0) { ZM_MMA(PH, 0, s, x0, x0l, wa, wal) }                                                          \
+        }                                                                                                         \
+        if (pc == 0) { ZM_EPILOGUE((PH + 1) % 4, fz, 0, false) }                                                  \
+        else { _Pragma("unroll") for (int k = 0; k < NS; ++k) __builtin_amdgcn_raw_buffer_store_b64(zz_, yrs, 0x80000000u, 0, 0); } \
+      }                                                                                                           \
+      ++tsub;                                                                                                     \
+      tslot = tslot + 1 == NSLOT ? 0 : tslot + 1;                                                                 \
+      wbuf ^= 1;                                                                                                  \
+    }                                                                                                             \
+    ++i;                                                                                                          \
+  }
+
     // steps 0 .. nin: the last one (no input plane left: all groups off) only carries the epilogue of the last output plane
     int i = 0, islot = 0;
+    int tsub = 0, tslot = 0, wbuf = 0;      // PS: sub-step counter, its ring slot and weight buffer
+    if constexpr (PS) {
+      while (true) {
+        ZM_STEP_PS(0)
+        if (i > nin) break;
+        ZM_STEP_PS(1)
+        if (i > nin) break;
+        ZM_STEP_PS(2)
+        if (i > nin) break;
+        ZM_STEP_PS(3)
+        if (i > nin) break;
+      }
+    } else
     while (true) {
       ZM_STEP(0)
       if (i > nin) break;
@@ -750,6 +874,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       ZM_STEP(3)
       if (i > nin) break;
     }
+#undef ZM_STEP_PS
+#undef ZM_LDW_B
 #undef ZM_STEP
 #undef ZM_MMA_D0
 #undef ZM_MMA0
@@ -779,7 +905,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   }
 }
 
-template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false, bool POOL = false, bool SPLIT = false>
+template <int P, int NT, int MT, int NSLOT, bool WLDS, int NW, int STATS, int ACT, bool HL = false, bool POOL = false, bool SPLIT = false, bool PS = false>
 static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   constexpr int KS = (18 * P + 3) / 4;
   constexpr int NCH = (HL ? 2 : 1) * P * (NW * MT + 2) * 18 * 2;
@@ -787,7 +913,7 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
   constexpr int S = NJ * NW * 1024;
   // ring (+ 1 KiB per wave where the counted-wait filler DMAs land) (+ the weight fragments; pairs: hi and lo)
   // (+ the bias table of the ELU instances: at most 75 border classes)
-  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? (HL ? 2 : 1) * 3 * KS * NT * 1024 : 0) + (ACT == 2 ? 75 * NT * 64 : 0);
+  constexpr int lds_bytes = NSLOT * S + NW * 1024 + (WLDS ? (PS ? 2 : 1) * (HL ? 2 : 1) * 3 * KS * NT * 1024 : 0) + (ACT == 2 ? 75 * NT * 64 : 0);
   static_assert(lds_bytes <= 160 * 1024, "ring + weights do not fit LDS");
   ConvZmDev Q;
   Q.a = *a;
@@ -813,7 +939,11 @@ static int launch_zm2(const sp_conv_args* a, const void* zeros, hipStream_t st) 
     grid = 8u * (unsigned)a->nslices * (32u / (unsigned)a->nslices);
     SP_CHECK_ARG(planes >= (uint64_t)grid / a->nslices, "sp_conv3d_zm: too few (column, plane) pairs for %d slices in one launch", a->nslices);
   }
-  if constexpr (SPLIT) {
+  if constexpr (PS) {
+    auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, HL, false, false, true>;
+    SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
+  } else if constexpr (SPLIT) {
     auto kern = conv_zm3_kernel<P, NT, MT, NSLOT, WLDS, NW, STATS, ACT, bf16_t, false, false, false, true>;
     SP_ENSURE_LDS(kern, lds_bytes, "sp_conv3d_zm");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds_bytes, st, Q);
@@ -938,6 +1068,24 @@ extern "C" int sp_conv3d_zm_config_hl(int32_t P, int32_t NT, int32_t* MT, int32_
   return mt ? SP_OK : SP_EINVAL;
 }
 
+// plane-serial instances (sp_conv_args.pser_planes > 0): output tiles NT, bf16 or bf16 pairs -> (MT, NSLOT, NW); runtime/plan.py
+// (ZM_CONFIGS_PS) must agree (tests/test_cabi.py)
+extern "C" int sp_conv3d_zm_config_ps(int32_t NT, int32_t hl, int32_t* MT, int32_t* NSLOT, int32_t* NW) {
+  int mt = 0, ns = 3, nw = 8;
+  if (!hl && NT == 1) mt = 4;                      // 110 KiB: ring 3 x 24, weight buffers 2 x 15
+  else if (!hl && NT == 2) mt = 2;                 // 116 KiB: ring 3 x 16, weight buffers 2 x 30
+  else if (hl && NT == 1) { mt = 4; ns = 2; }      // 148 KiB: ring 2 x 40, weight buffers 2 x 30
+  if (MT) *MT = mt;
+  if (NSLOT) *NSLOT = ns;
+  if (NW) *NW = nw;
+  return mt ? SP_OK : SP_EINVAL;
+}
+template <int NT, int MT, int NSLOT, bool HL>
+static int launch_zm_ps(const sp_conv_args* a, const void* zeros, hipStream_t st) {
+  if (a->stats) return launch_zm2<1, NT, MT, NSLOT, true, 8, 1, 1, HL, false, false, true>(a, zeros, st);
+  return launch_zm2<1, NT, MT, NSLOT, true, 8, 0, 1, HL, false, false, true>(a, zeros, st);
+}
+
 template <int P, int NT, int MT, int NSLOT, int NW>
 static int launch_zm_hl(const sp_conv_args* a, const void* zeros, hipStream_t st) {
   if (a->pool_y) {      // MaxPool3d(2) of the pair values in the epilogue
@@ -998,12 +1146,21 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
                "sp_conv3d_zm: y8 needs a dense bf16 output, a positive y8_scale and y8_plane >= one plane of the output");
   const int P = a->CPi / 16;
   SP_CHECK_ARG(hl || a->dtype_out != SP_HL, "sp_conv3d_zm: a bf16 pair output needs a bf16 pair input");
+  SP_CHECK_ARG(a->pser_planes == 0 || (a->pser_planes == P && P >= 2 && (a->act == SP_ACT_LEAKY || a->act == SP_ACT_NONE) && !a->y8 && !a->y2 && !a->pool_y && a->stats_mode == 0 &&
+                                       a->nslices <= 1 && a->group_batch == 0 && !a->bias_tab && a->dtype_out != SP_F32),
+               "sp_conv3d_zm: pser_planes (plane-serial march) = CPi / 16 >= 2, bias / LeakyReLU / identity epilogue");
   // every byte offset the kernel forms must fit 32 bits (per-sample base is 64-bit)
   const uint64_t span = a->x_plane ? (uint64_t)P * (uint64_t)a->x_plane * 2 : (uint64_t)a->Di * a->Hi * a->Wi * a->CPi * 2;
   SP_CHECK_ARG(span < (1ull << 31), "sp_conv3d_zm: input too large for 32-bit offsets");
   SP_CHECK_ARG((uint64_t)a->YD * a->YH * a->YW * a->CPo * 4 < (1ull << 31), "sp_conv3d_zm: output sample too large for a buffer descriptor");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   int32_t mt = 0, ns = 0, nw = 0;
+  if (a->pser_planes > 0) {
+    SP_CHECK_ARG(sp_conv3d_zm_config_ps(a->NT, hl ? 1 : 0, &mt, &ns, &nw) == SP_OK && mt == a->MT, "sp_conv3d_zm: no plane-serial kernel for NT=%d MT=%d (%s)", a->NT, a->MT, hl ? "pairs" : "bf16");
+    if (hl) return launch_zm_ps<1, 4, 2, true>(a, zeros, st);
+    if (a->NT == 1) return launch_zm_ps<1, 4, 3, false>(a, zeros, st);
+    return launch_zm_ps<2, 2, 3, false>(a, zeros, st);
+  }
   if (hl) {
     SP_CHECK_ARG(sp_conv3d_zm_config_hl(P, a->NT, &mt, &ns, &nw) == SP_OK && mt == a->MT, "sp_conv3d_zm: no bf16-pair kernel for P=%d NT=%d MT=%d", P, a->NT, a->MT);
     if (P == 1 && a->NT == 1) return launch_zm_hl<1, 1, 4, 3, 8>(a, zeros, st);

@@ -53,7 +53,7 @@ class ConvArgs(C.Structure):
                                                                            ("group_batch", i32), ("nslices", i32),
                                                                           ("slice_wfrag_stride", i64), ("x_lo_delta", i64), ("y_lo_delta", i64),
                                                                           ("bias_tab", vp), ("bias_tab_gstride", i32), ("pad_", i32), ("wfrag_gstride", i64),
-                                                                          ("bnb", BnBwdArgs), ("dz_sums", vp), ("pool_y", vp), ("pool_lo_delta", i64), ("y2", vp), ("split_nt", i32), ("CPo2", i32)]
+                                                                          ("bnb", BnBwdArgs), ("dz_sums", vp), ("pool_y", vp), ("pool_lo_delta", i64), ("y2", vp), ("split_nt", i32), ("CPo2", i32), ("pser_planes", i32), ("pad2_", i32)]
 
 
 class WgradArgs(C.Structure):
@@ -127,6 +127,7 @@ _SIGS = {
     "sp_conv3d_zm": ([C.POINTER(ConvArgs), vp, vp], i32),
     "sp_conv3d_zm_config": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
     "sp_conv3d_zm_config_hl": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
+    "sp_conv3d_zm_config_ps": ([i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)], i32),
     "sp_bn_stats_ncdhw_f32": ([vp, i32, i32, i64, i32, vp, i32, vp], i32),
     "sp_first_prep_hl": ([vp, vp, vp, vp, vp, vp, vp, i32, vp], i32),
     "sp_first_conv_fwd_hl": ([vp, i32, i32, i32, i32, vp, vp, vp, i32, f32, vp, vp, vp, i32, i32, vp], i32),

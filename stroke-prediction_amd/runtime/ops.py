@@ -34,6 +34,7 @@ def bump_param_epoch():
 
 FUSE_BN_FINALIZE = bool(int(os.environ.get("SP_FUSE_BN_FINALIZE", "1")))   # sp_bn_finalize inside the weight re-pack kernel of the folded layers (one launch less per layer)
 SPLIT_G = bool(int(os.environ.get("SP_SPLIT_G1", "1")))   # one-launch split of a concatenating layer's data gradient into two dense tensors (ConvRunner.zm_split_ok)
+HL_PSER_SLICES = bool(int(os.environ.get("SP_HL_PSER_SLICES", "0")))   # pair mode: 96 -> 32 as two plane-serial launches of 16 output channels -- measured: 2 x 134 us against 275 us on the tiled kernel, no gain (off)
 FUSE_POOL = bool(int(os.environ.get("SP_FUSE_POOL", "1")))   # MaxPool3d(2) in the epilogue of the down blocks' second convolution (training steps)
 FUSE_DZ = bool(int(os.environ.get("SP_FUSE_DZ", "1")))   # the second convolution's data gradient writes the first one's dz (BatchNorm / activation backward in its epilogue)
 BN_SUMS_FROM_WGRAD = not os.environ.get("SP_BN_SUMS_DGRAD")   # BatchNorm-backward sums from the weight-gradient accumulator (layers.py)
@@ -205,7 +206,7 @@ class ConvRunner:
 
     def zm_y8_ok(self):
         """the z-marching instance of this runner can also write the e4m3 plane-major copy of its output (run(y8=...))"""
-        return bool(self.uses_zm() and self.zms is None and self.zm["P"] == 1 and self.zm["NT"] == 2)
+        return bool(self.uses_zm() and self.zms is None and self.zm["P"] == 1 and self.zm["NT"] == 2 and not self.zm.get("pser"))
 
     def _run_zm(self, a, x_planar, batch, with_stats, st):
         return _run_zm_impl(self, a, x_planar, batch, with_stats, st)
@@ -238,6 +239,12 @@ class ConvRunner:
                 subs.append(d)
             st["subs"] = subs
             zm = P.zm_plan(op, tile=zm_tile) if (USE_ZM and USE_DMA and zm_batch) else None
+            # plane-serial march (round 5): ops with more input planes than a whole-set ring holds (96 -> 32), and the (P, NT) pairs
+            # measured faster there (plan.ZM_PSER_PREFER)
+            if USE_ZM and USE_DMA and zm_batch and (zm is None or P.ZM_PSER_ALL or (op.cpi // 16, -(-op.cout // 16), op.dtype) in P.ZM_PSER_PREFER):
+                zp = P.zm_pser_plan(op, tile=zm_tile)
+                if zp is not None:
+                    zm = zp
             if zm is not None:
                 cols = -(-op.subs[0].out_dims[1] // zm["TH"]) * -(-op.subs[0].out_dims[2] // zm["TW"])
                 if zm_batch * cols * op.subs[0].out_dims[0] < ZM_MIN_PLANES:
@@ -271,6 +278,17 @@ class ConvRunner:
                         hi = pool[i * frag:(i + 1) * frag] if fuse_m else torch.empty(z["nsteps"] * z["NT"] * 64 * 8, dtype=torch.bfloat16, device=device)
                         zms.append(dict(z, c0=c0, cn=cn, ktab_d=_dev_i32(z["ktab"], device), kmap_d=_dev_i32(z["kmap"], device), hi=hi,
                                         fuse_m=fuse_m, wstride=frag * 2))
+            # ... and bf16-PAIR ops past the plane-serial pair instance's one output tile: a plane-serial launch per 16 output channels
+            if zm is None and zms is None and USE_ZM and USE_DMA and zm_batch and USE_ZM_SLICES and op.dtype == L.SP_HL and HL_PSER_SLICES:
+                sl = P.zm_pser_slices(op)
+                if sl:
+                    zms = []
+                    for c0, cn, sub_op in sl:
+                        z = P.zm_pser_plan(sub_op, tile=zm_tile)
+                        n = z["nsteps"] * z["NT"] * 64 * 8
+                        zms.append(dict(z, c0=c0, cn=cn, ktab_d=_dev_i32(z["ktab"], device), kmap_d=_dev_i32(z["kmap"], device),
+                                        hi=torch.empty(n, dtype=torch.bfloat16, device=device), lo=torch.empty(n, dtype=torch.bfloat16, device=device),
+                                        fuse_m=0, wstride=0))
             st["zms"] = zms
             fc = P.fc_plan(op) if (USE_FC and zm is None and zms is None and op.dtype != L.SP_HL) else None
             if fc is not None:      # split-K kernel for FC-like layers: its own (tap-major) K order and fragments
@@ -326,7 +344,7 @@ class ConvRunner:
     @staticmethod
     def zm_plan_bn_bwd_ok(z):
         """the z-marching instance of plan z exists with the BatchNorm-backward-sums epilogue (stats_mode 1: sum g, sum g x)"""
-        return bool(z is not None and z["NW"] == 8 and z["P"] <= 2 and z["MT"] * z["NT"] == 4 and z["nslot"] == 3)
+        return bool(z is not None and not z.get("pser") and z["NW"] == 8 and z["P"] <= 2 and z["MT"] * z["NT"] == 4 and z["nslot"] == 3)
 
     def par_ok(self, dtype_out):
         """csrc/sp_conv_par.hip runs this op (all parity classes / the strided convolution in one pass; its epilogue takes
@@ -337,7 +355,7 @@ class ConvRunner:
         """run(pool=...) applies: a z-marching instance with the MaxPool3d(2) epilogue ((P, NT) = (1, 1) / (2, 2), rows in pairs per
         wave, the classic 16-voxel-wide tile) -- the second convolutions of the down blocks"""
         z = self.zm
-        return bool(FUSE_POOL and z is not None and self.zms is None and (z["P"], z["NT"]) in ((1, 1), (2, 2)) and z["MT"] % 2 == 0
+        return bool(FUSE_POOL and z is not None and self.zms is None and not z.get("pser") and (z["P"], z["NT"]) in ((1, 1), (2, 2)) and z["MT"] % 2 == 0
                     and (z["NW"] == 8 or self.op.dtype == L.SP_HL) and z["TW"] == 16 and z["TH"] == z["NW"] * z["MT"]
                     and min(self.op.y_dims) >= 2 and tuple(self.op.subs[0].out_dims) == tuple(self.op.y_dims))
 
@@ -345,7 +363,7 @@ class ConvRunner:
         """run(y2=..., split_nt=...) applies: the z-marching instance with two output tensors ((P, NT) = (1, 3): 16 -> 48, the data
         gradient of the 3-scale network's last concatenating layer)"""
         z = self.zm
-        return bool(SPLIT_G and z is not None and self.zms is None and self.op.dtype == L.SP_BF16 and (z["P"], z["NT"]) == (1, 3) and z["NW"] == 8
+        return bool(SPLIT_G and z is not None and self.zms is None and not z.get("pser") and self.op.dtype == L.SP_BF16 and (z["P"], z["NT"]) == (1, 3) and z["NW"] == 8
                     and tuple(self.op.subs[0].out_dims) == tuple(self.op.y_dims))
 
     def zm_bn_bwd_ok(self):
@@ -356,7 +374,7 @@ class ConvRunner:
         will run this op read; all but the output-channel slices of the z-marching kernel cover the whole op"""
         cout = self.op.cout
         if self.zms is not None:
-            return [(z["kmap_d"], z["nsteps"], z["hi"], None, z["NT"], z["c0"], z["cn"]) for z in self.zms]
+            return [(z["kmap_d"], z["nsteps"], z["hi"], z.get("lo"), z["NT"], z["c0"], z["cn"]) for z in self.zms]
         if self.uses_zm():
             z = self.zm
             return [(z["kmap_d"], z["nsteps"], z["hi"], z.get("lo"), z["NT"], 0, cout)]
@@ -603,6 +621,8 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
         a.bias = (runner.bias.data_ptr() + 4 * z["c0"]) if (runner.has_bias and use_bias) else None
         a.stats = None if stats is None else stats.data_ptr() + 16 * z["c0"]
     a.wfrag_hi, a.wfrag_lo, a.ktab = ptr(z["hi"] if wfrag is None else wfrag), ptr(z.get("lo")), ptr(z["ktab_d"])
+    if sliced and op.dtype == L.SP_HL:      # (pairs: the lo halves sit at the same delta behind the slice's channels)
+        pass
     if wfrag is not None:
         a.bias = None
     a.Do, a.Ho, a.Wo = sub.out_dims
@@ -614,6 +634,7 @@ def _run_zm_impl(runner, a, x_planar, batch, with_stats, st, z=None, y=None, sta
     a.Cout = z["NT"] * 16            # whole tiles: channels past op.cout have zero weights and bias
     a.dma, a.persist, a.zfill = 1, 5, 0
     a.octs_per_group, a.ngroups, a.opp, a.vsb = 2 * z["P"], 1, 2, 32
+    a.pser_planes = z.get("PT", 0) if z.get("pser") else 0
     a.x_plane = (batch * int(np.prod(op.in_dims)) * 16) if x_planar else 0
     m = z.get("fuse_m", 0) if sliced else 0
     a.nslices, a.slice_wfrag_stride = (m, z["wstride"]) if m else (0, 0)

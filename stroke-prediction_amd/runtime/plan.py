@@ -455,6 +455,55 @@ def zm_plan(op: ConvOp, tile=None):
     return dict(P=P_, NT=NT, MT=MT, NW=nw, TH=th, TW=tw, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=3 * ks)
 
 
+# ------------------------------------------------------------------------------------------------ plane-serial z-marching plan
+# csrc/sp_conv_zm.hip, PS instances (round 5): (output tiles NT, bf16 pairs?) -> (MT rows per wave, ring slots, waves).  Mirrors
+# sp_conv3d_zm_config_ps (tests/test_cabi.py).  The march takes ONE 16-channel plane per sub-step and streams that plane's weight
+# fragments through two LDS buffers, so the number of input planes is not limited by LDS.
+ZM_CONFIGS_PS = {(1, False): (4, 3, 8), (2, False): (2, 3, 8), (1, True): (4, 2, 8)}
+# (P, NT, dtype) with a plain z-marching instance that nevertheless run plane-serial (measured faster); SP_ZM_PSER="" turns all off,
+# "all" routes every op with a PS instance there
+_ps_env = os.environ.get("SP_ZM_PSER", "3,1,2")      # (bf16 48 -> 16 measured SLOWER plane-serial: 60-MFMA sub-steps are too short for their barrier)
+ZM_PSER_PREFER = {tuple(int(v) for v in it.split(",")) for it in _ps_env.split(";") if it and it != "all"}
+ZM_PSER_ALL = _ps_env == "all"
+ZM_PSER_ON = _ps_env != ""
+
+
+def zm_pser_plan(op: ConvOp, tile=None):
+    """K tables of the plane-serial z-march for a stride-1 3x3x3 op of two or more 16-channel input planes, or None:
+      ktab[s*4 + g]                          byte offset of the octet inside a ONE-plane ring slot: (dy*(TW + 2) + dx)*32 + o*16
+      kmap[((p*3 + dz)*KS + s)*4 + g]        (source tap << 16) | input octet of channel plane p, -1 for the padding octets
+    (KS = 5 steps of four octets cover the 18 in-plane octets of one plane; fragments in memory: [p][(dz KS + s) NT + n])"""
+    if not ZM_PSER_ON or op.dtype not in (0, 2) or tuple(op.stride) != (1, 1, 1) or len(op.subs) != 1:
+        return None
+    sub = op.subs[0]
+    if len(sub.taps) != 27 or tuple(sub.ext) != (3, 3, 3) or tuple(sub.out_stride) != (1, 1, 1) or tuple(sub.out_off) != (0, 0, 0):
+        return None
+    PT, NT = op.cpi // 16, -(-op.cout // 16)
+    hl = op.dtype == 2
+    if op.cpi % 16 or op.cpo % 16 or op.cin > op.cpi or op.cpo < NT * 16 or PT < 2 or (NT, hl) not in ZM_CONFIGS_PS:
+        return None
+    MT, nslot, nw = ZM_CONFIGS_PS[(NT, hl)]
+    ith = nw * MT + 2
+    if tile == "classic":
+        tile = (16, nw * MT)
+    tw, th = tile if tile is not None else zm_tile(sub.out_dims[1], sub.out_dims[2], nw, MT)
+    assert tw * th <= 16 * nw * MT and (tw + 2) * (th + 2) <= ith * ZM_ITW
+    ks = 5
+    src = {(t[0], t[1], t[2]): t[3] for t in sub.taps}
+    ktab = np.zeros(ks * 4, dtype=np.int32)
+    kmap = np.full(PT * 3 * ks * 4, -1, dtype=np.int32)
+    for e in range(18):
+        t2d, o = divmod(e, 2)
+        dy, dx = divmod(t2d, 3)
+        ktab[e] = (dy * (tw + 2) + dx) * 32 + o * 16
+        for p in range(PT):
+            for dz in range(3):
+                kmap[((p * 3 + dz) * ks) * 4 + e] = (src[(dz, dy, dx)] << 16) | (p * 2 + o)
+    for e in range(18, ks * 4):
+        ktab[e] = ktab[e - 2]                # zero-weight padding octets: any valid, conflict-free address
+    return dict(P=1, PT=PT, NT=NT, MT=MT, NW=nw, TH=th, TW=tw, nslot=nslot, KS=ks, ITH=ith, ktab=ktab, kmap=kmap, nsteps=PT * 3 * ks, pser=True)
+
+
 # ------------------------------------------------------------------------------------------------ fp8 z-marching plan
 # csrc/sp_conv_zm8.hip: (P planes of 16 fp8 input channels, NT output tiles) -> (MT rows per wave, ring slots, waves).
 # Mirrors sp_conv3d_zm8_config (tests/test_cabi.py).
@@ -549,6 +598,22 @@ def fc_plan(op: ConvOp):
             kmap[ti * spt * 4 + o] = (t[3] << 16) | o
     taps = np.array([[t[0], t[1], t[2]] for t in sub.taps], dtype=np.int32)
     return dict(ntap=ntap, spt=spt, nsteps=ntap * spt, NT=-(-op.cout // 16), kmap=kmap, taps=taps, pointwise=False)
+
+
+def zm_pser_slices(op: ConvOp):
+    """[(c0, cn, sub-op)]: a bf16-PAIR op with two or more input planes and more output tiles than the plane-serial pair instance
+    holds (96 -> 32 of the pair mode: the tiled kernel takes 2.7 x its bf16 time there) as one plane-serial launch per 16 output
+    channels, every launch reading the input again; None when the op is not a candidate"""
+    import dataclasses
+    if not ZM_PSER_ON or op.dtype != 2 or op.cout % 16 or op.cpi % 16 or op.cpi // 16 < 2 or op.cout // 16 < 2 or zm_pser_plan(op) is not None:
+        return None
+    out = []
+    for c0 in range(0, op.cout, 16):
+        sub_op = dataclasses.replace(op, cout=16)
+        if zm_pser_plan(sub_op) is None:
+            return None
+        out.append((c0, 16, sub_op))
+    return out
 
 
 def zm_slices(op: ConvOp):

@@ -48,6 +48,21 @@ def test_zm_config_matches_the_planner():
                 assert rc != 0, (p, nt)
 
 
+def test_plane_serial_config_matches_the_planner():
+    """sp_conv3d_zm_config_ps (plane-serial instances, round 5) and plan.ZM_CONFIGS_PS agree"""
+    import ctypes as C
+    from stroke_prediction_amd.runtime import plan as P
+    lib = L.load()
+    for nt in range(1, 5):
+        for hl in (0, 1):
+            mt, ns, nw = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            rc = lib.sp_conv3d_zm_config_ps(nt, hl, C.byref(mt), C.byref(ns), C.byref(nw))
+            if (nt, bool(hl)) in P.ZM_CONFIGS_PS:
+                assert rc == 0 and (mt.value, ns.value, nw.value) == P.ZM_CONFIGS_PS[(nt, bool(hl))], (nt, hl)
+            else:
+                assert rc != 0, (nt, hl)
+
+
 def test_conv3d_plan_tables_match_the_planner():
     """sp_conv3d_plan / sp_conv3d_tables (the header-only caller's route to the z-marching kernel) build the same K tables
     as runtime/plan.py:zm_plan does for the Python host side, forward and data gradient (pure host code: no GPU)"""

@@ -500,3 +500,58 @@ def test_header_only_padded_and_transposed_layers(kind, cin, cout, pad):
         s1 = torch.ones(cin, device=DEV)
         assert lib.sp_conv3d_set_weights(C.byref(d), C.byref(pl), ws.data_ptr(), w.to(DEV).data_ptr(), None, s1.data_ptr(), s1.data_ptr(), st) != 0
         assert "BatchNorm" in L.last_error()
+
+
+# ------------------------------------------------------------------------------------------------ plane-serial z-march
+# cin, cout, input dims, batch, bf16 pairs, plane-major input: 96 -> 32 and 48 -> 16 (the two layers behind a concatenation), a
+# two-plane case, ragged planes, volumes small enough that pieces start in the middle of a column
+PS_CASES = [(48, 16, (7, 37, 21), 2, False, True), (96, 32, (6, 19, 33), 2, False, True), (48, 16, (5, 30, 30), 1, False, False),
+            (96, 32, (9, 20, 40), 1, False, False), (32, 16, (9, 35, 17), 1, False, False), (48, 16, (7, 37, 21), 2, True, True),
+            (32, 16, (6, 20, 40), 1, True, False), (96, 32, (6, 19, 33), 2, True, True), (96, 32, (5, 20, 24), 1, True, False)]
+
+
+@pytest.mark.parametrize("cin,cout,dims,B,hl,planar", PS_CASES)
+def test_plane_serial_march_matches_conv3d(cin, cout, dims, B, hl, planar, monkeypatch):
+    """sp_conv3d_zm with pser_planes (round 5): one 16-channel plane per sub-step, that plane's weight fragments streamed through two
+    LDS buffers -- bias, LeakyReLU and statistics against float64 torch on the operands the kernel sees, for bf16 and bf16-pair
+    operands, plane-major (concat buffers) and channels-last inputs"""
+    monkeypatch.setattr(O, "ZM_MIN_PLANES", 0)
+    monkeypatch.setattr(P, "ZM_PSER_ALL", True)
+    monkeypatch.setattr(O, "HL_PSER_SLICES", True)
+    g = torch.Generator().manual_seed(cin * 7 + cout + B)
+    dt = L.SP_HL if hl else L.SP_BF16
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout, dt)
+    run = O.ConvRunner(op, DEV, zm_batch=B)
+    if hl and cout > 16:      # pairs: one plane-serial launch per 16 output channels (plan.zm_pser_slices)
+        assert run.zm is None and len(run.zms) == cout // 16 and all(z.get("pser") and z["PT"] == cin // 16 for z in run.zms)
+    else:
+        assert run.zm is not None and run.zm.get("pser") and run.zm["PT"] == cin // 16
+    x = torch.randn(B, cin, *dims, generator=g)
+    w = torch.randn(cout, cin, 3, 3, 3, generator=g) / math.sqrt(27 * cin)
+    b = torch.randn(cout, generator=g) * 0.1
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.1
+    run.prep(w.to(DEV), b.to(DEV), sc.to(DEV), sh.to(DEV))
+
+    def lay(t):      # channels-last (B, D, H, W, C) tensor, or its plane-major form in the same shape
+        t = _to_cl(t, cin)
+        return t.view(B, *dims, cin // 16, 16).permute(4, 0, 1, 2, 3, 5).contiguous().view(B, *dims, cin) if planar else t
+    xh = bf(x)
+    xs = lay(xh)
+    xl = lay(bf(x - xh)) if hl else None
+    nrep = 64
+    od = tuple(op.y_dims)
+    y = torch.full((2 if hl else 1, B) + od + (cout,), 7.0, dtype=torch.bfloat16, device=DEV)
+    st = torch.zeros(nrep * cout * 2, dtype=torch.float64, device=DEV)
+    kw = dict(x_lo=xl, y_lo=y[1]) if hl else {}
+    run.run(xs, y[0], B, None, None, L.ACT_LEAKY, LEAKY, st, dtype_out=dt, stats_nrep=nrep, x_planar=planar, **kw)
+    torch.cuda.synchronize()
+    xv = (xh + bf(x - xh)) if hl else xh
+    wf = w * sc.view(1, -1, 1, 1, 1)
+    ref = F.leaky_relu(F.conv3d(xv.double(), wf.double()) + (b + (w * sh.view(1, -1, 1, 1, 1)).sum((1, 2, 3, 4))).double().view(1, -1, 1, 1, 1), LEAKY)
+    got = _from_cl(y[0], cout).double() + (_from_cl(y[1], cout).double() if hl else 0)
+    tol = 2e-4 if hl else 3e-2
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol * float(ref.abs().max()))
+    s = st.view(nrep, cout, 2).sum(0).cpu()
+    n = got.numel() / cout
+    torch.testing.assert_close(s[:, 0], got.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(n))
+    torch.testing.assert_close(s[:, 1], (got ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(n))

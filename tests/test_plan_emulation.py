@@ -212,6 +212,56 @@ def test_zm_tile_covers_the_plane_with_the_fewest_tiles():
     assert int(z["ktab"].max()) + 16 <= z["P"] * z["ITH"] * P.ZM_ITW * 32
 
 
+@pytest.mark.parametrize("cin,cout", [(48, 16), (96, 32), (32, 16)])
+def test_plane_serial_tables(cin, cout, monkeypatch):
+    """plan.zm_pser_plan (round 5): the z-march that takes one 16-channel plane per sub-step -- the one-plane K table and the
+    per-plane weight maps reproduce the convolution (every (tap, input octet) exactly once)"""
+    monkeypatch.setattr(P, "ZM_PSER_ON", True)
+    torch.manual_seed(cin + cout)
+    dims = (5, 6, 19)
+    x = torch.randn(1, cin, *dims, dtype=torch.float64)
+    w = torch.randn(cout, cin, 3, 3, 3, dtype=torch.float64)
+    ref = F.conv3d(x, w)
+    op = P.conv_fwd_op(cin, cout, 3, 1, 0, dims, cin, cout)
+    z = P.zm_pser_plan(op)
+    assert z is not None and z["pser"] and z["P"] == 1 and z["PT"] == cin // 16 and z["NT"] == cout // 16 and z["nsteps"] == z["PT"] * 3 * z["KS"]
+    assert (z["MT"], z["nslot"], z["NW"]) == P.ZM_CONFIGS_PS[(cout // 16, False)]
+    sub = op.subs[0]
+    qd, qh, qw = sub.out_dims
+    xc = to_cl(x, cin)
+    wf = w.reshape(-1).tolist()
+    y = torch.zeros((1, qd, qh, qw, cout), dtype=torch.float64)
+    qy, qx = torch.meshgrid(torch.arange(qh), torch.arange(qw), indexing="ij")
+    ks = z["KS"]
+    seen = set()
+    for zi in range(qd + 2):
+        for p in range(z["PT"]):                      # the sub-steps of input plane zi
+            for dz in range(3):
+                zo = zi - dz
+                if not (0 <= zo < qd):
+                    continue
+                for e in range(ks * 4):
+                    km = int(z["kmap"][((p * 3 + dz) * ks) * 4 + e])
+                    if km < 0:
+                        continue
+                    src, octet = km >> 16, km & 0xffff
+                    assert octet // 2 == p
+                    vox, r2 = divmod(int(z["ktab"][e]), 32)
+                    dy, dx = divmod(vox, z["TW"] + 2)
+                    assert r2 // 16 == octet % 2 and dy < 3 and dx < 3
+                    if zi == 2:
+                        seen.add((src, octet))
+                    xv = xc[0, zi][qy + dy, qx + dx][..., octet * 8:octet * 8 + 8]
+                    for j in range(8):
+                        ci = octet * 8 + j
+                        wv = torch.tensor([wf[co * op.w_sco + ci * op.w_sci + src] for co in range(cout)], dtype=torch.float64)
+                        y[0, zo, :, :, :cout] += xv[..., j:j + 1] * wv
+    torch.testing.assert_close(from_cl(y, cout), ref, rtol=1e-10, atol=1e-10)
+    assert len(seen) == 27 * cin // 8
+    assert P.zm_pser_plan(P.conv_fwd_op(16, 16, 3, 1, 0, dims, 16, 16)) is None          # one input plane: the plain march
+    assert P.zm_pser_plan(P.conv_fwd_op(64, 64, 3, 1, 0, dims, 64, 64)) is None          # four output tiles: no instance
+
+
 def test_fc_plan_tables():
     """runtime/plan.py:fc_plan (split-K kernel for the FC-like layers): tap-major K order, steps per tap padded to the kernel's
     prefetch depth, every (tap, octet) exactly once, padding entries -1"""
