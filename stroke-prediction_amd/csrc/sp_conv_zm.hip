@@ -175,6 +175,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr int WB = (HL ? 2 : 1) * NWF * 1024;      // bytes of one set of weight fragments in LDS (PS: two such buffers)
   constexpr int NJW = PS ? (((HL ? 2 : 1) * NWF + NW - 1) / NW) : 0;      // PS: weight DMA instructions per wave and sub-step
   constexpr bool PSPIPE = PS && !HL && NT == 1;      // PS: double-buffered fragment reads (the other instances spill with them)
+#ifdef SP_PS_NOFRONT
+  constexpr bool PSFRONT = false;
+#else
+  constexpr bool PSFRONT = true;      // PS with two ring slots: the prefetched plane's DMAs at the top of the sub-step, not between its MFMAs
+#endif
   constexpr int BTOFF = WOFF + (WLDS ? (PS ? 2 : 1) * WB : 0);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const sp_conv_args& a = Q.a;
@@ -789,6 +794,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     // its plane (issued D sub-steps ago) and its weights (issued at the top of sub-step t - 1, BEFORE that sub-step's plane
     // DMAs and stores) have landed once all but the youngest NJ + NS operations are done; every sub-step issues exactly NJW + NJ
     // + NS operations (fillers / dropped stores where there is nothing to do), so the count holds from sub-step D on.
+#define ZM_DMA_PS(s_) if constexpr (!(D == 1 && PSFRONT)) { ZM_DMA(s_) }
 #define ZM_STEP_PS(PH)                                                                                            \
   {                                                                                                               \
     const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
@@ -809,6 +815,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         pl_fill = false;                                                                                          \
         if (ia < nin) plane_begin(ia, (tslot + D) % NSLOT, pa);                                                   \
         else { pl_mask = 0; pl_fill = true; pl_dst0 = ring + NSLOT * S + wave * 1024; }                           \
+        /* two slots (prefetch distance 1): the whole plane goes out NOW -- it has to land within this sub-step */  \
+        if constexpr (D == 1 && PSFRONT) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) plane_dma(j, true); }   \
       }                                                                                                           \
       const unsigned char* sb = ring + tslot * S;                                                                 \
       const unsigned char* wlb = wl + wbuf * WB;                                                                  \
@@ -827,14 +835,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         ZM_LDW_B(wa, wal, 0, wlb)                                                                                 \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                          \
           if (s + 1 < KS) { if ((s & 1) == 0) { ZM_LDX(x1, x1l, s + 1) ZM_LDW_B(wb, wbl, s + 1, wlb) } else { ZM_LDX(x0, x0l, s + 1) ZM_LDW_B(wa, wal, s + 1, wlb) } } \
-          if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) ZM_MMA(PH, 0, s, x0, x0l, wa, wal) } \
-          else { ZM_MMA((PH + 2) % 4, 2, s, x1, x1l, wb, wbl) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x1, x1l, wb, wbl) ZM_MMA(PH, 0, s, x1, x1l, wb, wbl) } \
+          if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) ZM_DMA_PS(s) ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) ZM_MMA(PH, 0, s, x0, x0l, wa, wal) } \
+          else { ZM_MMA((PH + 2) % 4, 2, s, x1, x1l, wb, wbl) ZM_DMA_PS(s) ZM_MMA((PH + 3) % 4, 1, s, x1, x1l, wb, wbl) ZM_MMA(PH, 0, s, x1, x1l, wb, wbl) } \
         }                                                                                                         \
       } else {                                                                                                    \
         _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                          \
           ZM_LDX(x0, x0l, s)                                                                                      \
           ZM_LDW_B(wa, wal, s, wlb)                                                                               \
-          ZM_DMA(s)                                                                                               \
+          ZM_DMA_PS(s)                                                                                               \
           if (v2) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) }                                                \
           if (v1) { ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) }                                                \
           if (v0) { ZM_MMA(PH, 0, s, x0, x0l, wa, wal) }                                                          \
@@ -875,6 +883,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       if (i > nin) break;
     }
 #undef ZM_STEP_PS
+#undef ZM_DMA_PS
 #undef ZM_LDW_B
 #undef ZM_STEP
 #undef ZM_MMA_D0
