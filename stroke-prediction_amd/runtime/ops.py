@@ -34,6 +34,7 @@ def bump_param_epoch():
 
 FUSE_BN_FINALIZE = bool(int(os.environ.get("SP_FUSE_BN_FINALIZE", "1")))   # sp_bn_finalize inside the weight re-pack kernel of the folded layers (one launch less per layer)
 SPLIT_G = bool(int(os.environ.get("SP_SPLIT_G1", "1")))   # one-launch split of a concatenating layer's data gradient into two dense tensors (ConvRunner.zm_split_ok)
+PSER_FALLBACK = bool(int(os.environ.get("SP_ZM_PSER_FALLBACK", "0")))   # plane-serial march for ops with no whole-set instance (bf16 96 -> 32): 124 us against 95 us on the tiled kernel (off)
 HL_PSER_SLICES = bool(int(os.environ.get("SP_HL_PSER_SLICES", "0")))   # pair mode: 96 -> 32 as two plane-serial launches of 16 output channels -- measured: 2 x 134 us against 275 us on the tiled kernel, no gain (off)
 FUSE_POOL = bool(int(os.environ.get("SP_FUSE_POOL", "1")))   # MaxPool3d(2) in the epilogue of the down blocks' second convolution (training steps)
 FUSE_DZ = bool(int(os.environ.get("SP_FUSE_DZ", "1")))   # the second convolution's data gradient writes the first one's dz (BatchNorm / activation backward in its epilogue)
@@ -239,9 +240,10 @@ class ConvRunner:
                 subs.append(d)
             st["subs"] = subs
             zm = P.zm_plan(op, tile=zm_tile) if (USE_ZM and USE_DMA and zm_batch) else None
-            # plane-serial march (round 5): ops with more input planes than a whole-set ring holds (96 -> 32), and the (P, NT) pairs
-            # measured faster there (plan.ZM_PSER_PREFER)
-            if USE_ZM and USE_DMA and zm_batch and (zm is None or P.ZM_PSER_ALL or (op.cpi // 16, -(-op.cout // 16), op.dtype) in P.ZM_PSER_PREFER):
+            # plane-serial march (round 5): the (P, NT, dtype) triples measured faster there (plan.ZM_PSER_PREFER: the pair mode's 48 -> 16).
+            # Ops with more input planes than a whole-set ring holds (bf16 96 -> 32) stay on the tiled kernel: 94 us against 124 us
+            # plane-serial in one call (SP_ZM_PSER_FALLBACK=1 routes them here)
+            if USE_ZM and USE_DMA and zm_batch and ((zm is None and PSER_FALLBACK) or P.ZM_PSER_ALL or (op.cpi // 16, -(-op.cout // 16), op.dtype) in P.ZM_PSER_PREFER):
                 zp = P.zm_pser_plan(op, tile=zm_tile)
                 if zp is not None:
                     zm = zp
