@@ -394,6 +394,10 @@ def zm_tile(ho, wo, nw, mt):
     rows = nw * mt
     if ZM_TILE == "16":
         return 16, rows
+    if "x" in ZM_TILE:      # "32x16": that shape wherever it fits (A/B runs), else the automatic choice
+        tw, th = (int(v) for v in ZM_TILE.split("x"))
+        if tw * th <= 16 * rows and (tw + 2) * (th + 2) <= (rows + 2) * 18 and tw <= 253 and th <= 253:
+            return tw, th
     best = None
     for tw in range(4, min(wo, 253) + 1):
         for th in range(2, min(ho, 253) + 1):
