@@ -174,6 +174,23 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   constexpr bool PB = ACT == 2;
   constexpr int WB = (HL ? 2 : 1) * NWF * 1024;      // bytes of one set of weight fragments in LDS (PS: two such buffers)
   constexpr int NJW = PS ? (((HL ? 2 : 1) * NWF + NW - 1) / NW) : 0;      // PS: weight DMA instructions per wave and sub-step
+  // One wave per SIMD (NW == 4): nothing but this wave's own instruction order hides an LDS round trip.  Left alone the scheduler sinks
+  // the fragment reads of K step s + 1 to just in front of their MFMAs (one register set, an lgkmcnt wait in front of every group of
+  // four MFMAs: the pipe busy 43 % in 48 -> 16 @92^3); the fence keeps them above the MFMAs of step s.  With two waves per SIMD the
+  // partner covers the wait and the second register set would spill.
+#ifdef SP_ZM_NOFRONT
+  constexpr bool ZFRONT = false;
+#else
+  // two ring slots: the prefetched plane's DMAs at the top of the step (they have to land within it), not between its MFMAs.  Only with
+  // two waves per SIMD: a four-wave instance stalls its own MFMAs behind the burst (pair mode: +15 us per step)
+  constexpr bool ZFRONT = NW == 8;
+#endif
+#ifdef SP_ZM_NOFENCE
+  constexpr bool FENCE = false;
+#else
+  constexpr bool FENCE = NW == 4 && !PS;
+#endif
+#define ZM_FENCE if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
   constexpr bool PSPIPE = PS && !HL && NT == 1;      // PS: double-buffered fragment reads (the other instances spill with them)
 #ifdef SP_PS_NOFRONT
   constexpr bool PSFRONT = false;
@@ -698,7 +715,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
             if constexpr (HL) dstl[dz][n] = *reinterpret_cast<const bf16x8*>((wb_) + (NWF + (dz * KS + (s_)) * NT + n) * 1024); \
         }                                                                                                         \
   }
-#define ZM_DMA(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KS; j < (((s_) + 1) * NJ) / KS; ++j) plane_dma(j, true);
+#define ZM_DMA_(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KS; j < (((s_) + 1) * NJ) / KS; ++j) plane_dma(j, true);
+#define ZM_DMA(s_) if constexpr (!(D == 1 && ZFRONT && !PS)) { ZM_DMA_(s_) }
 #define ZM_W(DZ_, s_, n_, wv) (WLDS ? wv[DZ_][n_] : w[WLDS ? 0 : DZ_][WLDS ? 0 : s_][WLDS ? 0 : n_])
     // HL: the two cross terms follow the hi x hi product into the same accumulator
 #define ZM_MMA_X(R_, DZ_, xv, xvl, wv, wvl)                                                                       \
@@ -755,6 +773,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     pl_fill = false;                                                                                              \
     if (i + D < nin) plane_begin(i + D, (islot + D) % NSLOT);                                                     \
     else { pl_mask = 0; pl_fill = true; pl_dst0 = ring + NSLOT * S + wave * 1024; }                               \
+    /* two ring slots (prefetch distance 1): the whole plane goes out NOW -- it has to land within this step */     \
+    if constexpr (D == 1 && ZFRONT) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) plane_dma(j, true); }        \
     ZM_T(ts2);                                                                                                    \
     const unsigned char* sb = ring + islot * S;                                                                   \
     const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
@@ -768,6 +788,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
       ZM_LDW(wa, wal, 0)                                                                                          \
       _Pragma("unroll") for (int s = 0; s < KS; ++s) {                                                            \
         if (s + 1 < KS) { if ((s & 1) == 0) { ZM_LDX(x1, x1l, s + 1) ZM_LDW(wb, wbl, s + 1) } else { ZM_LDX(x0, x0l, s + 1) ZM_LDW(wa, wal, s + 1) } } \
+        ZM_FENCE                                                                                                  \
         if ((s & 1) == 0) { ZM_MMA((PH + 2) % 4, 2, s, x0, x0l, wa, wal) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x0, x0l, wa, wal) ZM_MMA_D0(PH, s, x0, x0l, wa, wal) }  \
         else { ZM_MMA((PH + 2) % 4, 2, s, x1, x1l, wb, wbl) ZM_DMA(s) ZM_MMA((PH + 3) % 4, 1, s, x1, x1l, wb, wbl) ZM_MMA_D0(PH, s, x1, x1l, wb, wbl) } \
       }                                                                                                           \
@@ -794,7 +815,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     // its plane (issued D sub-steps ago) and its weights (issued at the top of sub-step t - 1, BEFORE that sub-step's plane
     // DMAs and stores) have landed once all but the youngest NJ + NS operations are done; every sub-step issues exactly NJW + NJ
     // + NS operations (fillers / dropped stores where there is nothing to do), so the count holds from sub-step D on.
-#define ZM_DMA_PS(s_) if constexpr (!(D == 1 && PSFRONT)) { ZM_DMA(s_) }
+#define ZM_DMA_PS(s_) if constexpr (!(D == 1 && PSFRONT)) { ZM_DMA_(s_) }
 #define ZM_STEP_PS(PH)                                                                                            \
   {                                                                                                               \
     const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
@@ -892,6 +913,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #undef ZM_MMA_X
 #undef ZM_W
 #undef ZM_DMA
+#undef ZM_DMA_
 #undef ZM_LDW
 #undef ZM_LDX
 #undef ZM_EPILOGUE
@@ -1042,6 +1064,11 @@ static int launch_zm(const sp_conv_args* a, const void* zeros, hipStream_t st) {
 
 // (P, NT) -> rows per wave, ring slots, waves per workgroup; SP_EINVAL = no kernel.  runtime/plan.py (ZM_CONFIGS) must agree:
 // tests/test_cabi.py checks it.  SP_ZM_NW=4 forces the one-wave-per-SIMD set everywhere (A/B runs; read on both sides).
+// three input planes (48 -> 16): eight waves on 24 x 16 tiles and TWO ring slots (three would not fit beside the 41 KB of weight
+// fragments), the prefetched plane's DMAs at the top of the step.  The four-wave form (16 x 16 tiles, three slots) spent 1.8 us of
+// every 2.9 us step outside the MFMAs -- DMA issue, epilogue and barrier of a wave are not covered by a partner on its SIMD --:
+// 161 -> 143 us at 4 x 92^3.  SP_ZM_31=w4 brings it back (A/B runs; read on both sides).
+static bool zm_31w4() { static const bool v = getenv("SP_ZM_31") && !strcmp(getenv("SP_ZM_31"), "w4"); return v; }
 static bool zm_nw4() { static const bool v = getenv("SP_ZM_NW") && atoi(getenv("SP_ZM_NW")) == 4; return v; }
 extern "C" int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* NSLOT, int32_t* NW) {
   int mt = 0, ns = 3, nw = 8;
@@ -1053,7 +1080,7 @@ extern "C" int sp_conv3d_zm_config(int32_t P, int32_t NT, int32_t* MT, int32_t* 
   else if (P == 1 && NT == 3) mt = 2;
   else if (P == 2 && NT == 1) mt = 4;
   else if (P == 2 && NT == 2) mt = 2;
-  else if (P == 3 && NT == 1) { mt = 4; nw = 4; }
+  else if (P == 3 && NT == 1) { mt = 3; ns = 2; if (zm_31w4() || zm_nw4()) { mt = 4; ns = 3; nw = 4; } }
   if (zm_nw4() && mt && nw == 8) { mt *= 2; nw = 4; }
   if (MT) *MT = mt;
   if (NSLOT) *NSLOT = ns;
@@ -1192,6 +1219,7 @@ extern "C" int sp_conv3d_zm(const sp_conv_args* a, const void* zeros, sp_stream_
     if (P == 3 && a->NT == 1) return v(5) == 1 ? launch_zm<3, 1, 4, 3, false, 4>(a, zeros, st) : launch_zm<3, 1, 4, 3, true, 4>(a, zeros, st);
     return SP_EINVAL;
   }
+  if (P == 3 && a->NT == 1) return launch_zm<3, 1, 3, 2, true, 8>(a, zeros, st);      // (the only eight-wave instance with two ring slots)
   if (P == 1 && a->NT == 1) return v(0) == 1 ? launch_zm<1, 1, 4, 3, true, 8>(a, zeros, st) : launch_zm<1, 1, 4, 3, false, 8>(a, zeros, st);
   if (P == 1 && a->NT == 2) return launch_zm<1, 2, 2, 3, true, 8>(a, zeros, st);
   if (P == 1 && a->NT == 3) return launch_zm<1, 3, 2, 3, true, 8>(a, zeros, st);

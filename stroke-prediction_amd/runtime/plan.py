@@ -370,8 +370,10 @@ def wgrad_taps(k, transposed_roles=False):
 # two agree).  Default: eight waves (two per SIMD -- one wave's epilogue / DMA / LDS instructions issue under its partner's
 # MFMAs), four for three input planes; SP_ZM_NW=4: four waves with twice the rows each everywhere (read on both sides; A/B runs).
 ZM_CONFIGS_NW4 = {(1, 1): (8, 3, 4), (1, 2): (4, 3, 4), (1, 3): (4, 3, 4), (2, 1): (8, 3, 4), (2, 2): (4, 3, 4), (3, 1): (4, 3, 4)}
-ZM_CONFIGS_DEFAULT = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (1, 3): (2, 3, 8), (2, 1): (4, 3, 8), (2, 2): (2, 3, 8), (3, 1): (4, 3, 4)}
+ZM_CONFIGS_DEFAULT = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (1, 3): (2, 3, 8), (2, 1): (4, 3, 8), (2, 2): (2, 3, 8), (3, 1): (3, 2, 8)}
 ZM_CONFIGS = ZM_CONFIGS_NW4 if os.environ.get("SP_ZM_NW") == "4" else ZM_CONFIGS_DEFAULT
+if os.environ.get("SP_ZM_31") == "w4":      # A/B: three input planes on four waves, 16 x 16 tiles, three ring slots (the form up to round 5)
+    ZM_CONFIGS = {**ZM_CONFIGS, (3, 1): (4, 3, 4)}
 # bf16-pair instances (dtype 2 = SP_HL, the forward convolutions of the "bf16x3" mode): twice the planes per ring slot and hi + lo
 # weight fragments in LDS -> smaller tiles / two ring slots where Cin x Cout grows.  Mirrors sp_conv3d_zm_config_hl.
 ZM_CONFIGS_HL = {(1, 1): (4, 3, 8), (1, 2): (2, 3, 8), (2, 1): (4, 2, 4), (2, 2): (2, 2, 4), (3, 1): (2, 2, 4)}
