@@ -184,6 +184,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
   // two ring slots: the prefetched plane's DMAs at the top of the step (they have to land within it), not between its MFMAs.  Only with
   // two waves per SIMD: a four-wave instance stalls its own MFMAs behind the burst (pair mode: +15 us per step)
   constexpr bool ZFRONT = NW == 8;
+  // ... spread over the FIRST HALF of the K steps rather than in one burst (eight waves issuing six DMAs each at once: 300 cycles per
+  // instruction, 24 % of the 48 -> 16 kernel with every wave stuck in the burst; tools/stamp_zm.py)
+#ifdef SP_ZM_NOHALF
+  constexpr bool ZHALF = false;
+#else
+  constexpr bool ZHALF = true;
+#endif
+  constexpr int KH = (KS + 1) / 2;
+#ifdef SP_PS_NOHALF
+  constexpr bool PSHALF = false;
+#else
+  constexpr bool PSHALF = true;
+#endif
 #endif
 #ifdef SP_ZM_NOFENCE
   constexpr bool FENCE = false;
@@ -716,7 +729,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         }                                                                                                         \
   }
 #define ZM_DMA_(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KS; j < (((s_) + 1) * NJ) / KS; ++j) plane_dma(j, true);
-#define ZM_DMA(s_) if constexpr (!(D == 1 && ZFRONT && !PS)) { ZM_DMA_(s_) }
+#define ZM_DMA_H(s_) _Pragma("unroll") for (int j = ((s_) * NJ) / KH; j < ((s_) < KH ? (((s_) + 1) * NJ) / KH : 0); ++j) plane_dma(j, true);
+#define ZM_DMA(s_) if constexpr (D == 1 && ZFRONT && !PS) { if constexpr (ZHALF) { ZM_DMA_H(s_) } } else { ZM_DMA_(s_) }
 #define ZM_W(DZ_, s_, n_, wv) (WLDS ? wv[DZ_][n_] : w[WLDS ? 0 : DZ_][WLDS ? 0 : s_][WLDS ? 0 : n_])
     // HL: the two cross terms follow the hi x hi product into the same accumulator
 #define ZM_MMA_X(R_, DZ_, xv, xvl, wv, wvl)                                                                       \
@@ -774,7 +788,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     if (i + D < nin) plane_begin(i + D, (islot + D) % NSLOT);                                                     \
     else { pl_mask = 0; pl_fill = true; pl_dst0 = ring + NSLOT * S + wave * 1024; }                               \
     /* two ring slots (prefetch distance 1): the whole plane goes out NOW -- it has to land within this step */     \
-    if constexpr (D == 1 && ZFRONT) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) plane_dma(j, true); }        \
+    if constexpr (D == 1 && ZFRONT && !ZHALF) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) plane_dma(j, true); } \
     ZM_T(ts2);                                                                                                    \
     const unsigned char* sb = ring + islot * S;                                                                   \
     const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
@@ -815,7 +829,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
     // its plane (issued D sub-steps ago) and its weights (issued at the top of sub-step t - 1, BEFORE that sub-step's plane
     // DMAs and stores) have landed once all but the youngest NJ + NS operations are done; every sub-step issues exactly NJW + NJ
     // + NS operations (fillers / dropped stores where there is nothing to do), so the count holds from sub-step D on.
-#define ZM_DMA_PS(s_) if constexpr (!(D == 1 && PSFRONT)) { ZM_DMA_(s_) }
+#define ZM_DMA_PS(s_) if constexpr (D == 1 && PSFRONT) { if constexpr (PSHALF) { ZM_DMA_H(s_) } } else { ZM_DMA_(s_) }
 #define ZM_STEP_PS(PH)                                                                                            \
   {                                                                                                               \
     const bool v0 = i < nz, v1 = i >= 1 && i - 1 < nz, v2 = i >= 2 && i - 2 < nz;                                 \
@@ -837,7 +851,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
         if (ia < nin) plane_begin(ia, (tslot + D) % NSLOT, pa);                                                   \
         else { pl_mask = 0; pl_fill = true; pl_dst0 = ring + NSLOT * S + wave * 1024; }                           \
         /* two slots (prefetch distance 1): the whole plane goes out NOW -- it has to land within this sub-step */  \
-        if constexpr (D == 1 && PSFRONT) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) plane_dma(j, true); }   \
+        if constexpr (D == 1 && PSFRONT && !PSHALF) { _Pragma("unroll") for (int j = 0; j < NJ; ++j) plane_dma(j, true); } \
       }                                                                                                           \
       const unsigned char* sb = ring + tslot * S;                                                                 \
       const unsigned char* wlb = wl + wbuf * WB;                                                                  \
@@ -914,6 +928,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void conv_zm3_kernel(const ConvZmD
 #undef ZM_W
 #undef ZM_DMA
 #undef ZM_DMA_
+#undef ZM_DMA_H
 #undef ZM_LDW
 #undef ZM_LDX
 #undef ZM_EPILOGUE
