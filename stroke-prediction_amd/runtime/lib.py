@@ -313,6 +313,10 @@ def build(verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     jobs, links = [], []
     for variant, (fname, flags) in VARIANTS.items():
+        if os.environ.get("SP_LIB_PATH"):
+            # a diagnostic build named by the environment (tools/build_variant*.sh, tools/build_asan.sh) is used as it is: nothing is
+            # compiled beside it (the precision variants would land in ITS directory: six minutes of hipcc inside the sanitizer run)
+            break
         out = lib_path(variant)
         if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in srcs + hdrs):
             continue
