@@ -748,6 +748,11 @@ class WgradRunner:
             # bound by the DMA latency per tile -- 32->100 @7x25x25: 8 workgroups x 36 tiles = 119 us -- : floor 128)
             floor = 512 if (a.sD, a.sH, a.sW) == (1, 1, 1) else int(os.environ.get("SP_WGRAD_STRIDED_FLOOR", "128"))
             nb = max(8, min(512 // yz, vox // floor)) // 8 * 8
+            # few output voxels under a LARGE weight tensor (the CAE's 100 -> 800 layer: 1200 voxels, 9.7 MB of dw): every partial
+            # block is a whole dw written and read again -- 8 blocks = 77 MB for 0.2 MB of operands.  The tile grid alone fills the chip.
+            big = int(os.environ.get("SP_WGRAD_BIG_BLOCKS", "2"))
+            if big > 0 and total * 4 >= (4 << 20) and yz >= 64:
+                nb = min(nb, big)
             if getattr(self, "groups", 1) > 1:      # group-aware finish: the partial blocks of a group are consecutive
                 q = 8 * self.groups // math.gcd(8, self.groups)
                 nb = max(q, nb // q * q)
