@@ -745,6 +745,10 @@ int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, int64_t t_bs
 /* loss = 1 - sum_c w_c (2 I_c + eps)/(O_c + T_c + eps);  coef[c] = (ca, cb): d loss/d o = ca*t + cb*o */
 int sp_dice_finalize(const double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
                      sp_stream_t stream);
+/* the same, and the replica rows are zeroed again after they are read: the caller keeps one accumulator across steps and needs no fill
+ * launch in front of the next sp_dice_sums (BatchDiceLoss of common/metrics.py in a captured training step) */
+int sp_dice_finalize_clear(double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
+                           sp_stream_t stream);
 /* The CAE reconstruction loss (CaeReconstructionLearner.py:52-70) in three launches:
  *   [ mean(|p-i| - (p-i)) + mean(|p-c| - (p-c)) + Dice(c, tc) + Dice(p, tp) + Dice(l, tl) + factor * mean|zi - zl| ] / (5 + factor)
  * c, p, l, i: the reconstructions (B, 1, DHW) fp32 with batch strides *bs (elements; slices of a stacked tensor are read in place),

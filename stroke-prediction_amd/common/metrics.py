@@ -69,6 +69,9 @@ def batch_mean(t):
     return torch.mean(t)
 
 
+_DICE_SUMS = {}      # (device, C, stream) -> [replica rows of the Dice sums (zero between calls), busy]
+
+
 class _DiceFn(torch.autograd.Function):
     """loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps); sums over batch and volume per channel.  Three HIP
     launches forward (sums, finalize) and one backward; the scalar algebra never leaves the device."""
@@ -80,7 +83,14 @@ class _DiceFn(torch.autograd.Function):
         t, tbs = _batch_strided(targets)
         B, C = o.shape[0], o.shape[1]
         dhw = o.numel() // (B * C)
-        sums = torch.zeros(L.SP_REDUCE_ROWS, (3 * C + 15) // 16 * 16, dtype=torch.float64, device=o.device)   # replica rows
+        # ONE accumulator per (device, C), zeroed once: sp_dice_finalize_clear leaves it zero again (no fill launch per call -- 5 us of a
+        # captured step's dependent chain).  ``busy``: a call that died between the two launches left sums behind -> zero them here.
+        key = (o.device, C, int(torch.cuda.current_stream(o.device).cuda_stream))      # (per stream: launches of one stream are ordered)
+        ent = _DICE_SUMS.get(key)
+        if ent is None or ent[1]:
+            ent = _DICE_SUMS[key] = [torch.zeros(L.SP_REDUCE_ROWS, (3 * C + 15) // 16 * 16, dtype=torch.float64, device=o.device), False]
+        sums = ent[0]   # replica rows
+        ent[1] = True
         L.call("sp_dice_sums", O.ptr(o), obs, O.ptr(t), tbs, B, C, dhw, O.ptr(sums), O.stream())
         from stroke_prediction_amd.runtime.layers import SYNC, _allreduce
         if SYNC["on"]:                  # Dice is a ratio of WHOLE-batch sums (metrics.py:24-27): make them global
@@ -88,7 +98,8 @@ class _DiceFn(torch.autograd.Function):
         w = _weights_on(o.device, weights)      # cached: no host->device copy inside a (graph-captured) step
         loss = torch.empty((), dtype=torch.float32, device=o.device)
         coef = torch.empty(2 * C, dtype=torch.float32, device=o.device)
-        L.call("sp_dice_finalize", O.ptr(sums), O.ptr(w), float(eps), C, O.ptr(loss), O.ptr(coef), O.stream())
+        L.call("sp_dice_finalize_clear", O.ptr(sums), O.ptr(w), float(eps), C, O.ptr(loss), O.ptr(coef), O.stream())
+        ent[1] = False
         ctx.save_for_backward(o, t, coef)
         ctx.strides = (obs, tbs)
         return loss

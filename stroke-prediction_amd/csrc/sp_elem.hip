@@ -2050,25 +2050,39 @@ extern "C" int sp_dice_sums(const float* o, int64_t o_bstride, const float* t, i
 }
 // loss = 1 - sum_c w_c (2 I_c + eps) / (O_c + T_c + eps);  coef[c] = (ca, cb) with d loss / d o = ca*t + cb*o:
 // ca = -2 w / den, cb = 2 w num / den^2.  One launch instead of a dozen one-element torch kernels.
+// clear != NULL (= sums): the replica rows are zeroed again once they are read -- the caller keeps ONE accumulator and needs no fill
+// launch in front of the next sp_dice_sums (4.9 us of a training step's dependent chain)
 __global__ void dice_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ w, double eps, int C,
-                                     float* __restrict__ loss, float* __restrict__ coef) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double acc = 0.0;
+                                     float* __restrict__ loss, float* __restrict__ coef, double* __restrict__ clear) {
   const int pitch = SP_DICE_PITCH(C);
-  for (int c = 0; c < C; ++c) {
-    const double num = 2.0 * sp_rows_sum(sums, c * 3, pitch) + eps;
-    const double den = sp_rows_sum(sums, c * 3 + 1, pitch) + sp_rows_sum(sums, c * 3 + 2, pitch) + eps;
-    acc += (double)w[c] * num / den;
-    coef[2 * c] = (float)(-2.0 * w[c] / den);
-    coef[2 * c + 1] = (float)(2.0 * w[c] * num / (den * den));
+  if (threadIdx.x == 0) {
+    double acc = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const double num = 2.0 * sp_rows_sum(sums, c * 3, pitch) + eps;
+      const double den = sp_rows_sum(sums, c * 3 + 1, pitch) + sp_rows_sum(sums, c * 3 + 2, pitch) + eps;
+      acc += (double)w[c] * num / den;
+      coef[2 * c] = (float)(-2.0 * w[c] / den);
+      coef[2 * c + 1] = (float)(2.0 * w[c] * num / (den * den));
+    }
+    *loss = (float)(1.0 - acc);
   }
-  *loss = (float)(1.0 - acc);
+  if (clear) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < SP_REDUCE_ROWS * pitch; k += blockDim.x) clear[k] = 0.0;
+  }
 }
 extern "C" int sp_dice_finalize(const double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
                                 sp_stream_t stream) {
   SP_CHECK_ARG(sums && weights && loss && coef && C >= 1, "sp_dice_finalize: bad arguments");
-  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), sums, weights, eps, C, loss, coef);
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), sums, weights, eps, C, loss, coef, (double*)nullptr);
   SP_CHECK_LAUNCH("sp_dice_finalize");
+  return SP_OK;
+}
+extern "C" int sp_dice_finalize_clear(double* sums, const float* weights, double eps, int32_t C, float* loss, float* coef,
+                                      sp_stream_t stream) {
+  SP_CHECK_ARG(sums && weights && loss && coef && C >= 1, "sp_dice_finalize_clear: bad arguments");
+  hipLaunchKernelGGL(dice_finalize_kernel, dim3(1), dim3(64), 0, ST(stream), sums, weights, eps, C, loss, coef, sums);
+  SP_CHECK_LAUNCH("sp_dice_finalize_clear");
   return SP_OK;
 }
 

@@ -202,9 +202,23 @@ class Learner(Inference):
         loss = self.loss_step(dto, epoch)
 
         self._optimizer.zero_grad()
-        loss.backward()
+        loss.backward(self._root_grad(loss))
         self._optimizer.step()
         return dto, loss
+
+    _ROOT_ONES = {}
+
+    @classmethod
+    def _root_grad(cls, loss):
+        """the ``1`` that ``loss.backward()`` would create with a fill launch per call (5 us on the step's dependent chain): one cached
+        tensor per device and dtype (autograd reads it, never writes it); non-scalar losses keep autograd's own behaviour (an error)"""
+        if loss.dim() != 0 or not loss.is_cuda:
+            return None
+        key = (loss.device, loss.dtype)
+        one = cls._ROOT_ONES.get(key)
+        if one is None:
+            one = cls._ROOT_ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return one
 
     def graph_key(self, epoch):
         """whatever ``loss_step`` bakes into the captured step besides tensors (an epoch-dependent Python constant):
@@ -287,7 +301,7 @@ class Learner(Inference):
                         g["dto"] = self.inference_step(sbatch)
                         g["loss"] = self.loss_step(g["dto"], epoch)
                         self._optimizer.zero_grad()
-                        g["loss"].backward()
+                        g["loss"].backward(self._root_grad(g["loss"]))
                     else:
                         g["dto"], g["loss"] = self._optimise(sbatch, epoch)
             finally:

@@ -192,6 +192,7 @@ _SIGS = {
     "sp_out_grad_to_cl": ([vp, vp, i32, i32, i64, i32, i32, i32, f32, vp, vp, vp], i32),
     "sp_dice_sums": ([vp, i64, vp, i64, i32, i32, i64, vp, vp], i32),
     "sp_dice_finalize": ([vp, vp, f64, i32, vp, vp, vp], i32),
+    "sp_dice_finalize_clear": ([vp, vp, f64, i32, vp, vp, vp], i32),
     "sp_dice_bwd": ([vp, i64, vp, i64, vp, vp, i32, i32, i64, vp, vp], i32),
     "sp_head_supported": ([i32, i32, i32], i32),
     "sp_head_supported_dtype": ([i32, i32, i32, i32], i32),
