@@ -555,3 +555,35 @@ def test_plane_serial_march_matches_conv3d(cin, cout, dims, B, hl, planar, monke
     n = got.numel() / cout
     torch.testing.assert_close(s[:, 0], got.sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(n))
     torch.testing.assert_close(s[:, 1], (got ** 2).sum(dim=(0, 2, 3, 4)), rtol=1e-3, atol=4e-3 * math.sqrt(n))
+
+
+def test_dice_accumulator_clears_itself_between_calls():
+    """common/metrics.py keeps ONE accumulator of the Dice sums per (device, channels, stream); sp_dice_finalize_clear zeroes it after
+    reading (no fill launch per call).  Three calls in a row, a call after a simulated failure between the two launches, and the
+    gradient all agree with the formula of metrics.py:16-28."""
+    from common import metrics as M
+    torch.manual_seed(5)
+    loss_fn = M.BatchDiceLoss([0.4, 0.6])
+
+    def ref(o, t, w=(0.4, 0.6), eps=1e-7):
+        num = 2 * (o.double() * t.double()).sum(dim=(0, 2, 3, 4)) + eps
+        den = (o.double() ** 2).sum(dim=(0, 2, 3, 4)) + (t.double() ** 2).sum(dim=(0, 2, 3, 4)) + eps
+        return 1 - (torch.tensor(w, dtype=torch.float64, device=o.device) * num / den).sum()
+
+    for k in range(3):
+        o = torch.rand(2, 2, 9, 10, 11, device=DEV, requires_grad=True)
+        t = (torch.rand(2, 2, 9, 10, 11, device=DEV) > 0.5).float()
+        loss = loss_fn(o, t)
+        assert abs(float(loss) - float(ref(o.detach(), t))) < 2e-6, (k, float(loss))
+        loss.backward()
+        o2 = o.detach().double().requires_grad_(True)
+        ref(o2, t).backward()
+        assert torch.allclose(o.grad.double(), o2.grad, rtol=1e-4, atol=1e-9)
+    ents = [e for e in M._DICE_SUMS.values()]
+    assert ents and all(float(e[0].abs().sum()) == 0.0 and not e[1] for e in ents)      # left clean
+    for e in ents:                                      # a call that died after sp_dice_sums: sums behind, flag up
+        e[0].fill_(3.0)
+        e[1] = True
+    o = torch.rand(2, 2, 9, 10, 11, device=DEV)
+    t = (torch.rand(2, 2, 9, 10, 11, device=DEV) > 0.5).float()
+    assert abs(float(loss_fn(o, t)) - float(ref(o, t))) < 2e-6
